@@ -1,0 +1,16 @@
+"""MI355X-native Top-K SpMV engine: host-side mirror of the reference's operator interface for the hot path.
+
+The compute path is hand-written HIP (csrc/engine.hip) behind the C ABI in include/tkspmv.h; this package only
+marshals pointers. There is no CPU fallback.
+"""
+from . import _lib
+from ._lib import TkspmvError, F32, Q1_7, MAX_COLS, MAX_K
+from .host import CooMatrix, Options, Packed, create_sample_vector, generate_matrix, read_mtx, write_mtx
+from .engine import SpMV, topk_spmv
+
+__all__ = ["SpMV", "topk_spmv", "CooMatrix", "Options", "Packed", "create_sample_vector", "generate_matrix",
+           "read_mtx", "write_mtx", "TkspmvError", "F32", "Q1_7", "MAX_COLS", "MAX_K"]
+
+
+def device_count():
+    return _lib.lib().tkspmv_device_count()

@@ -1,0 +1,226 @@
+// c_api.cpp -- extern "C" surface declared in include/tkspmv.h (plain pointers and sizes only).
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "../../include/tkspmv.h"
+#include "engine.hpp"
+#include "host_utils.hpp"
+#include "wbscsr.hpp"
+
+using namespace tkspmv;
+
+struct tkspmv_engine {
+    Engine *e;
+};
+struct tkspmv_packed {
+    PackedMatrix pm;
+    int k;
+};
+
+static thread_local std::string g_err;
+
+static int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+
+extern "C" {
+
+const char *tkspmv_last_error(void) { return g_err.c_str(); }
+
+int tkspmv_device_count(void) { return device_count(); }
+
+int tkspmv_create(tkspmv_t **out, const tkspmv_desc *desc) {
+    if (!out || !desc) return fail(TKSPMV_ERR_INVALID, "NULL argument");
+    *out = nullptr;
+    std::string err;
+    int status = TKSPMV_OK;
+    Engine *e = nullptr;
+    try {
+        e = Engine::create(*desc, err, status);
+    } catch (const std::bad_alloc &) {
+        return fail(TKSPMV_ERR_NOMEM, "out of host memory while packing");
+    }
+    if (!e) return fail(status, err);
+    *out = new tkspmv_engine{e};
+    return TKSPMV_OK;
+}
+
+void tkspmv_destroy(tkspmv_t *h) {
+    if (!h) return;
+    delete h->e;
+    delete h;
+}
+
+#define ENGINE_CALL(call)                                        \
+    if (!h) return fail(TKSPMV_ERR_INVALID, "NULL engine");      \
+    std::string err;                                             \
+    int st = h->e->call;                                         \
+    if (st != TKSPMV_OK) g_err = err;                            \
+    return st;
+
+int tkspmv_get_info(const tkspmv_t *h, tkspmv_info *info) {
+    if (!h || !info) return fail(TKSPMV_ERR_INVALID, "NULL argument");
+    h->e->info(info);
+    return TKSPMV_OK;
+}
+int tkspmv_set_query(tkspmv_t *h, const float *host_x, double *elapsed_ns) { ENGINE_CALL(set_query(host_x, elapsed_ns, err)) }
+int tkspmv_set_query_device(tkspmv_t *h, const float *dev_x) { ENGINE_CALL(set_query_device(dev_x, err)) }
+int tkspmv_run(tkspmv_t *h, double *kernel_ns) { ENGINE_CALL(run(kernel_ns, err)) }
+int tkspmv_enqueue(tkspmv_t *h, const float *dev_x, uint32_t *dev_idx, float *dev_val, void *stream) {
+    ENGINE_CALL(enqueue(dev_x, dev_idx, dev_val, stream, err))
+}
+int tkspmv_synchronize(tkspmv_t *h) { ENGINE_CALL(synchronize(err)) }
+int tkspmv_read(tkspmv_t *h, uint32_t *idx, float *val, int32_t *n) { ENGINE_CALL(read(idx, val, n, err)) }
+int tkspmv_result_device(tkspmv_t *h, const uint32_t **dev_idx, const float **dev_val) {
+    if (!h) return fail(TKSPMV_ERR_INVALID, "NULL engine");
+    return h->e->result_device(dev_idx, dev_val);
+}
+int tkspmv_scores(tkspmv_t *h, float *host_y) { ENGINE_CALL(scores(host_y, err)) }
+int tkspmv_profile(tkspmv_t *h, const float *dev_xs, int32_t n_x, int32_t iters, tkspmv_timing *out) {
+    ENGINE_CALL(profile(dev_xs, n_x, iters, out, err))
+}
+
+// ---- host helpers ------------------------------------------------------------------------------------
+static int coo_to_c(CooMatrix &m, tkspmv_coo *out) {
+    std::memset(out, 0, sizeof(*out));
+    out->rows = m.rows;
+    out->cols = m.cols;
+    out->nnz = m.nnz();
+    out->num_rows_coo = m.num_rows_coo;
+    out->index_base = m.index_base;
+    out->symmetric = m.symmetric ? 1 : 0;
+    size_t n = m.row.size();
+    out->row = (uint32_t *)malloc(std::max<size_t>(n, 1) * 4);
+    out->col = (uint32_t *)malloc(std::max<size_t>(n, 1) * 4);
+    out->val = (float *)malloc(std::max<size_t>(n, 1) * 4);
+    if (!out->row || !out->col || !out->val) {
+        free(out->row);
+        free(out->col);
+        free(out->val);
+        std::memset(out, 0, sizeof(*out));
+        return fail(TKSPMV_ERR_NOMEM, "out of memory");
+    }
+    if (n) {
+        std::memcpy(out->row, m.row.data(), n * 4);
+        std::memcpy(out->col, m.col.data(), n * 4);
+        std::memcpy(out->val, m.val.data(), n * 4);
+    }
+    return TKSPMV_OK;
+}
+
+int tkspmv_mtx_read(const char *path, int32_t index_base, int32_t read_values, int32_t sort, tkspmv_coo *out) {
+    if (!path || !out) return fail(TKSPMV_ERR_INVALID, "NULL argument");
+    CooMatrix m;
+    IoError e = read_mtx(path, index_base, read_values != 0, sort != 0, m);
+    if (e.code) return fail(e.code, e.message);
+    return coo_to_c(m, out);
+}
+
+void tkspmv_mtx_free(tkspmv_coo *m) {
+    if (!m) return;
+    free(m->row);
+    free(m->col);
+    free(m->val);
+    std::memset(m, 0, sizeof(*m));
+}
+
+int tkspmv_mtx_write(const char *path, uint32_t rows, uint32_t cols, uint64_t nnz, const uint32_t *row,
+                     const uint32_t *col, const float *val, int32_t index_base, int32_t precision) {
+    if (!path || (nnz && (!row || !col))) return fail(TKSPMV_ERR_INVALID, "NULL argument");
+    IoError e = write_mtx(path, rows, cols, nnz, row, col, val, index_base, precision);
+    if (e.code) return fail(e.code, e.message);
+    return TKSPMV_OK;
+}
+
+int tkspmv_sample_vector(float *vec, int32_t size, int32_t random, int32_t sum_to_one, int32_t norm_one,
+                         int32_t seed) {
+    if (!vec || size < 0) return fail(TKSPMV_ERR_INVALID, "bad arguments");
+    sample_vector(vec, size, random != 0, sum_to_one != 0, norm_one != 0, seed);
+    return TKSPMV_OK;
+}
+
+int tkspmv_generate(uint32_t rows, uint32_t cols, uint32_t avg_nnz, int32_t dist, uint64_t seed, tkspmv_coo *out) {
+    if (!out || cols == 0 || avg_nnz == 0) return fail(TKSPMV_ERR_INVALID, "bad arguments");
+    if (dist != DIST_UNIFORM && dist != DIST_GAMMA) return fail(TKSPMV_ERR_INVALID, "dist must be 0 (uniform) or 1 (gamma)");
+    CooMatrix m;
+    try {
+        generate_matrix(rows, cols, avg_nnz, dist, seed, m);
+    } catch (const std::bad_alloc &) {
+        return fail(TKSPMV_ERR_NOMEM, "out of memory");
+    }
+    return coo_to_c(m, out);
+}
+
+int tkspmv_options_parse(int argc, char **argv, tkspmv_options *out) {
+    if (!out || (argc > 0 && !argv)) return fail(TKSPMV_ERR_INVALID, "NULL argument");
+    Options o(argc, argv);
+    std::memset(out, 0, sizeof(*out));
+    std::strncpy(out->matrix_path, o.matrix_path.c_str(), sizeof(out->matrix_path) - 1);
+    std::strncpy(out->xclbin_path, o.xclbin_path.c_str(), sizeof(out->xclbin_path) - 1);
+    out->use_sample_matrix = o.use_sample_matrix;
+    out->reset = o.reset;
+    out->num_tests = (int32_t)o.num_tests;
+    out->debug = o.debug;
+    out->ignore_matrix_values = o.ignore_matrix_values;
+    out->top_k_value = o.top_k_value;
+    out->gpu_impl = o.gpu_impl;
+    out->use_half_precision_gpu = o.use_half_precision_gpu;
+    out->block_size_1d = o.block_size_1d;
+    out->block_size_2d = o.block_size_2d;
+    out->num_blocks = o.num_blocks;
+    return TKSPMV_OK;
+}
+
+int tkspmv_pack(const tkspmv_desc *d, uint32_t n_wave_partitions_hint, tkspmv_packed **out) {
+    if (!d || !out) return fail(TKSPMV_ERR_INVALID, "NULL argument");
+    *out = nullptr;
+    tkspmv_packed *p = new tkspmv_packed();
+    int kind = 0;
+    uint32_t C = d->nnz_per_lane > 0 ? (uint32_t)d->nnz_per_lane : 4u;
+    std::string err = pack_wbscsr(d->rows, d->cols, d->nnz, d->row, d->col, d->val, (Precision)d->precision, C,
+                                  n_wave_partitions_hint ? n_wave_partitions_hint : 4096u, 4, p->pm, kind);
+    if (!err.empty()) {
+        delete p;
+        return fail(kind == 2 ? TKSPMV_ERR_NOT_SORTED : TKSPMV_ERR_INVALID, err);
+    }
+    p->k = d->k;
+    *out = p;
+    return TKSPMV_OK;
+}
+
+int tkspmv_packed_info(const tkspmv_packed *p, tkspmv_info *info) {
+    if (!p || !info) return fail(TKSPMV_ERR_INVALID, "NULL argument");
+    fill_info(p->pm, p->k, info);
+    return TKSPMV_OK;
+}
+
+int tkspmv_packed_decode(const tkspmv_packed *p, uint32_t *row, uint32_t *col, float *val, uint64_t *n) {
+    if (!p || !n) return fail(TKSPMV_ERR_INVALID, "NULL argument");
+    std::vector<uint32_t> r, c;
+    std::vector<float> v;
+    decode_wbscsr(p->pm, r, c, v);
+    *n = r.size();
+    if (row) std::memcpy(row, r.data(), r.size() * 4);
+    if (col) std::memcpy(col, c.data(), c.size() * 4);
+    if (val) std::memcpy(val, v.data(), v.size() * 4);
+    return TKSPMV_OK;
+}
+
+int tkspmv_packed_raw(const tkspmv_packed *p, const void **packets, uint64_t *packet_bytes, const uint32_t **pkt_row,
+                      const uint32_t **part_first, const uint32_t **part_count, uint32_t *n_parts) {
+    if (!p) return fail(TKSPMV_ERR_INVALID, "NULL argument");
+    if (packets) *packets = p->pm.packets.data();
+    if (packet_bytes) *packet_bytes = p->pm.packet_bytes;
+    if (pkt_row) *pkt_row = p->pm.pkt_row.data();
+    if (part_first) *part_first = p->pm.part_first.data();
+    if (part_count) *part_count = p->pm.part_count.data();
+    if (n_parts) *n_parts = (uint32_t)p->pm.part_first.size();
+    return TKSPMV_OK;
+}
+
+void tkspmv_packed_free(tkspmv_packed *p) { delete p; }
+
+}  // extern "C"

@@ -1,0 +1,42 @@
+// engine.hpp -- device engine behind the C ABI (include/tkspmv.h). Mirrors the reference's per-back-end
+// `struct SpMV` (host_spmv_bscsr.cpp:79-485, host_spmv_topk_csr_gpu.cu:44-263): setup once, then per
+// query reset(vec) -> operator()() -> read_result().
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/tkspmv.h"
+#include "wbscsr.hpp"
+
+namespace tkspmv {
+
+struct EngineImpl;  // HIP state lives in engine.hip
+
+class Engine {
+   public:
+    // Returns nullptr and fills err/status on failure.
+    static Engine *create(const tkspmv_desc &desc, std::string &err, int &status);
+    ~Engine();
+
+    int set_query(const float *host_x, double *elapsed_ns, std::string &err);
+    int set_query_device(const float *dev_x, std::string &err);
+    int run(double *kernel_ns, std::string &err);
+    int enqueue(const float *dev_x, uint32_t *dev_idx, float *dev_val, void *stream, std::string &err);
+    int synchronize(std::string &err);
+    int read(uint32_t *idx, float *val, int32_t *n, std::string &err);
+    int result_device(const uint32_t **dev_idx, const float **dev_val);
+    int scores(float *host_y, std::string &err);
+    int profile(const float *dev_xs, int32_t n_x, int32_t iters, tkspmv_timing *out, std::string &err);
+    void info(tkspmv_info *out) const;
+
+   private:
+    Engine() = default;
+    EngineImpl *impl_ = nullptr;
+};
+
+void fill_info(const PackedMatrix &pm, int k, tkspmv_info *out);
+uint64_t algorithmic_bytes(uint64_t nnz, uint32_t rows, uint32_t cols, uint32_t value_bytes, int k);
+int device_count();
+
+}  // namespace tkspmv

@@ -1,0 +1,88 @@
+// wbscsr.hpp -- "wave block-streaming CSR": the packet layout the fused kernel streams from HBM.
+//
+// Counterpart of the reference's BSCSR 512-bit packets (src/common/types.hpp:57-79,
+// src/fpga/src/ip/fpga_utils.hpp:264-365, packer src/fpga/src/host_spmv_bscsr.cpp:133-248), re-derived for
+// 64-lane wavefronts and 128-byte HBM3E transactions instead of 32 pseudo-channels x 512-bit words:
+//
+//   * a PACKET holds PE = 64 * C consecutive entries of the row-sorted matrix (C = entries per lane, 4 or 8);
+//     lane l of the wave owns entries [l*C, l*C+C) so every lane loads 16 contiguous bytes of values
+//     (global_load_dwordx4 => 1 KiB per wave instruction) and 8 (C=4) or 16 (C=8) bytes of column words;
+//   * packet bytes: [PE values (fp32, or u8 for Q1.7)] [PE x u16 column words], packets are 128-B aligned;
+//   * a column word is  bit0 = ROW_END (this entry is the last of its row; the reference stores 4-bit
+//     cumulative row-end offsets + the xf bit instead), bit1 = SKIP (placeholder entry of an empty row:
+//     keeps row counting implicit, never becomes a candidate), bits 15..2 = column (reference: 10 bits),
+//     i.e. (word & 0xFFFC) is directly the byte offset of x[col] in the LDS copy of the fp32 query;
+//   * for C = 8 the lane's entries are stored as two planes of 4 (plane q at +q*1024 B values, +q*512 B
+//     column words) so that every wave load instruction still touches one dense 1 KiB / 512 B span;
+//   * no row ids are stored per entry: rows are counted from pkt_row[p] (row id of the first row that
+//     ends in packet p; 4 B per packet) -- the reference counts rows in its "summary" stage;
+//   * rows are grouped into WAVE PARTITIONS (contiguous row ranges, one per wave, balanced by entries and
+//     padded to whole packets so a partition starts and ends on a row boundary). The reference's
+//     32 partitions -> HBM channels becomes n_CU * waves_per_CU partitions -> waves.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace tkspmv {
+
+constexpr uint16_t COLW_ROW_END = 0x0001u;
+constexpr uint16_t COLW_SKIP = 0x0002u;
+constexpr uint16_t COLW_COL_SHIFT = 2;
+constexpr uint32_t MAX_COLS = 1u << 14;
+constexpr uint32_t WAVE = 64;
+
+// Position of stream slot s (0..PE-1, row-major order of the matrix) inside a packet: lane = s / C owns
+// C consecutive slots; they are stored in planes of 4.
+inline uint32_t slot_to_index(uint32_t s, uint32_t C) {
+    uint32_t lane = s / C, j = s % C;
+    return (j >> 2) * (WAVE * 4) + lane * 4 + (j & 3);
+}
+
+enum class Precision : int32_t { F32 = 0, Q1_7 = 1 };
+
+inline uint32_t value_bytes(Precision p) { return p == Precision::F32 ? 4u : 1u; }
+
+// Unsigned fixed point with 1 integer and 7 fraction bits, truncation toward zero and saturation at the
+// top of the range when converting from float (restating ap_ufixed<8,1,AP_TRN_ZERO>, fpga_types.hpp:20).
+inline uint8_t to_q1_7(float v) {
+    if (!(v > 0.0f)) return 0;
+    float s = v * 128.0f;
+    if (s >= 255.0f) return 255;
+    return (uint8_t)s;  // truncation
+}
+inline float from_q1_7(uint32_t q) { return (float)q * (1.0f / 128.0f); }
+
+struct PackedMatrix {
+    uint32_t rows = 0, cols = 0;
+    uint64_t nnz = 0;
+    Precision precision = Precision::F32;
+    uint32_t C = 4;               // entries per lane
+    uint32_t packet_entries = 0;  // 64*C
+    uint32_t packet_bytes = 0;    // packet_entries*(value_bytes+2)
+    uint32_t n_packets = 0;
+    uint32_t packets_per_partition = 0;  // m: fill capacity (partitions holding one giant row may exceed it)
+    uint64_t packed_entries = 0;         // n_packets * packet_entries
+    uint64_t placeholders = 0;           // empty rows inside [0, last_row]
+    std::vector<uint8_t> packets;        // n_packets * packet_bytes
+    std::vector<uint32_t> pkt_row;       // [n_packets]
+    std::vector<uint32_t> part_first;    // [n_parts] first packet
+    std::vector<uint32_t> part_count;    // [n_parts] packets
+    std::vector<uint32_t> part_row0;     // [n_parts] first row of the partition
+    std::vector<uint32_t> part_rows;     // [n_parts] rows (incl. placeholders) in the partition
+
+    uint64_t stream_bytes() const { return (uint64_t)n_packets * packet_bytes; }
+    uint64_t side_bytes() const { return (uint64_t)pkt_row.size() * 4 + (uint64_t)part_first.size() * 8; }
+};
+
+// Packs a row-sorted COO. Returns empty string on success, else an error message.
+// kind: 0 ok, 1 invalid, 2 not sorted.
+std::string pack_wbscsr(uint32_t rows, uint32_t cols, uint64_t nnz, const uint32_t *row, const uint32_t *col,
+                        const float *val, Precision precision, uint32_t C, uint32_t n_partitions_hint,
+                        uint32_t min_packets_per_partition, PackedMatrix &out, int &kind);
+
+// Inverse of pack (placeholders and padding dropped). Values come back as float (Q1.7 decoded).
+void decode_wbscsr(const PackedMatrix &pm, std::vector<uint32_t> &row, std::vector<uint32_t> &col,
+                   std::vector<float> &val);
+
+}  // namespace tkspmv

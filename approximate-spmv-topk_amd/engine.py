@@ -1,0 +1,119 @@
+"""Python mirror of the reference's engine concept `struct SpMV` (setup in the constructor, then per query
+reset(vec) -> operator()() -> read_result()), bound to the HIP engine through the C ABI (include/tkspmv.h).
+
+  SpMV(...)            <- src/gpu/host_spmv_topk_csr_gpu.cu:95-169, src/fpga/src/host_spmv_bscsr.cpp:104-131
+  SpMV.__call__(debug) <- operator()(int debug): runs one query, returns the kernel time in ns  (:171 / :323)
+  SpMV.read_result()   <- read_result(res, res_idx): (values, indices), value-descending       (:233 / :399)
+  SpMV.reset(vec)      <- reset(vec, debug): installs a new query vector, returns ns          (:241 / :450)
+
+The compute path is the HIP library only; constructing an engine without a GPU raises TkspmvError(ERR_DEVICE).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+class SpMV:
+    def __init__(self, x, y, val, num_rows, num_cols, num_nnz=None, vec=None, k=20, debug=0, *, device=-1,
+                 first_row=0, min_score=0.0, partitions=1, k_per_partition=0, precision=_lib.F32, waves_per_cu=0,
+                 threads_per_wg=0, nnz_per_lane=0):
+        """x, y, val: row-sorted COO (row ids, column ids, values) as the FPGA host passes them
+        (host_spmv_bscsr.cpp:585); val=None means all ones (-v)."""
+        self._h = C.c_void_p()
+        row = np.ascontiguousarray(x, dtype=np.uint32)
+        col = np.ascontiguousarray(y, dtype=np.uint32)
+        v = None if val is None else np.ascontiguousarray(val, dtype=np.float32)
+        nnz = int(row.shape[0]) if num_nnz is None else int(num_nnz)
+        d = _lib.Desc()
+        d.rows, d.cols, d.nnz = int(num_rows), int(num_cols), nnz
+        d.row = row.ctypes.data_as(C.POINTER(C.c_uint32))
+        d.col = col.ctypes.data_as(C.POINTER(C.c_uint32))
+        d.val = v.ctypes.data_as(C.POINTER(C.c_float)) if v is not None else None
+        d.k, d.partitions, d.k_per_partition, d.precision = int(k), int(partitions), int(k_per_partition), precision
+        d.device, d.first_row, d.min_score = int(device), int(first_row), float(min_score)
+        d.waves_per_cu, d.threads_per_wg, d.nnz_per_lane = int(waves_per_cu), int(threads_per_wg), int(nnz_per_lane)
+        _lib.check(_lib.lib().tkspmv_create(C.byref(self._h), C.byref(d)))
+        self.k = int(k)
+        self.num_rows, self.num_cols, self.num_nnz = int(num_rows), int(num_cols), nnz
+        self.debug = debug
+        if vec is not None:
+            self.reset(vec)
+
+    # -- the four verbs ---------------------------------------------------------------------------------
+    def reset(self, vec, debug=0):
+        v = np.ascontiguousarray(vec, dtype=np.float32)
+        if v.shape[0] != self.num_cols:
+            raise ValueError(f"query vector has {v.shape[0]} entries, expected {self.num_cols}")
+        ns = C.c_double()
+        _lib.check(_lib.lib().tkspmv_set_query(self._h, v.ctypes.data_as(C.POINTER(C.c_float)), C.byref(ns)))
+        return int(ns.value)
+
+    def __call__(self, debug=0):
+        ns = C.c_double()
+        _lib.check(_lib.lib().tkspmv_run(self._h, C.byref(ns)))
+        return ns.value
+
+    def read_result(self, debug=0):
+        idx = np.empty(self.k, dtype=np.uint32)
+        val = np.empty(self.k, dtype=np.float32)
+        n = C.c_int32()
+        _lib.check(_lib.lib().tkspmv_read(self._h, idx.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                          val.ctypes.data_as(C.POINTER(C.c_float)), C.byref(n)))
+        return val[:n.value], idx[:n.value]
+
+    # -- extras -----------------------------------------------------------------------------------------
+    def reset_device(self, dev_ptr):
+        """Query vector already resident in HBM (raw device pointer, e.g. torch tensor.data_ptr())."""
+        _lib.check(_lib.lib().tkspmv_set_query_device(self._h, C.c_void_p(int(dev_ptr))))
+
+    def enqueue(self, dev_x=0, dev_idx=0, dev_val=0, stream=0):
+        """Asynchronous launch of one query on `stream` (raw hipStream_t handle; 0 = engine stream)."""
+        _lib.check(_lib.lib().tkspmv_enqueue(self._h, C.c_void_p(int(dev_x)), C.c_void_p(int(dev_idx)),
+                                             C.c_void_p(int(dev_val)), C.c_void_p(int(stream))))
+
+    def synchronize(self):
+        _lib.check(_lib.lib().tkspmv_synchronize(self._h))
+
+    def scores(self):
+        """Full y = A.x of the current query (verification aid; the hot path never materialises it)."""
+        y = np.empty(max(self.num_rows, 1), dtype=np.float32)
+        _lib.check(_lib.lib().tkspmv_scores(self._h, y.ctypes.data_as(C.POINTER(C.c_float))))
+        return y[:self.num_rows]
+
+    def profile(self, dev_xs, n_x, iters):
+        t = _lib.Timing()
+        _lib.check(_lib.lib().tkspmv_profile(self._h, C.c_void_p(int(dev_xs)), int(n_x), int(iters), C.byref(t)))
+        return {n: getattr(t, n) for n, _ in t._fields_ if n != "reserved"}
+
+    def result_device(self):
+        a, b = C.c_void_p(), C.c_void_p()
+        _lib.check(_lib.lib().tkspmv_result_device(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def info(self):
+        i = _lib.Info()
+        _lib.check(_lib.lib().tkspmv_get_info(self._h, C.byref(i)))
+        return i.as_dict()
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().tkspmv_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def topk_spmv(m, vec, k=100, **kw):
+    """One-shot helper: build the engine for CooMatrix m, run one query, return (values, indices)."""
+    e = SpMV(m.row, m.col, m.val, m.rows, m.cols, vec=vec, k=k, **kw)
+    try:
+        e()
+        return e.read_result()
+    finally:
+        e.close()

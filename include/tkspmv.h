@@ -1,0 +1,193 @@
+/*
+ * tkspmv.h -- C ABI of the MI355X-native Top-K SpMV engine.
+ *
+ * This is the drop-in boundary for the ONE hot path of AlbertoParravicini/approximate-spmv-topk:
+ * "given a fixed sparse matrix A (row-sorted COO, <= 16384 columns) and a fresh dense query x,
+ *  return the K rows with the largest A.x".
+ *
+ * The reference has no FFI; the boundary it re-implements per back-end is the `struct SpMV`
+ * engine concept (4 verbs) plus the loader/options helpers every `main` calls. Each entry point
+ * below cites the reference interface it replaces (paths relative to the reference repo root):
+ *
+ *   tkspmv_create        <- SpMV::SpMV + packet_coo + setup   src/fpga/src/host_spmv_bscsr.cpp:104-131,133-321
+ *                                                             src/gpu/host_spmv_topk_csr_gpu.cu:95-169
+ *   tkspmv_set_query     <- SpMV::reset(vec)                  src/fpga/src/host_spmv_bscsr.cpp:450-485
+ *                                                             src/gpu/host_spmv_topk_csr_gpu.cu:241-263
+ *   tkspmv_run           <- SpMV::operator()(debug) + wait    src/fpga/src/host_spmv_bscsr.cpp:323-397
+ *                                                             src/gpu/host_spmv_topk_csr_gpu.cu:171-231
+ *   tkspmv_read          <- SpMV::read_result                 src/fpga/src/host_spmv_bscsr.cpp:399-448
+ *                                                             src/gpu/host_spmv_topk_csr_gpu.cu:233-239
+ *   tkspmv_mtx_read      <- readMtx / readTuples / mm_read_*  src/common/utils/utils.hpp:372-404,474-520
+ *                                                             src/common/utils/mmio.hpp:124-230
+ *   tkspmv_sample_vector <- create_sample_vector              src/common/utils/utils.hpp:234-267
+ *   tkspmv_options_parse <- Options::Options(argc, argv)      src/common/utils/options.hpp:62-132
+ *   tkspmv_generate      <- create_sparse_matrix              src/resources/python/create_matrices.py:58-128
+ *
+ * Plain pointers and sizes only; no C++/torch types cross this boundary. All functions return a
+ * tkspmv_status (0 = OK) unless stated; tkspmv_last_error() returns a thread-local message.
+ * The engine NEVER falls back to a CPU path: without a usable HIP device tkspmv_create fails with
+ * TKSPMV_ERR_DEVICE.
+ */
+#ifndef TKSPMV_H
+#define TKSPMV_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TKSPMV_VERSION 1
+#define TKSPMV_MAX_COLS 16384u /* 14 column bits per packed entry (reference MAX_COLS = 1024, types.hpp:55) */
+#define TKSPMV_MAX_K 1024      /* reference GPU path: get_topk<<<1,1024>>> => k <= 1024 */
+
+typedef enum {
+    TKSPMV_OK = 0,
+    TKSPMV_ERR_INVALID = 1,     /* bad argument / descriptor */
+    TKSPMV_ERR_NOT_SORTED = 2,  /* COO rows not non-decreasing (reference requires row-major input) */
+    TKSPMV_ERR_DEVICE = 3,      /* HIP runtime error or no device */
+    TKSPMV_ERR_NOMEM = 4,
+    TKSPMV_ERR_IO = 5,          /* file not found / bad MatrixMarket banner */
+    TKSPMV_ERR_UNSUPPORTED = 6,
+    TKSPMV_ERR_STATE = 7        /* e.g. run before set_query */
+} tkspmv_status;
+
+typedef enum {
+    TKSPMV_F32 = 0,  /* fp32 values, fp32 x, fp32 accumulate (USE_FLOAT build / GPU hosts) */
+    TKSPMV_Q1_7 = 1  /* unsigned fixed point, 1 integer + 7 fraction bits (FIXED_WIDTH=8 style), see DESIGN.md */
+} tkspmv_precision;
+
+typedef struct tkspmv_engine tkspmv_t;
+
+/* Engine descriptor. Caller owns row/col/val; they are only read during tkspmv_create
+ * (the reference keeps raw pointers for the engine lifetime; this engine copies what it needs). */
+typedef struct {
+    uint32_t rows;            /* logical row count (ids returned are < first_row + rows) */
+    uint32_t cols;            /* length of the query vector, <= TKSPMV_MAX_COLS */
+    uint64_t nnz;
+    const uint32_t *row;      /* [nnz] COO row ids, non-decreasing (reference `x`) */
+    const uint32_t *col;      /* [nnz] COO column ids (reference `y`) */
+    const float *val;         /* [nnz] values; NULL => all ones (reference -v / ignore_matrix_values) */
+    int32_t k;                /* results per query, 1..TKSPMV_MAX_K (reference -k, default 20) */
+    int32_t partitions;       /* logical row partitions, reference SPMV_PARTITIONS; 0/1 => one (exact top-k) */
+    int32_t k_per_partition;  /* candidates kept per logical partition, reference K (types.hpp:49); 0 => k */
+    int32_t precision;        /* tkspmv_precision */
+    int32_t device;           /* HIP device ordinal; -1 => current device */
+    uint32_t first_row;       /* added to every returned row id (row-sharded multi-GPU) */
+    float min_score;          /* rows scoring below this are never returned; gold uses 0 (gold_algorithms.hpp:200) */
+    /* tuning knobs, 0 = auto */
+    int32_t waves_per_cu;
+    int32_t threads_per_wg;
+    int32_t nnz_per_lane;     /* 4 or 8 entries per lane per packet */
+    int32_t reserved[5];
+} tkspmv_desc;
+
+typedef struct {
+    uint32_t rows, cols;
+    uint64_t nnz;
+    uint64_t packed_entries;      /* nnz + placeholders for empty rows + tail padding */
+    uint64_t packed_bytes;        /* bytes of the packet stream + side tables resident in HBM */
+    uint64_t algorithmic_bytes;   /* nnz*(sizeof(val)+2) + rows*4 + cols*sizeof(val) + k*8 */
+    uint32_t n_packets;
+    uint32_t packet_entries;      /* entries per packet = 64 lanes * nnz_per_lane */
+    uint32_t n_wave_partitions;   /* physical row ranges, one per wave */
+    uint32_t packets_per_partition;
+    uint32_t grid, block;         /* launch geometry of the streaming kernel */
+    uint32_t n_groups;            /* threshold groups publishing maxima */
+    uint32_t lds_bytes;
+    int32_t k, partitions, k_per_partition, precision, device;
+    uint32_t num_cus;
+    uint32_t reserved[7];
+} tkspmv_info;
+
+typedef struct {
+    double stream_kernel_ns;   /* average device time of the fused streaming kernel */
+    double select_kernel_ns;   /* average device time of the final candidate-select kernel */
+    double query_ns;           /* average device time per query, back-to-back enqueue (all kernels) */
+    double candidates_avg;     /* average number of candidates reaching the select stage */
+    uint32_t n_queries;
+    uint32_t reserved[5];
+} tkspmv_timing;
+
+/* ---- engine ------------------------------------------------------------------------------- */
+int tkspmv_create(tkspmv_t **out, const tkspmv_desc *desc);
+void tkspmv_destroy(tkspmv_t *e);
+int tkspmv_get_info(const tkspmv_t *e, tkspmv_info *info);
+
+/* Install a new query vector (host pointer, `cols` floats): H2D copy. Returns ns in *elapsed_ns if non-NULL. */
+int tkspmv_set_query(tkspmv_t *e, const float *host_x, double *elapsed_ns);
+/* Same, but x already lives in device memory (no copy; pointer must stay valid until the run completes). */
+int tkspmv_set_query_device(tkspmv_t *e, const float *dev_x);
+
+/* Run one query on the current vector and wait. *kernel_ns = device time of the kernels (hipEvents). */
+int tkspmv_run(tkspmv_t *e, double *kernel_ns);
+/* Enqueue one query on `stream` (hipStream_t cast to void*; NULL => engine stream), no host sync.
+ * dev_idx/dev_val: optional device output buffers of k entries (NULL => engine-owned result buffers). */
+int tkspmv_enqueue(tkspmv_t *e, const float *dev_x, uint32_t *dev_idx, float *dev_val, void *stream);
+int tkspmv_synchronize(tkspmv_t *e);
+
+/* Copy back the k results of the last completed query, sorted by (score desc, row desc)
+ * (sort_tuples order, evaluation_utils.hpp:40-62). *n receives the count (always k; entries past the
+ * number of qualifying rows are (0, 0.0f), as the gold's zero-initialised list). */
+int tkspmv_read(tkspmv_t *e, uint32_t *idx, float *val, int32_t *n);
+/* Device pointers of the engine-owned result buffers (k entries each). */
+int tkspmv_result_device(tkspmv_t *e, const uint32_t **dev_idx, const float **dev_val);
+/* Debug/verification: full score vector y = A.x of the current query (rows floats, host). */
+int tkspmv_scores(tkspmv_t *e, float *host_y);
+
+/* Benchmark helper: run `iters` queries cycling over `n_x` device-resident vectors (stride cols floats)
+ * back-to-back on the engine stream, timed with hipEvents on that stream. */
+int tkspmv_profile(tkspmv_t *e, const float *dev_xs, int32_t n_x, int32_t iters, tkspmv_timing *out);
+
+const char *tkspmv_last_error(void);
+int tkspmv_device_count(void);
+
+/* ---- host-side helpers (no GPU needed) --------------------------------------------------------- */
+typedef struct {
+    uint32_t rows, cols;   /* from the size line */
+    uint64_t nnz;
+    uint32_t *row, *col;   /* malloc'd, release with tkspmv_mtx_free */
+    float *val;
+    uint32_t num_rows_coo; /* max(row)+1, as coo_t derives it (coo_matrix.hpp:21-27) */
+    int32_t index_base;    /* index base actually applied: 0 or 1 */
+    int32_t symmetric;     /* banner said symmetric */
+} tkspmv_coo;
+
+/* index_base: 0 = file is zero-indexed (the reference's compiled-in behaviour, zero_indexed_file=true),
+ *             1 = file is one-indexed (create_matrices.py output), -1 = auto-detect (min index == 0 ? 0 : 1).
+ * read_values = 0 => all values 1.0 (reference -v). sort = non-zero => (row,col) sort like customSort. */
+int tkspmv_mtx_read(const char *path, int32_t index_base, int32_t read_values, int32_t sort, tkspmv_coo *out);
+void tkspmv_mtx_free(tkspmv_coo *m);
+int tkspmv_mtx_write(const char *path, uint32_t rows, uint32_t cols, uint64_t nnz, const uint32_t *row,
+                     const uint32_t *col, const float *val, int32_t index_base, int32_t precision);
+
+/* create_sample_vector(vec,size,random,sum_to_one,norm_one,seed): seed==0 => std::random_device. */
+int tkspmv_sample_vector(float *vec, int32_t size, int32_t random, int32_t sum_to_one, int32_t norm_one, int32_t seed);
+
+/* Synthetic matrix with the distributions of create_matrices.py (dist: 0 = uniform, 1 = gamma). Own PRNG. */
+int tkspmv_generate(uint32_t rows, uint32_t cols, uint32_t avg_nnz, int32_t dist, uint64_t seed, tkspmv_coo *out);
+
+typedef struct {
+    char matrix_path[1024];
+    int32_t use_sample_matrix, reset, num_tests, debug, ignore_matrix_values, top_k_value;
+    char xclbin_path[1024];
+    int32_t gpu_impl, use_half_precision_gpu, block_size_1d, block_size_2d, num_blocks;
+} tkspmv_options;
+int tkspmv_options_parse(int argc, char **argv, tkspmv_options *out);
+
+/* Layout introspection for tests: pack on the host, decode back to COO (+ placeholders dropped). */
+typedef struct tkspmv_packed tkspmv_packed;
+int tkspmv_pack(const tkspmv_desc *desc, uint32_t n_wave_partitions_hint, tkspmv_packed **out);
+int tkspmv_packed_info(const tkspmv_packed *p, tkspmv_info *info);
+/* Decodes into caller arrays sized >= nnz; returns the number of decoded entries in *n. */
+int tkspmv_packed_decode(const tkspmv_packed *p, uint32_t *row, uint32_t *col, float *val, uint64_t *n);
+/* Raw views (host memory owned by p). */
+int tkspmv_packed_raw(const tkspmv_packed *p, const void **packets, uint64_t *packet_bytes, const uint32_t **pkt_row,
+                      const uint32_t **part_first, const uint32_t **part_count, uint32_t *n_parts);
+void tkspmv_packed_free(tkspmv_packed *p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TKSPMV_H */

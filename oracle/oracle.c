@@ -1,0 +1,524 @@
+/*
+ * oracle.c -- CPU ORACLE for the Top-K SpMV hot path (see oracle.h). TEST INFRASTRUCTURE ONLY: the product never
+ * links this file. Each function cites the reference code it restates (paths relative to the reference root).
+ */
+#define _GNU_SOURCE
+#include "oracle.h"
+
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------------------------------------------
+ * spmv_coo_gold_top_k -- src/fpga/src/gold_algorithms/gold_algorithms.hpp:188-246
+ * Streams the row-sorted COO; when a row is complete and its score is >= the current worst entry of the k-slot
+ * list it overwrites that entry, then the worst is re-located by a left-to-right scan with a strict '<'
+ * (:219-230). The list starts as k x (0, 0.0) (:203-206). The last row is offered without a re-scan (:241-245).
+ * ---------------------------------------------------------------------------------------------------------- */
+void oracle_gold_topk(const uint32_t *row, const uint32_t *col, const float *val, uint64_t nnz, const float *vec, int k,
+                      uint32_t *res_idx, float *res_val) {
+    for (int i = 0; i < k; i++) {
+        res_idx[i] = 0;
+        res_val[i] = 0.0f;
+    }
+    if (nnz == 0 || k <= 0) return;
+    uint32_t curr_row = row[0];
+    float curr_out = 0.0f;
+    uint32_t worst_idx = 0;
+    float worst_val = 0.0f;
+    for (uint64_t i = 0; i < nnz; i++) {
+        /* the reference first scatters vec into an nnz-long array (:191-194); same values, same order */
+        float contribution = val[i] * vec[col[i]];
+        if (row[i] == curr_row) {
+            curr_out += contribution;
+        } else {
+            if (curr_out >= worst_val) {
+                res_idx[worst_idx] = curr_row;
+                res_val[worst_idx] = curr_out;
+                uint32_t w_i = 0;
+                float w_v = res_val[0];
+                for (int j = 0; j < k; j++) {
+                    if (res_val[j] < w_v) {
+                        w_i = (uint32_t)j;
+                        w_v = res_val[j];
+                    }
+                }
+                worst_idx = w_i;
+                worst_val = w_v;
+            }
+            curr_row = row[i];
+            curr_out = contribution;
+        }
+    }
+    if (curr_out >= worst_val) {
+        res_idx[worst_idx] = curr_row;
+        res_val[worst_idx] = curr_out;
+    }
+}
+
+/* sort_tuples -- src/common/utils/evaluation_utils.hpp:40-62 */
+typedef struct {
+    uint32_t idx;
+    float val;
+} tuple_t;
+static int tuple_cmp(const void *a, const void *b) {
+    const tuple_t *l = (const tuple_t *)a, *r = (const tuple_t *)b;
+    if (l->val != r->val) return (l->val > r->val) ? -1 : 1;
+    if (l->idx != r->idx) return (l->idx > r->idx) ? -1 : 1;
+    return 0;
+}
+void oracle_sort_tuples(uint64_t n, uint32_t *idx, float *val) {
+    tuple_t *t = (tuple_t *)malloc((n ? n : 1) * sizeof(tuple_t));
+    for (uint64_t i = 0; i < n; i++) {
+        t[i].idx = idx[i];
+        t[i].val = val[i];
+    }
+    qsort(t, n, sizeof(tuple_t), tuple_cmp);
+    for (uint64_t i = 0; i < n; i++) {
+        idx[i] = t[i].idx;
+        val[i] = t[i].val;
+    }
+    free(t);
+}
+
+void oracle_gold_topk_sorted(const uint32_t *row, const uint32_t *col, const float *val, uint64_t nnz,
+                             const float *vec, int k, uint32_t *res_idx, float *res_val) {
+    oracle_gold_topk(row, col, val, nnz, vec, k, res_idx, res_val);
+    oracle_sort_tuples((uint64_t)(k > 0 ? k : 0), res_idx, res_val);
+}
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Row scores (the quantity the gold accumulates per row, :208-217)
+ * ---------------------------------------------------------------------------------------------------------- */
+void oracle_scores_f32_seq(const uint32_t *row, const uint32_t *col, const float *val, uint64_t nnz, const float *vec,
+                           uint32_t rows, float *y, uint8_t *present) {
+    memset(y, 0, (size_t)rows * sizeof(float));
+    if (present) memset(present, 0, rows);
+    uint64_t i = 0;
+    while (i < nnz) {
+        uint32_t r = row[i];
+        float acc = val[i] * vec[col[i]];
+        i++;
+        while (i < nnz && row[i] == r) {
+            acc += val[i] * vec[col[i]];
+            i++;
+        }
+        if (r < rows) {
+            y[r] = acc;
+            if (present) present[r] = 1;
+        }
+    }
+}
+
+void oracle_scores_f64(const uint32_t *row, const uint32_t *col, const float *val, uint64_t nnz, const float *vec,
+                       uint32_t rows, double *y, uint8_t *present) {
+    memset(y, 0, (size_t)rows * sizeof(double));
+    if (present) memset(present, 0, rows);
+    for (uint64_t i = 0; i < nnz; i++) {
+        uint32_t r = row[i];
+        if (r >= rows) continue;
+        y[r] += (double)val[i] * (double)vec[col[i]];
+        if (present) present[r] = 1;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Exact top-k with the sort_tuples total order; min-heap of composite keys.
+ * ---------------------------------------------------------------------------------------------------------- */
+static inline uint32_t order_key(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+static inline float key_to_float(uint32_t k) {
+    uint32_t u = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+static void heap_sift_down(uint64_t *h, int n, int i) {
+    for (;;) {
+        int l = 2 * i + 1, r = l + 1, m = i;
+        if (l < n && h[l] < h[m]) m = l;
+        if (r < n && h[r] < h[m]) m = r;
+        if (m == i) return;
+        uint64_t t = h[i];
+        h[i] = h[m];
+        h[m] = t;
+        i = m;
+    }
+}
+static int u64_desc(const void *a, const void *b) {
+    uint64_t x = *(const uint64_t *)a, y = *(const uint64_t *)b;
+    return (x > y) ? -1 : (x < y) ? 1 : 0;
+}
+void oracle_select_topk(const float *y, const uint8_t *present, uint32_t rows, int k, float min_score,
+                        uint32_t first_row, uint32_t *res_idx, float *res_val) {
+    uint64_t *h = (uint64_t *)malloc((size_t)(k > 0 ? k : 1) * sizeof(uint64_t));
+    int n = 0;
+    for (uint32_t r = 0; r < rows; r++) {
+        if (present && !present[r]) continue;
+        if (!(y[r] >= min_score)) continue;
+        uint64_t key = ((uint64_t)order_key(y[r]) << 32) | r;
+        if (n < k) {
+            h[n++] = key;
+            if (n == k)
+                for (int i = n / 2 - 1; i >= 0; i--) heap_sift_down(h, n, i);
+        } else if (key > h[0]) {
+            h[0] = key;
+            heap_sift_down(h, n, 0);
+        }
+    }
+    qsort(h, (size_t)n, sizeof(uint64_t), u64_desc);
+    for (int i = 0; i < k; i++) {
+        if (i < n) {
+            res_idx[i] = (uint32_t)(h[i] & 0xFFFFFFFFu) + first_row;
+            res_val[i] = key_to_float((uint32_t)(h[i] >> 32));
+        } else {
+            res_idx[i] = 0;
+            res_val[i] = 0.0f;
+        }
+    }
+    free(h);
+}
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Order-matched model of the fused kernel on the wave-BSCSR layout. Mirrors, statement for statement, the
+ * arithmetic of stream_kernel in approximate-spmv-topk_amd/csrc/engine.hip (products, in-lane segmented sums,
+ * clipped Kogge-Stone scan over the 64 lanes, packet carry). Column word: bit0 ROW_END, bit1 SKIP, bits 15..2 col.
+ * ---------------------------------------------------------------------------------------------------------- */
+void oracle_packed_scores(const uint8_t *packets, uint64_t packet_bytes, const uint32_t *pkt_row,
+                          const uint32_t *part_first, const uint32_t *part_count, uint32_t n_parts, uint32_t C,
+                          const float *x, uint32_t rows, float *y, uint8_t *present) {
+    memset(y, 0, (size_t)rows * sizeof(float));
+    if (present) memset(present, 0, rows);
+    const uint32_t PE = 64 * C;
+    for (uint32_t q = 0; q < n_parts; q++) {
+        float carry = 0.0f;
+        for (uint32_t i = 0; i < part_count[q]; i++) {
+            const uint32_t pidx = part_first[q] + i;
+            const uint8_t *pk = packets + (size_t)pidx * packet_bytes;
+            const float *vals = (const float *)pk;
+            const uint16_t *cws = (const uint16_t *)(pk + (size_t)PE * 4);
+            float s[64][8], rs[64][8], head[64], tail[64], vv[64], nv[64];
+            uint32_t e[64][8], skip[64][8];
+            int first[64], any_e[64], dist[64];
+            for (uint32_t l = 0; l < 64; l++) {
+                float p[8] = {0};
+                for (uint32_t j = 0; j < C; j++) {
+                    uint32_t at = (j >> 2) * 256 + l * 4 + (j & 3);
+                    uint16_t w = cws[at];
+                    float xv = x[w >> 2];
+                    p[j] = vals[at] * xv;
+                    e[l][j] = w & 1u;
+                    skip[l][j] = w & 2u;
+                }
+                p[0] = p[0] + (l == 0 ? carry : 0.0f);
+                s[l][0] = p[0];
+                for (uint32_t j = 1; j < C; j++) s[l][j] = (e[l][j - 1] ? 0.0f : s[l][j - 1]) + p[j];
+                any_e[l] = 0;
+                first[l] = (int)C - 1;
+                for (int j = (int)C - 1; j >= 0; j--) {
+                    any_e[l] |= (int)e[l][j];
+                    if (e[l][j]) first[l] = j;
+                }
+                head[l] = s[l][C - 1];
+                for (int j = (int)C - 2; j >= 0; j--)
+                    if (e[l][j]) head[l] = s[l][j];
+                tail[l] = e[l][C - 1] ? 0.0f : s[l][C - 1];
+            }
+            /* distance to the nearest lane at or below l holding a row end (lane 0 if none) */
+            for (int l = 0; l < 64; l++) {
+                int m = 0;
+                for (int t = l; t >= 0; t--)
+                    if (any_e[t]) {
+                        m = t;
+                        break;
+                    }
+                dist[l] = l - m;
+                vv[l] = tail[l];
+            }
+            for (int d = 1; d < 64; d <<= 1) {
+                for (int l = 0; l < 64; l++) nv[l] = (dist[l] >= d) ? (vv[l] + vv[l - d]) : vv[l];
+                memcpy(vv, nv, sizeof(vv));
+            }
+            uint32_t r = pkt_row[pidx];
+            for (int l = 0; l < 64; l++) {
+                float cin = (l == 0) ? 0.0f : vv[l - 1];
+                float S = cin + head[l];
+                for (uint32_t j = 0; j < C; j++) {
+                    rs[l][j] = ((int)j == first[l]) ? S : s[l][j];
+                    if (e[l][j]) {
+                        if (!skip[l][j] && r < rows) {
+                            y[r] = rs[l][j];
+                            if (present) present[r] = 1;
+                        }
+                        r++;
+                    }
+                }
+            }
+            carry = vv[63];
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------------------
+ * create_sample_vector -- src/common/utils/utils.hpp:234-267 with std::mt19937 / uniform_real_distribution<double>
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct {
+    uint32_t mt[624];
+    int idx;
+} mt19937_t;
+static void mt_seed(mt19937_t *g, uint32_t seed) {
+    g->mt[0] = seed;
+    for (int i = 1; i < 624; i++) g->mt[i] = 1812433253u * (g->mt[i - 1] ^ (g->mt[i - 1] >> 30)) + (uint32_t)i;
+    g->idx = 624;
+}
+static uint32_t mt_next(mt19937_t *g) {
+    if (g->idx >= 624) {
+        for (int i = 0; i < 624; i++) {
+            uint32_t yv = (g->mt[i] & 0x80000000u) | (g->mt[(i + 1) % 624] & 0x7FFFFFFFu);
+            uint32_t v = g->mt[(i + 397) % 624] ^ (yv >> 1);
+            if (yv & 1u) v ^= 0x9908B0DFu;
+            g->mt[i] = v;
+        }
+        g->idx = 0;
+    }
+    uint32_t yv = g->mt[g->idx++];
+    yv ^= yv >> 11;
+    yv ^= (yv << 7) & 0x9D2C5680u;
+    yv ^= (yv << 15) & 0xEFC60000u;
+    yv ^= yv >> 18;
+    return yv;
+}
+/* libstdc++ generate_canonical<double, 53>: two 32-bit draws, low word first, divided by 2^64 */
+static double mt_canonical(mt19937_t *g) {
+    double sum = 0.0, tmp = 1.0;
+    for (int k = 0; k < 2; k++) {
+        sum += (double)mt_next(g) * tmp;
+        tmp *= 4294967296.0;
+    }
+    double ret = sum / tmp;
+    if (ret >= 1.0) ret = nextafter(1.0, 0.0);
+    return ret;
+}
+void oracle_sample_vector(float *vec, int size, int sum_to_one, int norm_one, uint32_t seed) {
+    mt19937_t g;
+    mt_seed(&g, seed);
+    for (int i = 0; i < size; i++) vec[i] = (float)mt_canonical(&g);
+    if (sum_to_one) {
+        float sum = 0;
+        for (int i = 0; i < size; i++) sum += vec[i];
+        for (int i = 0; i < size; i++) vec[i] = vec[i] / sum;
+    } else if (norm_one) {
+        double sum = 0;
+        for (int i = 0; i < size; i++) sum += vec[i] * vec[i];
+        double root = sqrt(sum);
+        for (int i = 0; i < size; i++) vec[i] = (float)(vec[i] / root);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------------------
+ * CPU baseline: sparse_dot_topn restated (third party, absent here; un-pinned upstream). For an N x 1 right-hand
+ * side its kernel reduces, per row, to sum_j A[i,j] * x[j] in CSR order (fp64), kept when > lower_bound; the
+ * threaded variant gives each of n_jobs threads one contiguous block of rows (test_cpu.py:104 uses n_jobs=40).
+ * ---------------------------------------------------------------------------------------------------------- */
+int oracle_coo_to_csr_f64(const uint32_t *row, const uint32_t *col, const float *val, uint64_t nnz, uint32_t rows,
+                          uint64_t *ptr, uint32_t *idx, double *v, uint64_t *nnz_out) {
+    /* csr_matrix((val,(x,y))): counting sort by row, then per row sort by column and sum duplicates */
+    memset(ptr, 0, ((size_t)rows + 1) * sizeof(uint64_t));
+    for (uint64_t i = 0; i < nnz; i++) {
+        if (row[i] >= rows) return 1;
+        ptr[row[i] + 1]++;
+    }
+    for (uint32_t r = 0; r < rows; r++) ptr[r + 1] += ptr[r];
+    uint64_t *fill = (uint64_t *)malloc(((size_t)rows + 1) * sizeof(uint64_t));
+    uint32_t *tidx = (uint32_t *)malloc((nnz ? nnz : 1) * sizeof(uint32_t));
+    double *tv = (double *)malloc((nnz ? nnz : 1) * sizeof(double));
+    if (!fill || !tidx || !tv) {
+        free(fill);
+        free(tidx);
+        free(tv);
+        return 2;
+    }
+    memcpy(fill, ptr, ((size_t)rows + 1) * sizeof(uint64_t));
+    for (uint64_t i = 0; i < nnz; i++) {
+        uint64_t d = fill[row[i]]++;
+        tidx[d] = col[i];
+        tv[d] = (double)val[i];
+    }
+    uint64_t out = 0;
+    for (uint32_t r = 0; r < rows; r++) {
+        uint64_t b = ptr[r], e = ptr[r + 1];
+        /* insertion sort by column (rows are short), stable */
+        for (uint64_t i = b + 1; i < e; i++) {
+            uint32_t ci = tidx[i];
+            double vi = tv[i];
+            uint64_t j = i;
+            while (j > b && tidx[j - 1] > ci) {
+                tidx[j] = tidx[j - 1];
+                tv[j] = tv[j - 1];
+                j--;
+            }
+            tidx[j] = ci;
+            tv[j] = vi;
+        }
+        uint64_t start = out;
+        for (uint64_t i = b; i < e; i++) {
+            if (out > start && idx[out - 1] == tidx[i]) {
+                v[out - 1] += tv[i];
+            } else {
+                idx[out] = tidx[i];
+                v[out] = tv[i];
+                out++;
+            }
+        }
+        ptr[r] = start;
+    }
+    ptr[rows] = out;
+    if (nnz_out) *nnz_out = out;
+    free(fill);
+    free(tidx);
+    free(tv);
+    return 0;
+}
+
+typedef struct {
+    const uint64_t *ptr;
+    const uint32_t *idx;
+    const double *v;
+    const double *x;
+    const float *vf;
+    const float *xf;
+    uint32_t r0, r1;
+    double lower_bound;
+    double *scores;
+    float *scores_f;
+    uint8_t *kept;
+} job_t;
+
+static void *topn_job(void *arg) {
+    job_t *j = (job_t *)arg;
+    for (uint32_t r = j->r0; r < j->r1; r++) {
+        double sum = 0.0;
+        for (uint64_t p = j->ptr[r]; p < j->ptr[r + 1]; p++) sum += j->v[p] * j->x[j->idx[p]];
+        int keep = sum > j->lower_bound;
+        j->scores[r] = keep ? sum : 0.0;
+        j->kept[r] = (uint8_t)keep;
+    }
+    return NULL;
+}
+static void *spmv_f32_job(void *arg) {
+    job_t *j = (job_t *)arg;
+    for (uint32_t r = j->r0; r < j->r1; r++) {
+        float sum = 0.0f;
+        for (uint64_t p = j->ptr[r]; p < j->ptr[r + 1]; p++) sum += j->vf[p] * j->xf[j->idx[p]];
+        j->scores_f[r] = sum;
+    }
+    return NULL;
+}
+static int run_jobs(job_t *proto, uint32_t rows, int n_threads, void *(*fn)(void *)) {
+    if (n_threads < 1) n_threads = 1;
+    pthread_t *th = (pthread_t *)malloc((size_t)n_threads * sizeof(pthread_t));
+    job_t *jobs = (job_t *)malloc((size_t)n_threads * sizeof(job_t));
+    if (!th || !jobs) {
+        free(th);
+        free(jobs);
+        return 2;
+    }
+    uint32_t per = (rows + (uint32_t)n_threads - 1) / (uint32_t)n_threads;
+    int started = 0;
+    for (int t = 0; t < n_threads; t++) {
+        jobs[t] = *proto;
+        uint64_t a = (uint64_t)per * (uint64_t)t, b = a + per;
+        jobs[t].r0 = (uint32_t)(a < rows ? a : rows);
+        jobs[t].r1 = (uint32_t)(b < rows ? b : rows);
+        if (n_threads == 1) {
+            fn(&jobs[t]);
+        } else if (pthread_create(&th[t], NULL, fn, &jobs[t]) == 0) {
+            started++;
+        } else {
+            fn(&jobs[t]);
+        }
+    }
+    if (n_threads > 1)
+        for (int t = 0; t < started; t++) pthread_join(th[t], NULL);
+    free(th);
+    free(jobs);
+    return 0;
+}
+int oracle_cpu_topn(const uint64_t *ptr, const uint32_t *idx, const double *v, uint32_t rows, const double *x,
+                    double lower_bound, int n_threads, double *scores, uint8_t *kept) {
+    job_t proto;
+    memset(&proto, 0, sizeof(proto));
+    proto.ptr = ptr;
+    proto.idx = idx;
+    proto.v = v;
+    proto.x = x;
+    proto.lower_bound = lower_bound;
+    proto.scores = scores;
+    proto.kept = kept;
+    return run_jobs(&proto, rows, n_threads, topn_job);
+}
+int oracle_cpu_spmv_f32(const uint64_t *ptr, const uint32_t *idx, const float *v, uint32_t rows, const float *x,
+                        int n_threads, float *scores) {
+    job_t proto;
+    memset(&proto, 0, sizeof(proto));
+    proto.ptr = ptr;
+    proto.idx = idx;
+    proto.vf = v;
+    proto.xf = x;
+    proto.scores_f = scores;
+    return run_jobs(&proto, rows, n_threads, spmv_f32_job);
+}
+
+typedef struct {
+    double v;
+    uint32_t r;
+} dpair_t;
+static int dpair_less(const dpair_t *a, const dpair_t *b) { /* a ranks below b */
+    if (a->v != b->v) return a->v < b->v;
+    return a->r < b->r;
+}
+static void dheap_sift(dpair_t *h, int n, int i) {
+    for (;;) {
+        int l = 2 * i + 1, r = l + 1, m = i;
+        if (l < n && dpair_less(&h[l], &h[m])) m = l;
+        if (r < n && dpair_less(&h[r], &h[m])) m = r;
+        if (m == i) return;
+        dpair_t t = h[i];
+        h[i] = h[m];
+        h[m] = t;
+        i = m;
+    }
+}
+static int dpair_desc(const void *a, const void *b) {
+    const dpair_t *x = (const dpair_t *)a, *y = (const dpair_t *)b;
+    if (dpair_less(y, x)) return -1;
+    if (dpair_less(x, y)) return 1;
+    return 0;
+}
+void oracle_cpu_global_topk(const double *scores, const uint8_t *kept, uint32_t rows, int k, uint32_t *res_idx,
+                            double *res_val) {
+    dpair_t *h = (dpair_t *)malloc((size_t)(k > 0 ? k : 1) * sizeof(dpair_t));
+    int n = 0;
+    for (uint32_t r = 0; r < rows; r++) {
+        if (kept && !kept[r]) continue;
+        dpair_t c = {scores[r], r};
+        if (n < k) {
+            h[n++] = c;
+            if (n == k)
+                for (int i = n / 2 - 1; i >= 0; i--) dheap_sift(h, n, i);
+        } else if (dpair_less(&h[0], &c)) {
+            h[0] = c;
+            dheap_sift(h, n, 0);
+        }
+    }
+    qsort(h, (size_t)n, sizeof(dpair_t), dpair_desc);
+    for (int i = 0; i < k; i++) {
+        res_idx[i] = i < n ? h[i].r : 0;
+        res_val[i] = i < n ? h[i].v : 0.0;
+    }
+    free(h);
+}

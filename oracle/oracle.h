@@ -1,0 +1,71 @@
+/*
+ * oracle.h -- CPU ORACLE for the Top-K SpMV hot path. TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library. The product
+ * (approximate-spmv-topk_amd/) never links, imports or executes anything under oracle/.
+ *
+ * Parity status: PINNED. Every function that restates reference code is checked in tests/test_oracle_pin.py
+ * against oracle/_ref/libref_gold.so (the reference's own headers compiled here by `make ref`) and against the
+ * committed golden vectors in tests/golden/ that were generated from it (tests/golden/make_golden.py).
+ * Exception: oracle_cpu_topn restates the third-party package sparse_dot_topn (un-pinned "pip install",
+ * reference README.md:49-50; call site test_cpu.py:104), which is absent here: "parity unpinned" at that
+ * boundary; it is pinned instead against scipy's csr @ x on the same inputs.
+ */
+#ifndef TKSPMV_ORACLE_H
+#define TKSPMV_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* spmv_coo_gold_top_k (src/fpga/src/gold_algorithms/gold_algorithms.hpp:188-246), T = float as the GPU hosts
+ * instantiate it (src/gpu/host_spmv_topk_csr_gpu.cu:28-29,278-281). Output unsorted, as the reference leaves it. */
+void oracle_gold_topk(const uint32_t *row, const uint32_t *col, const float *val, uint64_t nnz, const float *vec, int k,
+                      uint32_t *res_idx, float *res_val);
+/* sort_tuples (src/common/utils/evaluation_utils.hpp:40-62): value descending, ties by index descending. */
+void oracle_sort_tuples(uint64_t n, uint32_t *idx, float *val);
+/* sw_test's top-k leg (host_spmv_topk_csr_gpu.cu:268-286) = gold_topk followed by sort_tuples. */
+void oracle_gold_topk_sorted(const uint32_t *row, const uint32_t *col, const float *val, uint64_t nnz,
+                             const float *vec, int k, uint32_t *res_idx, float *res_val);
+
+/* Row scores. present[r] = 1 iff row r has at least one entry. y arrays have `rows` elements. */
+void oracle_scores_f32_seq(const uint32_t *row, const uint32_t *col, const float *val, uint64_t nnz, const float *vec,
+                           uint32_t rows, float *y, uint8_t *present); /* gold's sequential fp32 order */
+void oracle_scores_f64(const uint32_t *row, const uint32_t *col, const float *val, uint64_t nnz, const float *vec,
+                       uint32_t rows, double *y, uint8_t *present);
+
+/* Exact top-k by (score desc, row desc) among present rows with score >= min_score; padded with (0, 0.0f). */
+void oracle_select_topk(const float *y, const uint8_t *present, uint32_t rows, int k, float min_score,
+                        uint32_t first_row, uint32_t *res_idx, float *res_val);
+
+/* Order-matched model of the fused kernel's arithmetic on the wave-BSCSR layout (wbscsr.hpp): same products,
+ * same in-lane sums, same clipped Kogge-Stone tree, same carries => bit-identical fp32 row scores.
+ * C = entries per lane (4 or 8). Rows never finished by a ROW_END keep present = 0. */
+void oracle_packed_scores(const uint8_t *packets, uint64_t packet_bytes, const uint32_t *pkt_row,
+                          const uint32_t *part_first, const uint32_t *part_count, uint32_t n_parts, uint32_t C,
+                          const float *x, uint32_t rows, float *y, uint8_t *present);
+
+/* create_sample_vector(vec, size, random=true, sum_to_one, norm_one, seed != 0) (src/common/utils/utils.hpp:234-267)
+ * with std::mt19937 and std::uniform_real_distribution<double> restated (libstdc++ generate_canonical). */
+void oracle_sample_vector(float *vec, int size, int sum_to_one, int norm_one, uint32_t seed);
+
+/* CPU baseline: restatement of sparse_dot_topn's threaded kernel for an N x 1 right-hand side
+ * (awesome_cossim_topn(csr, vec.T, K, 0.0, use_threads=True, n_jobs), test_cpu.py:104): fp64 CSR rows, contiguous
+ * row blocks over n_threads, keep scores > lower_bound. Returns 0 on success.
+ * csr_* from oracle_coo_to_csr_f64 (duplicates summed, like scipy's csr_matrix((val,(x,y)))). */
+int oracle_coo_to_csr_f64(const uint32_t *row, const uint32_t *col, const float *val, uint64_t nnz, uint32_t rows,
+                          uint64_t *ptr /* rows+1 */, uint32_t *idx /* nnz */, double *v /* nnz */, uint64_t *nnz_out);
+int oracle_cpu_topn(const uint64_t *ptr, const uint32_t *idx, const double *v, uint32_t rows, const double *x,
+                    double lower_bound, int n_threads, double *scores /* rows */, uint8_t *kept /* rows */);
+/* Global top-k over the kept scores (the step a user of the CPU path does next); (score desc, row desc). */
+void oracle_cpu_global_topk(const double *scores, const uint8_t *kept, uint32_t rows, int k, uint32_t *res_idx,
+                            double *res_val);
+/* fp32 variant of the threaded SpMV (values and x in float, float accumulation), for the fp32 baseline line. */
+int oracle_cpu_spmv_f32(const uint64_t *ptr, const uint32_t *idx, const float *v, uint32_t rows, const float *x,
+                        int n_threads, float *scores);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
