@@ -49,7 +49,9 @@ class Info(C.Structure):
 class Timing(C.Structure):
     _fields_ = [
         ("stream_kernel_ns", C.c_double), ("select_kernel_ns", C.c_double), ("query_ns", C.c_double),
-        ("candidates_avg", C.c_double), ("n_queries", C.c_uint32), ("reserved", C.c_uint32 * 5),
+        ("candidates_avg", C.c_double), ("scores_kernel_ns", C.c_double), ("slow_paths_avg", C.c_double),
+        ("appended_avg", C.c_double), ("n_queries", C.c_uint32),
+        ("reserved", C.c_uint32 * 3),
     ]
 
 

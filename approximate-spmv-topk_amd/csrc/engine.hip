@@ -22,6 +22,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -53,17 +54,24 @@ struct StreamParams {
     uint32_t n_groups_pub;  // power of two, groups [0, n_groups_pub) publish maxima
     uint32_t gpw;           // groups per workgroup
     float min_score;
-    uint32_t *gmax;  // [n_groups_pub] order keys
-    uint2 *wg_cand;  // [grid][cand_cap] {score bits, local row}
-    uint32_t *wg_count;
+    uint32_t *gmax;  // [MAX_GM*64] order keys of the group maxima (zero beyond n_groups_pub)
+    uint32_t *tau_g; // one word: order key of the broadcast threshold (monotone, atomic max)
+    uint32_t n_reducers;  // workgroups [0, n_reducers) reduce gmax -> tau_g; the others only read tau_g
+    uint2 *wg_cand;  // [grid][WG_SLOTS] {score bits, local row}; unused slots carry row SLOT_INVALID
     uint32_t cand_cap;
     uint2 *ovf_cand;
     uint32_t *ovf_count;
     uint32_t ovf_cap;
     float *scores;  // SCORES variant only
+    uint32_t dbg_flags;       // ablation switches (TKSPMV_DBG_FLAGS): 1 no publish, 2 no offers, 4 no tau duty, 8 no flush
+    unsigned long long *dbg;  // optional counters (TKSPMV_STATS=1): [0] slow-path executions, [1] appended rows
 };
 
-constexpr int MISC_CAND_CNT = 0, MISC_TAU = 1, MISC_FLUSH_CNT = 2, MISC_GRPMAX = 4;
+constexpr int MISC_CAND_CNT = 0, MISC_TAU = 1, MISC_FLUSH_CNT = 2, MISC_FLUSH_POS = 3, MISC_OVF_BASE = 4, MISC_DONE = 5,
+              MISC_GRPMAX = 8 /* [8] */, MISC_PUBLISHED = 16 /* [8] */, MISC_WORDS = 32;  // <= 8 groups per workgroup
+constexpr uint32_t CAND_CAP = 1024;  // per-workgroup candidate list entries in LDS
+constexpr uint32_t WG_SLOTS = 8;              // fixed result slots every workgroup writes (no count round trip)
+constexpr uint32_t SLOT_INVALID = 0xFFFFFFFFu;  // row id of an unused slot
 
 template <int C>
 struct Pkt {
@@ -86,217 +94,448 @@ __device__ __forceinline__ void load_packet(const uint8_t *__restrict__ pk, uint
     }
 }
 
-// tau = min over sets of (max over the set's groups). Executed by one wave.
-__device__ __forceinline__ float refresh_tau(const StreamParams &P, uint32_t lane) {
+// DPP lane movement (gfx950 keeps the GFX9 controls): lanes without a valid source receive 0.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_zero(float src) {
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, src), CTRL, ROW_MASK, 0xF, true));
+}
+constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114, DPP_ROW_SHR8 = 0x118;
+constexpr int DPP_WAVE_SHR1 = 0x138, DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143;
+
+// Wave-wide maximum with DPP (result uniform, returned through an SGPR).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_keep(float v) {  // lanes without a valid source keep their own value
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v),
+                                                                 CTRL, ROW_MASK, 0xF, false));
+}
+__device__ __forceinline__ float wave_max(float v) {
+    v = fmaxf(v, dpp_keep<DPP_ROW_SHR1, 0xF>(v));
+    v = fmaxf(v, dpp_keep<DPP_ROW_SHR2, 0xF>(v));
+    v = fmaxf(v, dpp_keep<DPP_ROW_SHR4, 0xF>(v));
+    v = fmaxf(v, dpp_keep<DPP_ROW_SHR8, 0xF>(v));
+    v = fmaxf(v, dpp_keep<DPP_ROW_BCAST15, 0xA>(v));
+    v = fmaxf(v, dpp_keep<DPP_ROW_BCAST31, 0xC>(v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+    auto mv = [](uint32_t a, uint32_t b) { return b < a ? b : a; };
+    v = mv(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_ROW_SHR1, 0xF, 0xF, false));
+    v = mv(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_ROW_SHR2, 0xF, 0xF, false));
+    v = mv(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_ROW_SHR4, 0xF, 0xF, false));
+    v = mv(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_ROW_SHR8, 0xF, 0xF, false));
+    v = mv(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_ROW_BCAST15, 0xA, 0xF, false));
+    v = mv(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_ROW_BCAST31, 0xC, 0xF, false));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// Threshold exchange, reader side. One wave: (1) issue the loads of the published maxima early, (2) much later
+// stage them in LDS and reduce: tau = min over sets of (max over the set's groups).
+constexpr int MAX_GM = 16;  // n_groups_pub <= 1024 => at most 16 values per lane
+struct TauRegs {
+    uint32_t k[MAX_GM];
+};
+__device__ __forceinline__ void tau_issue(const StreamParams &P, uint32_t lane, TauRegs &t) {
+    // gmax is allocated with MAX_GM * 64 entries (zero beyond n_groups_pub), so no bounds predicate is needed;
+    // whole 256-B rows beyond the used part are skipped with a uniform branch.
+#pragma unroll
+    for (int i = 0; i < MAX_GM; ++i) {
+        t.k[i] = 0u;
+        if (64u * i < P.n_groups_pub)
+            t.k[i] = __hip_atomic_load(&P.gmax[lane + 64u * i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+__device__ __forceinline__ float tau_finish(const StreamParams &P, uint32_t lane, const TauRegs &t, uint32_t *gm_lds) {
+#pragma unroll
+    for (int i = 0; i < MAX_GM; ++i) {
+        if (64u * i < P.n_groups_pub) gm_lds[lane + 64u * i] = t.k[i];
+    }
+    // same wave wrote and reads: LDS operations of one wave complete in order
     uint32_t vmin = 0xFFFFFFFFu;
-    for (uint32_t t = lane; t < P.n_sets; t += 64) {
+    for (uint32_t st = lane; st < P.n_sets; st += 64) {
         uint32_t smax = 0;
-        for (uint32_t s = t; s < P.n_groups_pub; s += P.n_sets) {
-            uint32_t kx = __hip_atomic_load(&P.gmax[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (uint32_t s = st; s < P.n_groups_pub; s += P.n_sets) {
+            const uint32_t kx = gm_lds[s];
             smax = kx > smax ? kx : smax;
         }
         vmin = smax < vmin ? smax : vmin;
     }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        uint32_t o = (uint32_t)__shfl_xor((int)vmin, d);
-        vmin = o < vmin ? o : vmin;
-    }
+    vmin = wave_min_u32(vmin);
     float tau = P.min_score;
     if (vmin != 0u && vmin != 0xFFFFFFFFu) {
-        float f = key_to_float(vmin);
+        const float f = key_to_float(vmin);
         tau = f > tau ? f : tau;
     }
     return tau;
 }
 
+// Writer side: lanes 0..gpw-1 of the calling wave push the workgroup's group maxima (kept in LDS) to gmax.
+__device__ __forceinline__ void publish_group_max(const StreamParams &P, uint32_t lane, uint32_t *misc) {
+    if (lane < P.gpw) {
+        const uint32_t g = blockIdx.x * P.gpw + lane;
+        const uint32_t key = misc[MISC_GRPMAX + lane];
+        if (g < P.n_groups_pub && key > misc[MISC_PUBLISHED + lane]) {
+            misc[MISC_PUBLISHED + lane] = key;
+            // single writer per slot (this workgroup): a write-through store, no memory-side read-modify-write
+            __hip_atomic_store(&P.gmax[g], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // The fused streaming kernel
 // ------------------------------------------------------------------------------------------------------------
+// Finished-row sums of one packet as seen by one lane. flags: bit j = ROW_END of entry j, bit 8+j = SKIP.
+template <int C>
+struct RowSums {
+    float rs[C];
+    uint32_t flags;
+    __device__ __forceinline__ bool end(int j) const { return (flags >> j) & 1u; }
+    __device__ __forceinline__ bool valid(int j) const { return ((flags >> j) & 0x101u) == 1u; }  // end and not skip
+};
+
+// Products, in-lane segmented sums, cross-lane segmented scan. Updates the packet carry.
+template <int C>
+__device__ __forceinline__ RowSums<C> reduce_packet(const Pkt<C> &cur, uint32_t lane, float &carry, const float *x_lds) {
+    float p[C];
+    uint32_t e[C];
+    uint32_t flags = 0;
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+        const uint32_t w = (j & 1) ? (cur.cw[j >> 1] >> 16) : (cur.cw[j >> 1] & 0xFFFFu);
+        const float xv =
+            *reinterpret_cast<const float *>(reinterpret_cast<const unsigned char *>(x_lds) + (w & 0xFFFCu));
+        p[j] = __fmul_rn(cur.v[j], xv);
+        e[j] = w & 1u;
+        flags |= (w & 1u) << j;
+        flags |= ((w >> 1) & 1u) << (8 + j);
+    }
+    p[0] = __fadd_rn(p[0], lane == 0 ? carry : 0.0f);
+
+    // in-lane segmented sums
+    float s[C];
+    s[0] = p[0];
+#pragma unroll
+    for (int j = 1; j < C; ++j) s[j] = __fadd_rn(e[j - 1] ? 0.0f : s[j - 1], p[j]);
+    uint32_t any_e = 0;
+    int first = C - 1;
+#pragma unroll
+    for (int j = C - 1; j >= 0; --j) {
+        any_e |= e[j];
+        first = e[j] ? j : first;
+    }
+    float head = s[C - 1];
+#pragma unroll
+    for (int j = C - 2; j >= 0; --j) head = e[j] ? s[j] : head;
+    const float tail = e[C - 1] ? 0.0f : s[C - 1];
+
+    // Cross-lane segmented inclusive scan of the tails.
+    // dist = lanes back to the nearest lane (<= this one) that holds a row end; lane id if there is none.
+    // Kogge-Stone inside each row of 16 lanes (DPP row_shr), then the row totals travel with
+    // row_bcast:15 / row_bcast:31; every add is clipped by dist so sums never cross a row end.
+    const uint64_t H = __ballot(any_e != 0u);
+    const uint64_t le_mask = (lane == 63u) ? ~0ull : ((2ull << lane) - 1ull);
+    const uint64_t hb = H & le_mask;
+    const int dist = (int)lane - (hb ? (63 - __builtin_clzll(hb)) : 0);
+    const int l16 = (int)(lane & 15u), l32 = (int)(lane & 31u);
+    float vv = tail;
+    {
+        float up;
+        up = dpp_zero<DPP_ROW_SHR1, 0xF>(vv);
+        vv = (dist >= 1) ? __fadd_rn(vv, up) : vv;
+        up = dpp_zero<DPP_ROW_SHR2, 0xF>(vv);
+        vv = (dist >= 2) ? __fadd_rn(vv, up) : vv;
+        up = dpp_zero<DPP_ROW_SHR4, 0xF>(vv);
+        vv = (dist >= 4) ? __fadd_rn(vv, up) : vv;
+        up = dpp_zero<DPP_ROW_SHR8, 0xF>(vv);
+        vv = (dist >= 8) ? __fadd_rn(vv, up) : vv;
+        up = dpp_zero<DPP_ROW_BCAST15, 0xA>(vv);  // lane 15 -> row 1, lane 47 -> row 3
+        vv = (dist > l16) ? __fadd_rn(vv, up) : vv;
+        up = dpp_zero<DPP_ROW_BCAST31, 0xC>(vv);  // lane 31 -> rows 2 and 3
+        vv = (dist > l32) ? __fadd_rn(vv, up) : vv;
+    }
+    const float cin = dpp_zero<DPP_WAVE_SHR1, 0xF>(vv);  // lane l-1's inclusive sum; 0 for lane 0
+    const float S = __fadd_rn(cin, head);
+    carry = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, vv), 63));
+
+    RowSums<C> out;
+#pragma unroll
+    for (int j = 0; j < C; ++j) out.rs[j] = (j == first) ? S : s[j];
+    out.flags = flags;
+    return out;
+}
+
+template <int C>
+__device__ __forceinline__ float lane_best(const RowSums<C> &R) {
+    float best = -__builtin_huge_valf();
+#pragma unroll
+    for (int j = 0; j < C; ++j) best = (R.valid(j) && R.rs[j] > best) ? R.rs[j] : best;
+    return best;
+}
+
+// Number of row ends in lower lanes (=> row id of this lane's first row end is rb + that).
+template <int C>
+__device__ __forceinline__ uint32_t ends_below(const RowSums<C> &R) {
+    uint32_t below = 0;
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+        const uint64_t b = __ballot(R.end(j));
+        below += __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+    }
+    return below;
+}
+
+// Candidate path (rare once tau has converged). Everything is aggregated per wave: one LDS atomic reserves list
+// slots, one LDS atomic raises the group maximum (the wave on threshold duty pushes it to global memory).
+template <int C>
+__device__ __forceinline__ void offer_candidates(const StreamParams &P, const RowSums<C> &R, uint32_t rb, float tau,
+                                                 float best, uint32_t lane, uint32_t grp_local, bool publishes,
+                                                 uint2 *cand, uint32_t *misc) {
+    bool pass[C];
+    uint32_t slot[C];
+    uint32_t total = 0;
+    const uint32_t below = ends_below<C>(R);
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+        pass[j] = R.valid(j) && R.rs[j] >= tau;
+        const uint64_t pb = __ballot(pass[j]);
+        slot[j] = total + __builtin_amdgcn_mbcnt_hi((uint32_t)(pb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pb, 0u));
+        total += (uint32_t)__popcll(pb);
+    }
+    const float wmax = wave_max(best >= tau ? best : -__builtin_huge_valf());
+    uint32_t base = 0;
+    if (lane == 0) {
+        if (publishes)
+            (void)__hip_atomic_fetch_max(&misc[MISC_GRPMAX + grp_local], order_key(wmax), __ATOMIC_RELAXED,
+                                         __HIP_MEMORY_SCOPE_WORKGROUP);
+        base = atomicAdd(&misc[MISC_CAND_CNT], total);
+        if (P.dbg) {
+            atomicAdd(&P.dbg[0], 1ull);
+            atomicAdd(&P.dbg[1], (unsigned long long)total);
+        }
+    }
+    base = __builtin_amdgcn_readfirstlane(base);
+    uint32_t r = rb + below;
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+        if (pass[j]) {
+            const uint32_t pos = base + slot[j];
+            if (pos < P.cand_cap) {
+                cand[pos] = make_uint2(__float_as_uint(R.rs[j]), r);
+            } else {
+                const uint32_t gp = atomicAdd(P.ovf_count, 1u);
+                if (gp < P.ovf_cap) P.ovf_cand[gp] = make_uint2(__float_as_uint(R.rs[j]), r);
+            }
+        }
+        r += R.end(j) ? 1u : 0u;
+    }
+}
+
+constexpr int DEFER = 3;  // packets per wave whose rows are judged at the end (threshold exchange cold start)
+
 template <int C, bool SCORES>
-__global__ void __launch_bounds__(1024) stream_kernel(const StreamParams P) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+__global__ void __launch_bounds__(576, 5) stream_kernel(const StreamParams P) {
+    // Static LDS objects are addressed with ds_* instructions for certain; a pointer carved out of the dynamic
+    // region can degrade to flat_* accesses, and one flat access in the loop forces s_waitcnt vmcnt(0), which
+    // would drain the packet prefetch every iteration.
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // x only: cols * 4 bytes
+    __shared__ uint2 cand[CAND_CAP];                                       // candidate list {score bits, row}
+    __shared__ uint32_t misc[MISC_WORDS];
+    __shared__ uint32_t gm_lds[MAX_GM * 64];  // staging of the published maxima
     float *x_lds = reinterpret_cast<float *>(smem);
-    uint2 *cand = reinterpret_cast<uint2 *>(smem + P.x_lds_bytes);
-    uint32_t *misc = reinterpret_cast<uint32_t *>(smem + P.x_lds_bytes + (size_t)P.cand_cap * 8);
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t nwaves = blockDim.x >> 6;
-    const uint32_t grp_local = wave * P.gpw / nwaves;
+    // The last wave of the workgroup is the exchange SERVER, the others stream. vmcnt retires in order, so a slow
+    // remote access (the hot threshold word, the maxima of 512 workgroups) issued by a streaming wave would hold
+    // back the visibility of every packet load behind it; the server keeps such traffic out of the stream.
+    const uint32_t nwaves = (blockDim.x >> 6) - 1u;  // streaming waves
+    const bool is_server = (wave == nwaves);
+    const uint32_t grp_local = is_server ? 0u : wave * P.gpw / nwaves;
     const uint32_t grp_global = blockIdx.x * P.gpw + grp_local;
     const bool publishes = (P.n_sets != 0u) && (grp_global < P.n_groups_pub);
+    const bool reducer = blockIdx.x < P.n_reducers;
 
     // Stage the dense query vector in LDS (reference: URAM copies, spmv_bscsr_top_k_multicore.cpp:87-140).
     for (uint32_t i = tid; i < (P.x_lds_bytes >> 2); i += blockDim.x) x_lds[i] = (i < P.cols) ? P.x[i] : 0.0f;
-    if (tid < MISC_GRPMAX + P.gpw) misc[tid] = (tid == MISC_TAU) ? __float_as_uint(P.min_score) : 0u;
+    if (tid < MISC_WORDS) misc[tid] = (tid == MISC_TAU) ? __float_as_uint(P.min_score) : 0u;
     __syncthreads();
 
+    if (is_server) {
+        if (!SCORES && P.n_sets != 0u && !(P.dbg_flags & 4u)) {
+            for (;;) {
+                if (!(P.dbg_flags & 1u)) publish_group_max(P, lane, misc);
+                float t;
+                if (reducer) {
+                    TauRegs tr;
+                    tau_issue(P, lane, tr);
+                    t = tau_finish(P, lane, tr, gm_lds);
+                    if (lane == 0 && t > P.min_score)
+                        __hip_atomic_fetch_max(P.tau_g, order_key(t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    const uint32_t kx = __hip_atomic_load(P.tau_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    t = kx ? key_to_float(kx) : P.min_score;
+                }
+                if (lane == 0) {
+                    const float cur_tau = __uint_as_float(
+                        __hip_atomic_load(&misc[MISC_TAU], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                    if (t > cur_tau)
+                        __hip_atomic_store(&misc[MISC_TAU], __float_as_uint(t), __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                // every streaming wave counts itself out; none of them ever waits, so this loop always ends
+                const uint32_t done =
+                    __hip_atomic_load(&misc[MISC_DONE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (__builtin_amdgcn_readfirstlane(done) >= nwaves) break;
+                __builtin_amdgcn_s_sleep(8);
+            }
+        }
+    }
     const uint32_t total_waves = nwaves * gridDim.x;
-    for (uint32_t q = wave * gridDim.x + blockIdx.x; q < P.n_parts; q += total_waves) {
+    for (uint32_t q = is_server ? P.n_parts : wave * gridDim.x + blockIdx.x; q < P.n_parts; q += total_waves) {
         const uint32_t p0 = P.part_first[q];
         const uint32_t np = P.part_count[q];
         const uint8_t *pk = P.packets + (size_t)p0 * P.packet_bytes;
         float carry = 0.0f;
 
-        Pkt<C> cur, nxt;
-        uint32_t rb_cur = 0, rb_nxt = 0;
-        if (np) {
-            load_packet<C>(pk, lane, cur);
-            rb_cur = P.pkt_row[p0];
+        RowSums<C> st[DEFER];  // deferred packets
+        uint32_t st_rb[DEFER];
+#pragma unroll
+        for (int d = 0; d < DEFER; ++d) {
+            st[d].flags = 0u;
+            st_rb[d] = 0u;
+#pragma unroll
+            for (int j = 0; j < C; ++j) st[d].rs[j] = 0.0f;
         }
-        for (uint32_t i = 0; i < np; ++i) {
-            if (i + 1 < np) {
-                load_packet<C>(pk + (size_t)(i + 1) * P.packet_bytes, lane, nxt);
-                rb_nxt = P.pkt_row[p0 + i + 1];
-            }
-            if (!SCORES && wave == 0 && P.n_sets != 0u) {
-                float t = refresh_tau(P, lane);
-                if (lane == 0) misc[MISC_TAU] = __float_as_uint(t);
-            }
 
-            // ---- products ----------------------------------------------------------------------------
-            float p[C];
-            uint32_t e[C], skip[C];
+        // Two packets in flight behind the one being reduced. The three buffers rotate by NAME (the loop is
+        // unrolled by three): copying a freshly loaded buffer into another would wait for the youngest load
+        // and drain the prefetch queue every iteration.
+        Pkt<C> buf[3];
+        uint32_t rbs[3] = {0u, 0u, 0u};
+        if (np > 0) {
+            load_packet<C>(pk, lane, buf[0]);
+            rbs[0] = P.pkt_row[p0];
+        }
+        if (np > 0) {
+            const uint32_t i1 = np > 1 ? 1u : 0u;
+            load_packet<C>(pk + (size_t)i1 * P.packet_bytes, lane, buf[1]);
+            rbs[1] = P.pkt_row[p0 + i1];
+        }
+        for (uint32_t i0 = 0; i0 < np; i0 += 3) {
 #pragma unroll
-            for (int j = 0; j < C; ++j) {
-                const uint32_t w = (j & 1) ? (cur.cw[j >> 1] >> 16) : (cur.cw[j >> 1] & 0xFFFFu);
-                const float xv = *reinterpret_cast<const float *>(reinterpret_cast<const unsigned char *>(x_lds) +
-                                                                   (w & 0xFFFCu));
-                p[j] = __fmul_rn(cur.v[j], xv);
-                e[j] = w & 1u;
-                skip[j] = w & 2u;
+            for (int u = 0; u < 3; ++u) {
+                const uint32_t i = i0 + (uint32_t)u;
+                if (i >= np) break;
+                const Pkt<C> &cur = buf[u];
+                const uint32_t rb_cur = rbs[u];
+                Pkt<C> &ahead = buf[(u + 2) % 3];
+                uint32_t &rb_ahead = rbs[(u + 2) % 3];
+            {
+                // Unconditional (index clamped to the last packet): a fixed number of younger loads lets the
+                // compiler wait with a counted vmcnt instead of vmcnt(0).
+                const uint32_t ia = (i + 2 < np) ? (i + 2) : (np - 1);
+                load_packet<C>(pk + (size_t)ia * P.packet_bytes, lane, ahead);
+                rb_ahead = P.pkt_row[p0 + ia];
             }
-            p[0] = __fadd_rn(p[0], lane == 0 ? carry : 0.0f);
+            float tau = 0.0f;
+            if (!SCORES)
+                tau = __uint_as_float(
+                    __hip_atomic_load(&misc[MISC_TAU], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
 
-            // ---- in-lane segmented sums -----------------------------------------------------------------
-            float s[C];
-            s[0] = p[0];
-#pragma unroll
-            for (int j = 1; j < C; ++j) s[j] = __fadd_rn(e[j - 1] ? 0.0f : s[j - 1], p[j]);
-            uint32_t any_e = 0;
-            int first = C - 1;
-#pragma unroll
-            for (int j = C - 1; j >= 0; --j) {
-                any_e |= e[j];
-                first = e[j] ? j : first;
-            }
-            float head = s[C - 1];
-#pragma unroll
-            for (int j = C - 2; j >= 0; --j) head = e[j] ? s[j] : head;
-            const float tail = e[C - 1] ? 0.0f : s[C - 1];
-
-            // ---- cross-lane segmented inclusive scan of the tails (Kogge-Stone clipped at row ends) ------
-            const uint64_t H = __ballot(any_e != 0u);
-            const uint64_t le_mask = (lane == 63u) ? ~0ull : ((2ull << lane) - 1ull);
-            const uint64_t hb = H & le_mask;
-            const int dist = (int)lane - (hb ? (63 - __builtin_clzll(hb)) : 0);
-            float vv = tail;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const float up = __shfl_up(vv, d);
-                vv = (dist >= d) ? __fadd_rn(vv, up) : vv;
-            }
-            const float prev = __shfl_up(vv, 1);
-            const float cin = (lane == 0) ? 0.0f : prev;
-            const float S = __fadd_rn(cin, head);
-            carry = __shfl(vv, 63);
-
-            // ---- finished rows of this lane ------------------------------------------------------------------
-            float rs[C];
-#pragma unroll
-            for (int j = 0; j < C; ++j) rs[j] = (j == first) ? S : s[j];
+            const RowSums<C> R = reduce_packet<C>(cur, lane, carry, x_lds);
 
             if (SCORES) {
-                uint32_t below = 0;
+                uint32_t r = rb_cur + ends_below<C>(R);
 #pragma unroll
                 for (int j = 0; j < C; ++j) {
-                    const uint64_t b = __ballot(e[j] != 0u);
-                    below += __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
-                }
-                uint32_t r = rb_cur + below;
-#pragma unroll
-                for (int j = 0; j < C; ++j) {
-                    if (e[j]) {
-                        if (!skip[j]) P.scores[r] = rs[j];
+                    if (R.end(j)) {
+                        if (R.valid(j)) P.scores[r] = R.rs[j];
                         ++r;
                     }
                 }
             } else {
-                const float tau = __uint_as_float(*reinterpret_cast<volatile uint32_t *>(&misc[MISC_TAU]));
-                float best = -__builtin_huge_valf();
+                const float best = lane_best<C>(R);
+                if (i < (uint32_t)DEFER && P.n_sets != 0u) {
+                    // Cold start of the threshold exchange: keep the sums in registers, only feed the maxima.
 #pragma unroll
-                for (int j = 0; j < C; ++j) best = (e[j] && !skip[j] && rs[j] > best) ? rs[j] : best;
-                if (__any(best >= tau)) {
-                    // Slow path (rare once tau has converged): row ids, group maximum, candidate append.
-                    uint32_t below = 0;
-#pragma unroll
-                    for (int j = 0; j < C; ++j) {
-                        const uint64_t b = __ballot(e[j] != 0u);
-                        below +=
-                            __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
-                    }
-                    uint32_t r = rb_cur + below;
-#pragma unroll
-                    for (int j = 0; j < C; ++j) {
-                        if (e[j]) {
-                            if (!skip[j] && rs[j] >= tau) {
-                                const uint32_t key = order_key(rs[j]);
-                                if (publishes) {
-                                    const uint32_t old = atomicMax(&misc[MISC_GRPMAX + grp_local], key);
-                                    if (key > old)
-                                        __hip_atomic_fetch_max(&P.gmax[grp_global], key, __ATOMIC_RELAXED,
-                                                               __HIP_MEMORY_SCOPE_AGENT);
-                                }
-                                const uint32_t pos = atomicAdd(&misc[MISC_CAND_CNT], 1u);
-                                if (pos < P.cand_cap) {
-                                    cand[pos] = make_uint2(__float_as_uint(rs[j]), r);
-                                } else {
-                                    const uint32_t gp = atomicAdd(P.ovf_count, 1u);
-                                    if (gp < P.ovf_cap) P.ovf_cand[gp] = make_uint2(__float_as_uint(rs[j]), r);
-                                }
-                            }
-                            ++r;
+                    for (int d = 0; d < DEFER; ++d) {
+                        if (i == (uint32_t)d) {
+                            st[d] = R;
+                            st_rb[d] = rb_cur;
                         }
                     }
+                    const float wmax = wave_max(best);
+                    if (lane == 0 && publishes && wmax >= P.min_score)
+                        (void)__hip_atomic_fetch_max(&misc[MISC_GRPMAX + grp_local], order_key(wmax), __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_WORKGROUP);
+                } else if (__any(best >= tau) && !(P.dbg_flags & 2u)) {
+                    offer_candidates<C>(P, R, rb_cur, tau, best, lane, grp_local, publishes, cand, misc);
                 }
             }
-            cur = nxt;
-            rb_cur = rb_nxt;
+            }
+        }
+        if (!SCORES && P.n_sets != 0u) {
+            // The deferred packets, against the threshold as it stands now.
+            const float tau =
+                __uint_as_float(__hip_atomic_load(&misc[MISC_TAU], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+#pragma unroll
+            for (int d = 0; d < DEFER; ++d) {
+                const float best = lane_best<C>(st[d]);
+                if (np > (uint32_t)d && __any(best >= tau))
+                    offer_candidates<C>(P, st[d], st_rb[d], tau, best, lane, grp_local, publishes, cand, misc);
+            }
         }
     }
 
     if (SCORES) return;
+    if (!is_server && lane == 0) atomicAdd(&misc[MISC_DONE], 1u);
+    if (P.dbg_flags & 8u) return;
 
     // ---- flush: keep what still clears the (now much tighter) threshold --------------------------------------
     __syncthreads();
-    if (wave == 0 && P.n_sets != 0u) {
-        float t = refresh_tau(P, lane);
-        if (lane == 0) misc[MISC_TAU] = __float_as_uint(t);
-    }
-    __syncthreads();
+    // Last publication of this workgroup's maxima (fire and forget): the select stage derives its own, exact
+    // threshold from the complete set, so no final refresh is needed here.
+    if (is_server && P.n_sets != 0u) publish_group_max(P, lane, misc);
     const float tau = __uint_as_float(misc[MISC_TAU]);
     const uint32_t n = misc[MISC_CAND_CNT] < P.cand_cap ? misc[MISC_CAND_CNT] : P.cand_cap;
-    uint2 *out = P.wg_cand + (size_t)blockIdx.x * P.cand_cap;
+    // pass 1: count survivors
+    uint32_t mine = 0;
+    for (uint32_t i = tid; i < n; i += blockDim.x) mine += (__uint_as_float(cand[i].x) >= tau);
+    if (mine) atomicAdd(&misc[MISC_FLUSH_CNT], mine);
+    __syncthreads();
+    const uint32_t surv = misc[MISC_FLUSH_CNT];
+    if (tid == 0) {
+        uint32_t ob = 0;
+        if (surv > WG_SLOTS) ob = atomicAdd(P.ovf_count, surv - WG_SLOTS);
+        misc[MISC_OVF_BASE] = ob;
+    }
+    __syncthreads();
+    // pass 2: the first WG_SLOTS survivors go to this workgroup's fixed slots, the rest to the shared overflow list
+    const uint32_t ovf_base = misc[MISC_OVF_BASE];
+    uint2 *out = P.wg_cand + (size_t)blockIdx.x * WG_SLOTS;
     for (uint32_t i = tid; i < n; i += blockDim.x) {
         const uint2 c = cand[i];
         if (__uint_as_float(c.x) >= tau) {
-            const uint32_t pos = atomicAdd(&misc[MISC_FLUSH_CNT], 1u);
-            out[pos] = c;
+            const uint32_t pos = atomicAdd(&misc[MISC_FLUSH_POS], 1u);
+            if (pos < WG_SLOTS) {
+                out[pos] = c;
+            } else {
+                const uint32_t gp = ovf_base + (pos - WG_SLOTS);
+                if (gp < P.ovf_cap) P.ovf_cand[gp] = c;
+            }
         }
     }
-    __syncthreads();
-    if (tid == 0) P.wg_count[blockIdx.x] = misc[MISC_FLUSH_CNT];
+    if (tid < WG_SLOTS && tid >= surv) out[tid] = make_uint2(0u, SLOT_INVALID);
 }
 
 // ------------------------------------------------------------------------------------------------------------
 // Final exact selection over the surviving candidates (single workgroup).
 // ------------------------------------------------------------------------------------------------------------
 struct SelectParams {
-    const uint2 *wg_cand;
-    const uint32_t *wg_count;
-    uint32_t n_wg, cand_cap;
+    const uint2 *wg_cand;  // [n_wg][WG_SLOTS]
+    uint32_t n_wg;
     const uint2 *ovf_cand;
     uint32_t *ovf_count;
     uint32_t ovf_cap;
@@ -304,83 +543,103 @@ struct SelectParams {
     uint32_t *out_idx;
     float *out_val;
     uint32_t *gmax;
+    uint32_t *tau_g;
     uint32_t n_groups_pub;
-    unsigned long long *scratch;  // [n_wg*cand_cap + ovf_cap] composite keys (general path)
+    uint32_t use_gmax;  // n_sets != 0 and n_groups_pub >= k
+    unsigned long long *scratch;  // [n_wg*WG_SLOTS + ovf_cap] composite keys (general path)
     unsigned long long *stats;    // [0] += candidates, [1] += queries, [2] = max candidates, [3] += general-path runs
 };
 
 constexpr uint32_t SEL_THREADS = 1024;
 constexpr uint32_t SEL_CAP = 4096;
+constexpr uint32_t SEL_PER_THREAD = 8;  // slot entries held in registers per thread => n_wg*WG_SLOTS <= 8192
 
 __device__ __forceinline__ unsigned long long make_ckey(uint2 c) {
     return ((unsigned long long)order_key(__uint_as_float(c.x)) << 32) | (unsigned long long)c.y;
 }
 
 __global__ void __launch_bounds__(SEL_THREADS) select_kernel(const SelectParams P) {
-    __shared__ unsigned long long keys[SEL_CAP];
-    __shared__ uint32_t wsum[SEL_THREADS / 64];
-    __shared__ uint32_t sh_cnt;
-    __shared__ uint32_t sh_total;
-    __shared__ uint32_t sh_total_wg;
+    __shared__ __attribute__((aligned(16))) unsigned long long keys[SEL_CAP + 8];
+    __shared__ uint32_t sh_cnt, sh_total, sh_thr;
 
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t n_slots = P.n_wg * WG_SLOTS;
 
-    // Exclusive prefix sum of the per-workgroup candidate counts (n_wg <= SEL_THREADS * stride handled below).
-    // Each thread owns the workgroups tid, tid + SEL_THREADS, ...
-    uint32_t mycnt = 0;
-    for (uint32_t g = tid; g < P.n_wg; g += SEL_THREADS) {
-        uint32_t c = P.wg_count[g];
-        mycnt += c < P.cand_cap ? c : P.cand_cap;
-    }
-    uint32_t incl = mycnt;
+    // One round trip: every thread loads its slots, the overflow count and (wave 0) the group maxima blindly.
+    uint2 mine[SEL_PER_THREAD];
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t up = (uint32_t)__shfl_up((int)incl, d);
-        if ((int)lane >= d) incl += up;
+    for (uint32_t u = 0; u < SEL_PER_THREAD; ++u) {
+        const uint32_t f = tid + u * SEL_THREADS;
+        mine[u] = make_uint2(0u, SLOT_INVALID);
+        if (f < n_slots) mine[u] = P.wg_cand[f];
     }
-    if (lane == 63) wsum[wave] = incl;
-    __syncthreads();
+    uint32_t gk[MAX_GM];
+#pragma unroll
+    for (int i = 0; i < MAX_GM; ++i) {
+        const uint32_t sidx = lane + 64u * i;
+        gk[i] = 0u;
+        if (tid < 64 && P.use_gmax && sidx < P.n_groups_pub) gk[i] = P.gmax[sidx];
+    }
+    uint32_t novf = *P.ovf_count;
+    novf = novf < P.ovf_cap ? novf : P.ovf_cap;
     if (tid == 0) {
-        uint32_t run = 0;
-        for (uint32_t w = 0; w < SEL_THREADS / 64; ++w) {
-            uint32_t t = wsum[w];
-            wsum[w] = run;
-            run += t;
-        }
-        uint32_t novf = *P.ovf_count;
-        novf = novf < P.ovf_cap ? novf : P.ovf_cap;
-        sh_total = run + novf;
         sh_cnt = 0;
+        sh_total = 0;
+        sh_thr = 0;
     }
     __syncthreads();
-    const uint32_t my_off = wsum[wave] + incl - mycnt;
-    const uint32_t total = sh_total;
-    if (tid == SEL_THREADS - 1) sh_total_wg = my_off + mycnt;
-    __syncthreads();
-    const uint32_t total_wg = sh_total_wg;
-    const uint32_t n_ovf = total - total_wg;
-
-    const bool small = total <= SEL_CAP;
-    unsigned long long *dst = small ? keys : P.scratch;
-
-    // Gather composite keys.
-    {
-        uint32_t o = my_off;
-        for (uint32_t g = tid; g < P.n_wg; g += SEL_THREADS) {
-            uint32_t c = P.wg_count[g];
-            c = c < P.cand_cap ? c : P.cand_cap;
-            const uint2 *src = P.wg_cand + (size_t)g * P.cand_cap;
-            for (uint32_t i = 0; i < c; ++i) dst[o + i] = make_ckey(src[i]);
-            o += c;
+    // Exact k-th largest of the group maxima (bisection on the order keys, wave 0): the maxima are scores of k
+    // distinct rows, so it is a valid lower bound of the k-th best score, and a tight one; it prunes the
+    // candidates that were appended while the running threshold was still converging.
+    if (tid < 64 && P.use_gmax) {
+        uint32_t prefix = 0u;
+        for (int bit = 31; bit >= 0; --bit) {
+            const uint32_t trial = prefix | (1u << bit);
+            uint32_t c = 0;
+#pragma unroll
+            for (int i = 0; i < MAX_GM; ++i) c += (uint32_t)__popcll(__ballot(gk[i] >= trial));
+            if (c >= P.k) prefix = trial;
         }
-        for (uint32_t i = tid; i < n_ovf; i += SEL_THREADS) dst[total_wg + i] = make_ckey(P.ovf_cand[i]);
+        if (lane == 0) sh_thr = prefix;
     }
     __syncthreads();
+    const uint32_t thr = sh_thr;  // order key; 0 keeps everything
+    uint32_t spos[SEL_PER_THREAD];
+    uint32_t wtot = 0;
+#pragma unroll
+    for (uint32_t u = 0; u < SEL_PER_THREAD; ++u) {
+        const bool ok = (mine[u].y != SLOT_INVALID) && (order_key(__uint_as_float(mine[u].x)) >= thr);
+        if (!ok) mine[u].y = SLOT_INVALID;
+        const uint64_t bm = __ballot(ok);
+        spos[u] = wtot + __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
+        wtot += (uint32_t)__popcll(bm);
+    }
+    uint32_t wbase = 0;
+    if (lane == 0 && wtot) wbase = atomicAdd(&sh_total, wtot);
+    wbase = __builtin_amdgcn_readfirstlane(wbase);
+    __syncthreads();
+    const uint32_t n_from_slots = sh_total;
+    const uint32_t total = n_from_slots + novf;
+    const bool small = total <= SEL_CAP;
+    uint32_t n_sel;
 
-    uint32_t n_sel = total;  // number of keys to rank, resident in `keys`
-    if (!small) {
-        // General path: bisection for the k-th largest composite key, then compaction into LDS.
-        __threadfence_block();
+    if (small) {
+#pragma unroll
+        for (uint32_t u = 0; u < SEL_PER_THREAD; ++u) {
+            if (mine[u].y != SLOT_INVALID) keys[wbase + spos[u]] = make_ckey(mine[u]);
+        }
+        for (uint32_t i = tid; i < novf; i += SEL_THREADS) keys[n_from_slots + i] = make_ckey(P.ovf_cand[i]);
+        __syncthreads();
+        n_sel = total;
+    } else {
+        // General path (threshold exchange disabled or not converged): all keys to global scratch, bisection for
+        // the k-th largest composite key, then compaction of the keys >= it into LDS.
+#pragma unroll
+        for (uint32_t u = 0; u < SEL_PER_THREAD; ++u) {
+            if (mine[u].y != SLOT_INVALID) P.scratch[novf + wbase + spos[u]] = make_ckey(mine[u]);
+        }
+        for (uint32_t i = tid; i < novf; i += SEL_THREADS) P.scratch[i] = make_ckey(P.ovf_cand[i]);
+        __syncthreads();
         unsigned long long prefix = 0ull;
         if (total > P.k) {
             for (int bit = 63; bit >= 0; --bit) {
@@ -402,20 +661,25 @@ __global__ void __launch_bounds__(SEL_THREADS) select_kernel(const SelectParams 
         for (uint32_t i = tid; i < total; i += SEL_THREADS) {
             const unsigned long long kx = P.scratch[i];
             if (kx >= prefix) {
-                uint32_t pos = atomicAdd(&sh_cnt, 1u);
+                const uint32_t pos = atomicAdd(&sh_cnt, 1u);
                 if (pos < SEL_CAP) keys[pos] = kx;
             }
         }
         __syncthreads();
         n_sel = sh_cnt < SEL_CAP ? sh_cnt : SEL_CAP;
-        __syncthreads();
     }
+    if (tid < 8) keys[n_sel + tid] = 0ull;  // padding for the unrolled rank loop (0 is below every real key)
+    __syncthreads();
 
     // Rank by counting: keys are unique (distinct rows), rank r = number of larger keys.
+    const uint32_t n_pad = (n_sel + 7u) & ~7u;
     for (uint32_t i = tid; i < n_sel; i += SEL_THREADS) {
         const unsigned long long kx = keys[i];
         uint32_t r = 0;
-        for (uint32_t j = 0; j < n_sel; ++j) r += (keys[j] > kx);
+        for (uint32_t j = 0; j < n_pad; j += 8) {
+#pragma unroll
+            for (uint32_t u = 0; u < 8; ++u) r += (keys[j + u] > kx);
+        }
         if (r < P.k) {
             P.out_idx[r] = (uint32_t)(kx & 0xFFFFFFFFull) + P.first_row;
             P.out_val[r] = key_to_float((uint32_t)(kx >> 32));
@@ -430,6 +694,7 @@ __global__ void __launch_bounds__(SEL_THREADS) select_kernel(const SelectParams 
     for (uint32_t i = tid; i < P.n_groups_pub; i += SEL_THREADS) P.gmax[i] = 0u;
     if (tid == 0) {
         *P.ovf_count = 0u;
+        *P.tau_g = 0u;
         P.stats[0] += total;
         P.stats[1] += 1ull;
         if (total > P.stats[2]) P.stats[2] = total;
@@ -461,12 +726,15 @@ struct EngineImpl {
     uint32_t *d_pkt_row = nullptr, *d_part_first = nullptr, *d_part_count = nullptr;
     float *d_x = nullptr;
     const float *d_x_cur = nullptr;
+    uint32_t *d_tau_g = nullptr;
     uint32_t *d_gmax = nullptr, *d_wg_count = nullptr, *d_ovf_count = nullptr, *d_out_idx = nullptr;
     uint2 *d_wg_cand = nullptr, *d_ovf = nullptr;
     float *d_out_val = nullptr, *d_scores = nullptr;
     unsigned long long *d_scratch = nullptr, *d_stats = nullptr;
     uint32_t grid = 0, block = 0, gpw = 1, n_sets = 0, n_groups_pub = 0, cand_cap = 0, ovf_cap = 0, lds_bytes = 0,
              x_lds_bytes = 0;
+    bool collect_stats = false;
+    uint32_t dbg_flags = 0;
     bool have_query = false;
     bool ran = false;
 
@@ -486,21 +754,22 @@ struct EngineImpl {
         P.gpw = gpw;
         P.min_score = desc.min_score;
         P.gmax = d_gmax;
+        P.tau_g = d_tau_g;
+        P.n_reducers = grid < 8u ? grid : 8u;
         P.wg_cand = d_wg_cand;
-        P.wg_count = d_wg_count;
         P.cand_cap = cand_cap;
         P.ovf_cand = d_ovf;
         P.ovf_count = d_ovf_count;
         P.ovf_cap = ovf_cap;
         P.scores = d_scores;
+        P.dbg = collect_stats ? d_stats + 4 : nullptr;
+        P.dbg_flags = dbg_flags;
         return P;
     }
     SelectParams select_params(uint32_t *out_idx, float *out_val) const {
         SelectParams S{};
         S.wg_cand = d_wg_cand;
-        S.wg_count = d_wg_count;
         S.n_wg = grid;
-        S.cand_cap = cand_cap;
         S.ovf_cand = d_ovf;
         S.ovf_count = d_ovf_count;
         S.ovf_cap = ovf_cap;
@@ -509,7 +778,9 @@ struct EngineImpl {
         S.out_idx = out_idx;
         S.out_val = out_val;
         S.gmax = d_gmax;
+        S.tau_g = d_tau_g;
         S.n_groups_pub = n_groups_pub;
+        S.use_gmax = (n_sets != 0u && n_groups_pub >= (uint32_t)desc.k) ? 1u : 0u;
         S.scratch = d_scratch;
         S.stats = d_stats;
         return S;
@@ -517,9 +788,9 @@ struct EngineImpl {
     void launch_stream(const float *x, hipStream_t s) const {
         StreamParams P = stream_params(x);
         if (info.packet_entries == 256)
-            hipLaunchKernelGGL((stream_kernel<4, false>), dim3(grid), dim3(block), lds_bytes, s, P);
+            hipLaunchKernelGGL((stream_kernel<4, false>), dim3(grid), dim3(block + 64), lds_bytes, s, P);
         else
-            hipLaunchKernelGGL((stream_kernel<8, false>), dim3(grid), dim3(block), lds_bytes, s, P);
+            hipLaunchKernelGGL((stream_kernel<8, false>), dim3(grid), dim3(block + 64), lds_bytes, s, P);
     }
     void launch_select(uint32_t *out_idx, float *out_val, hipStream_t s) const {
         SelectParams S = select_params(out_idx, out_val);
@@ -572,7 +843,7 @@ Engine::~Engine() {
     if (m.stream) (void)hipStreamSynchronize(m.stream);
     void *bufs[] = {m.d_packets,  m.d_pkt_row, m.d_part_first, m.d_part_count, m.d_x,       m.d_gmax,   m.d_wg_count,
                     m.d_ovf_count, m.d_out_idx, m.d_wg_cand,    m.d_ovf,        m.d_out_val, m.d_scores, m.d_scratch,
-                    m.d_stats};
+                    m.d_stats,     m.d_tau_g};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (m.ev0) (void)hipEventDestroy(m.ev0);
@@ -620,13 +891,17 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err) {
     m.desc.row = m.desc.col = nullptr;
     m.desc.val = nullptr;
     m.block = d.threads_per_wg > 0 ? (uint32_t)d.threads_per_wg : 512u;
-    if (m.block % 64 || m.block > 1024) {
-        err = "threads_per_wg must be a multiple of 64, at most 1024";
+    if (m.block % 64 || m.block > 512 || m.block < 64) {
+        err = "threads_per_wg must be a multiple of 64, at most 512";
         return TKSPMV_ERR_INVALID;
     }
     const uint32_t waves_per_cu = d.waves_per_cu > 0 ? (uint32_t)d.waves_per_cu : 16u;
-    const uint32_t waves_per_wg = m.block / 64;
+    const uint32_t waves_per_wg = m.block / 64;  // streaming waves; one more wave per workgroup serves the exchange
     m.grid = std::max(1u, num_cus * waves_per_cu / waves_per_wg);
+    if ((uint64_t)m.grid * WG_SLOTS > (uint64_t)SEL_PER_THREAD * SEL_THREADS) {
+        err = "launch geometry too large: waves_per_cu * num_cus / waves_per_wg must be <= 1024 workgroups";
+        return TKSPMV_ERR_INVALID;
+    }
     const uint32_t C = d.nnz_per_lane > 0 ? (uint32_t)d.nnz_per_lane : 4u;
 
     int kind = 0;
@@ -641,17 +916,18 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err) {
     // Threshold-exchange geometry: n_sets = next_pow2(k) sets over a power-of-two number of publishing groups.
     m.n_sets = next_pow2((uint32_t)d.k);
     m.gpw = 1;
-    while (floor_pow2(m.grid * m.gpw) < m.n_sets && m.gpw < waves_per_wg && (waves_per_wg % (m.gpw * 2) == 0))
+    while (floor_pow2(m.grid * m.gpw) < m.n_sets && m.gpw < 8 && m.gpw < waves_per_wg &&
+           (waves_per_wg % (m.gpw * 2) == 0))
         m.gpw *= 2;
     m.n_groups_pub = floor_pow2(m.grid * m.gpw);
     if (m.n_groups_pub < m.n_sets) {
         m.n_sets = 0;  // cannot form k disjoint sets: exchange disabled, every row >= min_score is a candidate
         m.n_groups_pub = 1;
     }
-    m.cand_cap = 1024;
+    m.cand_cap = CAND_CAP;
     m.ovf_cap = std::max<uint32_t>(d.rows, 1u);
     m.x_lds_bytes = ((d.cols * 4u + 15u) / 16u) * 16u;
-    m.lds_bytes = m.x_lds_bytes + m.cand_cap * 8u + (MISC_GRPMAX + m.gpw) * 4u + 16u;
+    m.lds_bytes = m.x_lds_bytes;  // dynamic part only (x); candidate list, misc and staging are static
 
     HIP_TRY(hipStreamCreateWithFlags(&m.stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&m.ev0));
@@ -676,19 +952,24 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err) {
     std::vector<uint32_t>().swap(m.pm.pkt_row);
 
     HIP_TRY(hipMalloc((void **)&m.d_x, (size_t)d.cols * 4));
-    HIP_TRY(hipMalloc((void **)&m.d_gmax, (size_t)m.n_groups_pub * 4));
+    HIP_TRY(hipMalloc((void **)&m.d_gmax, (size_t)MAX_GM * 64 * 4));
     HIP_TRY(hipMalloc((void **)&m.d_wg_count, (size_t)m.grid * 4));
     HIP_TRY(hipMalloc((void **)&m.d_ovf_count, 4));
-    HIP_TRY(hipMalloc((void **)&m.d_wg_cand, (size_t)m.grid * m.cand_cap * 8));
+    HIP_TRY(hipMalloc((void **)&m.d_wg_cand, (size_t)m.grid * WG_SLOTS * 8));
+    HIP_TRY(hipMemset(m.d_wg_cand, 0xFF, (size_t)m.grid * WG_SLOTS * 8));
     HIP_TRY(hipMalloc((void **)&m.d_ovf, (size_t)m.ovf_cap * 8));
     HIP_TRY(hipMalloc((void **)&m.d_out_idx, (size_t)d.k * 4));
     HIP_TRY(hipMalloc((void **)&m.d_out_val, (size_t)d.k * 4));
-    HIP_TRY(hipMalloc((void **)&m.d_scratch, ((size_t)m.grid * m.cand_cap + m.ovf_cap) * 8));
-    HIP_TRY(hipMalloc((void **)&m.d_stats, 4 * 8));
-    HIP_TRY(hipMemset(m.d_gmax, 0, (size_t)m.n_groups_pub * 4));
+    HIP_TRY(hipMalloc((void **)&m.d_scratch, ((size_t)m.grid * WG_SLOTS + m.ovf_cap) * 8));
+    HIP_TRY(hipMalloc((void **)&m.d_stats, 8 * 8));
+    m.collect_stats = getenv("TKSPMV_STATS") != nullptr;
+    if (const char *f = getenv("TKSPMV_DBG_FLAGS")) m.dbg_flags = (uint32_t)atoi(f);
+    HIP_TRY(hipMemset(m.d_gmax, 0, (size_t)MAX_GM * 64 * 4));
+    HIP_TRY(hipMalloc((void **)&m.d_tau_g, 256));
+    HIP_TRY(hipMemset(m.d_tau_g, 0, 256));
     HIP_TRY(hipMemset(m.d_wg_count, 0, (size_t)m.grid * 4));
     HIP_TRY(hipMemset(m.d_ovf_count, 0, 4));
-    HIP_TRY(hipMemset(m.d_stats, 0, 4 * 8));
+    HIP_TRY(hipMemset(m.d_stats, 0, 8 * 8));
     HIP_TRY(hipMemset(m.d_out_idx, 0, (size_t)d.k * 4));
     HIP_TRY(hipMemset(m.d_out_val, 0, (size_t)d.k * 4));
 
@@ -828,9 +1109,9 @@ int Engine::scores(float *host_y, std::string &err) {
     HIP_TRY(hipMemsetAsync(m.d_scores, 0, std::max<size_t>(m.desc.rows, 1) * 4, m.stream));
     StreamParams P = m.stream_params(m.d_x_cur);
     if (m.info.packet_entries == 256)
-        hipLaunchKernelGGL((stream_kernel<4, true>), dim3(m.grid), dim3(m.block), m.lds_bytes, m.stream, P);
+        hipLaunchKernelGGL((stream_kernel<4, true>), dim3(m.grid), dim3(m.block + 64), m.lds_bytes, m.stream, P);
     else
-        hipLaunchKernelGGL((stream_kernel<8, true>), dim3(m.grid), dim3(m.block), m.lds_bytes, m.stream, P);
+        hipLaunchKernelGGL((stream_kernel<8, true>), dim3(m.grid), dim3(m.block + 64), m.lds_bytes, m.stream, P);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(host_y, m.d_scores, (size_t)m.desc.rows * 4, hipMemcpyDeviceToHost, m.stream));
     HIP_TRY(hipStreamSynchronize(m.stream));
@@ -846,7 +1127,7 @@ int Engine::profile(const float *dev_xs, int32_t n_x, int32_t iters, tkspmv_timi
     std::memset(out, 0, sizeof(*out));
     HIP_TRY(hipSetDevice(m.device));
     HIP_TRY(hipStreamSynchronize(m.stream));
-    unsigned long long st0[4], st1[4];
+    unsigned long long st0[8], st1[8];
     HIP_TRY(hipMemcpy(st0, m.d_stats, sizeof(st0), hipMemcpyDeviceToHost));
     const size_t stride = m.desc.cols;
     // (1) whole queries back-to-back
@@ -863,6 +1144,8 @@ int Engine::profile(const float *dev_xs, int32_t n_x, int32_t iters, tkspmv_timi
     out->query_ns = (double)ms * 1e6 / iters;
     HIP_TRY(hipMemcpy(st1, m.d_stats, sizeof(st1), hipMemcpyDeviceToHost));
     out->candidates_avg = (double)(st1[0] - st0[0]) / (double)std::max<unsigned long long>(1, st1[1] - st0[1]);
+    out->slow_paths_avg = (double)(st1[4] - st0[4]) / (double)std::max<unsigned long long>(1, st1[1] - st0[1]);
+    out->appended_avg = (double)(st1[5] - st0[5]) / (double)std::max<unsigned long long>(1, st1[1] - st0[1]);
     // (2) per-kernel: events around each kernel of each query
     double t_stream = 0, t_select = 0;
     for (int i = 0; i < iters; ++i) {
@@ -878,6 +1161,23 @@ int Engine::profile(const float *dev_xs, int32_t n_x, int32_t iters, tkspmv_timi
         HIP_TRY(hipEventElapsedTime(&b, m.ev1, m.ev2));
         t_stream += a;
         t_select += b;
+    }
+    // (3) SpMV-only variant (hw_spmv_only_time of the reference's GPU host): full y written, no top-k
+    {
+        if (!m.d_scores) HIP_TRY(hipMalloc((void **)&m.d_scores, std::max<size_t>(m.desc.rows, 1) * 4));
+        HIP_TRY(hipEventRecord(m.ev0, m.stream));
+        for (int i = 0; i < iters; ++i) {
+            StreamParams P = m.stream_params(dev_xs + (size_t)(i % n_x) * stride);
+            if (m.info.packet_entries == 256)
+                hipLaunchKernelGGL((stream_kernel<4, true>), dim3(m.grid), dim3(m.block + 64), m.lds_bytes, m.stream, P);
+            else
+                hipLaunchKernelGGL((stream_kernel<8, true>), dim3(m.grid), dim3(m.block + 64), m.lds_bytes, m.stream, P);
+        }
+        HIP_TRY(hipEventRecord(m.ev1, m.stream));
+        HIP_TRY(hipEventSynchronize(m.ev1));
+        float ms2 = 0;
+        HIP_TRY(hipEventElapsedTime(&ms2, m.ev0, m.ev1));
+        out->scores_kernel_ns = (double)ms2 * 1e6 / iters;
     }
     out->stream_kernel_ns = t_stream * 1e6 / iters;
     out->select_kernel_ns = t_select * 1e6 / iters;

@@ -106,8 +106,11 @@ typedef struct {
     double select_kernel_ns;   /* average device time of the final candidate-select kernel */
     double query_ns;           /* average device time per query, back-to-back enqueue (all kernels) */
     double candidates_avg;     /* average number of candidates reaching the select stage */
+    double scores_kernel_ns;   /* average device time of the SpMV-only variant (writes the full y; no top-k) */
+    double slow_paths_avg;     /* TKSPMV_STATS=1: wave-packets per query that took the candidate path */
+    double appended_avg;       /* TKSPMV_STATS=1: rows per query appended to the in-LDS candidate lists */
     uint32_t n_queries;
-    uint32_t reserved[5];
+    uint32_t reserved[3];
 } tkspmv_timing;
 
 /* ---- engine ------------------------------------------------------------------------------- */

@@ -239,10 +239,27 @@ void oracle_packed_scores(const uint8_t *packets, uint64_t packet_bytes, const u
                 dist[l] = l - m;
                 vv[l] = tail[l];
             }
-            for (int d = 1; d < 64; d <<= 1) {
-                for (int l = 0; l < 64; l++) nv[l] = (dist[l] >= d) ? (vv[l] + vv[l - d]) : vv[l];
+            /* Kogge-Stone inside each row of 16 lanes (DPP row_shr:1,2,4,8; lanes without a source add 0) */
+            for (int d = 1; d < 16; d <<= 1) {
+                for (int l = 0; l < 64; l++) {
+                    float up = ((l & 15) >= d) ? vv[l - d] : 0.0f;
+                    nv[l] = (dist[l] >= d) ? (vv[l] + up) : vv[l];
+                }
                 memcpy(vv, nv, sizeof(vv));
             }
+            /* row_bcast:15 (row_mask 0xA): lane 15 -> row 1, lane 47 -> row 3 */
+            for (int l = 0; l < 64; l++) {
+                int row = l >> 4;
+                float up = (row == 1 || row == 3) ? vv[row * 16 - 1] : 0.0f;
+                nv[l] = (dist[l] > (l & 15)) ? (vv[l] + up) : vv[l];
+            }
+            memcpy(vv, nv, sizeof(vv));
+            /* row_bcast:31 (row_mask 0xC): lane 31 -> rows 2 and 3 */
+            for (int l = 0; l < 64; l++) {
+                float up = (l >= 32) ? vv[31] : 0.0f;
+                nv[l] = (dist[l] > (l & 31)) ? (vv[l] + up) : vv[l];
+            }
+            memcpy(vv, nv, sizeof(vv));
             uint32_t r = pkt_row[pidx];
             for (int l = 0; l < 64; l++) {
                 float cin = (l == 0) ? 0.0f : vv[l - 1];
