@@ -723,6 +723,8 @@ struct EngineImpl {
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
     // device buffers
     uint8_t *d_packets = nullptr;
+    std::vector<uint8_t *> d_replicas;  // extra copies of the packet stream (cache-defeat mode)
+    mutable uint64_t launch_counter = 0;
     uint32_t *d_pkt_row = nullptr, *d_part_first = nullptr, *d_part_count = nullptr;
     float *d_x = nullptr;
     const float *d_x_cur = nullptr;
@@ -740,7 +742,7 @@ struct EngineImpl {
 
     StreamParams stream_params(const float *x) const {
         StreamParams P{};
-        P.packets = d_packets;
+        P.packets = d_replicas.empty() ? d_packets : d_replicas[launch_counter % d_replicas.size()];
         P.pkt_row = d_pkt_row;
         P.part_first = d_part_first;
         P.part_count = d_part_count;
@@ -787,6 +789,7 @@ struct EngineImpl {
     }
     void launch_stream(const float *x, hipStream_t s) const {
         StreamParams P = stream_params(x);
+        ++launch_counter;
         if (info.packet_entries == 256)
             hipLaunchKernelGGL((stream_kernel<4, false>), dim3(grid), dim3(block + 64), lds_bytes, s, P);
         else
@@ -846,6 +849,7 @@ Engine::~Engine() {
                     m.d_stats,     m.d_tau_g};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
+    for (size_t r = 1; r < m.d_replicas.size(); ++r) (void)hipFree(m.d_replicas[r]);
     if (m.ev0) (void)hipEventDestroy(m.ev0);
     if (m.ev1) (void)hipEventDestroy(m.ev1);
     if (m.ev2) (void)hipEventDestroy(m.ev2);
@@ -947,6 +951,15 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err) {
         HIP_TRY(hipMemcpy(m.d_part_first, m.pm.part_first.data(), m.pm.part_first.size() * 4, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(m.d_part_count, m.pm.part_count.data(), m.pm.part_count.size() * 4, hipMemcpyHostToDevice));
     }
+    if (d.stream_replicas > 1 && m.pm.stream_bytes()) {
+        m.d_replicas.push_back(m.d_packets);
+        for (int r = 1; r < d.stream_replicas; ++r) {
+            uint8_t *p = nullptr;
+            HIP_TRY(hipMalloc((void **)&p, stream_bytes));
+            HIP_TRY(hipMemcpy(p, m.d_packets, m.pm.stream_bytes(), hipMemcpyDeviceToDevice));
+            m.d_replicas.push_back(p);
+        }
+    }
     // The packed stream now lives in HBM; drop the host copy.
     std::vector<uint8_t>().swap(m.pm.packets);
     std::vector<uint32_t>().swap(m.pm.pkt_row);
@@ -1047,6 +1060,23 @@ int Engine::enqueue(const float *dev_x, uint32_t *dev_idx, float *dev_val, void 
     HIP_TRY(hipSetDevice(m.device));
     m.launch_stream(x, s);
     m.launch_select(dev_idx ? dev_idx : m.d_out_idx, dev_val ? dev_val : m.d_out_val, s);
+    HIP_TRY(hipGetLastError());
+    m.ran = true;
+    return TKSPMV_OK;
+}
+
+int Engine::enqueue_many(const float *dev_xs, int32_t n_x, int32_t count, void *stream, std::string &err) {
+    EngineImpl &m = *impl_;
+    if (!dev_xs || n_x < 1 || count < 0) {
+        err = "bad arguments to enqueue_many";
+        return TKSPMV_ERR_INVALID;
+    }
+    hipStream_t s = stream ? (hipStream_t)stream : m.stream;
+    HIP_TRY(hipSetDevice(m.device));
+    for (int i = 0; i < count; ++i) {
+        m.launch_stream(dev_xs + (size_t)(i % n_x) * m.desc.cols, s);
+        m.launch_select(m.d_out_idx, m.d_out_val, s);
+    }
     HIP_TRY(hipGetLastError());
     m.ran = true;
     return TKSPMV_OK;

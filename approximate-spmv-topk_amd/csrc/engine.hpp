@@ -23,6 +23,7 @@ class Engine {
     int set_query_device(const float *dev_x, std::string &err);
     int run(double *kernel_ns, std::string &err);
     int enqueue(const float *dev_x, uint32_t *dev_idx, float *dev_val, void *stream, std::string &err);
+    int enqueue_many(const float *dev_xs, int32_t n_x, int32_t count, void *stream, std::string &err);
     int synchronize(std::string &err);
     int read(uint32_t *idx, float *val, int32_t *n, std::string &err);
     int result_device(const uint32_t **dev_idx, const float **dev_val);

@@ -50,6 +50,12 @@ std::string pack_wbscsr(uint32_t rows, uint32_t cols, uint64_t nnz, const uint32
     out.packet_bytes = out.packet_entries * (value_bytes(precision) + 2);
 
     // Row lengths over [0, last_row]; validates ordering and ranges.
+    for (uint64_t i = 1; i < nnz; ++i) {
+        if (row[i] < row[i - 1]) {
+            kind = 2;
+            return "COO rows are not sorted in non-decreasing order";
+        }
+    }
     uint32_t last_row = 0;
     if (nnz > 0) {
         last_row = row[nnz - 1];
@@ -57,14 +63,8 @@ std::string pack_wbscsr(uint32_t rows, uint32_t cols, uint64_t nnz, const uint32
     }
     std::vector<uint32_t> len(nnz ? (size_t)last_row + 1 : 0, 0u);
     for (uint64_t i = 0; i < nnz; ++i) {
-        uint32_t r = row[i];
-        if (i > 0 && r < row[i - 1]) {
-            kind = 2;
-            return "COO rows are not sorted in non-decreasing order";
-        }
-        if (r > last_row) return "row id out of range";
         if (col[i] >= cols) return "column id out of range (>= cols)";
-        ++len[r];
+        ++len[row[i]];
     }
     uint64_t placeholders = 0;
     for (uint32_t L : len) placeholders += (L == 0);

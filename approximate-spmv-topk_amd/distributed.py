@@ -1,0 +1,104 @@
+"""Row-sharded Top-K SpMV over several GPUs (one process per GPU, torch.distributed; backend "nccl" is RCCL on ROCm).
+
+The reference is single-device; its only scaling axis is the row partitioning of the matrix (32 partitions -> HBM
+channels, host_spmv_bscsr.cpp:133-141) with a host-side merge of the per-partition candidates
+(host_spmv_bscsr.cpp:399-448). Here the same idea is applied one level up:
+
+  * rows are split into contiguous shards balanced by nnz; every rank owns one engine over its shard and returns
+    GLOBAL row ids (desc.first_row, cf. `local + first_row` at host_spmv_bscsr.cpp:415);
+  * the query x (<= 64 KiB) is replicated;
+  * ONE exchange step per query: an all-gather of k (row, score) pairs per rank (800 B at k=100) over xGMI;
+  * the final merge of world*k candidates keeps the sort_tuples order (score desc, row desc).
+    Each shard returns its full local top-k, so the union contains the global top-k (exactness, cf. topk_errors.py).
+
+The merge is written against plain tensors so the same code runs on CPU with gloo in the tests.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds_by_nnz(row, rows, world):
+    """Contiguous row ranges [r0, r1) per rank with ~equal nnz. `row` is the sorted COO row array."""
+    row = np.asarray(row)
+    nnz = row.shape[0]
+    bounds = [0]
+    for r in range(1, world):
+        target = (nnz * r) // world
+        if nnz == 0:
+            bounds.append((rows * r) // world)
+            continue
+        cut_row = int(row[min(target, nnz - 1)])  # the row containing the target nnz starts the next shard
+        cut_row = max(cut_row, bounds[-1])
+        bounds.append(min(cut_row, rows))
+    bounds.append(rows)
+    return [(bounds[i], bounds[i + 1]) for i in range(world)]
+
+
+def shard_coo(row, col, val, r0, r1):
+    """Entries of rows [r0, r1), with local row ids."""
+    row = np.asarray(row)
+    lo = int(np.searchsorted(row, r0, side="left"))
+    hi = int(np.searchsorted(row, r1, side="left"))
+    return (row[lo:hi] - np.uint32(r0)).astype(np.uint32), np.asarray(col)[lo:hi], np.asarray(val)[lo:hi]
+
+
+def _order_key(val_f32):
+    """Monotone map float32 -> int64 in [0, 2^32): larger score <=> larger key (same map as the kernels)."""
+    u = val_f32.contiguous().view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+    neg = (u & 0x80000000) != 0
+    return torch.where(neg, (~u) & 0xFFFFFFFF, u | 0x80000000)
+
+
+def merge_candidates(idx_i64, val_f32, k):
+    """Top-k of the gathered candidates in sort_tuples order (score desc, row desc). Filler entries (0, 0.0)
+    produced by shards with fewer than k qualifying rows sort last among equal scores and are kept only if needed.
+    idx_i64: int64 [n] global row ids, val_f32: float32 [n]."""
+    key = (_order_key(val_f32) << 32) | (idx_i64 & 0xFFFFFFFF)
+    # de-duplicate fillers: several shards may contribute (0, 0.0); a real row id appears in one shard only
+    key_sorted, order = torch.sort(key, descending=True)
+    keep = torch.ones_like(key_sorted, dtype=torch.bool)
+    keep[1:] = key_sorted[1:] != key_sorted[:-1]
+    order = order[keep][:k]
+    out_idx = idx_i64[order]
+    out_val = val_f32[order]
+    if out_idx.shape[0] < k:  # pad like the gold's zero-initialised list
+        pad = k - out_idx.shape[0]
+        out_idx = torch.cat([out_idx, torch.zeros(pad, dtype=out_idx.dtype, device=out_idx.device)])
+        out_val = torch.cat([out_val, torch.zeros(pad, dtype=out_val.dtype, device=out_val.device)])
+    return out_idx, out_val
+
+
+class ShardedTopK:
+    """Exchange + merge step. `local_idx` / `local_val` are this rank's k results (global row ids)."""
+
+    def __init__(self, k, device, group=None):
+        self.k = k
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.device = device
+        # one packed buffer per rank: [k] int32 row ids followed by [k] float32 scores viewed as int32
+        self.local = torch.zeros(2 * k, dtype=torch.int32, device=device)
+        self.gathered = torch.zeros(self.world * 2 * k, dtype=torch.int32, device=device)
+
+    def local_views(self):
+        """(idx_view int32[k], val_view float32[k]) into the send buffer; engines write their results here."""
+        return self.local[: self.k], self.local[self.k:].view(torch.float32)
+
+    def exchange(self):
+        """The one collective of the path: all-gather of k pairs per rank."""
+        if self.world == 1:
+            self.gathered.copy_(self.local)
+        else:
+            dist.all_gather_into_tensor(self.gathered, self.local, group=self.group)
+        return self.gathered
+
+    def merge(self):
+        g = self.gathered.view(self.world, 2, self.k)
+        idx = (g[:, 0, :].reshape(-1).to(torch.int64)) & 0xFFFFFFFF
+        val = g[:, 1, :].reshape(-1).view(torch.float32)
+        return merge_candidates(idx, val, self.k)
+
+    def step(self):
+        self.exchange()
+        return self.merge()

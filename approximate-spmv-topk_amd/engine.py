@@ -18,7 +18,7 @@ from . import _lib
 class SpMV:
     def __init__(self, x, y, val, num_rows, num_cols, num_nnz=None, vec=None, k=20, debug=0, *, device=-1,
                  first_row=0, min_score=0.0, partitions=1, k_per_partition=0, precision=_lib.F32, waves_per_cu=0,
-                 threads_per_wg=0, nnz_per_lane=0):
+                 threads_per_wg=0, nnz_per_lane=0, stream_replicas=0):
         """x, y, val: row-sorted COO (row ids, column ids, values) as the FPGA host passes them
         (host_spmv_bscsr.cpp:585); val=None means all ones (-v)."""
         self._h = C.c_void_p()
@@ -34,6 +34,7 @@ class SpMV:
         d.k, d.partitions, d.k_per_partition, d.precision = int(k), int(partitions), int(k_per_partition), precision
         d.device, d.first_row, d.min_score = int(device), int(first_row), float(min_score)
         d.waves_per_cu, d.threads_per_wg, d.nnz_per_lane = int(waves_per_cu), int(threads_per_wg), int(nnz_per_lane)
+        d.stream_replicas = int(stream_replicas)
         _lib.check(_lib.lib().tkspmv_create(C.byref(self._h), C.byref(d)))
         self.k = int(k)
         self.num_rows, self.num_cols, self.num_nnz = int(num_rows), int(num_cols), nnz
@@ -72,6 +73,11 @@ class SpMV:
         """Asynchronous launch of one query on `stream` (raw hipStream_t handle; 0 = engine stream)."""
         _lib.check(_lib.lib().tkspmv_enqueue(self._h, C.c_void_p(int(dev_x)), C.c_void_p(int(dev_idx)),
                                              C.c_void_p(int(dev_val)), C.c_void_p(int(stream))))
+
+    def enqueue_many(self, dev_xs, n_x, count, stream=0):
+        """`count` queries back to back from a device array of n_x query vectors (no host sync)."""
+        _lib.check(_lib.lib().tkspmv_enqueue_many(self._h, C.c_void_p(int(dev_xs)), int(n_x), int(count),
+                                                  C.c_void_p(int(stream))))
 
     def synchronize(self):
         _lib.check(_lib.lib().tkspmv_synchronize(self._h))

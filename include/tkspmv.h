@@ -80,7 +80,9 @@ typedef struct {
     int32_t waves_per_cu;
     int32_t threads_per_wg;
     int32_t nnz_per_lane;     /* 4 or 8 entries per lane per packet */
-    int32_t reserved[5];
+    int32_t stream_replicas;  /* measurement aid: keep R copies of the packet stream in HBM and rotate them per query so
+                                 that consecutive queries cannot be served from the 256 MiB Infinity Cache; 0/1 = off */
+    int32_t reserved[4];
 } tkspmv_desc;
 
 typedef struct {
@@ -128,6 +130,8 @@ int tkspmv_run(tkspmv_t *e, double *kernel_ns);
 /* Enqueue one query on `stream` (hipStream_t cast to void*; NULL => engine stream), no host sync.
  * dev_idx/dev_val: optional device output buffers of k entries (NULL => engine-owned result buffers). */
 int tkspmv_enqueue(tkspmv_t *e, const float *dev_x, uint32_t *dev_idx, float *dev_val, void *stream);
+/* Enqueue `count` queries back to back (query i uses dev_xs + (i % n_x) * cols), no host sync. */
+int tkspmv_enqueue_many(tkspmv_t *e, const float *dev_xs, int32_t n_x, int32_t count, void *stream);
 int tkspmv_synchronize(tkspmv_t *e);
 
 /* Copy back the k results of the last completed query, sorted by (score desc, row desc)

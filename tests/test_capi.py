@@ -1,0 +1,82 @@
+"""The C-ABI shared library: loads, exports every symbol include/tkspmv.h declares, and fails loudly (no CPU
+fallback) when there is no GPU. No compute calls here."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "tkspmv.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(tkspmv_[a-z_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    lib = pkg._lib.lib()
+    declared = _declared_symbols()
+    assert len(declared) >= 25
+    for sym in declared:
+        assert hasattr(lib, sym), f"{sym} is declared in include/tkspmv.h but not exported"
+    assert sorted(pkg._lib.EXPORTED_SYMBOLS) == declared
+
+
+def test_struct_layouts_match_header(pkg):
+    """Sizes the C compiler sees for the ABI structs == the ctypes mirrors."""
+    src = r'''
+    #include <stdio.h>
+    #include "tkspmv.h"
+    int main(void) { printf("%zu %zu %zu %zu %zu\n", sizeof(tkspmv_desc), sizeof(tkspmv_info), sizeof(tkspmv_timing),
+                            sizeof(tkspmv_coo), sizeof(tkspmv_options)); return 0; }
+    '''
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.c"), "w").write(src)
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")])
+        out = subprocess.check_output([os.path.join(d, "t")]).decode().split()
+    L = pkg._lib
+    assert [int(x) for x in out] == [C.sizeof(L.Desc), C.sizeof(L.Info), C.sizeof(L.Timing), C.sizeof(L.Coo),
+                                    C.sizeof(L.OptionsC)]
+
+
+def test_no_gpu_means_loud_failure_not_fallback(pkg):
+    if pkg.device_count() > 0:
+        pytest.skip("a GPU is present")
+    m = pkg.generate_matrix(100, 32, 5, "uniform", 1)
+    with pytest.raises(pkg.TkspmvError) as e:
+        pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, k=8)
+    assert e.value.status == pkg._lib.ERR_DEVICE
+    assert "no CPU fallback" in e.value.message
+
+
+def test_argument_validation_before_device(pkg):
+    """Descriptor errors are reported with ERR_INVALID / ERR_UNSUPPORTED regardless of the device."""
+    m = pkg.generate_matrix(50, 16, 4, "uniform", 2)
+    for kw, status in ((dict(k=0), pkg._lib.ERR_INVALID), (dict(k=2000), pkg._lib.ERR_INVALID),
+                       (dict(k=8, precision=pkg.Q1_7), pkg._lib.ERR_UNSUPPORTED),
+                       (dict(k=8, partitions=32), pkg._lib.ERR_UNSUPPORTED)):
+        with pytest.raises(pkg.TkspmvError) as e:
+            pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, **kw)
+        assert e.value.status == status, kw
+
+
+def test_executable_reports_errors_like_the_reference(pkg, tmp_path):
+    exe = os.path.join(ROOT, "bin", "approximate-spmv-mi355x-topk")
+    assert os.path.exists(exe), "run make"
+    r = subprocess.run([exe, "-m", str(tmp_path / "nope.mtx")], capture_output=True, text=True)
+    assert r.returncode == 1 and "not found" in r.stderr  # utils.hpp:486-490
+    bad = tmp_path / "bad.mtx"
+    bad.write_text("garbage\n")
+    r = subprocess.run([exe, "-m", str(bad)], capture_output=True, text=True)
+    assert r.returncode == 1 and "Could not process Matrix Market banner" in r.stdout  # utils.hpp:493-496
+    if pkg.device_count() == 0:
+        g = pkg.generate_matrix(200, 64, 6, "gamma", 1)
+        p = tmp_path / "ok.mtx"
+        pkg.write_mtx(str(p), g, index_base=1)
+        r = subprocess.run([exe, "-m", str(p), "-k", "8", "-t", "1"], capture_output=True, text=True)
+        assert r.returncode == 1 and "no HIP device" in r.stderr

@@ -1,0 +1,261 @@
+"""GPU tests of the engine boundary beyond plain parity: the reference's golden vectors through the HIP path, edge
+cases (empty rows, k > rows, single row, rows longer than a packet, k = 1024, wide x), size-independent properties at
+the full BASELINE size, the drop-in executable's CSV, and the asynchronous/device-pointer entry points."""
+import glob
+import json
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+CASE_FILES = sorted(p for p in glob.glob(os.path.join(GOLD, "gold_*.npz")) if re.search(r"_\d+x\d+\.npz$", p))
+RTOL = 1e-4
+
+
+def _expected(pkg, oracle, m, x, k, eng, min_score=0.0, first_row=0):
+    info = eng.info()
+    C = info["packet_entries"] // 64
+    packed = pkg.Packed(m, k=k, nnz_per_lane=C, n_wave_partitions=info["grid"] * info["block"] // 64)
+    assert packed.info()["n_wave_partitions"] == info["n_wave_partitions"]
+    yp, present = oracle.packed_scores(packed.raw(), x, m.rows, C)
+    return oracle.select_topk(yp, present, k, min_score, first_row)
+
+
+@pytest.mark.parametrize("path", CASE_FILES, ids=[os.path.basename(p) for p in CASE_FILES])
+def test_reference_golden_vectors_through_the_gpu(pkg, oracle, path):
+    z = np.load(path)
+    cases = json.loads(bytes(z["cases"]).decode())
+    m = pkg.CooMatrix(int(z["rows"]), int(z["cols"]), z["row"], z["col"], z["val"])
+    for c in cases:
+        t, k = c["tag"], c["k"]
+        x = z[f"x_{t}"]
+        eng = pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, vec=x, k=k, device=0)
+        eng()
+        val, idx = eng.read_result()
+        ei, ev = _expected(pkg, oracle, m, x, k, eng)
+        assert np.array_equal(idx, ei) and np.array_equal(val.view(np.uint32), ev.view(np.uint32))
+        gi, gv = z[f"idx_{t}"], z[f"val_{t}"]
+        if np.all(gv > 0) and len(np.unique(gv)) == k:  # full list of distinct positive scores: the north-star bar
+            assert set(idx.tolist()) == set(gi.tolist())
+            assert np.allclose(val, gv, rtol=RTOL, atol=0)
+        else:  # fillers / zero scores: same positive part, (0, 0.0) padding behind it
+            npos = int((gv > 0).sum())
+            assert set(idx[:npos].tolist()) == set(gi[:npos].tolist())
+            assert np.allclose(val[:npos], gv[:npos], rtol=RTOL, atol=0)
+            assert np.all(val[npos:] == 0)
+        eng.close()
+
+
+def _coo(pkg, rows, cols, lens, seed=0, neg=False):
+    rng = np.random.RandomState(seed)
+    r, c, v = [], [], []
+    for i, n in enumerate(lens):
+        cs = np.sort(rng.randint(0, cols, n))
+        vs = rng.rand(n).astype(np.float32) - (0.5 if neg else 0.0)
+        r += [i] * n
+        c += cs.tolist()
+        v += vs.tolist()
+    return pkg.CooMatrix(rows, cols, np.array(r, np.uint32), np.array(c, np.uint32), np.array(v, np.float32))
+
+
+@pytest.mark.parametrize("name,lens,cols,k", [
+    ("empty_rows", [3, 0, 0, 5, 1, 0, 7, 2, 0, 0, 0, 4] * 40, 64, 20),
+    ("single_row", [9], 32, 4),
+    ("single_entry", [1], 8, 1),
+    ("k_gt_rows", [2, 3, 4], 16, 50),
+    ("long_rows", [1100, 1, 300, 2, 257, 256, 255, 1, 1, 700], 1024, 5),
+    ("one_nnz_rows", [1] * 3000, 128, 100),
+    ("k_1024", [6] * 5000, 256, 1024),
+    ("wide_x", [30] * 2000, 16384, 64),
+    ("trailing_empty", [4, 4, 4, 0, 0, 0], 16, 3),
+])
+def test_edge_cases(pkg, oracle, name, lens, cols, k):
+    m = _coo(pkg, len(lens) + (3 if name == "trailing_empty" else 0), cols, lens, seed=len(lens))
+    x = pkg.create_sample_vector(cols, True, False, True, 77)
+    eng = pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, vec=x, k=k, device=0)
+    eng()
+    val, idx = eng.read_result()
+    ei, ev = _expected(pkg, oracle, m, x, k, eng)
+    assert np.array_equal(idx, ei), name
+    assert np.array_equal(val.view(np.uint32), ev.view(np.uint32)), name
+    # against the gold: the rows with a positive score agree (set), scores within tolerance
+    gi, gv = oracle.gold_topk(m.row, m.col, m.val, x, k)
+    npos = int((gv > 0).sum())
+    assert set(idx[:npos].tolist()) == set(gi[:npos].tolist())
+    assert np.allclose(val[:npos], gv[:npos], rtol=RTOL, atol=0)
+    y = eng.scores()
+    ys, present = oracle.scores_f32_seq(m.row, m.col, m.val, x, m.rows)
+    assert np.allclose(y[present.astype(bool)], ys[present.astype(bool)], rtol=RTOL, atol=1e-30)
+    assert np.all(y[~present.astype(bool)] == 0)
+    eng.close()
+
+
+def test_negative_scores_and_min_score(pkg, oracle):
+    """General (signed) matrices: rows scoring below min_score never come back (gold: initial worst = 0)."""
+    m = _coo(pkg, 4000, 128, [8] * 4000, seed=3, neg=True)
+    x = pkg.create_sample_vector(128, True, False, True, 9)
+    for min_score in (0.0, -1e30, 0.05):
+        eng = pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, vec=x, k=100, device=0, min_score=min_score)
+        eng()
+        val, idx = eng.read_result()
+        ei, ev = _expected(pkg, oracle, m, x, 100, eng, min_score=min_score)
+        assert np.array_equal(idx, ei) and np.array_equal(val.view(np.uint32), ev.view(np.uint32))
+        eng.close()
+    gi, gv = oracle.gold_topk(m.row, m.col, m.val, x, 100)
+    eng = pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, vec=x, k=100, device=0)
+    eng()
+    val, idx = eng.read_result()
+    assert set(idx.tolist()) == set(gi.tolist()) and np.allclose(val, gv, rtol=RTOL, atol=0)
+    eng.close()
+
+
+def test_ignore_matrix_values(pkg, oracle):
+    m = pkg.generate_matrix(5000, 256, 10, "uniform", 12)
+    x = pkg.create_sample_vector(256, True, False, True, 2)
+    eng = pkg.SpMV(m.row, m.col, None, m.rows, m.cols, vec=x, k=16, device=0)  # -v: all ones
+    eng()
+    val, idx = eng.read_result()
+    ones = np.ones_like(m.val)
+    gi, gv = oracle.gold_topk(m.row, m.col, ones, x, 16)
+    assert set(idx.tolist()) == set(gi.tolist()) and np.allclose(val, gv, rtol=RTOL, atol=0)
+    eng.close()
+
+
+@pytest.fixture(scope="module")
+def big(pkg):
+    m = pkg.generate_matrix(1000000, 1024, 20, "gamma", 2)  # BASELINE configs[1]
+    eng = pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, k=100, device=0)
+    yield m, eng
+    eng.close()
+
+
+def test_full_size_parity_and_properties(pkg, oracle, big):
+    m, eng = big
+    x = pkg.create_sample_vector(1024, True, False, True, 4242)
+    eng.reset(x)
+    eng()
+    val, idx = eng.read_result()
+    # (1) the gold itself at full size (19.5M nnz takes the oracle well under a second)
+    gi, gv = oracle.gold_topk(m.row, m.col, m.val, x, 100)
+    y64, present = oracle.scores_f64(m.row, m.col, m.val, x, m.rows)
+    if set(idx.tolist()) != set(gi.tolist()):
+        kth = np.sort(y64)[-100]
+        for r in set(idx.tolist()) ^ set(gi.tolist()):
+            assert abs(y64[r] - kth) <= 2e-6 * kth, "only k-th boundary near-ties may differ"
+    assert np.allclose(np.sort(val), np.sort(gv), rtol=RTOL, atol=0)
+    # (2) sortedness + uniqueness + every returned score is that row's score
+    assert np.all(val[:-1] >= val[1:]) and len(set(idx.tolist())) == 100
+    assert np.allclose(val, y64[idx], rtol=RTOL, atol=0)
+    # (3) nothing outside the list beats the list (checksum of the whole score vector through the SpMV-only kernel)
+    y = eng.scores()
+    assert np.allclose(y, y64, rtol=RTOL, atol=1e-12)
+    rest = np.ones(m.rows, dtype=bool)
+    rest[idx] = False
+    assert y[rest].max() <= val[-1]
+    # (4) idempotence and scale equivariance: same x twice -> identical bits; 2x -> same rows, doubled scores
+    eng()
+    val2, idx2 = eng.read_result()
+    assert np.array_equal(idx, idx2) and np.array_equal(val.view(np.uint32), val2.view(np.uint32))
+    eng.reset(2.0 * x)
+    eng()
+    val3, idx3 = eng.read_result()
+    assert np.array_equal(idx3, idx) and np.array_equal(val3, 2.0 * val)
+    # (5) bit-exact against the order-matched oracle at full size
+    ei, ev = _expected(pkg, oracle, m, x, 100, eng)
+    assert np.array_equal(idx, ei) and np.array_equal(val.view(np.uint32), ev.view(np.uint32))
+
+
+def test_k8_is_the_32_partition_result(pkg, oracle, big):
+    """BASELINE configs[2]: 32 row partitions with K=8 lists each, query K=8. The union of the per-partition top-8
+    contains the global top-8, so the partitioned model and the exact engine must agree."""
+    m, _ = big
+    x = pkg.create_sample_vector(1024, True, False, True, 99)
+    eng = pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, vec=x, k=8, device=0)
+    eng()
+    val, idx = eng.read_result()
+    y, present = oracle.scores_f32_seq(m.row, m.col, m.val, x, m.rows)
+    per = (m.rows + 31) // 32  # host_spmv_bscsr.cpp:136
+    cand_i, cand_v = [], []
+    for p in range(32):
+        a, b = p * per, min((p + 1) * per, m.rows)
+        pi, pv = oracle.select_topk(y[a:b], present[a:b], 8, 0.0, first_row=a)
+        cand_i += pi.tolist()
+        cand_v += pv.tolist()
+    order = np.lexsort((-np.array(cand_i, np.int64), -np.array(cand_v, np.float64)))[:8]
+    assert set(idx.tolist()) == set(np.array(cand_i)[order].tolist())
+    assert np.allclose(val, np.array(cand_v, np.float32)[order], rtol=RTOL, atol=0)
+    eng.close()
+
+
+def test_device_pointers_async_and_replicas(pkg, oracle):
+    import torch
+    m = pkg.generate_matrix(60000, 1024, 20, "gamma", 8)
+    xs = np.stack([pkg.create_sample_vector(1024, True, False, True, 500 + i) for i in range(5)])
+    dxs = torch.from_numpy(xs).cuda()
+    out_i = torch.zeros(5, 100, dtype=torch.int32, device="cuda")
+    out_v = torch.zeros(5, 100, dtype=torch.float32, device="cuda")
+    eng = pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, k=100, device=0, stream_replicas=3)
+    stream = torch.cuda.current_stream().cuda_stream
+    for q in range(5):  # caller-owned device buffers, caller's stream, no host sync in between
+        eng.enqueue(dxs[q].data_ptr(), out_i[q].data_ptr(), out_v[q].data_ptr(), stream)
+    torch.cuda.synchronize()
+    for q in range(5):
+        gi, gv = oracle.gold_topk(m.row, m.col, m.val, xs[q], 100)
+        assert set(out_i[q].cpu().numpy().astype(np.uint32).tolist()) == set(gi.tolist())
+        assert np.allclose(out_v[q].cpu().numpy(), gv, rtol=RTOL, atol=0)
+    t = eng.profile(dxs.data_ptr(), 5, 20)
+    assert t["stream_kernel_ns"] > 0 and t["query_ns"] > 0 and 100 <= t["candidates_avg"] < 20000
+    eng.reset_device(dxs[2].data_ptr())
+    eng()
+    val, idx = eng.read_result()
+    assert np.array_equal(idx.astype(np.int64), out_i[2].cpu().numpy().astype(np.int64) & 0xFFFFFFFF)
+    # first_row offsets the returned ids (row-sharded use)
+    eng2 = pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, vec=xs[2], k=100, device=0, first_row=123456)
+    eng2()
+    val2, idx2 = eng2.read_result()
+    assert np.array_equal(idx2, idx + 123456) and np.array_equal(val2, val)
+    eng.close()
+    eng2.close()
+
+
+def test_run_before_query_is_an_error(pkg):
+    m = pkg.generate_matrix(100, 32, 4, "uniform", 1)
+    eng = pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, k=4, device=0)
+    with pytest.raises(pkg.TkspmvError) as e:
+        eng()
+    assert e.value.status == pkg._lib.ERR_STATE
+    eng.close()
+
+
+def test_drop_in_executable_csv(pkg, oracle, tmp_path):
+    """The call site of test_spmv_topk.py:63,79-82: same flags, GPU-host CSV schema, zero errors against its gold."""
+    exe = os.path.join(ROOT, "bin", "approximate-spmv-mi355x-topk")
+    g = pkg.generate_matrix(10000, 1024, 20, "gamma", 1)  # BASELINE configs[0] shape, generator output format
+    p = tmp_path / "matrix_10000_1024_20_gamma.mtx"
+    pkg.write_mtx(str(p), g, index_base=1)
+    env = dict(os.environ, TKSPMV_SEED="5")
+    r = subprocess.run([exe, "-t", "4", "-m", str(p), "-k", "100", "-i", "0", "-r"], capture_output=True, text=True,
+                       env=env, timeout=300)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.strip().split("\n")
+    assert lines[0] == ("iteration,error_idx,error_val,sw_full_time_ms,sw_topk_time_ms,hw_setup_time_ms,"
+                        "hw_spmv_only_time_ms,hw_exec_time_ms,readback_time_ms,k,sw_res_idx,sw_res_val,hw_res_idx,"
+                        "hw_res_val")
+    assert len(lines) == 5
+    for i, ln in enumerate(lines[1:]):
+        f = ln.split(",")
+        assert len(f) == 14 and int(f[0]) == i and int(f[9]) == 100
+        sw_idx, hw_idx = f[10].split(";"), f[12].split(";")
+        assert len(sw_idx) == 100 and len(hw_idx) == 100
+        assert set(sw_idx) == set(hw_idx)            # same top-k index set as the CPU gold
+        assert int(f[2]) == 0                        # error_val: |diff| <= 1e-5 everywhere
+        assert np.allclose(np.array(f[11].split(";"), float), np.array(f[13].split(";"), float), rtol=1e-4, atol=1e-6)
+    # -d prints the verbose form and still exits 0
+    r = subprocess.run([exe, "-d", "-t", "1", "-m", str(p), "-k", "8"], capture_output=True, text=True, env=env,
+                       timeout=300)
+    assert r.returncode == 0 and "hw results=" in r.stdout and "precision=1" in r.stdout
