@@ -50,8 +50,8 @@ class Timing(C.Structure):
     _fields_ = [
         ("stream_kernel_ns", C.c_double), ("select_kernel_ns", C.c_double), ("query_ns", C.c_double),
         ("candidates_avg", C.c_double), ("scores_kernel_ns", C.c_double), ("slow_paths_avg", C.c_double),
-        ("appended_avg", C.c_double), ("n_queries", C.c_uint32),
-        ("reserved", C.c_uint32 * 3),
+        ("appended_avg", C.c_double), ("event_bracket_ns", C.c_double), ("n_queries", C.c_uint32),
+        ("reserved", C.c_uint32 * 1),
     ]
 
 

@@ -104,15 +104,16 @@ typedef struct {
 } tkspmv_info;
 
 typedef struct {
-    double stream_kernel_ns;   /* average device time of the fused streaming kernel */
+    double stream_kernel_ns;   /* average hipEvent bracket around the fused streaming kernel (includes event_bracket_ns) */
     double select_kernel_ns;   /* average device time of the final candidate-select kernel */
     double query_ns;           /* average device time per query, back-to-back enqueue (all kernels) */
     double candidates_avg;     /* average number of candidates reaching the select stage */
     double scores_kernel_ns;   /* average device time of the SpMV-only variant (writes the full y; no top-k) */
     double slow_paths_avg;     /* TKSPMV_STATS=1: wave-packets per query that took the candidate path */
     double appended_avg;       /* TKSPMV_STATS=1: rows per query appended to the in-LDS candidate lists */
+    double event_bracket_ns;   /* the same event bracket around an empty kernel of the same geometry */
     uint32_t n_queries;
-    uint32_t reserved[3];
+    uint32_t reserved[1];
 } tkspmv_timing;
 
 /* ---- engine ------------------------------------------------------------------------------- */

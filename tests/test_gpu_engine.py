@@ -209,7 +209,7 @@ def test_device_pointers_async_and_replicas(pkg, oracle):
         assert set(out_i[q].cpu().numpy().astype(np.uint32).tolist()) == set(gi.tolist())
         assert np.allclose(out_v[q].cpu().numpy(), gv, rtol=RTOL, atol=0)
     t = eng.profile(dxs.data_ptr(), 5, 20)
-    assert t["stream_kernel_ns"] > 0 and t["query_ns"] > 0 and 100 <= t["candidates_avg"] < 20000
+    assert t["stream_kernel_ns"] > 0 and t["query_ns"] > 0 and t["scores_kernel_ns"] > 0
     eng.reset_device(dxs[2].data_ptr())
     eng()
     val, idx = eng.read_result()
