@@ -49,7 +49,7 @@ struct StreamParams {
     const uint32_t *part_first;
     const uint32_t *part_count;
     const float *x;
-    uint32_t n_parts, cols, x_lds_bytes, packet_bytes;
+    uint32_t n_parts, cols, packet_bytes;
     uint32_t n_sets;        // 0 => threshold exchange disabled
     uint32_t n_groups_pub;  // power of two, groups [0, n_groups_pub) publish maxima
     uint32_t gpw;           // groups per workgroup
@@ -119,7 +119,7 @@ struct SelectParams {
 
 constexpr int MAX_GM = 16;  // n_groups_pub <= 1024 => at most 16 published maxima per lane
 constexpr uint32_t SEL_THREADS = 1024;
-constexpr uint32_t SEL_CAP = 4096;
+constexpr uint32_t SEL_CAP = 2048;
 constexpr uint32_t SEL_PER_THREAD = 8;  // slot entries held in registers per thread
 
 struct SelectShared {
@@ -397,88 +397,135 @@ __device__ __forceinline__ void publish_group_max(const StreamParams &P, uint32_
 // ------------------------------------------------------------------------------------------------------------
 // The fused streaming kernel
 // ------------------------------------------------------------------------------------------------------------
-// Finished-row sums of one packet as seen by one lane. flags: bit j = ROW_END of entry j, bit 8+j = SKIP.
+// ---- single-instruction helpers ---------------------------------------------------------------------------------
+// hipcc turns mask arithmetic back into v_cmp + v_cndmask (+ s_nop hazards); these keep it at one VALU op each.
+// All are plain VGPR -> VGPR VALU operations (no hazard besides the DPP one noted at `tail` below).
+template <int BIT>
+__device__ __forceinline__ uint32_t bit_mask(uint32_t w) {  // all ones iff bit BIT of w is set
+    uint32_t r;
+    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(r) : "v"(w), "n"(BIT));
+    return r;
+}
+__device__ __forceinline__ float mask_select(uint32_t m, float if_set, float if_clear) {  // bitwise m ? a : b
+    float r;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(m), "v"(if_set), "v"(if_clear));
+    return r;
+}
+__device__ __forceinline__ float mask_clear(uint32_t m, float a) {  // a where m is clear, +0.0 where set
+    float r;
+    asm("v_bfi_b32 %0, %1, 0, %2" : "=v"(r) : "v"(m), "v"(a));
+    return r;
+}
+__device__ __forceinline__ float max3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+// Finished-row sums of one packet as seen by one lane. The flags stay where they are, in the packet's column
+// words: entry j -> word j/2, bits 16*(j&1) (ROW_END) and 16*(j&1)+1 (SKIP).
 template <int C>
 struct RowSums {
     float rs[C];
-    uint32_t flags;
-    __device__ __forceinline__ bool end(int j) const { return (flags >> j) & 1u; }
-    __device__ __forceinline__ bool valid(int j) const { return ((flags >> j) & 0x101u) == 1u; }  // end and not skip
+    uint32_t cw[C / 2];
+    float best_any;  // max over the lane's row ends, placeholders included: only the hot-path trigger uses it
+    __device__ __forceinline__ bool end(int j) const { return (cw[j >> 1] >> (16 * (j & 1))) & 1u; }
+    __device__ __forceinline__ bool valid(int j) const { return ((cw[j >> 1] >> (16 * (j & 1))) & 3u) == 1u; }
 };
 
 // Products, in-lane segmented sums, cross-lane segmented scan. Updates the packet carry.
+// Arithmetic (mirrored statement for statement by oracle_packed_scores in oracle/oracle.c):
+//   p_j = v_j * x[col_j];  p_0 += carry on lane 0;  s_0 = p_0,  s_j = (end_{j-1} ? +0 : s_{j-1}) + p_j
+//   tail = end_{C-1} ? +0 : s_{C-1};   head = s at the lane's first row end
+//   vv = clipped Kogge-Stone scan of tail over the 64 lanes (never across a lane that holds a row end)
+//   row sum at the lane's first row end = vv[lane-1] + head, at its later row ends = s_j; carry' = vv[63]
 template <int C>
-__device__ __forceinline__ RowSums<C> reduce_packet(const Pkt<C> &cur, uint32_t lane, float &carry, const float *x_lds) {
+__device__ __forceinline__ RowSums<C> reduce_packet(const Pkt<C> &cur, float &carry, const float *x_lds) {
     float p[C];
-    uint32_t e[C];
-    uint32_t flags = 0;
+    uint32_t m[C];  // all-ones where entry j ends a row
 #pragma unroll
     for (int j = 0; j < C; ++j) {
-        const uint32_t w = (j & 1) ? (cur.cw[j >> 1] >> 16) : (cur.cw[j >> 1] & 0xFFFFu);
-        const float xv =
-            *reinterpret_cast<const float *>(reinterpret_cast<const unsigned char *>(x_lds) + (w & 0xFFFCu));
+        const uint32_t word = cur.cw[j >> 1];
+        const uint32_t off = (j & 1) ? ((word >> 16) & 0xFFFCu) : (word & 0xFFFCu);  // byte offset of x[col]
+        const float xv = *reinterpret_cast<const float *>(reinterpret_cast<const unsigned char *>(x_lds) + off);
         p[j] = __fmul_rn(cur.v[j], xv);
-        e[j] = w & 1u;
-        flags |= (w & 1u) << j;
-        flags |= ((w >> 1) & 1u) << (8 + j);
+        m[j] = (j & 1) ? bit_mask<16>(word) : bit_mask<0>(word);
     }
-    p[0] = __fadd_rn(p[0], lane == 0 ? carry : 0.0f);
+    p[0] = __builtin_amdgcn_inverse_ballot_w64(1ull) ? __fadd_rn(p[0], carry) : p[0];  // lane 0 only
 
-    // in-lane segmented sums
     float s[C];
+    uint32_t o[C];  // o_j = m_0 | ... | m_j
     s[0] = p[0];
+    o[0] = m[0];
 #pragma unroll
-    for (int j = 1; j < C; ++j) s[j] = __fadd_rn(e[j - 1] ? 0.0f : s[j - 1], p[j]);
-    uint32_t any_e = 0;
-    int first = C - 1;
-#pragma unroll
-    for (int j = C - 1; j >= 0; --j) {
-        any_e |= e[j];
-        first = e[j] ? j : first;
+    for (int j = 1; j < C; ++j) {
+        s[j] = __fadd_rn(mask_clear(m[j - 1], s[j - 1]), p[j]);
+        o[j] = o[j - 1] | m[j];
     }
     float head = s[C - 1];
 #pragma unroll
-    for (int j = C - 2; j >= 0; --j) head = e[j] ? s[j] : head;
-    const float tail = e[C - 1] ? 0.0f : s[C - 1];
+    for (int j = C - 2; j >= 0; --j) head = mask_select(m[j], s[j], head);
+    float tail;
+    // (the DPP instruction that reads `tail` next needs two wait states after a VALU write; the compiler does
+    //  not look inside asm, hence the explicit s_nop)
+    asm("v_bfi_b32 %0, %1, 0, %2\n\ts_nop 1" : "=v"(tail) : "v"(m[C - 1]), "v"(s[C - 1]));
 
-    // Cross-lane segmented inclusive scan of the tails.
-    // dist = lanes back to the nearest lane (<= this one) that holds a row end; lane id if there is none.
-    // Kogge-Stone inside each row of 16 lanes (DPP row_shr), then the row totals travel with
-    // row_bcast:15 / row_bcast:31; every add is clipped by dist so sums never cross a row end.
-    const uint64_t H = __ballot(any_e != 0u);
-    const uint64_t le_mask = (lane == 63u) ? ~0ull : ((2ull << lane) - 1ull);
-    const uint64_t hb = H & le_mask;
-    const int dist = (int)lane - (hb ? (63 - __builtin_clzll(hb)) : 0);
-    const int l16 = (int)(lane & 15u), l32 = (int)(lane & 31u);
+    // Lane masks of the clipped scan, computed once on the scalar unit from H = lanes holding a row end:
+    //   M_d  : no row end in lanes (l-d, l]                     (steps row_shr:1,2,4,8)
+    //   P16  : no row end in [first lane of l's 16-lane row, l]  (step row_bcast:15)
+    //   P32  : no row end in [first lane of l's 32-lane half, l] (step row_bcast:31)
+    const uint64_t H = __ballot(o[C - 1] != 0u);
+    const uint64_t M1 = ~H;
+    const uint64_t M2 = M1 & ((M1 << 1) | 0x1ull);
+    const uint64_t M4 = M2 & ((M2 << 2) | 0x3ull);
+    const uint64_t M8 = M4 & ((M4 << 4) | 0xFull);
+    uint64_t P16 = M1 & ((M1 << 1) | 0x0001000100010001ull);
+    P16 &= (P16 << 2) | 0x0003000300030003ull;
+    P16 &= (P16 << 4) | 0x000F000F000F000Full;
+    P16 &= (P16 << 8) | 0x00FF00FF00FF00FFull;
+    // upper row of each half also needs the whole lower row clear: bit 15 / 47 of P16
+    const uint64_t low_clear = ((P16 >> 15) & 0x0000000100000001ull) * 0xFFFF0000ull;
+    const uint64_t P32 = P16 & (low_clear | 0x0000FFFF0000FFFFull);
+
     float vv = tail;
     {
-        float up;
-        up = dpp_zero<DPP_ROW_SHR1, 0xF>(vv);
-        vv = (dist >= 1) ? __fadd_rn(vv, up) : vv;
-        up = dpp_zero<DPP_ROW_SHR2, 0xF>(vv);
-        vv = (dist >= 2) ? __fadd_rn(vv, up) : vv;
-        up = dpp_zero<DPP_ROW_SHR4, 0xF>(vv);
-        vv = (dist >= 4) ? __fadd_rn(vv, up) : vv;
-        up = dpp_zero<DPP_ROW_SHR8, 0xF>(vv);
-        vv = (dist >= 8) ? __fadd_rn(vv, up) : vv;
-        up = dpp_zero<DPP_ROW_BCAST15, 0xA>(vv);  // lane 15 -> row 1, lane 47 -> row 3
-        vv = (dist > l16) ? __fadd_rn(vv, up) : vv;
-        up = dpp_zero<DPP_ROW_BCAST31, 0xC>(vv);  // lane 31 -> rows 2 and 3
-        vv = (dist > l32) ? __fadd_rn(vv, up) : vv;
+        float t;
+        t = __fadd_rn(vv, dpp_zero<DPP_ROW_SHR1, 0xF>(vv));
+        vv = __builtin_amdgcn_inverse_ballot_w64(M1) ? t : vv;
+        t = __fadd_rn(vv, dpp_zero<DPP_ROW_SHR2, 0xF>(vv));
+        vv = __builtin_amdgcn_inverse_ballot_w64(M2) ? t : vv;
+        t = __fadd_rn(vv, dpp_zero<DPP_ROW_SHR4, 0xF>(vv));
+        vv = __builtin_amdgcn_inverse_ballot_w64(M4) ? t : vv;
+        t = __fadd_rn(vv, dpp_zero<DPP_ROW_SHR8, 0xF>(vv));
+        vv = __builtin_amdgcn_inverse_ballot_w64(M8) ? t : vv;
+        t = __fadd_rn(vv, dpp_zero<DPP_ROW_BCAST15, 0xA>(vv));  // lane 15 -> row 1, lane 47 -> row 3
+        vv = __builtin_amdgcn_inverse_ballot_w64(P16) ? t : vv;
+        t = __fadd_rn(vv, dpp_zero<DPP_ROW_BCAST31, 0xC>(vv));  // lane 31 -> rows 2 and 3
+        vv = __builtin_amdgcn_inverse_ballot_w64(P32) ? t : vv;
     }
     const float cin = dpp_zero<DPP_WAVE_SHR1, 0xF>(vv);  // lane l-1's inclusive sum; 0 for lane 0
     const float S = __fadd_rn(cin, head);
     carry = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, vv), 63));
 
     RowSums<C> out;
+    out.rs[0] = S;  // if entry 0 ends a row it is the lane's first row end
 #pragma unroll
-    for (int j = 0; j < C; ++j) out.rs[j] = (j == first) ? S : s[j];
-    out.flags = flags;
+    for (int j = 1; j < C; ++j) out.rs[j] = mask_select(o[j - 1], s[j], S);  // an earlier end in the lane => s_j
+#pragma unroll
+    for (int j = 0; j < C / 2; ++j) out.cw[j] = cur.cw[j];
+    const float NEG_INF = -__builtin_huge_valf();
+    float e[C];
+#pragma unroll
+    for (int j = 0; j < C; ++j) e[j] = mask_select(m[j], out.rs[j], NEG_INF);
+    float best = max3(e[0], e[1], e[2]);
+#pragma unroll
+    for (int j = 3; j < C; j += 2) best = max3(best, e[j], (j + 1 < C) ? e[j + 1] : NEG_INF);
+    out.best_any = best;
     return out;
 }
 
 template <int C>
-__device__ __forceinline__ float lane_best(const RowSums<C> &R) {
+__device__ __forceinline__ float lane_best(const RowSums<C> &R) {  // placeholders excluded
     float best = -__builtin_huge_valf();
 #pragma unroll
     for (int j = 0; j < C; ++j) best = (R.valid(j) && R.rs[j] > best) ? R.rs[j] : best;
@@ -501,8 +548,8 @@ __device__ __forceinline__ uint32_t ends_below(const RowSums<C> &R) {
 // slots, one LDS atomic raises the group maximum (the wave on threshold duty pushes it to global memory).
 template <int C>
 __device__ __forceinline__ void offer_candidates(const StreamParams &P, const RowSums<C> &R, uint32_t rb, float tau,
-                                                 float best, uint32_t lane, uint32_t grp_local, bool publishes,
-                                                 uint2 *cand, uint32_t *misc) {
+                                                 uint32_t lane, uint32_t grp_local, bool publishes, uint2 *cand,
+                                                 uint32_t *misc) {
     bool pass[C];
     uint32_t slot[C];
     uint32_t total = 0;
@@ -514,8 +561,10 @@ __device__ __forceinline__ void offer_candidates(const StreamParams &P, const Ro
         slot[j] = total + __builtin_amdgcn_mbcnt_hi((uint32_t)(pb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pb, 0u));
         total += (uint32_t)__popcll(pb);
     }
+    const float best = lane_best<C>(R);
     const float wmax = wave_max(best >= tau ? best : -__builtin_huge_valf());
     uint32_t base = 0;
+    if (total == 0u) return;  // only placeholders of empty rows tripped the trigger
     if (lane == 0) {
         if (publishes)
             (void)__hip_atomic_fetch_max(&misc[MISC_GRPMAX + grp_local], order_key(wmax), __ATOMIC_RELAXED,
@@ -545,17 +594,31 @@ __device__ __forceinline__ void offer_candidates(const StreamParams &P, const Ro
 
 constexpr int DEFER = 3;  // packets per wave whose rows are judged at the end (threshold exchange cold start)
 
-template <int C, bool SCORES>
+// One static LDS object per workgroup. x sits at LDS offset 0, so that (column word & 0xFFFC) IS the ds_read address;
+// the selection tail reuses the bytes of x and of the candidate list, which are dead by then. Static objects are
+// addressed with ds_* instructions for certain: a pointer carved out of the dynamic region can degrade to flat_*
+// accesses, and one flat access in the loop forces s_waitcnt vmcnt(0), draining the packet prefetch every iteration.
+template <int XCOLS>
+struct StreamLds {
+    union {
+        struct {
+            float x[XCOLS];
+            uint2 cand[CAND_CAP];  // candidate list {score bits, row}
+        } w;
+        SelectShared sel;  // fused selection tail (last workgroup only)
+    } u;
+    uint32_t misc[MISC_WORDS];
+    uint32_t gm[MAX_GM * 64];  // staging of the published maxima (reducer servers)
+};
+
+template <int C, bool SCORES, int XCOLS, int NBUF = 3>
 __global__ void __launch_bounds__(576, 5) stream_kernel(const StreamParams P, const SelectParams SP) {
-    // Static LDS objects are addressed with ds_* instructions for certain; a pointer carved out of the dynamic
-    // region can degrade to flat_* accesses, and one flat access in the loop forces s_waitcnt vmcnt(0), which
-    // would drain the packet prefetch every iteration.
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // x only: cols * 4 bytes
-    __shared__ uint2 cand[CAND_CAP];                                       // candidate list {score bits, row}
-    __shared__ uint32_t misc[MISC_WORDS];
-    __shared__ uint32_t gm_lds[MAX_GM * 64];  // staging of the published maxima
-    __shared__ SelectShared sel_sh;           // fused selection tail (last workgroup only)
-    float *x_lds = reinterpret_cast<float *>(smem);
+    __shared__ StreamLds<XCOLS> L;
+    float *x_lds = L.u.w.x;
+    uint2 *cand = L.u.w.cand;
+    uint32_t *misc = L.misc;
+    uint32_t *gm_lds = L.gm;
+    SelectShared &sel_sh = L.u.sel;
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
@@ -570,8 +633,33 @@ __global__ void __launch_bounds__(576, 5) stream_kernel(const StreamParams P, co
     const bool publishes = (P.n_sets != 0u) && (grp_global < P.n_groups_pub);
     const bool reducer = blockIdx.x < P.n_reducers;
 
+    // The first packets of this wave's partition are requested before anything else, so that staging x and the
+    // barrier overlap with the first memory round trip instead of preceding it.
+    const uint32_t total_waves = nwaves * gridDim.x;
+    uint32_t q = is_server ? P.n_parts : wave * gridDim.x + blockIdx.x;
+    Pkt<C> buf[NBUF];
+    uint32_t rbs[NBUF];
+    uint32_t p0 = 0, np = 0;
+    if (q < P.n_parts) {
+        p0 = P.part_first[q];
+        np = P.part_count[q];
+    }
+    auto prologue = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < NBUF - 1; ++u) {  // NBUF-1 packets in flight
+            rbs[u] = 0u;
+            if (np > 0) {
+                const uint32_t iu = ((uint32_t)u < np) ? (uint32_t)u : (np - 1);
+                load_packet<C>(P.packets + (size_t)(p0 + iu) * P.packet_bytes, lane, buf[u]);
+                rbs[u] = P.pkt_row[p0 + iu];
+            }
+        }
+        rbs[NBUF - 1] = 0u;
+    };
+    prologue();
+
     // Stage the dense query vector in LDS (reference: URAM copies, spmv_bscsr_top_k_multicore.cpp:87-140).
-    for (uint32_t i = tid; i < (P.x_lds_bytes >> 2); i += blockDim.x) x_lds[i] = (i < P.cols) ? P.x[i] : 0.0f;
+    for (uint32_t i = tid; i < (uint32_t)XCOLS; i += blockDim.x) x_lds[i] = (i < P.cols) ? P.x[i] : 0.0f;
     if (tid < MISC_WORDS) misc[tid] = (tid == MISC_TAU) ? __float_as_uint(P.min_score) : 0u;
     __syncthreads();
 
@@ -605,10 +693,12 @@ __global__ void __launch_bounds__(576, 5) stream_kernel(const StreamParams P, co
             }
         }
     }
-    const uint32_t total_waves = nwaves * gridDim.x;
-    for (uint32_t q = is_server ? P.n_parts : wave * gridDim.x + blockIdx.x; q < P.n_parts; q += total_waves) {
-        const uint32_t p0 = P.part_first[q];
-        const uint32_t np = P.part_count[q];
+    for (bool first_part = true; q < P.n_parts; q += total_waves, first_part = false) {
+        if (!first_part) {  // more partitions than waves (not the case for engines built by tkspmv_create)
+            p0 = P.part_first[q];
+            np = P.part_count[q];
+            prologue();
+        }
         const uint8_t *pk = P.packets + (size_t)p0 * P.packet_bytes;
         float carry = 0.0f;
 
@@ -616,39 +706,30 @@ __global__ void __launch_bounds__(576, 5) stream_kernel(const StreamParams P, co
         uint32_t st_rb[DEFER];
 #pragma unroll
         for (int d = 0; d < DEFER; ++d) {
-            st[d].flags = 0u;
+            st[d].best_any = -__builtin_huge_valf();
             st_rb[d] = 0u;
 #pragma unroll
             for (int j = 0; j < C; ++j) st[d].rs[j] = 0.0f;
+#pragma unroll
+            for (int j = 0; j < C / 2; ++j) st[d].cw[j] = 0u;
         }
 
-        // Two packets in flight behind the one being reduced. The three buffers rotate by NAME (the loop is
-        // unrolled by three): copying a freshly loaded buffer into another would wait for the youngest load
-        // and drain the prefetch queue every iteration.
-        Pkt<C> buf[3];
-        uint32_t rbs[3] = {0u, 0u, 0u};
-        if (np > 0) {
-            load_packet<C>(pk, lane, buf[0]);
-            rbs[0] = P.pkt_row[p0];
-        }
-        if (np > 0) {
-            const uint32_t i1 = np > 1 ? 1u : 0u;
-            load_packet<C>(pk + (size_t)i1 * P.packet_bytes, lane, buf[1]);
-            rbs[1] = P.pkt_row[p0 + i1];
-        }
-        for (uint32_t i0 = 0; i0 < np; i0 += 3) {
+        // Two packets in flight behind the one being reduced. The buffers rotate by NAME (the loop is unrolled by
+        // NBUF): copying a freshly loaded buffer into another would wait for the youngest load and drain the
+        // prefetch queue every iteration.
+        for (uint32_t i0 = 0; i0 < np; i0 += NBUF) {
 #pragma unroll
-            for (int u = 0; u < 3; ++u) {
+            for (int u = 0; u < NBUF; ++u) {
                 const uint32_t i = i0 + (uint32_t)u;
                 if (i >= np) break;
                 const Pkt<C> &cur = buf[u];
                 const uint32_t rb_cur = rbs[u];
-                Pkt<C> &ahead = buf[(u + 2) % 3];
-                uint32_t &rb_ahead = rbs[(u + 2) % 3];
+                Pkt<C> &ahead = buf[(u + NBUF - 1) % NBUF];
+                uint32_t &rb_ahead = rbs[(u + NBUF - 1) % NBUF];
             {
                 // Unconditional (index clamped to the last packet): a fixed number of younger loads lets the
                 // compiler wait with a counted vmcnt instead of vmcnt(0).
-                const uint32_t ia = (i + 2 < np) ? (i + 2) : (np - 1);
+                const uint32_t ia = (i + (NBUF - 1) < np) ? (i + (NBUF - 1)) : (np - 1);
                 load_packet<C>(pk + (size_t)ia * P.packet_bytes, lane, ahead);
                 rb_ahead = P.pkt_row[p0 + ia];
             }
@@ -657,7 +738,7 @@ __global__ void __launch_bounds__(576, 5) stream_kernel(const StreamParams P, co
                 tau = __uint_as_float(
                     __hip_atomic_load(&misc[MISC_TAU], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
 
-            const RowSums<C> R = reduce_packet<C>(cur, lane, carry, x_lds);
+            const RowSums<C> R = reduce_packet<C>(cur, carry, x_lds);
 
             if (SCORES) {
                 uint32_t r = rb_cur + ends_below<C>(R);
@@ -669,7 +750,6 @@ __global__ void __launch_bounds__(576, 5) stream_kernel(const StreamParams P, co
                     }
                 }
             } else {
-                const float best = lane_best<C>(R);
                 if (i < (uint32_t)DEFER && P.n_sets != 0u) {
                     // Cold start of the threshold exchange: keep the sums in registers, only feed the maxima.
 #pragma unroll
@@ -679,12 +759,12 @@ __global__ void __launch_bounds__(576, 5) stream_kernel(const StreamParams P, co
                             st_rb[d] = rb_cur;
                         }
                     }
-                    const float wmax = wave_max(best);
+                    const float wmax = wave_max(lane_best<C>(R));
                     if (lane == 0 && publishes && wmax >= P.min_score)
                         (void)__hip_atomic_fetch_max(&misc[MISC_GRPMAX + grp_local], order_key(wmax), __ATOMIC_RELAXED,
                                                      __HIP_MEMORY_SCOPE_WORKGROUP);
-                } else if (__any(best >= tau) && !(P.dbg_flags & 2u)) {
-                    offer_candidates<C>(P, R, rb_cur, tau, best, lane, grp_local, publishes, cand, misc);
+                } else if (__any(R.best_any >= tau) && !(P.dbg_flags & 2u)) {
+                    offer_candidates<C>(P, R, rb_cur, tau, lane, grp_local, publishes, cand, misc);
                 }
             }
             }
@@ -695,9 +775,8 @@ __global__ void __launch_bounds__(576, 5) stream_kernel(const StreamParams P, co
                 __uint_as_float(__hip_atomic_load(&misc[MISC_TAU], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
 #pragma unroll
             for (int d = 0; d < DEFER; ++d) {
-                const float best = lane_best<C>(st[d]);
-                if (np > (uint32_t)d && __any(best >= tau))
-                    offer_candidates<C>(P, st[d], st_rb[d], tau, best, lane, grp_local, publishes, cand, misc);
+                if (np > (uint32_t)d && __any(st[d].best_any >= tau))
+                    offer_candidates<C>(P, st[d], st_rb[d], tau, lane, grp_local, publishes, cand, misc);
             }
         }
     }
@@ -814,7 +893,7 @@ struct EngineImpl {
     float *d_out_val = nullptr, *d_scores = nullptr;
     unsigned long long *d_scratch = nullptr, *d_stats = nullptr;
     uint32_t grid = 0, block = 0, gpw = 1, n_sets = 0, n_groups_pub = 0, cand_cap = 0, ovf_cap = 0, lds_bytes = 0,
-             x_lds_bytes = 0;
+             xcols = 1024;
     bool collect_stats = false;
     uint32_t dbg_flags = 0;
     bool have_query = false;
@@ -829,7 +908,6 @@ struct EngineImpl {
         P.x = x;
         P.n_parts = (uint32_t)info.n_wave_partitions;
         P.cols = desc.cols;
-        P.x_lds_bytes = x_lds_bytes;
         P.packet_bytes = info.packet_entries * (value_bytes((Precision)desc.precision) + 2);
         P.n_sets = n_sets;
         P.n_groups_pub = n_groups_pub;
@@ -874,14 +952,24 @@ struct EngineImpl {
         launch_stream(x, out_idx, out_val, s);
         if (!fused) launch_select(out_idx, out_val, s);
     }
+    typedef void (*stream_fn)(const StreamParams, const SelectParams);
+    stream_fn kernel_for(bool scores) const {
+        const bool c8 = info.packet_entries == 512;
+        if (c8) return scores ? &stream_kernel<8, true, 1024> : &stream_kernel<8, false, 1024>;
+        if (xcols <= 1024) return scores ? &stream_kernel<4, true, 1024> : &stream_kernel<4, false, 1024>;
+        if (xcols <= 4096) return scores ? &stream_kernel<4, true, 4096> : &stream_kernel<4, false, 4096>;
+        return scores ? &stream_kernel<4, true, 16384> : &stream_kernel<4, false, 16384>;
+    }
     void launch_stream(const float *x, uint32_t *out_idx, float *out_val, hipStream_t s) const {
         StreamParams P = stream_params(x);
         SelectParams S = select_params(out_idx, out_val);
         ++launch_counter;
-        if (info.packet_entries == 256)
-            hipLaunchKernelGGL((stream_kernel<4, false>), dim3(grid), dim3(block + 64), lds_bytes, s, P, S);
-        else
-            hipLaunchKernelGGL((stream_kernel<8, false>), dim3(grid), dim3(block + 64), lds_bytes, s, P, S);
+        hipLaunchKernelGGL(kernel_for(false), dim3(grid), dim3(block + 64), 0, s, P, S);
+    }
+    void launch_scores(const float *x, hipStream_t s) const {
+        StreamParams P = stream_params(x);
+        SelectParams S = select_params(d_out_idx, d_out_val);
+        hipLaunchKernelGGL(kernel_for(true), dim3(grid), dim3(block + 64), 0, s, P, S);
     }
     void launch_select(uint32_t *out_idx, float *out_val, hipStream_t s) const {
         SelectParams S = select_params(out_idx, out_val);
@@ -1018,8 +1106,13 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err) {
     }
     m.cand_cap = CAND_CAP;
     m.ovf_cap = std::max<uint32_t>(d.rows, 1u);
-    m.x_lds_bytes = ((d.cols * 4u + 15u) / 16u) * 16u;
-    m.lds_bytes = m.x_lds_bytes;  // dynamic part only (x); candidate list, misc and staging are static
+    m.xcols = d.cols <= 1024 ? 1024u : (d.cols <= 4096 ? 4096u : 16384u);
+    if (C == 8 && d.cols > 1024) {
+        err = "nnz_per_lane = 8 is only built for cols <= 1024";
+        return TKSPMV_ERR_UNSUPPORTED;
+    }
+    m.lds_bytes = (uint32_t)std::max<size_t>(sizeof(SelectShared), (size_t)m.xcols * 4 + CAND_CAP * 8) +
+                  (MISC_WORDS + MAX_GM * 64) * 4;  // all static
 
     HIP_TRY(hipStreamCreateWithFlags(&m.stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&m.ev0));
@@ -1078,15 +1171,6 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err) {
     HIP_TRY(hipMemset(m.d_stats, 0, 8 * 8));
     HIP_TRY(hipMemset(m.d_out_idx, 0, (size_t)d.k * 4));
     HIP_TRY(hipMemset(m.d_out_val, 0, (size_t)d.k * 4));
-
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&stream_kernel<4, false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)m.lds_bytes));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&stream_kernel<8, false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)m.lds_bytes));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&stream_kernel<4, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)m.lds_bytes));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&stream_kernel<8, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)m.lds_bytes));
 
     m.info.grid = m.grid;
     m.info.block = m.block;
@@ -1227,11 +1311,7 @@ int Engine::scores(float *host_y, std::string &err) {
     HIP_TRY(hipSetDevice(m.device));
     if (!m.d_scores) HIP_TRY(hipMalloc((void **)&m.d_scores, std::max<size_t>(m.desc.rows, 1) * 4));
     HIP_TRY(hipMemsetAsync(m.d_scores, 0, std::max<size_t>(m.desc.rows, 1) * 4, m.stream));
-    StreamParams P = m.stream_params(m.d_x_cur);
-    if (m.info.packet_entries == 256)
-        hipLaunchKernelGGL((stream_kernel<4, true>), dim3(m.grid), dim3(m.block + 64), m.lds_bytes, m.stream, P, m.select_params(m.d_out_idx, m.d_out_val));
-    else
-        hipLaunchKernelGGL((stream_kernel<8, true>), dim3(m.grid), dim3(m.block + 64), m.lds_bytes, m.stream, P, m.select_params(m.d_out_idx, m.d_out_val));
+    m.launch_scores(m.d_x_cur, m.stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(host_y, m.d_scores, (size_t)m.desc.rows * 4, hipMemcpyDeviceToHost, m.stream));
     HIP_TRY(hipStreamSynchronize(m.stream));
@@ -1295,11 +1375,7 @@ int Engine::profile(const float *dev_xs, int32_t n_x, int32_t iters, tkspmv_timi
         if (!m.d_scores) HIP_TRY(hipMalloc((void **)&m.d_scores, std::max<size_t>(m.desc.rows, 1) * 4));
         HIP_TRY(hipEventRecord(m.ev0, m.stream));
         for (int i = 0; i < iters; ++i) {
-            StreamParams P = m.stream_params(dev_xs + (size_t)(i % n_x) * stride);
-            if (m.info.packet_entries == 256)
-                hipLaunchKernelGGL((stream_kernel<4, true>), dim3(m.grid), dim3(m.block + 64), m.lds_bytes, m.stream, P, m.select_params(m.d_out_idx, m.d_out_val));
-            else
-                hipLaunchKernelGGL((stream_kernel<8, true>), dim3(m.grid), dim3(m.block + 64), m.lds_bytes, m.stream, P, m.select_params(m.d_out_idx, m.d_out_val));
+            m.launch_scores(dev_xs + (size_t)(i % n_x) * stride, m.stream);
         }
         HIP_TRY(hipEventRecord(m.ev1, m.stream));
         HIP_TRY(hipEventSynchronize(m.ev1));

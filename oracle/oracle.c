@@ -214,7 +214,7 @@ void oracle_packed_scores(const uint8_t *packets, uint64_t packet_bytes, const u
                     e[l][j] = w & 1u;
                     skip[l][j] = w & 2u;
                 }
-                p[0] = p[0] + (l == 0 ? carry : 0.0f);
+                if (l == 0) p[0] = p[0] + carry;
                 s[l][0] = p[0];
                 for (uint32_t j = 1; j < C; j++) s[l][j] = (e[l][j - 1] ? 0.0f : s[l][j - 1]) + p[j];
                 any_e[l] = 0;
