@@ -9,12 +9,12 @@
 //                   packet: gather x, multiply, in-lane segmented sums, cross-lane segmented scan, one compare
 //                   of the lane's best finished row against the running threshold tau. Rows that pass are
 //                   appended to a per-workgroup candidate list in LDS (rare). No N-vector is written.
-//   tau           : every workgroup publishes the best score it has seen (one u32 per group, atomic max).
-//                   The groups are dealt into n_sets >= k sets; min over sets of (max of the set) is a valid
-//                   lower bound of the global k-th best score (k distinct rows score at least that much), so
-//                   rows below it can be dropped. Stale or missing values only make tau smaller: correctness
-//                   never depends on inter-workgroup timing, only the candidate count does.
-//   select_kernel : exact top-k of the surviving candidates, ordered (score desc, row desc) = sort_tuples
+//   tau           : every workgroup publishes the best score it has seen (one u32 per group, single writer).
+//                   The published maxima are scores of distinct rows, so the k-th largest of them is a valid lower
+//                   bound of the global k-th best score and rows below it can be dropped. Stale or missing values
+//                   only make tau smaller: correctness never depends on inter-workgroup timing, only the
+//                   candidate count does. All exchange traffic is issued by one "server" wave per workgroup.
+//   select tail   : (last workgroup to finish, or select_kernel) exact top-k of the surviving candidates, ordered (score desc, row desc) = sort_tuples
 //                   (src/common/utils/evaluation_utils.hpp:40-62); pads with (0, 0.0f) like the gold's
 //                   zero-initialised list (gold_algorithms.hpp:203-206).
 #include <hip/hip_runtime.h>
@@ -50,8 +50,9 @@ struct StreamParams {
     const uint32_t *part_count;
     const float *x;
     uint32_t n_parts, cols, packet_bytes;
-    uint32_t n_sets;        // 0 => threshold exchange disabled
-    uint32_t n_groups_pub;  // power of two, groups [0, n_groups_pub) publish maxima
+    uint32_t n_sets;        // 0 => threshold exchange disabled (fewer publishing groups than k), else 1
+    uint32_t k;
+    uint32_t n_groups_pub;  // groups [0, n_groups_pub) publish maxima (<= 1024)
     uint32_t gpw;           // groups per workgroup
     float min_score;
     uint32_t *gmax;  // [MAX_GM*64] order keys of the group maxima (zero beyond n_groups_pub)
@@ -65,6 +66,7 @@ struct StreamParams {
     uint32_t fused;  // 1: the last workgroup to finish runs the selection (no second launch)
     float *scores;  // SCORES variant only
     uint32_t dbg_flags;       // ablation switches (TKSPMV_DBG_FLAGS): 1 no publish, 2 no offers, 4 no tau duty, 8 no flush
+    unsigned long long *stamps;  // optional (TKSPMV_STAMPS=1): s_memtime stamps of the selection tail, last workgroup
     unsigned long long *dbg;  // optional counters (TKSPMV_STATS=1): [0] slow-path executions, [1] appended rows
 };
 
@@ -141,14 +143,13 @@ __device__ __forceinline__ void st_agent(unsigned long long *p, unsigned long lo
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Lower bound of the k-th largest of the 64*GM keys held GM per lane: bisection on the top KTH_PROBES bits of the
-// order key (the remaining low bits are left zero, so the result never exceeds the true k-th largest). 20 bits =
-// sign + exponent + 11 mantissa bits: within 0.05 % of the exact value.
-constexpr int KTH_PROBES = 20;
-template <int GM>
+// Lower bound of the k-th largest of the 64*GM keys held GM per lane: bisection on the top PROBES bits of the
+// order key (the remaining low bits are left zero, so the result never exceeds the true k-th largest). 17 bits =
+// sign + exponent + 8 mantissa bits: within 0.4 % of the exact value.
+template <int GM, int PROBES>
 __device__ __forceinline__ uint32_t kth_largest_prefix(const uint32_t (&gk)[MAX_GM], uint32_t k) {
     uint32_t prefix = 0u;
-    for (int bit = 31; bit > 31 - KTH_PROBES; --bit) {
+    for (int bit = 31; bit > 31 - PROBES; --bit) {
         const uint32_t trial = prefix | (1u << bit);
         uint32_t c = 0;
 #pragma unroll
@@ -159,7 +160,8 @@ __device__ __forceinline__ uint32_t kth_largest_prefix(const uint32_t (&gk)[MAX_
 }
 
 __device__ __forceinline__ void select_body(const SelectParams &P, const uint32_t tid, const uint32_t nthreads,
-                                            SelectShared &S) {
+                                            SelectShared &S, const uint32_t dbg_flags = 0u,
+                                            unsigned long long *stamps = nullptr) {
     const uint32_t lane = tid & 63u;
     const uint32_t n_slots = P.n_wg * WG_SLOTS;  // host guarantees n_slots <= SEL_PER_THREAD * nthreads
 
@@ -172,36 +174,22 @@ __device__ __forceinline__ void select_body(const SelectParams &P, const uint32_
         mine[u] = ~0ull;
         if (f < n_slots) mine[u] = ld_agent(&P.wg_cand[f]);
     }
-    uint32_t gk[MAX_GM];
-#pragma unroll
-    for (int i = 0; i < MAX_GM; ++i) {
-        gk[i] = 0u;
-        if (tid < 64 && P.use_gmax && 64u * i < P.n_groups_pub)
-            gk[i] = __hip_atomic_load(&P.gmax[lane + 64u * i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    // The reducer servers keep the k-th largest published maximum in tau_g: a valid lower bound of the k-th best
+    // score (slightly stale, never too high). It prunes what was appended while the threshold was converging.
+    const uint32_t thr = P.use_gmax ? __hip_atomic_load(P.tau_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
     uint32_t novf = __hip_atomic_load(P.ovf_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     novf = novf < P.ovf_cap ? novf : P.ovf_cap;
+    if (stamps && tid == 0) stamps[4] = __builtin_amdgcn_s_memtime() + (mine[0] & 1ull) * 0ull;  // after the loads returned
+    if (dbg_flags & 256u) {  // timing aid: stop once the loads have landed
+        if (mine[0] == 1234567ull && thr == 7654321u) P.out_idx[0] = novf;
+        if (tid == 0) for (uint32_t c = 0; c < 9u; ++c) P.done_count[32u * c] = 0u;
+        return;
+    }
     if (tid == 0) {
         S.cnt = 0;
         S.total = 0;
-        S.thr = 0;
     }
     __syncthreads();
-    // Exact k-th largest of the group maxima (bisection on the order keys, wave 0): the maxima are scores of k
-    // distinct rows, so it is a valid lower bound of the k-th best score, and a tight one; it prunes the
-    // candidates that were appended while the running threshold was still converging.
-    if (tid < 64 && P.use_gmax) {
-        const uint32_t rows_used = (P.n_groups_pub + 63u) >> 6;  // registers that hold maxima
-        uint32_t prefix;
-        if (rows_used <= 1) prefix = kth_largest_prefix<1>(gk, P.k);
-        else if (rows_used <= 2) prefix = kth_largest_prefix<2>(gk, P.k);
-        else if (rows_used <= 4) prefix = kth_largest_prefix<4>(gk, P.k);
-        else if (rows_used <= 8) prefix = kth_largest_prefix<8>(gk, P.k);
-        else prefix = kth_largest_prefix<16>(gk, P.k);
-        if (lane == 0) S.thr = prefix;
-    }
-    __syncthreads();
-    const uint32_t thr = S.thr;  // order key; 0 keeps everything
     uint32_t spos[SEL_PER_THREAD];
     uint32_t wtot = 0;
 #pragma unroll
@@ -226,6 +214,7 @@ __device__ __forceinline__ void select_body(const SelectParams &P, const uint32_
             if (ok[u]) S.keys[wbase + spos[u]] = make_ckey(mine[u]);
         }
         for (uint32_t i = tid; i < novf; i += nthreads) S.keys[n_from_slots + i] = make_ckey(ld_agent(&P.ovf_cand[i]));
+        if (tid < 8) S.keys[total + tid] = 0ull;  // padding for the unrolled rank loop (0 is below every real key)
         __syncthreads();
         n_sel = total;
     } else {
@@ -264,41 +253,50 @@ __device__ __forceinline__ void select_body(const SelectParams &P, const uint32_
         }
         __syncthreads();
         n_sel = S.cnt < SEL_CAP ? S.cnt : SEL_CAP;
+        if (tid < 8) S.keys[n_sel + tid] = 0ull;
+        __syncthreads();
     }
-    if (tid < 8) S.keys[n_sel + tid] = 0ull;  // padding for the unrolled rank loop (0 is below every real key)
-    __syncthreads();
+    if (stamps && tid == 0) stamps[5] = __builtin_amdgcn_s_memtime();  // keys in LDS
 
-    // Rank by counting: keys are unique (distinct rows), rank r = number of larger keys.
+    // Rank by counting: keys are unique (distinct rows), rank r = number of larger keys. G threads share one key
+    // (each counts a slice of the list, partial counts meet through quad/oct shuffles) so the whole workgroup works.
+    uint32_t G = 1;
+    while (G < 8u && n_sel * (G * 2u) <= nthreads) G *= 2u;
     const uint32_t n_pad = (n_sel + 7u) & ~7u;
-    for (uint32_t i = tid; i < n_sel; i += nthreads) {
-        const unsigned long long kx = S.keys[i];
+    const uint32_t n_blocks = n_pad >> 3;  // blocks of 8 keys
+    for (uint32_t base = 0; base < n_sel; base += nthreads / G) {
+        const uint32_t i = base + tid / G, part = tid & (G - 1u);
+        const bool active = i < n_sel;
+        const unsigned long long kx = active ? S.keys[i] : ~0ull;
         uint32_t r = 0;
-        for (uint32_t j = 0; j < n_pad; j += 8) {
+        for (uint32_t blk = part; blk < n_blocks; blk += G) {
 #pragma unroll
-            for (uint32_t u = 0; u < 8; ++u) r += (S.keys[j + u] > kx);
+            for (uint32_t u = 0; u < 8; ++u) r += (S.keys[blk * 8u + u] > kx);
         }
-        if (r < P.k) {
+        for (uint32_t d = 1; d < G; d <<= 1) r += (uint32_t)__shfl_xor((int)r, (int)d);
+        if (active && part == 0u && r < P.k) {
             P.out_idx[r] = (uint32_t)(kx & 0xFFFFFFFFull) + P.first_row;
             P.out_val[r] = key_to_float((uint32_t)(kx >> 32));
         }
     }
+    if (stamps && tid == 0) stamps[6] = __builtin_amdgcn_s_memtime();  // ranked
     for (uint32_t r = n_sel + tid; r < P.k; r += nthreads) {
         P.out_idx[r] = 0u;
         P.out_val[r] = 0.0f;
     }
-
-    // Reset the exchange state for the next query (this is the last consumer of the query on the stream).
+    // Reset the exchange state for the next query (this is the last consumer of the query on the stream); last, so
+    // that no barrier above has to wait for these stores.
     for (uint32_t i = tid; i < P.n_groups_pub; i += nthreads) P.gmax[i] = 0u;
     if (tid == 0) {
         *P.ovf_count = 0u;
         *P.tau_g = 0u;
         for (uint32_t c = 0; c < 9u; ++c) P.done_count[32u * c] = 0u;
-        if (P.stats) {  // TKSPMV_STATS=1 only: four dependent global read-modify-writes
-            P.stats[0] += total;
-            P.stats[1] += 1ull;
-            if (total > P.stats[2]) P.stats[2] = total;
-            if (!small) P.stats[3] += 1ull;
-        }
+    }
+    if (tid == 0 && P.stats) {  // TKSPMV_STATS=1 only: four dependent global read-modify-writes
+        P.stats[0] += total;
+        P.stats[1] += 1ull;
+        if (total > P.stats[2]) P.stats[2] = total;
+        if (!small) P.stats[3] += 1ull;
     }
 }
 
@@ -357,25 +355,19 @@ __device__ __forceinline__ void tau_issue(const StreamParams &P, uint32_t lane, 
             t.k[i] = __hip_atomic_load(&P.gmax[lane + 64u * i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
-__device__ __forceinline__ float tau_finish(const StreamParams &P, uint32_t lane, const TauRegs &t, uint32_t *gm_lds) {
-#pragma unroll
-    for (int i = 0; i < MAX_GM; ++i) {
-        if (64u * i < P.n_groups_pub) gm_lds[lane + 64u * i] = t.k[i];
-    }
-    // same wave wrote and reads: LDS operations of one wave complete in order
-    uint32_t vmin = 0xFFFFFFFFu;
-    for (uint32_t st = lane; st < P.n_sets; st += 64) {
-        uint32_t smax = 0;
-        for (uint32_t s = st; s < P.n_groups_pub; s += P.n_sets) {
-            const uint32_t kx = gm_lds[s];
-            smax = kx > smax ? kx : smax;
-        }
-        vmin = smax < vmin ? smax : vmin;
-    }
-    vmin = wave_min_u32(vmin);
+// tau = (lower bound within 2^-8 relative of) the k-th largest published maximum: the maxima are scores of distinct
+// rows, so k of them at or above tau prove that the k-th best score overall is at least tau.
+__device__ __forceinline__ float tau_from_maxima(const StreamParams &P, const TauRegs &t) {
+    const uint32_t rows_used = (P.n_groups_pub + 63u) >> 6;
+    uint32_t key;
+    if (rows_used <= 1) key = kth_largest_prefix<1, 17>(t.k, P.k);
+    else if (rows_used <= 2) key = kth_largest_prefix<2, 17>(t.k, P.k);
+    else if (rows_used <= 4) key = kth_largest_prefix<4, 17>(t.k, P.k);
+    else if (rows_used <= 8) key = kth_largest_prefix<8, 17>(t.k, P.k);
+    else key = kth_largest_prefix<16, 17>(t.k, P.k);
     float tau = P.min_score;
-    if (vmin != 0u && vmin != 0xFFFFFFFFu) {
-        const float f = key_to_float(vmin);
+    if (key != 0u) {
+        const float f = key_to_float(key);
         tau = f > tau ? f : tau;
     }
     return tau;
@@ -608,7 +600,6 @@ struct StreamLds {
         SelectShared sel;  // fused selection tail (last workgroup only)
     } u;
     uint32_t misc[MISC_WORDS];
-    uint32_t gm[MAX_GM * 64];  // staging of the published maxima (reducer servers)
 };
 
 template <int C, bool SCORES, int XCOLS, int NBUF = 3>
@@ -617,7 +608,6 @@ __global__ void __launch_bounds__(576, 5) stream_kernel(const StreamParams P, co
     float *x_lds = L.u.w.x;
     uint2 *cand = L.u.w.cand;
     uint32_t *misc = L.misc;
-    uint32_t *gm_lds = L.gm;
     SelectShared &sel_sh = L.u.sel;
 
     const uint32_t tid = threadIdx.x;
@@ -671,7 +661,7 @@ __global__ void __launch_bounds__(576, 5) stream_kernel(const StreamParams P, co
                 if (reducer) {
                     TauRegs tr;
                     tau_issue(P, lane, tr);
-                    t = tau_finish(P, lane, tr, gm_lds);
+                    t = tau_from_maxima(P, tr);
                     if (lane == 0 && t > P.min_score)
                         __hip_atomic_fetch_max(P.tau_g, order_key(t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 } else {
@@ -782,6 +772,7 @@ __global__ void __launch_bounds__(576, 5) stream_kernel(const StreamParams P, co
     }
 
     if (SCORES) return;
+    const unsigned long long ts_stream_end = P.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
     if (!is_server && lane == 0) atomicAdd(&misc[MISC_DONE], 1u);
     if (P.dbg_flags & 8u) return;
 
@@ -827,8 +818,10 @@ __global__ void __launch_bounds__(576, 5) stream_kernel(const StreamParams P, co
     // Hand-off (cdna_hip_programming.md Guideline 16): every storing wave drains its write-through stores, the
     // workgroup barrier orders them before ONE agent-scope ticket add; the workgroup whose add came last takes an
     // agent-scope acquire, a barrier, and only then loads what the others stored.
+    const unsigned long long ts_flush_issued = P.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    const unsigned long long ts_flush_done = P.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
     if (tid == 0) {
         // Two-level ticket: 8 group counters (blockIdx % 8) and a top counter, each on its own 128-B line, so the
         // workgroups that finish together do not serialise on one word. Which workgroups share a group is
@@ -844,14 +837,23 @@ __global__ void __launch_bounds__(576, 5) stream_kernel(const StreamParams P, co
                 __hip_atomic_fetch_add(&SP.done_count[32u * 8u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             last = (t2 == n_groups - 1u) ? 1u : 0u;
         }
-        if (last) {
+        if (last && !(P.dbg_flags & 32u)) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         sel_sh.last = last;
     }
     __syncthreads();
-    if (sel_sh.last && !(P.dbg_flags & 16u)) select_body(SP, tid, blockDim.x, sel_sh);
+    const unsigned long long ts_ticket = P.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
+    if (sel_sh.last && !(P.dbg_flags & 16u)) select_body(SP, tid, blockDim.x, sel_sh, P.dbg_flags, P.stamps);
+    if (P.stamps && sel_sh.last && tid == 0) {
+        P.stamps[0] = ts_stream_end;
+        P.stamps[1] = ts_flush_issued;
+        P.stamps[2] = ts_flush_done;
+        P.stamps[3] = ts_ticket;
+        P.stamps[7] = __builtin_amdgcn_s_memtime();
+        P.stamps[8] = __builtin_amdgcn_s_memrealtime();
+    }
 }
 
 // Empty kernel with the stream kernel's geometry: calibrates what an event bracket adds around one launch.
@@ -895,6 +897,7 @@ struct EngineImpl {
     uint32_t grid = 0, block = 0, gpw = 1, n_sets = 0, n_groups_pub = 0, cand_cap = 0, ovf_cap = 0, lds_bytes = 0,
              xcols = 1024;
     bool collect_stats = false;
+    bool collect_stamps = false;
     uint32_t dbg_flags = 0;
     bool have_query = false;
     bool ran = false;
@@ -910,6 +913,7 @@ struct EngineImpl {
         P.cols = desc.cols;
         P.packet_bytes = info.packet_entries * (value_bytes((Precision)desc.precision) + 2);
         P.n_sets = n_sets;
+        P.k = (uint32_t)desc.k;
         P.n_groups_pub = n_groups_pub;
         P.gpw = gpw;
         P.min_score = desc.min_score;
@@ -924,6 +928,7 @@ struct EngineImpl {
         P.scores = d_scores;
         P.fused = fused ? 1u : 0u;
         P.dbg = collect_stats ? d_stats + 4 : nullptr;
+        P.stamps = collect_stamps ? d_stats + 16 : nullptr;
         P.dbg_flags = dbg_flags;
         return P;
     }
@@ -1004,17 +1009,6 @@ int device_count() {
     return n;
 }
 
-static uint32_t next_pow2(uint32_t v) {
-    uint32_t p = 1;
-    while (p < v) p <<= 1;
-    return p;
-}
-static uint32_t floor_pow2(uint32_t v) {
-    uint32_t p = 1;
-    while ((p << 1) <= v && (p << 1) != 0) p <<= 1;
-    return p;
-}
-
 Engine::~Engine() {
     if (!impl_) return;
     EngineImpl &m = *impl_;
@@ -1047,8 +1041,15 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err) {
         return TKSPMV_ERR_UNSUPPORTED;
     }
     if (d.partitions > 1) {
-        err = "logical partitions > 1 are not implemented by this build";
-        return TKSPMV_ERR_UNSUPPORTED;
+        // The reference keeps k_per_partition (its compile-time K) candidates per row partition and merges them on
+        // the host (host_spmv_bscsr.cpp:399-448). For k <= k_per_partition the union of the per-partition lists
+        // contains the global top-k, so the partitioned result IS the exact one computed here. The lossy regime
+        // (k > k_per_partition) is an accuracy knob of the FPGA design that is not reproduced.
+        const int kpp = d.k_per_partition > 0 ? d.k_per_partition : d.k;
+        if (d.k > kpp) {
+            err = "partitions > 1 with k > k_per_partition (the reference's lossy regime) is not implemented";
+            return TKSPMV_ERR_UNSUPPORTED;
+        }
     }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
@@ -1093,17 +1094,14 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err) {
     }
     fill_info(m.pm, d.k, &m.info);
 
-    // Threshold-exchange geometry: n_sets = next_pow2(k) sets over a power-of-two number of publishing groups.
-    m.n_sets = next_pow2((uint32_t)d.k);
+    // Threshold-exchange geometry: at least k publishing groups are needed (tau = k-th largest published maximum);
+    // if one group per workgroup is not enough, the waves of a workgroup are split into up to 8 groups.
     m.gpw = 1;
-    while (floor_pow2(m.grid * m.gpw) < m.n_sets && m.gpw < 8 && m.gpw < waves_per_wg &&
-           (waves_per_wg % (m.gpw * 2) == 0))
+    while (m.grid * m.gpw < (uint32_t)d.k && m.gpw < 8 && m.gpw < waves_per_wg && (waves_per_wg % (m.gpw * 2) == 0))
         m.gpw *= 2;
-    m.n_groups_pub = floor_pow2(m.grid * m.gpw);
-    if (m.n_groups_pub < m.n_sets) {
-        m.n_sets = 0;  // cannot form k disjoint sets: exchange disabled, every row >= min_score is a candidate
-        m.n_groups_pub = 1;
-    }
+    m.n_groups_pub = std::min<uint32_t>(m.grid * m.gpw, MAX_GM * 64);
+    m.n_sets = (m.n_groups_pub >= (uint32_t)d.k) ? 1u : 0u;  // 0: exchange disabled, every row >= min_score is a candidate
+    if (!m.n_sets) m.n_groups_pub = 1;
     m.cand_cap = CAND_CAP;
     m.ovf_cap = std::max<uint32_t>(d.rows, 1u);
     m.xcols = d.cols <= 1024 ? 1024u : (d.cols <= 4096 ? 4096u : 16384u);
@@ -1112,7 +1110,7 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err) {
         return TKSPMV_ERR_UNSUPPORTED;
     }
     m.lds_bytes = (uint32_t)std::max<size_t>(sizeof(SelectShared), (size_t)m.xcols * 4 + CAND_CAP * 8) +
-                  (MISC_WORDS + MAX_GM * 64) * 4;  // all static
+                  MISC_WORDS * 4;  // all static
 
     HIP_TRY(hipStreamCreateWithFlags(&m.stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&m.ev0));
@@ -1155,7 +1153,7 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err) {
     HIP_TRY(hipMalloc((void **)&m.d_out_idx, (size_t)d.k * 4));
     HIP_TRY(hipMalloc((void **)&m.d_out_val, (size_t)d.k * 4));
     HIP_TRY(hipMalloc((void **)&m.d_scratch, ((size_t)m.grid * WG_SLOTS + m.ovf_cap) * 8));
-    HIP_TRY(hipMalloc((void **)&m.d_stats, 8 * 8));
+    HIP_TRY(hipMalloc((void **)&m.d_stats, 32 * 8));
     m.collect_stats = getenv("TKSPMV_STATS") != nullptr;
     if (const char *f = getenv("TKSPMV_DBG_FLAGS")) m.dbg_flags = (uint32_t)atoi(f);
     HIP_TRY(hipMemset(m.d_gmax, 0, (size_t)MAX_GM * 64 * 4));
@@ -1168,7 +1166,8 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err) {
     if (const char *f = getenv("TKSPMV_FUSED")) m.fused = m.fused && atoi(f) != 0;
     HIP_TRY(hipMemset(m.d_wg_count, 0, (size_t)m.grid * 4));
     HIP_TRY(hipMemset(m.d_ovf_count, 0, 4));
-    HIP_TRY(hipMemset(m.d_stats, 0, 8 * 8));
+    HIP_TRY(hipMemset(m.d_stats, 0, 32 * 8));
+    m.collect_stamps = getenv("TKSPMV_STAMPS") != nullptr;
     HIP_TRY(hipMemset(m.d_out_idx, 0, (size_t)d.k * 4));
     HIP_TRY(hipMemset(m.d_out_val, 0, (size_t)d.k * 4));
 
@@ -1176,8 +1175,8 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err) {
     m.info.block = m.block;
     m.info.n_groups = m.n_sets ? m.n_groups_pub : 0;
     m.info.lds_bytes = m.lds_bytes;
-    m.info.partitions = 1;
-    m.info.k_per_partition = d.k;
+    m.info.partitions = d.partitions > 1 ? d.partitions : 1;
+    m.info.k_per_partition = d.k_per_partition > 0 ? d.k_per_partition : d.k;
     m.info.device = dev;
     m.info.num_cus = num_cus;
     HIP_TRY(hipDeviceSynchronize());
@@ -1409,6 +1408,13 @@ int Engine::profile(const float *dev_xs, int32_t n_x, int32_t iters, tkspmv_timi
     out->stream_kernel_ns = t_stream * 1e6 / iters;
     out->select_kernel_ns = t_select * 1e6 / iters;
     out->n_queries = (uint32_t)iters;
+    if (m.collect_stamps) {
+        unsigned long long st[16];
+        HIP_TRY(hipMemcpy(st, m.d_stats + 16, sizeof(st), hipMemcpyDeviceToHost));
+        fprintf(stderr, "[tkspmv stamps, shader cycles since stream end of the last workgroup] flush_issued %lld flush_done %lld ticket %lld loads %lld keys %lld ranked %lld end %lld\n",
+                (long long)(st[1] - st[0]), (long long)(st[2] - st[0]), (long long)(st[3] - st[0]), (long long)(st[4] - st[0]),
+                (long long)(st[5] - st[0]), (long long)(st[6] - st[0]), (long long)(st[7] - st[0]));
+    }
     m.ran = true;
     return TKSPMV_OK;
 }

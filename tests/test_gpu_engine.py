@@ -175,7 +175,8 @@ def test_k8_is_the_32_partition_result(pkg, oracle, big):
     contains the global top-8, so the partitioned model and the exact engine must agree."""
     m, _ = big
     x = pkg.create_sample_vector(1024, True, False, True, 99)
-    eng = pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, vec=x, k=8, device=0)
+    eng = pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, vec=x, k=8, device=0, partitions=32, k_per_partition=8)
+    assert eng.info()["partitions"] == 32 and eng.info()["k_per_partition"] == 8
     eng()
     val, idx = eng.read_result()
     y, present = oracle.scores_f32_seq(m.row, m.col, m.val, x, m.rows)
