@@ -70,31 +70,53 @@ struct StreamParams {
     unsigned long long *dbg;  // optional counters (TKSPMV_STATS=1): [0] slow-path executions, [1] appended rows
 };
 
-constexpr int MISC_CAND_CNT = 0, MISC_TAU = 1, MISC_FLUSH_CNT = 2, MISC_FLUSH_POS = 3, MISC_OVF_BASE = 4, MISC_DONE = 5,
+constexpr int MISC_CAND_CNT = 0, MISC_TAU = 1, MISC_FLUSH_CNT = 2, MISC_FLUSH_POS = 3, MISC_OVF_BASE = 4, MISC_DONE = 5, MISC_XMAX = 6,
               MISC_GRPMAX = 8 /* [8] */, MISC_PUBLISHED = 16 /* [8] */, MISC_WORDS = 32;  // <= 8 groups per workgroup
 constexpr uint32_t CAND_CAP = 1024;  // per-workgroup candidate list entries in LDS
 constexpr uint32_t WG_SLOTS = 8;              // fixed result slots every workgroup writes (no count round trip)
 constexpr uint32_t SLOT_INVALID = 0xFFFFFFFFu;  // row id of an unused slot
 
-template <int C>
+// One lane's share of a packet. Q8 = false: C fp32 values; Q8 = true: C Q1.7 values packed four to a dword.
+// QM: 0 = fp32, 1 = Q1.7 strict (8-bit wrapping sums, the FPGA's real_type), 2 = Q1.7 values with x block-scaled by a
+// power of two per query and exact wide accumulation.
+template <int C, bool Q8>
 struct Pkt {
-    float v[C];
+    float v[Q8 ? 1 : C];
+    uint32_t vq[Q8 ? C / 4 : 1];
     uint32_t cw[C / 2];
 };
 
-template <int C>
-__device__ __forceinline__ void load_packet(const uint8_t *__restrict__ pk, uint32_t lane, Pkt<C> &o) {
+template <int C, bool Q8>
+__device__ __forceinline__ void load_packet(const uint8_t *__restrict__ pk, uint32_t lane, Pkt<C, Q8> &o) {
 #pragma unroll
     for (int q = 0; q < C / 4; ++q) {
-        const float4 f = *reinterpret_cast<const float4 *>(pk + q * 1024 + lane * 16);
-        o.v[4 * q + 0] = f.x;
-        o.v[4 * q + 1] = f.y;
-        o.v[4 * q + 2] = f.z;
-        o.v[4 * q + 3] = f.w;
-        const uint2 c = *reinterpret_cast<const uint2 *>(pk + C * 256 + q * 512 + lane * 8);
-        o.cw[2 * q + 0] = c.x;
-        o.cw[2 * q + 1] = c.y;
+        if (Q8) {
+            o.vq[Q8 ? q : 0] = *reinterpret_cast<const uint32_t *>(pk + q * 256 + lane * 4);
+            const uint2 c = *reinterpret_cast<const uint2 *>(pk + C * 64 + q * 512 + lane * 8);
+            o.cw[2 * q + 0] = c.x;
+            o.cw[2 * q + 1] = c.y;
+        } else {
+            const float4 f = *reinterpret_cast<const float4 *>(pk + q * 1024 + lane * 16);
+            o.v[Q8 ? 0 : 4 * q + 0] = f.x;
+            o.v[Q8 ? 0 : 4 * q + 1] = f.y;
+            o.v[Q8 ? 0 : 4 * q + 2] = f.z;
+            o.v[Q8 ? 0 : 4 * q + 3] = f.w;
+            const uint2 c = *reinterpret_cast<const uint2 *>(pk + C * 256 + q * 512 + lane * 8);
+            o.cw[2 * q + 0] = c.x;
+            o.cw[2 * q + 1] = c.y;
+        }
     }
+}
+
+// Q1.7 helpers (restating ap_ufixed<8,1,AP_TRN_ZERO>, fpga_types.hpp:20: 1 integer + 7 fraction bits, truncation).
+// Conversion from float saturates at the top of the range (the HLS type would wrap there; inputs are expected in
+// [0, 2)). Products are truncated to Q1.7 and wrap to 8 bits; sums wrap to 8 bits (mod 2.0).
+__device__ __forceinline__ uint32_t to_q1_7_dev(float v) {
+    const float s = fminf(fmaxf(v * 128.0f, 0.0f), 255.0f);  // NaN -> 0
+    return (uint32_t)s;                                       // truncation
+}
+__device__ __forceinline__ float q17_wrap(float units) {  // units = exact integer sum held in fp32
+    return (float)(((uint32_t)units) & 255u);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -108,6 +130,7 @@ struct SelectParams {
     uint32_t *ovf_count;
     uint32_t ovf_cap;
     uint32_t k, first_row;
+    float out_scale;  // 1 for fp32; 1/128 for Q1.7 (scores travel as integer units)
     uint32_t *out_idx;
     float *out_val;
     uint32_t *gmax;
@@ -161,7 +184,8 @@ __device__ __forceinline__ uint32_t kth_largest_prefix(const uint32_t (&gk)[MAX_
 
 __device__ __forceinline__ void select_body(const SelectParams &P, const uint32_t tid, const uint32_t nthreads,
                                             SelectShared &S, const uint32_t dbg_flags = 0u,
-                                            unsigned long long *stamps = nullptr) {
+                                            unsigned long long *stamps = nullptr, const float out_scale_override = 0.0f) {
+    const float out_scale = out_scale_override != 0.0f ? out_scale_override : P.out_scale;
     const uint32_t lane = tid & 63u;
     const uint32_t n_slots = P.n_wg * WG_SLOTS;  // host guarantees n_slots <= SEL_PER_THREAD * nthreads
 
@@ -276,7 +300,7 @@ __device__ __forceinline__ void select_body(const SelectParams &P, const uint32_
         for (uint32_t d = 1; d < G; d <<= 1) r += (uint32_t)__shfl_xor((int)r, (int)d);
         if (active && part == 0u && r < P.k) {
             P.out_idx[r] = (uint32_t)(kx & 0xFFFFFFFFull) + P.first_row;
-            P.out_val[r] = key_to_float((uint32_t)(kx >> 32));
+            P.out_val[r] = key_to_float((uint32_t)(kx >> 32)) * out_scale;
         }
     }
     if (stamps && tid == 0) stamps[6] = __builtin_amdgcn_s_memtime();  // ranked
@@ -357,7 +381,7 @@ __device__ __forceinline__ void tau_issue(const StreamParams &P, uint32_t lane, 
 }
 // tau = (lower bound within 2^-8 relative of) the k-th largest published maximum: the maxima are scores of distinct
 // rows, so k of them at or above tau prove that the k-th best score overall is at least tau.
-__device__ __forceinline__ float tau_from_maxima(const StreamParams &P, const TauRegs &t) {
+__device__ __forceinline__ float tau_from_maxima(const StreamParams &P, const TauRegs &t, const float min_units) {
     const uint32_t rows_used = (P.n_groups_pub + 63u) >> 6;
     uint32_t key;
     if (rows_used <= 1) key = kth_largest_prefix<1, 17>(t.k, P.k);
@@ -365,7 +389,7 @@ __device__ __forceinline__ float tau_from_maxima(const StreamParams &P, const Ta
     else if (rows_used <= 4) key = kth_largest_prefix<4, 17>(t.k, P.k);
     else if (rows_used <= 8) key = kth_largest_prefix<8, 17>(t.k, P.k);
     else key = kth_largest_prefix<16, 17>(t.k, P.k);
-    float tau = P.min_score;
+    float tau = min_units;
     if (key != 0u) {
         const float f = key_to_float(key);
         tau = f > tau ? f : tau;
@@ -431,16 +455,24 @@ struct RowSums {
 //   tail = end_{C-1} ? +0 : s_{C-1};   head = s at the lane's first row end
 //   vv = clipped Kogge-Stone scan of tail over the 64 lanes (never across a lane that holds a row end)
 //   row sum at the lane's first row end = vv[lane-1] + head, at its later row ends = s_j; carry' = vv[63]
-template <int C>
-__device__ __forceinline__ RowSums<C> reduce_packet(const Pkt<C> &cur, float &carry, const float *x_lds) {
+template <int C, int QM>
+__device__ __forceinline__ RowSums<C> reduce_packet(const Pkt<C, (QM != 0)> &cur, float &carry, const float *x_lds) {
+    constexpr bool Q8 = QM != 0;
     float p[C];
     uint32_t m[C];  // all-ones where entry j ends a row
 #pragma unroll
     for (int j = 0; j < C; ++j) {
         const uint32_t word = cur.cw[j >> 1];
         const uint32_t off = (j & 1) ? ((word >> 16) & 0xFFFCu) : (word & 0xFFFCu);  // byte offset of x[col]
-        const float xv = *reinterpret_cast<const float *>(reinterpret_cast<const unsigned char *>(x_lds) + off);
-        p[j] = __fmul_rn(cur.v[j], xv);
+        if (Q8) {
+            // x is staged as Q1.7 integers; product truncated to Q1.7 and wrapped to 8 bits, exact in fp32
+            const uint32_t xq = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const unsigned char *>(x_lds) + off);
+            const uint32_t vq = (cur.vq[Q8 ? (j >> 2) : 0] >> (8 * (j & 3))) & 255u;
+            p[j] = (float)(QM == 2 ? ((vq * xq) >> 7) : (((vq * xq) >> 7) & 255u));  // wide mode: no wrap
+        } else {
+            const float xv = *reinterpret_cast<const float *>(reinterpret_cast<const unsigned char *>(x_lds) + off);
+            p[j] = __fmul_rn(cur.v[Q8 ? 0 : j], xv);
+        }
         m[j] = (j & 1) ? bit_mask<16>(word) : bit_mask<0>(word);
     }
     p[0] = __builtin_amdgcn_inverse_ballot_w64(1ull) ? __fadd_rn(p[0], carry) : p[0];  // lane 0 only
@@ -516,11 +548,18 @@ __device__ __forceinline__ RowSums<C> reduce_packet(const Pkt<C> &cur, float &ca
     return out;
 }
 
-template <int C>
+template <int C, int QM>
+__device__ __forceinline__ float row_score(const RowSums<C> &R, int j) {  // strict Q1.7: the 8-bit wrap of the row sum
+    return QM == 1 ? q17_wrap(R.rs[j]) : R.rs[j];
+}
+template <int C, int QM>
 __device__ __forceinline__ float lane_best(const RowSums<C> &R) {  // placeholders excluded
     float best = -__builtin_huge_valf();
 #pragma unroll
-    for (int j = 0; j < C; ++j) best = (R.valid(j) && R.rs[j] > best) ? R.rs[j] : best;
+    for (int j = 0; j < C; ++j) {
+        const float sc = row_score<C, QM>(R, j);
+        best = (R.valid(j) && sc > best) ? sc : best;
+    }
     return best;
 }
 
@@ -538,7 +577,7 @@ __device__ __forceinline__ uint32_t ends_below(const RowSums<C> &R) {
 
 // Candidate path (rare once tau has converged). Everything is aggregated per wave: one LDS atomic reserves list
 // slots, one LDS atomic raises the group maximum (the wave on threshold duty pushes it to global memory).
-template <int C>
+template <int C, int QM>
 __device__ __forceinline__ void offer_candidates(const StreamParams &P, const RowSums<C> &R, uint32_t rb, float tau,
                                                  uint32_t lane, uint32_t grp_local, bool publishes, uint2 *cand,
                                                  uint32_t *misc) {
@@ -548,12 +587,12 @@ __device__ __forceinline__ void offer_candidates(const StreamParams &P, const Ro
     const uint32_t below = ends_below<C>(R);
 #pragma unroll
     for (int j = 0; j < C; ++j) {
-        pass[j] = R.valid(j) && R.rs[j] >= tau;
+        pass[j] = R.valid(j) && row_score<C, QM>(R, j) >= tau;
         const uint64_t pb = __ballot(pass[j]);
         slot[j] = total + __builtin_amdgcn_mbcnt_hi((uint32_t)(pb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pb, 0u));
         total += (uint32_t)__popcll(pb);
     }
-    const float best = lane_best<C>(R);
+    const float best = lane_best<C, QM>(R);
     const float wmax = wave_max(best >= tau ? best : -__builtin_huge_valf());
     uint32_t base = 0;
     if (total == 0u) return;  // only placeholders of empty rows tripped the trigger
@@ -574,10 +613,10 @@ __device__ __forceinline__ void offer_candidates(const StreamParams &P, const Ro
         if (pass[j]) {
             const uint32_t pos = base + slot[j];
             if (pos < P.cand_cap) {
-                cand[pos] = make_uint2(__float_as_uint(R.rs[j]), r);
+                cand[pos] = make_uint2(__float_as_uint(row_score<C, QM>(R, j)), r);
             } else {
                 const uint32_t gp = atomicAdd(P.ovf_count, 1u);
-                if (gp < P.ovf_cap) st_agent(&P.ovf_cand[gp], pack_cand(__float_as_uint(R.rs[j]), r));
+                if (gp < P.ovf_cap) st_agent(&P.ovf_cand[gp], pack_cand(__float_as_uint(row_score<C, QM>(R, j)), r));
             }
         }
         r += R.end(j) ? 1u : 0u;
@@ -602,8 +641,9 @@ struct StreamLds {
     uint32_t misc[MISC_WORDS];
 };
 
-template <int C, bool SCORES, int XCOLS, int NBUF = 3>
+template <int C, bool SCORES, int XCOLS, int QM = 0, int NBUF = 3>
 __global__ void __launch_bounds__(576, 5) stream_kernel(const StreamParams P, const SelectParams SP) {
+    constexpr bool Q8 = QM != 0;
     __shared__ StreamLds<XCOLS> L;
     float *x_lds = L.u.w.x;
     uint2 *cand = L.u.w.cand;
@@ -627,7 +667,7 @@ __global__ void __launch_bounds__(576, 5) stream_kernel(const StreamParams P, co
     // barrier overlap with the first memory round trip instead of preceding it.
     const uint32_t total_waves = nwaves * gridDim.x;
     uint32_t q = is_server ? P.n_parts : wave * gridDim.x + blockIdx.x;
-    Pkt<C> buf[NBUF];
+    Pkt<C, Q8> buf[NBUF];
     uint32_t rbs[NBUF];
     uint32_t p0 = 0, np = 0;
     if (q < P.n_parts) {
@@ -640,7 +680,7 @@ __global__ void __launch_bounds__(576, 5) stream_kernel(const StreamParams P, co
             rbs[u] = 0u;
             if (np > 0) {
                 const uint32_t iu = ((uint32_t)u < np) ? (uint32_t)u : (np - 1);
-                load_packet<C>(P.packets + (size_t)(p0 + iu) * P.packet_bytes, lane, buf[u]);
+                load_packet<C, Q8>(P.packets + (size_t)(p0 + iu) * P.packet_bytes, lane, buf[u]);
                 rbs[u] = P.pkt_row[p0 + iu];
             }
         }
@@ -649,8 +689,41 @@ __global__ void __launch_bounds__(576, 5) stream_kernel(const StreamParams P, co
     prologue();
 
     // Stage the dense query vector in LDS (reference: URAM copies, spmv_bscsr_top_k_multicore.cpp:87-140).
-    for (uint32_t i = tid; i < (uint32_t)XCOLS; i += blockDim.x) x_lds[i] = (i < P.cols) ? P.x[i] : 0.0f;
-    if (tid < MISC_WORDS) misc[tid] = (tid == MISC_TAU) ? __float_as_uint(P.min_score) : 0u;
+    // Scores travel in "units": 1 for fp32; 1/128 for strict Q1.7; 1/(128 * 2^s) in wide mode, where s is the
+    // per-query block scale of x (largest s in [0,15] with max(x) * 2^s <= 255/128; every workgroup derives the
+    // same s from the same x).
+    if (tid < MISC_WORDS) misc[tid] = 0u;
+    float x_scale = 1.0f;    // applied to x before quantisation (2^s)
+    float unit_scale = 1.0f; // units per 1.0 of score
+    if (QM == 2) {
+        __syncthreads();
+        float lm = 0.0f;
+        for (uint32_t i = tid; i < P.cols; i += blockDim.x) lm = fmaxf(lm, P.x[i]);
+        lm = wave_max(lm);
+        if (lane == 0) atomicMax(&misc[MISC_XMAX], __float_as_uint(lm));  // non-negative floats order like their bits
+        __syncthreads();
+        const float xmax = __uint_as_float(misc[MISC_XMAX]);
+        int sh = 0;
+        if (xmax > 0.0f) {
+            const float ratio = 1.9921875f / xmax;
+            sh = (int)((__float_as_uint(ratio) >> 23) & 255u) - 127;
+            sh = sh < 0 ? 0 : (sh > 15 ? 15 : sh);
+        }
+        x_scale = (float)(1u << sh);
+        unit_scale = 128.0f * x_scale;
+    } else if (QM == 1) {
+        unit_scale = 128.0f;
+    }
+    const float inv_unit = 1.0f / unit_scale;             // exact: unit_scale is a power of two
+    const float min_units = P.min_score * unit_scale;
+    for (uint32_t i = tid; i < (uint32_t)XCOLS; i += blockDim.x) {
+        const float xv = (i < P.cols) ? P.x[i] : 0.0f;
+        if (Q8)
+            reinterpret_cast<uint32_t *>(x_lds)[i] = to_q1_7_dev(xv * x_scale);  // x quantised like the matrix values
+        else
+            x_lds[i] = xv;
+    }
+    if (tid == 0) misc[MISC_TAU] = __float_as_uint(min_units);
     __syncthreads();
 
     if (is_server) {
@@ -661,12 +734,12 @@ __global__ void __launch_bounds__(576, 5) stream_kernel(const StreamParams P, co
                 if (reducer) {
                     TauRegs tr;
                     tau_issue(P, lane, tr);
-                    t = tau_from_maxima(P, tr);
-                    if (lane == 0 && t > P.min_score)
+                    t = tau_from_maxima(P, tr, min_units);
+                    if (lane == 0 && t > min_units)
                         __hip_atomic_fetch_max(P.tau_g, order_key(t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 } else {
                     const uint32_t kx = __hip_atomic_load(P.tau_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    t = kx ? key_to_float(kx) : P.min_score;
+                    t = kx ? key_to_float(kx) : min_units;
                 }
                 if (lane == 0) {
                     const float cur_tau = __uint_as_float(
@@ -712,15 +785,15 @@ __global__ void __launch_bounds__(576, 5) stream_kernel(const StreamParams P, co
             for (int u = 0; u < NBUF; ++u) {
                 const uint32_t i = i0 + (uint32_t)u;
                 if (i >= np) break;
-                const Pkt<C> &cur = buf[u];
+                const Pkt<C, Q8> &cur = buf[u];
                 const uint32_t rb_cur = rbs[u];
-                Pkt<C> &ahead = buf[(u + NBUF - 1) % NBUF];
+                Pkt<C, Q8> &ahead = buf[(u + NBUF - 1) % NBUF];
                 uint32_t &rb_ahead = rbs[(u + NBUF - 1) % NBUF];
             {
                 // Unconditional (index clamped to the last packet): a fixed number of younger loads lets the
                 // compiler wait with a counted vmcnt instead of vmcnt(0).
                 const uint32_t ia = (i + (NBUF - 1) < np) ? (i + (NBUF - 1)) : (np - 1);
-                load_packet<C>(pk + (size_t)ia * P.packet_bytes, lane, ahead);
+                load_packet<C, Q8>(pk + (size_t)ia * P.packet_bytes, lane, ahead);
                 rb_ahead = P.pkt_row[p0 + ia];
             }
             float tau = 0.0f;
@@ -728,14 +801,14 @@ __global__ void __launch_bounds__(576, 5) stream_kernel(const StreamParams P, co
                 tau = __uint_as_float(
                     __hip_atomic_load(&misc[MISC_TAU], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
 
-            const RowSums<C> R = reduce_packet<C>(cur, carry, x_lds);
+            const RowSums<C> R = reduce_packet<C, QM>(cur, carry, x_lds);
 
             if (SCORES) {
                 uint32_t r = rb_cur + ends_below<C>(R);
 #pragma unroll
                 for (int j = 0; j < C; ++j) {
                     if (R.end(j)) {
-                        if (R.valid(j)) P.scores[r] = R.rs[j];
+                        if (R.valid(j)) P.scores[r] = row_score<C, QM>(R, j) * inv_unit;
                         ++r;
                     }
                 }
@@ -749,12 +822,12 @@ __global__ void __launch_bounds__(576, 5) stream_kernel(const StreamParams P, co
                             st_rb[d] = rb_cur;
                         }
                     }
-                    const float wmax = wave_max(lane_best<C>(R));
-                    if (lane == 0 && publishes && wmax >= P.min_score)
+                    const float wmax = wave_max(lane_best<C, QM>(R));
+                    if (lane == 0 && publishes && wmax >= min_units)
                         (void)__hip_atomic_fetch_max(&misc[MISC_GRPMAX + grp_local], order_key(wmax), __ATOMIC_RELAXED,
                                                      __HIP_MEMORY_SCOPE_WORKGROUP);
                 } else if (__any(R.best_any >= tau) && !(P.dbg_flags & 2u)) {
-                    offer_candidates<C>(P, R, rb_cur, tau, lane, grp_local, publishes, cand, misc);
+                    offer_candidates<C, QM>(P, R, rb_cur, tau, lane, grp_local, publishes, cand, misc);
                 }
             }
             }
@@ -766,7 +839,7 @@ __global__ void __launch_bounds__(576, 5) stream_kernel(const StreamParams P, co
 #pragma unroll
             for (int d = 0; d < DEFER; ++d) {
                 if (np > (uint32_t)d && __any(st[d].best_any >= tau))
-                    offer_candidates<C>(P, st[d], st_rb[d], tau, lane, grp_local, publishes, cand, misc);
+                    offer_candidates<C, QM>(P, st[d], st_rb[d], tau, lane, grp_local, publishes, cand, misc);
             }
         }
     }
@@ -845,7 +918,7 @@ __global__ void __launch_bounds__(576, 5) stream_kernel(const StreamParams P, co
     }
     __syncthreads();
     const unsigned long long ts_ticket = P.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
-    if (sel_sh.last && !(P.dbg_flags & 16u)) select_body(SP, tid, blockDim.x, sel_sh, P.dbg_flags, P.stamps);
+    if (sel_sh.last && !(P.dbg_flags & 16u)) select_body(SP, tid, blockDim.x, sel_sh, P.dbg_flags, P.stamps, inv_unit);
     if (P.stamps && sel_sh.last && tid == 0) {
         P.stamps[0] = ts_stream_end;
         P.stamps[1] = ts_flush_issued;
@@ -897,6 +970,7 @@ struct EngineImpl {
     uint32_t grid = 0, block = 0, gpw = 1, n_sets = 0, n_groups_pub = 0, cand_cap = 0, ovf_cap = 0, lds_bytes = 0,
              xcols = 1024;
     bool collect_stats = false;
+    bool q8 = false;
     bool collect_stamps = false;
     uint32_t dbg_flags = 0;
     bool have_query = false;
@@ -911,12 +985,12 @@ struct EngineImpl {
         P.x = x;
         P.n_parts = (uint32_t)info.n_wave_partitions;
         P.cols = desc.cols;
-        P.packet_bytes = info.packet_entries * (value_bytes((Precision)desc.precision) + 2);
+        P.packet_bytes = info.packet_entries * ((desc.precision == TKSPMV_F32 ? 4u : 1u) + 2u);
         P.n_sets = n_sets;
         P.k = (uint32_t)desc.k;
         P.n_groups_pub = n_groups_pub;
         P.gpw = gpw;
-        P.min_score = desc.min_score;
+        P.min_score = desc.min_score;  // converted to score units inside the kernel
         P.gmax = d_gmax;
         P.tau_g = d_tau_g;
         P.n_reducers = grid < 8u ? grid : 8u;
@@ -941,6 +1015,7 @@ struct EngineImpl {
         S.ovf_cap = ovf_cap;
         S.k = (uint32_t)desc.k;
         S.first_row = desc.first_row;
+        S.out_scale = desc.precision == TKSPMV_Q1_7 ? (1.0f / 128.0f) : 1.0f;  // wide mode: fused tail supplies it
         S.out_idx = out_idx;
         S.out_val = out_val;
         S.gmax = d_gmax;
@@ -960,6 +1035,16 @@ struct EngineImpl {
     typedef void (*stream_fn)(const StreamParams, const SelectParams);
     stream_fn kernel_for(bool scores) const {
         const bool c8 = info.packet_entries == 512;
+        if (desc.precision == TKSPMV_Q1_7) {
+            if (xcols <= 1024) return scores ? &stream_kernel<4, true, 1024, 1> : &stream_kernel<4, false, 1024, 1>;
+            if (xcols <= 4096) return scores ? &stream_kernel<4, true, 4096, 1> : &stream_kernel<4, false, 4096, 1>;
+            return scores ? &stream_kernel<4, true, 16384, 1> : &stream_kernel<4, false, 16384, 1>;
+        }
+        if (desc.precision == TKSPMV_Q1_7_WIDE) {
+            if (xcols <= 1024) return scores ? &stream_kernel<4, true, 1024, 2> : &stream_kernel<4, false, 1024, 2>;
+            if (xcols <= 4096) return scores ? &stream_kernel<4, true, 4096, 2> : &stream_kernel<4, false, 4096, 2>;
+            return scores ? &stream_kernel<4, true, 16384, 2> : &stream_kernel<4, false, 16384, 2>;
+        }
         if (c8) return scores ? &stream_kernel<8, true, 1024> : &stream_kernel<8, false, 1024>;
         if (xcols <= 1024) return scores ? &stream_kernel<4, true, 1024> : &stream_kernel<4, false, 1024>;
         if (xcols <= 4096) return scores ? &stream_kernel<4, true, 4096> : &stream_kernel<4, false, 4096>;
@@ -1036,10 +1121,15 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err) {
         err = "cols must be in [1, 16384]";
         return TKSPMV_ERR_INVALID;
     }
-    if (d.precision != TKSPMV_F32) {
-        err = "only TKSPMV_F32 is implemented by this build";
+    if (d.precision != TKSPMV_F32 && d.precision != TKSPMV_Q1_7 && d.precision != TKSPMV_Q1_7_WIDE) {
+        err = "unknown precision";
+        return TKSPMV_ERR_INVALID;
+    }
+    if (d.precision != TKSPMV_F32 && d.nnz_per_lane == 8) {
+        err = "the Q1.7 precisions are built for nnz_per_lane = 4 only";
         return TKSPMV_ERR_UNSUPPORTED;
     }
+    m.q8 = d.precision != TKSPMV_F32;
     if (d.partitions > 1) {
         // The reference keeps k_per_partition (its compile-time K) candidates per row partition and merges them on
         // the host (host_spmv_bscsr.cpp:399-448). For k <= k_per_partition the union of the per-partition lists
@@ -1086,7 +1176,8 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err) {
     const uint32_t C = d.nnz_per_lane > 0 ? (uint32_t)d.nnz_per_lane : 4u;
 
     int kind = 0;
-    std::string perr = pack_wbscsr(d.rows, d.cols, d.nnz, d.row, d.col, d.val, (Precision)d.precision, C,
+    std::string perr = pack_wbscsr(d.rows, d.cols, d.nnz, d.row, d.col, d.val,
+                                   d.precision == TKSPMV_F32 ? Precision::F32 : Precision::Q1_7, C,
                                    m.grid * waves_per_wg, 4, m.pm, kind);
     if (!perr.empty()) {
         err = perr;
@@ -1164,6 +1255,10 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err) {
     // Fused tail: the last workgroup (block + 64 threads) must hold every slot in SEL_PER_THREAD registers.
     m.fused = (uint64_t)m.grid * WG_SLOTS <= (uint64_t)SEL_PER_THREAD * (m.block + 64);
     if (const char *f = getenv("TKSPMV_FUSED")) m.fused = m.fused && atoi(f) != 0;
+    if (d.precision == TKSPMV_Q1_7_WIDE && !m.fused) {
+        err = "TKSPMV_Q1_7_WIDE needs the fused selection tail (the per-query block scale lives in the stream kernel)";
+        return TKSPMV_ERR_UNSUPPORTED;
+    }
     HIP_TRY(hipMemset(m.d_wg_count, 0, (size_t)m.grid * 4));
     HIP_TRY(hipMemset(m.d_ovf_count, 0, 4));
     HIP_TRY(hipMemset(m.d_stats, 0, 32 * 8));

@@ -124,6 +124,67 @@ void oracle_scores_f64(const uint32_t *row, const uint32_t *col, const float *va
 }
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Q1.7 integer model (see oracle.h). Integer arithmetic is associative, so the summation order is irrelevant.
+ * ---------------------------------------------------------------------------------------------------------- */
+static inline uint32_t to_q1_7(float v) {
+    if (!(v > 0.0f)) return 0;
+    float s = v * 128.0f;
+    if (s >= 255.0f) return 255;
+    return (uint32_t)s; /* truncation toward zero (AP_TRN_ZERO) */
+}
+void oracle_q17_scores(const uint32_t *row, const uint32_t *col, const float *val, uint64_t nnz, const float *vec,
+                       uint32_t rows, float *y, uint8_t *present) {
+    memset(y, 0, (size_t)rows * sizeof(float));
+    if (present) memset(present, 0, rows);
+    uint64_t i = 0;
+    while (i < nnz) {
+        uint32_t r = row[i];
+        uint32_t acc = 0;
+        while (i < nnz && row[i] == r) {
+            uint32_t p = ((to_q1_7(val[i]) * to_q1_7(vec[col[i]])) >> 7) & 255u; /* product in real_type */
+            acc = (acc + p) & 255u;                                                /* sum in real_type */
+            i++;
+        }
+        if (r < rows) {
+            y[r] = (float)acc * (1.0f / 128.0f);
+            if (present) present[r] = 1;
+        }
+    }
+}
+
+int oracle_q17_wide_scores(const uint32_t *row, const uint32_t *col, const float *val, uint64_t nnz, const float *vec,
+                           uint32_t cols, uint32_t rows, float *y, uint8_t *present) {
+    memset(y, 0, (size_t)rows * sizeof(float));
+    if (present) memset(present, 0, rows);
+    float xmax = 0.0f;
+    for (uint32_t i = 0; i < cols; i++) xmax = fmaxf(xmax, vec[i]);
+    int sh = 0;
+    if (xmax > 0.0f) {
+        float ratio = 1.9921875f / xmax;
+        uint32_t bits;
+        memcpy(&bits, &ratio, 4);
+        sh = (int)((bits >> 23) & 255u) - 127;
+        sh = sh < 0 ? 0 : (sh > 15 ? 15 : sh);
+    }
+    const float x_scale = (float)(1u << sh);
+    const float inv_unit = 1.0f / (128.0f * x_scale);
+    uint64_t i = 0;
+    while (i < nnz) {
+        uint32_t r = row[i];
+        uint32_t acc = 0;
+        while (i < nnz && row[i] == r) {
+            acc += (to_q1_7(val[i]) * to_q1_7(vec[col[i]] * x_scale)) >> 7;
+            i++;
+        }
+        if (r < rows) {
+            y[r] = (float)acc * inv_unit;
+            if (present) present[r] = 1;
+        }
+    }
+    return sh;
+}
+
+/* ------------------------------------------------------------------------------------------------------------
  * Exact top-k with the sort_tuples total order; min-heap of composite keys.
  * ---------------------------------------------------------------------------------------------------------- */
 static inline uint32_t order_key(float f) {

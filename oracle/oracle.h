@@ -35,6 +35,20 @@ void oracle_scores_f32_seq(const uint32_t *row, const uint32_t *col, const float
 void oracle_scores_f64(const uint32_t *row, const uint32_t *col, const float *val, uint64_t nnz, const float *vec,
                        uint32_t rows, double *y, uint8_t *present);
 
+/* Q1.7 fixed point (BASELINE configs[4], "FIXED_WIDTH-style"): restatement of ap_ufixed<8,1,AP_TRN_ZERO> arithmetic as
+ * the FPGA kernel applies it (src/fpga/src/ip/fpga_types.hpp:16-23; products and sums in `real_type`,
+ * spmv_bscsr_top_k_multicore.hpp:121-141): values and x are truncated to 1.7 bits, every product is truncated to 1.7
+ * bits and wraps at 2.0, sums wrap at 2.0. Deviation, stated: float -> Q1.7 SATURATES at 255/128 here (the HLS type
+ * would wrap); inputs are expected in [0, 2). No reference test pins this arithmetic (needs Xilinx headers):
+ * parity unpinned; the GPU path is checked bit for bit against THIS integer model. y[r] = wrapped_sum / 128. */
+void oracle_q17_scores(const uint32_t *row, const uint32_t *col, const float *val, uint64_t nnz, const float *vec,
+                       uint32_t rows, float *y, uint8_t *present);
+/* TKSPMV_Q1_7_WIDE (this repository's own variant, no reference counterpart): Q1.7 values; x scaled by 2^s, s the
+ * largest integer in [0,15] with max(x) * 2^s <= 255/128, then truncated to Q1.7; products truncated to 7 fraction
+ * bits WITHOUT wrap; sums exact. y[r] = sum / (128 * 2^s). Returns s. */
+int oracle_q17_wide_scores(const uint32_t *row, const uint32_t *col, const float *val, uint64_t nnz, const float *vec,
+                           uint32_t cols, uint32_t rows, float *y, uint8_t *present);
+
 /* Exact top-k by (score desc, row desc) among present rows with score >= min_score; padded with (0, 0.0f). */
 void oracle_select_topk(const float *y, const uint8_t *present, uint32_t rows, int k, float min_score,
                         uint32_t first_row, uint32_t *res_idx, float *res_val);

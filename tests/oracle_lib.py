@@ -87,6 +87,25 @@ def scores_f64(row, col, val, vec, rows):
     return y[:rows], present[:rows]
 
 
+def q17_scores(row, col, val, vec, rows):
+    row, col, val, vec = _u32(row), _u32(col), _f32(val), _f32(vec)
+    y = np.zeros(max(rows, 1), dtype=np.float32)
+    present = np.zeros(max(rows, 1), dtype=np.uint8)
+    oracle().oracle_q17_scores(_p(row, u32p), _p(col, u32p), _p(val, f32p), C.c_uint64(row.shape[0]), _p(vec, f32p),
+                               C.c_uint32(rows), _p(y, f32p), _p(present, u8p))
+    return y[:rows], present[:rows]
+
+
+def q17_wide_scores(row, col, val, vec, rows):
+    row, col, val, vec = _u32(row), _u32(col), _f32(val), _f32(vec)
+    y = np.zeros(max(rows, 1), dtype=np.float32)
+    present = np.zeros(max(rows, 1), dtype=np.uint8)
+    sh = oracle().oracle_q17_wide_scores(_p(row, u32p), _p(col, u32p), _p(val, f32p), C.c_uint64(row.shape[0]),
+                                         _p(vec, f32p), C.c_uint32(vec.shape[0]), C.c_uint32(rows), _p(y, f32p),
+                                         _p(present, u8p))
+    return y[:rows], present[:rows], sh
+
+
 def select_topk(y, present, k, min_score=0.0, first_row=0):
     y = _f32(y)
     rows = y.shape[0]

@@ -58,7 +58,8 @@ def test_argument_validation_before_device(pkg):
     """Descriptor errors are reported with ERR_INVALID / ERR_UNSUPPORTED regardless of the device."""
     m = pkg.generate_matrix(50, 16, 4, "uniform", 2)
     for kw, status in ((dict(k=0), pkg._lib.ERR_INVALID), (dict(k=2000), pkg._lib.ERR_INVALID),
-                       (dict(k=8, precision=pkg.Q1_7), pkg._lib.ERR_UNSUPPORTED),
+                       (dict(k=8, precision=pkg.Q1_7, nnz_per_lane=8), pkg._lib.ERR_UNSUPPORTED),
+                       (dict(k=8, precision=7), pkg._lib.ERR_INVALID),
                        (dict(k=100, partitions=32, k_per_partition=8), pkg._lib.ERR_UNSUPPORTED)):
         with pytest.raises(pkg.TkspmvError) as e:
             pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, **kw)

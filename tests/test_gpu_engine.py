@@ -260,3 +260,103 @@ def test_drop_in_executable_csv(pkg, oracle, tmp_path):
     r = subprocess.run([exe, "-d", "-t", "1", "-m", str(p), "-k", "8"], capture_output=True, text=True, env=env,
                        timeout=300)
     assert r.returncode == 0 and "hw results=" in r.stdout and "precision=1" in r.stdout
+
+
+# ---- BASELINE configs[4]: Q1.7 fixed-point values ("FIXED_WIDTH-style" reduced precision) ----------------------------
+@pytest.mark.parametrize("rows,cols,nnz,k,seed", [(3000, 512, 40, 100, 1), (60000, 512, 40, 100, 2),
+                                                  (20000, 1024, 20, 8, 3), (5000, 3000, 30, 50, 4)])
+def test_q1_7_bit_exact_against_integer_model(pkg, oracle, rows, cols, nnz, k, seed):
+    m = pkg.generate_matrix(rows, cols, nnz, "gamma", seed)
+    eng = pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, k=k, device=0, precision=pkg.Q1_7)
+    assert eng.info()["precision"] == pkg.Q1_7 and eng.info()["packed_bytes"] < 3.2 * m.nnz + 64 * rows
+    for q in range(2):
+        x = pkg.create_sample_vector(cols, True, False, True, 10 * seed + q + 1)
+        eng.reset(x)
+        eng()
+        val, idx = eng.read_result()
+        y, present = oracle.q17_scores(m.row, m.col, m.val, x, m.rows)
+        ei, ev = oracle.select_topk(y, present, k)
+        assert np.array_equal(idx, ei), "index list differs from the integer model"
+        assert np.array_equal(val.view(np.uint32), ev.view(np.uint32))
+        ys = eng.scores()
+        assert np.array_equal(ys.view(np.uint32), y.view(np.uint32))  # every row, bit for bit
+    eng.close()
+
+
+def test_q1_7_wraps_and_saturates_like_the_model(pkg, oracle):
+    """Values above 1.0, long rows and a large x: products wrap at 2.0, sums wrap at 2.0, conversion saturates."""
+    rng = np.random.RandomState(0)
+    lens = [300, 5, 1, 64, 257, 2, 900] * 20
+    r, c, v = [], [], []
+    for i, n in enumerate(lens):
+        r += [i] * n
+        c += np.sort(rng.randint(0, 64, n)).tolist()
+        v += (rng.rand(n) * 2.5).astype(np.float32).tolist()  # some above the Q1.7 range
+    m = pkg.CooMatrix(len(lens), 64, np.array(r, np.uint32), np.array(c, np.uint32), np.array(v, np.float32))
+    x = (rng.rand(64) * 1.9).astype(np.float32)
+    eng = pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, vec=x, k=16, device=0, precision=pkg.Q1_7)
+    eng()
+    val, idx = eng.read_result()
+    y, present = oracle.q17_scores(m.row, m.col, m.val, x, m.rows)
+    ei, ev = oracle.select_topk(y, present, 16)
+    assert np.array_equal(idx, ei) and np.array_equal(val, ev)
+    assert np.array_equal(eng.scores(), y)
+    eng.close()
+
+
+def test_q1_7_full_size_config(pkg, oracle):
+    """BASELINE configs[4]: 1M x 512, 40 nnz/row, K=100. Bit-exact against the integer model; precision@100 against
+    the fp32 gold is REPORTED (8-bit scores of ~20-term dot products are very coarse), not asserted beyond sanity."""
+    m = pkg.generate_matrix(1000000, 512, 40, "gamma", 5)
+    x = pkg.create_sample_vector(512, True, False, True, 31)
+    eng = pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, vec=x, k=100, device=0, precision=pkg.Q1_7)
+    eng()
+    val, idx = eng.read_result()
+    y, present = oracle.q17_scores(m.row, m.col, m.val, x, m.rows)
+    ei, ev = oracle.select_topk(y, present, 100)
+    assert np.array_equal(idx, ei) and np.array_equal(val, ev)
+    gi, _ = oracle.gold_topk(m.row, m.col, m.val, x, 100)
+    precision = len(set(idx.tolist()) & set(gi.tolist())) / 100.0
+    print(f"Q1.7 precision@100 vs fp32 gold: {precision:.2f}")
+    assert 0.0 <= precision <= 1.0
+    eng.close()
+
+
+@pytest.mark.parametrize("rows,cols,nnz,k,seed", [(3000, 512, 40, 100, 1), (60000, 512, 40, 100, 2),
+                                                  (20000, 1024, 20, 8, 3), (5000, 3000, 30, 50, 4)])
+def test_q1_7_wide_bit_exact_against_integer_model(pkg, oracle, rows, cols, nnz, k, seed):
+    m = pkg.generate_matrix(rows, cols, nnz, "gamma", seed)
+    eng = pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, k=k, device=0, precision=pkg.Q1_7_WIDE)
+    for q in range(2):
+        x = pkg.create_sample_vector(cols, True, False, True, 10 * seed + q + 1)
+        if q == 1:
+            x = x * 0.01  # a different block scale
+        eng.reset(x)
+        eng()
+        val, idx = eng.read_result()
+        y, present, sh = oracle.q17_wide_scores(m.row, m.col, m.val, x, m.rows)
+        assert sh > 0
+        ei, ev = oracle.select_topk(y, present, k)
+        assert np.array_equal(idx, ei), "index list differs from the integer model"
+        assert np.array_equal(val.view(np.uint32), ev.view(np.uint32))
+        assert np.array_equal(eng.scores().view(np.uint32), y.view(np.uint32))
+    eng.close()
+
+
+def test_q1_7_wide_full_size_config_has_usable_precision(pkg, oracle):
+    """BASELINE configs[4] shape with the wide-accumulation variant: bit-exact against its integer model and a
+    precision@100 against the fp32 gold that is actually usable (the strict 8-bit variant scores 0.00 here)."""
+    m = pkg.generate_matrix(1000000, 512, 40, "gamma", 5)
+    x = pkg.create_sample_vector(512, True, False, True, 31)
+    eng = pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, vec=x, k=100, device=0, precision=pkg.Q1_7_WIDE)
+    eng()
+    val, idx = eng.read_result()
+    y, present, sh = oracle.q17_wide_scores(m.row, m.col, m.val, x, m.rows)
+    ei, ev = oracle.select_topk(y, present, 100)
+    assert np.array_equal(idx, ei) and np.array_equal(val, ev)
+    gi, gv = oracle.gold_topk(m.row, m.col, m.val, x, 100)
+    precision = len(set(idx.tolist()) & set(gi.tolist())) / 100.0
+    print(f"Q1.7-wide precision@100 vs fp32 gold: {precision:.2f} (block scale 2^{sh})")
+    assert precision >= 0.5
+    assert np.allclose(val[0], gv[0], rtol=0.25)  # truncation at every step biases the scores low, uniformly
+    eng.close()
