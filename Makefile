@@ -16,12 +16,12 @@ REF   := oracle/_ref/libref_gold.so
 
 # -ffp-contract=off: products and sums are separately rounded on both sides so the packed-order oracle can be
 # matched bit for bit.
-HIPFLAGS := -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -ffp-contract=off -Wall -Wno-unused-result
+HIPFLAGS := -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -ffp-contract=off -Wall -Wno-unused-result -ldl
 CXXFLAGS := -O2 -std=c++17 -fPIC -ffp-contract=off -Wall
 CFLAGS   := -O2 -std=c11 -fPIC -ffp-contract=off -Wall -pthread
 
 HOST_SRCS := $(CSRC)/wbscsr.cpp $(CSRC)/host_utils.cpp $(CSRC)/c_api.cpp
-HIP_SRCS  := $(CSRC)/engine.hip
+HIP_SRCS  := $(CSRC)/engine.hip $(CSRC)/dist.hip
 HDRS      := $(wildcard $(CSRC)/*.hpp) include/tkspmv.h
 
 all: $(LIB) $(EXE) $(ORACLE)

@@ -81,6 +81,9 @@ EXPORTED_SYMBOLS = [
     "tkspmv_profile", "tkspmv_last_error", "tkspmv_device_count", "tkspmv_mtx_read", "tkspmv_mtx_free",
     "tkspmv_mtx_write", "tkspmv_sample_vector", "tkspmv_generate", "tkspmv_options_parse", "tkspmv_pack",
     "tkspmv_packed_info", "tkspmv_packed_decode", "tkspmv_packed_raw", "tkspmv_packed_free",
+    "tkspmv_dist_unique_id", "tkspmv_dist_create", "tkspmv_dist_set_batch", "tkspmv_dist_enqueue", "tkspmv_dist_run_many",
+    "tkspmv_dist_synchronize", "tkspmv_dist_read", "tkspmv_dist_destroy", "tkspmv_dist_last_error",
+    "tkspmv_merge_topk",
 ]
 
 _lib = None
@@ -127,6 +130,17 @@ def lib():
                                     C.POINTER(u32p), C.POINTER(C.c_uint32)]
     L.tkspmv_packed_free.argtypes = [vp]
     L.tkspmv_packed_free.restype = None
+    L.tkspmv_dist_last_error.restype = C.c_char_p
+    L.tkspmv_dist_unique_id.argtypes = [C.POINTER(C.c_uint8)]
+    L.tkspmv_dist_create.argtypes = [C.POINTER(vp), vp, C.POINTER(C.c_uint8), C.c_int32, C.c_int32]
+    L.tkspmv_dist_set_batch.argtypes = [vp, C.c_int32]
+    L.tkspmv_dist_enqueue.argtypes = [vp, vp]
+    L.tkspmv_dist_run_many.argtypes = [vp, vp, C.c_int32, C.c_int32]
+    L.tkspmv_dist_synchronize.argtypes = [vp]
+    L.tkspmv_dist_read.argtypes = [vp, u32p, f32p, C.POINTER(C.c_int32)]
+    L.tkspmv_dist_destroy.argtypes = [vp]
+    L.tkspmv_dist_destroy.restype = None
+    L.tkspmv_merge_topk.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, vp]
     _lib = L
     return L
 
@@ -134,3 +148,8 @@ def lib():
 def check(status):
     if status != OK:
         raise TkspmvError(status, lib().tkspmv_last_error().decode("utf-8", "replace"))
+
+
+def check_dist(status):
+    if status != OK:
+        raise TkspmvError(status, lib().tkspmv_dist_last_error().decode("utf-8", "replace"))

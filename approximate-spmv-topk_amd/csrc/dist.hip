@@ -1,0 +1,334 @@
+// dist.hip -- row-sharded multi-GPU step in native code: per query, the local fused kernel, ONE RCCL all-gather of
+// k (row, score) pairs per rank over xGMI, and a merge kernel; queries are exchanged in batches (default 8: one all-gather and one merge
+// launch per batch) on a side stream while the stream kernels of the next batch already run (two buffer sets, events
+// both ways).
+//
+// The reference is single-device: its row partitions are merged on the host (src/fpga/src/host_spmv_bscsr.cpp:399-448,
+// `local + first_row` at :415). This is that merge one level up. RCCL is loaded with dlopen at
+// tkspmv_dist_create, so the library has no link-time dependency on it and a missing/incompatible RCCL is an error
+// code, not a crash (bench.py then falls back to torch.distributed for the exchange).
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/tkspmv.h"
+#include "engine.hpp"
+
+namespace tkspmv {
+
+// ---- minimal RCCL surface (rccl.h: ncclGetUniqueId, ncclCommInitRank, ncclAllGather, ncclCommDestroy) ---------------
+struct NcclUniqueId {
+    char internal[128];
+};
+typedef void *nccl_comm_t;
+struct Rccl {
+    void *handle = nullptr;
+    int (*GetUniqueId)(NcclUniqueId *) = nullptr;
+    int (*CommInitRank)(nccl_comm_t *, int, NcclUniqueId, int) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int /*dtype*/, nccl_comm_t, hipStream_t) = nullptr;
+    int (*CommDestroy)(nccl_comm_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    bool load(std::string &err) {
+        if (handle) return true;
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char *n : names) {
+            handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (handle) break;
+        }
+        if (!handle) {
+            err = std::string("cannot load RCCL: ") + dlerror();
+            return false;
+        }
+        GetUniqueId = (int (*)(NcclUniqueId *))dlsym(handle, "ncclGetUniqueId");
+        CommInitRank = (int (*)(nccl_comm_t *, int, NcclUniqueId, int))dlsym(handle, "ncclCommInitRank");
+        AllGather = (int (*)(const void *, void *, size_t, int, nccl_comm_t, hipStream_t))dlsym(handle, "ncclAllGather");
+        CommDestroy = (int (*)(nccl_comm_t))dlsym(handle, "ncclCommDestroy");
+        GetErrorString = (const char *(*)(int))dlsym(handle, "ncclGetErrorString");
+        if (!GetUniqueId || !CommInitRank || !AllGather || !CommDestroy) {
+            err = "RCCL is missing an expected symbol";
+            return false;
+        }
+        return true;
+    }
+};
+static Rccl g_rccl;
+constexpr int NCCL_INT32 = 2;  // ncclInt32 / ncclInt
+
+// ---- merge kernel ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t order_key_d(float f) {
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+constexpr uint32_t MERGE_THREADS = 1024;
+constexpr uint32_t MERGE_MAX = 8192;  // world * k
+
+// gathered: [world][n_q][2][k] u32 (row ids, then score bits); block q merges query q of the batch. Output: the k best
+// by (score desc, row desc); equal keys (the (0, 0.0) fillers several shards may contribute) are ordered by position,
+// so ranks stay unique.
+__global__ void __launch_bounds__(MERGE_THREADS) merge_kernel(const uint32_t *__restrict__ gathered, uint32_t world,
+                                                              uint32_t k, uint32_t *__restrict__ out_idx,
+                                                              float *__restrict__ out_val) {
+    __shared__ unsigned long long keys[MERGE_MAX + 8];
+    const uint32_t n = world * k, tid = threadIdx.x, q = blockIdx.x, n_q = gridDim.x;
+    out_idx += (size_t)q * k;
+    out_val += (size_t)q * k;
+    for (uint32_t i = tid; i < n; i += MERGE_THREADS) {
+        const uint32_t r = i / k, j = i % k;
+        const uint32_t *src = gathered + ((size_t)r * n_q + q) * 2 * k;
+        keys[i] = ((unsigned long long)order_key_d(__uint_as_float(src[k + j])) << 32) | src[j];
+    }
+    if (tid < 8) keys[n + tid] = 0ull;
+    __syncthreads();
+    const uint32_t n_pad = (n + 7u) & ~7u;
+    for (uint32_t i = tid; i < n; i += MERGE_THREADS) {
+        const unsigned long long kx = keys[i];
+        uint32_t r = 0;
+        for (uint32_t j = 0; j < n_pad; j += 8) {
+#pragma unroll
+            for (uint32_t u = 0; u < 8; ++u) {
+                const unsigned long long o = keys[j + u];
+                r += (o > kx) || (o == kx && (j + u) < i);
+            }
+        }
+        if (r < k) {
+            const uint32_t key32 = (uint32_t)(kx >> 32);
+            const uint32_t u = (key32 & 0x80000000u) ? (key32 & 0x7FFFFFFFu) : ~key32;
+            out_idx[r] = (uint32_t)(kx & 0xFFFFFFFFull);
+            out_val[r] = __uint_as_float(u);
+        }
+    }
+}
+
+constexpr int MAX_BATCH = 32;
+
+struct Dist {
+    Engine *engine = nullptr;
+    int device = 0, rank = 0, world = 1, k = 0;
+    bool use_nccl = false;  // world > 1, or TKSPMV_DIST_FORCE_NCCL=1 (exercises the RCCL calls with one rank)
+    nccl_comm_t comm = nullptr;
+    hipStream_t compute = nullptr, comm_stream = nullptr;
+    hipEvent_t ev_comp[2] = {nullptr, nullptr}, ev_merge[2] = {nullptr, nullptr};
+    // Queries are exchanged in batches of up to `batch`: one all-gather and one merge launch per batch, so the
+    // collective's latency and the host's enqueue cost are paid once per batch. Two buffer sets alternate.
+    int batch = 8;
+    uint32_t *local[2] = {nullptr, nullptr};     // [batch][2k]: k row ids, k score bits per query
+    uint32_t *gathered[2] = {nullptr, nullptr};  // [world][n_q][2k]
+    uint32_t *out_idx[2] = {nullptr, nullptr};   // [batch][k]
+    float *out_val[2] = {nullptr, nullptr};
+    uint64_t steps = 0;    // queries enqueued
+    uint64_t flushes = 0;  // batches exchanged
+    int fill = 0;          // queries in the open batch (buffer set flushes & 1)
+    int last_set = -1, last_slot = -1;  // where the most recent query's merged result lands
+};
+
+}  // namespace tkspmv
+
+using namespace tkspmv;
+
+struct tkspmv_dist {
+    Dist d;
+};
+struct tkspmv_engine {  // same definition as in c_api.cpp
+    Engine *e;
+};
+
+static thread_local std::string g_dist_err;
+static int dfail(int code, const std::string &msg) {
+    g_dist_err = msg;
+    return code;
+}
+#define DHIP(expr)                                                                                          \
+    do {                                                                                                    \
+        hipError_t _e = (expr);                                                                             \
+        if (_e != hipSuccess) return dfail(TKSPMV_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+extern "C" {
+
+const char *tkspmv_dist_last_error(void) { return g_dist_err.c_str(); }
+
+int tkspmv_dist_unique_id(uint8_t *out128) {
+    if (!out128) return dfail(TKSPMV_ERR_INVALID, "NULL argument");
+    std::string err;
+    if (!g_rccl.load(err)) return dfail(TKSPMV_ERR_UNSUPPORTED, err);
+    NcclUniqueId id;
+    int rc = g_rccl.GetUniqueId(&id);
+    if (rc != 0) return dfail(TKSPMV_ERR_DEVICE, "ncclGetUniqueId failed");
+    std::memcpy(out128, id.internal, 128);
+    return TKSPMV_OK;
+}
+
+int tkspmv_merge_topk(const uint32_t *dev_gathered, int32_t world, int32_t k, uint32_t *dev_idx, float *dev_val,
+                      void *stream) {
+    if (!dev_gathered || !dev_idx || !dev_val || world < 1 || k < 1 || (uint64_t)world * k > MERGE_MAX)
+        return dfail(TKSPMV_ERR_INVALID, "bad arguments to tkspmv_merge_topk (world * k must be <= 8192)");
+    hipLaunchKernelGGL(merge_kernel, dim3(1), dim3(MERGE_THREADS), 0, (hipStream_t)stream, dev_gathered, (uint32_t)world,
+                       (uint32_t)k, dev_idx, dev_val);
+    DHIP(hipGetLastError());
+    return TKSPMV_OK;
+}
+
+int tkspmv_dist_create(tkspmv_dist_t **out, tkspmv_t *engine, const uint8_t *id128, int32_t rank, int32_t world) {
+    if (!out || !engine || world < 1 || rank < 0 || rank >= world) return dfail(TKSPMV_ERR_INVALID, "bad arguments");
+    *out = nullptr;
+    tkspmv_info info;
+    engine->e->info(&info);
+    if ((uint64_t)world * info.k > MERGE_MAX) return dfail(TKSPMV_ERR_INVALID, "world * k must be <= 8192");
+    tkspmv_dist *h = new tkspmv_dist();
+    Dist &d = h->d;
+    d.engine = engine->e;
+    d.device = info.device;
+    d.rank = rank;
+    d.world = world;
+    d.k = info.k;
+    DHIP(hipSetDevice(d.device));
+    d.use_nccl = world > 1 || getenv("TKSPMV_DIST_FORCE_NCCL") != nullptr;
+    if (d.use_nccl) {
+        if (!id128) {
+            delete h;
+            return dfail(TKSPMV_ERR_INVALID, "world > 1 needs the unique id of rank 0");
+        }
+        std::string err;
+        if (!g_rccl.load(err)) {
+            delete h;
+            return dfail(TKSPMV_ERR_UNSUPPORTED, err);
+        }
+        NcclUniqueId id;
+        std::memcpy(id.internal, id128, 128);
+        int rc = g_rccl.CommInitRank(&d.comm, world, id, rank);
+        if (rc != 0) {
+            delete h;
+            return dfail(TKSPMV_ERR_DEVICE, std::string("ncclCommInitRank failed: ") +
+                                                (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?"));
+        }
+    }
+    if (const char *e = getenv("TKSPMV_DIST_BATCH")) d.batch = atoi(e);
+    if (d.batch < 1) d.batch = 1;
+    if (d.batch > MAX_BATCH) d.batch = MAX_BATCH;
+    DHIP(hipStreamCreateWithFlags(&d.compute, hipStreamNonBlocking));
+    DHIP(hipStreamCreateWithFlags(&d.comm_stream, hipStreamNonBlocking));
+    for (int b = 0; b < 2; ++b) {
+        DHIP(hipEventCreateWithFlags(&d.ev_comp[b], hipEventDisableTiming));
+        DHIP(hipEventCreateWithFlags(&d.ev_merge[b], hipEventDisableTiming));
+        DHIP(hipMalloc((void **)&d.local[b], (size_t)MAX_BATCH * 2 * d.k * 4));
+        DHIP(hipMalloc((void **)&d.gathered[b], (size_t)world * MAX_BATCH * 2 * d.k * 4));
+        DHIP(hipMalloc((void **)&d.out_idx[b], (size_t)MAX_BATCH * d.k * 4));
+        DHIP(hipMalloc((void **)&d.out_val[b], (size_t)MAX_BATCH * d.k * 4));
+        DHIP(hipMemset(d.out_idx[b], 0, (size_t)MAX_BATCH * d.k * 4));
+        DHIP(hipMemset(d.out_val[b], 0, (size_t)MAX_BATCH * d.k * 4));
+    }
+    DHIP(hipDeviceSynchronize());
+    *out = h;
+    return TKSPMV_OK;
+}
+
+int tkspmv_dist_set_batch(tkspmv_dist_t *h, int32_t batch) {
+    if (!h || batch < 1 || batch > MAX_BATCH) return dfail(TKSPMV_ERR_INVALID, "batch must be in [1, 32]");
+    if (h->d.fill != 0) return dfail(TKSPMV_ERR_STATE, "a batch is open: synchronize first");
+    h->d.batch = batch;
+    return TKSPMV_OK;
+}
+
+// Exchange the open batch: all-gather of fill * 2k words per rank and one merge block per query, on the comm stream.
+static int dist_flush(Dist &d) {
+    if (d.fill == 0) return TKSPMV_OK;
+    const int b = (int)(d.flushes & 1);
+    const int n_q = d.fill;
+    DHIP(hipEventRecord(d.ev_comp[b], d.compute));
+    DHIP(hipStreamWaitEvent(d.comm_stream, d.ev_comp[b], 0));
+    if (d.use_nccl) {
+        int rc = g_rccl.AllGather(d.local[b], d.gathered[b], (size_t)n_q * 2 * d.k, NCCL_INT32, d.comm, d.comm_stream);
+        if (rc != 0) return dfail(TKSPMV_ERR_DEVICE, "ncclAllGather failed");
+    } else {
+        DHIP(hipMemcpyAsync(d.gathered[b], d.local[b], (size_t)n_q * 2 * d.k * 4, hipMemcpyDeviceToDevice, d.comm_stream));
+    }
+    hipLaunchKernelGGL(merge_kernel, dim3(n_q), dim3(MERGE_THREADS), 0, d.comm_stream, d.gathered[b], (uint32_t)d.world,
+                       (uint32_t)d.k, d.out_idx[b], d.out_val[b]);
+    DHIP(hipGetLastError());
+    DHIP(hipEventRecord(d.ev_merge[b], d.comm_stream));
+    d.fill = 0;
+    ++d.flushes;
+    return TKSPMV_OK;
+}
+
+// One query, asynchronously: local kernel on the compute stream; the batch it completes is exchanged on the comm
+// stream. Every rank must issue the same sequence of enqueue / synchronize / read calls (they are collective).
+int tkspmv_dist_enqueue(tkspmv_dist_t *h, const float *dev_x) {
+    if (!h || !dev_x) return dfail(TKSPMV_ERR_INVALID, "NULL argument");
+    Dist &d = h->d;
+    const int b = (int)(d.flushes & 1);
+    DHIP(hipSetDevice(d.device));
+    if (d.fill == 0 && d.flushes >= 2) DHIP(hipStreamWaitEvent(d.compute, d.ev_merge[b], 0));  // set b is free again
+    uint32_t *dst = d.local[b] + (size_t)d.fill * 2 * d.k;
+    std::string err;
+    int st = d.engine->enqueue(dev_x, dst, reinterpret_cast<float *>(dst + d.k), d.compute, err);
+    if (st != TKSPMV_OK) return dfail(st, err);
+    d.last_set = b;
+    d.last_slot = d.fill;
+    ++d.fill;
+    ++d.steps;
+    if (d.fill == d.batch) return dist_flush(d);
+    return TKSPMV_OK;
+}
+
+int tkspmv_dist_run_many(tkspmv_dist_t *h, const float *dev_xs, int32_t n_x, int32_t count) {
+    if (!h || !dev_xs || n_x < 1 || count < 0) return dfail(TKSPMV_ERR_INVALID, "bad arguments");
+    tkspmv_info info;
+    h->d.engine->info(&info);
+    for (int i = 0; i < count; ++i) {
+        int st = tkspmv_dist_enqueue(h, dev_xs + (size_t)(i % n_x) * info.cols);
+        if (st != TKSPMV_OK) return st;
+    }
+    return dist_flush(h->d);
+}
+
+int tkspmv_dist_synchronize(tkspmv_dist_t *h) {
+    if (!h) return dfail(TKSPMV_ERR_INVALID, "NULL argument");
+    DHIP(hipSetDevice(h->d.device));
+    int st = dist_flush(h->d);
+    if (st != TKSPMV_OK) return st;
+    DHIP(hipStreamSynchronize(h->d.compute));
+    DHIP(hipStreamSynchronize(h->d.comm_stream));
+    return TKSPMV_OK;
+}
+
+// Merged (global) top-k of the most recently enqueued query; waits for it.
+int tkspmv_dist_read(tkspmv_dist_t *h, uint32_t *idx, float *val, int32_t *n) {
+    if (!h) return dfail(TKSPMV_ERR_INVALID, "NULL argument");
+    Dist &d = h->d;
+    if (d.steps == 0) return dfail(TKSPMV_ERR_STATE, "no query has been enqueued");
+    int st = tkspmv_dist_synchronize(h);
+    if (st != TKSPMV_OK) return st;
+    const int b = d.last_set;
+    const size_t off = (size_t)d.last_slot * d.k;
+    if (idx) DHIP(hipMemcpy(idx, d.out_idx[b] + off, (size_t)d.k * 4, hipMemcpyDeviceToHost));
+    if (val) DHIP(hipMemcpy(val, d.out_val[b] + off, (size_t)d.k * 4, hipMemcpyDeviceToHost));
+    if (n) *n = d.k;
+    return TKSPMV_OK;
+}
+
+void tkspmv_dist_destroy(tkspmv_dist_t *h) {
+    if (!h) return;
+    Dist &d = h->d;
+    (void)hipSetDevice(d.device);
+    if (d.compute) (void)hipStreamSynchronize(d.compute);
+    if (d.comm_stream) (void)hipStreamSynchronize(d.comm_stream);
+    if (d.comm && g_rccl.CommDestroy) g_rccl.CommDestroy(d.comm);
+    for (int b = 0; b < 2; ++b) {
+        if (d.ev_comp[b]) (void)hipEventDestroy(d.ev_comp[b]);
+        if (d.ev_merge[b]) (void)hipEventDestroy(d.ev_merge[b]);
+        if (d.local[b]) (void)hipFree(d.local[b]);
+        if (d.gathered[b]) (void)hipFree(d.gathered[b]);
+        if (d.out_idx[b]) (void)hipFree(d.out_idx[b]);
+        if (d.out_val[b]) (void)hipFree(d.out_val[b]);
+    }
+    if (d.compute) (void)hipStreamDestroy(d.compute);
+    if (d.comm_stream) (void)hipStreamDestroy(d.comm_stream);
+    delete h;
+}
+
+}  // extern "C"

@@ -102,3 +102,78 @@ class ShardedTopK:
     def step(self):
         self.exchange()
         return self.merge()
+
+
+class NativeShardedSpMV:
+    """The same step in native code (csrc/dist.hip): local kernel, RCCL all-gather of k pairs per rank and merge
+    kernel; queries are exchanged in batches (default 8) on a side stream, overlapping the kernels of the next batch. torch.distributed is only used to ship
+    rank 0's RCCL unique id. Raises TkspmvError (e.g. ERR_UNSUPPORTED when RCCL cannot be loaded): callers fall back
+    to ShardedTopK."""
+
+    def __init__(self, engine, device, group=None):
+        import ctypes as C
+        from . import _lib
+        self._lib, self._C = _lib, C
+        self.engine = engine
+        self.k = engine.k
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+        idbuf = (C.c_uint8 * 128)()
+        import os
+        if world > 1 or os.environ.get("TKSPMV_DIST_FORCE_NCCL"):
+            t = torch.zeros(128, dtype=torch.uint8, device=device)
+            if rank == 0:
+                _lib.check_dist(_lib.lib().tkspmv_dist_unique_id(idbuf))
+                t.copy_(torch.tensor(list(idbuf), dtype=torch.uint8))
+            if world > 1:
+                dist.broadcast(t, src=0, group=group)
+            for i, b in enumerate(t.cpu().tolist()):
+                idbuf[i] = b
+        self._h = C.c_void_p()
+        _lib.check_dist(_lib.lib().tkspmv_dist_create(C.byref(self._h), engine._h, idbuf, rank, world))
+        self.world, self.rank = world, rank
+
+    def set_batch(self, batch):
+        """Queries per exchange (1..32, default 8): one all-gather + one merge launch per batch."""
+        self._lib.check_dist(self._lib.lib().tkspmv_dist_set_batch(self._h, int(batch)))
+
+    def enqueue(self, dev_x_ptr):
+        self._lib.check_dist(self._lib.lib().tkspmv_dist_enqueue(self._h, self._C.c_void_p(int(dev_x_ptr))))
+
+    def run_many(self, dev_xs_ptr, n_x, count):
+        self._lib.check_dist(self._lib.lib().tkspmv_dist_run_many(self._h, self._C.c_void_p(int(dev_xs_ptr)), n_x, count))
+
+    def synchronize(self):
+        self._lib.check_dist(self._lib.lib().tkspmv_dist_synchronize(self._h))
+
+    def read(self):
+        C = self._C
+        idx = np.empty(self.k, dtype=np.uint32)
+        val = np.empty(self.k, dtype=np.float32)
+        n = C.c_int32()
+        self._lib.check_dist(self._lib.lib().tkspmv_dist_read(self._h, idx.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                                             val.ctypes.data_as(C.POINTER(C.c_float)), C.byref(n)))
+        return val, idx
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.lib().tkspmv_dist_destroy(self._h)
+            self._h = self._C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def merge_topk_device(gathered_i32, world, k, stream=0):
+    """The native merge kernel on a [world][2][k] int32 CUDA tensor; returns (idx int32[k], val float32[k]) tensors."""
+    import ctypes as C
+    from . import _lib
+    out_idx = torch.zeros(k, dtype=torch.int32, device=gathered_i32.device)
+    out_val = torch.zeros(k, dtype=torch.float32, device=gathered_i32.device)
+    _lib.check_dist(_lib.lib().tkspmv_merge_topk(C.c_void_p(gathered_i32.data_ptr()), world, k,
+                                                 C.c_void_p(out_idx.data_ptr()), C.c_void_p(out_val.data_ptr()),
+                                                 C.c_void_p(int(stream))))
+    return out_idx, out_val

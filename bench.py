@@ -99,7 +99,10 @@ def main():
         sys.exit(2)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # TKSPMV_BENCH_FORCE_DIST=1 under torch.distributed.run with ONE rank takes the N > 1 code path (a one-rank
+    # RCCL communicator): the way to exercise that path on a single-GPU box.
+    multi = world > 1 or (os.environ.get("TKSPMV_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
+    if multi:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 
@@ -114,12 +117,12 @@ def main():
 
     def sync_all():
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             import torch.distributed as dist
             dist.barrier()
             torch.cuda.synchronize()
 
-    if world == 1:
+    if not multi:
         # ---- N = 1: K queries back to back on the engine stream -------------------------------------------------
         eng.enqueue_many(dxs.data_ptr(), a.queries, a.warmup)
         eng.synchronize()
@@ -165,22 +168,60 @@ def main():
         import torch.distributed as dist
         from importlib import import_module
         dmod = import_module("approximate_spmv_topk_amd.distributed")
-        sh = dmod.ShardedTopK(a.k, dev)
-        idx_v, val_v = sh.local_views()
-        stream = torch.cuda.current_stream().cuda_stream
+        native = None
+        if os.environ.get("TKSPMV_DIST", "native") == "native":
+            try:  # native RCCL exchange (csrc/dist.hip); any rank failing makes every rank fall back
+                native = dmod.NativeShardedSpMV(eng, dev)
+                ok = torch.ones(1, device=dev)
+            except Exception as e:  # noqa: BLE001
+                print(f"[rank {rank}] native exchange unavailable ({e}); using torch.distributed", file=sys.stderr)
+                ok = torch.zeros(1, device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if ok.item() == 0 and native is not None:
+                native.close()
+                native = None
+        if native is not None:
+            native.run_many(dxs.data_ptr(), a.queries, a.warmup)
+            native.synchronize()
+            sync_all()
+            t0 = time.perf_counter()
+            native.run_many(dxs.data_ptr(), a.queries, a.steps)
+            native.synchronize()
+            sync_all()
+            elapsed = time.perf_counter() - t0
+            exchange = ("native: RCCL ncclAllGather of 2*K int32 per rank and query + merge kernel, 8 queries per exchange, on a "
+                        "side stream overlapping the next batch's stream kernels (csrc/dist.hip)")
+            # outside the timed region: the last query again through torch.distributed's all-gather + torch merge
+            val_n, idx_n = native.read()
+            native.close()
+            sh = dmod.ShardedTopK(a.k, dev)
+            idx_v, val_v = sh.local_views()
+            eng.enqueue(dxs[(a.steps - 1) % a.queries].data_ptr(), idx_v.data_ptr(), val_v.data_ptr(),
+                        torch.cuda.current_stream().cuda_stream)
+            ei, ev = sh.step()
+            same = (np.array_equal(ei.cpu().numpy().astype(np.uint32), idx_n)
+                    and np.array_equal(ev.cpu().numpy(), val_n))
+            exchange += "; cross-check against the torch.distributed exchange: " + ("identical" if same else "MISMATCH")
+            if not same:
+                print(f"[rank {rank}] native exchange result differs from the torch.distributed exchange", file=sys.stderr)
+        else:
+            sh = dmod.ShardedTopK(a.k, dev)
+            idx_v, val_v = sh.local_views()
+            stream = torch.cuda.current_stream().cuda_stream
 
-        def step(i):
-            eng.enqueue(dxs[i % a.queries].data_ptr(), idx_v.data_ptr(), val_v.data_ptr(), stream)
-            return sh.step()
+            def step(i):
+                eng.enqueue(dxs[i % a.queries].data_ptr(), idx_v.data_ptr(), val_v.data_ptr(), stream)
+                return sh.step()
 
-        for i in range(a.warmup):
-            step(i)
-        sync_all()
-        t0 = time.perf_counter()
-        for i in range(a.steps):
-            out = step(i)
-        sync_all()
-        elapsed = time.perf_counter() - t0
+            for i in range(a.warmup):
+                step(i)
+            sync_all()
+            t0 = time.perf_counter()
+            for i in range(a.steps):
+                step(i)
+            sync_all()
+            elapsed = time.perf_counter() - t0
+            exchange = "torch.distributed all_gather_into_tensor of 2*K int32 per rank + on-device merge, every step"
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -188,8 +229,9 @@ def main():
         kernel_ns = prof["query_ns"]
         units = a.steps * world
         extra = {"global_queries_per_sec": a.steps / elapsed,
-                 "kernels_us": {"stream": prof["stream_kernel_ns"] / 1e3, "select": prof["select_kernel_ns"] / 1e3},
-                 "exchange": "all_gather_into_tensor of 2*K int32 per rank + on-device merge, every step"}
+                 "kernels_us": {"stream": prof["stream_kernel_ns"] / 1e3, "select": prof["select_kernel_ns"] / 1e3,
+                                "query_back_to_back": prof["query_ns"] / 1e3},
+                 "exchange": exchange}
 
     if rank == 0:
         line = {
@@ -216,7 +258,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(mod, m, xs, a.k, a.cpu_seconds)
         print(json.dumps(line))
     eng.close()
-    if world > 1:
+    if multi:
         import torch.distributed as dist
         dist.destroy_process_group()
 

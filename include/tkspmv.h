@@ -154,6 +154,31 @@ int tkspmv_profile(tkspmv_t *e, const float *dev_xs, int32_t n_x, int32_t iters,
 const char *tkspmv_last_error(void);
 int tkspmv_device_count(void);
 
+/* ---- row-sharded multi-GPU step (one process per GPU) ---------------------------------------------------------
+ * The reference merges its row partitions on the host (src/fpga/src/host_spmv_bscsr.cpp:399-448, global id =
+ * local + first_row at :415). One level up: every rank owns an engine over its row shard (desc.first_row = first
+ * global row), per query the local fused kernel, ONE RCCL all-gather of k (row, score) pairs per rank and a merge
+ * kernel. Queries are exchanged in batches (default 8, TKSPMV_DIST_BATCH / tkspmv_dist_set_batch; 1 = every query on
+ * its own): one all-gather and one merge launch per batch on a side stream, overlapping the kernels of the next batch
+ * (two buffer sets). synchronize / read flush an open batch. Every rank must issue the same call sequence. RCCL is
+ * loaded with dlopen inside tkspmv_dist_create / tkspmv_dist_unique_id: TKSPMV_ERR_UNSUPPORTED if it cannot be loaded. */
+typedef struct tkspmv_dist tkspmv_dist_t;
+/* rank 0 creates the 128-byte RCCL unique id and ships it to the other ranks (any transport). */
+int tkspmv_dist_unique_id(uint8_t *out128);
+/* id128 may be NULL when world == 1. The engine must outlive the returned object. */
+int tkspmv_dist_create(tkspmv_dist_t **out, tkspmv_t *engine, const uint8_t *id128, int32_t rank, int32_t world);
+int tkspmv_dist_set_batch(tkspmv_dist_t *d, int32_t batch);                    /* 1..32 queries per exchange */
+int tkspmv_dist_enqueue(tkspmv_dist_t *d, const float *dev_x);                 /* one query, asynchronous */
+int tkspmv_dist_run_many(tkspmv_dist_t *d, const float *dev_xs, int32_t n_x, int32_t count);
+int tkspmv_dist_synchronize(tkspmv_dist_t *d);
+/* merged (global) top-k of the most recently enqueued query (host buffers of k entries); waits for it */
+int tkspmv_dist_read(tkspmv_dist_t *d, uint32_t *idx, float *val, int32_t *n);
+void tkspmv_dist_destroy(tkspmv_dist_t *d);
+const char *tkspmv_dist_last_error(void);
+/* The merge step alone: dev_gathered = [world][2][k] u32 (row ids, then score bits) -> k best, sort_tuples order. */
+int tkspmv_merge_topk(const uint32_t *dev_gathered, int32_t world, int32_t k, uint32_t *dev_idx, float *dev_val,
+                      void *stream);
+
 /* ---- host-side helpers (no GPU needed) --------------------------------------------------------- */
 typedef struct {
     uint32_t rows, cols;   /* from the size line */

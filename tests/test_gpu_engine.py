@@ -360,3 +360,59 @@ def test_q1_7_wide_full_size_config_has_usable_precision(pkg, oracle):
     assert precision >= 0.5
     assert np.allclose(val[0], gv[0], rtol=0.25)  # truncation at every step biases the scores low, uniformly
     eng.close()
+
+
+# ---- multi-GPU exchange pieces that can be exercised on one GPU ------------------------------------------------------
+def test_native_merge_kernel_matches_python_merge(pkg):
+    import torch
+    from importlib import import_module
+    dmod = import_module("approximate_spmv_topk_amd.distributed")
+    rng = np.random.RandomState(1)
+    for world, k in ((2, 8), (4, 100), (8, 100), (8, 1000), (3, 7)):
+        g = np.zeros((world, 2, k), dtype=np.int32)
+        for r in range(world):
+            n_real = k if r % 2 == 0 else max(1, k // 3)  # some shards return fillers
+            sc = np.sort(rng.rand(n_real).astype(np.float32))[::-1]
+            ids = (rng.permutation(10 * k)[:n_real] + r * 10 * k).astype(np.uint32)
+            g[r, 0, :n_real] = ids.view(np.int32)
+            g[r, 1, :n_real] = sc.view(np.int32)
+        gt = torch.from_numpy(g).cuda()
+        oi, ov = dmod.merge_topk_device(gt.reshape(-1), world, k)
+        torch.cuda.synchronize()
+        idx = (gt[:, 0, :].reshape(-1).to(torch.int64)) & 0xFFFFFFFF
+        val = gt[:, 1, :].reshape(-1).contiguous().view(torch.float32)
+        ei, ev = dmod.merge_candidates(idx, val, k)
+        assert np.array_equal(oi.cpu().numpy().view(np.uint32).astype(np.int64), ei.cpu().numpy())
+        assert np.array_equal(ov.cpu().numpy(), ev.cpu().numpy())
+
+
+@pytest.mark.parametrize("force_nccl", [False, True])
+def test_native_sharded_step_single_rank(pkg, oracle, monkeypatch, force_nccl):
+    """world = 1: the pipelined native step (and, forced, a one-rank RCCL communicator with a real ncclAllGather)
+    must return exactly what the engine returns, for a stream of queries."""
+    import torch
+    from importlib import import_module
+    dmod = import_module("approximate_spmv_topk_amd.distributed")
+    if force_nccl:
+        monkeypatch.setenv("TKSPMV_DIST_FORCE_NCCL", "1")
+    m = pkg.generate_matrix(80000, 1024, 20, "gamma", 17)
+    xs = np.stack([pkg.create_sample_vector(1024, True, False, True, 900 + i) for i in range(6)])
+    dxs = torch.from_numpy(xs).cuda()
+    eng = pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, k=100, device=0, first_row=5000)
+    nat = dmod.NativeShardedSpMV(eng, torch.device("cuda", 0))
+    nat.set_batch(4)  # reads at q = 2 flush a partial batch, q = 5 lands in the middle of the next one
+    for q in range(6):
+        nat.enqueue(dxs[q].data_ptr())
+        if q in (2, 5):  # read after a few pipelined queries: the result must be that of the LAST one
+            val, idx = nat.read()
+            gi, gv = oracle.gold_topk(m.row, m.col, m.val, xs[q], 100)
+            assert set((idx - 5000).tolist()) == set(gi.tolist())
+            assert np.allclose(val, gv, rtol=1e-4, atol=0)
+    for batch in (1, 8, 32):
+        nat.set_batch(batch)
+        nat.run_many(dxs.data_ptr(), 6, 50)
+        val, idx = nat.read()
+        gi, gv = oracle.gold_topk(m.row, m.col, m.val, xs[49 % 6], 100)
+        assert set((idx - 5000).tolist()) == set(gi.tolist())
+    nat.close()
+    eng.close()
