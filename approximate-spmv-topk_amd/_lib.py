@@ -77,7 +77,7 @@ class OptionsC(C.Structure):
 # Every symbol include/tkspmv.h declares; tests check the library exports all of them.
 EXPORTED_SYMBOLS = [
     "tkspmv_create", "tkspmv_destroy", "tkspmv_get_info", "tkspmv_set_query", "tkspmv_set_query_device",
-    "tkspmv_run", "tkspmv_enqueue", "tkspmv_enqueue_many", "tkspmv_synchronize", "tkspmv_read", "tkspmv_result_device", "tkspmv_scores",
+    "tkspmv_run", "tkspmv_enqueue", "tkspmv_enqueue_many", "tkspmv_enqueue_batch", "tkspmv_synchronize", "tkspmv_read", "tkspmv_result_device", "tkspmv_scores",
     "tkspmv_profile", "tkspmv_last_error", "tkspmv_device_count", "tkspmv_mtx_read", "tkspmv_mtx_free",
     "tkspmv_mtx_write", "tkspmv_sample_vector", "tkspmv_generate", "tkspmv_options_parse", "tkspmv_pack",
     "tkspmv_packed_info", "tkspmv_packed_decode", "tkspmv_packed_raw", "tkspmv_packed_free",
@@ -110,6 +110,7 @@ def lib():
     L.tkspmv_run.argtypes = [vp, C.POINTER(C.c_double)]
     L.tkspmv_enqueue.argtypes = [vp, vp, vp, vp, vp]
     L.tkspmv_enqueue_many.argtypes = [vp, vp, C.c_int32, C.c_int32, vp]
+    L.tkspmv_enqueue_batch.argtypes = [vp, vp, C.c_int32, vp, vp, vp]
     L.tkspmv_synchronize.argtypes = [vp]
     L.tkspmv_read.argtypes = [vp, u32p, f32p, C.POINTER(C.c_int32)]
     L.tkspmv_result_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]

@@ -75,6 +75,9 @@ int tkspmv_enqueue(tkspmv_t *h, const float *dev_x, uint32_t *dev_idx, float *de
 int tkspmv_enqueue_many(tkspmv_t *h, const float *dev_xs, int32_t n_x, int32_t count, void *stream) {
     ENGINE_CALL(enqueue_many(dev_xs, n_x, count, stream, err))
 }
+int tkspmv_enqueue_batch(tkspmv_t *h, const float *dev_xs, int32_t count, uint32_t *dev_idx, float *dev_val, void *stream) {
+    ENGINE_CALL(enqueue_batch(dev_xs, count, dev_idx, dev_val, stream, err))
+}
 int tkspmv_synchronize(tkspmv_t *h) { ENGINE_CALL(synchronize(err)) }
 int tkspmv_read(tkspmv_t *h, uint32_t *idx, float *val, int32_t *n) { ENGINE_CALL(read(idx, val, n, err)) }
 int tkspmv_result_device(tkspmv_t *h, const uint32_t **dev_idx, const float **dev_val) {

@@ -238,6 +238,11 @@ static int dist_flush(Dist &d) {
     if (d.fill == 0) return TKSPMV_OK;
     const int b = (int)(d.flushes & 1);
     const int n_q = d.fill;
+    {
+        std::string err;  // the selection of the batch's last query (the others rode along with their successors)
+        int st = d.engine->drain(d.compute, err);
+        if (st != TKSPMV_OK) return dfail(st, err);
+    }
     DHIP(hipEventRecord(d.ev_comp[b], d.compute));
     DHIP(hipStreamWaitEvent(d.comm_stream, d.ev_comp[b], 0));
     if (d.use_nccl) {
@@ -265,7 +270,7 @@ int tkspmv_dist_enqueue(tkspmv_dist_t *h, const float *dev_x) {
     if (d.fill == 0 && d.flushes >= 2) DHIP(hipStreamWaitEvent(d.compute, d.ev_merge[b], 0));  // set b is free again
     uint32_t *dst = d.local[b] + (size_t)d.fill * 2 * d.k;
     std::string err;
-    int st = d.engine->enqueue(dev_x, dst, reinterpret_cast<float *>(dst + d.k), d.compute, err);
+    int st = d.engine->enqueue_deferred(dev_x, dst, reinterpret_cast<float *>(dst + d.k), d.compute, err);
     if (st != TKSPMV_OK) return dfail(st, err);
     d.last_set = b;
     d.last_slot = d.fill;

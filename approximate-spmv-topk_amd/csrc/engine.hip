@@ -64,6 +64,11 @@ struct StreamParams {
     uint32_t *ovf_count;
     uint32_t ovf_cap;
     uint32_t fused;  // 1: the last workgroup to finish runs the selection (no second launch)
+    // 1: deferred selection. Workgroup 0 of this launch selects the PREVIOUS query's top-k (its survivors sit in
+    // the other exchange-state set, complete and visible since that launch ended) and exits; workgroups 1..grid
+    // stream the current query and end with the flush. No ticket, no second launch, nothing on the critical path.
+    uint32_t deferred;
+    float *unit_inv_out;  // 1 / (score units per 1.0) of this query, for a selection that runs in a later launch
     float *scores;  // SCORES variant only
     uint32_t dbg_flags;       // ablation switches (TKSPMV_DBG_FLAGS): 1 no publish, 2 no offers, 4 no tau duty, 8 no flush
     unsigned long long *stamps;  // optional (TKSPMV_STAMPS=1): s_memtime stamps of the selection tail, last workgroup
@@ -79,6 +84,11 @@ constexpr uint32_t SLOT_INVALID = 0xFFFFFFFFu;  // row id of an unused slot
 // One lane's share of a packet. Q8 = false: C fp32 values; Q8 = true: C Q1.7 values packed four to a dword.
 // QM: 0 = fp32, 1 = Q1.7 strict (8-bit wrapping sums, the FPGA's real_type), 2 = Q1.7 values with x block-scaled by a
 // power of two per query and exact wide accumulation.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+// The packet stream is read once per query: nontemporal loads (a plain read kernel over the same bytes gains 12 %
+// from them when the stream comes from HBM, tools/stream_probe.hip).
 template <int C, bool Q8>
 struct Pkt {
     float v[Q8 ? 1 : C];
@@ -91,17 +101,17 @@ __device__ __forceinline__ void load_packet(const uint8_t *__restrict__ pk, uint
 #pragma unroll
     for (int q = 0; q < C / 4; ++q) {
         if (Q8) {
-            o.vq[Q8 ? q : 0] = *reinterpret_cast<const uint32_t *>(pk + q * 256 + lane * 4);
-            const uint2 c = *reinterpret_cast<const uint2 *>(pk + C * 64 + q * 512 + lane * 8);
+            o.vq[Q8 ? q : 0] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(pk + q * 256 + lane * 4));
+            const u32x2 c = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(pk + C * 64 + q * 512 + lane * 8));
             o.cw[2 * q + 0] = c.x;
             o.cw[2 * q + 1] = c.y;
         } else {
-            const float4 f = *reinterpret_cast<const float4 *>(pk + q * 1024 + lane * 16);
+            const f32x4 f = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(pk + q * 1024 + lane * 16));
             o.v[Q8 ? 0 : 4 * q + 0] = f.x;
             o.v[Q8 ? 0 : 4 * q + 1] = f.y;
             o.v[Q8 ? 0 : 4 * q + 2] = f.z;
             o.v[Q8 ? 0 : 4 * q + 3] = f.w;
-            const uint2 c = *reinterpret_cast<const uint2 *>(pk + C * 256 + q * 512 + lane * 8);
+            const u32x2 c = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(pk + C * 256 + q * 512 + lane * 8));
             o.cw[2 * q + 0] = c.x;
             o.cw[2 * q + 1] = c.y;
         }
@@ -131,6 +141,7 @@ struct SelectParams {
     uint32_t ovf_cap;
     uint32_t k, first_row;
     float out_scale;  // 1 for fp32; 1/128 for Q1.7 (scores travel as integer units)
+    const float *unit_inv_in;  // if set: out_scale is read from here (written by the stream kernel of that query)
     uint32_t *out_idx;
     float *out_val;
     uint32_t *gmax;
@@ -185,7 +196,8 @@ __device__ __forceinline__ uint32_t kth_largest_prefix(const uint32_t (&gk)[MAX_
 __device__ __forceinline__ void select_body(const SelectParams &P, const uint32_t tid, const uint32_t nthreads,
                                             SelectShared &S, const uint32_t dbg_flags = 0u,
                                             unsigned long long *stamps = nullptr, const float out_scale_override = 0.0f) {
-    const float out_scale = out_scale_override != 0.0f ? out_scale_override : P.out_scale;
+    const float out_scale =
+        out_scale_override != 0.0f ? out_scale_override : (P.unit_inv_in ? *P.unit_inv_in : P.out_scale);
     const uint32_t lane = tid & 63u;
     const uint32_t n_slots = P.n_wg * WG_SLOTS;  // host guarantees n_slots <= SEL_PER_THREAD * nthreads
 
@@ -398,9 +410,9 @@ __device__ __forceinline__ float tau_from_maxima(const StreamParams &P, const Ta
 }
 
 // Writer side: lanes 0..gpw-1 of the calling wave push the workgroup's group maxima (kept in LDS) to gmax.
-__device__ __forceinline__ void publish_group_max(const StreamParams &P, uint32_t lane, uint32_t *misc) {
+__device__ __forceinline__ void publish_group_max(const StreamParams &P, uint32_t bid, uint32_t lane, uint32_t *misc) {
     if (lane < P.gpw) {
-        const uint32_t g = blockIdx.x * P.gpw + lane;
+        const uint32_t g = bid * P.gpw + lane;
         const uint32_t key = misc[MISC_GRPMAX + lane];
         if (g < P.n_groups_pub && key > misc[MISC_PUBLISHED + lane]) {
             misc[MISC_PUBLISHED + lane] = key;
@@ -653,20 +665,29 @@ __global__ void __launch_bounds__(576, 5) stream_kernel(const StreamParams P, co
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    uint32_t bid = blockIdx.x, n_wg = gridDim.x;  // streaming workgroup id / count
+    if (!SCORES && P.deferred) {
+        if (bid == 0u) {  // the selection of the previous query rides along (n_wg = 0: there is none)
+            if (SP.n_wg != 0u) select_body(SP, tid, blockDim.x, sel_sh);
+            return;
+        }
+        bid -= 1u;
+        n_wg -= 1u;
+    }
     // The last wave of the workgroup is the exchange SERVER, the others stream. vmcnt retires in order, so a slow
     // remote access (the hot threshold word, the maxima of 512 workgroups) issued by a streaming wave would hold
     // back the visibility of every packet load behind it; the server keeps such traffic out of the stream.
     const uint32_t nwaves = (blockDim.x >> 6) - 1u;  // streaming waves
     const bool is_server = (wave == nwaves);
     const uint32_t grp_local = is_server ? 0u : wave * P.gpw / nwaves;
-    const uint32_t grp_global = blockIdx.x * P.gpw + grp_local;
+    const uint32_t grp_global = bid * P.gpw + grp_local;
     const bool publishes = (P.n_sets != 0u) && (grp_global < P.n_groups_pub);
-    const bool reducer = blockIdx.x < P.n_reducers;
+    const bool reducer = bid < P.n_reducers;
 
     // The first packets of this wave's partition are requested before anything else, so that staging x and the
     // barrier overlap with the first memory round trip instead of preceding it.
-    const uint32_t total_waves = nwaves * gridDim.x;
-    uint32_t q = is_server ? P.n_parts : wave * gridDim.x + blockIdx.x;
+    const uint32_t total_waves = nwaves * n_wg;
+    uint32_t q = is_server ? P.n_parts : wave * n_wg + bid;
     Pkt<C, Q8> buf[NBUF];
     uint32_t rbs[NBUF];
     uint32_t p0 = 0, np = 0;
@@ -729,7 +750,7 @@ __global__ void __launch_bounds__(576, 5) stream_kernel(const StreamParams P, co
     if (is_server) {
         if (!SCORES && P.n_sets != 0u && !(P.dbg_flags & 4u)) {
             for (;;) {
-                if (!(P.dbg_flags & 1u)) publish_group_max(P, lane, misc);
+                if (!(P.dbg_flags & 1u)) publish_group_max(P, bid, lane, misc);
                 float t;
                 if (reducer) {
                     TauRegs tr;
@@ -801,6 +822,13 @@ __global__ void __launch_bounds__(576, 5) stream_kernel(const StreamParams P, co
                 tau = __uint_as_float(
                     __hip_atomic_load(&misc[MISC_TAU], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
 
+            if (P.dbg_flags & 64u) {  // ablation: loads only
+                uint32_t a = cur.cw[0] ^ cur.cw[1] ^ rb_cur;
+                if (!Q8) a ^= __float_as_uint(cur.v[0]) ^ __float_as_uint(cur.v[1]) ^ __float_as_uint(cur.v[2]) ^ __float_as_uint(cur.v[3]);
+                else a ^= cur.vq[0];
+                if (a == 0x12345678u) misc[MISC_XMAX] = a;
+                continue;
+            }
             const RowSums<C> R = reduce_packet<C, QM>(cur, carry, x_lds);
 
             if (SCORES) {
@@ -853,7 +881,7 @@ __global__ void __launch_bounds__(576, 5) stream_kernel(const StreamParams P, co
     __syncthreads();
     // Last publication of this workgroup's maxima (fire and forget): the select stage derives its own, exact
     // threshold from the complete set, so no final refresh is needed here.
-    if (is_server && P.n_sets != 0u) publish_group_max(P, lane, misc);
+    if (is_server && P.n_sets != 0u) publish_group_max(P, bid, lane, misc);
     const float tau = __uint_as_float(misc[MISC_TAU]);
     const uint32_t n = misc[MISC_CAND_CNT] < P.cand_cap ? misc[MISC_CAND_CNT] : P.cand_cap;
     // pass 1: count survivors
@@ -871,7 +899,7 @@ __global__ void __launch_bounds__(576, 5) stream_kernel(const StreamParams P, co
     // pass 2: the first WG_SLOTS survivors go to this workgroup's fixed slots, the rest to the shared overflow list.
     // Write-through (sc1) stores: in fused mode another workgroup of this launch reads them.
     const uint32_t ovf_base = misc[MISC_OVF_BASE];
-    unsigned long long *out = P.wg_cand + (size_t)blockIdx.x * WG_SLOTS;
+    unsigned long long *out = P.wg_cand + (size_t)bid * WG_SLOTS;
     for (uint32_t i = tid; i < n; i += blockDim.x) {
         const uint2 c = cand[i];
         if (__uint_as_float(c.x) >= tau) {
@@ -885,7 +913,10 @@ __global__ void __launch_bounds__(576, 5) stream_kernel(const StreamParams P, co
         }
     }
     if (tid < WG_SLOTS && tid >= surv) st_agent(&out[tid], pack_cand(0u, SLOT_INVALID));
-    if (!P.fused) return;
+    if (!P.fused) {
+        if (bid == 0u && tid == 0u && P.unit_inv_out) *P.unit_inv_out = inv_unit;
+        return;
+    }
 
     // ---- fused tail: the last workgroup to get here selects the final top-k -----------------------------------
     // Hand-off (cdna_hip_programming.md Guideline 16): every storing wave drains its write-through stores, the
@@ -899,9 +930,9 @@ __global__ void __launch_bounds__(576, 5) stream_kernel(const StreamParams P, co
         // Two-level ticket: 8 group counters (blockIdx % 8) and a top counter, each on its own 128-B line, so the
         // workgroups that finish together do not serialise on one word. Which workgroups share a group is
         // irrelevant for correctness.
-        const uint32_t g = blockIdx.x & 7u;
-        const uint32_t n_in_group = (gridDim.x - g + 7u) >> 3;
-        const uint32_t n_groups = gridDim.x < 8u ? gridDim.x : 8u;
+        const uint32_t g = bid & 7u;
+        const uint32_t n_in_group = (n_wg - g + 7u) >> 3;
+        const uint32_t n_groups = n_wg < 8u ? n_wg : 8u;
         uint32_t last = 0u;
         const uint32_t t1 =
             __hip_atomic_fetch_add(&SP.done_count[32u * g], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -960,13 +991,27 @@ struct EngineImpl {
     uint32_t *d_pkt_row = nullptr, *d_part_first = nullptr, *d_part_count = nullptr;
     float *d_x = nullptr;
     const float *d_x_cur = nullptr;
-    uint32_t *d_tau_g = nullptr;
-    uint32_t *d_gmax = nullptr, *d_wg_count = nullptr, *d_ovf_count = nullptr, *d_out_idx = nullptr;
-    unsigned long long *d_wg_cand = nullptr, *d_ovf = nullptr;
+    // Exchange state of one query in flight (published maxima, threshold word, survivor slots, overflow list).
+    // Two sets: with deferred selection, launch q+1 streams into one set while its workgroup 0 selects query q from
+    // the other. Everything else uses set 0.
+    struct ExState {
+        uint32_t *tau_g = nullptr, *gmax = nullptr, *ovf_count = nullptr;
+        unsigned long long *wg_cand = nullptr, *ovf = nullptr, *scratch = nullptr;
+        float *unit_inv = nullptr;
+    };
+    static constexpr int N_STATE = 2;
+    ExState st[N_STATE];
+    mutable int cur_set = 0;                  // set the next deferred launch streams into
+    mutable bool pending = false;             // a deferred selection is owed for ...
+    mutable int pending_set = 0;              // ... this set, into ...
+    mutable uint32_t *pending_idx = nullptr;  // ... these result buffers
+    mutable float *pending_val = nullptr;
+    uint32_t *d_wg_count = nullptr, *d_out_idx = nullptr;
     uint32_t *d_done = nullptr;
     bool fused = true;
+    bool can_defer = false;
     float *d_out_val = nullptr, *d_scores = nullptr;
-    unsigned long long *d_scratch = nullptr, *d_stats = nullptr;
+    unsigned long long *d_stats = nullptr;
     uint32_t grid = 0, block = 0, gpw = 1, n_sets = 0, n_groups_pub = 0, cand_cap = 0, ovf_cap = 0, lds_bytes = 0,
              xcols = 1024;
     bool collect_stats = false;
@@ -976,8 +1021,9 @@ struct EngineImpl {
     bool have_query = false;
     bool ran = false;
 
-    StreamParams stream_params(const float *x) const {
+    StreamParams stream_params(const float *x, int set = 0) const {
         StreamParams P{};
+        const ExState &E = st[set];
         P.packets = d_replicas.empty() ? d_packets : d_replicas[launch_counter % d_replicas.size()];
         P.pkt_row = d_pkt_row;
         P.part_first = d_part_first;
@@ -991,46 +1037,80 @@ struct EngineImpl {
         P.n_groups_pub = n_groups_pub;
         P.gpw = gpw;
         P.min_score = desc.min_score;  // converted to score units inside the kernel
-        P.gmax = d_gmax;
-        P.tau_g = d_tau_g;
+        P.gmax = E.gmax;
+        P.tau_g = E.tau_g;
         P.n_reducers = grid < 8u ? grid : 8u;
-        P.wg_cand = d_wg_cand;
+        P.wg_cand = E.wg_cand;
         P.cand_cap = cand_cap;
-        P.ovf_cand = d_ovf;
-        P.ovf_count = d_ovf_count;
+        P.ovf_cand = E.ovf;
+        P.ovf_count = E.ovf_count;
         P.ovf_cap = ovf_cap;
         P.scores = d_scores;
         P.fused = fused ? 1u : 0u;
+        P.deferred = 0u;
+        P.unit_inv_out = E.unit_inv;
         P.dbg = collect_stats ? d_stats + 4 : nullptr;
         P.stamps = collect_stamps ? d_stats + 16 : nullptr;
         P.dbg_flags = dbg_flags;
         return P;
     }
-    SelectParams select_params(uint32_t *out_idx, float *out_val) const {
+    SelectParams select_params(uint32_t *out_idx, float *out_val, int set = 0) const {
         SelectParams S{};
-        S.wg_cand = d_wg_cand;
+        const ExState &E = st[set];
+        S.wg_cand = E.wg_cand;
         S.n_wg = grid;
-        S.ovf_cand = d_ovf;
-        S.ovf_count = d_ovf_count;
+        S.ovf_cand = E.ovf;
+        S.ovf_count = E.ovf_count;
         S.ovf_cap = ovf_cap;
         S.k = (uint32_t)desc.k;
         S.first_row = desc.first_row;
-        S.out_scale = desc.precision == TKSPMV_Q1_7 ? (1.0f / 128.0f) : 1.0f;  // wide mode: fused tail supplies it
+        S.out_scale = desc.precision == TKSPMV_Q1_7 ? (1.0f / 128.0f) : 1.0f;  // fused tail / unit_inv_in override it
+        S.unit_inv_in = nullptr;
         S.out_idx = out_idx;
         S.out_val = out_val;
-        S.gmax = d_gmax;
-        S.tau_g = d_tau_g;
+        S.gmax = E.gmax;
+        S.tau_g = E.tau_g;
         S.done_count = d_done;
         S.n_groups_pub = n_groups_pub;
         S.use_gmax = (n_sets != 0u && n_groups_pub >= (uint32_t)desc.k) ? 1u : 0u;
-        S.scratch = d_scratch;
+        S.scratch = E.scratch;
         S.stats = collect_stats ? d_stats : nullptr;
         return S;
     }
-    // One query: the stream kernel and, unless fused into its tail, the select kernel.
+    // The selection still owed to the last deferred launch, as its own small kernel.
+    void drain(hipStream_t s) const {
+        if (!pending) return;
+        launch_select(pending_idx, pending_val, s, pending_set);
+        pending = false;
+    }
+    // One query, its result complete in stream order right after these launches: the stream kernel and, unless
+    // fused into its tail, the select kernel.
     void launch_query(const float *x, uint32_t *out_idx, float *out_val, hipStream_t s) const {
+        drain(s);
         launch_stream(x, out_idx, out_val, s);
         if (!fused) launch_select(out_idx, out_val, s);
+    }
+    // One query of a back-to-back sequence: its selection runs inside the NEXT deferred launch (or in drain()).
+    void launch_deferred(const float *x, uint32_t *out_idx, float *out_val, hipStream_t s) const {
+        if (!can_defer) {
+            launch_query(x, out_idx, out_val, s);
+            return;
+        }
+        StreamParams P = stream_params(x, cur_set);
+        P.fused = 0u;
+        P.deferred = 1u;
+        SelectParams S{};  // n_wg = 0: nothing owed
+        if (pending) {
+            S = select_params(pending_idx, pending_val, pending_set);
+            S.unit_inv_in = st[pending_set].unit_inv;
+        }
+        ++launch_counter;
+        hipLaunchKernelGGL(kernel_for(false), dim3(grid + 1), dim3(block + 64), 0, s, P, S);
+        pending = true;
+        pending_set = cur_set;
+        pending_idx = out_idx;
+        pending_val = out_val;
+        cur_set ^= 1;
     }
     typedef void (*stream_fn)(const StreamParams, const SelectParams);
     stream_fn kernel_for(bool scores) const {
@@ -1061,8 +1141,9 @@ struct EngineImpl {
         SelectParams S = select_params(d_out_idx, d_out_val);
         hipLaunchKernelGGL(kernel_for(true), dim3(grid), dim3(block + 64), 0, s, P, S);
     }
-    void launch_select(uint32_t *out_idx, float *out_val, hipStream_t s) const {
-        SelectParams S = select_params(out_idx, out_val);
+    void launch_select(uint32_t *out_idx, float *out_val, hipStream_t s, int set = 0) const {
+        SelectParams S = select_params(out_idx, out_val, set);
+        S.unit_inv_in = st[set].unit_inv;  // written by the (unfused) stream kernel of that query
         hipLaunchKernelGGL(select_kernel, dim3(1), dim3(SEL_THREADS), 0, s, S);
     }
 };
@@ -1099,11 +1180,15 @@ Engine::~Engine() {
     EngineImpl &m = *impl_;
     (void)hipSetDevice(m.device);
     if (m.stream) (void)hipStreamSynchronize(m.stream);
-    void *bufs[] = {m.d_packets,  m.d_pkt_row, m.d_part_first, m.d_part_count, m.d_x,       m.d_gmax,   m.d_wg_count,
-                    m.d_ovf_count, m.d_out_idx, m.d_wg_cand,    m.d_ovf,        m.d_out_val, m.d_scores, m.d_scratch,
-                    m.d_stats,     m.d_tau_g,   m.d_done};
+    void *bufs[] = {m.d_packets, m.d_pkt_row, m.d_part_first, m.d_part_count, m.d_x,    m.d_wg_count,
+                    m.d_out_idx, m.d_out_val, m.d_scores,     m.d_stats,      m.d_done};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
+    for (auto &E : m.st) {
+        void *eb[] = {E.tau_g, E.gmax, E.ovf_count, E.wg_cand, E.ovf, E.scratch, E.unit_inv};
+        for (void *b : eb)
+            if (b) (void)hipFree(b);
+    }
     for (size_t r = 1; r < m.d_replicas.size(); ++r) (void)hipFree(m.d_replicas[r]);
     if (m.ev0) (void)hipEventDestroy(m.ev0);
     if (m.ev1) (void)hipEventDestroy(m.ev1);
@@ -1235,32 +1320,38 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err) {
     std::vector<uint32_t>().swap(m.pm.pkt_row);
 
     HIP_TRY(hipMalloc((void **)&m.d_x, (size_t)d.cols * 4));
-    HIP_TRY(hipMalloc((void **)&m.d_gmax, (size_t)MAX_GM * 64 * 4));
     HIP_TRY(hipMalloc((void **)&m.d_wg_count, (size_t)m.grid * 4));
-    HIP_TRY(hipMalloc((void **)&m.d_ovf_count, 4));
-    HIP_TRY(hipMalloc((void **)&m.d_wg_cand, (size_t)m.grid * WG_SLOTS * 8));
-    HIP_TRY(hipMemset(m.d_wg_cand, 0xFF, (size_t)m.grid * WG_SLOTS * 8));
-    HIP_TRY(hipMalloc((void **)&m.d_ovf, (size_t)m.ovf_cap * 8));
     HIP_TRY(hipMalloc((void **)&m.d_out_idx, (size_t)d.k * 4));
     HIP_TRY(hipMalloc((void **)&m.d_out_val, (size_t)d.k * 4));
-    HIP_TRY(hipMalloc((void **)&m.d_scratch, ((size_t)m.grid * WG_SLOTS + m.ovf_cap) * 8));
     HIP_TRY(hipMalloc((void **)&m.d_stats, 32 * 8));
     m.collect_stats = getenv("TKSPMV_STATS") != nullptr;
     if (const char *f = getenv("TKSPMV_DBG_FLAGS")) m.dbg_flags = (uint32_t)atoi(f);
-    HIP_TRY(hipMemset(m.d_gmax, 0, (size_t)MAX_GM * 64 * 4));
-    HIP_TRY(hipMalloc((void **)&m.d_tau_g, 256));
-    HIP_TRY(hipMemset(m.d_tau_g, 0, 256));
     HIP_TRY(hipMalloc((void **)&m.d_done, 9 * 128));
     HIP_TRY(hipMemset(m.d_done, 0, 9 * 128));
-    // Fused tail: the last workgroup (block + 64 threads) must hold every slot in SEL_PER_THREAD registers.
+    // Fused tail / deferred selection: one workgroup (block + 64 threads) must hold every slot in SEL_PER_THREAD
+    // registers per thread.
     m.fused = (uint64_t)m.grid * WG_SLOTS <= (uint64_t)SEL_PER_THREAD * (m.block + 64);
+    m.can_defer = m.fused;
     if (const char *f = getenv("TKSPMV_FUSED")) m.fused = m.fused && atoi(f) != 0;
-    if (d.precision == TKSPMV_Q1_7_WIDE && !m.fused) {
-        err = "TKSPMV_Q1_7_WIDE needs the fused selection tail (the per-query block scale lives in the stream kernel)";
-        return TKSPMV_ERR_UNSUPPORTED;
+    if (const char *f = getenv("TKSPMV_DEFER")) m.can_defer = m.can_defer && atoi(f) != 0;
+    for (int si = 0; si < EngineImpl::N_STATE; ++si) {
+        EngineImpl::ExState &E = m.st[si];
+        if (si > 0 && !m.can_defer) break;  // the second set only serves deferred selection
+        HIP_TRY(hipMalloc((void **)&E.gmax, (size_t)MAX_GM * 64 * 4));
+        HIP_TRY(hipMemset(E.gmax, 0, (size_t)MAX_GM * 64 * 4));
+        HIP_TRY(hipMalloc((void **)&E.tau_g, 256));
+        HIP_TRY(hipMemset(E.tau_g, 0, 256));
+        HIP_TRY(hipMalloc((void **)&E.ovf_count, 256));
+        HIP_TRY(hipMemset(E.ovf_count, 0, 256));
+        HIP_TRY(hipMalloc((void **)&E.wg_cand, (size_t)m.grid * WG_SLOTS * 8));
+        HIP_TRY(hipMemset(E.wg_cand, 0xFF, (size_t)m.grid * WG_SLOTS * 8));
+        HIP_TRY(hipMalloc((void **)&E.ovf, (size_t)m.ovf_cap * 8));
+        HIP_TRY(hipMalloc((void **)&E.scratch, ((size_t)m.grid * WG_SLOTS + m.ovf_cap) * 8));
+        HIP_TRY(hipMalloc((void **)&E.unit_inv, 256));
+        const float one = 1.0f;
+        HIP_TRY(hipMemcpy(E.unit_inv, &one, 4, hipMemcpyHostToDevice));
     }
     HIP_TRY(hipMemset(m.d_wg_count, 0, (size_t)m.grid * 4));
-    HIP_TRY(hipMemset(m.d_ovf_count, 0, 4));
     HIP_TRY(hipMemset(m.d_stats, 0, 32 * 8));
     m.collect_stamps = getenv("TKSPMV_STAMPS") != nullptr;
     HIP_TRY(hipMemset(m.d_out_idx, 0, (size_t)d.k * 4));
@@ -1344,10 +1435,54 @@ int Engine::enqueue_many(const float *dev_xs, int32_t n_x, int32_t count, void *
     hipStream_t s = stream ? (hipStream_t)stream : m.stream;
     HIP_TRY(hipSetDevice(m.device));
     for (int i = 0; i < count; ++i) {
-        m.launch_query(dev_xs + (size_t)(i % n_x) * m.desc.cols, m.d_out_idx, m.d_out_val, s);
+        m.launch_deferred(dev_xs + (size_t)(i % n_x) * m.desc.cols, m.d_out_idx, m.d_out_val, s);
     }
+    m.drain(s);
     HIP_TRY(hipGetLastError());
     m.ran = true;
+    return TKSPMV_OK;
+}
+
+int Engine::enqueue_batch(const float *dev_xs, int32_t count, uint32_t *dev_idx, float *dev_val, void *stream,
+                          std::string &err) {
+    EngineImpl &m = *impl_;
+    if (!dev_xs || count < 0 || (dev_idx == nullptr) != (dev_val == nullptr)) {
+        err = "bad arguments to enqueue_batch";
+        return TKSPMV_ERR_INVALID;
+    }
+    hipStream_t s = stream ? (hipStream_t)stream : m.stream;
+    HIP_TRY(hipSetDevice(m.device));
+    const size_t k = (size_t)m.desc.k;
+    for (int i = 0; i < count; ++i) {
+        m.launch_deferred(dev_xs + (size_t)i * m.desc.cols, dev_idx ? dev_idx + (size_t)i * k : m.d_out_idx,
+                          dev_val ? dev_val + (size_t)i * k : m.d_out_val, s);
+    }
+    m.drain(s);
+    HIP_TRY(hipGetLastError());
+    m.ran = true;
+    return TKSPMV_OK;
+}
+
+int Engine::enqueue_deferred(const float *dev_x, uint32_t *dev_idx, float *dev_val, void *stream, std::string &err) {
+    EngineImpl &m = *impl_;
+    if (!dev_x) {
+        err = "query vector is NULL";
+        return TKSPMV_ERR_INVALID;
+    }
+    hipStream_t s = stream ? (hipStream_t)stream : m.stream;
+    HIP_TRY(hipSetDevice(m.device));
+    m.launch_deferred(dev_x, dev_idx ? dev_idx : m.d_out_idx, dev_val ? dev_val : m.d_out_val, s);
+    HIP_TRY(hipGetLastError());
+    m.ran = true;
+    return TKSPMV_OK;
+}
+
+int Engine::drain(void *stream, std::string &err) {
+    EngineImpl &m = *impl_;
+    hipStream_t s = stream ? (hipStream_t)stream : m.stream;
+    HIP_TRY(hipSetDevice(m.device));
+    m.drain(s);
+    HIP_TRY(hipGetLastError());
     return TKSPMV_OK;
 }
 
@@ -1372,6 +1507,7 @@ int Engine::run(double *kernel_ns, std::string &err) {
 
 int Engine::synchronize(std::string &err) {
     HIP_TRY(hipSetDevice(impl_->device));
+    impl_->drain(impl_->stream);
     HIP_TRY(hipStreamSynchronize(impl_->stream));
     return TKSPMV_OK;
 }
@@ -1428,8 +1564,9 @@ int Engine::profile(const float *dev_xs, int32_t n_x, int32_t iters, tkspmv_timi
     HIP_TRY(hipEventRecord(m.ev0, m.stream));
     for (int i = 0; i < iters; ++i) {
         const float *x = dev_xs + (size_t)(i % n_x) * stride;
-        m.launch_query(x, m.d_out_idx, m.d_out_val, m.stream);
+        m.launch_deferred(x, m.d_out_idx, m.d_out_val, m.stream);
     }
+    m.drain(m.stream);
     HIP_TRY(hipEventRecord(m.ev1, m.stream));
     HIP_TRY(hipEventSynchronize(m.ev1));
     float ms = 0;
@@ -1486,7 +1623,7 @@ int Engine::profile(const float *dev_xs, int32_t n_x, int32_t iters, tkspmv_timi
         for (auto &e : evs) HIP_TRY(hipEventCreate(&e));
         for (int i = 0; i < n; ++i) {
             HIP_TRY(hipEventRecord(evs[2 * i], m.stream));
-            hipLaunchKernelGGL(null_kernel, dim3(m.grid), dim3(m.block + 64), 0, m.stream, m.d_gmax);
+            hipLaunchKernelGGL(null_kernel, dim3(m.grid), dim3(m.block + 64), 0, m.stream, m.st[0].gmax);
             HIP_TRY(hipEventRecord(evs[2 * i + 1], m.stream));
             if (!m.fused) m.launch_select(m.d_out_idx, m.d_out_val, m.stream);
         }

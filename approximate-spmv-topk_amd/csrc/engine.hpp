@@ -24,6 +24,12 @@ class Engine {
     int run(double *kernel_ns, std::string &err);
     int enqueue(const float *dev_x, uint32_t *dev_idx, float *dev_val, void *stream, std::string &err);
     int enqueue_many(const float *dev_xs, int32_t n_x, int32_t count, void *stream, std::string &err);
+    int enqueue_batch(const float *dev_xs, int32_t count, uint32_t *dev_idx, float *dev_val, void *stream,
+                      std::string &err);
+    // Deferred selection (back-to-back sequences on ONE stream): the top-k of a query is selected inside the next
+    // enqueue_deferred launch, or by drain(). Results are complete in stream order only after drain().
+    int enqueue_deferred(const float *dev_x, uint32_t *dev_idx, float *dev_val, void *stream, std::string &err);
+    int drain(void *stream, std::string &err);
     int synchronize(std::string &err);
     int read(uint32_t *idx, float *val, int32_t *n, std::string &err);
     int result_device(const uint32_t **dev_idx, const float **dev_val);

@@ -79,6 +79,14 @@ class SpMV:
         _lib.check(_lib.lib().tkspmv_enqueue_many(self._h, C.c_void_p(int(dev_xs)), int(n_x), int(count),
                                                   C.c_void_p(int(stream))))
 
+    def enqueue_batch(self, dev_xs, count, dev_idx=0, dev_val=0, stream=0):
+        """A batch of `count` queries (rows of a device array, stride cols floats); query i's k results go to
+        dev_idx + i*k / dev_val + i*k (device pointers; 0 => engine buffers, last query wins). No host sync."""
+        _lib.check(_lib.lib().tkspmv_enqueue_batch(self._h, C.c_void_p(int(dev_xs)), int(count),
+                                                   C.c_void_p(int(dev_idx)) if dev_idx else None,
+                                                   C.c_void_p(int(dev_val)) if dev_val else None,
+                                                   C.c_void_p(int(stream))))
+
     def synchronize(self):
         _lib.check(_lib.lib().tkspmv_synchronize(self._h))
 

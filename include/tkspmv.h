@@ -134,8 +134,16 @@ int tkspmv_run(tkspmv_t *e, double *kernel_ns);
 /* Enqueue one query on `stream` (hipStream_t cast to void*; NULL => engine stream), no host sync.
  * dev_idx/dev_val: optional device output buffers of k entries (NULL => engine-owned result buffers). */
 int tkspmv_enqueue(tkspmv_t *e, const float *dev_x, uint32_t *dev_idx, float *dev_val, void *stream);
-/* Enqueue `count` queries back to back (query i uses dev_xs + (i % n_x) * cols), no host sync. */
+/* Enqueue `count` queries back to back (query i uses dev_xs + (i % n_x) * cols), no host sync; the engine-owned
+ * result buffers end up holding the last query's top-k. In a back-to-back sequence the selection of query i runs
+ * inside the launch of query i+1 (deferred selection) and a small closing launch serves the last one, so the
+ * sequence is complete in stream order when the call returns. */
 int tkspmv_enqueue_many(tkspmv_t *e, const float *dev_xs, int32_t n_x, int32_t count, void *stream);
+/* A batch of `count` queries (the loop of the reference's drivers, host_spmv_bscsr.cpp main: for each test vector
+ * reset -> operator() -> read_result): query i = dev_xs + i * cols, its k results go to dev_idx + i * k and
+ * dev_val + i * k (both NULL => engine-owned buffers, last query wins). Same launch scheme as enqueue_many. */
+int tkspmv_enqueue_batch(tkspmv_t *e, const float *dev_xs, int32_t count, uint32_t *dev_idx, float *dev_val,
+                         void *stream);
 int tkspmv_synchronize(tkspmv_t *e);
 
 /* Copy back the k results of the last completed query, sorted by (score desc, row desc)
