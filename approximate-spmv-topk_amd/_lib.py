@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtkspmv.so")
+LIB_PATH = os.environ.get("TKSPMV_LIB") or os.path.join(_HERE, "libtkspmv.so")  # TKSPMV_LIB: tuning builds
 
 OK, ERR_INVALID, ERR_NOT_SORTED, ERR_DEVICE, ERR_NOMEM, ERR_IO, ERR_UNSUPPORTED, ERR_STATE = range(8)
 F32, Q1_7, Q1_7_WIDE = 0, 1, 2
@@ -77,7 +77,7 @@ class OptionsC(C.Structure):
 # Every symbol include/tkspmv.h declares; tests check the library exports all of them.
 EXPORTED_SYMBOLS = [
     "tkspmv_create", "tkspmv_destroy", "tkspmv_get_info", "tkspmv_set_query", "tkspmv_set_query_device",
-    "tkspmv_run", "tkspmv_enqueue", "tkspmv_enqueue_many", "tkspmv_enqueue_batch", "tkspmv_synchronize", "tkspmv_read", "tkspmv_result_device", "tkspmv_scores",
+    "tkspmv_run", "tkspmv_enqueue", "tkspmv_enqueue_many", "tkspmv_enqueue_batch", "tkspmv_synchronize", "tkspmv_read", "tkspmv_result_device", "tkspmv_scores", "tkspmv_debug_trace",
     "tkspmv_profile", "tkspmv_last_error", "tkspmv_device_count", "tkspmv_mtx_read", "tkspmv_mtx_free",
     "tkspmv_mtx_write", "tkspmv_sample_vector", "tkspmv_generate", "tkspmv_options_parse", "tkspmv_pack",
     "tkspmv_packed_info", "tkspmv_packed_decode", "tkspmv_packed_raw", "tkspmv_packed_free",
@@ -115,6 +115,7 @@ def lib():
     L.tkspmv_read.argtypes = [vp, u32p, f32p, C.POINTER(C.c_int32)]
     L.tkspmv_result_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
     L.tkspmv_scores.argtypes = [vp, f32p]
+    L.tkspmv_debug_trace.argtypes = [vp, C.POINTER(C.c_uint64), C.c_uint64, C.POINTER(C.c_uint64)]
     L.tkspmv_profile.argtypes = [vp, vp, C.c_int32, C.c_int32, C.POINTER(Timing)]
     L.tkspmv_mtx_read.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(Coo)]
     L.tkspmv_mtx_free.argtypes = [C.POINTER(Coo)]

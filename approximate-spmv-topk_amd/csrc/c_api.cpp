@@ -85,6 +85,15 @@ int tkspmv_result_device(tkspmv_t *h, const uint32_t **dev_idx, const float **de
     return h->e->result_device(dev_idx, dev_val);
 }
 int tkspmv_scores(tkspmv_t *h, float *host_y) { ENGINE_CALL(scores(host_y, err)) }
+int tkspmv_debug_trace(tkspmv_t *h, uint64_t *host, uint64_t max_words, uint64_t *words) {
+    size_t w = 0;
+    if (!h) return fail(TKSPMV_ERR_INVALID, "NULL engine");
+    std::string err;
+    int st = h->e->read_trace(reinterpret_cast<unsigned long long *>(host), (size_t)max_words, &w, err);
+    if (st != TKSPMV_OK) g_err = err;
+    if (words) *words = w;
+    return st;
+}
 int tkspmv_profile(tkspmv_t *h, const float *dev_xs, int32_t n_x, int32_t iters, tkspmv_timing *out) {
     ENGINE_CALL(profile(dev_xs, n_x, iters, out, err))
 }

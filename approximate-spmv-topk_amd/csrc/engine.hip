@@ -65,19 +65,21 @@ struct StreamParams {
     uint32_t ovf_cap;
     uint32_t fused;  // 1: the last workgroup to finish runs the selection (no second launch)
     // 1: deferred selection. Workgroup 0 of this launch selects the PREVIOUS query's top-k (its survivors sit in
-    // the other exchange-state set, complete and visible since that launch ended) and exits; workgroups 1..grid
+    // the other exchange-state set, complete and visible since that launch ended) and exits; workgroups 1..grid-1
     // stream the current query and end with the flush. No ticket, no second launch, nothing on the critical path.
     uint32_t deferred;
     float *unit_inv_out;  // 1 / (score units per 1.0) of this query, for a selection that runs in a later launch
     float *scores;  // SCORES variant only
     uint32_t dbg_flags;       // ablation switches (TKSPMV_DBG_FLAGS): 1 no publish, 2 no offers, 4 no tau duty, 8 no flush
+    unsigned long long *trace;   // optional (TKSPMV_TRACE=1): per-wave s_memrealtime stamps, [grid+1][9 waves][8]
     unsigned long long *stamps;  // optional (TKSPMV_STAMPS=1): s_memtime stamps of the selection tail, last workgroup
     unsigned long long *dbg;  // optional counters (TKSPMV_STATS=1): [0] slow-path executions, [1] appended rows
 };
 
-constexpr int MISC_CAND_CNT = 0, MISC_TAU = 1, MISC_FLUSH_CNT = 2, MISC_FLUSH_POS = 3, MISC_OVF_BASE = 4, MISC_DONE = 5, MISC_XMAX = 6,
+constexpr int MISC_CAND_CNT = 0, MISC_TAU = 1, MISC_DONE = 5, MISC_XMAX = 6, MISC_SLOW_CNT = 7,
               MISC_GRPMAX = 8 /* [8] */, MISC_PUBLISHED = 16 /* [8] */, MISC_WORDS = 32;  // <= 8 groups per workgroup
-constexpr uint32_t CAND_CAP = 1024;  // per-workgroup candidate list entries in LDS
+constexpr uint32_t CAND_CAP = 1024;  // candidate list entries in LDS per workgroup ...
+constexpr uint32_t WAVE_CAP = 128;   // ... = 8 streaming waves x a private list each
 constexpr uint32_t WG_SLOTS = 8;              // fixed result slots every workgroup writes (no count round trip)
 constexpr uint32_t SLOT_INVALID = 0xFFFFFFFFu;  // row id of an unused slot
 
@@ -134,7 +136,7 @@ __device__ __forceinline__ float q17_wrap(float units) {  // units = exact integ
 // workgroup to finish: no second launch) or as its own single-workgroup kernel.
 // ------------------------------------------------------------------------------------------------------------
 struct SelectParams {
-    const unsigned long long *wg_cand;  // [n_wg][WG_SLOTS] packed {score bits | row << 32}
+    unsigned long long *wg_cand;  // [n_wg][WG_SLOTS] packed {score bits | row << 32}; row SLOT_INVALID = empty
     uint32_t n_wg;
     const unsigned long long *ovf_cand;
     uint32_t *ovf_count;
@@ -240,27 +242,46 @@ __device__ __forceinline__ void select_body(const SelectParams &P, const uint32_
     wbase = __builtin_amdgcn_readfirstlane(wbase);
     __syncthreads();
     const uint32_t n_from_slots = S.total;
-    const uint32_t total = n_from_slots + novf;
+    // Overflow entries are pruned against the same threshold (waves that finish early flush against a threshold
+    // that is not final yet, and a late threshold floods the list): count first, then place.
+    {
+        uint32_t c = 0;
+        for (uint32_t i = tid; i < novf; i += nthreads)
+            c += (order_key(__uint_as_float((uint32_t)ld_agent(&P.ovf_cand[i]))) >= thr) ? 1u : 0u;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) c += (uint32_t)__shfl_xor((int)c, d);
+        if (lane == 0 && c) atomicAdd(&S.cnt, c);
+    }
+    __syncthreads();
+    const uint32_t total = n_from_slots + S.cnt;
     const bool small = total <= SEL_CAP;
+    __syncthreads();  // everybody has read S.cnt before the general path reuses it
+    unsigned long long *dst = small ? S.keys : P.scratch;
+#pragma unroll
+    for (uint32_t u = 0; u < SEL_PER_THREAD; ++u) {
+        if (ok[u]) dst[wbase + spos[u]] = make_ckey(mine[u]);
+    }
+    for (uint32_t i0 = 0; i0 < novf; i0 += nthreads) {  // wave-uniform trip count
+        const uint32_t i = i0 + tid;
+        const unsigned long long v = i < novf ? ld_agent(&P.ovf_cand[i]) : 0ull;
+        const bool keep = i < novf && order_key(__uint_as_float((uint32_t)v)) >= thr;
+        const uint64_t bm = __ballot(keep);
+        uint32_t base = 0;
+        if (lane == 0 && bm) base = atomicAdd(&S.total, (uint32_t)__popcll(bm));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (keep)
+            dst[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u))] =
+                make_ckey(v);
+    }
     uint32_t n_sel;
 
     if (small) {
-#pragma unroll
-        for (uint32_t u = 0; u < SEL_PER_THREAD; ++u) {
-            if (ok[u]) S.keys[wbase + spos[u]] = make_ckey(mine[u]);
-        }
-        for (uint32_t i = tid; i < novf; i += nthreads) S.keys[n_from_slots + i] = make_ckey(ld_agent(&P.ovf_cand[i]));
         if (tid < 8) S.keys[total + tid] = 0ull;  // padding for the unrolled rank loop (0 is below every real key)
         __syncthreads();
         n_sel = total;
     } else {
-        // General path (threshold exchange disabled or not converged): all keys to global scratch, bisection for
-        // the k-th largest composite key, then compaction of the keys >= it into LDS.
-#pragma unroll
-        for (uint32_t u = 0; u < SEL_PER_THREAD; ++u) {
-            if (ok[u]) P.scratch[novf + wbase + spos[u]] = make_ckey(mine[u]);
-        }
-        for (uint32_t i = tid; i < novf; i += nthreads) P.scratch[i] = make_ckey(ld_agent(&P.ovf_cand[i]));
+        // General path (threshold exchange disabled or not converged): the keys went to global scratch; bisection
+        // for the k-th largest composite key, then compaction of the keys >= it into LDS.
         __syncthreads();
         unsigned long long prefix = 0ull;
         if (total > P.k) {
@@ -321,7 +342,13 @@ __device__ __forceinline__ void select_body(const SelectParams &P, const uint32_
         P.out_val[r] = 0.0f;
     }
     // Reset the exchange state for the next query (this is the last consumer of the query on the stream); last, so
-    // that no barrier above has to wait for these stores.
+    // that no barrier above has to wait for these stores. Slots: only the ones that held a survivor need a store
+    // (the stream kernel writes a slot only when it has one).
+#pragma unroll
+    for (uint32_t u = 0; u < SEL_PER_THREAD; ++u) {
+        const uint32_t f = tid + u * nthreads;
+        if (f < n_slots && (uint32_t)(mine[u] >> 32) != SLOT_INVALID) P.wg_cand[f] = pack_cand(0u, SLOT_INVALID);
+    }
     for (uint32_t i = tid; i < P.n_groups_pub; i += nthreads) P.gmax[i] = 0u;
     if (tid == 0) {
         *P.ovf_count = 0u;
@@ -587,12 +614,32 @@ __device__ __forceinline__ uint32_t ends_below(const RowSums<C> &R) {
     return below;
 }
 
-// Candidate path (rare once tau has converged). Everything is aggregated per wave: one LDS atomic reserves list
-// slots, one LDS atomic raises the group maximum (the wave on threshold duty pushes it to global memory).
+// Drop from a wave's private candidate list what the (risen) threshold has made obsolete; returns the new length.
+// All reads are issued before any write (LDS executes a wave's instructions in order), so writing the kept entries
+// to the front cannot clobber an entry another lane still has to read.
+__device__ __forceinline__ uint32_t compact_list(uint2 *wcand, uint32_t n, float tau, uint32_t lane, uint2 &e0, uint2 &e1,
+                                                 uint32_t &p0, uint32_t &p1, bool &k0, bool &k1) {
+    e0 = make_uint2(0u, 0u);
+    e1 = make_uint2(0u, 0u);
+    if (lane < n) e0 = wcand[lane];
+    if (lane + 64u < n) e1 = wcand[lane + 64u];
+    k0 = lane < n && __uint_as_float(e0.x) >= tau;
+    k1 = lane + 64u < n && __uint_as_float(e1.x) >= tau;
+    const uint64_t b0 = __ballot(k0), b1 = __ballot(k1);
+    const uint32_t c0 = (uint32_t)__popcll(b0);
+    p0 = __builtin_amdgcn_mbcnt_hi((uint32_t)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b0, 0u));
+    p1 = c0 + __builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, 0u));
+    return c0 + (uint32_t)__popcll(b1);
+}
+
+// Candidate path (rare once tau has converged). Every streaming wave owns a private list of WAVE_CAP entries in LDS
+// (its length lives in an SGPR: no atomic, no other wave involved). A full list is first compacted against the
+// current threshold; only what still does not fit goes to the shared overflow list in global memory, with ONE
+// atomic per wave and packet. One LDS atomic raises the group maximum (the server wave pushes it to global memory).
 template <int C, int QM>
 __device__ __forceinline__ void offer_candidates(const StreamParams &P, const RowSums<C> &R, uint32_t rb, float tau,
-                                                 uint32_t lane, uint32_t grp_local, bool publishes, uint2 *cand,
-                                                 uint32_t *misc) {
+                                                 uint32_t lane, uint32_t grp_local, bool publishes, uint2 *wcand,
+                                                 uint32_t &wcnt, uint32_t *misc) {
     bool pass[C];
     uint32_t slot[C];
     uint32_t total = 0;
@@ -606,36 +653,58 @@ __device__ __forceinline__ void offer_candidates(const StreamParams &P, const Ro
     }
     const float best = lane_best<C, QM>(R);
     const float wmax = wave_max(best >= tau ? best : -__builtin_huge_valf());
-    uint32_t base = 0;
     if (total == 0u) return;  // only placeholders of empty rows tripped the trigger
     if (lane == 0) {
         if (publishes)
             (void)__hip_atomic_fetch_max(&misc[MISC_GRPMAX + grp_local], order_key(wmax), __ATOMIC_RELAXED,
                                          __HIP_MEMORY_SCOPE_WORKGROUP);
-        base = atomicAdd(&misc[MISC_CAND_CNT], total);
-        if (P.dbg) {
-            atomicAdd(&P.dbg[0], 1ull);
-            atomicAdd(&P.dbg[1], (unsigned long long)total);
+        if (P.dbg) {  // TKSPMV_STATS=1: summed into global memory when the wave finishes
+            atomicAdd(&misc[MISC_SLOW_CNT], 1u);
+            atomicAdd(&misc[MISC_CAND_CNT], total);
         }
     }
-    base = __builtin_amdgcn_readfirstlane(base);
+    if (wcnt + total > WAVE_CAP) {
+        uint2 e0, e1;
+        uint32_t p0, p1;
+        bool k0, k1;
+        wcnt = compact_list(wcand, wcnt, tau, lane, e0, e1, p0, p1, k0, k1);
+        if (k0) wcand[p0] = e0;
+        if (k1) wcand[p1] = e1;
+    }
+    const uint32_t base = wcnt;
+    const uint32_t first_ovf = base < WAVE_CAP ? WAVE_CAP : base;  // list position of the first overflowing row
+    uint32_t gbase = 0u;
+    if (base + total > WAVE_CAP) {
+        if (lane == 0) gbase = atomicAdd(P.ovf_count, base + total - first_ovf);
+        gbase = __builtin_amdgcn_readfirstlane(gbase);
+    }
     uint32_t r = rb + below;
 #pragma unroll
     for (int j = 0; j < C; ++j) {
         if (pass[j]) {
             const uint32_t pos = base + slot[j];
-            if (pos < P.cand_cap) {
-                cand[pos] = make_uint2(__float_as_uint(row_score<C, QM>(R, j)), r);
+            if (pos < WAVE_CAP) {
+                wcand[pos] = make_uint2(__float_as_uint(row_score<C, QM>(R, j)), r);
             } else {
-                const uint32_t gp = atomicAdd(P.ovf_count, 1u);
+                const uint32_t gp = gbase + (pos - first_ovf);
                 if (gp < P.ovf_cap) st_agent(&P.ovf_cand[gp], pack_cand(__float_as_uint(row_score<C, QM>(R, j)), r));
             }
         }
         r += R.end(j) ? 1u : 0u;
     }
+    wcnt = base + total < WAVE_CAP ? base + total : WAVE_CAP;
 }
 
-constexpr int DEFER = 3;  // packets per wave whose rows are judged at the end (threshold exchange cold start)
+#ifndef TKSPMV_STREAM_PRIO
+#define TKSPMV_STREAM_PRIO 2
+#endif
+#ifndef TKSPMV_REDUCER_SLEEP
+#define TKSPMV_REDUCER_SLEEP 8
+#endif
+#ifndef TKSPMV_DEFER_PACKETS
+#define TKSPMV_DEFER_PACKETS 3
+#endif
+constexpr int DEFER = TKSPMV_DEFER_PACKETS;  // packets per wave whose rows are judged at the end (threshold exchange cold start)
 
 // One static LDS object per workgroup. x sits at LDS offset 0, so that (column word & 0xFFFC) IS the ds_read address;
 // the selection tail reuses the bytes of x and of the candidate list, which are dead by then. Static objects are
@@ -653,7 +722,10 @@ struct StreamLds {
     uint32_t misc[MISC_WORDS];
 };
 
-template <int C, bool SCORES, int XCOLS, int QM = 0, int NBUF = 3>
+#ifndef TKSPMV_NBUF
+#define TKSPMV_NBUF 3
+#endif
+template <int C, bool SCORES, int XCOLS, int QM = 0, int NBUF = TKSPMV_NBUF>
 __global__ void __launch_bounds__(576, 5) stream_kernel(const StreamParams P, const SelectParams SP) {
     constexpr bool Q8 = QM != 0;
     __shared__ StreamLds<XCOLS> L;
@@ -666,9 +738,21 @@ __global__ void __launch_bounds__(576, 5) stream_kernel(const StreamParams P, co
     const uint32_t lane = tid & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     uint32_t bid = blockIdx.x, n_wg = gridDim.x;  // streaming workgroup id / count
+    // TKSPMV_TRACE=1: 100 MHz wall-clock stamps per wave (kept in SGPRs, written once at the very end)
+    unsigned long long *tr = (!SCORES && P.trace) ? P.trace + ((size_t)blockIdx.x * 9u + wave) * 8u : nullptr;
+    unsigned long long tr0 = 0, tr1 = 0, tr2 = 0, tr3 = 0, tr4 = 0;
+    if (tr) tr0 = __builtin_amdgcn_s_memrealtime();
     if (!SCORES && P.deferred) {
-        if (bid == 0u) {  // the selection of the previous query rides along (n_wg = 0: there is none)
+        // The selection of the previous query rides along in workgroup 0 (SP.n_wg = 0: there is none); the others
+        // stream. The launch has as many workgroups as fit the GPU at once (two per CU) and the matrix is cut into
+        // one partition per streaming wave of grid - 1 workgroups, so nothing waits for a free slot: the selection
+        // runs during the launch's start-up, when the memory system is still idle.
+        if (bid == 0u) {
             if (SP.n_wg != 0u) select_body(SP, tid, blockDim.x, sel_sh);
+            if (tr && lane == 0) {
+                tr[0] = tr0;
+                tr[5] = __builtin_amdgcn_s_memrealtime();
+            }
             return;
         }
         bid -= 1u;
@@ -679,6 +763,9 @@ __global__ void __launch_bounds__(576, 5) stream_kernel(const StreamParams P, co
     // back the visibility of every packet load behind it; the server keeps such traffic out of the stream.
     const uint32_t nwaves = (blockDim.x >> 6) - 1u;  // streaming waves
     const bool is_server = (wave == nwaves);
+    // Streaming waves outrank the server waves at instruction issue: a reducer's k-th-largest search otherwise slows
+    // the workgroups sharing its CU (they were the launch's stragglers by ~2 us).
+    if (!is_server) __builtin_amdgcn_s_setprio(TKSPMV_STREAM_PRIO);
     const uint32_t grp_local = is_server ? 0u : wave * P.gpw / nwaves;
     const uint32_t grp_global = bid * P.gpw + grp_local;
     const bool publishes = (P.n_sets != 0u) && (grp_global < P.n_groups_pub);
@@ -746,16 +833,19 @@ __global__ void __launch_bounds__(576, 5) stream_kernel(const StreamParams P, co
     }
     if (tid == 0) misc[MISC_TAU] = __float_as_uint(min_units);
     __syncthreads();
+    if (tr) tr1 = __builtin_amdgcn_s_memrealtime();
 
     if (is_server) {
         if (!SCORES && P.n_sets != 0u && !(P.dbg_flags & 4u)) {
             for (;;) {
                 if (!(P.dbg_flags & 1u)) publish_group_max(P, bid, lane, misc);
+                // Only a few servers read all published maxima (many readers of those 16 lines slow the whole
+                // stream down: measured); the others read the one word the reducers keep up to date.
                 float t;
                 if (reducer) {
-                    TauRegs tr;
-                    tau_issue(P, lane, tr);
-                    t = tau_from_maxima(P, tr, min_units);
+                    TauRegs tr_;
+                    tau_issue(P, lane, tr_);
+                    t = tau_from_maxima(P, tr_, min_units);
                     if (lane == 0 && t > min_units)
                         __hip_atomic_fetch_max(P.tau_g, order_key(t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 } else {
@@ -773,10 +863,17 @@ __global__ void __launch_bounds__(576, 5) stream_kernel(const StreamParams P, co
                 const uint32_t done =
                     __hip_atomic_load(&misc[MISC_DONE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (__builtin_amdgcn_readfirstlane(done) >= nwaves) break;
-                __builtin_amdgcn_s_sleep(8);
+                if (reducer) __builtin_amdgcn_s_sleep(TKSPMV_REDUCER_SLEEP);
+                else __builtin_amdgcn_s_sleep(8);
             }
         }
+        // Last publication of this workgroup's maxima, now complete (fire and forget). Outside the fused tail the
+        // server has no further part: every streaming wave flushes on its own, nobody waits for this wave.
+        if (!SCORES && P.n_sets != 0u) publish_group_max(P, bid, lane, misc);
+        if (!SCORES && !P.fused) return;
     }
+    uint2 *wcand = cand + (is_server ? 0u : wave) * WAVE_CAP;  // this wave's private candidate list
+    uint32_t wcnt = 0u;                                         // its length (wave-uniform)
     for (bool first_part = true; q < P.n_parts; q += total_waves, first_part = false) {
         if (!first_part) {  // more partitions than waves (not the case for engines built by tkspmv_create)
             p0 = P.part_first[q];
@@ -822,14 +919,8 @@ __global__ void __launch_bounds__(576, 5) stream_kernel(const StreamParams P, co
                 tau = __uint_as_float(
                     __hip_atomic_load(&misc[MISC_TAU], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
 
-            if (P.dbg_flags & 64u) {  // ablation: loads only
-                uint32_t a = cur.cw[0] ^ cur.cw[1] ^ rb_cur;
-                if (!Q8) a ^= __float_as_uint(cur.v[0]) ^ __float_as_uint(cur.v[1]) ^ __float_as_uint(cur.v[2]) ^ __float_as_uint(cur.v[3]);
-                else a ^= cur.vq[0];
-                if (a == 0x12345678u) misc[MISC_XMAX] = a;
-                continue;
-            }
             const RowSums<C> R = reduce_packet<C, QM>(cur, carry, x_lds);
+            if (tr && i == 0u) tr2 = __builtin_amdgcn_s_memrealtime() + (__float_as_uint(R.best_any) & 0u);
 
             if (SCORES) {
                 uint32_t r = rb_cur + ends_below<C>(R);
@@ -855,11 +946,12 @@ __global__ void __launch_bounds__(576, 5) stream_kernel(const StreamParams P, co
                         (void)__hip_atomic_fetch_max(&misc[MISC_GRPMAX + grp_local], order_key(wmax), __ATOMIC_RELAXED,
                                                      __HIP_MEMORY_SCOPE_WORKGROUP);
                 } else if (__any(R.best_any >= tau) && !(P.dbg_flags & 2u)) {
-                    offer_candidates<C, QM>(P, R, rb_cur, tau, lane, grp_local, publishes, cand, misc);
+                    offer_candidates<C, QM>(P, R, rb_cur, tau, lane, grp_local, publishes, wcand, wcnt, misc);
                 }
             }
             }
         }
+        if (tr) tr3 = __builtin_amdgcn_s_memrealtime();
         if (!SCORES && P.n_sets != 0u) {
             // The deferred packets, against the threshold as it stands now.
             const float tau =
@@ -867,52 +959,59 @@ __global__ void __launch_bounds__(576, 5) stream_kernel(const StreamParams P, co
 #pragma unroll
             for (int d = 0; d < DEFER; ++d) {
                 if (np > (uint32_t)d && __any(st[d].best_any >= tau))
-                    offer_candidates<C, QM>(P, st[d], st_rb[d], tau, lane, grp_local, publishes, cand, misc);
+                    offer_candidates<C, QM>(P, st[d], st_rb[d], tau, lane, grp_local, publishes, wcand, wcnt, misc);
             }
         }
     }
 
     if (SCORES) return;
+    if (tr) tr4 = __builtin_amdgcn_s_memrealtime();
     const unsigned long long ts_stream_end = P.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
     if (!is_server && lane == 0) atomicAdd(&misc[MISC_DONE], 1u);
     if (P.dbg_flags & 8u) return;
 
-    // ---- flush: keep what still clears the (now much tighter) threshold --------------------------------------
-    __syncthreads();
-    // Last publication of this workgroup's maxima (fire and forget): the select stage derives its own, exact
-    // threshold from the complete set, so no final refresh is needed here.
-    if (is_server && P.n_sets != 0u) publish_group_max(P, bid, lane, misc);
-    const float tau = __uint_as_float(misc[MISC_TAU]);
-    const uint32_t n = misc[MISC_CAND_CNT] < P.cand_cap ? misc[MISC_CAND_CNT] : P.cand_cap;
-    // pass 1: count survivors
-    uint32_t mine = 0;
-    for (uint32_t i = tid; i < n; i += blockDim.x) mine += (__uint_as_float(cand[i].x) >= tau);
-    if (mine) atomicAdd(&misc[MISC_FLUSH_CNT], mine);
-    __syncthreads();
-    const uint32_t surv = misc[MISC_FLUSH_CNT];
-    if (tid == 0) {
-        uint32_t ob = 0;
-        if (surv > WG_SLOTS) ob = atomicAdd(P.ovf_count, surv - WG_SLOTS);
-        misc[MISC_OVF_BASE] = ob;
-    }
-    __syncthreads();
-    // pass 2: the first WG_SLOTS survivors go to this workgroup's fixed slots, the rest to the shared overflow list.
-    // Write-through (sc1) stores: in fused mode another workgroup of this launch reads them.
-    const uint32_t ovf_base = misc[MISC_OVF_BASE];
-    unsigned long long *out = P.wg_cand + (size_t)bid * WG_SLOTS;
-    for (uint32_t i = tid; i < n; i += blockDim.x) {
-        const uint2 c = cand[i];
-        if (__uint_as_float(c.x) >= tau) {
-            const uint32_t pos = atomicAdd(&misc[MISC_FLUSH_POS], 1u);
-            if (pos < WG_SLOTS) {
-                st_agent(&out[pos], pack_cand(c.x, c.y));
-            } else {
-                const uint32_t gp = ovf_base + (pos - WG_SLOTS);
-                if (gp < P.ovf_cap) st_agent(&P.ovf_cand[gp], pack_cand(c.x, c.y));
+    // ---- flush: every wave on its own, no workgroup synchronisation. What still clears the (now much tighter)
+    // threshold leaves the wave's private list: the first survivor to this wave's fixed slot, further ones to the
+    // shared overflow list. Slots without a survivor are NOT written: the selection resets every slot it consumed,
+    // so an untouched slot is invalid by construction. Write-through (sc1) stores: in fused mode another workgroup
+    // of this launch reads them.
+    if (!is_server) {
+        const float tau = __uint_as_float(
+            __hip_atomic_load(&misc[MISC_TAU], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        uint2 e0, e1;
+        uint32_t p0, p1;
+        bool k0, k1;
+        const uint32_t surv = compact_list(wcand, wcnt, tau, lane, e0, e1, p0, p1, k0, k1);
+        if (surv != 0u) {
+            uint32_t gbase = 0u;
+            if (surv > 1u) {
+                if (lane == 0) gbase = atomicAdd(P.ovf_count, surv - 1u);
+                gbase = __builtin_amdgcn_readfirstlane(gbase);
+            }
+            unsigned long long *slot = P.wg_cand + (size_t)bid * WG_SLOTS + wave;
+            if (k0) {
+                if (p0 == 0u) st_agent(slot, pack_cand(e0.x, e0.y));
+                else if (gbase + p0 - 1u < P.ovf_cap) st_agent(&P.ovf_cand[gbase + p0 - 1u], pack_cand(e0.x, e0.y));
+            }
+            if (k1) {
+                if (p1 == 0u) st_agent(slot, pack_cand(e1.x, e1.y));
+                else if (gbase + p1 - 1u < P.ovf_cap) st_agent(&P.ovf_cand[gbase + p1 - 1u], pack_cand(e1.x, e1.y));
             }
         }
+        if (P.dbg && lane == 0 && wave == 0u) {  // TKSPMV_STATS=1 (approximate: waves still running are not counted)
+            atomicAdd(&P.dbg[0], (unsigned long long)misc[MISC_SLOW_CNT]);
+            atomicAdd(&P.dbg[1], (unsigned long long)misc[MISC_CAND_CNT]);
+        }
     }
-    if (tid < WG_SLOTS && tid >= surv) st_agent(&out[tid], pack_cand(0u, SLOT_INVALID));
+    if (tr && lane == 0) {
+        tr[0] = tr0;
+        tr[1] = tr1;
+        tr[2] = tr2;
+        tr[3] = tr3;
+        tr[4] = tr4;
+        tr[5] = __builtin_amdgcn_s_memrealtime();
+        tr[6] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | (uint32_t)__builtin_amdgcn_s_getreg(63492);  // XCC_ID | HW_ID
+    }
     if (!P.fused) {
         if (bid == 0u && tid == 0u && P.unit_inv_out) *P.unit_inv_out = inv_unit;
         return;
@@ -1010,6 +1109,7 @@ struct EngineImpl {
     uint32_t *d_done = nullptr;
     bool fused = true;
     bool can_defer = false;
+    uint32_t n_reducers = 0;  // TKSPMV_REDUCERS (tuning): workgroups whose server derives tau from all maxima itself
     float *d_out_val = nullptr, *d_scores = nullptr;
     unsigned long long *d_stats = nullptr;
     uint32_t grid = 0, block = 0, gpw = 1, n_sets = 0, n_groups_pub = 0, cand_cap = 0, ovf_cap = 0, lds_bytes = 0,
@@ -1017,6 +1117,8 @@ struct EngineImpl {
     bool collect_stats = false;
     bool q8 = false;
     bool collect_stamps = false;
+    unsigned long long *d_trace = nullptr;  // TKSPMV_TRACE=1: 4 launches x [grid+1][9][8] stamps
+    size_t trace_words = 0;
     uint32_t dbg_flags = 0;
     bool have_query = false;
     bool ran = false;
@@ -1039,7 +1141,8 @@ struct EngineImpl {
         P.min_score = desc.min_score;  // converted to score units inside the kernel
         P.gmax = E.gmax;
         P.tau_g = E.tau_g;
-        P.n_reducers = grid < 8u ? grid : 8u;
+        P.n_reducers = n_reducers ? n_reducers : (grid < 8u ? grid : 8u);
+
         P.wg_cand = E.wg_cand;
         P.cand_cap = cand_cap;
         P.ovf_cand = E.ovf;
@@ -1051,6 +1154,7 @@ struct EngineImpl {
         P.unit_inv_out = E.unit_inv;
         P.dbg = collect_stats ? d_stats + 4 : nullptr;
         P.stamps = collect_stamps ? d_stats + 16 : nullptr;
+        P.trace = d_trace ? d_trace + (launch_counter % 4) * trace_words : nullptr;
         P.dbg_flags = dbg_flags;
         return P;
     }
@@ -1105,7 +1209,7 @@ struct EngineImpl {
             S.unit_inv_in = st[pending_set].unit_inv;
         }
         ++launch_counter;
-        hipLaunchKernelGGL(kernel_for(false), dim3(grid + 1), dim3(block + 64), 0, s, P, S);
+        hipLaunchKernelGGL(kernel_for(false), dim3(grid), dim3(block + 64), 0, s, P, S);
         pending = true;
         pending_set = cur_set;
         pending_idx = out_idx;
@@ -1181,7 +1285,7 @@ Engine::~Engine() {
     (void)hipSetDevice(m.device);
     if (m.stream) (void)hipStreamSynchronize(m.stream);
     void *bufs[] = {m.d_packets, m.d_pkt_row, m.d_part_first, m.d_part_count, m.d_x,    m.d_wg_count,
-                    m.d_out_idx, m.d_out_val, m.d_scores,     m.d_stats,      m.d_done};
+                    m.d_out_idx, m.d_out_val, m.d_scores,     m.d_stats,      m.d_done, m.d_trace};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     for (auto &E : m.st) {
@@ -1261,9 +1365,12 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err) {
     const uint32_t C = d.nnz_per_lane > 0 ? (uint32_t)d.nnz_per_lane : 4u;
 
     int kind = 0;
+    // Deferred selection gives workgroup 0 of a back-to-back launch to the previous query's selection: one
+    // partition per streaming wave of the remaining grid - 1 workgroups.
+    const bool defer_capable = m.grid >= 2 && (uint64_t)m.grid * WG_SLOTS <= (uint64_t)SEL_PER_THREAD * (m.block + 64);
     std::string perr = pack_wbscsr(d.rows, d.cols, d.nnz, d.row, d.col, d.val,
                                    d.precision == TKSPMV_F32 ? Precision::F32 : Precision::Q1_7, C,
-                                   m.grid * waves_per_wg, 4, m.pm, kind);
+                                   (m.grid - (defer_capable ? 1u : 0u)) * waves_per_wg, 4, m.pm, kind);
     if (!perr.empty()) {
         err = perr;
         return kind == 2 ? TKSPMV_ERR_NOT_SORTED : TKSPMV_ERR_INVALID;
@@ -1331,8 +1438,9 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err) {
     // Fused tail / deferred selection: one workgroup (block + 64 threads) must hold every slot in SEL_PER_THREAD
     // registers per thread.
     m.fused = (uint64_t)m.grid * WG_SLOTS <= (uint64_t)SEL_PER_THREAD * (m.block + 64);
-    m.can_defer = m.fused;
+    m.can_defer = defer_capable;
     if (const char *f = getenv("TKSPMV_FUSED")) m.fused = m.fused && atoi(f) != 0;
+    if (const char *f = getenv("TKSPMV_REDUCERS")) m.n_reducers = (uint32_t)atoi(f);
     if (const char *f = getenv("TKSPMV_DEFER")) m.can_defer = m.can_defer && atoi(f) != 0;
     for (int si = 0; si < EngineImpl::N_STATE; ++si) {
         EngineImpl::ExState &E = m.st[si];
@@ -1354,6 +1462,11 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err) {
     HIP_TRY(hipMemset(m.d_wg_count, 0, (size_t)m.grid * 4));
     HIP_TRY(hipMemset(m.d_stats, 0, 32 * 8));
     m.collect_stamps = getenv("TKSPMV_STAMPS") != nullptr;
+    if (getenv("TKSPMV_TRACE")) {
+        m.trace_words = (size_t)(m.grid + 1) * 9 * 8;
+        HIP_TRY(hipMalloc((void **)&m.d_trace, m.trace_words * 4 * 8));
+        HIP_TRY(hipMemset(m.d_trace, 0, m.trace_words * 4 * 8));
+    }
     HIP_TRY(hipMemset(m.d_out_idx, 0, (size_t)d.k * 4));
     HIP_TRY(hipMemset(m.d_out_val, 0, (size_t)d.k * 4));
 
@@ -1523,6 +1636,20 @@ int Engine::read(uint32_t *idx, float *val, int32_t *n, std::string &err) {
     if (idx) HIP_TRY(hipMemcpy(idx, m.d_out_idx, (size_t)m.desc.k * 4, hipMemcpyDeviceToHost));
     if (val) HIP_TRY(hipMemcpy(val, m.d_out_val, (size_t)m.desc.k * 4, hipMemcpyDeviceToHost));
     if (n) *n = m.desc.k;
+    return TKSPMV_OK;
+}
+
+int Engine::read_trace(unsigned long long *host, size_t max_words, size_t *words, std::string &err) {
+    EngineImpl &m = *impl_;
+    if (!m.d_trace) {
+        err = "tracing is off (set TKSPMV_TRACE=1 before tkspmv_create)";
+        return TKSPMV_ERR_STATE;
+    }
+    HIP_TRY(hipSetDevice(m.device));
+    HIP_TRY(hipDeviceSynchronize());
+    const size_t n = std::min(max_words, m.trace_words * 4);
+    HIP_TRY(hipMemcpy(host, m.d_trace, n * 8, hipMemcpyDeviceToHost));
+    if (words) *words = n;
     return TKSPMV_OK;
 }
 

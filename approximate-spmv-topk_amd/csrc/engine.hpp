@@ -34,6 +34,7 @@ class Engine {
     int read(uint32_t *idx, float *val, int32_t *n, std::string &err);
     int result_device(const uint32_t **dev_idx, const float **dev_val);
     int scores(float *host_y, std::string &err);
+    int read_trace(unsigned long long *host, size_t max_words, size_t *words, std::string &err);
     int profile(const float *dev_xs, int32_t n_x, int32_t iters, tkspmv_timing *out, std::string &err);
     void info(tkspmv_info *out) const;
 

@@ -155,6 +155,11 @@ int tkspmv_result_device(tkspmv_t *e, const uint32_t **dev_idx, const float **de
 /* Debug/verification: full score vector y = A.x of the current query (rows floats, host). */
 int tkspmv_scores(tkspmv_t *e, float *host_y);
 
+/* Diagnostics (TKSPMV_TRACE=1 at create time): per-wave 100 MHz wall-clock stamps of the last four launches,
+ * [4][grid+1][9 waves][8] words: entry, x staged, first packet reduced, stream loop done, deferred packets judged,
+ * flush done. tools/timeline.py turns them into a timeline. TKSPMV_ERR_STATE when tracing is off. */
+int tkspmv_debug_trace(tkspmv_t *e, uint64_t *host, uint64_t max_words, uint64_t *words);
+
 /* Benchmark helper: run `iters` queries cycling over `n_x` device-resident vectors (stride cols floats)
  * back-to-back on the engine stream, timed with hipEvents on that stream. */
 int tkspmv_profile(tkspmv_t *e, const float *dev_xs, int32_t n_x, int32_t iters, tkspmv_timing *out);
