@@ -78,7 +78,7 @@ class OptionsC(C.Structure):
 EXPORTED_SYMBOLS = [
     "tkspmv_create", "tkspmv_destroy", "tkspmv_get_info", "tkspmv_set_query", "tkspmv_set_query_device",
     "tkspmv_run", "tkspmv_enqueue", "tkspmv_enqueue_many", "tkspmv_enqueue_batch", "tkspmv_synchronize", "tkspmv_read", "tkspmv_result_device", "tkspmv_scores", "tkspmv_debug_trace",
-    "tkspmv_profile", "tkspmv_last_error", "tkspmv_device_count", "tkspmv_mtx_read", "tkspmv_mtx_free",
+    "tkspmv_time_queries", "tkspmv_profile", "tkspmv_last_error", "tkspmv_device_count", "tkspmv_mtx_read", "tkspmv_mtx_free",
     "tkspmv_mtx_write", "tkspmv_sample_vector", "tkspmv_generate", "tkspmv_options_parse", "tkspmv_pack",
     "tkspmv_packed_info", "tkspmv_packed_decode", "tkspmv_packed_raw", "tkspmv_packed_free",
     "tkspmv_dist_unique_id", "tkspmv_dist_create", "tkspmv_dist_set_batch", "tkspmv_dist_enqueue", "tkspmv_dist_run_many",
@@ -116,6 +116,7 @@ def lib():
     L.tkspmv_result_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
     L.tkspmv_scores.argtypes = [vp, f32p]
     L.tkspmv_debug_trace.argtypes = [vp, C.POINTER(C.c_uint64), C.c_uint64, C.POINTER(C.c_uint64)]
+    L.tkspmv_time_queries.argtypes = [vp, vp, C.c_int32, C.c_int32, C.POINTER(C.c_double)]
     L.tkspmv_profile.argtypes = [vp, vp, C.c_int32, C.c_int32, C.POINTER(Timing)]
     L.tkspmv_mtx_read.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(Coo)]
     L.tkspmv_mtx_free.argtypes = [C.POINTER(Coo)]

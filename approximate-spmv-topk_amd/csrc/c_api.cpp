@@ -94,6 +94,9 @@ int tkspmv_debug_trace(tkspmv_t *h, uint64_t *host, uint64_t max_words, uint64_t
     if (words) *words = w;
     return st;
 }
+int tkspmv_time_queries(tkspmv_t *h, const float *dev_xs, int32_t n_x, int32_t iters, double *ns_per_query) {
+    ENGINE_CALL(time_queries(dev_xs, n_x, iters, ns_per_query, err))
+}
 int tkspmv_profile(tkspmv_t *h, const float *dev_xs, int32_t n_x, int32_t iters, tkspmv_timing *out) {
     ENGINE_CALL(profile(dev_xs, n_x, iters, out, err))
 }

@@ -78,8 +78,13 @@ struct StreamParams {
 
 constexpr int MISC_CAND_CNT = 0, MISC_TAU = 1, MISC_DONE = 5, MISC_XMAX = 6, MISC_SLOW_CNT = 7,
               MISC_GRPMAX = 8 /* [8] */, MISC_PUBLISHED = 16 /* [8] */, MISC_WORDS = 32;  // <= 8 groups per workgroup
-constexpr uint32_t CAND_CAP = 1024;  // candidate list entries in LDS per workgroup ...
-constexpr uint32_t WAVE_CAP = 128;   // ... = 8 streaming waves x a private list each
+// Private candidate list of a streaming wave (entries in LDS): 256 while x is small, 128 when x itself takes 64 KiB
+// (two workgroups must still fit the CU's 160 KiB).
+template <int XCOLS>
+struct ListGeom {
+    static constexpr uint32_t WAVE_CAP = XCOLS <= 4096 ? 256u : 128u;
+    static constexpr uint32_t CAND_CAP = 8u * WAVE_CAP;  // per workgroup: up to 8 streaming waves
+};
 constexpr uint32_t WG_SLOTS = 8;              // fixed result slots every workgroup writes (no count round trip)
 constexpr uint32_t SLOT_INVALID = 0xFFFFFFFFu;  // row id of an unused slot
 
@@ -614,29 +619,46 @@ __device__ __forceinline__ uint32_t ends_below(const RowSums<C> &R) {
     return below;
 }
 
-// Drop from a wave's private candidate list what the (risen) threshold has made obsolete; returns the new length.
-// All reads are issued before any write (LDS executes a wave's instructions in order), so writing the kept entries
-// to the front cannot clobber an entry another lane still has to read.
-__device__ __forceinline__ uint32_t compact_list(uint2 *wcand, uint32_t n, float tau, uint32_t lane, uint2 &e0, uint2 &e1,
-                                                 uint32_t &p0, uint32_t &p1, bool &k0, bool &k1) {
-    e0 = make_uint2(0u, 0u);
-    e1 = make_uint2(0u, 0u);
-    if (lane < n) e0 = wcand[lane];
-    if (lane + 64u < n) e1 = wcand[lane + 64u];
-    k0 = lane < n && __uint_as_float(e0.x) >= tau;
-    k1 = lane + 64u < n && __uint_as_float(e1.x) >= tau;
-    const uint64_t b0 = __ballot(k0), b1 = __ballot(k1);
-    const uint32_t c0 = (uint32_t)__popcll(b0);
-    p0 = __builtin_amdgcn_mbcnt_hi((uint32_t)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b0, 0u));
-    p1 = c0 + __builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, 0u));
-    return c0 + (uint32_t)__popcll(b1);
+// Filter a wave's private candidate list against the threshold: lane l holds entries l, l+64, ... (EPL per lane);
+// keep[] / pos[] tell which survive and where they go in the compacted order. Returns the number kept.
+template <uint32_t EPL>
+struct ListScan {
+    uint2 e[EPL];
+    uint32_t pos[EPL];
+    bool keep[EPL];
+};
+template <uint32_t EPL>
+__device__ __forceinline__ uint32_t scan_list(const uint2 *wcand, uint32_t n, float tau, uint32_t lane, ListScan<EPL> &L) {
+    uint32_t total = 0;
+#pragma unroll
+    for (uint32_t u = 0; u < EPL; ++u) {
+        const uint32_t i = lane + 64u * u;
+        L.e[u] = make_uint2(0u, 0u);
+        if (i < n) L.e[u] = wcand[i];
+        L.keep[u] = i < n && __uint_as_float(L.e[u].x) >= tau;
+        const uint64_t b = __ballot(L.keep[u]);
+        L.pos[u] = total + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+        total += (uint32_t)__popcll(b);
+    }
+    return total;
+}
+// Drop what the (risen) threshold has made obsolete. All reads are issued before any write (LDS executes a wave's
+// instructions in order), so writing the kept entries to the front cannot clobber an entry still to be read.
+template <uint32_t EPL>
+__device__ __forceinline__ uint32_t compact_list(uint2 *wcand, uint32_t n, float tau, uint32_t lane) {
+    ListScan<EPL> L;
+    const uint32_t kept = scan_list<EPL>(wcand, n, tau, lane, L);
+#pragma unroll
+    for (uint32_t u = 0; u < EPL; ++u)
+        if (L.keep[u]) wcand[L.pos[u]] = L.e[u];
+    return kept;
 }
 
 // Candidate path (rare once tau has converged). Every streaming wave owns a private list of WAVE_CAP entries in LDS
 // (its length lives in an SGPR: no atomic, no other wave involved). A full list is first compacted against the
 // current threshold; only what still does not fit goes to the shared overflow list in global memory, with ONE
 // atomic per wave and packet. One LDS atomic raises the group maximum (the server wave pushes it to global memory).
-template <int C, int QM>
+template <int C, int QM, uint32_t WAVE_CAP>
 __device__ __forceinline__ void offer_candidates(const StreamParams &P, const RowSums<C> &R, uint32_t rb, float tau,
                                                  uint32_t lane, uint32_t grp_local, bool publishes, uint2 *wcand,
                                                  uint32_t &wcnt, uint32_t *misc) {
@@ -663,14 +685,7 @@ __device__ __forceinline__ void offer_candidates(const StreamParams &P, const Ro
             atomicAdd(&misc[MISC_CAND_CNT], total);
         }
     }
-    if (wcnt + total > WAVE_CAP) {
-        uint2 e0, e1;
-        uint32_t p0, p1;
-        bool k0, k1;
-        wcnt = compact_list(wcand, wcnt, tau, lane, e0, e1, p0, p1, k0, k1);
-        if (k0) wcand[p0] = e0;
-        if (k1) wcand[p1] = e1;
-    }
+    if (wcnt + total > WAVE_CAP) wcnt = compact_list<WAVE_CAP / 64u>(wcand, wcnt, tau, lane);
     const uint32_t base = wcnt;
     const uint32_t first_ovf = base < WAVE_CAP ? WAVE_CAP : base;  // list position of the first overflowing row
     uint32_t gbase = 0u;
@@ -715,7 +730,7 @@ struct StreamLds {
     union {
         struct {
             float x[XCOLS];
-            uint2 cand[CAND_CAP];  // candidate list {score bits, row}
+            uint2 cand[ListGeom<XCOLS>::CAND_CAP];  // private candidate lists {score bits, row}
         } w;
         SelectShared sel;  // fused selection tail (last workgroup only)
     } u;
@@ -872,6 +887,7 @@ __global__ void __launch_bounds__(576, 5) stream_kernel(const StreamParams P, co
         if (!SCORES && P.n_sets != 0u) publish_group_max(P, bid, lane, misc);
         if (!SCORES && !P.fused) return;
     }
+    constexpr uint32_t WAVE_CAP = ListGeom<XCOLS>::WAVE_CAP;
     uint2 *wcand = cand + (is_server ? 0u : wave) * WAVE_CAP;  // this wave's private candidate list
     uint32_t wcnt = 0u;                                         // its length (wave-uniform)
     for (bool first_part = true; q < P.n_parts; q += total_waves, first_part = false) {
@@ -946,7 +962,7 @@ __global__ void __launch_bounds__(576, 5) stream_kernel(const StreamParams P, co
                         (void)__hip_atomic_fetch_max(&misc[MISC_GRPMAX + grp_local], order_key(wmax), __ATOMIC_RELAXED,
                                                      __HIP_MEMORY_SCOPE_WORKGROUP);
                 } else if (__any(R.best_any >= tau) && !(P.dbg_flags & 2u)) {
-                    offer_candidates<C, QM>(P, R, rb_cur, tau, lane, grp_local, publishes, wcand, wcnt, misc);
+                    offer_candidates<C, QM, ListGeom<XCOLS>::WAVE_CAP>(P, R, rb_cur, tau, lane, grp_local, publishes, wcand, wcnt, misc);
                 }
             }
             }
@@ -959,7 +975,7 @@ __global__ void __launch_bounds__(576, 5) stream_kernel(const StreamParams P, co
 #pragma unroll
             for (int d = 0; d < DEFER; ++d) {
                 if (np > (uint32_t)d && __any(st[d].best_any >= tau))
-                    offer_candidates<C, QM>(P, st[d], st_rb[d], tau, lane, grp_local, publishes, wcand, wcnt, misc);
+                    offer_candidates<C, QM, ListGeom<XCOLS>::WAVE_CAP>(P, st[d], st_rb[d], tau, lane, grp_local, publishes, wcand, wcnt, misc);
             }
         }
     }
@@ -978,10 +994,8 @@ __global__ void __launch_bounds__(576, 5) stream_kernel(const StreamParams P, co
     if (!is_server) {
         const float tau = __uint_as_float(
             __hip_atomic_load(&misc[MISC_TAU], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-        uint2 e0, e1;
-        uint32_t p0, p1;
-        bool k0, k1;
-        const uint32_t surv = compact_list(wcand, wcnt, tau, lane, e0, e1, p0, p1, k0, k1);
+        ListScan<WAVE_CAP / 64u> LS;
+        const uint32_t surv = scan_list<WAVE_CAP / 64u>(wcand, wcnt, tau, lane, LS);
         if (surv != 0u) {
             uint32_t gbase = 0u;
             if (surv > 1u) {
@@ -989,13 +1003,13 @@ __global__ void __launch_bounds__(576, 5) stream_kernel(const StreamParams P, co
                 gbase = __builtin_amdgcn_readfirstlane(gbase);
             }
             unsigned long long *slot = P.wg_cand + (size_t)bid * WG_SLOTS + wave;
-            if (k0) {
-                if (p0 == 0u) st_agent(slot, pack_cand(e0.x, e0.y));
-                else if (gbase + p0 - 1u < P.ovf_cap) st_agent(&P.ovf_cand[gbase + p0 - 1u], pack_cand(e0.x, e0.y));
-            }
-            if (k1) {
-                if (p1 == 0u) st_agent(slot, pack_cand(e1.x, e1.y));
-                else if (gbase + p1 - 1u < P.ovf_cap) st_agent(&P.ovf_cand[gbase + p1 - 1u], pack_cand(e1.x, e1.y));
+#pragma unroll
+            for (uint32_t u = 0; u < WAVE_CAP / 64u; ++u) {
+                if (LS.keep[u]) {
+                    const unsigned long long v = pack_cand(LS.e[u].x, LS.e[u].y);
+                    if (LS.pos[u] == 0u) st_agent(slot, v);
+                    else if (gbase + LS.pos[u] - 1u < P.ovf_cap) st_agent(&P.ovf_cand[gbase + LS.pos[u] - 1u], v);
+                }
             }
         }
         if (P.dbg && lane == 0 && wave == 0u) {  // TKSPMV_STATS=1 (approximate: waves still running are not counted)
@@ -1385,14 +1399,14 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err) {
     m.n_groups_pub = std::min<uint32_t>(m.grid * m.gpw, MAX_GM * 64);
     m.n_sets = (m.n_groups_pub >= (uint32_t)d.k) ? 1u : 0u;  // 0: exchange disabled, every row >= min_score is a candidate
     if (!m.n_sets) m.n_groups_pub = 1;
-    m.cand_cap = CAND_CAP;
     m.ovf_cap = std::max<uint32_t>(d.rows, 1u);
     m.xcols = d.cols <= 1024 ? 1024u : (d.cols <= 4096 ? 4096u : 16384u);
+    m.cand_cap = m.xcols <= 4096 ? 2048u : 1024u;  // ListGeom<XCOLS>::CAND_CAP
     if (C == 8 && d.cols > 1024) {
         err = "nnz_per_lane = 8 is only built for cols <= 1024";
         return TKSPMV_ERR_UNSUPPORTED;
     }
-    m.lds_bytes = (uint32_t)std::max<size_t>(sizeof(SelectShared), (size_t)m.xcols * 4 + CAND_CAP * 8) +
+    m.lds_bytes = (uint32_t)std::max<size_t>(sizeof(SelectShared), (size_t)m.xcols * 4 + (size_t)m.cand_cap * 8) +
                   MISC_WORDS * 4;  // all static
 
     HIP_TRY(hipStreamCreateWithFlags(&m.stream, hipStreamNonBlocking));
@@ -1672,6 +1686,27 @@ int Engine::scores(float *host_y, std::string &err) {
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(host_y, m.d_scores, (size_t)m.desc.rows * 4, hipMemcpyDeviceToHost, m.stream));
     HIP_TRY(hipStreamSynchronize(m.stream));
+    return TKSPMV_OK;
+}
+
+int Engine::time_queries(const float *dev_xs, int32_t n_x, int32_t iters, double *ns_per_query, std::string &err) {
+    EngineImpl &m = *impl_;
+    if (!dev_xs || n_x < 1 || iters < 1 || !ns_per_query) {
+        err = "bad arguments to time_queries";
+        return TKSPMV_ERR_INVALID;
+    }
+    HIP_TRY(hipSetDevice(m.device));
+    HIP_TRY(hipStreamSynchronize(m.stream));
+    HIP_TRY(hipEventRecord(m.ev0, m.stream));
+    for (int i = 0; i < iters; ++i)
+        m.launch_deferred(dev_xs + (size_t)(i % n_x) * m.desc.cols, m.d_out_idx, m.d_out_val, m.stream);
+    m.drain(m.stream);
+    HIP_TRY(hipEventRecord(m.ev1, m.stream));
+    HIP_TRY(hipEventSynchronize(m.ev1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, m.ev0, m.ev1));
+    *ns_per_query = (double)ms * 1e6 / iters;
+    m.ran = true;
     return TKSPMV_OK;
 }
 

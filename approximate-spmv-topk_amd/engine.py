@@ -79,6 +79,12 @@ class SpMV:
         _lib.check(_lib.lib().tkspmv_enqueue_many(self._h, C.c_void_p(int(dev_xs)), int(n_x), int(count),
                                                   C.c_void_p(int(stream))))
 
+    def time_queries(self, dev_xs, n_x, iters):
+        """ns per query of `iters` back-to-back queries (one hipEvent pair around the batch; nothing else launched)."""
+        ns = C.c_double()
+        _lib.check(_lib.lib().tkspmv_time_queries(self._h, C.c_void_p(int(dev_xs)), int(n_x), int(iters), C.byref(ns)))
+        return ns.value
+
     def enqueue_batch(self, dev_xs, count, dev_idx=0, dev_val=0, stream=0):
         """A batch of `count` queries (rows of a device array, stride cols floats); query i's k results go to
         dev_idx + i*k / dev_val + i*k (device pointers; 0 => engine buffers, last query wins). No host sync."""

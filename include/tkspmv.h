@@ -160,6 +160,10 @@ int tkspmv_scores(tkspmv_t *e, float *host_y);
  * flush done. tools/timeline.py turns them into a timeline. TKSPMV_ERR_STATE when tracing is off. */
 int tkspmv_debug_trace(tkspmv_t *e, uint64_t *host, uint64_t max_words, uint64_t *words);
 
+/* `iters` queries back to back on the engine stream (cycling over n_x device-resident vectors), ONE hipEvent pair
+ * around the batch: *ns_per_query = batch time / iters. Nothing else is launched (for profiler runs). */
+int tkspmv_time_queries(tkspmv_t *e, const float *dev_xs, int32_t n_x, int32_t iters, double *ns_per_query);
+
 /* Benchmark helper: run `iters` queries cycling over `n_x` device-resident vectors (stride cols floats)
  * back-to-back on the engine stream, timed with hipEvents on that stream. */
 int tkspmv_profile(tkspmv_t *e, const float *dev_xs, int32_t n_x, int32_t iters, tkspmv_timing *out);

@@ -1,0 +1,21 @@
+#!/bin/bash
+# Round-end measurement on the GPU box (run from the repository root through gpurun):
+#   bash tools/profile_round.sh r01
+# 1. plain bench line; 2. the same command under rocprofv3 --kernel-trace --stats; 3. separate --pmc passes for the
+# memory-side counters (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE do not fit one pass; no trace domains with --pmc).
+# Everything lands in gpurun_out/prof_<tag>/; tools/summarize_profile.py turns it into the files kept under profiles/.
+set -u
+TAG=${1:-r01}
+REPO=$PWD
+OUT=$REPO/gpurun_out/prof_$TAG
+mkdir -p "$OUT"
+python3 bench.py --steps 3000 --warmup 300 > "$OUT/bench_plain.json" 2> "$OUT/bench_plain.err"
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/ktrace" -- python3 "$REPO/bench.py" --steps 2000 --warmup 200 --cpu-seconds 0 --skip-warm > "$OUT/bench_under_rocprofv3.json" 2> "$OUT/ktrace.err"
+i=0
+for counters in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
+    i=$((i + 1))
+    rocprofv3 --pmc $counters --kernel-trace --output-format csv -d "$OUT/pmc$i" -- python3 "$REPO/bench.py" --steps 300 --warmup 30 --cpu-seconds 0 --skip-warm > "$OUT/pmc$i.json" 2> "$OUT/pmc$i.err"
+done
+cd "$REPO"
+python3 tools/summarize_profile.py "$OUT" "$TAG"

@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Condenses one tools/profile_round.sh run into the small files kept under profiles/:
+  <tag>_kernel_stats.csv, <tag>_domain_stats.csv  (rocprofv3 --kernel-trace --stats, verbatim)
+  <tag>_bench_plain.json, <tag>_bench_under_rocprofv3.json
+  <tag>_pmc_summary.json   per-launch means of the counters for the stream kernel
+  pmc_traffic.json         HBM-side bytes per launch (FETCH_SIZE doubled: gfx950 correction of MI355X_MICROARCH.md)
+Written next to the raw output (gpurun_out/prof_<tag>/summary/); copy that directory's content into profiles/."""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+out, tag = sys.argv[1], sys.argv[2]
+dst = os.path.join(out, "summary")
+os.makedirs(dst, exist_ok=True)
+
+
+def find(pattern):
+    hits = glob.glob(os.path.join(out, pattern), recursive=True)
+    return hits[0] if hits else None
+
+
+for src, name in ((find("ktrace/**/*kernel_stats.csv"), f"{tag}_kernel_stats.csv"),
+                  (find("ktrace/**/*domain_stats.csv"), f"{tag}_domain_stats.csv")):
+    if src:
+        shutil.copy(src, os.path.join(dst, name))
+for src, name in (("bench_plain.json", f"{tag}_bench_plain.json"),
+                  ("bench_under_rocprofv3.json", f"{tag}_bench_under_rocprofv3.json")):
+    p = os.path.join(out, src)
+    if os.path.exists(p):
+        lines = [l for l in open(p).read().splitlines() if l.startswith("{")]
+        if lines:
+            open(os.path.join(dst, name), "w").write(lines[-1] + "\n")
+
+summary = {}
+for d in sorted(glob.glob(os.path.join(out, "pmc*"))):
+    if not os.path.isdir(d):
+        continue
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        acc = {}
+        for row in csv.DictReader(open(f)):
+            if "stream_kernel" not in row.get("Kernel_Name", "") or "Lb1E" in row.get("Kernel_Name", ""):
+                continue  # Lb1E = the SpMV-only variant
+            acc.setdefault(row["Counter_Name"], {}).setdefault(row["Dispatch_Id"], 0.0)
+            acc[row["Counter_Name"]][row["Dispatch_Id"]] += float(row["Counter_Value"])
+        for name, per in acc.items():
+            v = sorted(per.values())
+            v = v[len(v) // 10:]  # drop the first launches (warm-up of the run)
+            summary[name] = {"launches": len(v), "mean": sum(v) / len(v), "min": v[0], "max": v[-1]}
+json.dump(summary, open(os.path.join(dst, f"{tag}_pmc_summary.json"), "w"), indent=1)
+if "FETCH_SIZE" in summary and "WRITE_SIZE" in summary:
+    fetch = summary["FETCH_SIZE"]["mean"] * 1024.0 * 2.0  # KiB -> B, x2: gfx950 tallies 128-B requests at 64 B
+    write = summary["WRITE_SIZE"]["mean"] * 1024.0
+    json.dump({"stream_kernel_hbm_bytes_per_launch": fetch + write, "fetch_bytes_corrected": fetch, "write_bytes": write,
+               "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on bench.py --skip-warm, tag {tag}; "
+                         "FETCH_SIZE x 1024 x 2 (gfx950 correction, MI355X_MICROARCH.md) + WRITE_SIZE x 1024, mean per launch"},
+              open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
+print(json.dumps({k: round(v["mean"], 2) for k, v in summary.items()}))
+print(open(os.path.join(dst, f"{tag}_bench_plain.json")).read()[:600] if os.path.exists(os.path.join(dst, f"{tag}_bench_plain.json")) else "no plain bench line")
+ks = os.path.join(dst, f"{tag}_kernel_stats.csv")
+if os.path.exists(ks):
+    print(open(ks).read()[:1500])
