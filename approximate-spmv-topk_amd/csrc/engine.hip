@@ -71,6 +71,8 @@ struct StreamParams {
     float *unit_inv_out;  // 1 / (score units per 1.0) of this query, for a selection that runs in a later launch
     float *scores;  // SCORES variant only
     uint32_t dbg_flags;       // ablation switches (TKSPMV_DBG_FLAGS): 1 no publish, 2 no offers, 4 no tau duty, 8 no flush
+    const uint8_t *rep_packets[4];  // experiment (TKSPMV_DBG_REPEAT): stream copies the repeats rotate over
+    uint32_t dbg_repeat;            // experiment: passes over the partition within ONE launch (0/1 = normal)
     unsigned long long *trace;   // optional (TKSPMV_TRACE=1): per-wave s_memrealtime stamps, [grid+1][9 waves][8]
     unsigned long long *stamps;  // optional (TKSPMV_STAMPS=1): s_memtime stamps of the selection tail, last workgroup
     unsigned long long *dbg;  // optional counters (TKSPMV_STATS=1): [0] slow-path executions, [1] appended rows
@@ -82,7 +84,7 @@ constexpr int MISC_CAND_CNT = 0, MISC_TAU = 1, MISC_DONE = 5, MISC_XMAX = 6, MIS
 // (two workgroups must still fit the CU's 160 KiB).
 template <int XCOLS>
 struct ListGeom {
-    static constexpr uint32_t WAVE_CAP = XCOLS <= 4096 ? 256u : 128u;
+    static constexpr uint32_t WAVE_CAP = XCOLS <= 1024 ? 256u : 128u;
     static constexpr uint32_t CAND_CAP = 8u * WAVE_CAP;  // per workgroup: up to 8 streaming waves
 };
 constexpr uint32_t WG_SLOTS = 8;              // fixed result slots every workgroup writes (no count round trip)
@@ -204,7 +206,7 @@ __device__ __forceinline__ void select_body(const SelectParams &P, const uint32_
                                             SelectShared &S, const uint32_t dbg_flags = 0u,
                                             unsigned long long *stamps = nullptr, const float out_scale_override = 0.0f) {
     const float out_scale =
-        out_scale_override != 0.0f ? out_scale_override : (P.unit_inv_in ? *P.unit_inv_in : P.out_scale);
+        out_scale_override != 0.0f ? out_scale_override : (P.unit_inv_in ? __hip_atomic_load(P.unit_inv_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : P.out_scale);
     const uint32_t lane = tid & 63u;
     const uint32_t n_slots = P.n_wg * WG_SLOTS;  // host guarantees n_slots <= SEL_PER_THREAD * nthreads
 
@@ -365,6 +367,7 @@ __device__ __forceinline__ void select_body(const SelectParams &P, const uint32_
         P.stats[1] += 1ull;
         if (total > P.stats[2]) P.stats[2] = total;
         if (!small) P.stats[3] += 1ull;
+        P.stats[8] += novf;  // overflow-list entries before pruning
     }
 }
 
@@ -914,6 +917,9 @@ __global__ void __launch_bounds__(576, 5) stream_kernel(const StreamParams P, co
         // Two packets in flight behind the one being reduced. The buffers rotate by NAME (the loop is unrolled by
         // NBUF): copying a freshly loaded buffer into another would wait for the youngest load and drain the
         // prefetch queue every iteration.
+        const uint32_t np_one = np;
+        if (P.dbg_repeat > 1u) np *= P.dbg_repeat;  // experiment: what a persistent multi-query kernel would stream
+        uint32_t ia_cur = NBUF - 1 < np_one ? NBUF - 1 : 0u, ia_rep = 0u;
         for (uint32_t i0 = 0; i0 < np; i0 += NBUF) {
 #pragma unroll
             for (int u = 0; u < NBUF; ++u) {
@@ -926,8 +932,20 @@ __global__ void __launch_bounds__(576, 5) stream_kernel(const StreamParams P, co
             {
                 // Unconditional (index clamped to the last packet): a fixed number of younger loads lets the
                 // compiler wait with a counted vmcnt instead of vmcnt(0).
-                const uint32_t ia = (i + (NBUF - 1) < np) ? (i + (NBUF - 1)) : (np - 1);
-                load_packet<C, Q8>(pk + (size_t)ia * P.packet_bytes, lane, ahead);
+                uint32_t ia = (i + (NBUF - 1) < np) ? (i + (NBUF - 1)) : (np - 1);
+                const uint8_t *pk_a = pk;
+                if (P.dbg_repeat > 1u) {
+                    ia = ia_cur;
+                    pk_a = P.rep_packets[ia_rep & 3u] + (size_t)p0 * P.packet_bytes;
+                    if (i + (NBUF - 1) < np) {
+                        ++ia_cur;
+                        if (ia_cur == np_one) {
+                            ia_cur = 0u;
+                            ++ia_rep;
+                        }
+                    }
+                }
+                load_packet<C, Q8>(pk_a + (size_t)ia * P.packet_bytes, lane, ahead);
                 rb_ahead = P.pkt_row[p0 + ia];
             }
             float tau = 0.0f;
@@ -1073,6 +1091,423 @@ __global__ void __launch_bounds__(576, 5) stream_kernel(const StreamParams P, co
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// Batch kernel: up to BATCH_MAX queries in ONE launch. Measured on the single-query kernel: a launch costs ~6.5 us
+// beyond its steady-state streaming (launch turnaround, first-touch latency of every launch, end skew), and the
+// streaming loop alone runs at ~6.4 TB/s once it is going (TKSPMV_DBG_REPEAT experiment). Here every streaming wave
+// walks its partition once per query with ONE continuous packet prefetch pipeline across query boundaries; nobody
+// waits for another workgroup:
+//   * workgroups 1..grid-1 stream; per query the workgroup's server wave stages x into one of two LDS buffers
+//     (x of query q+1 while the streaming waves are still in q), serves the threshold exchange of the newest query
+//     through that query's own exchange-state set, and, when its 8 streaming waves have counted themselves out of a
+//     query, copies their staged survivors to the query's slots, drains ITS stores and adds the workgroup's ticket
+//     (release). Streaming waves never wait for global memory they do not need: their survivors go to LDS.
+//   * workgroup 0 is the selector: for q = 0, 1, ... it waits until all tickets of q are in (acquire) and runs
+//     select_body on q's state. It waits for the streaming workgroups; none of them ever waits for it or for each
+//     other, so there is no cycle even if not all workgroups are resident at once.
+// Waits inside a streaming workgroup are on its own LDS flags (x staged / waves done), set by waves of the same
+// workgroup that never block on anything but memory.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int BATCH_MAX = 32;
+constexpr uint32_t STG_N = 8;  // survivors a wave can stage per query (64 lanes = 8 waves x 8 when the server copies)
+#ifndef TKSPMV_TAU_WAIT
+#define TKSPMV_TAU_WAIT 3000
+#endif
+constexpr unsigned long long BATCH_TAU_WAIT = TKSPMV_TAU_WAIT;  // x 10 ns (s_memrealtime runs at 100 MHz)
+constexpr int MISC_XREADY = 2, MISC_MINU = 3;  // batch kernel only: x staged for query (value - 1); min score in units
+
+struct BatchQuery {
+    const float *x;
+    const uint8_t *packets;
+    uint32_t *gmax, *tau_g, *ovf_count;
+    unsigned long long *wg_cand, *ovf_cand, *scratch;
+    float *unit_inv;
+    uint32_t *out_idx;
+    float *out_val;
+};
+struct BatchParams {
+    uint32_t n_q;
+    uint32_t *tickets;  // [BATCH_MAX] counters, 32 words apart
+    BatchQuery q[BATCH_MAX];
+};
+
+template <int XCOLS>
+struct BatchLds {
+    union {
+        struct {
+            float x[2][XCOLS];                           // query vector, double-buffered by query parity
+            uint2 cand[ListGeom<XCOLS>::CAND_CAP];       // private candidate lists of the streaming waves
+        } w;
+        SelectShared sel;  // selector workgroup only
+    } u;
+    uint32_t misc[2][MISC_WORDS];                        // per query parity
+    unsigned long long stg[2][8][STG_N];                 // survivors staged by the streaming waves
+    uint32_t stg_cnt[2][8];
+    // Deferred packets (threshold exchange cold start) wait here, not in registers: row sums and packed row flags per
+    // lane. No register cost, so more packets can be deferred (5 while x is small) and fewer rows are appended before
+    // the threshold has arrived.
+#ifndef TKSPMV_DEFER_B
+#define TKSPMV_DEFER_B 2
+#endif
+    static constexpr int DEFER_B = XCOLS <= 1024 ? TKSPMV_DEFER_B : 2;
+    float4 drs[8][DEFER_B][64];
+    uint32_t dfl[8][DEFER_B][64];
+    uint32_t drb[8][DEFER_B];
+};
+
+__device__ __forceinline__ uint32_t lds_load(const uint32_t *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+template <int C, int XCOLS, int QM>
+__global__ void __launch_bounds__(576, 5) batch_kernel(const StreamParams P0, const SelectParams SP0, const BatchParams B) {
+    constexpr bool Q8 = QM != 0;
+    constexpr int NBUF = 3;
+    constexpr uint32_t WAVE_CAP = ListGeom<XCOLS>::WAVE_CAP;
+    __shared__ BatchLds<XCOLS> L;
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t nwaves = (blockDim.x >> 6) - 1u;  // streaming waves
+    const bool is_server = (wave == nwaves);
+    const uint32_t nq = B.n_q;
+
+    if (blockIdx.x == 0u) {
+        // ---- selector workgroup ------------------------------------------------------------------------------
+        const uint32_t n_stream = gridDim.x - 1u;
+        for (uint32_t q = 0; q < nq; ++q) {
+            if (tid == 0) {
+                uint32_t *t = B.tickets + 32u * q;
+                // Polled with a compare-and-swap (which also resets the counter for the next launch): atomics execute
+                // at the device-wide coherence point, whereas a load -- even agent-scope -- can keep hitting a stale
+                // copy of the line in this XCD's L2 (seen: 33 ms on an otherwise idle L2).
+                while (atomicCAS(t, n_stream, 0u) != n_stream) __builtin_amdgcn_s_sleep(32);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            __syncthreads();
+            SelectParams S = SP0;
+            S.wg_cand = B.q[q].wg_cand;
+            S.ovf_cand = B.q[q].ovf_cand;
+            S.ovf_count = B.q[q].ovf_count;
+            S.gmax = B.q[q].gmax;
+            S.tau_g = B.q[q].tau_g;
+            S.scratch = B.q[q].scratch;
+            S.unit_inv_in = B.q[q].unit_inv;
+            S.out_idx = B.q[q].out_idx;
+            S.out_val = B.q[q].out_val;
+            select_body(S, tid, blockDim.x, L.u.sel);
+            __syncthreads();
+            if (P0.trace && tid == 0 && q < 8u) P0.trace[q] = __builtin_amdgcn_s_memrealtime();
+        }
+        return;
+    }
+    const uint32_t bid = blockIdx.x - 1u, n_wg = gridDim.x - 1u;
+    // traced queries: the first, the middle and the last of the batch
+#define TRSLOT(q) ((q) == 0u ? 0u : ((q) == nq / 2u ? 1u : ((q) + 1u == nq ? 2u : 9u)))
+    unsigned long long *trw = P0.trace ? P0.trace + ((size_t)blockIdx.x * 9u + wave) * 8u : nullptr;
+    if (trw && lane == 0) trw[0] = __builtin_amdgcn_s_memrealtime();
+    if (tid < 2u * MISC_WORDS) (&L.misc[0][0])[tid] = 0u;
+    if (tid < 16u) (&L.stg_cnt[0][0])[tid] = 0u;
+    __syncthreads();
+    const uint32_t grp_local = is_server ? 0u : wave * P0.gpw / nwaves;
+    const bool publishes = (bid * P0.gpw + grp_local) < P0.n_groups_pub;
+    const bool reducer = bid < P0.n_reducers;
+
+    if (is_server) {
+        // ---- server wave: x staging, threshold exchange of the newest query, finalisation of the oldest -------
+        uint32_t staged = 0u, tail = 0u;
+        float inv_unit_q[2] = {1.0f, 1.0f}, min_units_q[2] = {0.0f, 0.0f};
+        for (;;) {
+            if (staged < nq && staged - tail < 2u) {
+                const uint32_t par = staged & 1u;
+                const float *xg = B.q[staged].x;
+                float x_scale = 1.0f, unit_scale = 1.0f;
+                if (QM == 2) {
+                    float lm = 0.0f;
+#pragma unroll 1
+                    for (uint32_t b0 = 0; b0 < (uint32_t)XCOLS; b0 += 1024u) {  // 16 loads in flight per lane
+                        float r[16];
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) {
+                            const uint32_t i = b0 + lane + 64u * (uint32_t)u;
+                            r[u] = (i < P0.cols) ? xg[i] : 0.0f;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) lm = fmaxf(lm, r[u]);
+                    }
+                    const float xmax = wave_max(lm);
+                    int sh = 0;
+                    if (xmax > 0.0f) {
+                        const float ratio = 1.9921875f / xmax;
+                        sh = (int)((__float_as_uint(ratio) >> 23) & 255u) - 127;
+                        sh = sh < 0 ? 0 : (sh > 15 ? 15 : sh);
+                    }
+                    x_scale = (float)(1u << sh);
+                    unit_scale = 128.0f * x_scale;
+                } else if (QM == 1) {
+                    unit_scale = 128.0f;
+                }
+                inv_unit_q[par] = 1.0f / unit_scale;
+                min_units_q[par] = P0.min_score * unit_scale;
+                float *xl = L.u.w.x[par];
+#pragma unroll 1
+                for (uint32_t b0 = 0; b0 < (uint32_t)XCOLS; b0 += 1024u) {  // 16 loads in flight per lane
+                    float r[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) {
+                        const uint32_t i = b0 + lane + 64u * (uint32_t)u;
+                        r[u] = (i < P0.cols) ? xg[i] : 0.0f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) {
+                        const uint32_t i = b0 + lane + 64u * (uint32_t)u;
+                        if (Q8)
+                            reinterpret_cast<uint32_t *>(xl)[i] = to_q1_7_dev(r[u] * x_scale);
+                        else
+                            xl[i] = r[u];
+                    }
+                }
+                uint32_t *mp = L.misc[par];
+                if (lane < (uint32_t)MISC_WORDS && lane != (uint32_t)MISC_XREADY) mp[lane] = 0u;
+                if (lane < 8u) L.stg_cnt[par][lane] = 0u;
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                if (lane == 0) {
+                    mp[MISC_TAU] = __float_as_uint(min_units_q[par]);
+                    mp[MISC_MINU] = __float_as_uint(min_units_q[par]);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_store(&mp[MISC_XREADY], staged + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (trw && lane == 0 && TRSLOT(staged) < 3u) trw[1 + TRSLOT(staged)] = __builtin_amdgcn_s_memrealtime();
+                ++staged;
+            }
+            // Threshold exchange of the query this workgroup's waves are streaming: the oldest unfinished one until
+            // half of the waves have left it, then the next (whose waves need a threshold most).
+            if (P0.n_sets != 0u && !(P0.dbg_flags & 4u)) {
+                uint32_t hq = tail;
+                if (tail + 1u < staged &&
+                    2u * __builtin_amdgcn_readfirstlane(lds_load(&L.misc[tail & 1u][MISC_DONE])) >= nwaves)
+                    hq = tail + 1u;
+                {
+                    const uint32_t sq = hq;
+                    StreamParams P = P0;
+                    P.gmax = B.q[sq].gmax;
+                    P.tau_g = B.q[sq].tau_g;
+                    uint32_t *mp = L.misc[sq & 1u];
+                    const float min_units = min_units_q[sq & 1u];
+                    publish_group_max(P, bid, lane, mp);
+                    float t;
+                    if (reducer) {
+                        TauRegs tr_;
+                        tau_issue(P, lane, tr_);
+                        t = tau_from_maxima(P, tr_, min_units);
+                        if (lane == 0 && t > min_units)
+                            __hip_atomic_fetch_max(P.tau_g, order_key(t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } else {
+                        const uint32_t kx = __hip_atomic_load(P.tau_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        t = kx ? key_to_float(kx) : min_units;
+                    }
+                    if (lane == 0) {
+                        const float cur_tau = __uint_as_float(lds_load(&mp[MISC_TAU]));
+                        if (t > cur_tau)
+                            __hip_atomic_store(&mp[MISC_TAU], __float_as_uint(t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+            }
+            // finalise the oldest query once its streaming waves have all counted themselves out
+            {
+                const uint32_t tp = tail & 1u;
+                uint32_t *mp = L.misc[tp];
+                if (tail < staged && __builtin_amdgcn_readfirstlane(lds_load(&mp[MISC_DONE])) >= nwaves) {
+                    asm volatile("" ::: "memory");
+                    StreamParams P = P0;
+                    P.gmax = B.q[tail].gmax;
+                    if (P0.n_sets != 0u) publish_group_max(P, bid, lane, mp);  // complete maxima (fire and forget)
+                    // lane l copies entry (l % 8) of wave (l / 8): the first goes to the wave's slot, others to the
+                    // query's overflow list
+                    const uint32_t w = lane >> 3, e = lane & 7u;
+                    const uint32_t cnt = L.stg_cnt[tp][w];
+                    const bool have = e < cnt;
+                    const unsigned long long v = have ? L.stg[tp][w][e] : 0ull;
+                    const bool extra = have && e > 0u;
+                    const uint64_t bm = __ballot(extra);
+                    uint32_t gbase = 0u;
+                    if (bm) {
+                        if (lane == 0) gbase = atomicAdd(B.q[tail].ovf_count, (uint32_t)__popcll(bm));
+                        gbase = __builtin_amdgcn_readfirstlane(gbase);
+                    }
+                    if (have && e == 0u) st_agent(B.q[tail].wg_cand + (size_t)bid * WG_SLOTS + w, v);
+                    if (extra) {
+                        const uint32_t gp = gbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
+                        if (gp < P0.ovf_cap) st_agent(&B.q[tail].ovf_cand[gp], v);
+                    }
+                    if (bid == 0u && lane == 0)
+                        __hip_atomic_store(B.q[tail].unit_inv, inv_unit_q[tp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    // Hand-off as in the fused tail (cdna_hip_programming.md Guideline 16): everything above is a
+                    // write-through (sc1) store; drain them, then a RELAXED agent-scope add. A release-ordered atomic
+                    // would write back the whole L2 (buffer_wbl2) once per workgroup and query: measured 4 ms/query.
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (lane == 0)
+                        (void)__hip_atomic_fetch_add(B.tickets + 32u * tail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (trw && lane == 0 && TRSLOT(tail) < 3u) trw[4 + TRSLOT(tail)] = __builtin_amdgcn_s_memrealtime();
+                    ++tail;
+                }
+            }
+            if (tail == nq) break;
+            if (reducer) __builtin_amdgcn_s_sleep(TKSPMV_REDUCER_SLEEP);
+            else __builtin_amdgcn_s_sleep(8);
+        }
+        return;
+    }
+
+    // ---- streaming waves ---------------------------------------------------------------------------------------
+    __builtin_amdgcn_s_setprio(TKSPMV_STREAM_PRIO);
+    const uint32_t part = wave * n_wg + bid;
+    uint32_t p0 = 0, np = 0;
+    if (part < P0.n_parts) {
+        p0 = P0.part_first[part];
+        np = P0.part_count[part];
+    }
+    uint2 *wcand = L.u.w.cand + wave * WAVE_CAP;
+    if (np == 0u) {  // no partition: only take part in the per-query protocol
+        for (uint32_t q = 0; q < nq; ++q) {
+            uint32_t *mp = L.misc[q & 1u];
+            while (lds_load(&mp[MISC_XREADY]) != q + 1u) __builtin_amdgcn_s_sleep(4);
+            if (lane == 0) atomicAdd(&mp[MISC_DONE], 1u);
+        }
+        return;
+    }
+
+    Pkt<C, Q8> buf[NBUF];
+    uint32_t rbs[NBUF];
+    uint32_t qa = 0u, ja = 0u;  // next packet to request: (query, packet of the partition)
+    const uint8_t *pk_a = B.q[0].packets + (size_t)p0 * P0.packet_bytes;  // partition base in the stream copy of query qa
+#define TKSPMV_REQUEST(dst, rb_dst)                                                                                   \
+    do {                                                                                                              \
+        load_packet<C, Q8>(pk_a + (size_t)ja * P0.packet_bytes, lane, dst);                                           \
+        rb_dst = P0.pkt_row[p0 + ja];                                                                                 \
+        if (!(qa + 1u == nq && ja + 1u == np)) { /* past the end: the last packet is requested again (counted vmcnt) */ \
+            ++ja;                                                                                                     \
+            if (ja == np) {                                                                                           \
+                ja = 0u;                                                                                              \
+                ++qa;                                                                                                 \
+                pk_a = B.q[qa].packets + (size_t)p0 * P0.packet_bytes;                                                \
+            }                                                                                                         \
+        }                                                                                                             \
+    } while (0)
+#pragma unroll
+    for (int u = 0; u < NBUF - 1; ++u) TKSPMV_REQUEST(buf[u], rbs[u]);
+    rbs[NBUF - 1] = 0u;
+
+    uint32_t qc = 0u, jc = 0u;  // packet being reduced
+    float carry = 0.0f, min_units = 0.0f;
+    uint32_t wcnt = 0u;
+    uint32_t *mp = L.misc[0];
+    const float *xq = L.u.w.x[0];
+    StreamParams P = P0;
+    constexpr uint32_t DEFER_B = (uint32_t)BatchLds<XCOLS>::DEFER_B;
+    static_assert(C == 4, "the batch kernel is built for 4 entries per lane");
+
+    const uint32_t total = np * nq;
+    for (uint32_t i0 = 0; i0 < total; i0 += NBUF) {
+#pragma unroll
+        for (int u = 0; u < NBUF; ++u) {
+            if (i0 + (uint32_t)u >= total) break;
+            const Pkt<C, Q8> &cur = buf[u];
+            const uint32_t rb_cur = rbs[u];
+            TKSPMV_REQUEST(buf[(u + NBUF - 1) % NBUF], rbs[(u + NBUF - 1) % NBUF]);
+            if (jc == 0u) {  // a new query starts: its x must have been staged
+                mp = L.misc[qc & 1u];
+                xq = L.u.w.x[qc & 1u];
+                while (lds_load(&mp[MISC_XREADY]) != qc + 1u) __builtin_amdgcn_s_sleep(2);
+                asm volatile("" ::: "memory");
+                min_units = __uint_as_float(lds_load(&mp[MISC_MINU]));
+                if (trw && lane == 0 && TRSLOT(qc) < 3u) trw[1 + TRSLOT(qc)] = __builtin_amdgcn_s_memrealtime();
+                P.ovf_cand = B.q[qc].ovf_cand;
+                P.ovf_count = B.q[qc].ovf_count;
+                carry = 0.0f;
+                wcnt = 0u;
+            }
+            const float tau = __uint_as_float(lds_load(&mp[MISC_TAU]));
+            const RowSums<C> R = reduce_packet<C, QM>(cur, carry, xq);
+            if (jc < DEFER_B && P0.n_sets != 0u) {
+                L.drs[wave][jc][lane] = make_float4(R.rs[0], R.rs[1], R.rs[2], R.rs[3]);
+                L.dfl[wave][jc][lane] = (R.cw[0] & 0x00030003u) | ((R.cw[1] & 0x00030003u) << 2);
+                if (lane == 0) L.drb[wave][jc] = rb_cur;
+                const float wmax = wave_max(lane_best<C, QM>(R));
+                if (lane == 0 && publishes && wmax >= min_units)
+                    (void)__hip_atomic_fetch_max(&mp[MISC_GRPMAX + grp_local], order_key(wmax), __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else if (__any(R.best_any >= tau) && !(P0.dbg_flags & 2u)) {
+                offer_candidates<C, QM, WAVE_CAP>(P, R, rb_cur, tau, lane, grp_local, publishes, wcand, wcnt, mp);
+            }
+            if (jc + 1u == np) {  // the query ends for this wave
+                if (P0.n_sets != 0u) {
+                    // A workgroup that runs ahead of the others can get here before any threshold exists for this
+                    // query; judging now would keep (and dump to global memory) every row it has seen. Give the
+                    // exchange a moment -- bounded: after BATCH_TAU_WAIT the wave goes on without a threshold, so
+                    // progress never depends on other workgroups being resident.
+                    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                    while (lds_load(&mp[MISC_TAU]) == __float_as_uint(min_units) && !(P0.dbg_flags & 4u) &&
+                           __builtin_amdgcn_s_memrealtime() - t0 < BATCH_TAU_WAIT)
+                        __builtin_amdgcn_s_sleep(4);
+                    const float tau2 = __uint_as_float(lds_load(&mp[MISC_TAU]));
+                    const uint32_t nd = np < DEFER_B ? np : DEFER_B;
+                    for (uint32_t d = 0; d < nd; ++d) {
+                        const float4 v = L.drs[wave][d][lane];
+                        const uint32_t c = L.dfl[wave][d][lane];
+                        RowSums<C> S;
+                        S.rs[0] = v.x;
+                        S.rs[1] = v.y;
+                        S.rs[2] = v.z;
+                        S.rs[3] = v.w;
+                        S.cw[0] = c & 0x00030003u;
+                        S.cw[1] = (c >> 2) & 0x00030003u;
+                        float best = -__builtin_huge_valf();
+#pragma unroll
+                        for (int j = 0; j < C; ++j) best = (S.end(j) && S.rs[j] > best) ? S.rs[j] : best;
+                        S.best_any = best;
+                        const uint32_t rb_d = __builtin_amdgcn_readfirstlane(L.drb[wave][d]);
+                        if (__any(best >= tau2))
+                            offer_candidates<C, QM, WAVE_CAP>(P, S, rb_d, tau2, lane, grp_local, publishes, wcand, wcnt, mp);
+                    }
+                }
+                const float tau3 = __uint_as_float(lds_load(&mp[MISC_TAU]));
+                ListScan<WAVE_CAP / 64u> LS;
+                const uint32_t surv = scan_list<WAVE_CAP / 64u>(wcand, wcnt, tau3, lane, LS);
+                uint32_t gbase = 0u;
+                if (surv > STG_N) {  // rare: more survivors than the staging area holds go to global memory directly
+                    if (lane == 0) gbase = atomicAdd(P.ovf_count, surv - STG_N);
+                    gbase = __builtin_amdgcn_readfirstlane(gbase);
+                }
+#pragma unroll
+                for (uint32_t e = 0; e < WAVE_CAP / 64u; ++e) {
+                    if (LS.keep[e]) {
+                        const unsigned long long v = pack_cand(LS.e[e].x, LS.e[e].y);
+                        if (LS.pos[e] < STG_N) L.stg[qc & 1u][wave][LS.pos[e]] = v;
+                        else if (gbase + LS.pos[e] - STG_N < P0.ovf_cap) st_agent(&P.ovf_cand[gbase + LS.pos[e] - STG_N], v);
+                    }
+                }
+                if (surv > STG_N) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // those stores precede the ticket
+                if (lane == 0) L.stg_cnt[qc & 1u][wave] = surv < STG_N ? surv : STG_N;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) atomicAdd(&mp[MISC_DONE], 1u);
+                if (trw && lane == 0 && TRSLOT(qc) < 3u) {
+                    trw[4 + TRSLOT(qc)] = __builtin_amdgcn_s_memrealtime();
+                    trw[7] = (TRSLOT(qc) == 0u ? 0ull : trw[7]) | ((unsigned long long)(surv > 0xFFFFu ? 0xFFFFu : surv) << (16u * TRSLOT(qc))) |
+                             ((unsigned long long)(tau3 <= min_units ? 1u : 0u) << (48u + TRSLOT(qc)));
+                }
+                ++qc;
+                jc = 0u;
+            } else {
+                ++jc;
+            }
+        }
+    }
+#undef TKSPMV_REQUEST
+}
+
 // Empty kernel with the stream kernel's geometry: calibrates what an event bracket adds around one launch.
 __global__ void __launch_bounds__(576) null_kernel(const uint32_t *p) {
     if (p == nullptr && threadIdx.x == 123456u) __builtin_trap();
@@ -1112,7 +1547,7 @@ struct EngineImpl {
         unsigned long long *wg_cand = nullptr, *ovf = nullptr, *scratch = nullptr;
         float *unit_inv = nullptr;
     };
-    static constexpr int N_STATE = 2;
+    static constexpr int N_STATE = BATCH_MAX;  // deferred selection uses sets 0/1, the batch kernel one per query
     ExState st[N_STATE];
     mutable int cur_set = 0;                  // set the next deferred launch streams into
     mutable bool pending = false;             // a deferred selection is owed for ...
@@ -1123,6 +1558,8 @@ struct EngineImpl {
     uint32_t *d_done = nullptr;
     bool fused = true;
     bool can_defer = false;
+    bool can_batch = false;         // batch kernel usable (exchange on, x double-buffered in LDS, 4 entries per lane)
+    uint32_t *d_tickets = nullptr;  // [BATCH_MAX] x 32 words
     uint32_t n_reducers = 0;  // TKSPMV_REDUCERS (tuning): workgroups whose server derives tau from all maxima itself
     float *d_out_val = nullptr, *d_scores = nullptr;
     unsigned long long *d_stats = nullptr;
@@ -1134,6 +1571,7 @@ struct EngineImpl {
     unsigned long long *d_trace = nullptr;  // TKSPMV_TRACE=1: 4 launches x [grid+1][9][8] stamps
     size_t trace_words = 0;
     uint32_t dbg_flags = 0;
+    uint32_t dbg_repeat = 0;
     bool have_query = false;
     bool ran = false;
 
@@ -1170,6 +1608,9 @@ struct EngineImpl {
         P.stamps = collect_stamps ? d_stats + 16 : nullptr;
         P.trace = d_trace ? d_trace + (launch_counter % 4) * trace_words : nullptr;
         P.dbg_flags = dbg_flags;
+        P.dbg_repeat = dbg_repeat;
+        for (int r = 0; r < 4; ++r)
+            P.rep_packets[r] = d_replicas.empty() ? d_packets : d_replicas[(launch_counter + r) % d_replicas.size()];
         return P;
     }
     SelectParams select_params(uint32_t *out_idx, float *out_val, int set = 0) const {
@@ -1207,6 +1648,49 @@ struct EngineImpl {
         drain(s);
         launch_stream(x, out_idx, out_val, s);
         if (!fused) launch_select(out_idx, out_val, s);
+    }
+    typedef void (*batch_fn)(const StreamParams, const SelectParams, const BatchParams);
+    batch_fn batch_kernel_for() const {
+        if (desc.precision == TKSPMV_Q1_7) return xcols <= 1024 ? &batch_kernel<4, 1024, 1> : &batch_kernel<4, 4096, 1>;
+        if (desc.precision == TKSPMV_Q1_7_WIDE) return xcols <= 1024 ? &batch_kernel<4, 1024, 2> : &batch_kernel<4, 4096, 2>;
+        return xcols <= 1024 ? &batch_kernel<4, 1024, 0> : &batch_kernel<4, 4096, 0>;
+    }
+    // n <= BATCH_MAX queries in one launch of the batch kernel; results complete in stream order after the launch.
+    void launch_batch(const float *const *xs, uint32_t *const *out_idx, float *const *out_val, int n, hipStream_t s) const {
+        drain(s);
+        StreamParams P = stream_params(xs[0], 0);
+        P.fused = 0u;
+        SelectParams S = select_params(out_idx[0], out_val[0], 0);
+        BatchParams B{};
+        B.n_q = (uint32_t)n;
+        B.tickets = d_tickets;
+        for (int q = 0; q < n; ++q) {
+            const ExState &E = st[q];
+            BatchQuery &Q = B.q[q];
+            Q.x = xs[q];
+            Q.packets = d_replicas.empty() ? d_packets : d_replicas[(launch_counter + q) % d_replicas.size()];
+            Q.gmax = E.gmax;
+            Q.tau_g = E.tau_g;
+            Q.ovf_count = E.ovf_count;
+            Q.wg_cand = E.wg_cand;
+            Q.ovf_cand = E.ovf;
+            Q.scratch = E.scratch;
+            Q.unit_inv = E.unit_inv;
+            Q.out_idx = out_idx[q];
+            Q.out_val = out_val[q];
+        }
+        launch_counter += (uint64_t)n;
+        hipLaunchKernelGGL(batch_kernel_for(), dim3(grid), dim3(block + 64), 0, s, P, S, B);
+    }
+    // A back-to-back sequence of queries given as pointer lists: batch kernel launches of up to BATCH_MAX queries
+    // when it is available, else deferred selection.
+    void launch_sequence(const float *const *xs, uint32_t *const *out_idx, float *const *out_val, int n, hipStream_t s) const {
+        if (!can_batch) {
+            for (int i = 0; i < n; ++i) launch_deferred(xs[i], out_idx[i], out_val[i], s);
+            drain(s);
+            return;
+        }
+        for (int i = 0; i < n; i += BATCH_MAX) launch_batch(xs + i, out_idx + i, out_val + i, std::min(BATCH_MAX, n - i), s);
     }
     // One query of a back-to-back sequence: its selection runs inside the NEXT deferred launch (or in drain()).
     void launch_deferred(const float *x, uint32_t *out_idx, float *out_val, hipStream_t s) const {
@@ -1299,11 +1783,11 @@ Engine::~Engine() {
     (void)hipSetDevice(m.device);
     if (m.stream) (void)hipStreamSynchronize(m.stream);
     void *bufs[] = {m.d_packets, m.d_pkt_row, m.d_part_first, m.d_part_count, m.d_x,    m.d_wg_count,
-                    m.d_out_idx, m.d_out_val, m.d_scores,     m.d_stats,      m.d_done, m.d_trace};
+                    m.d_out_idx, m.d_out_val, m.d_scores,     m.d_stats,      m.d_done, m.d_trace, m.d_tickets};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     for (auto &E : m.st) {
-        void *eb[] = {E.tau_g, E.gmax, E.ovf_count, E.wg_cand, E.ovf, E.scratch, E.unit_inv};
+        void *eb[] = {E.tau_g, E.gmax, E.ovf_count, E.wg_cand, E.ovf, (&E == &m.st[0]) ? (void *)E.scratch : nullptr, E.unit_inv};
         for (void *b : eb)
             if (b) (void)hipFree(b);
     }
@@ -1313,6 +1797,18 @@ Engine::~Engine() {
     if (m.ev2) (void)hipEventDestroy(m.ev2);
     if (m.stream) (void)hipStreamDestroy(m.stream);
     delete impl_;
+}
+
+// Exchange words that other XCDs poll (published maxima, threshold word, tickets) live in fine-grained device memory:
+// it is not cached in the per-XCD L2s, so a poll never hits a stale copy (with ordinary memory an agent-scope load can
+// keep returning the old value until the line happens to be evicted: milliseconds on an idle L2).
+static hipError_t malloc_exchange(void **p, size_t bytes) {
+    if (getenv("TKSPMV_COARSE_EXCHANGE") == nullptr &&
+        hipExtMallocWithFlags(p, bytes, hipDeviceMallocFinegrained) == hipSuccess)
+        return hipSuccess;
+    if (getenv("TKSPMV_DEBUG_OCC")) fprintf(stderr, "[tkspmv] fine-grained allocation unavailable, using hipMalloc\n");
+    (void)hipGetLastError();
+    return hipMalloc(p, bytes);
 }
 
 static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err) {
@@ -1401,7 +1897,7 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err) {
     if (!m.n_sets) m.n_groups_pub = 1;
     m.ovf_cap = std::max<uint32_t>(d.rows, 1u);
     m.xcols = d.cols <= 1024 ? 1024u : (d.cols <= 4096 ? 4096u : 16384u);
-    m.cand_cap = m.xcols <= 4096 ? 2048u : 1024u;  // ListGeom<XCOLS>::CAND_CAP
+    m.cand_cap = m.xcols <= 1024 ? 2048u : 1024u;  // ListGeom<XCOLS>::CAND_CAP
     if (C == 8 && d.cols > 1024) {
         err = "nnz_per_lane = 8 is only built for cols <= 1024";
         return TKSPMV_ERR_UNSUPPORTED;
@@ -1447,7 +1943,8 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err) {
     HIP_TRY(hipMalloc((void **)&m.d_stats, 32 * 8));
     m.collect_stats = getenv("TKSPMV_STATS") != nullptr;
     if (const char *f = getenv("TKSPMV_DBG_FLAGS")) m.dbg_flags = (uint32_t)atoi(f);
-    HIP_TRY(hipMalloc((void **)&m.d_done, 9 * 128));
+    if (const char *f = getenv("TKSPMV_DBG_REPEAT")) m.dbg_repeat = (uint32_t)atoi(f);
+    HIP_TRY(malloc_exchange((void **)&m.d_done, 9 * 128));
     HIP_TRY(hipMemset(m.d_done, 0, 9 * 128));
     // Fused tail / deferred selection: one workgroup (block + 64 threads) must hold every slot in SEL_PER_THREAD
     // registers per thread.
@@ -1456,19 +1953,26 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err) {
     if (const char *f = getenv("TKSPMV_FUSED")) m.fused = m.fused && atoi(f) != 0;
     if (const char *f = getenv("TKSPMV_REDUCERS")) m.n_reducers = (uint32_t)atoi(f);
     if (const char *f = getenv("TKSPMV_DEFER")) m.can_defer = m.can_defer && atoi(f) != 0;
+    m.can_batch = m.can_defer && m.n_sets != 0u && m.xcols <= 1024u && C == 4u;  // larger x: two workgroups no longer fit a CU
+    if (const char *f = getenv("TKSPMV_BATCH")) m.can_batch = m.can_batch && atoi(f) != 0;
+    HIP_TRY(malloc_exchange((void **)&m.d_tickets, BATCH_MAX * 32 * 4));
+    HIP_TRY(hipMemset(m.d_tickets, 0, BATCH_MAX * 32 * 4));
     for (int si = 0; si < EngineImpl::N_STATE; ++si) {
         EngineImpl::ExState &E = m.st[si];
-        if (si > 0 && !m.can_defer) break;  // the second set only serves deferred selection
-        HIP_TRY(hipMalloc((void **)&E.gmax, (size_t)MAX_GM * 64 * 4));
+        if (si > 0 && !m.can_defer) break;  // further sets only serve deferred selection / the batch kernel
+        if (si > 1 && !m.can_batch) break;
+        HIP_TRY(malloc_exchange((void **)&E.gmax, (size_t)MAX_GM * 64 * 4));
         HIP_TRY(hipMemset(E.gmax, 0, (size_t)MAX_GM * 64 * 4));
-        HIP_TRY(hipMalloc((void **)&E.tau_g, 256));
+        HIP_TRY(malloc_exchange((void **)&E.tau_g, 256));
         HIP_TRY(hipMemset(E.tau_g, 0, 256));
         HIP_TRY(hipMalloc((void **)&E.ovf_count, 256));
         HIP_TRY(hipMemset(E.ovf_count, 0, 256));
         HIP_TRY(hipMalloc((void **)&E.wg_cand, (size_t)m.grid * WG_SLOTS * 8));
         HIP_TRY(hipMemset(E.wg_cand, 0xFF, (size_t)m.grid * WG_SLOTS * 8));
         HIP_TRY(hipMalloc((void **)&E.ovf, (size_t)m.ovf_cap * 8));
-        HIP_TRY(hipMalloc((void **)&E.scratch, ((size_t)m.grid * WG_SLOTS + m.ovf_cap) * 8));
+        // the scratch of the selection's general path is used by one selection at a time: shared by all sets
+        if (si == 0) HIP_TRY(hipMalloc((void **)&E.scratch, ((size_t)m.grid * WG_SLOTS + m.ovf_cap) * 8));
+        else E.scratch = m.st[0].scratch;
         HIP_TRY(hipMalloc((void **)&E.unit_inv, 256));
         const float one = 1.0f;
         HIP_TRY(hipMemcpy(E.unit_inv, &one, 4, hipMemcpyHostToDevice));
@@ -1484,6 +1988,14 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err) {
     HIP_TRY(hipMemset(m.d_out_idx, 0, (size_t)d.k * 4));
     HIP_TRY(hipMemset(m.d_out_val, 0, (size_t)d.k * 4));
 
+    if (getenv("TKSPMV_DEBUG_OCC")) {
+        int n1 = -1, n2 = -1;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n1, reinterpret_cast<const void *>(m.kernel_for(false)), (int)m.block + 64, 0);
+        if (m.can_batch)
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n2, reinterpret_cast<const void *>(m.batch_kernel_for()), (int)m.block + 64, 0);
+        fprintf(stderr, "[tkspmv] workgroups per CU by the runtime's occupancy calculator: stream kernel %d, batch kernel %d; LDS per CU %zu\n",
+                n1, n2, (size_t)prop.maxSharedMemoryPerMultiProcessor);
+    }
     m.info.grid = m.grid;
     m.info.block = m.block;
     m.info.n_groups = m.n_sets ? m.n_groups_pub : 0;
@@ -1553,6 +2065,20 @@ int Engine::enqueue(const float *dev_x, uint32_t *dev_idx, float *dev_val, void 
     return TKSPMV_OK;
 }
 
+// Pointer lists of a back-to-back sequence (query i = dev_xs + (i % n_x) * cols; results to out + i * stride).
+static void sequence_lists(const EngineImpl &m, const float *dev_xs, int32_t n_x, int32_t count, uint32_t *idx, float *val,
+                           size_t stride, std::vector<const float *> &xs, std::vector<uint32_t *> &oi,
+                           std::vector<float *> &ov) {
+    xs.resize(count);
+    oi.resize(count);
+    ov.resize(count);
+    for (int i = 0; i < count; ++i) {
+        xs[i] = dev_xs + (size_t)(i % n_x) * m.desc.cols;
+        oi[i] = idx + (size_t)i * stride;
+        ov[i] = val + (size_t)i * stride;
+    }
+}
+
 int Engine::enqueue_many(const float *dev_xs, int32_t n_x, int32_t count, void *stream, std::string &err) {
     EngineImpl &m = *impl_;
     if (!dev_xs || n_x < 1 || count < 0) {
@@ -1561,10 +2087,11 @@ int Engine::enqueue_many(const float *dev_xs, int32_t n_x, int32_t count, void *
     }
     hipStream_t s = stream ? (hipStream_t)stream : m.stream;
     HIP_TRY(hipSetDevice(m.device));
-    for (int i = 0; i < count; ++i) {
-        m.launch_deferred(dev_xs + (size_t)(i % n_x) * m.desc.cols, m.d_out_idx, m.d_out_val, s);
-    }
-    m.drain(s);
+    std::vector<const float *> xs;
+    std::vector<uint32_t *> oi;
+    std::vector<float *> ov;
+    sequence_lists(m, dev_xs, n_x, count, m.d_out_idx, m.d_out_val, 0, xs, oi, ov);
+    m.launch_sequence(xs.data(), oi.data(), ov.data(), count, s);
     HIP_TRY(hipGetLastError());
     m.ran = true;
     return TKSPMV_OK;
@@ -1579,12 +2106,27 @@ int Engine::enqueue_batch(const float *dev_xs, int32_t count, uint32_t *dev_idx,
     }
     hipStream_t s = stream ? (hipStream_t)stream : m.stream;
     HIP_TRY(hipSetDevice(m.device));
-    const size_t k = (size_t)m.desc.k;
-    for (int i = 0; i < count; ++i) {
-        m.launch_deferred(dev_xs + (size_t)i * m.desc.cols, dev_idx ? dev_idx + (size_t)i * k : m.d_out_idx,
-                          dev_val ? dev_val + (size_t)i * k : m.d_out_val, s);
+    std::vector<const float *> xs;
+    std::vector<uint32_t *> oi;
+    std::vector<float *> ov;
+    sequence_lists(m, dev_xs, count > 0 ? count : 1, count, dev_idx ? dev_idx : m.d_out_idx, dev_val ? dev_val : m.d_out_val,
+                   dev_idx ? (size_t)m.desc.k : 0, xs, oi, ov);
+    m.launch_sequence(xs.data(), oi.data(), ov.data(), count, s);
+    HIP_TRY(hipGetLastError());
+    m.ran = true;
+    return TKSPMV_OK;
+}
+
+int Engine::enqueue_list(const float *const *dev_xs, uint32_t *const *dev_idx, float *const *dev_val, int32_t count,
+                         void *stream, std::string &err) {
+    EngineImpl &m = *impl_;
+    if (!dev_xs || !dev_idx || !dev_val || count < 0) {
+        err = "bad arguments to enqueue_list";
+        return TKSPMV_ERR_INVALID;
     }
-    m.drain(s);
+    hipStream_t s = stream ? (hipStream_t)stream : m.stream;
+    HIP_TRY(hipSetDevice(m.device));
+    m.launch_sequence(dev_xs, dev_idx, dev_val, count, s);
     HIP_TRY(hipGetLastError());
     m.ran = true;
     return TKSPMV_OK;
@@ -1698,9 +2240,13 @@ int Engine::time_queries(const float *dev_xs, int32_t n_x, int32_t iters, double
     HIP_TRY(hipSetDevice(m.device));
     HIP_TRY(hipStreamSynchronize(m.stream));
     HIP_TRY(hipEventRecord(m.ev0, m.stream));
-    for (int i = 0; i < iters; ++i)
-        m.launch_deferred(dev_xs + (size_t)(i % n_x) * m.desc.cols, m.d_out_idx, m.d_out_val, m.stream);
-    m.drain(m.stream);
+    {
+        std::vector<const float *> xs;
+        std::vector<uint32_t *> oi;
+        std::vector<float *> ov;
+        sequence_lists(m, dev_xs, n_x, iters, m.d_out_idx, m.d_out_val, 0, xs, oi, ov);
+        m.launch_sequence(xs.data(), oi.data(), ov.data(), iters, m.stream);
+    }
     HIP_TRY(hipEventRecord(m.ev1, m.stream));
     HIP_TRY(hipEventSynchronize(m.ev1));
     float ms = 0;
@@ -1724,11 +2270,13 @@ int Engine::profile(const float *dev_xs, int32_t n_x, int32_t iters, tkspmv_timi
     const size_t stride = m.desc.cols;
     // (1) whole queries back-to-back
     HIP_TRY(hipEventRecord(m.ev0, m.stream));
-    for (int i = 0; i < iters; ++i) {
-        const float *x = dev_xs + (size_t)(i % n_x) * stride;
-        m.launch_deferred(x, m.d_out_idx, m.d_out_val, m.stream);
+    {
+        std::vector<const float *> xs;
+        std::vector<uint32_t *> oi;
+        std::vector<float *> ov;
+        sequence_lists(m, dev_xs, n_x, iters, m.d_out_idx, m.d_out_val, 0, xs, oi, ov);
+        m.launch_sequence(xs.data(), oi.data(), ov.data(), iters, m.stream);
     }
-    m.drain(m.stream);
     HIP_TRY(hipEventRecord(m.ev1, m.stream));
     HIP_TRY(hipEventSynchronize(m.ev1));
     float ms = 0;
@@ -1802,6 +2350,12 @@ int Engine::profile(const float *dev_xs, int32_t n_x, int32_t iters, tkspmv_timi
     out->stream_kernel_ns = t_stream * 1e6 / iters;
     out->select_kernel_ns = t_select * 1e6 / iters;
     out->n_queries = (uint32_t)iters;
+    if (m.collect_stats) {
+        unsigned long long sx[12];
+        HIP_TRY(hipMemcpy(sx, m.d_stats, sizeof(sx), hipMemcpyDeviceToHost));
+        fprintf(stderr, "[tkspmv stats] selections %llu, general-path selections %llu, max candidates %llu, overflow entries per selection %.1f\n",
+                sx[1], sx[3], sx[2], (double)sx[8] / (double)std::max<unsigned long long>(1, sx[1]));
+    }
     if (m.collect_stamps) {
         unsigned long long st[16];
         HIP_TRY(hipMemcpy(st, m.d_stats + 16, sizeof(st), hipMemcpyDeviceToHost));

@@ -26,6 +26,9 @@ class Engine {
     int enqueue_many(const float *dev_xs, int32_t n_x, int32_t count, void *stream, std::string &err);
     int enqueue_batch(const float *dev_xs, int32_t count, uint32_t *dev_idx, float *dev_val, void *stream,
                       std::string &err);
+    // A back-to-back sequence given as lists of device pointers (count entries each); complete in stream order.
+    int enqueue_list(const float *const *dev_xs, uint32_t *const *dev_idx, float *const *dev_val, int32_t count,
+                     void *stream, std::string &err);
     // Deferred selection (back-to-back sequences on ONE stream): the top-k of a query is selected inside the next
     // enqueue_deferred launch, or by drain(). Results are complete in stream order only after drain().
     int enqueue_deferred(const float *dev_x, uint32_t *dev_idx, float *dev_val, void *stream, std::string &err);

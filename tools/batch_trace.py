@@ -1,0 +1,52 @@
+import os, sys, ctypes as C
+os.environ["TKSPMV_TRACE"] = "1"
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import _pkg
+import torch
+from importlib import import_module
+mod = _pkg.load()
+_lib = import_module("approximate_spmv_topk_amd._lib")
+m = mod.generate_matrix(1000000, 1024, 20, "gamma", 2)
+xs = np.stack([mod.create_sample_vector(1024, True, False, True, 1000 + i) for i in range(8)])
+dxs = torch.from_numpy(xs).cuda()
+eng = mod.SpMV(m.row, m.col, m.val, m.rows, m.cols, k=100, device=0, stream_replicas=4)
+grid = eng.info()["grid"]
+eng.enqueue_many(dxs.data_ptr(), 8, int(os.environ.get('NQ', '3')))
+eng.synchronize()
+words = 4 * (grid + 1) * 9 * 8
+buf = np.zeros(words, dtype=np.uint64)
+got = C.c_uint64()
+_lib.check(_lib.lib().tkspmv_debug_trace(eng._h, buf.ctypes.data_as(C.POINTER(C.c_uint64)), words, C.byref(got)))
+t = buf.reshape(4, grid + 1, 9, 8).astype(np.int64)
+slot = int(np.argmax(t[:, 1:, 0, 0].max(axis=1)))
+w = t[slot]
+base = w[1:, :, 0][w[1:, :, 0] > 0].min()
+print("slot", slot, "selector stamps (us):", ((w[0, 0, :8] - base) * 0.01).round(1).tolist())
+names = ["entry", "qF start", "qM start", "qL start", "qF end", "qM end", "qL end"]
+st = w[1:, :8, :]
+for j, nm in enumerate(names):
+    v = (st[..., j][st[..., j] > 0] - base) * 0.01
+    if len(v): print(f"waves  {nm:9s} n={len(v):5d} min {v.min():7.1f} p1 {np.percentile(v,1):7.1f} p10 {np.percentile(v,10):7.1f} p50 {np.percentile(v,50):7.1f} p90 {np.percentile(v,90):7.1f} p99 {np.percentile(v,99):7.1f} max {v.max():7.1f}")
+sv = w[1:, 8, :]
+for j, nm in enumerate(["entry", "q0 staged", "q1 staged", "q2 staged", "q0 final", "q1 final", "q2 final"]):
+    v = (sv[:, j][sv[:, j] > 0] - base) * 0.01
+    if len(v): print(f"server {nm:9s} n={len(v):5d} min {v.min():9.1f} p50 {np.percentile(v,50):9.1f} p99 {np.percentile(v,99):9.1f} max {v.max():9.1f}")
+late = np.argsort(sv[:, 5])[-5:]
+print("slowest q1-final workgroups:", late.tolist(), ((sv[late, 5] - base) * 0.01).round(1).tolist())
+for b in late[-2:]:
+    print(" wg", b, "wave q1 end:", ((st[b, :, 5] - base) * 0.01).round(1).tolist(), "q1 start:", ((st[b, :, 2] - base) * 0.01).round(1).tolist())
+
+# drift between the two workgroups of a CU-slot round (blocks 1..256 vs 257..511) per query
+for j, nm in ((4, "q0 end"), (5, "q1 end"), (6, "q2 end")):
+    a = st[:256, :, j]; b = st[256:, :, j]
+    a = (a[a > 0] - base) * 0.01; b = (b[b > 0] - base) * 0.01
+    print(f"{nm}: first-round workgroups p50 {np.percentile(a,50):7.1f}, second-round p50 {np.percentile(b,50):7.1f}")
+
+sv7 = st[..., 7]
+for slot_i, nm in enumerate(("qF", "qM", "qL")):
+    surv = (sv7 >> (16 * slot_i)) & 0xFFFF
+    notau = (sv7 >> (48 + slot_i)) & 1
+    live = st[..., 4 + slot_i] > 0
+    print(f"{nm}: survivors per wave at flush: mean {surv[live].mean():6.1f} p50 {np.percentile(surv[live],50):5.0f} p90 {np.percentile(surv[live],90):5.0f} max {surv[live].max()};"
+          f" waves with NO threshold at flush: {int(notau[live].sum())} of {int(live.sum())}; first-round mean {surv[:256][live[:256]].mean():6.1f} second-round mean {surv[256:][live[256:]].mean():6.1f}")
