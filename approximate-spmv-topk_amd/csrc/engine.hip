@@ -502,26 +502,12 @@ struct RowSums {
 //   tail = end_{C-1} ? +0 : s_{C-1};   head = s at the lane's first row end
 //   vv = clipped Kogge-Stone scan of tail over the 64 lanes (never across a lane that holds a row end)
 //   row sum at the lane's first row end = vv[lane-1] + head, at its later row ends = s_j; carry' = vv[63]
-template <int C, int QM>
-__device__ __forceinline__ RowSums<C> reduce_packet(const Pkt<C, (QM != 0)> &cur, float &carry, const float *x_lds) {
-    constexpr bool Q8 = QM != 0;
-    float p[C];
+// The reduction proper, from the C products of a lane (p) and its column words (cwv).
+template <int C>
+__device__ __forceinline__ RowSums<C> reduce_core(float (&p)[C], const uint32_t (&cwv)[C / 2], float &carry) {
     uint32_t m[C];  // all-ones where entry j ends a row
 #pragma unroll
-    for (int j = 0; j < C; ++j) {
-        const uint32_t word = cur.cw[j >> 1];
-        const uint32_t off = (j & 1) ? ((word >> 16) & 0xFFFCu) : (word & 0xFFFCu);  // byte offset of x[col]
-        if (Q8) {
-            // x is staged as Q1.7 integers; product truncated to Q1.7 and wrapped to 8 bits, exact in fp32
-            const uint32_t xq = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const unsigned char *>(x_lds) + off);
-            const uint32_t vq = (cur.vq[Q8 ? (j >> 2) : 0] >> (8 * (j & 3))) & 255u;
-            p[j] = (float)(QM == 2 ? ((vq * xq) >> 7) : (((vq * xq) >> 7) & 255u));  // wide mode: no wrap
-        } else {
-            const float xv = *reinterpret_cast<const float *>(reinterpret_cast<const unsigned char *>(x_lds) + off);
-            p[j] = __fmul_rn(cur.v[Q8 ? 0 : j], xv);
-        }
-        m[j] = (j & 1) ? bit_mask<16>(word) : bit_mask<0>(word);
-    }
+    for (int j = 0; j < C; ++j) m[j] = (j & 1) ? bit_mask<16>(cwv[j >> 1]) : bit_mask<0>(cwv[j >> 1]);
     p[0] = __builtin_amdgcn_inverse_ballot_w64(1ull) ? __fadd_rn(p[0], carry) : p[0];  // lane 0 only
 
     float s[C];
@@ -583,7 +569,7 @@ __device__ __forceinline__ RowSums<C> reduce_packet(const Pkt<C, (QM != 0)> &cur
 #pragma unroll
     for (int j = 1; j < C; ++j) out.rs[j] = mask_select(o[j - 1], s[j], S);  // an earlier end in the lane => s_j
 #pragma unroll
-    for (int j = 0; j < C / 2; ++j) out.cw[j] = cur.cw[j];
+    for (int j = 0; j < C / 2; ++j) out.cw[j] = cwv[j];
     const float NEG_INF = -__builtin_huge_valf();
     float e[C];
 #pragma unroll
@@ -593,6 +579,28 @@ __device__ __forceinline__ RowSums<C> reduce_packet(const Pkt<C, (QM != 0)> &cur
     for (int j = 3; j < C; j += 2) best = max3(best, e[j], (j + 1 < C) ? e[j + 1] : NEG_INF);
     out.best_any = best;
     return out;
+}
+
+// Products from a packet and the x vector staged in LDS, then the reduction.
+template <int C, int QM>
+__device__ __forceinline__ RowSums<C> reduce_packet(const Pkt<C, (QM != 0)> &cur, float &carry, const float *x_lds) {
+    constexpr bool Q8 = QM != 0;
+    float p[C];
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+        const uint32_t word = cur.cw[j >> 1];
+        const uint32_t off = (j & 1) ? ((word >> 16) & 0xFFFCu) : (word & 0xFFFCu);  // byte offset of x[col]
+        if (Q8) {
+            // x is staged as Q1.7 integers; product truncated to Q1.7 and wrapped to 8 bits, exact in fp32
+            const uint32_t xq = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const unsigned char *>(x_lds) + off);
+            const uint32_t vq = (cur.vq[Q8 ? (j >> 2) : 0] >> (8 * (j & 3))) & 255u;
+            p[j] = (float)(QM == 2 ? ((vq * xq) >> 7) : (((vq * xq) >> 7) & 255u));  // wide mode: no wrap
+        } else {
+            const float xv = *reinterpret_cast<const float *>(reinterpret_cast<const unsigned char *>(x_lds) + off);
+            p[j] = __fmul_rn(cur.v[Q8 ? 0 : j], xv);
+        }
+    }
+    return reduce_core<C>(p, cur.cw, carry);
 }
 
 template <int C, int QM>
@@ -1217,8 +1225,13 @@ __global__ void __launch_bounds__(576, 5) batch_kernel(const StreamParams P0, co
 
     if (is_server) {
         // ---- server wave: x staging, threshold exchange of the newest query, finalisation of the oldest -------
+        // The reducers' search must not starve: in a batch the streaming waves (priority 2) never pause, and a reducer at
+        // the default priority got ONE pass per query (traced), i.e. the threshold arrived when the query was over.
+        if (reducer) __builtin_amdgcn_s_setprio(3);
         uint32_t staged = 0u, tail = 0u;
         float inv_unit_q[2] = {1.0f, 1.0f}, min_units_q[2] = {0.0f, 0.0f};
+        unsigned long long dbg_first_duty = 0ull;
+        uint32_t dbg_iters = 0u;
         for (;;) {
             if (staged < nq && staged - tail < 2u) {
                 const uint32_t par = staged & 1u;
@@ -1312,6 +1325,11 @@ __global__ void __launch_bounds__(576, 5) batch_kernel(const StreamParams P0, co
                         const float cur_tau = __uint_as_float(lds_load(&mp[MISC_TAU]));
                         if (t > cur_tau)
                             __hip_atomic_store(&mp[MISC_TAU], __float_as_uint(t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (trw && TRSLOT(sq) == 1u) {
+                            if (t > cur_tau && cur_tau <= min_units) trw[7] = __builtin_amdgcn_s_memrealtime();  // first threshold
+                            if (dbg_first_duty == 0ull) dbg_first_duty = __builtin_amdgcn_s_memrealtime();
+                            ++dbg_iters;
+                        }
                     }
                 }
             }
@@ -1324,6 +1342,10 @@ __global__ void __launch_bounds__(576, 5) batch_kernel(const StreamParams P0, co
                     StreamParams P = P0;
                     P.gmax = B.q[tail].gmax;
                     if (P0.n_sets != 0u) publish_group_max(P, bid, lane, mp);  // complete maxima (fire and forget)
+                    if (P0.dbg && lane == 0) {  // TKSPMV_STATS=1
+                        atomicAdd(&P0.dbg[0], (unsigned long long)mp[MISC_SLOW_CNT]);
+                        atomicAdd(&P0.dbg[1], (unsigned long long)mp[MISC_CAND_CNT]);
+                    }
                     // lane l copies entry (l % 8) of wave (l / 8): the first goes to the wave's slot, others to the
                     // query's overflow list
                     const uint32_t w = lane >> 3, e = lane & 7u;
@@ -1351,6 +1373,10 @@ __global__ void __launch_bounds__(576, 5) batch_kernel(const StreamParams P0, co
                     if (lane == 0)
                         (void)__hip_atomic_fetch_add(B.tickets + 32u * tail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (trw && lane == 0 && TRSLOT(tail) < 3u) trw[4 + TRSLOT(tail)] = __builtin_amdgcn_s_memrealtime();
+                    if (trw && lane == 0 && TRSLOT(tail) == 1u) {
+                        trw[3] = dbg_first_duty;
+                        trw[6] = dbg_iters;  // (overwritten by the last query's finalise stamp; read when nq is small only)
+                    }
                     ++tail;
                 }
             }
@@ -1401,6 +1427,7 @@ __global__ void __launch_bounds__(576, 5) batch_kernel(const StreamParams P0, co
     rbs[NBUF - 1] = 0u;
 
     uint32_t qc = 0u, jc = 0u;  // packet being reduced
+    uint32_t first_tau_pkt = 0xFFu;  // tracing: packet at which this query's threshold was first seen
     float carry = 0.0f, min_units = 0.0f;
     uint32_t wcnt = 0u;
     uint32_t *mp = L.misc[0];
@@ -1428,8 +1455,10 @@ __global__ void __launch_bounds__(576, 5) batch_kernel(const StreamParams P0, co
                 P.ovf_count = B.q[qc].ovf_count;
                 carry = 0.0f;
                 wcnt = 0u;
+                first_tau_pkt = 0xFFu;
             }
             const float tau = __uint_as_float(lds_load(&mp[MISC_TAU]));
+            if (trw && first_tau_pkt == 0xFFu && tau > min_units) first_tau_pkt = jc;
             const RowSums<C> R = reduce_packet<C, QM>(cur, carry, xq);
             if (jc < DEFER_B && P0.n_sets != 0u) {
                 L.drs[wave][jc][lane] = make_float4(R.rs[0], R.rs[1], R.rs[2], R.rs[3]);
@@ -1495,7 +1524,7 @@ __global__ void __launch_bounds__(576, 5) batch_kernel(const StreamParams P0, co
                 if (lane == 0) atomicAdd(&mp[MISC_DONE], 1u);
                 if (trw && lane == 0 && TRSLOT(qc) < 3u) {
                     trw[4 + TRSLOT(qc)] = __builtin_amdgcn_s_memrealtime();
-                    trw[7] = (TRSLOT(qc) == 0u ? 0ull : trw[7]) | ((unsigned long long)(surv > 0xFFFFu ? 0xFFFFu : surv) << (16u * TRSLOT(qc))) |
+                    trw[7] = (TRSLOT(qc) == 0u ? 0ull : trw[7]) | ((unsigned long long)(((surv > 0xFFu ? 0xFFu : surv) << 8) | first_tau_pkt) << (16u * TRSLOT(qc))) |
                              ((unsigned long long)(tau3 <= min_units ? 1u : 0u) << (48u + TRSLOT(qc)));
                 }
                 ++qc;

@@ -45,8 +45,17 @@ for j, nm in ((4, "q0 end"), (5, "q1 end"), (6, "q2 end")):
 
 sv7 = st[..., 7]
 for slot_i, nm in enumerate(("qF", "qM", "qL")):
-    surv = (sv7 >> (16 * slot_i)) & 0xFFFF
+    surv = (sv7 >> (16 * slot_i + 8)) & 0xFF
+    ftp = (sv7 >> (16 * slot_i)) & 0xFF
     notau = (sv7 >> (48 + slot_i)) & 1
     live = st[..., 4 + slot_i] > 0
     print(f"{nm}: survivors per wave at flush: mean {surv[live].mean():6.1f} p50 {np.percentile(surv[live],50):5.0f} p90 {np.percentile(surv[live],90):5.0f} max {surv[live].max()};"
+          f" first packet with a threshold: p10 {np.percentile(ftp[live],10):4.0f} p50 {np.percentile(ftp[live],50):4.0f} p90 {np.percentile(ftp[live],90):4.0f} (255 = never);"
           f" waves with NO threshold at flush: {int(notau[live].sum())} of {int(live.sum())}; first-round mean {surv[:256][live[:256]].mean():6.1f} second-round mean {surv[256:][live[256:]].mean():6.1f}")
+
+# server of the middle query: staged, first duty iteration, first threshold, finalised; iterations of duty
+sv = w[1:, 8, :]
+ok = sv[:, 5] > 0
+stg_t = (sv[ok, 2] - base) * 0.01; fd = (sv[ok, 3] - base) * 0.01; ft = np.where(sv[ok, 7] > 0, (sv[ok, 7] - base) * 0.01, np.nan); fin = (sv[ok, 5] - base) * 0.01
+print(f"middle query, servers: staged p50 {np.percentile(stg_t,50):7.1f}  first duty p50 {np.percentile(fd,50):7.1f}  first threshold p10 {np.nanpercentile(ft,10):7.1f} p50 {np.nanpercentile(ft,50):7.1f} p90 {np.nanpercentile(ft,90):7.1f} (none: {int(np.isnan(ft).sum())})  finalised p50 {np.percentile(fin,50):7.1f}; duty iterations p50 {np.percentile(sv[ok,0],50):4.0f}")
+print("reducers:", "first threshold", ((sv[:8, 7] - base) * 0.01).round(1).tolist(), "iters", sv[:8, 0].tolist())
