@@ -114,7 +114,7 @@ struct Dist {
     hipEvent_t ev_comp[2] = {nullptr, nullptr}, ev_merge[2] = {nullptr, nullptr};
     // Queries are exchanged in batches of up to `batch`: one all-gather and one merge launch per batch, so the
     // collective's latency and the host's enqueue cost are paid once per batch. Two buffer sets alternate.
-    int batch = 8;
+    int batch = MAX_BATCH;
     uint32_t *local[2] = {nullptr, nullptr};     // [batch][2k]: k row ids, k score bits per query
     uint32_t *gathered[2] = {nullptr, nullptr};  // [world][n_q][2k]
     uint32_t *out_idx[2] = {nullptr, nullptr};   // [batch][k]
@@ -122,6 +122,9 @@ struct Dist {
     uint64_t steps = 0;    // queries enqueued
     uint64_t flushes = 0;  // batches exchanged
     int fill = 0;          // queries in the open batch (buffer set flushes & 1)
+    const float *pend_x[MAX_BATCH] = {};  // their query vectors: the local kernels are launched when the batch closes
+    uint32_t *pend_idx[MAX_BATCH] = {};
+    float *pend_val[MAX_BATCH] = {};
     int last_set = -1, last_slot = -1;  // where the most recent query's merged result lands
 };
 
@@ -239,8 +242,11 @@ static int dist_flush(Dist &d) {
     const int b = (int)(d.flushes & 1);
     const int n_q = d.fill;
     {
-        std::string err;  // the selection of the batch's last query (the others rode along with their successors)
-        int st = d.engine->drain(d.compute, err);
+        // The local step of the whole batch as ONE back-to-back sequence (the engine's batch kernel when available):
+        // its launch overhead is paid once per exchange batch, like the collective's.
+        if (d.flushes >= 2) DHIP(hipStreamWaitEvent(d.compute, d.ev_merge[b], 0));  // buffer set b is free again
+        std::string err;
+        int st = d.engine->enqueue_list(d.pend_x, d.pend_idx, d.pend_val, n_q, d.compute, err);
         if (st != TKSPMV_OK) return dfail(st, err);
     }
     DHIP(hipEventRecord(d.ev_comp[b], d.compute));
@@ -260,18 +266,17 @@ static int dist_flush(Dist &d) {
     return TKSPMV_OK;
 }
 
-// One query, asynchronously: local kernel on the compute stream; the batch it completes is exchanged on the comm
-// stream. Every rank must issue the same sequence of enqueue / synchronize / read calls (they are collective).
+// One query, asynchronously: it joins the open batch; a full batch is launched on the compute stream and exchanged on
+// the comm stream. Every rank must issue the same sequence of enqueue / synchronize / read calls (they are collective).
 int tkspmv_dist_enqueue(tkspmv_dist_t *h, const float *dev_x) {
     if (!h || !dev_x) return dfail(TKSPMV_ERR_INVALID, "NULL argument");
     Dist &d = h->d;
     const int b = (int)(d.flushes & 1);
     DHIP(hipSetDevice(d.device));
-    if (d.fill == 0 && d.flushes >= 2) DHIP(hipStreamWaitEvent(d.compute, d.ev_merge[b], 0));  // set b is free again
     uint32_t *dst = d.local[b] + (size_t)d.fill * 2 * d.k;
-    std::string err;
-    int st = d.engine->enqueue_deferred(dev_x, dst, reinterpret_cast<float *>(dst + d.k), d.compute, err);
-    if (st != TKSPMV_OK) return dfail(st, err);
+    d.pend_x[d.fill] = dev_x;  // must stay valid until the batch has been flushed (batch full, synchronize or read)
+    d.pend_idx[d.fill] = dst;
+    d.pend_val[d.fill] = reinterpret_cast<float *>(dst + d.k);
     d.last_set = b;
     d.last_slot = d.fill;
     ++d.fill;

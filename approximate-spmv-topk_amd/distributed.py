@@ -106,7 +106,8 @@ class ShardedTopK:
 
 class NativeShardedSpMV:
     """The same step in native code (csrc/dist.hip): local kernel, RCCL all-gather of k pairs per rank and merge
-    kernel; queries are exchanged in batches (default 8) on a side stream, overlapping the kernels of the next batch. torch.distributed is only used to ship
+    kernel; queries are exchanged in batches (default 32) on a side stream, overlapping the local step of the next batch.
+    A query vector passed to enqueue() must stay valid until the batch is flushed (batch full, synchronize or read). torch.distributed is only used to ship
     rank 0's RCCL unique id. Raises TkspmvError (e.g. ERR_UNSUPPORTED when RCCL cannot be loaded): callers fall back
     to ShardedTopK."""
 
@@ -134,7 +135,7 @@ class NativeShardedSpMV:
         self.world, self.rank = world, rank
 
     def set_batch(self, batch):
-        """Queries per exchange (1..32, default 8): one all-gather + one merge launch per batch."""
+        """Queries per exchange (1..32, default 32): one local sequence, one all-gather, one merge launch per batch."""
         self._lib.check_dist(self._lib.lib().tkspmv_dist_set_batch(self._h, int(batch)))
 
     def enqueue(self, dev_x_ptr):

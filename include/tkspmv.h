@@ -175,9 +175,10 @@ int tkspmv_device_count(void);
  * The reference merges its row partitions on the host (src/fpga/src/host_spmv_bscsr.cpp:399-448, global id =
  * local + first_row at :415). One level up: every rank owns an engine over its row shard (desc.first_row = first
  * global row), per query the local fused kernel, ONE RCCL all-gather of k (row, score) pairs per rank and a merge
- * kernel. Queries are exchanged in batches (default 8, TKSPMV_DIST_BATCH / tkspmv_dist_set_batch; 1 = every query on
- * its own): one all-gather and one merge launch per batch on a side stream, overlapping the kernels of the next batch
- * (two buffer sets). synchronize / read flush an open batch. Every rank must issue the same call sequence. RCCL is
+ * kernel. Queries are exchanged in batches (default 32, TKSPMV_DIST_BATCH / tkspmv_dist_set_batch; 1 = every query on
+ * its own): the local step of a batch is launched as one back-to-back sequence when the batch closes, then one
+ * all-gather and one merge launch per batch on a side stream, overlapping the local step of the next batch (two buffer
+ * sets). synchronize / read flush an open batch; a query vector passed to tkspmv_dist_enqueue must stay valid until then. Every rank must issue the same call sequence. RCCL is
  * loaded with dlopen inside tkspmv_dist_create / tkspmv_dist_unique_id: TKSPMV_ERR_UNSUPPORTED if it cannot be loaded. */
 typedef struct tkspmv_dist tkspmv_dist_t;
 /* rank 0 creates the 128-byte RCCL unique id and ships it to the other ranks (any transport). */

@@ -11,11 +11,11 @@ OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 python3 bench.py --steps 3000 --warmup 300 > "$OUT/bench_plain.json" 2> "$OUT/bench_plain.err"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/ktrace" -- python3 "$REPO/bench.py" --steps 2000 --warmup 200 --cpu-seconds 0 --skip-warm > "$OUT/bench_under_rocprofv3.json" 2> "$OUT/ktrace.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/ktrace" -- python3 "$REPO/bench.py" --steps 2048 --warmup 256 --cpu-seconds 0 --skip-warm > "$OUT/bench_under_rocprofv3.json" 2> "$OUT/ktrace.err"
 i=0
 for counters in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
     i=$((i + 1))
-    rocprofv3 --pmc $counters --kernel-trace --output-format csv -d "$OUT/pmc$i" -- python3 "$REPO/bench.py" --steps 300 --warmup 30 --cpu-seconds 0 --skip-warm > "$OUT/pmc$i.json" 2> "$OUT/pmc$i.err"
+    rocprofv3 --pmc $counters --kernel-trace --output-format csv -d "$OUT/pmc$i" -- python3 "$REPO/bench.py" --steps 320 --warmup 32 --cpu-seconds 0 --skip-warm > "$OUT/pmc$i.json" 2> "$OUT/pmc$i.err"
 done
 cd "$REPO"
 python3 tools/summarize_profile.py "$OUT" "$TAG"

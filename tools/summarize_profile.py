@@ -38,26 +38,37 @@ summary = {}
 for d in sorted(glob.glob(os.path.join(out, "pmc*"))):
     if not os.path.isdir(d):
         continue
+    # queries the profiled run executed: warm-up + timed steps + the kernel-timing batch (bench.py --skip-warm)
+    n_queries = None
+    try:
+        line = [l for l in open(d + ".json").read().splitlines() if l.startswith("{")][-1]
+        j = json.loads(line)
+        n_queries = j["warmup"] + j["steps"] + min(max(j["steps"], 50), 500)
+    except Exception:
+        pass
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         acc = {}
         for row in csv.DictReader(open(f)):
-            if "stream_kernel" not in row.get("Kernel_Name", "") or "Lb1E" in row.get("Kernel_Name", ""):
-                continue  # Lb1E = the SpMV-only variant
+            kn = row.get("Kernel_Name", "")
+            # the kernels that stream the matrix for a top-k query: batch_kernel (up to 32 queries per launch) and
+            # stream_kernel<.., false, ..> (one query); Lb1E = the SpMV-only variant
+            if not (("batch_kernel" in kn) or ("stream_kernel" in kn and "Lb1E" not in kn and "true" not in kn)):
+                continue
             acc.setdefault(row["Counter_Name"], {}).setdefault(row["Dispatch_Id"], 0.0)
             acc[row["Counter_Name"]][row["Dispatch_Id"]] += float(row["Counter_Value"])
         for name, per in acc.items():
-            v = sorted(per.values())
-            v = v[len(v) // 10:]  # drop the first launches (warm-up of the run)
-            summary[name] = {"launches": len(v), "mean": sum(v) / len(v), "min": v[0], "max": v[-1]}
+            total = sum(per.values())
+            summary[name] = {"launches": len(per), "queries": n_queries, "sum": total,
+                             "mean_per_query": total / n_queries if n_queries else None}
 json.dump(summary, open(os.path.join(dst, f"{tag}_pmc_summary.json"), "w"), indent=1)
 if "FETCH_SIZE" in summary and "WRITE_SIZE" in summary:
-    fetch = summary["FETCH_SIZE"]["mean"] * 1024.0 * 2.0  # KiB -> B, x2: gfx950 tallies 128-B requests at 64 B
-    write = summary["WRITE_SIZE"]["mean"] * 1024.0
-    json.dump({"stream_kernel_hbm_bytes_per_launch": fetch + write, "fetch_bytes_corrected": fetch, "write_bytes": write,
+    fetch = summary["FETCH_SIZE"]["mean_per_query"] * 1024.0 * 2.0  # KiB -> B, x2: gfx950 tallies 128-B requests at 64 B
+    write = summary["WRITE_SIZE"]["mean_per_query"] * 1024.0
+    json.dump({"stream_kernel_hbm_bytes_per_launch": fetch + write, "unit": "bytes per query (a batch launch streams the matrix once per query)", "fetch_bytes_corrected": fetch, "write_bytes": write,
                "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on bench.py --skip-warm, tag {tag}; "
-                         "FETCH_SIZE x 1024 x 2 (gfx950 correction, MI355X_MICROARCH.md) + WRITE_SIZE x 1024, mean per launch"},
+                         "FETCH_SIZE x 1024 x 2 (gfx950 correction, MI355X_MICROARCH.md) + WRITE_SIZE x 1024, summed over the launches and divided by the queries they served"},
               open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
-print(json.dumps({k: round(v["mean"], 2) for k, v in summary.items()}))
+print(json.dumps({k: round(v["mean_per_query"] or 0, 2) for k, v in summary.items()}))
 print(open(os.path.join(dst, f"{tag}_bench_plain.json")).read()[:600] if os.path.exists(os.path.join(dst, f"{tag}_bench_plain.json")) else "no plain bench line")
 ks = os.path.join(dst, f"{tag}_kernel_stats.csv")
 if os.path.exists(ks):
