@@ -466,3 +466,60 @@ def test_batch_results_equal_single_query_results(pkg, oracle, monkeypatch, prec
         gi, gv = oracle.gold_topk(m.row, m.col, m.val, xs[3], 100)
         assert set(single[3][1].tolist()) == set(gi.tolist())
     eng.close()
+
+
+def test_long_batches_cross_launch_boundaries(pkg, oracle):
+    """75 distinct queries through tkspmv_enqueue_batch = three launches of the batch kernel (32 + 32 + 11): every
+    query bit-identical to its single-query result, and a sample of them identical to the oracle's packed-order model
+    (scores) with the gold's top-K index set."""
+    import torch
+    m = pkg.generate_matrix(200000, 1024, 20, "gamma", 77)
+    nq = 75
+    xs = np.stack([pkg.create_sample_vector(1024, True, False, True, 4000 + i) for i in range(nq)])
+    dxs = torch.from_numpy(xs).cuda()
+    eng = pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, k=100, device=0, stream_replicas=2)
+    out_i = torch.full((nq, 100), -1, dtype=torch.int32, device="cuda")
+    out_v = torch.full((nq, 100), -1.0, dtype=torch.float32, device="cuda")
+    eng.enqueue_batch(dxs.data_ptr(), nq, out_i.data_ptr(), out_v.data_ptr())
+    eng.synchronize()
+    bi = out_i.cpu().numpy().view(np.uint32)
+    bv = out_v.cpu().numpy()
+    for q in range(nq):
+        assert np.all(bv[q][:-1] >= bv[q][1:]) and len(set(bi[q].tolist())) == 100, q
+    for q in (0, 1, 31, 32, 33, 63, 64, 74):  # around the launch boundaries
+        eng.reset_device(dxs[q].data_ptr())
+        eng()
+        val, idx = eng.read_result()
+        assert np.array_equal(bi[q], idx) and np.array_equal(bv[q], val), q
+        gi, gv = oracle.gold_topk(m.row, m.col, m.val, xs[q], 100)
+        assert set(idx.tolist()) == set(gi.tolist()), q
+        assert np.allclose(val, gv, rtol=RTOL, atol=0), q
+    # the same batch again (state sets of all 32 queries are reused) gives the same bits
+    out_i2 = torch.full((nq, 100), -1, dtype=torch.int32, device="cuda")
+    out_v2 = torch.full((nq, 100), -1.0, dtype=torch.float32, device="cuda")
+    eng.enqueue_batch(dxs.data_ptr(), nq, out_i2.data_ptr(), out_v2.data_ptr())
+    eng.synchronize()
+    assert torch.equal(out_i, out_i2) and torch.equal(out_v, out_v2)
+    eng.close()
+
+
+@pytest.mark.parametrize("cols,k", [(4096, 100), (1024, 600), (16384, 10)])
+def test_batches_on_geometries_without_the_batch_kernel(pkg, oracle, cols, k):
+    """x too large to sit twice in LDS, or K above the number of publishing workgroups (several groups per workgroup /
+    exchange off): sequences fall back to one launch per query; results must not care."""
+    import torch
+    m = pkg.generate_matrix(30000, cols, 20, "gamma", 5)
+    nq = 5
+    xs = np.stack([pkg.create_sample_vector(cols, True, False, True, 300 + i) for i in range(nq)])
+    dxs = torch.from_numpy(xs).cuda()
+    eng = pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, k=k, device=0)
+    out_i = torch.full((nq, k), -1, dtype=torch.int32, device="cuda")
+    out_v = torch.full((nq, k), -1.0, dtype=torch.float32, device="cuda")
+    eng.enqueue_batch(dxs.data_ptr(), nq, out_i.data_ptr(), out_v.data_ptr())
+    eng.synchronize()
+    for q in range(nq):
+        gi, gv = oracle.gold_topk(m.row, m.col, m.val, xs[q], k)
+        got = out_i[q].cpu().numpy().view(np.uint32)
+        assert set(got.tolist()) == set(gi.tolist()), q
+        assert np.allclose(out_v[q].cpu().numpy(), gv, rtol=RTOL, atol=0), q
+    eng.close()
