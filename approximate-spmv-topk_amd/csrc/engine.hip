@@ -594,7 +594,9 @@ __device__ __forceinline__ RowSums<C> reduce_packet(const Pkt<C, (QM != 0)> &cur
             // x is staged as Q1.7 integers; product truncated to Q1.7 and wrapped to 8 bits, exact in fp32
             const uint32_t xq = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const unsigned char *>(x_lds) + off);
             const uint32_t vq = (cur.vq[Q8 ? (j >> 2) : 0] >> (8 * (j & 3))) & 255u;
-            p[j] = (float)(QM == 2 ? ((vq * xq) >> 7) : (((vq * xq) >> 7) & 255u));  // wide mode: no wrap
+            // both factors are below 2^8: the 24-bit multiply is exact (and full rate; v_mul_lo_u32 is quarter rate)
+            const uint32_t t = __umul24(vq, xq);
+            p[j] = (float)(QM == 2 ? (t >> 7) : ((t >> 7) & 255u));  // wide mode: no wrap
         } else {
             const float xv = *reinterpret_cast<const float *>(reinterpret_cast<const unsigned char *>(x_lds) + off);
             p[j] = __fmul_rn(cur.v[Q8 ? 0 : j], xv);
