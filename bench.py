@@ -3,7 +3,9 @@
 
   python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
 
-A "step" is one query: one pass of the fused Top-K SpMV over the whole matrix for a fresh dense vector x.
+A "step" is one query: one pass of the Top-K SpMV hot path over the whole matrix for a fresh dense vector x. The
+queries are issued back to back on one stream (tkspmv_enqueue_many: the engine launches its batch kernel once per 32
+queries; every query still streams the whole matrix and is selected exactly).
 Workload at N=1 = BASELINE.json configs[1]: 1M x 1024, 20 nnz/row (gamma), K=100, fp32, synthetic (own seeded
 generator restating create_matrices.py's distributions). All inputs (packed matrix, 64 query vectors) are
 resident in HBM before the timed region; results stay in HBM.
@@ -13,7 +15,7 @@ them per query, so no query can be served from the 256 MiB Infinity Cache and th
 HBM fraction. The steady-state number for ONE matrix (which fits the Infinity Cache) is reported as `cache_warm`.
 
 N > 1 (weak scaling): every rank owns a 1M-row shard of an (N x 1M)-row matrix; per step each rank runs its local
-engine, then ONE RCCL all-gather of K (row, score) pairs per rank and the merge. `value` = N * steps / time
+engine, then ONE RCCL all-gather of K (row, score) pairs per rank and the merge (32 steps per exchange, pipelined). `value` = N * steps / time
 (1M-row-shard queries per second, whole job); `global_queries_per_sec` = steps / time.
 """
 import argparse
@@ -32,8 +34,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=2048)
+    ap.add_argument("--warmup", type=int, default=256)
     ap.add_argument("--rows", type=int, default=1000000)
     ap.add_argument("--cols", type=int, default=1024)
     ap.add_argument("--nnz", type=int, default=20)
