@@ -1171,7 +1171,7 @@ __device__ __forceinline__ uint32_t lds_load(const uint32_t *p) {
 }
 
 template <int C, int XCOLS, int QM>
-__global__ void __launch_bounds__(576, 5) batch_kernel(const StreamParams P0, const SelectParams SP0, const BatchParams B) {
+__global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0, const SelectParams SP0, const BatchParams B) {
     constexpr bool Q8 = QM != 0;
     constexpr int NBUF = 3;
     constexpr uint32_t WAVE_CAP = ListGeom<XCOLS>::WAVE_CAP;
