@@ -1681,10 +1681,10 @@ struct EngineImpl {
         if (!fused) launch_select(out_idx, out_val, s);
     }
     typedef void (*batch_fn)(const StreamParams, const SelectParams, const BatchParams);
-    batch_fn batch_kernel_for() const {
-        if (desc.precision == TKSPMV_Q1_7) return xcols <= 1024 ? &batch_kernel<4, 1024, 1> : &batch_kernel<4, 4096, 1>;
-        if (desc.precision == TKSPMV_Q1_7_WIDE) return xcols <= 1024 ? &batch_kernel<4, 1024, 2> : &batch_kernel<4, 4096, 2>;
-        return xcols <= 1024 ? &batch_kernel<4, 1024, 0> : &batch_kernel<4, 4096, 0>;
+    batch_fn batch_kernel_for() const {  // can_batch: x of at most 1024 columns (it is held twice in LDS)
+        if (desc.precision == TKSPMV_Q1_7) return &batch_kernel<4, 1024, 1>;
+        if (desc.precision == TKSPMV_Q1_7_WIDE) return &batch_kernel<4, 1024, 2>;
+        return &batch_kernel<4, 1024, 0>;
     }
     // n <= BATCH_MAX queries in one launch of the batch kernel; results complete in stream order after the launch.
     void launch_batch(const float *const *xs, uint32_t *const *out_idx, float *const *out_val, int n, hipStream_t s) const {
