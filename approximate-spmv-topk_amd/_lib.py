@@ -80,7 +80,8 @@ EXPORTED_SYMBOLS = [
     "tkspmv_run", "tkspmv_enqueue", "tkspmv_enqueue_many", "tkspmv_enqueue_batch", "tkspmv_synchronize", "tkspmv_read", "tkspmv_result_device", "tkspmv_scores", "tkspmv_debug_trace",
     "tkspmv_time_queries", "tkspmv_profile", "tkspmv_last_error", "tkspmv_device_count", "tkspmv_mtx_read", "tkspmv_mtx_free",
     "tkspmv_mtx_write", "tkspmv_sample_vector", "tkspmv_generate", "tkspmv_options_parse", "tkspmv_pack",
-    "tkspmv_packed_info", "tkspmv_packed_decode", "tkspmv_packed_raw", "tkspmv_packed_free",
+    "tkspmv_packed_info", "tkspmv_packed_decode", "tkspmv_packed_raw", "tkspmv_packed_free", "tkspmv_wave_partitions", "tkspmv_packed_save", "tkspmv_packed_load",
+    "tkspmv_create_packed",
     "tkspmv_dist_unique_id", "tkspmv_dist_create", "tkspmv_dist_set_batch", "tkspmv_dist_enqueue", "tkspmv_dist_run_many",
     "tkspmv_dist_synchronize", "tkspmv_dist_read", "tkspmv_dist_destroy", "tkspmv_dist_last_error",
     "tkspmv_merge_topk",
@@ -131,6 +132,10 @@ def lib():
     L.tkspmv_packed_decode.argtypes = [vp, u32p, u32p, f32p, C.POINTER(C.c_uint64)]
     L.tkspmv_packed_raw.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_uint64), C.POINTER(u32p), C.POINTER(u32p),
                                     C.POINTER(u32p), C.POINTER(C.c_uint32)]
+    L.tkspmv_wave_partitions.argtypes = [C.POINTER(Desc), C.POINTER(C.c_uint32)]
+    L.tkspmv_packed_save.argtypes = [vp, C.c_char_p]
+    L.tkspmv_packed_load.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.tkspmv_create_packed.argtypes = [C.POINTER(vp), vp, C.POINTER(Desc)]
     L.tkspmv_packed_free.argtypes = [vp]
     L.tkspmv_packed_free.restype = None
     L.tkspmv_dist_last_error.restype = C.c_char_p

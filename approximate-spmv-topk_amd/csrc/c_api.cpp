@@ -241,4 +241,58 @@ int tkspmv_packed_raw(const tkspmv_packed *p, const void **packets, uint64_t *pa
 
 void tkspmv_packed_free(tkspmv_packed *p) { delete p; }
 
+int tkspmv_packed_save(const tkspmv_packed *p, const char *path) {
+    if (!p || !path) return fail(TKSPMV_ERR_INVALID, "NULL argument");
+    const std::string err = save_packed(p->pm, path);
+    if (!err.empty()) return fail(TKSPMV_ERR_IO, err);
+    return TKSPMV_OK;
+}
+
+int tkspmv_packed_load(const char *path, tkspmv_packed **out) {
+    if (!path || !out) return fail(TKSPMV_ERR_INVALID, "NULL argument");
+    *out = nullptr;
+    tkspmv_packed *p = new tkspmv_packed();
+    const std::string err = load_packed(path, p->pm);
+    if (!err.empty()) {
+        delete p;
+        return fail(TKSPMV_ERR_IO, err);
+    }
+    p->k = 0;
+    *out = p;
+    return TKSPMV_OK;
+}
+
+int tkspmv_wave_partitions(const tkspmv_desc *desc, uint32_t *n) {
+    if (!desc || !n) return fail(TKSPMV_ERR_INVALID, "NULL argument");
+    std::string err;
+    int st = wave_partitions_for(*desc, n, err);
+    if (st != TKSPMV_OK) g_err = err;
+    return st;
+}
+
+int tkspmv_create_packed(tkspmv_t **out, const tkspmv_packed *p, const tkspmv_desc *desc) {
+    if (!out || !p || !desc) return fail(TKSPMV_ERR_INVALID, "NULL argument");
+    *out = nullptr;
+    tkspmv_desc d = *desc;
+    d.rows = p->pm.rows;
+    d.cols = p->pm.cols;
+    d.nnz = p->pm.nnz;
+    d.precision = (p->pm.precision == Precision::F32) ? (desc->precision == TKSPMV_F32 ? TKSPMV_F32 : desc->precision)
+                                                      : (desc->precision == TKSPMV_Q1_7_WIDE ? TKSPMV_Q1_7_WIDE : TKSPMV_Q1_7);
+    if ((p->pm.precision == Precision::F32) != (d.precision == TKSPMV_F32))
+        return fail(TKSPMV_ERR_INVALID, "the packed matrix holds a different value type than desc.precision asks for");
+    d.nnz_per_lane = (int32_t)p->pm.C;
+    std::string err;
+    int status = TKSPMV_OK;
+    Engine *e = nullptr;
+    try {
+        e = Engine::create(d, err, status, &p->pm);
+    } catch (const std::bad_alloc &) {
+        return fail(TKSPMV_ERR_NOMEM, "out of host memory");
+    }
+    if (!e) return fail(status, err);
+    *out = new tkspmv_engine{e};
+    return TKSPMV_OK;
+}
+
 }  // extern "C"

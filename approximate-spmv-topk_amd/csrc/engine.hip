@@ -1842,7 +1842,7 @@ static hipError_t malloc_exchange(void **p, size_t bytes) {
     return hipMalloc(p, bytes);
 }
 
-static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err) {
+static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, const PackedMatrix *prepacked = nullptr) {
     if (d.k < 1 || d.k > TKSPMV_MAX_K) {
         err = "k must be in [1, 1024]";
         return TKSPMV_ERR_INVALID;
@@ -1909,12 +1909,35 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err) {
     // Deferred selection gives workgroup 0 of a back-to-back launch to the previous query's selection: one
     // partition per streaming wave of the remaining grid - 1 workgroups.
     const bool defer_capable = m.grid >= 2 && (uint64_t)m.grid * WG_SLOTS <= (uint64_t)SEL_PER_THREAD * (m.block + 64);
-    std::string perr = pack_wbscsr(d.rows, d.cols, d.nnz, d.row, d.col, d.val,
-                                   d.precision == TKSPMV_F32 ? Precision::F32 : Precision::Q1_7, C,
-                                   (m.grid - (defer_capable ? 1u : 0u)) * waves_per_wg, 4, m.pm, kind);
-    if (!perr.empty()) {
-        err = perr;
-        return kind == 2 ? TKSPMV_ERR_NOT_SORTED : TKSPMV_ERR_INVALID;
+    const uint32_t n_stream_waves = (m.grid - (defer_capable ? 1u : 0u)) * waves_per_wg;
+    if (prepacked) {
+        // A matrix packed earlier (tkspmv_pack / a .tkspmv file): it must describe the same problem and must not have
+        // more partitions than this launch geometry has streaming waves (the batch kernel gives every wave one).
+        const PackedMatrix &q = *prepacked;
+        if (q.rows != d.rows || q.cols != d.cols || q.precision != (d.precision == TKSPMV_F32 ? Precision::F32 : Precision::Q1_7) ||
+            q.C != C) {
+            err = "the packed matrix does not match the descriptor (rows, cols, precision or entries per lane)";
+            return TKSPMV_ERR_INVALID;
+        }
+        if (q.part_first.size() > n_stream_waves) {
+            err = "the packed matrix has more wave partitions than this GPU's launch geometry has streaming waves: pack it "
+                  "again with tkspmv_pack(desc, " + std::to_string(n_stream_waves) + ", ...)";
+            return TKSPMV_ERR_UNSUPPORTED;
+        }
+        if (q.packets.size() != q.stream_bytes() || q.pkt_row.size() != q.n_packets) {
+            err = "the packed matrix is incomplete";
+            return TKSPMV_ERR_INVALID;
+        }
+        m.pm = q;  // copy: the engine drops its host copy of the stream after the upload
+        m.desc.nnz = q.nnz;
+    } else {
+        std::string perr = pack_wbscsr(d.rows, d.cols, d.nnz, d.row, d.col, d.val,
+                                       d.precision == TKSPMV_F32 ? Precision::F32 : Precision::Q1_7, C, n_stream_waves, 4,
+                                       m.pm, kind);
+        if (!perr.empty()) {
+            err = perr;
+            return kind == 2 ? TKSPMV_ERR_NOT_SORTED : TKSPMV_ERR_INVALID;
+        }
     }
     fill_info(m.pm, d.k, &m.info);
 
@@ -2039,10 +2062,10 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err) {
     return TKSPMV_OK;
 }
 
-Engine *Engine::create(const tkspmv_desc &desc, std::string &err, int &status) {
+Engine *Engine::create(const tkspmv_desc &desc, std::string &err, int &status, const PackedMatrix *prepacked) {
     Engine *e = new Engine();
     e->impl_ = new EngineImpl();
-    status = create_impl(desc, *e->impl_, err);
+    status = create_impl(desc, *e->impl_, err, prepacked);
     if (status != TKSPMV_OK) {
         delete e;
         return nullptr;
@@ -2051,6 +2074,20 @@ Engine *Engine::create(const tkspmv_desc &desc, std::string &err, int &status) {
 }
 
 void Engine::info(tkspmv_info *out) const { *out = impl_->info; }
+
+int wave_partitions_for(const tkspmv_desc &d, uint32_t *out, std::string &err) {
+    int dev = d.device;
+    if (dev < 0) HIP_TRY(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    const uint32_t block = d.threads_per_wg > 0 ? (uint32_t)d.threads_per_wg : 512u;
+    const uint32_t waves_per_cu = d.waves_per_cu > 0 ? (uint32_t)d.waves_per_cu : 16u;
+    const uint32_t waves_per_wg = block / 64;
+    const uint32_t grid = std::max(1u, (uint32_t)prop.multiProcessorCount * waves_per_cu / waves_per_wg);
+    const bool defer_capable = grid >= 2 && (uint64_t)grid * WG_SLOTS <= (uint64_t)SEL_PER_THREAD * (block + 64);
+    *out = (grid - (defer_capable ? 1u : 0u)) * waves_per_wg;
+    return TKSPMV_OK;
+}
 
 int Engine::set_query(const float *host_x, double *elapsed_ns, std::string &err) {
     EngineImpl &m = *impl_;

@@ -16,7 +16,8 @@ struct EngineImpl;  // HIP state lives in engine.hip
 class Engine {
    public:
     // Returns nullptr and fills err/status on failure.
-    static Engine *create(const tkspmv_desc &desc, std::string &err, int &status);
+    // prepacked: a matrix packed earlier (then desc.row/col/val are not read)
+    static Engine *create(const tkspmv_desc &desc, std::string &err, int &status, const PackedMatrix *prepacked = nullptr);
     ~Engine();
 
     int set_query(const float *host_x, double *elapsed_ns, std::string &err);
@@ -50,5 +51,7 @@ class Engine {
 void fill_info(const PackedMatrix &pm, int k, tkspmv_info *out);
 uint64_t algorithmic_bytes(uint64_t nnz, uint32_t rows, uint32_t cols, uint32_t value_bytes, int k);
 int device_count();
+// Wave partitions tkspmv_create would cut the matrix into on desc.device (= streaming waves of its launch geometry).
+int wave_partitions_for(const tkspmv_desc &desc, uint32_t *out, std::string &err);
 
 }  // namespace tkspmv

@@ -22,6 +22,8 @@
 #include <vector>
 
 #include "../../include/tkspmv.h"
+#include <sys/stat.h>
+
 #include "host_utils.hpp"
 
 namespace chrono = std::chrono;
@@ -33,7 +35,11 @@ struct SpMV {
     tkspmv_t *engine = nullptr;
     int k;
 
-    SpMV(const CooMatrix &m, uint32_t rows, uint32_t cols, float *vec, int k_, int debug) : k(k_) {
+    // packed != nullptr: a packed matrix from the cache (TKSPMV_CACHE_DIR); if this GPU cannot use it (packed for a
+    // larger launch geometry) the engine is built from the COO instead. cache_path non-empty and no usable packed
+    // matrix: the matrix is packed here and written there for the next run.
+    SpMV(const CooMatrix &m, uint32_t rows, uint32_t cols, float *vec, int k_, int debug, const tkspmv_packed *packed = nullptr,
+         const std::string &cache_path = std::string()) : k(k_) {
         tkspmv_desc d{};
         d.rows = rows;
         d.cols = cols;
@@ -45,7 +51,22 @@ struct SpMV {
         d.precision = TKSPMV_F32;
         d.device = -1;
         d.min_score = 0.0f;
-        if (tkspmv_create(&engine, &d) != TKSPMV_OK) {
+        bool have = false;
+        if (packed) {
+            have = tkspmv_create_packed(&engine, packed, &d) == TKSPMV_OK;
+            if (!have && debug) std::cout << "cached packed matrix not used: " << tkspmv_last_error() << std::endl;
+        }
+        if (!have && !cache_path.empty()) {
+            uint32_t n_parts = 0;
+            tkspmv_packed *fresh = nullptr;
+            if (tkspmv_wave_partitions(&d, &n_parts) == TKSPMV_OK && tkspmv_pack(&d, n_parts, &fresh) == TKSPMV_OK) {
+                have = tkspmv_create_packed(&engine, fresh, &d) == TKSPMV_OK;
+                if (have && tkspmv_packed_save(fresh, cache_path.c_str()) != TKSPMV_OK && debug)
+                    std::cout << "could not write " << cache_path << ": " << tkspmv_last_error() << std::endl;
+                tkspmv_packed_free(fresh);
+            }
+        }
+        if (!have && tkspmv_create(&engine, &d) != TKSPMV_OK) {
             std::cerr << "engine setup failed: " << tkspmv_last_error() << std::endl;
             exit(1);
         }
@@ -128,13 +149,48 @@ int main(int argc, char *argv[]) {
     auto start_1 = clock_type::now();
     CooMatrix coo;
     const std::string path = options.use_sample_matrix ? tkspmv::Options::default_matrix() : options.matrix_path;
-    tkspmv::IoError io = tkspmv::read_mtx(path, index_base, !options.ignore_matrix_values, false, coo);
-    if (io.code) {  // the reference prints and exit(1)s (utils.hpp:486-500)
-        if (io.message.rfind("File ", 0) == 0)
-            std::cerr << io.message << std::endl;
-        else
-            std::cout << io.message << std::endl;
-        return 1;
+    // TKSPMV_CACHE_DIR: keep the packed matrix next to... wherever that directory is, keyed by the file's name, size
+    // and the -v flag. A hit skips the MatrixMarket parser and the packer (the reference redoes both on every run);
+    // the COO the software check needs is decoded from the packed matrix.
+    std::string cache_path;
+    tkspmv_packed *cached = nullptr;
+    if (const char *dir = getenv("TKSPMV_CACHE_DIR")) {
+        struct stat sb;
+        if (stat(path.c_str(), &sb) == 0) {
+            const size_t slash = path.find_last_of('/');
+            cache_path = std::string(dir) + "/" + (slash == std::string::npos ? path : path.substr(slash + 1)) + "." +
+                         std::to_string((long long)sb.st_size) + (options.ignore_matrix_values ? ".v" : "") +
+                         (index_base >= 0 ? ".b" + std::to_string(index_base) : "") + ".tkspmv";
+            if (tkspmv_packed_load(cache_path.c_str(), &cached) != TKSPMV_OK) cached = nullptr;
+        }
+    }
+    if (cached) {
+        tkspmv_info pi;
+        tkspmv_packed_info(cached, &pi);
+        coo.rows = coo.num_rows_coo = pi.rows;
+        coo.cols = pi.cols;
+        coo.index_base = index_base;
+        coo.row.resize(pi.nnz);
+        coo.col.resize(pi.nnz);
+        coo.val.resize(pi.nnz);
+        uint64_t n = 0;
+        tkspmv_packed_decode(cached, coo.row.data(), coo.col.data(), coo.val.data(), &n);
+        if (n != pi.nnz) {  // cannot happen for a file that passed its checks; fall back to the text
+            tkspmv_packed_free(cached);
+            cached = nullptr;
+        } else if (debug) {
+            std::cout << "packed matrix read from " << cache_path << std::endl;
+        }
+    }
+    if (!cached) {
+        tkspmv::IoError io = tkspmv::read_mtx(path, index_base, !options.ignore_matrix_values, false, coo);
+        if (io.code) {  // the reference prints and exit(1)s (utils.hpp:486-500)
+            if (io.message.rfind("File ", 0) == 0)
+                std::cerr << io.message << std::endl;
+            else
+                std::cout << io.message << std::endl;
+            return 1;
+        }
     }
     const uint32_t rows = std::max(coo.rows, coo.num_rows_coo);
     const uint32_t cols = coo.cols;
@@ -161,7 +217,8 @@ int main(int argc, char *argv[]) {
     }
 
     auto start_4 = clock_type::now();
-    SpMV spmv(coo, rows, cols, vec.data(), top_k_value, debug);
+    SpMV spmv(coo, rows, cols, vec.data(), top_k_value, debug, cached, cached ? std::string() : cache_path);
+    if (cached) tkspmv_packed_free(cached);
     auto gpu_setup_time = chrono::duration_cast<chrono::milliseconds>(clock_type::now() - start_4).count();
     if (debug) std::cout << "gpu setup time=" << gpu_setup_time << " ms" << std::endl;
 

@@ -2,6 +2,10 @@
 // Role of the reference's SpMV::packet_coo / packet_coo_partition (src/fpga/src/host_spmv_bscsr.cpp:133-248).
 #include "wbscsr.hpp"
 
+#include <cstdio>
+#include <cstring>
+#include <new>
+
 #include <algorithm>
 #include <cstring>
 
@@ -193,6 +197,150 @@ void decode_wbscsr(const PackedMatrix &pm, std::vector<uint32_t> &row, std::vect
             }
         }
     }
+}
+
+// ---- binary cache -----------------------------------------------------------------------------------------------------
+namespace {
+struct FileHeader {  // 128 bytes, little endian (the only byte order this code is built for)
+    char magic[8];   // "TKSPMV1\0"
+    uint32_t version, precision, C, packet_entries, packet_bytes, n_packets, packets_per_partition, n_parts;
+    uint32_t rows, cols;
+    uint64_t nnz, packed_entries, placeholders;
+    uint64_t payload_bytes, checksum;  // FNV-1a 64 over the payload
+    uint8_t pad[128 - 8 - 10 * 4 - 5 * 8];
+};
+static_assert(sizeof(FileHeader) == 128, "header layout");
+const char MAGIC[8] = {'T', 'K', 'S', 'P', 'M', 'V', '1', '\0'};
+
+uint64_t fnv1a(uint64_t h, const void *p, size_t n) {
+    const unsigned char *b = static_cast<const unsigned char *>(p);
+    for (size_t i = 0; i < n; ++i) {
+        h ^= b[i];
+        h *= 1099511628211ull;
+    }
+    return h;
+}
+// The checksum walks the payload in 8-byte words where it can: a 0.7 GB stream is hashed in well under a second.
+uint64_t fnv1a_words(uint64_t h, const void *p, size_t n) {
+    const unsigned char *b = static_cast<const unsigned char *>(p);
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        uint64_t w;
+        std::memcpy(&w, b + i, 8);
+        h ^= w;
+        h *= 1099511628211ull;
+    }
+    return fnv1a(h, b + i, n - i);
+}
+}  // namespace
+
+std::string save_packed(const PackedMatrix &pm, const char *path) {
+    if (!path) return "path is NULL";
+    const size_t n_parts = pm.part_first.size();
+    if (pm.part_count.size() != n_parts || pm.part_row0.size() != n_parts || pm.part_rows.size() != n_parts ||
+        pm.pkt_row.size() != pm.n_packets || pm.packets.size() != pm.stream_bytes())
+        return "packed matrix is incomplete (was it already uploaded and dropped?)";
+    FileHeader hd;
+    std::memset(&hd, 0, sizeof(hd));
+    std::memcpy(hd.magic, MAGIC, 8);
+    hd.version = 1;
+    hd.precision = (uint32_t)pm.precision;
+    hd.C = pm.C;
+    hd.packet_entries = pm.packet_entries;
+    hd.packet_bytes = pm.packet_bytes;
+    hd.n_packets = pm.n_packets;
+    hd.packets_per_partition = pm.packets_per_partition;
+    hd.n_parts = (uint32_t)n_parts;
+    hd.rows = pm.rows;
+    hd.cols = pm.cols;
+    hd.nnz = pm.nnz;
+    hd.packed_entries = pm.packed_entries;
+    hd.placeholders = pm.placeholders;
+    const struct {
+        const void *p;
+        size_t n;
+    } parts[] = {{pm.packets.data(), pm.packets.size()},          {pm.pkt_row.data(), pm.pkt_row.size() * 4},
+                 {pm.part_first.data(), n_parts * 4},              {pm.part_count.data(), n_parts * 4},
+                 {pm.part_row0.data(), n_parts * 4},               {pm.part_rows.data(), n_parts * 4}};
+    uint64_t sum = 1469598103934665603ull;
+    for (const auto &q : parts) {
+        hd.payload_bytes += q.n;
+        sum = fnv1a_words(sum, q.p, q.n);
+    }
+    hd.checksum = sum;
+    FILE *f = std::fopen(path, "wb");
+    if (!f) return std::string("cannot open ") + path + " for writing";
+    bool ok = std::fwrite(&hd, sizeof(hd), 1, f) == 1;
+    for (const auto &q : parts) ok = ok && (q.n == 0 || std::fwrite(q.p, 1, q.n, f) == q.n);
+    ok = (std::fclose(f) == 0) && ok;
+    if (!ok) return std::string("short write to ") + path;
+    return "";
+}
+
+std::string load_packed(const char *path, PackedMatrix &pm) {
+    if (!path) return "path is NULL";
+    FILE *f = std::fopen(path, "rb");
+    if (!f) return std::string("cannot open ") + path;
+    FileHeader hd;
+    auto fail = [&](const std::string &m) {
+        std::fclose(f);
+        return m;
+    };
+    if (std::fread(&hd, sizeof(hd), 1, f) != 1) return fail("file too short for a header");
+    if (std::memcmp(hd.magic, MAGIC, 8) != 0) return fail("not a .tkspmv file (bad magic)");
+    if (hd.version != 1) return fail("unsupported .tkspmv version");
+    if ((hd.precision != (uint32_t)Precision::F32 && hd.precision != (uint32_t)Precision::Q1_7) || (hd.C != 4 && hd.C != 8) ||
+        hd.packet_entries != 64 * hd.C ||
+        hd.packet_bytes != hd.packet_entries * (value_bytes((Precision)hd.precision) + 2) ||
+        hd.packed_entries != (uint64_t)hd.n_packets * hd.packet_entries)
+        return fail("inconsistent header");
+    const uint64_t expect = (uint64_t)hd.n_packets * hd.packet_bytes + (uint64_t)hd.n_packets * 4 + (uint64_t)hd.n_parts * 16;
+    if (hd.payload_bytes != expect) return fail("payload size does not match the header");
+    PackedMatrix out;
+    out.rows = hd.rows;
+    out.cols = hd.cols;
+    out.nnz = hd.nnz;
+    out.precision = (Precision)hd.precision;
+    out.C = hd.C;
+    out.packet_entries = hd.packet_entries;
+    out.packet_bytes = hd.packet_bytes;
+    out.n_packets = hd.n_packets;
+    out.packets_per_partition = hd.packets_per_partition;
+    out.packed_entries = hd.packed_entries;
+    out.placeholders = hd.placeholders;
+    try {
+        out.packets.resize((size_t)hd.n_packets * hd.packet_bytes);
+        out.pkt_row.resize(hd.n_packets);
+        out.part_first.resize(hd.n_parts);
+        out.part_count.resize(hd.n_parts);
+        out.part_row0.resize(hd.n_parts);
+        out.part_rows.resize(hd.n_parts);
+    } catch (const std::bad_alloc &) {
+        return fail("out of host memory");
+    }
+    struct {
+        void *p;
+        size_t n;
+    } parts[] = {{out.packets.data(), out.packets.size()},      {out.pkt_row.data(), out.pkt_row.size() * 4},
+                 {out.part_first.data(), out.part_first.size() * 4}, {out.part_count.data(), out.part_count.size() * 4},
+                 {out.part_row0.data(), out.part_row0.size() * 4},   {out.part_rows.data(), out.part_rows.size() * 4}};
+    uint64_t sum = 1469598103934665603ull;
+    for (auto &q : parts) {
+        if (q.n != 0 && std::fread(q.p, 1, q.n, f) != q.n) return fail("file is truncated");
+        sum = fnv1a_words(sum, q.p, q.n);
+    }
+    if (std::fgetc(f) != EOF) return fail("trailing bytes after the payload");
+    std::fclose(f);
+    if (sum != hd.checksum) return "checksum mismatch (corrupted file)";
+    // structural checks the kernels rely on: packet ranges of the partitions are in bounds, row ids below `rows`
+    for (uint32_t p = 0; p < hd.n_parts; ++p) {
+        if ((uint64_t)out.part_first[p] + out.part_count[p] > hd.n_packets) return "partition table out of range";
+    }
+    for (uint32_t p = 0; p < hd.n_packets; ++p) {
+        if (out.pkt_row[p] > hd.rows) return "packet row table out of range";
+    }
+    pm = std::move(out);
+    return "";
 }
 
 }  // namespace tkspmv

@@ -85,4 +85,10 @@ std::string pack_wbscsr(uint32_t rows, uint32_t cols, uint64_t nnz, const uint32
 void decode_wbscsr(const PackedMatrix &pm, std::vector<uint32_t> &row, std::vector<uint32_t> &col,
                    std::vector<float> &val);
 
+// Binary cache of a packed matrix (".tkspmv": 128-byte header, the packet stream, the side tables, FNV-1a checksum). The
+// reference parses the MatrixMarket text and re-packs on every run (utils.hpp:380-388, host_spmv_bscsr.cpp:133-248);
+// a packed file is read back at disk speed. Returns an empty string on success, else an error message.
+std::string save_packed(const PackedMatrix &pm, const char *path);
+std::string load_packed(const char *path, PackedMatrix &pm);
+
 }  // namespace tkspmv

@@ -42,6 +42,28 @@ class SpMV:
         if vec is not None:
             self.reset(vec)
 
+    @classmethod
+    def from_packed(cls, packed, k=20, debug=0, *, vec=None, device=-1, first_row=0, min_score=0.0, precision=None,
+                    stream_replicas=0):
+        """Engine straight from a packed matrix (host.Packed, e.g. Packed.load("matrix.tkspmv")): no MatrixMarket
+        parsing, no packing. precision: None = the packed value type (F32 / Q1_7), or Q1_7_WIDE for Q1.7 values."""
+        self = cls.__new__(cls)
+        self._h = C.c_void_p()
+        info = packed.info()
+        d = _lib.Desc()
+        d.rows, d.cols, d.nnz = info["rows"], info["cols"], info["nnz"]
+        d.k = int(k)
+        d.precision = info["precision"] if precision is None else precision
+        d.device, d.first_row, d.min_score = int(device), int(first_row), float(min_score)
+        d.stream_replicas = int(stream_replicas)
+        _lib.check(_lib.lib().tkspmv_create_packed(C.byref(self._h), packed._h, C.byref(d)))
+        self.k = int(k)
+        self.num_rows, self.num_cols, self.num_nnz = info["rows"], info["cols"], info["nnz"]
+        self.debug = debug
+        if vec is not None:
+            self.reset(vec)
+        return self
+
     # -- the four verbs ---------------------------------------------------------------------------------
     def reset(self, vec, debug=0):
         v = np.ascontiguousarray(vec, dtype=np.float32)

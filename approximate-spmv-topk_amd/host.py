@@ -122,6 +122,27 @@ class Packed:
         _lib.check(_lib.lib().tkspmv_pack(C.byref(d), n_wave_partitions, C.byref(self._h)))
         self.nnz = int(d.nnz)
 
+    @classmethod
+    def load(cls, path):
+        """A packed matrix read back from a .tkspmv file (raises TkspmvError ERR_IO if it is missing or damaged)."""
+        self = cls.__new__(cls)
+        self._h = C.c_void_p()
+        _lib.check(_lib.lib().tkspmv_packed_load(str(path).encode(), C.byref(self._h)))
+        self.nnz = self.info()["nnz"]
+        return self
+
+    def save(self, path):
+        _lib.check(_lib.lib().tkspmv_packed_save(self._h, str(path).encode()))
+
+    @staticmethod
+    def wave_partitions(device=-1, waves_per_cu=0, threads_per_wg=0):
+        """Wave partitions an engine on `device` cuts a matrix into (the n_wave_partitions to pack for). Needs a GPU."""
+        d = _lib.Desc()
+        d.device, d.waves_per_cu, d.threads_per_wg = int(device), int(waves_per_cu), int(threads_per_wg)
+        n = C.c_uint32()
+        _lib.check(_lib.lib().tkspmv_wave_partitions(C.byref(d), C.byref(n)))
+        return int(n.value)
+
     def info(self):
         i = _lib.Info()
         _lib.check(_lib.lib().tkspmv_packed_info(self._h, C.byref(i)))

@@ -241,6 +241,20 @@ int tkspmv_packed_raw(const tkspmv_packed *p, const void **packets, uint64_t *pa
                       const uint32_t **part_first, const uint32_t **part_count, uint32_t *n_parts);
 void tkspmv_packed_free(tkspmv_packed *p);
 
+/* ---- packed-matrix cache ------------------------------------------------------------------------
+ * The reference parses the MatrixMarket text (utils.hpp:380-388, minutes at 10^7 rows) and packs
+ * (host_spmv_bscsr.cpp:133-248, `hw_setup_time_ms`) on every run. Here the packed matrix can be written once
+ * (".tkspmv": 128-byte header, packet stream, side tables, checksum) and an engine created straight from it.
+ * tkspmv_wave_partitions: how many wave partitions tkspmv_create would use on desc->device (pass it to tkspmv_pack
+ * as the hint so that the file suits that GPU; a file with MORE partitions than the GPU has streaming waves is
+ * rejected with TKSPMV_ERR_UNSUPPORTED, fewer is fine). tkspmv_packed_load: TKSPMV_ERR_IO for a missing, truncated,
+ * inconsistent or corrupted file. tkspmv_create_packed: rows/cols/nnz and the value type come from the packed matrix,
+ * everything else (k, device, min_score, first_row, stream_replicas, TKSPMV_Q1_7 vs TKSPMV_Q1_7_WIDE) from desc. */
+int tkspmv_wave_partitions(const tkspmv_desc *desc, uint32_t *n);
+int tkspmv_packed_save(const tkspmv_packed *p, const char *path);
+int tkspmv_packed_load(const char *path, tkspmv_packed **out);
+int tkspmv_create_packed(tkspmv_t **out, const tkspmv_packed *p, const tkspmv_desc *desc);
+
 #ifdef __cplusplus
 }
 #endif

@@ -260,6 +260,20 @@ def test_drop_in_executable_csv(pkg, oracle, tmp_path):
     r = subprocess.run([exe, "-d", "-t", "1", "-m", str(p), "-k", "8"], capture_output=True, text=True, env=env,
                        timeout=300)
     assert r.returncode == 0 and "hw results=" in r.stdout and "precision=1" in r.stdout
+    # TKSPMV_CACHE_DIR: the first run writes the packed matrix, the second reads it (no MatrixMarket parsing, no
+    # packing) and must print the same results, software gold included (its COO is decoded from the packed matrix)
+    cache = tmp_path / "cache"
+    cache.mkdir()
+    env_c = dict(env, TKSPMV_CACHE_DIR=str(cache))
+    outs = []
+    for run in range(2):
+        r = subprocess.run([exe, "-d", "-t", "2", "-m", str(p), "-k", "100", "-r"], capture_output=True, text=True,
+                           env=env_c, timeout=300)
+        assert r.returncode == 0, r.stderr
+        assert ("packed matrix read from" in r.stdout) == (run == 1)
+        outs.append([ln for ln in r.stdout.split("\n") if ") document " in ln])
+    assert len(list(cache.glob("*.tkspmv"))) == 1
+    assert outs[0] == outs[1] and len(outs[0]) >= 400  # sw + hw lists of both iterations
 
 
 # ---- BASELINE configs[4]: Q1.7 fixed-point values ("FIXED_WIDTH-style" reduced precision) ----------------------------
@@ -523,3 +537,46 @@ def test_batches_on_geometries_without_the_batch_kernel(pkg, oracle, cols, k):
         assert set(got.tolist()) == set(gi.tolist()), q
         assert np.allclose(out_v[q].cpu().numpy(), gv, rtol=RTOL, atol=0), q
     eng.close()
+
+
+# ---- packed-matrix cache: an engine created from a .tkspmv file ------------------------------------------------------
+@pytest.mark.parametrize("precision", ["F32", "Q1_7_WIDE"])
+def test_engine_from_packed_file_equals_engine_from_coo(pkg, oracle, tmp_path, precision):
+    import time
+    m = pkg.generate_matrix(150000, 1024 if precision == "F32" else 512, 20, "gamma", 12)
+    x = pkg.create_sample_vector(m.cols, True, False, True, 77)
+    if precision != "F32":
+        x = (x * np.float32(30.0)).astype(np.float32)
+    prec = getattr(pkg, precision)
+    t0 = time.perf_counter()
+    a = pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, vec=x, k=100, device=0, precision=prec)
+    t_coo = time.perf_counter() - t0
+    a()
+    va, ia = a.read_result()
+    n_parts = pkg.Packed.wave_partitions(device=0)
+    assert n_parts == a.info()["grid"] * 8 - 8  # one partition per streaming wave, workgroup 0 left to the selection
+    packed = pkg.Packed(m, k=100, n_wave_partitions=n_parts, precision=pkg.F32 if precision == "F32" else pkg.Q1_7)
+    path = tmp_path / "m.tkspmv"
+    packed.save(path)
+    t0 = time.perf_counter()
+    b = pkg.SpMV.from_packed(pkg.Packed.load(path), k=100, vec=x, device=0, precision=prec)
+    t_file = time.perf_counter() - t0
+    b()
+    vb, ib = b.read_result()
+    assert np.array_equal(ia, ib) and np.array_equal(va, vb)
+    assert a.info()["n_packets"] == b.info()["n_packets"] and a.info()["n_wave_partitions"] == b.info()["n_wave_partitions"]
+    print(f"setup from COO {t_coo * 1e3:.1f} ms, from the packed file {t_file * 1e3:.1f} ms")
+    # a file packed for a bigger launch geometry is refused, a smaller one works (idle waves)
+    big = pkg.Packed(m, k=100, n_wave_partitions=2 * n_parts, precision=pkg.F32 if precision == "F32" else pkg.Q1_7)
+    if big.info()["n_wave_partitions"] > n_parts:
+        with pytest.raises(pkg.TkspmvError) as ei:
+            pkg.SpMV.from_packed(big, k=100, device=0, precision=prec)
+        assert ei.value.status == pkg._lib.ERR_UNSUPPORTED
+    small = pkg.Packed(m, k=100, n_wave_partitions=n_parts // 3, precision=pkg.F32 if precision == "F32" else pkg.Q1_7)
+    c = pkg.SpMV.from_packed(small, k=100, vec=x, device=0, precision=prec)
+    c()
+    vc, ic = c.read_result()
+    assert np.array_equal(ia, ic)  # same rows, same order; the sums may differ in the last bit (other packet cuts)
+    assert np.allclose(va, vc, rtol=1e-5, atol=0)
+    for e in (a, b, c):
+        e.close()

@@ -171,3 +171,55 @@ def test_eval_helpers_match_reference(pkg):
     z = np.load(os.path.join(GOLD, "gold_eval.npz"))
     order = np.lexsort((-z["idx"].astype(np.int64), -z["val"].astype(np.float64)))
     assert np.array_equal(z["idx"][order], z["sorted_idx"]) and np.array_equal(z["val"][order], z["sorted_val"])
+
+
+# ---- packed-matrix cache (.tkspmv files) -----------------------------------------------------------------
+@pytest.mark.parametrize("precision", ["F32", "Q1_7"])
+def test_packed_file_round_trip_is_bit_identical(pkg, tmp_path, precision):
+    m = pkg.generate_matrix(3000, 512, 20, "gamma", 9)
+    p = pkg.Packed(m, k=50, n_wave_partitions=64, precision=getattr(pkg, precision))
+    path = tmp_path / "m.tkspmv"
+    p.save(path)
+    q = pkg.Packed.load(path)
+    a, b = p.raw(), q.raw()
+    assert a[1] == b[1]
+    for u, v in zip((a[0], a[2], a[3], a[4]), (b[0], b[2], b[3], b[4])):
+        assert np.array_equal(u, v)
+    ia, ib = p.info(), q.info()
+    for key in ("rows", "cols", "nnz", "packed_entries", "packed_bytes", "n_packets", "packet_entries",
+                "n_wave_partitions", "packets_per_partition", "precision"):
+        assert ia[key] == ib[key], key
+    ra, ca, va = p.decode()
+    rb, cb, vb = q.decode()
+    assert np.array_equal(ra, rb) and np.array_equal(ca, cb) and np.array_equal(va, vb)
+
+
+def test_packed_file_rejects_damage(pkg, tmp_path):
+    m = pkg.generate_matrix(500, 64, 8, "uniform", 3)
+    p = pkg.Packed(m, n_wave_partitions=8)
+    path = tmp_path / "m.tkspmv"
+    p.save(path)
+    raw = bytearray(path.read_bytes())
+    cases = {
+        "missing": None,
+        "truncated": bytes(raw[: len(raw) - 100]),
+        "trailing": bytes(raw) + b"\0\0\0\0",
+        "bad magic": b"XXXXXXXX" + bytes(raw[8:]),
+        "flipped payload bit": bytes(raw[:1000]) + bytes([raw[1000] ^ 0x10]) + bytes(raw[1001:]),
+        "header only": bytes(raw[:128]),
+        "empty": b"",
+    }
+    for name, blob in cases.items():
+        f = tmp_path / (name.replace(" ", "_") + ".tkspmv")
+        if blob is not None:
+            f.write_bytes(blob)
+        with pytest.raises(pkg.TkspmvError) as ei:
+            pkg.Packed.load(f)
+        assert ei.value.status == pkg._lib.ERR_IO, name
+    # an inconsistent header (packet count raised) must not lead to out-of-bounds reads either
+    bad = bytearray(raw)
+    bad[28:32] = (int.from_bytes(raw[28:32], "little") + 7).to_bytes(4, "little")  # n_packets
+    f = tmp_path / "header.tkspmv"
+    f.write_bytes(bytes(bad))
+    with pytest.raises(pkg.TkspmvError):
+        pkg.Packed.load(f)
