@@ -57,6 +57,7 @@ struct StreamParams {
     float min_score;
     uint32_t *gmax;  // [MAX_GM*64] order keys of the group maxima (zero beyond n_groups_pub)
     uint32_t *tau_g; // one word: order key of the broadcast threshold (monotone, atomic max)
+    uint32_t tau_possible;  // 1: at least k publishing groups own rows, so a threshold can form (else nobody waits for one)
     uint32_t n_reducers;  // workgroups [0, n_reducers) reduce gmax -> tau_g; the others only read tau_g
     unsigned long long *wg_cand;  // [grid][WG_SLOTS] packed {score bits | row << 32}; unused slots: row SLOT_INVALID
     uint32_t cand_cap;
@@ -729,6 +730,7 @@ __device__ __forceinline__ void offer_candidates(const StreamParams &P, const Ro
 #ifndef TKSPMV_REDUCER_SLEEP
 #define TKSPMV_REDUCER_SLEEP 8
 #endif
+constexpr unsigned long long FLUSH_TAU_WAIT = 2000;  // x 10 ns: longest wait of a wave for a first threshold
 #ifndef TKSPMV_DEFER_PACKETS
 #define TKSPMV_DEFER_PACKETS 3
 #endif
@@ -997,6 +999,18 @@ __global__ void __launch_bounds__(576, 5) stream_kernel(const StreamParams P, co
         }
         if (tr) tr3 = __builtin_amdgcn_s_memrealtime();
         if (!SCORES && P.n_sets != 0u) {
+            // A short partition (small matrix: a handful of packets per wave) is over before the exchange has produced
+            // any threshold (~8 us); judging now would keep -- and dump to global memory -- every row, and the
+            // selection would face the whole matrix (measured: 100 us per query at 200k rows). Give the exchange a
+            // moment, bounded, and only where a threshold can form at all (>= k groups own rows). With long
+            // partitions the threshold exists long before this point and the loop does not spin.
+            if (P.tau_possible && first_part) {
+                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                while (__hip_atomic_load(&misc[MISC_TAU], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ==
+                           __float_as_uint(min_units) &&
+                       __builtin_amdgcn_s_memrealtime() - t0 < FLUSH_TAU_WAIT)
+                    __builtin_amdgcn_s_sleep(4);
+            }
             // The deferred packets, against the threshold as it stands now.
             const float tau =
                 __uint_as_float(__hip_atomic_load(&misc[MISC_TAU], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
@@ -1224,6 +1238,14 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0, co
     const uint32_t grp_local = is_server ? 0u : wave * P0.gpw / nwaves;
     const bool publishes = (bid * P0.gpw + grp_local) < P0.n_groups_pub;
     const bool reducer = bid < P0.n_reducers;
+    // Streaming waves that own a partition (wave w streams partition w * n_wg + bid): only they take part in the
+    // per-query protocol. Waves without one leave at once -- spinning at stream priority on every query's x flag, six of
+    // them per workgroup on a small matrix, they starved the server wave (585 us per query at 50k rows).
+    uint32_t n_active = 0;
+    for (uint32_t w = 0; w < nwaves; ++w) {  // the very test the waves apply to themselves below
+        const uint32_t pw = w * n_wg + bid;
+        if (pw < P0.n_parts && P0.part_count[pw] != 0u) ++n_active;
+    }
 
     if (is_server) {
         // ---- server wave: x staging, threshold exchange of the newest query, finalisation of the oldest -------
@@ -1302,7 +1324,7 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0, co
             if (P0.n_sets != 0u && !(P0.dbg_flags & 4u)) {
                 uint32_t hq = tail;
                 if (tail + 1u < staged &&
-                    2u * __builtin_amdgcn_readfirstlane(lds_load(&L.misc[tail & 1u][MISC_DONE])) >= nwaves)
+                    2u * __builtin_amdgcn_readfirstlane(lds_load(&L.misc[tail & 1u][MISC_DONE])) >= n_active)
                     hq = tail + 1u;
                 {
                     const uint32_t sq = hq;
@@ -1339,7 +1361,7 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0, co
             {
                 const uint32_t tp = tail & 1u;
                 uint32_t *mp = L.misc[tp];
-                if (tail < staged && __builtin_amdgcn_readfirstlane(lds_load(&mp[MISC_DONE])) >= nwaves) {
+                if (tail < staged && __builtin_amdgcn_readfirstlane(lds_load(&mp[MISC_DONE])) >= n_active) {
                     asm volatile("" ::: "memory");
                     StreamParams P = P0;
                     P.gmax = B.q[tail].gmax;
@@ -1398,14 +1420,7 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0, co
         np = P0.part_count[part];
     }
     uint2 *wcand = L.u.w.cand + wave * WAVE_CAP;
-    if (np == 0u) {  // no partition: only take part in the per-query protocol
-        for (uint32_t q = 0; q < nq; ++q) {
-            uint32_t *mp = L.misc[q & 1u];
-            while (lds_load(&mp[MISC_XREADY]) != q + 1u) __builtin_amdgcn_s_sleep(4);
-            if (lane == 0) atomicAdd(&mp[MISC_DONE], 1u);
-        }
-        return;
-    }
+    if (np == 0u) return;  // no partition (n_active does not count this wave)
 
     Pkt<C, Q8> buf[NBUF];
     uint32_t rbs[NBUF];
@@ -1480,7 +1495,7 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0, co
                     // exchange a moment -- bounded: after BATCH_TAU_WAIT the wave goes on without a threshold, so
                     // progress never depends on other workgroups being resident.
                     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-                    while (lds_load(&mp[MISC_TAU]) == __float_as_uint(min_units) && !(P0.dbg_flags & 4u) &&
+                    while (P0.tau_possible && lds_load(&mp[MISC_TAU]) == __float_as_uint(min_units) && !(P0.dbg_flags & 4u) &&
                            __builtin_amdgcn_s_memrealtime() - t0 < BATCH_TAU_WAIT)
                         __builtin_amdgcn_s_sleep(4);
                     const float tau2 = __uint_as_float(lds_load(&mp[MISC_TAU]));
@@ -1591,6 +1606,7 @@ struct EngineImpl {
     bool can_defer = false;
     bool can_batch = false;         // batch kernel usable (exchange on, x double-buffered in LDS, 4 entries per lane)
     uint32_t *d_tickets = nullptr;  // [BATCH_MAX] x 32 words
+    uint32_t groups_with_rows = 0;  // publishing groups that own at least one wave partition
     uint32_t n_reducers = 0;  // TKSPMV_REDUCERS (tuning): workgroups whose server derives tau from all maxima itself
     float *d_out_val = nullptr, *d_scores = nullptr;
     unsigned long long *d_stats = nullptr;
@@ -1625,6 +1641,7 @@ struct EngineImpl {
         P.gmax = E.gmax;
         P.tau_g = E.tau_g;
         P.n_reducers = n_reducers ? n_reducers : (grid < 8u ? grid : 8u);
+        P.tau_possible = groups_with_rows >= (uint32_t)desc.k ? 1u : 0u;
 
         P.wg_cand = E.wg_cand;
         P.cand_cap = cand_cap;
@@ -1952,6 +1969,17 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
     m.ovf_cap = std::max<uint32_t>(d.rows, 1u);
     m.xcols = d.cols <= 1024 ? 1024u : (d.cols <= 4096 ? 4096u : 16384u);
     m.cand_cap = m.xcols <= 1024 ? 2048u : 1024u;  // ListGeom<XCOLS>::CAND_CAP
+    {
+        // groups (workgroup, local group) whose first wave owns a partition: wave w of streaming workgroup b streams
+        // partition w * n_wg + b, where n_wg is the number of streaming workgroups of a sequence launch
+        const uint32_t n_wg = m.grid - (defer_capable ? 1u : 0u), n_parts = (uint32_t)m.pm.part_first.size();
+        m.groups_with_rows = 0;
+        for (uint32_t b = 0; b < n_wg; ++b)
+            for (uint32_t g = 0; g < m.gpw; ++g) {
+                const uint32_t w0 = g * waves_per_wg / m.gpw;
+                if ((uint64_t)w0 * n_wg + b < n_parts && (uint64_t)b * m.gpw + g < m.n_groups_pub) ++m.groups_with_rows;
+            }
+    }
     if (C == 8 && d.cols > 1024) {
         err = "nnz_per_lane = 8 is only built for cols <= 1024";
         return TKSPMV_ERR_UNSUPPORTED;

@@ -1,0 +1,110 @@
+"""Experiment driver pieces and accuracy metrics.
+
+Counterpart of the reference's result post-processing: the executables print one CSV line per iteration with the CPU
+gold's list (`sw_res_idx/sw_res_val`) and the accelerator's (`hw_res_idx/hw_res_val`)
+(host_spmv_topk_csr_gpu.cu:452,466-467; host_spmv_bscsr.cpp:638-691), and
+src/resources/python/plotting/plot_errors.py:85-93,182-231 turns them into precision@t, Kendall's tau and NDCG.
+Those three definitions are restated here (and pinned against the reference's functions by golden vectors,
+tests/golden/make_golden_metrics.py) so that numbers are comparable with the paper's tables.
+"""
+import csv
+import math
+import os
+
+import numpy as np
+
+THRESHOLDS = (1, 8, 16, 32, 50, 75, 100)  # the reference evaluates these prefixes (plot_errors.py THRESHOLDS)
+
+GPU_COLUMNS = ["iteration", "error_idx", "error_val", "sw_full_time_ms", "sw_topk_time_ms", "hw_setup_time_ms",
+               "hw_spmv_only_time_ms", "hw_exec_time_ms", "readback_time_ms", "k", "sw_res_idx", "sw_res_val",
+               "hw_res_idx", "hw_res_val"]
+
+
+def precision_at(sw_idx, hw_idx, t):
+    """|top-t of the gold ∩ top-t of the accelerator| / t (plot_errors.py:86-88)."""
+    return len(set(sw_idx[:t]) & set(hw_idx[:t])) / t
+
+
+def kendall_tau(reference_rank, predicted_rank):
+    """Kendall's tau over the union of the two lists (plot_errors.py:182-216): pairs ranked by both lists count +1 when
+    the two orders agree and -1 otherwise; the sum is divided by sqrt(pairs ranked by the reference) *
+    sqrt(pairs ranked by the prediction)."""
+    items = list(set(reference_rank) | set(predicted_rank))
+    ref = {it: p for p, it in enumerate(reference_rank)}
+    pred = {it: p for p, it in enumerate(predicted_rank)}
+    agree = disagree = in_ref = in_pred = 0
+    for a in range(len(items)):
+        for b in range(a + 1, len(items)):
+            i1, i2 = items[a], items[b]
+            r = i1 in ref and i2 in ref
+            p = i1 in pred and i2 in pred
+            in_ref += r
+            in_pred += p
+            if r and p:
+                if (ref[i1] - ref[i2]) * (pred[i1] - pred[i2]) > 0:
+                    agree += 1
+                else:
+                    disagree += 1
+    return (agree - disagree) / (math.sqrt(in_ref) * math.sqrt(in_pred))
+
+
+def ndcg(sw_idx, sw_val, hw_idx, hw_val):
+    """NDCG of the accelerator's list with the gold's scores as relevance (plot_errors.py:219-231): a returned row
+    that the gold does not contain has relevance 0; discount 1 / log2(position + 2). Returns (ndcg, dcg, idcg)."""
+    rel = dict(zip(sw_idx, sw_val))
+    dcg = sum(rel.get(idx, 0) / math.log2(i + 2) for i, idx in enumerate(hw_idx))
+    idcg = sum(v / math.log2(i + 2) for i, v in enumerate(sw_val))
+    return dcg / idcg, dcg, idcg
+
+
+def read_result_csv(path):
+    """Rows of a result CSV in the GPU-host schema (the one bin/approximate-spmv-mi355x-topk prints), lists decoded."""
+    out = []
+    with open(path, newline="") as f:
+        for row in csv.DictReader(f):
+            if set(GPU_COLUMNS) - set(row):
+                raise ValueError(f"{path}: not a GPU-host result file (columns {sorted(row)})")
+            k = int(row["k"])
+            rec = {c: float(row[c]) for c in GPU_COLUMNS[3:9]}
+            rec.update(iteration=int(row["iteration"]), error_idx=int(row["error_idx"]), error_val=int(row["error_val"]), k=k,
+                       sw_res_idx=[int(x) for x in row["sw_res_idx"].split(";")][:k],
+                       sw_res_val=[float(x) for x in row["sw_res_val"].split(";")][:k],
+                       hw_res_idx=[int(x) for x in row["hw_res_idx"].split(";")][:k],
+                       hw_res_val=[float(x) for x in row["hw_res_val"].split(";")][:k])
+            out.append(rec)
+    return out
+
+
+def accuracy(rows, thresholds=THRESHOLDS, skip=2):
+    """Mean precision@t / Kendall's tau / NDCG over the iterations of one result file, and the mean and standard
+    deviation of hw_exec_time_ms; the first `skip` iterations are dropped like the reference's own summary does
+    (host_spmv_bscsr.cpp:699)."""
+    rows = rows[skip:] if len(rows) > skip else rows
+    res = {"iterations": len(rows)}
+    for t in thresholds:
+        use = [r for r in rows if r["k"] >= t]
+        if not use:
+            continue
+        res[f"prec_{t}"] = float(np.mean([precision_at(r["sw_res_idx"], r["hw_res_idx"], t) for r in use]))
+        res[f"kendall_{t}"] = float(np.mean([kendall_tau(r["sw_res_idx"][:t], r["hw_res_idx"][:t]) for r in use])) if t > 1 else 1.0
+        res[f"ndcg_{t}"] = float(np.mean([ndcg(r["sw_res_idx"][:t], r["sw_res_val"][:t], r["hw_res_idx"][:t],
+                                                r["hw_res_val"][:t])[0] for r in use]))
+    ex = np.array([r["hw_exec_time_ms"] for r in rows])
+    res["hw_exec_time_ms_mean"] = float(ex.mean()) if len(ex) else float("nan")
+    res["hw_exec_time_ms_std"] = float(ex.std()) if len(ex) else float("nan")
+    res["sw_topk_time_ms_mean"] = float(np.mean([r["sw_topk_time_ms"] for r in rows])) if rows else float("nan")
+    return res
+
+
+def matrix_name(rows, cols, nnz, dist):
+    """File name convention of the reference's matrices (test_spmv_topk.py:108): matrix_{rows}_{cols}_{nnz}_{dist}.mtx"""
+    return f"matrix_{rows}_{cols}_{nnz}_{dist}.mtx"
+
+
+def result_name(rows, cols, dist, nnz, k, niter, tag="mi355x"):
+    """Result file name in the reference's pattern (test_spmv_topk.py:73,80): {t}_{s}_{c}_{d}_{n}_..._{K}_{NITER}.csv"""
+    return f"{tag}_{rows}_{cols}_{dist}_{nnz}_f32_{k}_{niter}.csv"
+
+
+def default_exe():
+    return os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bin", "approximate-spmv-mi355x-topk")

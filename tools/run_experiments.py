@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Experiment driver: the role of the reference's test_spmv_topk.py:66-111 for this engine.
+
+For every (rows, cols, distribution, nnz/row) of the grid: make sure the MatrixMarket file exists in the matrix folder
+(reference naming: matrix_{rows}_{cols}_{nnz}_{dist}.mtx; generated with this package's generator when missing), run
+the drop-in executable with the reference's flags (-t NITER -k K -r), keep its CSV in the output folder, then print
+the accuracy table (precision@t, Kendall's tau, NDCG against the executable's own CPU gold) and kernel times.
+Needs a GPU. Example:
+  python tools/run_experiments.py --rows 10000 100000 --cols 512 1024 --dist uniform gamma --nnz 20 40 -k 100 -t 30
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import _pkg  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--rows", type=int, nargs="+", default=[10000, 100000])
+ap.add_argument("--cols", type=int, nargs="+", default=[512, 1024])
+ap.add_argument("--dist", nargs="+", default=["uniform", "gamma"])
+ap.add_argument("--nnz", type=int, nargs="+", default=[20, 40])
+ap.add_argument("-k", type=int, default=100)
+ap.add_argument("-t", "--niter", type=int, default=30)
+ap.add_argument("--matrix-folder", default=os.path.join(ROOT, "gpurun_out", "matrices"))
+ap.add_argument("--out-folder", default=os.path.join(ROOT, "gpurun_out", "results", time.strftime("%Y_%m_%d_%H_%M_%S")))
+ap.add_argument("--cache", action="store_true", help="keep packed matrices next to the MatrixMarket files (TKSPMV_CACHE_DIR)")
+ap.add_argument("--seed", type=int, default=1)
+a = ap.parse_args()
+
+mod = _pkg.load()
+from importlib import import_module  # noqa: E402
+ex = import_module("approximate_spmv_topk_amd.experiments")
+
+os.makedirs(a.matrix_folder, exist_ok=True)
+os.makedirs(a.out_folder, exist_ok=True)
+env = dict(os.environ, TKSPMV_SEED=str(a.seed))
+if a.cache:
+    env["TKSPMV_CACHE_DIR"] = a.matrix_folder
+grid = [(s, c, d, n) for s in a.rows for c in a.cols for d in a.dist for n in a.nnz]
+table = []
+for i, (s, c, d, n) in enumerate(grid):
+    mtx = os.path.join(a.matrix_folder, ex.matrix_name(s, c, n, d))
+    if not os.path.exists(mtx):
+        mod.write_mtx(mtx, mod.generate_matrix(s, c, n, d, a.seed + i), index_base=1)
+    out = os.path.join(a.out_folder, ex.result_name(s, c, d, n, a.k, a.niter))
+    cmd = [ex.default_exe(), "-t", str(a.niter), "-m", mtx, "-k", str(a.k), "-r"]
+    print(f"running {i + 1}/{len(grid)}: {' '.join(cmd)} > {out}", flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env)
+    if r.returncode != 0:
+        print("  failed:", r.stderr.strip() or r.stdout.strip()[-300:])
+        continue
+    open(out, "w").write(r.stdout)
+    acc = ex.accuracy(ex.read_result_csv(out), thresholds=[t for t in ex.THRESHOLDS if t <= a.k])
+    acc.update(rows=s, cols=c, dist=d, nnz=n, k=a.k, file=os.path.basename(out))
+    table.append(acc)
+    ts = [t for t in (1, 8, 50, 100) if f"prec_{t}" in acc]
+    print("  " + "  ".join(f"prec@{t} {acc[f'prec_{t}']:.3f} tau@{t} {acc[f'kendall_{t}']:.3f} ndcg@{t} {acc[f'ndcg_{t}']:.4f}" for t in ts[-2:])
+          + f"  hw_exec {acc['hw_exec_time_ms_mean'] * 1e3:.1f} us (+- {acc['hw_exec_time_ms_std'] * 1e3:.1f})  cpu gold top-k {acc['sw_topk_time_ms_mean']:.2f} ms")
+json.dump(table, open(os.path.join(a.out_folder, "accuracy.json"), "w"), indent=1)
+print("results in", a.out_folder)
