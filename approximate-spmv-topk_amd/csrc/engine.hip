@@ -1960,11 +1960,16 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
 
     // Threshold-exchange geometry: at least k publishing groups are needed (tau = k-th largest published maximum);
     // if one group per workgroup is not enough, the waves of a workgroup are split into up to 8 groups.
+    // Counted on the workgroups that stream in a sequence launch (grid - 1: workgroup 0 selects). Aim for 4k groups
+    // where the 1024-word limit of the exchange allows: with k close to the number of groups the k-th largest maximum
+    // is a weak bound (k = 256 on 511 groups ran 2x slower than k = 100).
+    const uint32_t n_pub_wg = m.grid - (defer_capable ? 1u : 0u);
     m.gpw = 1;
-    while (m.grid * m.gpw < (uint32_t)d.k && m.gpw < 8 && m.gpw < waves_per_wg && (waves_per_wg % (m.gpw * 2) == 0))
+    while (n_pub_wg * m.gpw < 4u * (uint32_t)d.k && m.gpw < 8 && m.gpw < waves_per_wg && (waves_per_wg % (m.gpw * 2) == 0) &&
+           m.grid * m.gpw * 2 <= (uint32_t)MAX_GM * 64)
         m.gpw *= 2;
     m.n_groups_pub = std::min<uint32_t>(m.grid * m.gpw, MAX_GM * 64);
-    m.n_sets = (m.n_groups_pub >= (uint32_t)d.k) ? 1u : 0u;  // 0: exchange disabled, every row >= min_score is a candidate
+    m.n_sets = (std::min<uint32_t>(n_pub_wg * m.gpw, MAX_GM * 64) >= (uint32_t)d.k) ? 1u : 0u;  // 0: exchange disabled, every row >= min_score is a candidate
     if (!m.n_sets) m.n_groups_pub = 1;
     m.ovf_cap = std::max<uint32_t>(d.rows, 1u);
     m.xcols = d.cols <= 1024 ? 1024u : (d.cols <= 4096 ? 4096u : 16384u);
