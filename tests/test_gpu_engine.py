@@ -580,3 +580,33 @@ def test_engine_from_packed_file_equals_engine_from_coo(pkg, oracle, tmp_path, p
     assert np.allclose(va, vc, rtol=1e-5, atol=0)
     for e in (a, b, c):
         e.close()
+
+
+def test_three_million_rows(pkg, oracle):
+    """Beyond BASELINE configs[1]: 3M x 1024 (58M nnz, 0.35 GB packed, 56 packets per wave partition) -- the size one
+    GPU holds of configs[3] with room to spare. Single query against the CPU gold; a batch against the single queries."""
+    import torch
+    m = pkg.generate_matrix(3000000, 1024, 20, "gamma", 21)
+    xs = np.stack([pkg.create_sample_vector(1024, True, False, True, 8000 + i) for i in range(3)])
+    dxs = torch.from_numpy(xs).cuda()
+    eng = pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, k=100, device=0)
+    info = eng.info()
+    assert info["nnz"] == m.row.shape[0] and info["packets_per_partition"] >= 50
+    singles = []
+    for q in range(3):
+        eng.reset_device(dxs[q].data_ptr())
+        eng()
+        singles.append(eng.read_result())
+    gi, gv = oracle.gold_topk(m.row, m.col, m.val, xs[0], 100)
+    assert set(singles[0][1].tolist()) == set(gi.tolist())
+    assert np.allclose(singles[0][0], gv, rtol=RTOL, atol=0)
+    out_i = torch.zeros(3, 100, dtype=torch.int32, device="cuda")
+    out_v = torch.zeros(3, 100, dtype=torch.float32, device="cuda")
+    eng.enqueue_batch(dxs.data_ptr(), 3, out_i.data_ptr(), out_v.data_ptr())
+    eng.synchronize()
+    for q in range(3):
+        assert np.array_equal(out_i[q].cpu().numpy().view(np.uint32), singles[q][1])
+        assert np.array_equal(out_v[q].cpu().numpy(), singles[q][0])
+    ns = eng.time_queries(dxs.data_ptr(), 3, 64)
+    print(f"3M rows: {ns / 1e3:.1f} us per query, {info['algorithmic_bytes'] / ns:.0f} GB/s algorithmic")
+    eng.close()
