@@ -198,7 +198,7 @@ int tkspmv_pack(const tkspmv_desc *d, uint32_t n_wave_partitions_hint, tkspmv_pa
     tkspmv_packed *p = new tkspmv_packed();
     int kind = 0;
     uint32_t C = d->nnz_per_lane > 0 ? (uint32_t)d->nnz_per_lane : 4u;
-    std::string err = pack_wbscsr(d->rows, d->cols, d->nnz, d->row, d->col, d->val, (Precision)d->precision, C,
+    std::string err = pack_wbscsr(d->rows, d->cols, d->nnz, d->row, d->col, d->val, stream_precision(d->precision), C,
                                   n_wave_partitions_hint ? n_wave_partitions_hint : 4096u, 4, p->pm, kind);
     if (!err.empty()) {
         delete p;
@@ -277,10 +277,9 @@ int tkspmv_create_packed(tkspmv_t **out, const tkspmv_packed *p, const tkspmv_de
     d.rows = p->pm.rows;
     d.cols = p->pm.cols;
     d.nnz = p->pm.nnz;
-    d.precision = (p->pm.precision == Precision::F32) ? (desc->precision == TKSPMV_F32 ? TKSPMV_F32 : desc->precision)
-                                                      : (desc->precision == TKSPMV_Q1_7_WIDE ? TKSPMV_Q1_7_WIDE : TKSPMV_Q1_7);
-    if ((p->pm.precision == Precision::F32) != (d.precision == TKSPMV_F32))
-        return fail(TKSPMV_ERR_INVALID, "the packed matrix holds a different value type than desc.precision asks for");
+    // desc.precision chooses among the arithmetic modes of the packed value type (only Q1.7 has two)
+    if (stream_precision(desc->precision) != p->pm.precision)
+        d.precision = p->pm.precision == Precision::F32 ? TKSPMV_F32 : (p->pm.precision == Precision::F16 ? TKSPMV_F16 : TKSPMV_Q1_7);
     d.nnz_per_lane = (int32_t)p->pm.C;
     std::string err;
     int status = TKSPMV_OK;

@@ -91,36 +91,46 @@ struct ListGeom {
 constexpr uint32_t WG_SLOTS = 8;              // fixed result slots every workgroup writes (no count round trip)
 constexpr uint32_t SLOT_INVALID = 0xFFFFFFFFu;  // row id of an unused slot
 
-// One lane's share of a packet. Q8 = false: C fp32 values; Q8 = true: C Q1.7 values packed four to a dword.
-// QM: 0 = fp32, 1 = Q1.7 strict (8-bit wrapping sums, the FPGA's real_type), 2 = Q1.7 values with x block-scaled by a
-// power of two per query and exact wide accumulation.
+// One lane's share of a packet. VT = value type of the stream: 0 = C fp32 values; 1 = C Q1.7 values packed four to a
+// dword; 2 = C fp16 values packed two to a dword.
+// QM (kernel template parameter): 0 = fp32, 1 = Q1.7 strict (8-bit wrapping sums, the FPGA's real_type), 2 = Q1.7 values
+// with x block-scaled by a power of two per query and exact wide accumulation, 3 = fp16 values, fp32 x, fp32 arithmetic
+// (the CUDA comparator's half mode, -a: host_spmv_topk_csr_gpu.cu:132-136,152-160).
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+constexpr int value_type_of(int QM) { return QM == 3 ? 2 : (QM != 0 ? 1 : 0); }
 
 // The packet stream is read once per query: nontemporal loads (a plain read kernel over the same bytes gains 12 %
 // from them when the stream comes from HBM, tools/stream_probe.hip).
-template <int C, bool Q8>
+template <int C, int VT>
 struct Pkt {
-    float v[Q8 ? 1 : C];
-    uint32_t vq[Q8 ? C / 4 : 1];
+    float v[VT == 0 ? C : 1];
+    uint32_t vq[VT == 1 ? C / 4 : (VT == 2 ? C / 2 : 1)];
     uint32_t cw[C / 2];
 };
 
-template <int C, bool Q8>
-__device__ __forceinline__ void load_packet(const uint8_t *__restrict__ pk, uint32_t lane, Pkt<C, Q8> &o) {
+template <int C, int VT>
+__device__ __forceinline__ void load_packet(const uint8_t *__restrict__ pk, uint32_t lane, Pkt<C, VT> &o) {
 #pragma unroll
     for (int q = 0; q < C / 4; ++q) {
-        if (Q8) {
-            o.vq[Q8 ? q : 0] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(pk + q * 256 + lane * 4));
+        if (VT == 1) {
+            o.vq[VT == 1 ? q : 0] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(pk + q * 256 + lane * 4));
             const u32x2 c = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(pk + C * 64 + q * 512 + lane * 8));
+            o.cw[2 * q + 0] = c.x;
+            o.cw[2 * q + 1] = c.y;
+        } else if (VT == 2) {
+            const u32x2 hv = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(pk + q * 512 + lane * 8));
+            o.vq[VT == 2 ? 2 * q + 0 : 0] = hv.x;
+            o.vq[VT == 2 ? 2 * q + 1 : 0] = hv.y;
+            const u32x2 c = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(pk + C * 128 + q * 512 + lane * 8));
             o.cw[2 * q + 0] = c.x;
             o.cw[2 * q + 1] = c.y;
         } else {
             const f32x4 f = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(pk + q * 1024 + lane * 16));
-            o.v[Q8 ? 0 : 4 * q + 0] = f.x;
-            o.v[Q8 ? 0 : 4 * q + 1] = f.y;
-            o.v[Q8 ? 0 : 4 * q + 2] = f.z;
-            o.v[Q8 ? 0 : 4 * q + 3] = f.w;
+            o.v[VT == 0 ? 4 * q + 0 : 0] = f.x;
+            o.v[VT == 0 ? 4 * q + 1 : 0] = f.y;
+            o.v[VT == 0 ? 4 * q + 2 : 0] = f.z;
+            o.v[VT == 0 ? 4 * q + 3 : 0] = f.w;
             const u32x2 c = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(pk + C * 256 + q * 512 + lane * 8));
             o.cw[2 * q + 0] = c.x;
             o.cw[2 * q + 1] = c.y;
@@ -584,23 +594,28 @@ __device__ __forceinline__ RowSums<C> reduce_core(float (&p)[C], const uint32_t 
 
 // Products from a packet and the x vector staged in LDS, then the reduction.
 template <int C, int QM>
-__device__ __forceinline__ RowSums<C> reduce_packet(const Pkt<C, (QM != 0)> &cur, float &carry, const float *x_lds) {
-    constexpr bool Q8 = QM != 0;
+__device__ __forceinline__ RowSums<C> reduce_packet(const Pkt<C, value_type_of(QM)> &cur, float &carry, const float *x_lds) {
+    constexpr int VT = value_type_of(QM);
     float p[C];
 #pragma unroll
     for (int j = 0; j < C; ++j) {
         const uint32_t word = cur.cw[j >> 1];
         const uint32_t off = (j & 1) ? ((word >> 16) & 0xFFFCu) : (word & 0xFFFCu);  // byte offset of x[col]
-        if (Q8) {
+        if (VT == 1) {
             // x is staged as Q1.7 integers; product truncated to Q1.7 and wrapped to 8 bits, exact in fp32
             const uint32_t xq = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const unsigned char *>(x_lds) + off);
-            const uint32_t vq = (cur.vq[Q8 ? (j >> 2) : 0] >> (8 * (j & 3))) & 255u;
+            const uint32_t vq = (cur.vq[VT == 1 ? (j >> 2) : 0] >> (8 * (j & 3))) & 255u;
             // both factors are below 2^8: the 24-bit multiply is exact (and full rate; v_mul_lo_u32 is quarter rate)
             const uint32_t t = __umul24(vq, xq);
             p[j] = (float)(QM == 2 ? (t >> 7) : ((t >> 7) & 255u));  // wide mode: no wrap
+        } else if (VT == 2) {
+            const float xv = *reinterpret_cast<const float *>(reinterpret_cast<const unsigned char *>(x_lds) + off);
+            const uint32_t hw = cur.vq[VT == 2 ? (j >> 1) : 0];
+            const _Float16 hv = __builtin_bit_cast(_Float16, (uint16_t)((j & 1) ? (hw >> 16) : (hw & 0xFFFFu)));
+            p[j] = __fmul_rn((float)hv, xv);  // the conversion is exact
         } else {
             const float xv = *reinterpret_cast<const float *>(reinterpret_cast<const unsigned char *>(x_lds) + off);
-            p[j] = __fmul_rn(cur.v[Q8 ? 0 : j], xv);
+            p[j] = __fmul_rn(cur.v[VT == 0 ? j : 0], xv);
         }
     }
     return reduce_core<C>(p, cur.cw, carry);
@@ -757,7 +772,8 @@ struct StreamLds {
 #endif
 template <int C, bool SCORES, int XCOLS, int QM = 0, int NBUF = TKSPMV_NBUF>
 __global__ void __launch_bounds__(576, 5) stream_kernel(const StreamParams P, const SelectParams SP) {
-    constexpr bool Q8 = QM != 0;
+    constexpr bool Q8 = QM == 1 || QM == 2;  // x staged as Q1.7 integers
+    constexpr int VT = value_type_of(QM);
     __shared__ StreamLds<XCOLS> L;
     float *x_lds = L.u.w.x;
     uint2 *cand = L.u.w.cand;
@@ -805,7 +821,7 @@ __global__ void __launch_bounds__(576, 5) stream_kernel(const StreamParams P, co
     // barrier overlap with the first memory round trip instead of preceding it.
     const uint32_t total_waves = nwaves * n_wg;
     uint32_t q = is_server ? P.n_parts : wave * n_wg + bid;
-    Pkt<C, Q8> buf[NBUF];
+    Pkt<C, VT> buf[NBUF];
     uint32_t rbs[NBUF];
     uint32_t p0 = 0, np = 0;
     if (q < P.n_parts) {
@@ -818,7 +834,7 @@ __global__ void __launch_bounds__(576, 5) stream_kernel(const StreamParams P, co
             rbs[u] = 0u;
             if (np > 0) {
                 const uint32_t iu = ((uint32_t)u < np) ? (uint32_t)u : (np - 1);
-                load_packet<C, Q8>(P.packets + (size_t)(p0 + iu) * P.packet_bytes, lane, buf[u]);
+                load_packet<C, VT>(P.packets + (size_t)(p0 + iu) * P.packet_bytes, lane, buf[u]);
                 rbs[u] = P.pkt_row[p0 + iu];
             }
         }
@@ -937,9 +953,9 @@ __global__ void __launch_bounds__(576, 5) stream_kernel(const StreamParams P, co
             for (int u = 0; u < NBUF; ++u) {
                 const uint32_t i = i0 + (uint32_t)u;
                 if (i >= np) break;
-                const Pkt<C, Q8> &cur = buf[u];
+                const Pkt<C, VT> &cur = buf[u];
                 const uint32_t rb_cur = rbs[u];
-                Pkt<C, Q8> &ahead = buf[(u + NBUF - 1) % NBUF];
+                Pkt<C, VT> &ahead = buf[(u + NBUF - 1) % NBUF];
                 uint32_t &rb_ahead = rbs[(u + NBUF - 1) % NBUF];
             {
                 // Unconditional (index clamped to the last packet): a fixed number of younger loads lets the
@@ -957,7 +973,7 @@ __global__ void __launch_bounds__(576, 5) stream_kernel(const StreamParams P, co
                         }
                     }
                 }
-                load_packet<C, Q8>(pk_a + (size_t)ia * P.packet_bytes, lane, ahead);
+                load_packet<C, VT>(pk_a + (size_t)ia * P.packet_bytes, lane, ahead);
                 rb_ahead = P.pkt_row[p0 + ia];
             }
             float tau = 0.0f;
@@ -1186,7 +1202,8 @@ __device__ __forceinline__ uint32_t lds_load(const uint32_t *p) {
 
 template <int C, int XCOLS, int QM>
 __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0, const SelectParams SP0, const BatchParams B) {
-    constexpr bool Q8 = QM != 0;
+    constexpr bool Q8 = QM == 1 || QM == 2;  // x staged as Q1.7 integers
+    constexpr int VT = value_type_of(QM);
     constexpr int NBUF = 3;
     constexpr uint32_t WAVE_CAP = ListGeom<XCOLS>::WAVE_CAP;
     __shared__ BatchLds<XCOLS> L;
@@ -1422,13 +1439,13 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0, co
     uint2 *wcand = L.u.w.cand + wave * WAVE_CAP;
     if (np == 0u) return;  // no partition (n_active does not count this wave)
 
-    Pkt<C, Q8> buf[NBUF];
+    Pkt<C, VT> buf[NBUF];
     uint32_t rbs[NBUF];
     uint32_t qa = 0u, ja = 0u;  // next packet to request: (query, packet of the partition)
     const uint8_t *pk_a = B.q[0].packets + (size_t)p0 * P0.packet_bytes;  // partition base in the stream copy of query qa
 #define TKSPMV_REQUEST(dst, rb_dst)                                                                                   \
     do {                                                                                                              \
-        load_packet<C, Q8>(pk_a + (size_t)ja * P0.packet_bytes, lane, dst);                                           \
+        load_packet<C, VT>(pk_a + (size_t)ja * P0.packet_bytes, lane, dst);                                           \
         rb_dst = P0.pkt_row[p0 + ja];                                                                                 \
         if (!(qa + 1u == nq && ja + 1u == np)) { /* past the end: the last packet is requested again (counted vmcnt) */ \
             ++ja;                                                                                                     \
@@ -1458,7 +1475,7 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0, co
 #pragma unroll
         for (int u = 0; u < NBUF; ++u) {
             if (i0 + (uint32_t)u >= total) break;
-            const Pkt<C, Q8> &cur = buf[u];
+            const Pkt<C, VT> &cur = buf[u];
             const uint32_t rb_cur = rbs[u];
             TKSPMV_REQUEST(buf[(u + NBUF - 1) % NBUF], rbs[(u + NBUF - 1) % NBUF]);
             if (jc == 0u) {  // a new query starts: its x must have been staged
@@ -1632,7 +1649,7 @@ struct EngineImpl {
         P.x = x;
         P.n_parts = (uint32_t)info.n_wave_partitions;
         P.cols = desc.cols;
-        P.packet_bytes = info.packet_entries * ((desc.precision == TKSPMV_F32 ? 4u : 1u) + 2u);
+        P.packet_bytes = info.packet_entries * (value_bytes(stream_precision(desc.precision)) + 2u);
         P.n_sets = n_sets;
         P.k = (uint32_t)desc.k;
         P.n_groups_pub = n_groups_pub;
@@ -1701,6 +1718,7 @@ struct EngineImpl {
     batch_fn batch_kernel_for() const {  // can_batch: x of at most 1024 columns (it is held twice in LDS)
         if (desc.precision == TKSPMV_Q1_7) return &batch_kernel<4, 1024, 1>;
         if (desc.precision == TKSPMV_Q1_7_WIDE) return &batch_kernel<4, 1024, 2>;
+        if (desc.precision == TKSPMV_F16) return &batch_kernel<4, 1024, 3>;
         return &batch_kernel<4, 1024, 0>;
     }
     // n <= BATCH_MAX queries in one launch of the batch kernel; results complete in stream order after the launch.
@@ -1769,6 +1787,11 @@ struct EngineImpl {
             if (xcols <= 1024) return scores ? &stream_kernel<4, true, 1024, 1> : &stream_kernel<4, false, 1024, 1>;
             if (xcols <= 4096) return scores ? &stream_kernel<4, true, 4096, 1> : &stream_kernel<4, false, 4096, 1>;
             return scores ? &stream_kernel<4, true, 16384, 1> : &stream_kernel<4, false, 16384, 1>;
+        }
+        if (desc.precision == TKSPMV_F16) {
+            if (xcols <= 1024) return scores ? &stream_kernel<4, true, 1024, 3> : &stream_kernel<4, false, 1024, 3>;
+            if (xcols <= 4096) return scores ? &stream_kernel<4, true, 4096, 3> : &stream_kernel<4, false, 4096, 3>;
+            return scores ? &stream_kernel<4, true, 16384, 3> : &stream_kernel<4, false, 16384, 3>;
         }
         if (desc.precision == TKSPMV_Q1_7_WIDE) {
             if (xcols <= 1024) return scores ? &stream_kernel<4, true, 1024, 2> : &stream_kernel<4, false, 1024, 2>;
@@ -1868,15 +1891,16 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
         err = "cols must be in [1, 16384]";
         return TKSPMV_ERR_INVALID;
     }
-    if (d.precision != TKSPMV_F32 && d.precision != TKSPMV_Q1_7 && d.precision != TKSPMV_Q1_7_WIDE) {
+    if (d.precision != TKSPMV_F32 && d.precision != TKSPMV_Q1_7 && d.precision != TKSPMV_Q1_7_WIDE &&
+        d.precision != TKSPMV_F16) {
         err = "unknown precision";
         return TKSPMV_ERR_INVALID;
     }
     if (d.precision != TKSPMV_F32 && d.nnz_per_lane == 8) {
-        err = "the Q1.7 precisions are built for nnz_per_lane = 4 only";
+        err = "the reduced precisions are built for nnz_per_lane = 4 only";
         return TKSPMV_ERR_UNSUPPORTED;
     }
-    m.q8 = d.precision != TKSPMV_F32;
+    m.q8 = d.precision == TKSPMV_Q1_7 || d.precision == TKSPMV_Q1_7_WIDE;
     if (d.partitions > 1) {
         // The reference keeps k_per_partition (its compile-time K) candidates per row partition and merges them on
         // the host (host_spmv_bscsr.cpp:399-448). For k <= k_per_partition the union of the per-partition lists
@@ -1931,7 +1955,7 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
         // A matrix packed earlier (tkspmv_pack / a .tkspmv file): it must describe the same problem and must not have
         // more partitions than this launch geometry has streaming waves (the batch kernel gives every wave one).
         const PackedMatrix &q = *prepacked;
-        if (q.rows != d.rows || q.cols != d.cols || q.precision != (d.precision == TKSPMV_F32 ? Precision::F32 : Precision::Q1_7) ||
+        if (q.rows != d.rows || q.cols != d.cols || q.precision != stream_precision(d.precision) ||
             q.C != C) {
             err = "the packed matrix does not match the descriptor (rows, cols, precision or entries per lane)";
             return TKSPMV_ERR_INVALID;
@@ -1949,7 +1973,7 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
         m.desc.nnz = q.nnz;
     } else {
         std::string perr = pack_wbscsr(d.rows, d.cols, d.nnz, d.row, d.col, d.val,
-                                       d.precision == TKSPMV_F32 ? Precision::F32 : Precision::Q1_7, C, n_stream_waves, 4,
+                                       stream_precision(d.precision), C, n_stream_waves, 4,
                                        m.pm, kind);
         if (!perr.empty()) {
             err = perr;

@@ -39,7 +39,7 @@ struct SpMV {
     // larger launch geometry) the engine is built from the COO instead. cache_path non-empty and no usable packed
     // matrix: the matrix is packed here and written there for the next run.
     SpMV(const CooMatrix &m, uint32_t rows, uint32_t cols, float *vec, int k_, int debug, const tkspmv_packed *packed = nullptr,
-         const std::string &cache_path = std::string()) : k(k_) {
+         const std::string &cache_path = std::string(), int precision = TKSPMV_F32) : k(k_) {
         tkspmv_desc d{};
         d.rows = rows;
         d.cols = cols;
@@ -48,7 +48,7 @@ struct SpMV {
         d.col = m.col.data();
         d.val = m.val.data();
         d.k = k_;
-        d.precision = TKSPMV_F32;
+        d.precision = precision;
         d.device = -1;
         d.min_score = 0.0f;
         bool have = false;
@@ -135,8 +135,8 @@ int main(int argc, char *argv[]) {
         std::cerr << "k must be in [1, " << TKSPMV_MAX_K << "]" << std::endl;
         return 1;
     }
-    if (options.use_half_precision_gpu && debug)
-        std::cout << "note: -a (half precision) is accepted; this build computes in fp32" << std::endl;
+    // -a: the CUDA comparator's half mode (values stored as fp16, host_spmv_topk_csr_gpu.cu:132-136) -> TKSPMV_F16
+    const int precision = options.use_half_precision_gpu ? TKSPMV_F16 : TKSPMV_F32;
 
     int index_base = -1;
     if (const char *ib = getenv("TKSPMV_INDEX_BASE")) {
@@ -159,7 +159,7 @@ int main(int argc, char *argv[]) {
         if (stat(path.c_str(), &sb) == 0) {
             const size_t slash = path.find_last_of('/');
             cache_path = std::string(dir) + "/" + (slash == std::string::npos ? path : path.substr(slash + 1)) + "." +
-                         std::to_string((long long)sb.st_size) + (options.ignore_matrix_values ? ".v" : "") +
+                         std::to_string((long long)sb.st_size) + (options.ignore_matrix_values ? ".v" : "") + (options.use_half_precision_gpu ? ".h" : "") +
                          (index_base >= 0 ? ".b" + std::to_string(index_base) : "") + ".tkspmv";
             if (tkspmv_packed_load(cache_path.c_str(), &cached) != TKSPMV_OK) cached = nullptr;
         }
@@ -217,7 +217,7 @@ int main(int argc, char *argv[]) {
     }
 
     auto start_4 = clock_type::now();
-    SpMV spmv(coo, rows, cols, vec.data(), top_k_value, debug, cached, cached ? std::string() : cache_path);
+    SpMV spmv(coo, rows, cols, vec.data(), top_k_value, debug, cached, cached ? std::string() : cache_path, precision);
     if (cached) tkspmv_packed_free(cached);
     auto gpu_setup_time = chrono::duration_cast<chrono::milliseconds>(clock_type::now() - start_4).count();
     if (debug) std::cout << "gpu setup time=" << gpu_setup_time << " ms" << std::endl;

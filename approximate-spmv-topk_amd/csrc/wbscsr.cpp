@@ -153,6 +153,9 @@ std::string pack_wbscsr(uint32_t rows, uint32_t cols, uint64_t nnz, const uint32
                 if (stream_slot == 0) prow[pk] = r;
                 if (precision == Precision::F32) {
                     std::memcpy(pkt + (size_t)slot * 4, &v, 4);
+                } else if (precision == Precision::F16) {
+                    const uint16_t hv = to_half(v);
+                    std::memcpy(pkt + (size_t)slot * 2, &hv, 2);
                 } else {
                     pkt[slot] = to_q1_7(v);
                 }
@@ -181,10 +184,15 @@ void decode_wbscsr(const PackedMatrix &pm, std::vector<uint32_t> &row, std::vect
                 uint16_t cw;
                 std::memcpy(&cw, pkt + (size_t)PE * vb + (size_t)s * 2, 2);
                 float v;
-                if (pm.precision == Precision::F32)
+                if (pm.precision == Precision::F32) {
                     std::memcpy(&v, pkt + (size_t)s * 4, 4);
-                else
+                } else if (pm.precision == Precision::F16) {
+                    uint16_t hv;
+                    std::memcpy(&hv, pkt + (size_t)s * 2, 2);
+                    v = from_half(hv);
+                } else {
                     v = from_q1_7(pkt[s]);
+                }
                 if (!(cw & COLW_SKIP)) {
                     row.push_back(r);
                     col.push_back((uint32_t)(cw >> COLW_COL_SHIFT));
@@ -289,7 +297,9 @@ std::string load_packed(const char *path, PackedMatrix &pm) {
     if (std::fread(&hd, sizeof(hd), 1, f) != 1) return fail("file too short for a header");
     if (std::memcmp(hd.magic, MAGIC, 8) != 0) return fail("not a .tkspmv file (bad magic)");
     if (hd.version != 1) return fail("unsupported .tkspmv version");
-    if ((hd.precision != (uint32_t)Precision::F32 && hd.precision != (uint32_t)Precision::Q1_7) || (hd.C != 4 && hd.C != 8) ||
+    if ((hd.precision != (uint32_t)Precision::F32 && hd.precision != (uint32_t)Precision::Q1_7 &&
+         hd.precision != (uint32_t)Precision::F16) ||
+        (hd.C != 4 && hd.C != 8) ||
         hd.packet_entries != 64 * hd.C ||
         hd.packet_bytes != hd.packet_entries * (value_bytes((Precision)hd.precision) + 2) ||
         hd.packed_entries != (uint64_t)hd.n_packets * hd.packet_entries)

@@ -21,6 +21,7 @@
 //     32 partitions -> HBM channels becomes n_CU * waves_per_CU partitions -> waves.
 #pragma once
 #include <cstdint>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -39,9 +40,59 @@ inline uint32_t slot_to_index(uint32_t s, uint32_t C) {
     return (j >> 2) * (WAVE * 4) + lane * 4 + (j & 3);
 }
 
-enum class Precision : int32_t { F32 = 0, Q1_7 = 1 };
+enum class Precision : int32_t { F32 = 0, Q1_7 = 1, F16 = 3 };  // value type in the packet stream
 
-inline uint32_t value_bytes(Precision p) { return p == Precision::F32 ? 4u : 1u; }
+inline uint32_t value_bytes(Precision p) { return p == Precision::F32 ? 4u : (p == Precision::F16 ? 2u : 1u); }
+// Value type of the stream for a tkspmv_precision (TKSPMV_Q1_7 and TKSPMV_Q1_7_WIDE share the Q1.7 stream).
+inline Precision stream_precision(int32_t api_precision) {
+    return api_precision == 0 ? Precision::F32 : (api_precision == 3 ? Precision::F16 : Precision::Q1_7);
+}
+
+// IEEE binary16 <-> binary32, round to nearest even, overflow to infinity (the CUDA comparator's half mode converts
+// its values the same way: host_spmv_topk_csr_gpu.cu:132-136,152-160 with __float2half).
+inline uint16_t to_half(float f) {
+    uint32_t x;
+    std::memcpy(&x, &f, 4);
+    const uint16_t sign = (uint16_t)((x >> 16) & 0x8000u);
+    x &= 0x7FFFFFFFu;
+    if (x >= 0x7F800000u) return (uint16_t)(sign | (x > 0x7F800000u ? 0x7E00u : 0x7C00u));  // NaN / infinity
+    if (x >= 0x477FF000u) return (uint16_t)(sign | 0x7C00u);                                  // >= 65520 rounds to infinity
+    uint32_t q, rem, half;
+    if (x < 0x38800000u) {  // below 2^-14: subnormal half (or zero)
+        if (x < 0x33000000u) return sign;  // below 2^-25 (2^-25 itself ties to even = 0)
+        const uint32_t e = x >> 23, M = (x & 0x7FFFFFu) | 0x800000u, shift = 126u - e;  // 14..24
+        q = M >> shift;
+        rem = M & ((1u << shift) - 1u);
+        half = 1u << (shift - 1u);
+    } else {
+        q = (((x >> 23) - 112u) << 10) | ((x & 0x7FFFFFu) >> 13);
+        rem = x & 0x1FFFu;
+        half = 0x1000u;
+    }
+    if (rem > half || (rem == half && (q & 1u))) ++q;  // a carry out of the mantissa bumps the exponent, as it should
+    return (uint16_t)(sign | q);
+}
+inline float from_half(uint16_t hbits) {
+    const uint32_t sign = (uint32_t)(hbits & 0x8000u) << 16, e = (hbits >> 10) & 31u, m = hbits & 0x3FFu;
+    uint32_t x;
+    if (e == 31u) {
+        x = sign | 0x7F800000u | (m << 13);
+    } else if (e != 0u) {
+        x = sign | ((e + 112u) << 23) | (m << 13);
+    } else if (m == 0u) {
+        x = sign;
+    } else {  // subnormal: normalise
+        uint32_t mm = m, ee = 113u;
+        while (!(mm & 0x400u)) {
+            mm <<= 1;
+            --ee;
+        }
+        x = sign | (ee << 23) | ((mm & 0x3FFu) << 13);
+    }
+    float f;
+    std::memcpy(&f, &x, 4);
+    return f;
+}
 
 // Unsigned fixed point with 1 integer and 7 fraction bits, truncation toward zero and saturation at the
 // top of the range when converting from float (restating ap_ufixed<8,1,AP_TRN_ZERO>, fpga_types.hpp:20).

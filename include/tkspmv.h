@@ -57,8 +57,10 @@ typedef enum {
     TKSPMV_F32 = 0,  /* fp32 values, fp32 x, fp32 accumulate (USE_FLOAT build / GPU hosts) */
     TKSPMV_Q1_7 = 1, /* unsigned fixed point, 1 integer + 7 fraction bits: values, x, products AND sums in 8 bits
                         (the FPGA's ap_ufixed<FIXED_WIDTH,1> real_type with FIXED_WIDTH = 8), see DESIGN.md */
-    TKSPMV_Q1_7_WIDE = 2 /* Q1.7 values and products, x block-scaled by a power of two per query, exact (non-wrapping)
-                            accumulation: the same 3 B/nnz stream with usable ranking quality */
+    TKSPMV_Q1_7_WIDE = 2, /* Q1.7 values and products, x block-scaled by a power of two per query, exact (non-wrapping)
+                             accumulation: the same 3 B/nnz stream with usable ranking quality */
+    TKSPMV_F16 = 3        /* fp16 values (round to nearest even), fp32 x, fp32 products and sums: 4 B/nnz. The CUDA
+                             comparator's half mode (-a, host_spmv_topk_csr_gpu.cu:132-136,152-160) */
 } tkspmv_precision;
 
 typedef struct tkspmv_engine tkspmv_t;

@@ -249,6 +249,56 @@ void oracle_select_topk(const float *y, const uint8_t *present, uint32_t rows, i
  * arithmetic of stream_kernel in approximate-spmv-topk_amd/csrc/engine.hip (products, in-lane segmented sums,
  * clipped Kogge-Stone scan over the 64 lanes, packet carry). Column word: bit0 ROW_END, bit1 SKIP, bits 15..2 col.
  * ---------------------------------------------------------------------------------------------------------- */
+/* IEEE binary16 <-> binary32, round to nearest even, overflow to infinity: what __float2half does in the CUDA
+ * comparator's half mode (host_spmv_topk_csr_gpu.cu:132-136,152-160). Pinned against numpy.float16 in the tests. */
+uint16_t oracle_float_to_half(float f) {
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    const uint16_t sign = (uint16_t)((x >> 16) & 0x8000u);
+    x &= 0x7FFFFFFFu;
+    if (x >= 0x7F800000u) return (uint16_t)(sign | (x > 0x7F800000u ? 0x7E00u : 0x7C00u));
+    if (x >= 0x477FF000u) return (uint16_t)(sign | 0x7C00u);
+    uint32_t q, rem, half;
+    if (x < 0x38800000u) {
+        if (x < 0x33000000u) return sign;
+        const uint32_t e = x >> 23, M = (x & 0x7FFFFFu) | 0x800000u, shift = 126u - e;
+        q = M >> shift;
+        rem = M & ((1u << shift) - 1u);
+        half = 1u << (shift - 1u);
+    } else {
+        q = (((x >> 23) - 112u) << 10) | ((x & 0x7FFFFFu) >> 13);
+        rem = x & 0x1FFFu;
+        half = 0x1000u;
+    }
+    if (rem > half || (rem == half && (q & 1u))) ++q;
+    return (uint16_t)(sign | q);
+}
+float oracle_half_to_float(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 31u, m = h & 0x3FFu;
+    uint32_t x;
+    if (e == 31u) {
+        x = sign | 0x7F800000u | (m << 13);
+    } else if (e != 0u) {
+        x = sign | ((e + 112u) << 23) | (m << 13);
+    } else if (m == 0u) {
+        x = sign;
+    } else {
+        uint32_t mm = m, ee = 113u;
+        while (!(mm & 0x400u)) {
+            mm <<= 1;
+            --ee;
+        }
+        x = sign | (ee << 23) | ((mm & 0x3FFu) << 13);
+    }
+    float f;
+    memcpy(&f, &x, 4);
+    return f;
+}
+/* values rounded to fp16 and back, in place semantics of TKSPMV_F16's value stream */
+void oracle_round_values_to_half(const float *in, float *out, uint64_t n) {
+    for (uint64_t i = 0; i < n; i++) out[i] = oracle_half_to_float(oracle_float_to_half(in[i]));
+}
+
 void oracle_packed_scores(const uint8_t *packets, uint64_t packet_bytes, const uint32_t *pkt_row,
                           const uint32_t *part_first, const uint32_t *part_count, uint32_t n_parts, uint32_t C,
                           const float *x, uint32_t rows, float *y, uint8_t *present) {
@@ -260,8 +310,12 @@ void oracle_packed_scores(const uint8_t *packets, uint64_t packet_bytes, const u
         for (uint32_t i = 0; i < part_count[q]; i++) {
             const uint32_t pidx = part_first[q] + i;
             const uint8_t *pk = packets + (size_t)pidx * packet_bytes;
+            /* value type from the packet size: 4 bytes = fp32, 2 bytes = fp16 (TKSPMV_F16; converted exactly to fp32
+             * before the multiply, as the kernel does) */
+            const uint32_t vb = (uint32_t)(packet_bytes / PE) - 2u;
             const float *vals = (const float *)pk;
-            const uint16_t *cws = (const uint16_t *)(pk + (size_t)PE * 4);
+            const uint16_t *hvals = (const uint16_t *)pk;
+            const uint16_t *cws = (const uint16_t *)(pk + (size_t)PE * vb);
             float s[64][8], rs[64][8], head[64], tail[64], vv[64], nv[64];
             uint32_t e[64][8], skip[64][8];
             int first[64], any_e[64], dist[64];
@@ -271,7 +325,7 @@ void oracle_packed_scores(const uint8_t *packets, uint64_t packet_bytes, const u
                     uint32_t at = (j >> 2) * 256 + l * 4 + (j & 3);
                     uint16_t w = cws[at];
                     float xv = x[w >> 2];
-                    p[j] = vals[at] * xv;
+                    p[j] = (vb == 2u ? oracle_half_to_float(hvals[at]) : vals[at]) * xv;
                     e[l][j] = w & 1u;
                     skip[l][j] = w & 2u;
                 }

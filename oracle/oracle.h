@@ -60,6 +60,12 @@ void oracle_packed_scores(const uint8_t *packets, uint64_t packet_bytes, const u
                           const uint32_t *part_first, const uint32_t *part_count, uint32_t n_parts, uint32_t C,
                           const float *x, uint32_t rows, float *y, uint8_t *present);
 
+/* TKSPMV_F16 (the CUDA comparator's half mode, host_spmv_topk_csr_gpu.cu:132-136,152-160): values rounded to IEEE
+ * binary16 (nearest even), everything else fp32. oracle_packed_scores reads a 2-byte value stream itself. */
+uint16_t oracle_float_to_half(float f);
+float oracle_half_to_float(uint16_t h);
+void oracle_round_values_to_half(const float *in, float *out, uint64_t n);
+
 /* create_sample_vector(vec, size, random=true, sum_to_one, norm_one, seed != 0) (src/common/utils/utils.hpp:234-267)
  * with std::mt19937 and std::uniform_real_distribution<double> restated (libstdc++ generate_canonical). */
 void oracle_sample_vector(float *vec, int size, int sum_to_one, int norm_one, uint32_t seed);

@@ -131,6 +131,14 @@ def packed_scores(packed, x, rows, C_lane=4):
     return y[:rows], present[:rows]
 
 
+def round_to_half(values):
+    """values rounded to IEEE binary16 (nearest even) and back: the value stream of TKSPMV_F16."""
+    v = _f32(values)
+    out = np.empty_like(v)
+    oracle().oracle_round_values_to_half(_p(v, f32p), _p(out, f32p), C.c_uint64(v.shape[0]))
+    return out
+
+
 def sample_vector(size, sum_to_one=False, norm_one=True, seed=1):
     v = np.zeros(size, dtype=np.float32)
     oracle().oracle_sample_vector(_p(v, f32p), C.c_int(size), C.c_int(int(sum_to_one)), C.c_int(int(norm_one)),

@@ -274,6 +274,15 @@ def test_drop_in_executable_csv(pkg, oracle, tmp_path):
         outs.append([ln for ln in r.stdout.split("\n") if ") document " in ln])
     assert len(list(cache.glob("*.tkspmv"))) == 1
     assert outs[0] == outs[1] and len(outs[0]) >= 400  # sw + hw lists of both iterations
+    # -a: the comparator's half-precision mode -> fp16 values; the CSV reports its precision against the fp32 gold
+    r = subprocess.run([exe, "-t", "3", "-m", str(p), "-k", "100", "-r", "-a"], capture_output=True, text=True, env=env,
+                       timeout=300)
+    assert r.returncode == 0, r.stderr
+    for ln in r.stdout.strip().split("\n")[1:]:
+        f = ln.split(",")
+        sw_idx, hw_idx = f[10].split(";"), f[12].split(";")
+        assert len(set(sw_idx) & set(hw_idx)) >= 90
+        assert np.allclose(np.array(f[11].split(";"), float), np.array(f[13].split(";"), float), rtol=5e-3, atol=1e-6)
 
 
 # ---- BASELINE configs[4]: Q1.7 fixed-point values ("FIXED_WIDTH-style" reduced precision) ----------------------------
@@ -433,7 +442,7 @@ def test_native_sharded_step_single_rank(pkg, oracle, monkeypatch, force_nccl):
 
 
 # ---- batches: the selection of query i rides inside the launch of query i+1 (deferred selection) ----------------------
-@pytest.mark.parametrize("precision", ["F32", "Q1_7", "Q1_7_WIDE"])
+@pytest.mark.parametrize("precision", ["F32", "Q1_7", "Q1_7_WIDE", "F16"])
 @pytest.mark.parametrize("defer", ["1", "0"])
 def test_batch_results_equal_single_query_results(pkg, oracle, monkeypatch, precision, defer):
     """tkspmv_enqueue_batch: every query of a batch must return bit for bit what the same query returns alone
@@ -441,11 +450,11 @@ def test_batch_results_equal_single_query_results(pkg, oracle, monkeypatch, prec
     deferred scheme is switched off. Different x per query, so a mixed-up state set or result buffer shows."""
     import torch
     monkeypatch.setenv("TKSPMV_DEFER", defer)
-    cols = 1024 if precision == "F32" else 512
+    cols = 1024 if precision in ("F32", "F16") else 512
     m = pkg.generate_matrix(70000, cols, 20, "gamma", 31)
     nq = 7
     xs = np.stack([pkg.create_sample_vector(cols, True, False, True, 700 + i) for i in range(nq)])
-    if precision != "F32":
+    if precision in ("Q1_7", "Q1_7_WIDE"):
         xs = (xs * np.float32(40.0)).astype(np.float32)  # keep Q1.7 scores away from all-zero
     dxs = torch.from_numpy(xs).cuda()
     eng = pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, k=100, device=0, precision=getattr(pkg, precision),
@@ -609,4 +618,35 @@ def test_three_million_rows(pkg, oracle):
         assert np.array_equal(out_v[q].cpu().numpy(), singles[q][0])
     ns = eng.time_queries(dxs.data_ptr(), 3, 64)
     print(f"3M rows: {ns / 1e3:.1f} us per query, {info['algorithmic_bytes'] / ns:.0f} GB/s algorithmic")
+    eng.close()
+
+
+# ---- TKSPMV_F16: fp16 values, fp32 x and arithmetic (the CUDA comparator's -a mode) -----------------------------------
+@pytest.mark.parametrize("rows,cols,nnz,k,seed", [(3000, 512, 40, 100, 1), (120000, 1024, 20, 100, 2), (20000, 3000, 30, 8, 3)])
+def test_f16_values_bit_exact_against_the_half_model(pkg, oracle, rows, cols, nnz, k, seed):
+    """Bit-exact against the order-matched oracle reading the same 2-byte value stream; and, against the fp32 gold,
+    the ranking quality the reference reports for its half mode: high precision@K, scores within fp16 rounding."""
+    m = pkg.generate_matrix(rows, cols, nnz, "gamma", seed)
+    eng = pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, k=k, device=0, precision=pkg.F16)
+    info = eng.info()
+    assert info["packet_entries"] == 256 and info["packed_bytes"] < 4.1 * m.row.shape[0] + 8 * rows + 70000
+    packed = pkg.Packed(m, k=k, n_wave_partitions=pkg.Packed.wave_partitions(0), precision=pkg.F16)
+    assert packed.info()["n_wave_partitions"] == info["n_wave_partitions"]
+    for q in range(2):
+        x = pkg.create_sample_vector(cols, True, False, True, 50 * seed + q)
+        eng.reset(x)
+        eng()
+        val, idx = eng.read_result()
+        yp, present = oracle.packed_scores(packed.raw(), x, m.rows, 4)
+        ei, ev = oracle.select_topk(yp, present, k)
+        assert np.array_equal(idx, ei), "index list differs from the half-value oracle"
+        assert np.array_equal(val.view(np.uint32), ev.view(np.uint32)), "scores are not bit-identical"
+        assert np.array_equal(eng.scores().view(np.uint32), yp.view(np.uint32))
+        # the same thing said differently: the fp32 gold over values rounded to half
+        gi_h, gv_h = oracle.gold_topk(m.row, m.col, oracle.round_to_half(m.val), x, k)
+        assert len(set(idx.tolist()) & set(gi_h.tolist())) >= k - 1 and np.allclose(val, gv_h, rtol=1e-4, atol=0)
+        gi, gv = oracle.gold_topk(m.row, m.col, m.val, x, k)
+        prec = len(set(idx.tolist()) & set(gi.tolist())) / k
+        assert prec >= 0.9, prec
+        assert np.allclose(val, gv, rtol=2e-3, atol=0)
     eng.close()

@@ -174,7 +174,7 @@ def test_eval_helpers_match_reference(pkg):
 
 
 # ---- packed-matrix cache (.tkspmv files) -----------------------------------------------------------------
-@pytest.mark.parametrize("precision", ["F32", "Q1_7"])
+@pytest.mark.parametrize("precision", ["F32", "Q1_7", "F16"])
 def test_packed_file_round_trip_is_bit_identical(pkg, tmp_path, precision):
     m = pkg.generate_matrix(3000, 512, 20, "gamma", 9)
     p = pkg.Packed(m, k=50, n_wave_partitions=64, precision=getattr(pkg, precision))
@@ -223,3 +223,27 @@ def test_packed_file_rejects_damage(pkg, tmp_path):
     f.write_bytes(bytes(bad))
     with pytest.raises(pkg.TkspmvError):
         pkg.Packed.load(f)
+
+
+def test_half_conversion_is_ieee_round_to_nearest_even(pkg, oracle):
+    """TKSPMV_F16's value stream: the packer's and the oracle's float -> half conversion against numpy.float16 (IEEE
+    binary16, round to nearest even, overflow to infinity), including subnormals, ties and the overflow boundary."""
+    rng = np.random.RandomState(3)
+    special = np.array([0.0, 1.0, 0.5, 1.0 / 3.0, 65504.0, 65519.9, 65520.0, 1e5, 6.1035156e-05, 6.0e-05, 5.9604645e-08,
+                        2.9802322e-08, 2.9802326e-08, 1e-9, 1.0009765625, 1.00048828125, 1.00146484375, 0.99951171875,
+                        2049.0, 2051.0, 4097.0], dtype=np.float32)
+    vals = np.concatenate([special, rng.rand(5000).astype(np.float32), (rng.rand(2000) * 1e-4).astype(np.float32),
+                           (rng.rand(2000) * 7e4).astype(np.float32), (10.0 ** rng.uniform(-9, 5, 3000)).astype(np.float32)])
+    with np.errstate(over="ignore"):
+        want = vals.astype(np.float16).astype(np.float32)
+    got = oracle.round_to_half(vals)
+    finite = np.isfinite(want)
+    assert np.array_equal(np.isfinite(got), finite)
+    assert np.array_equal(got[finite].view(np.uint32), want[finite].view(np.uint32))
+    # the packer writes the same halves: one row per value, decode gives them back
+    n = 3000
+    m = pkg.CooMatrix(n, 8, np.arange(n, dtype=np.uint32), np.zeros(n, dtype=np.uint32), vals[:n].copy())
+    p = pkg.Packed(m, n_wave_partitions=16, precision=pkg.F16)
+    r, c, v = p.decode()
+    assert np.array_equal(r, m.row) and np.array_equal(v.view(np.uint32), want[:n].view(np.uint32))
+    assert p.info()["packed_bytes"] < pkg.Packed(m, n_wave_partitions=16).info()["packed_bytes"]
