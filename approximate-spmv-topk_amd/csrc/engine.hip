@@ -1172,7 +1172,7 @@ struct BatchParams {
     BatchQuery q[BATCH_MAX];
 };
 
-template <int XCOLS>
+template <int XCOLS, int C = 4>
 struct BatchLds {
     union {
         struct {
@@ -1190,8 +1190,8 @@ struct BatchLds {
 #ifndef TKSPMV_DEFER_B
 #define TKSPMV_DEFER_B 2
 #endif
-    static constexpr int DEFER_B = XCOLS <= 1024 ? TKSPMV_DEFER_B : 2;
-    float4 drs[8][DEFER_B][64];
+    static constexpr int DEFER_B = C == 8 ? 1 : (XCOLS <= 1024 ? TKSPMV_DEFER_B : 2);
+    float4 drs[8][DEFER_B][C / 4][64];
     uint32_t dfl[8][DEFER_B][64];
     uint32_t drb[8][DEFER_B];
 };
@@ -1204,9 +1204,9 @@ template <int C, int XCOLS, int QM>
 __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0, const SelectParams SP0, const BatchParams B) {
     constexpr bool Q8 = QM == 1 || QM == 2;  // x staged as Q1.7 integers
     constexpr int VT = value_type_of(QM);
-    constexpr int NBUF = 3;
+    constexpr int NBUF = C == 8 ? 2 : 3;  // packets of 8 entries per lane are twice as large: one ahead is as many bytes
     constexpr uint32_t WAVE_CAP = ListGeom<XCOLS>::WAVE_CAP;
-    __shared__ BatchLds<XCOLS> L;
+    __shared__ BatchLds<XCOLS, C> L;
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
@@ -1467,8 +1467,8 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0, co
     uint32_t *mp = L.misc[0];
     const float *xq = L.u.w.x[0];
     StreamParams P = P0;
-    constexpr uint32_t DEFER_B = (uint32_t)BatchLds<XCOLS>::DEFER_B;
-    static_assert(C == 4, "the batch kernel is built for 4 entries per lane");
+    constexpr uint32_t DEFER_B = (uint32_t)BatchLds<XCOLS, C>::DEFER_B;
+    static_assert(C == 4 || C == 8, "the batch kernel is built for 4 or 8 entries per lane");
 
     const uint32_t total = np * nq;
     for (uint32_t i0 = 0; i0 < total; i0 += NBUF) {
@@ -1495,8 +1495,13 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0, co
             if (trw && first_tau_pkt == 0xFFu && tau > min_units) first_tau_pkt = jc;
             const RowSums<C> R = reduce_packet<C, QM>(cur, carry, xq);
             if (jc < DEFER_B && P0.n_sets != 0u) {
-                L.drs[wave][jc][lane] = make_float4(R.rs[0], R.rs[1], R.rs[2], R.rs[3]);
-                L.dfl[wave][jc][lane] = (R.cw[0] & 0x00030003u) | ((R.cw[1] & 0x00030003u) << 2);
+                uint32_t fl = 0u;
+#pragma unroll
+                for (int h = 0; h < C / 4; ++h) {
+                    L.drs[wave][jc][h][lane] = make_float4(R.rs[4 * h], R.rs[4 * h + 1], R.rs[4 * h + 2], R.rs[4 * h + 3]);
+                    fl |= ((R.cw[2 * h] & 0x00030003u) << (4 * h)) | ((R.cw[2 * h + 1] & 0x00030003u) << (4 * h + 2));
+                }
+                L.dfl[wave][jc][lane] = fl;
                 if (lane == 0) L.drb[wave][jc] = rb_cur;
                 const float wmax = wave_max(lane_best<C, QM>(R));
                 if (lane == 0 && publishes && wmax >= min_units)
@@ -1518,15 +1523,18 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0, co
                     const float tau2 = __uint_as_float(lds_load(&mp[MISC_TAU]));
                     const uint32_t nd = np < DEFER_B ? np : DEFER_B;
                     for (uint32_t d = 0; d < nd; ++d) {
-                        const float4 v = L.drs[wave][d][lane];
                         const uint32_t c = L.dfl[wave][d][lane];
                         RowSums<C> S;
-                        S.rs[0] = v.x;
-                        S.rs[1] = v.y;
-                        S.rs[2] = v.z;
-                        S.rs[3] = v.w;
-                        S.cw[0] = c & 0x00030003u;
-                        S.cw[1] = (c >> 2) & 0x00030003u;
+#pragma unroll
+                        for (int h = 0; h < C / 4; ++h) {
+                            const float4 v = L.drs[wave][d][h][lane];
+                            S.rs[4 * h] = v.x;
+                            S.rs[4 * h + 1] = v.y;
+                            S.rs[4 * h + 2] = v.z;
+                            S.rs[4 * h + 3] = v.w;
+                            S.cw[2 * h] = (c >> (4 * h)) & 0x00030003u;
+                            S.cw[2 * h + 1] = (c >> (4 * h + 2)) & 0x00030003u;
+                        }
                         float best = -__builtin_huge_valf();
 #pragma unroll
                         for (int j = 0; j < C; ++j) best = (S.end(j) && S.rs[j] > best) ? S.rs[j] : best;
@@ -1719,6 +1727,7 @@ struct EngineImpl {
         if (desc.precision == TKSPMV_Q1_7) return &batch_kernel<4, 1024, 1>;
         if (desc.precision == TKSPMV_Q1_7_WIDE) return &batch_kernel<4, 1024, 2>;
         if (desc.precision == TKSPMV_F16) return &batch_kernel<4, 1024, 3>;
+        if (info.packet_entries == 512) return &batch_kernel<8, 1024, 0>;
         return &batch_kernel<4, 1024, 0>;
     }
     // n <= BATCH_MAX queries in one launch of the batch kernel; results complete in stream order after the launch.
@@ -2064,7 +2073,7 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
     if (const char *f = getenv("TKSPMV_FUSED")) m.fused = m.fused && atoi(f) != 0;
     if (const char *f = getenv("TKSPMV_REDUCERS")) m.n_reducers = (uint32_t)atoi(f);
     if (const char *f = getenv("TKSPMV_DEFER")) m.can_defer = m.can_defer && atoi(f) != 0;
-    m.can_batch = m.can_defer && m.n_sets != 0u && m.xcols <= 1024u && C == 4u;  // larger x: two workgroups no longer fit a CU
+    m.can_batch = m.can_defer && m.n_sets != 0u && m.xcols <= 1024u && (C == 4u || (C == 8u && d.precision == TKSPMV_F32));  // larger x: two workgroups no longer fit a CU
     if (const char *f = getenv("TKSPMV_BATCH")) m.can_batch = m.can_batch && atoi(f) != 0;
     HIP_TRY(malloc_exchange((void **)&m.d_tickets, BATCH_MAX * 32 * 4));
     HIP_TRY(hipMemset(m.d_tickets, 0, BATCH_MAX * 32 * 4));
