@@ -1151,25 +1151,39 @@ __global__ void __launch_bounds__(576, 5) stream_kernel(const StreamParams P, co
 // ------------------------------------------------------------------------------------------------------------
 constexpr int BATCH_MAX = 32;
 constexpr uint32_t STG_N = 8;  // survivors a wave can stage per query (64 lanes = 8 waves x 8 when the server copies)
+#ifndef TKSPMV_ALL_SERVERS_PRIO
+#define TKSPMV_ALL_SERVERS_PRIO 0
+#endif
 #ifndef TKSPMV_TAU_WAIT
 #define TKSPMV_TAU_WAIT 3000
 #endif
 constexpr unsigned long long BATCH_TAU_WAIT = TKSPMV_TAU_WAIT;  // x 10 ns (s_memrealtime runs at 100 MHz)
 constexpr int MISC_XREADY = 2, MISC_MINU = 3;  // batch kernel only: x staged for query (value - 1); min score in units
 
-struct BatchQuery {
+// Per query only what differs from query to query travels in the kernel arguments (32 bytes); the exchange-state set of
+// query q is set 0 plus q strides (the sets are allocated as one block per field), so the argument block stays small (64 queries would fit the 4 KiB limit; 32 are used: longer batches measured no faster).
+struct BatchIO {
     const float *x;
     const uint8_t *packets;
-    uint32_t *gmax, *tau_g, *ovf_count;
-    unsigned long long *wg_cand, *ovf_cand, *scratch;
-    float *unit_inv;
     uint32_t *out_idx;
     float *out_val;
 };
 struct BatchParams {
     uint32_t n_q;
     uint32_t *tickets;  // [BATCH_MAX] counters, 32 words apart
-    BatchQuery q[BATCH_MAX];
+    // exchange-state set 0 and the distance (in elements) to the next set
+    uint32_t *gmax0, *tau_g0, *ovf_count0;
+    unsigned long long *wg_cand0, *ovf_cand0, *scratch;
+    float *unit_inv0;
+    uint32_t gmax_stride, word_stride, cand_stride;
+    uint64_t ovf_stride;
+    BatchIO io[BATCH_MAX];
+    __device__ __forceinline__ uint32_t *gmax(uint32_t q) const { return gmax0 + (size_t)q * gmax_stride; }
+    __device__ __forceinline__ uint32_t *tau_g(uint32_t q) const { return tau_g0 + (size_t)q * word_stride; }
+    __device__ __forceinline__ uint32_t *ovf_count(uint32_t q) const { return ovf_count0 + (size_t)q * word_stride; }
+    __device__ __forceinline__ float *unit_inv(uint32_t q) const { return unit_inv0 + (size_t)q * word_stride; }
+    __device__ __forceinline__ unsigned long long *wg_cand(uint32_t q) const { return wg_cand0 + (size_t)q * cand_stride; }
+    __device__ __forceinline__ unsigned long long *ovf_cand(uint32_t q) const { return ovf_cand0 + (size_t)q * ovf_stride; }
 };
 
 template <int XCOLS, int C = 4>
@@ -1229,15 +1243,15 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0, co
             }
             __syncthreads();
             SelectParams S = SP0;
-            S.wg_cand = B.q[q].wg_cand;
-            S.ovf_cand = B.q[q].ovf_cand;
-            S.ovf_count = B.q[q].ovf_count;
-            S.gmax = B.q[q].gmax;
-            S.tau_g = B.q[q].tau_g;
-            S.scratch = B.q[q].scratch;
-            S.unit_inv_in = B.q[q].unit_inv;
-            S.out_idx = B.q[q].out_idx;
-            S.out_val = B.q[q].out_val;
+            S.wg_cand = B.wg_cand(q);
+            S.ovf_cand = B.ovf_cand(q);
+            S.ovf_count = B.ovf_count(q);
+            S.gmax = B.gmax(q);
+            S.tau_g = B.tau_g(q);
+            S.scratch = B.scratch;
+            S.unit_inv_in = B.unit_inv(q);
+            S.out_idx = B.io[q].out_idx;
+            S.out_val = B.io[q].out_val;
             select_body(S, tid, blockDim.x, L.u.sel);
             __syncthreads();
             if (P0.trace && tid == 0 && q < 8u) P0.trace[q] = __builtin_amdgcn_s_memrealtime();
@@ -1268,7 +1282,11 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0, co
         // ---- server wave: x staging, threshold exchange of the newest query, finalisation of the oldest -------
         // The reducers' search must not starve: in a batch the streaming waves (priority 2) never pause, and a reducer at
         // the default priority got ONE pass per query (traced), i.e. the threshold arrived when the query was over.
+#if TKSPMV_ALL_SERVERS_PRIO
+        __builtin_amdgcn_s_setprio(3);
+#else
         if (reducer) __builtin_amdgcn_s_setprio(3);
+#endif
         uint32_t staged = 0u, tail = 0u;
         float inv_unit_q[2] = {1.0f, 1.0f}, min_units_q[2] = {0.0f, 0.0f};
         unsigned long long dbg_first_duty = 0ull;
@@ -1276,7 +1294,7 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0, co
         for (;;) {
             if (staged < nq && staged - tail < 2u) {
                 const uint32_t par = staged & 1u;
-                const float *xg = B.q[staged].x;
+                const float *xg = B.io[staged].x;
                 float x_scale = 1.0f, unit_scale = 1.0f;
                 if (QM == 2) {
                     float lm = 0.0f;
@@ -1346,8 +1364,8 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0, co
                 {
                     const uint32_t sq = hq;
                     StreamParams P = P0;
-                    P.gmax = B.q[sq].gmax;
-                    P.tau_g = B.q[sq].tau_g;
+                    P.gmax = B.gmax(sq);
+                    P.tau_g = B.tau_g(sq);
                     uint32_t *mp = L.misc[sq & 1u];
                     const float min_units = min_units_q[sq & 1u];
                     publish_group_max(P, bid, lane, mp);
@@ -1381,7 +1399,7 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0, co
                 if (tail < staged && __builtin_amdgcn_readfirstlane(lds_load(&mp[MISC_DONE])) >= n_active) {
                     asm volatile("" ::: "memory");
                     StreamParams P = P0;
-                    P.gmax = B.q[tail].gmax;
+                    P.gmax = B.gmax(tail);
                     if (P0.n_sets != 0u) publish_group_max(P, bid, lane, mp);  // complete maxima (fire and forget)
                     if (P0.dbg && lane == 0) {  // TKSPMV_STATS=1
                         atomicAdd(&P0.dbg[0], (unsigned long long)mp[MISC_SLOW_CNT]);
@@ -1397,16 +1415,16 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0, co
                     const uint64_t bm = __ballot(extra);
                     uint32_t gbase = 0u;
                     if (bm) {
-                        if (lane == 0) gbase = atomicAdd(B.q[tail].ovf_count, (uint32_t)__popcll(bm));
+                        if (lane == 0) gbase = atomicAdd(B.ovf_count(tail), (uint32_t)__popcll(bm));
                         gbase = __builtin_amdgcn_readfirstlane(gbase);
                     }
-                    if (have && e == 0u) st_agent(B.q[tail].wg_cand + (size_t)bid * WG_SLOTS + w, v);
+                    if (have && e == 0u) st_agent(B.wg_cand(tail) + (size_t)bid * WG_SLOTS + w, v);
                     if (extra) {
                         const uint32_t gp = gbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
-                        if (gp < P0.ovf_cap) st_agent(&B.q[tail].ovf_cand[gp], v);
+                        if (gp < P0.ovf_cap) st_agent(&B.ovf_cand(tail)[gp], v);
                     }
                     if (bid == 0u && lane == 0)
-                        __hip_atomic_store(B.q[tail].unit_inv, inv_unit_q[tp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(B.unit_inv(tail), inv_unit_q[tp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     // Hand-off as in the fused tail (cdna_hip_programming.md Guideline 16): everything above is a
                     // write-through (sc1) store; drain them, then a RELAXED agent-scope add. A release-ordered atomic
                     // would write back the whole L2 (buffer_wbl2) once per workgroup and query: measured 4 ms/query.
@@ -1442,7 +1460,7 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0, co
     Pkt<C, VT> buf[NBUF];
     uint32_t rbs[NBUF];
     uint32_t qa = 0u, ja = 0u;  // next packet to request: (query, packet of the partition)
-    const uint8_t *pk_a = B.q[0].packets + (size_t)p0 * P0.packet_bytes;  // partition base in the stream copy of query qa
+    const uint8_t *pk_a = B.io[0].packets + (size_t)p0 * P0.packet_bytes;  // partition base in the stream copy of query qa
 #define TKSPMV_REQUEST(dst, rb_dst)                                                                                   \
     do {                                                                                                              \
         load_packet<C, VT>(pk_a + (size_t)ja * P0.packet_bytes, lane, dst);                                           \
@@ -1452,7 +1470,7 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0, co
             if (ja == np) {                                                                                           \
                 ja = 0u;                                                                                              \
                 ++qa;                                                                                                 \
-                pk_a = B.q[qa].packets + (size_t)p0 * P0.packet_bytes;                                                \
+                pk_a = B.io[qa].packets + (size_t)p0 * P0.packet_bytes;                                                \
             }                                                                                                         \
         }                                                                                                             \
     } while (0)
@@ -1485,8 +1503,8 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0, co
                 asm volatile("" ::: "memory");
                 min_units = __uint_as_float(lds_load(&mp[MISC_MINU]));
                 if (trw && lane == 0 && TRSLOT(qc) < 3u) trw[1 + TRSLOT(qc)] = __builtin_amdgcn_s_memrealtime();
-                P.ovf_cand = B.q[qc].ovf_cand;
-                P.ovf_count = B.q[qc].ovf_count;
+                P.ovf_cand = B.ovf_cand(qc);
+                P.ovf_count = B.ovf_count(qc);
                 carry = 0.0f;
                 wcnt = 0u;
                 first_tau_pkt = 0xFFu;
@@ -1619,6 +1637,7 @@ struct EngineImpl {
         float *unit_inv = nullptr;
     };
     static constexpr int N_STATE = BATCH_MAX;  // deferred selection uses sets 0/1, the batch kernel one per query
+    static constexpr uint32_t GMAX_WORDS = MAX_GM * 64, STATE_WORD_STRIDE = 64;  // set-to-set distances (elements)
     ExState st[N_STATE];
     mutable int cur_set = 0;                  // set the next deferred launch streams into
     mutable bool pending = false;             // a deferred selection is owed for ...
@@ -1739,18 +1758,21 @@ struct EngineImpl {
         BatchParams B{};
         B.n_q = (uint32_t)n;
         B.tickets = d_tickets;
+        B.gmax0 = st[0].gmax;
+        B.tau_g0 = st[0].tau_g;
+        B.ovf_count0 = st[0].ovf_count;
+        B.wg_cand0 = st[0].wg_cand;
+        B.ovf_cand0 = st[0].ovf;
+        B.scratch = st[0].scratch;
+        B.unit_inv0 = st[0].unit_inv;
+        B.gmax_stride = GMAX_WORDS;
+        B.word_stride = STATE_WORD_STRIDE;
+        B.cand_stride = grid * WG_SLOTS;
+        B.ovf_stride = ovf_cap;
         for (int q = 0; q < n; ++q) {
-            const ExState &E = st[q];
-            BatchQuery &Q = B.q[q];
+            BatchIO &Q = B.io[q];
             Q.x = xs[q];
             Q.packets = d_replicas.empty() ? d_packets : d_replicas[(launch_counter + q) % d_replicas.size()];
-            Q.gmax = E.gmax;
-            Q.tau_g = E.tau_g;
-            Q.ovf_count = E.ovf_count;
-            Q.wg_cand = E.wg_cand;
-            Q.ovf_cand = E.ovf;
-            Q.scratch = E.scratch;
-            Q.unit_inv = E.unit_inv;
             Q.out_idx = out_idx[q];
             Q.out_val = out_val[q];
         }
@@ -1866,8 +1888,9 @@ Engine::~Engine() {
                     m.d_out_idx, m.d_out_val, m.d_scores,     m.d_stats,      m.d_done, m.d_trace, m.d_tickets};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
-    for (auto &E : m.st) {
-        void *eb[] = {E.tau_g, E.gmax, E.ovf_count, E.wg_cand, E.ovf, (&E == &m.st[0]) ? (void *)E.scratch : nullptr, E.unit_inv};
+    {
+        EngineImpl::ExState &E = m.st[0];  // the other sets point into these blocks
+        void *eb[] = {E.tau_g, E.gmax, E.ovf_count, E.wg_cand, E.ovf, E.scratch, E.unit_inv};
         for (void *b : eb)
             if (b) (void)hipFree(b);
     }
@@ -2077,25 +2100,35 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
     if (const char *f = getenv("TKSPMV_BATCH")) m.can_batch = m.can_batch && atoi(f) != 0;
     HIP_TRY(malloc_exchange((void **)&m.d_tickets, BATCH_MAX * 32 * 4));
     HIP_TRY(hipMemset(m.d_tickets, 0, BATCH_MAX * 32 * 4));
-    for (int si = 0; si < EngineImpl::N_STATE; ++si) {
-        EngineImpl::ExState &E = m.st[si];
-        if (si > 0 && !m.can_defer) break;  // further sets only serve deferred selection / the batch kernel
-        if (si > 1 && !m.can_batch) break;
-        HIP_TRY(malloc_exchange((void **)&E.gmax, (size_t)MAX_GM * 64 * 4));
-        HIP_TRY(hipMemset(E.gmax, 0, (size_t)MAX_GM * 64 * 4));
-        HIP_TRY(malloc_exchange((void **)&E.tau_g, 256));
-        HIP_TRY(hipMemset(E.tau_g, 0, 256));
-        HIP_TRY(hipMalloc((void **)&E.ovf_count, 256));
-        HIP_TRY(hipMemset(E.ovf_count, 0, 256));
-        HIP_TRY(hipMalloc((void **)&E.wg_cand, (size_t)m.grid * WG_SLOTS * 8));
-        HIP_TRY(hipMemset(E.wg_cand, 0xFF, (size_t)m.grid * WG_SLOTS * 8));
-        HIP_TRY(hipMalloc((void **)&E.ovf, (size_t)m.ovf_cap * 8));
+    {
+        // Exchange-state sets: one block per field, set s at s strides (the batch kernel addresses them that way).
+        const int n_sets_alloc = m.can_batch ? EngineImpl::N_STATE : (m.can_defer ? 2 : 1);
+        const size_t ns = (size_t)n_sets_alloc;
+        EngineImpl::ExState &E0 = m.st[0];
+        HIP_TRY(malloc_exchange((void **)&E0.gmax, ns * EngineImpl::GMAX_WORDS * 4));
+        HIP_TRY(hipMemset(E0.gmax, 0, ns * EngineImpl::GMAX_WORDS * 4));
+        HIP_TRY(malloc_exchange((void **)&E0.tau_g, ns * EngineImpl::STATE_WORD_STRIDE * 4));
+        HIP_TRY(hipMemset(E0.tau_g, 0, ns * EngineImpl::STATE_WORD_STRIDE * 4));
+        HIP_TRY(hipMalloc((void **)&E0.ovf_count, ns * EngineImpl::STATE_WORD_STRIDE * 4));
+        HIP_TRY(hipMemset(E0.ovf_count, 0, ns * EngineImpl::STATE_WORD_STRIDE * 4));
+        HIP_TRY(hipMalloc((void **)&E0.wg_cand, ns * m.grid * WG_SLOTS * 8));
+        HIP_TRY(hipMemset(E0.wg_cand, 0xFF, ns * m.grid * WG_SLOTS * 8));
+        HIP_TRY(hipMalloc((void **)&E0.ovf, ns * m.ovf_cap * 8));
         // the scratch of the selection's general path is used by one selection at a time: shared by all sets
-        if (si == 0) HIP_TRY(hipMalloc((void **)&E.scratch, ((size_t)m.grid * WG_SLOTS + m.ovf_cap) * 8));
-        else E.scratch = m.st[0].scratch;
-        HIP_TRY(hipMalloc((void **)&E.unit_inv, 256));
-        const float one = 1.0f;
-        HIP_TRY(hipMemcpy(E.unit_inv, &one, 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc((void **)&E0.scratch, ((size_t)m.grid * WG_SLOTS + m.ovf_cap) * 8));
+        HIP_TRY(hipMalloc((void **)&E0.unit_inv, ns * EngineImpl::STATE_WORD_STRIDE * 4));
+        std::vector<float> ones(ns * EngineImpl::STATE_WORD_STRIDE, 1.0f);
+        HIP_TRY(hipMemcpy(E0.unit_inv, ones.data(), ones.size() * 4, hipMemcpyHostToDevice));
+        for (int si = 1; si < n_sets_alloc; ++si) {
+            EngineImpl::ExState &E = m.st[si];
+            E.gmax = E0.gmax + (size_t)si * EngineImpl::GMAX_WORDS;
+            E.tau_g = E0.tau_g + (size_t)si * EngineImpl::STATE_WORD_STRIDE;
+            E.ovf_count = E0.ovf_count + (size_t)si * EngineImpl::STATE_WORD_STRIDE;
+            E.wg_cand = E0.wg_cand + (size_t)si * m.grid * WG_SLOTS;
+            E.ovf = E0.ovf + (size_t)si * m.ovf_cap;
+            E.scratch = E0.scratch;
+            E.unit_inv = E0.unit_inv + (size_t)si * EngineImpl::STATE_WORD_STRIDE;
+        }
     }
     HIP_TRY(hipMemset(m.d_wg_count, 0, (size_t)m.grid * 4));
     HIP_TRY(hipMemset(m.d_stats, 0, 32 * 8));
