@@ -60,7 +60,6 @@ struct StreamParams {
     uint32_t tau_possible;  // 1: at least k publishing groups own rows, so a threshold can form (else nobody waits for one)
     uint32_t n_reducers;  // workgroups [0, n_reducers) reduce gmax -> tau_g; the others only read tau_g
     unsigned long long *wg_cand;  // [grid][WG_SLOTS] packed {score bits | row << 32}; unused slots: row SLOT_INVALID
-    uint32_t cand_cap;
     unsigned long long *ovf_cand;
     uint32_t *ovf_count;
     uint32_t ovf_cap;
@@ -1644,7 +1643,7 @@ struct EngineImpl {
     mutable int pending_set = 0;              // ... this set, into ...
     mutable uint32_t *pending_idx = nullptr;  // ... these result buffers
     mutable float *pending_val = nullptr;
-    uint32_t *d_wg_count = nullptr, *d_out_idx = nullptr;
+    uint32_t *d_out_idx = nullptr;
     uint32_t *d_done = nullptr;
     bool fused = true;
     bool can_defer = false;
@@ -1688,7 +1687,6 @@ struct EngineImpl {
         P.tau_possible = groups_with_rows >= (uint32_t)desc.k ? 1u : 0u;
 
         P.wg_cand = E.wg_cand;
-        P.cand_cap = cand_cap;
         P.ovf_cand = E.ovf;
         P.ovf_count = E.ovf_count;
         P.ovf_cap = ovf_cap;
@@ -1884,7 +1882,7 @@ Engine::~Engine() {
     EngineImpl &m = *impl_;
     (void)hipSetDevice(m.device);
     if (m.stream) (void)hipStreamSynchronize(m.stream);
-    void *bufs[] = {m.d_packets, m.d_pkt_row, m.d_part_first, m.d_part_count, m.d_x,    m.d_wg_count,
+    void *bufs[] = {m.d_packets, m.d_pkt_row, m.d_part_first, m.d_part_count, m.d_x,
                     m.d_out_idx, m.d_out_val, m.d_scores,     m.d_stats,      m.d_done, m.d_trace, m.d_tickets};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
@@ -2080,7 +2078,6 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
     std::vector<uint32_t>().swap(m.pm.pkt_row);
 
     HIP_TRY(hipMalloc((void **)&m.d_x, (size_t)d.cols * 4));
-    HIP_TRY(hipMalloc((void **)&m.d_wg_count, (size_t)m.grid * 4));
     HIP_TRY(hipMalloc((void **)&m.d_out_idx, (size_t)d.k * 4));
     HIP_TRY(hipMalloc((void **)&m.d_out_val, (size_t)d.k * 4));
     HIP_TRY(hipMalloc((void **)&m.d_stats, 32 * 8));
@@ -2130,7 +2127,6 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
             E.unit_inv = E0.unit_inv + (size_t)si * EngineImpl::STATE_WORD_STRIDE;
         }
     }
-    HIP_TRY(hipMemset(m.d_wg_count, 0, (size_t)m.grid * 4));
     HIP_TRY(hipMemset(m.d_stats, 0, 32 * 8));
     m.collect_stamps = getenv("TKSPMV_STAMPS") != nullptr;
     if (getenv("TKSPMV_TRACE")) {
