@@ -650,3 +650,29 @@ def test_f16_values_bit_exact_against_the_half_model(pkg, oracle, rows, cols, nn
         assert prec >= 0.9, prec
         assert np.allclose(val, gv, rtol=2e-3, atol=0)
     eng.close()
+
+
+def test_batch_corner_counts_and_a_long_run(pkg, oracle):
+    """count = 0 and 1, counts around the launch size, and 20 000 queries in one call (625 launches of the batch kernel:
+    tickets, state sets and the replica rotation keep cycling) -- the last result must still be the right one."""
+    import torch
+    m = pkg.generate_matrix(40000, 1024, 20, "gamma", 3)
+    nx = 5
+    xs = np.stack([pkg.create_sample_vector(1024, True, False, True, 600 + i) for i in range(nx)])
+    dxs = torch.from_numpy(xs).cuda()
+    eng = pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, k=50, device=0, stream_replicas=3)
+    single = []
+    for q in range(nx):
+        eng.reset_device(dxs[q].data_ptr())
+        eng()
+        single.append(eng.read_result())
+    eng.enqueue_batch(dxs.data_ptr(), 0)
+    eng.synchronize()
+    for count in (1, 2, 31, 32, 33, 64, 65):
+        eng.enqueue_many(dxs.data_ptr(), nx, count)
+        val, idx = eng.read_result()
+        assert np.array_equal(idx, single[(count - 1) % nx][1]) and np.array_equal(val, single[(count - 1) % nx][0]), count
+    eng.enqueue_many(dxs.data_ptr(), nx, 20000)
+    val, idx = eng.read_result()
+    assert np.array_equal(idx, single[(20000 - 1) % nx][1]) and np.array_equal(val, single[(20000 - 1) % nx][0])
+    eng.close()
