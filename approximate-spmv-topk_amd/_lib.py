@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TKSPMV_LIB") or os.path.join(_HERE, "libtkspmv.so")  # TKSPMV_LIB: tuning builds
 
 OK, ERR_INVALID, ERR_NOT_SORTED, ERR_DEVICE, ERR_NOMEM, ERR_IO, ERR_UNSUPPORTED, ERR_STATE = range(8)
-F32, Q1_7, Q1_7_WIDE, F16 = 0, 1, 2, 3
+F32, Q1_7, Q1_7_WIDE, F16, FIXED = 0, 1, 2, 3, 4
 MAX_COLS = 16384
 MAX_K = 1024
 
@@ -28,7 +28,7 @@ class Desc(C.Structure):
         ("k", C.c_int32), ("partitions", C.c_int32), ("k_per_partition", C.c_int32), ("precision", C.c_int32),
         ("device", C.c_int32), ("first_row", C.c_uint32), ("min_score", C.c_float),
         ("waves_per_cu", C.c_int32), ("threads_per_wg", C.c_int32), ("nnz_per_lane", C.c_int32),
-        ("stream_replicas", C.c_int32), ("reserved", C.c_int32 * 4),
+        ("stream_replicas", C.c_int32), ("fixed_width", C.c_int32), ("reserved", C.c_int32 * 3),
     ]
 
 
@@ -39,7 +39,7 @@ class Info(C.Structure):
         ("packet_entries", C.c_uint32), ("n_wave_partitions", C.c_uint32), ("packets_per_partition", C.c_uint32),
         ("grid", C.c_uint32), ("block", C.c_uint32), ("n_groups", C.c_uint32), ("lds_bytes", C.c_uint32),
         ("k", C.c_int32), ("partitions", C.c_int32), ("k_per_partition", C.c_int32), ("precision", C.c_int32),
-        ("device", C.c_int32), ("num_cus", C.c_uint32), ("reserved", C.c_uint32 * 7),
+        ("device", C.c_int32), ("num_cus", C.c_uint32), ("fixed_width", C.c_uint32), ("reserved", C.c_uint32 * 6),
     ]
 
     def as_dict(self):

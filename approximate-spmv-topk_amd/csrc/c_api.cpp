@@ -198,8 +198,10 @@ int tkspmv_pack(const tkspmv_desc *d, uint32_t n_wave_partitions_hint, tkspmv_pa
     tkspmv_packed *p = new tkspmv_packed();
     int kind = 0;
     uint32_t C = d->nnz_per_lane > 0 ? (uint32_t)d->nnz_per_lane : 4u;
-    std::string err = pack_wbscsr(d->rows, d->cols, d->nnz, d->row, d->col, d->val, stream_precision(d->precision), C,
-                                  n_wave_partitions_hint ? n_wave_partitions_hint : 4096u, 4, p->pm, kind);
+    const Precision sp = stream_precision(d->precision);
+    std::string err = pack_wbscsr(d->rows, d->cols, d->nnz, d->row, d->col, d->val, sp, C,
+                                  n_wave_partitions_hint ? n_wave_partitions_hint : 4096u, 4, p->pm, kind,
+                                  fixed_width_of(*d));
     if (!err.empty()) {
         delete p;
         return fail(kind == 2 ? TKSPMV_ERR_NOT_SORTED : TKSPMV_ERR_INVALID, err);
@@ -279,7 +281,11 @@ int tkspmv_create_packed(tkspmv_t **out, const tkspmv_packed *p, const tkspmv_de
     d.nnz = p->pm.nnz;
     // desc.precision chooses among the arithmetic modes of the packed value type (only Q1.7 has two)
     if (stream_precision(desc->precision) != p->pm.precision)
-        d.precision = p->pm.precision == Precision::F32 ? TKSPMV_F32 : (p->pm.precision == Precision::F16 ? TKSPMV_F16 : TKSPMV_Q1_7);
+        d.precision = p->pm.precision == Precision::F32
+                          ? TKSPMV_F32
+                          : (p->pm.precision == Precision::F16 ? TKSPMV_F16
+                                                               : (p->pm.precision == Precision::FIXED ? TKSPMV_FIXED : TKSPMV_Q1_7));
+    d.fixed_width = (int32_t)p->pm.fixed_width;  // a property of the packed values
     d.nnz_per_lane = (int32_t)p->pm.C;
     std::string err;
     int status = TKSPMV_OK;

@@ -55,6 +55,7 @@ struct StreamParams {
     uint32_t n_groups_pub;  // groups [0, n_groups_pub) publish maxima (<= 1024)
     uint32_t gpw;           // groups per workgroup
     float min_score;
+    uint32_t fixed_width, fixed_mask;  // TKSPMV_FIXED: bits per value and the mask of the top fixed_width bits
     uint32_t *gmax;  // [MAX_GM*64] order keys of the group maxima (zero beyond n_groups_pub)
     uint32_t *tau_g; // one word: order key of the broadcast threshold (monotone, atomic max)
     uint32_t tau_possible;  // 1: at least k publishing groups own rows, so a threshold can form (else nobody waits for one)
@@ -94,10 +95,11 @@ constexpr uint32_t SLOT_INVALID = 0xFFFFFFFFu;  // row id of an unused slot
 // dword; 2 = C fp16 values packed two to a dword.
 // QM (kernel template parameter): 0 = fp32, 1 = Q1.7 strict (8-bit wrapping sums, the FPGA's real_type), 2 = Q1.7 values
 // with x block-scaled by a power of two per query and exact wide accumulation, 3 = fp16 values, fp32 x, fp32 arithmetic
-// (the CUDA comparator's half mode, -a: host_spmv_topk_csr_gpu.cu:132-136,152-160).
+// (the CUDA comparator's half mode, -a: host_spmv_topk_csr_gpu.cu:132-136,152-160), 4 = fixed point of W bits (the
+// FPGA's real_type for any FIXED_WIDTH): values and x as left-aligned Q1.31 words, integer products and sums.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-constexpr int value_type_of(int QM) { return QM == 3 ? 2 : (QM != 0 ? 1 : 0); }
+constexpr int value_type_of(int QM) { return QM == 3 ? 2 : ((QM == 1 || QM == 2) ? 1 : 0); }  // QM 4: one u32 per value, loaded like fp32
 
 // The packet stream is read once per query: nontemporal loads (a plain read kernel over the same bytes gains 12 %
 // from them when the stream comes from HBM, tools/stream_probe.hip).
@@ -143,6 +145,14 @@ __device__ __forceinline__ void load_packet(const uint8_t *__restrict__ pk, uint
 __device__ __forceinline__ uint32_t to_q1_7_dev(float v) {
     const float s = fminf(fmaxf(v * 128.0f, 0.0f), 255.0f);  // NaN -> 0
     return (uint32_t)s;                                       // truncation
+}
+// Generic width (wbscsr.hpp to_fixed): W bits, 1 integer bit, left-aligned in a u32; truncation, saturation at the top.
+__device__ __forceinline__ uint32_t to_fixed_dev(float v, uint32_t W) {
+    if (!(v > 0.0f)) return 0u;
+    const float s = v * (float)(1u << (W - 1u));
+    const float top = W == 32u ? 4294967296.0f : (float)(1u << W);
+    const uint32_t q = s >= top ? (W == 32u ? 0xFFFFFFFFu : (1u << W) - 1u) : (uint32_t)s;
+    return q << (32u - W);
 }
 __device__ __forceinline__ float q17_wrap(float units) {  // units = exact integer sum held in fp32
     return (float)(((uint32_t)units) & 255u);
@@ -513,12 +523,21 @@ struct RowSums {
 //   vv = clipped Kogge-Stone scan of tail over the 64 lanes (never across a lane that holds a row end)
 //   row sum at the lane's first row end = vv[lane-1] + head, at its later row ends = s_j; carry' = vv[63]
 // The reduction proper, from the C products of a lane (p) and its column words (cwv).
-template <int C>
+// INT: the C "floats" (and the carry) hold u32 fixed-point words; every sum is an integer add (wrapping at 2^32 = 2.0 in
+// Q1.31: the reference's real_type sums wrap the same way), lane movement and masking are bitwise either way. At the end
+// the row sums are converted to fp32 (round to nearest even, what C's (float)u32 does) so that thresholds, candidate
+// lists and the selection see ordinary floats: "score units" of 2^-31.
+template <bool INT>
+__device__ __forceinline__ float add_rn(float a, float b) {
+    if (INT) return __uint_as_float(__float_as_uint(a) + __float_as_uint(b));
+    return __fadd_rn(a, b);
+}
+template <int C, bool INT = false>
 __device__ __forceinline__ RowSums<C> reduce_core(float (&p)[C], const uint32_t (&cwv)[C / 2], float &carry) {
     uint32_t m[C];  // all-ones where entry j ends a row
 #pragma unroll
     for (int j = 0; j < C; ++j) m[j] = (j & 1) ? bit_mask<16>(cwv[j >> 1]) : bit_mask<0>(cwv[j >> 1]);
-    p[0] = __builtin_amdgcn_inverse_ballot_w64(1ull) ? __fadd_rn(p[0], carry) : p[0];  // lane 0 only
+    p[0] = __builtin_amdgcn_inverse_ballot_w64(1ull) ? add_rn<INT>(p[0], carry) : p[0];  // lane 0 only
 
     float s[C];
     uint32_t o[C];  // o_j = m_0 | ... | m_j
@@ -526,7 +545,7 @@ __device__ __forceinline__ RowSums<C> reduce_core(float (&p)[C], const uint32_t 
     o[0] = m[0];
 #pragma unroll
     for (int j = 1; j < C; ++j) {
-        s[j] = __fadd_rn(mask_clear(m[j - 1], s[j - 1]), p[j]);
+        s[j] = add_rn<INT>(mask_clear(m[j - 1], s[j - 1]), p[j]);
         o[j] = o[j - 1] | m[j];
     }
     float head = s[C - 1];
@@ -557,27 +576,31 @@ __device__ __forceinline__ RowSums<C> reduce_core(float (&p)[C], const uint32_t 
     float vv = tail;
     {
         float t;
-        t = __fadd_rn(vv, dpp_zero<DPP_ROW_SHR1, 0xF>(vv));
+        t = add_rn<INT>(vv, dpp_zero<DPP_ROW_SHR1, 0xF>(vv));
         vv = __builtin_amdgcn_inverse_ballot_w64(M1) ? t : vv;
-        t = __fadd_rn(vv, dpp_zero<DPP_ROW_SHR2, 0xF>(vv));
+        t = add_rn<INT>(vv, dpp_zero<DPP_ROW_SHR2, 0xF>(vv));
         vv = __builtin_amdgcn_inverse_ballot_w64(M2) ? t : vv;
-        t = __fadd_rn(vv, dpp_zero<DPP_ROW_SHR4, 0xF>(vv));
+        t = add_rn<INT>(vv, dpp_zero<DPP_ROW_SHR4, 0xF>(vv));
         vv = __builtin_amdgcn_inverse_ballot_w64(M4) ? t : vv;
-        t = __fadd_rn(vv, dpp_zero<DPP_ROW_SHR8, 0xF>(vv));
+        t = add_rn<INT>(vv, dpp_zero<DPP_ROW_SHR8, 0xF>(vv));
         vv = __builtin_amdgcn_inverse_ballot_w64(M8) ? t : vv;
-        t = __fadd_rn(vv, dpp_zero<DPP_ROW_BCAST15, 0xA>(vv));  // lane 15 -> row 1, lane 47 -> row 3
+        t = add_rn<INT>(vv, dpp_zero<DPP_ROW_BCAST15, 0xA>(vv));  // lane 15 -> row 1, lane 47 -> row 3
         vv = __builtin_amdgcn_inverse_ballot_w64(P16) ? t : vv;
-        t = __fadd_rn(vv, dpp_zero<DPP_ROW_BCAST31, 0xC>(vv));  // lane 31 -> rows 2 and 3
+        t = add_rn<INT>(vv, dpp_zero<DPP_ROW_BCAST31, 0xC>(vv));  // lane 31 -> rows 2 and 3
         vv = __builtin_amdgcn_inverse_ballot_w64(P32) ? t : vv;
     }
     const float cin = dpp_zero<DPP_WAVE_SHR1, 0xF>(vv);  // lane l-1's inclusive sum; 0 for lane 0
-    const float S = __fadd_rn(cin, head);
+    const float S = add_rn<INT>(cin, head);
     carry = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, vv), 63));
 
     RowSums<C> out;
     out.rs[0] = S;  // if entry 0 ends a row it is the lane's first row end
 #pragma unroll
     for (int j = 1; j < C; ++j) out.rs[j] = mask_select(o[j - 1], s[j], S);  // an earlier end in the lane => s_j
+    if (INT) {
+#pragma unroll
+        for (int j = 0; j < C; ++j) out.rs[j] = (float)__float_as_uint(out.rs[j]);  // fixed-point word -> score units
+    }
 #pragma unroll
     for (int j = 0; j < C / 2; ++j) out.cw[j] = cwv[j];
     const float NEG_INF = -__builtin_huge_valf();
@@ -593,7 +616,8 @@ __device__ __forceinline__ RowSums<C> reduce_core(float (&p)[C], const uint32_t 
 
 // Products from a packet and the x vector staged in LDS, then the reduction.
 template <int C, int QM>
-__device__ __forceinline__ RowSums<C> reduce_packet(const Pkt<C, value_type_of(QM)> &cur, float &carry, const float *x_lds) {
+__device__ __forceinline__ RowSums<C> reduce_packet(const Pkt<C, value_type_of(QM)> &cur, float &carry, const float *x_lds,
+                                                    const uint32_t fixed_mask = 0u) {
     constexpr int VT = value_type_of(QM);
     float p[C];
 #pragma unroll
@@ -612,12 +636,28 @@ __device__ __forceinline__ RowSums<C> reduce_packet(const Pkt<C, value_type_of(Q
             const uint32_t hw = cur.vq[VT == 2 ? (j >> 1) : 0];
             const _Float16 hv = __builtin_bit_cast(_Float16, (uint16_t)((j & 1) ? (hw >> 16) : (hw & 0xFFFFu)));
             p[j] = __fmul_rn((float)hv, xv);  // the conversion is exact
+        } else if (QM == 4) {
+            // both factors are Q1.31 words: the 64-bit product is Q2.62; bits 31..62 are the product in Q1.31 (its integer
+            // part wrapped to one bit, like an assignment to real_type), masked down to the W-1 fraction bits kept
+            const uint32_t xq = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const unsigned char *>(x_lds) + off);
+            const uint32_t vq = __float_as_uint(cur.v[VT == 0 ? j : 0]);
+            if (fixed_mask & 0xFFu) {
+                p[j] = __uint_as_float(__builtin_amdgcn_alignbit(__umulhi(vq, xq), vq * xq, 31) & fixed_mask);
+            } else {
+                // W <= 24: the low 8 bits of every word are zero and x was staged shifted down by 8, so both factors are
+                // 24-bit integers (Q1.23) and the full-rate 24-bit multipliers give the 48-bit product (Q2.46), of which
+                // bits 15..46 are the product in Q1.31 (v_mul_lo/hi_u32 run at quarter rate)
+                uint32_t hi;
+                const uint32_t v24 = vq >> 8;
+                asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(hi) : "v"(v24), "v"(xq));
+                p[j] = __uint_as_float(__builtin_amdgcn_alignbit(hi, __umul24(v24, xq), 15) & fixed_mask);
+            }
         } else {
             const float xv = *reinterpret_cast<const float *>(reinterpret_cast<const unsigned char *>(x_lds) + off);
             p[j] = __fmul_rn(cur.v[VT == 0 ? j : 0], xv);
         }
     }
-    return reduce_core<C>(p, cur.cw, carry);
+    return reduce_core<C, QM == 4>(p, cur.cw, carry);
 }
 
 template <int C, int QM>
@@ -866,6 +906,8 @@ __global__ void __launch_bounds__(576, 5) stream_kernel(const StreamParams P, co
         unit_scale = 128.0f * x_scale;
     } else if (QM == 1) {
         unit_scale = 128.0f;
+    } else if (QM == 4) {
+        unit_scale = 2147483648.0f;  // scores are Q1.31 words converted to fp32
     }
     const float inv_unit = 1.0f / unit_scale;             // exact: unit_scale is a power of two
     const float min_units = P.min_score * unit_scale;
@@ -873,6 +915,8 @@ __global__ void __launch_bounds__(576, 5) stream_kernel(const StreamParams P, co
         const float xv = (i < P.cols) ? P.x[i] : 0.0f;
         if (Q8)
             reinterpret_cast<uint32_t *>(x_lds)[i] = to_q1_7_dev(xv * x_scale);  // x quantised like the matrix values
+        else if (QM == 4)  // W <= 24: as a 24-bit integer (see reduce_packet)
+            reinterpret_cast<uint32_t *>(x_lds)[i] = to_fixed_dev(xv, P.fixed_width) >> (P.fixed_width <= 24u ? 8 : 0);
         else
             x_lds[i] = xv;
     }
@@ -980,7 +1024,7 @@ __global__ void __launch_bounds__(576, 5) stream_kernel(const StreamParams P, co
                 tau = __uint_as_float(
                     __hip_atomic_load(&misc[MISC_TAU], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
 
-            const RowSums<C> R = reduce_packet<C, QM>(cur, carry, x_lds);
+            const RowSums<C> R = reduce_packet<C, QM>(cur, carry, x_lds, P.fixed_mask);
             if (tr && i == 0u) tr2 = __builtin_amdgcn_s_memrealtime() + (__float_as_uint(R.best_any) & 0u);
 
             if (SCORES) {
@@ -1319,6 +1363,8 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0, co
                     unit_scale = 128.0f * x_scale;
                 } else if (QM == 1) {
                     unit_scale = 128.0f;
+                } else if (QM == 4) {
+                    unit_scale = 2147483648.0f;
                 }
                 inv_unit_q[par] = 1.0f / unit_scale;
                 min_units_q[par] = P0.min_score * unit_scale;
@@ -1336,6 +1382,8 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0, co
                         const uint32_t i = b0 + lane + 64u * (uint32_t)u;
                         if (Q8)
                             reinterpret_cast<uint32_t *>(xl)[i] = to_q1_7_dev(r[u] * x_scale);
+                        else if (QM == 4)
+                            reinterpret_cast<uint32_t *>(xl)[i] = to_fixed_dev(r[u], P0.fixed_width) >> (P0.fixed_width <= 24u ? 8 : 0);
                         else
                             xl[i] = r[u];
                     }
@@ -1510,7 +1558,7 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0, co
             }
             const float tau = __uint_as_float(lds_load(&mp[MISC_TAU]));
             if (trw && first_tau_pkt == 0xFFu && tau > min_units) first_tau_pkt = jc;
-            const RowSums<C> R = reduce_packet<C, QM>(cur, carry, xq);
+            const RowSums<C> R = reduce_packet<C, QM>(cur, carry, xq, P0.fixed_mask);
             if (jc < DEFER_B && P0.n_sets != 0u) {
                 uint32_t fl = 0u;
 #pragma unroll
@@ -1681,6 +1729,8 @@ struct EngineImpl {
         P.n_groups_pub = n_groups_pub;
         P.gpw = gpw;
         P.min_score = desc.min_score;  // converted to score units inside the kernel
+        P.fixed_width = pm.fixed_width;
+        P.fixed_mask = pm.fixed_width ? fixed_mask(pm.fixed_width) : 0u;
         P.gmax = E.gmax;
         P.tau_g = E.tau_g;
         P.n_reducers = n_reducers ? n_reducers : (grid < 8u ? grid : 8u);
@@ -1713,7 +1763,8 @@ struct EngineImpl {
         S.ovf_cap = ovf_cap;
         S.k = (uint32_t)desc.k;
         S.first_row = desc.first_row;
-        S.out_scale = desc.precision == TKSPMV_Q1_7 ? (1.0f / 128.0f) : 1.0f;  // fused tail / unit_inv_in override it
+        S.out_scale = desc.precision == TKSPMV_Q1_7 ? (1.0f / 128.0f)
+                                                    : (desc.precision == TKSPMV_FIXED ? (1.0f / 2147483648.0f) : 1.0f);  // fused tail / unit_inv_in override it
         S.unit_inv_in = nullptr;
         S.out_idx = out_idx;
         S.out_val = out_val;
@@ -1744,6 +1795,7 @@ struct EngineImpl {
         if (desc.precision == TKSPMV_Q1_7) return &batch_kernel<4, 1024, 1>;
         if (desc.precision == TKSPMV_Q1_7_WIDE) return &batch_kernel<4, 1024, 2>;
         if (desc.precision == TKSPMV_F16) return &batch_kernel<4, 1024, 3>;
+        if (desc.precision == TKSPMV_FIXED) return &batch_kernel<4, 1024, 4>;
         if (info.packet_entries == 512) return &batch_kernel<8, 1024, 0>;
         return &batch_kernel<4, 1024, 0>;
     }
@@ -1822,6 +1874,11 @@ struct EngineImpl {
             if (xcols <= 4096) return scores ? &stream_kernel<4, true, 4096, 3> : &stream_kernel<4, false, 4096, 3>;
             return scores ? &stream_kernel<4, true, 16384, 3> : &stream_kernel<4, false, 16384, 3>;
         }
+        if (desc.precision == TKSPMV_FIXED) {
+            if (xcols <= 1024) return scores ? &stream_kernel<4, true, 1024, 4> : &stream_kernel<4, false, 1024, 4>;
+            if (xcols <= 4096) return scores ? &stream_kernel<4, true, 4096, 4> : &stream_kernel<4, false, 4096, 4>;
+            return scores ? &stream_kernel<4, true, 16384, 4> : &stream_kernel<4, false, 16384, 4>;
+        }
         if (desc.precision == TKSPMV_Q1_7_WIDE) {
             if (xcols <= 1024) return scores ? &stream_kernel<4, true, 1024, 2> : &stream_kernel<4, false, 1024, 2>;
             if (xcols <= 4096) return scores ? &stream_kernel<4, true, 4096, 2> : &stream_kernel<4, false, 4096, 2>;
@@ -1869,6 +1926,7 @@ void fill_info(const PackedMatrix &pm, int k, tkspmv_info *out) {
     out->packets_per_partition = pm.packets_per_partition;
     out->k = k;
     out->precision = (int32_t)pm.precision;
+    out->fixed_width = pm.fixed_width;
 }
 
 int device_count() {
@@ -1922,8 +1980,12 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
         return TKSPMV_ERR_INVALID;
     }
     if (d.precision != TKSPMV_F32 && d.precision != TKSPMV_Q1_7 && d.precision != TKSPMV_Q1_7_WIDE &&
-        d.precision != TKSPMV_F16) {
+        d.precision != TKSPMV_F16 && d.precision != TKSPMV_FIXED) {
         err = "unknown precision";
+        return TKSPMV_ERR_INVALID;
+    }
+    if (d.precision == TKSPMV_FIXED ? (d.fixed_width != 0 && (d.fixed_width < 8 || d.fixed_width > 32)) : d.fixed_width != 0) {
+        err = "fixed_width must be 0 (= 32) or in [8, 32] for TKSPMV_FIXED, and 0 for every other precision";
         return TKSPMV_ERR_INVALID;
     }
     if (d.precision != TKSPMV_F32 && d.nnz_per_lane == 8) {
@@ -1986,7 +2048,7 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
         // more partitions than this launch geometry has streaming waves (the batch kernel gives every wave one).
         const PackedMatrix &q = *prepacked;
         if (q.rows != d.rows || q.cols != d.cols || q.precision != stream_precision(d.precision) ||
-            q.C != C) {
+            q.C != C || q.fixed_width != fixed_width_of(d)) {
             err = "the packed matrix does not match the descriptor (rows, cols, precision or entries per lane)";
             return TKSPMV_ERR_INVALID;
         }
@@ -2004,7 +2066,7 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
     } else {
         std::string perr = pack_wbscsr(d.rows, d.cols, d.nnz, d.row, d.col, d.val,
                                        stream_precision(d.precision), C, n_stream_waves, 4,
-                                       m.pm, kind);
+                                       m.pm, kind, fixed_width_of(d));
         if (!perr.empty()) {
             err = perr;
             return kind == 2 ? TKSPMV_ERR_NOT_SORTED : TKSPMV_ERR_INVALID;

@@ -51,6 +51,12 @@ class Engine {
 void fill_info(const PackedMatrix &pm, int k, tkspmv_info *out);
 uint64_t algorithmic_bytes(uint64_t nnz, uint32_t rows, uint32_t cols, uint32_t value_bytes, int k);
 int device_count();
+// Bits per value of a descriptor: desc.fixed_width for TKSPMV_FIXED (0 => 32, the reference's default FIXED_WIDTH), 0 for
+// every other precision (where a non-zero fixed_width is rejected by the packer).
+inline uint32_t fixed_width_of(const tkspmv_desc &d) {
+    if (d.precision != TKSPMV_FIXED) return (uint32_t)d.fixed_width;
+    return d.fixed_width == 0 ? 32u : (uint32_t)d.fixed_width;
+}
 // Wave partitions tkspmv_create would cut the matrix into on desc.device (= streaming waves of its launch geometry).
 int wave_partitions_for(const tkspmv_desc &desc, uint32_t *out, std::string &err);
 

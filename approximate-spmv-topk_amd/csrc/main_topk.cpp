@@ -39,7 +39,7 @@ struct SpMV {
     // larger launch geometry) the engine is built from the COO instead. cache_path non-empty and no usable packed
     // matrix: the matrix is packed here and written there for the next run.
     SpMV(const CooMatrix &m, uint32_t rows, uint32_t cols, float *vec, int k_, int debug, const tkspmv_packed *packed = nullptr,
-         const std::string &cache_path = std::string(), int precision = TKSPMV_F32) : k(k_) {
+         const std::string &cache_path = std::string(), int precision = TKSPMV_F32, int fixed_width = 0) : k(k_) {
         tkspmv_desc d{};
         d.rows = rows;
         d.cols = cols;
@@ -49,6 +49,7 @@ struct SpMV {
         d.val = m.val.data();
         d.k = k_;
         d.precision = precision;
+        d.fixed_width = fixed_width;
         d.device = -1;
         d.min_score = 0.0f;
         bool have = false;
@@ -136,7 +137,18 @@ int main(int argc, char *argv[]) {
         return 1;
     }
     // -a: the CUDA comparator's half mode (values stored as fp16, host_spmv_topk_csr_gpu.cu:132-136) -> TKSPMV_F16
-    const int precision = options.use_half_precision_gpu ? TKSPMV_F16 : TKSPMV_F32;
+    int precision = options.use_half_precision_gpu ? TKSPMV_F16 : TKSPMV_F32;
+    // TKSPMV_FIXED_WIDTH=W: the FPGA builds' fixed-point real_type (the reference fixes FIXED_WIDTH at compile time,
+    // types.hpp:20; its driver lists 20/21/25/26/32-bit bitstreams, test_spmv_topk.py:42-47) -> TKSPMV_FIXED
+    int fixed_width = 0;
+    if (const char *fw = getenv("TKSPMV_FIXED_WIDTH")) {
+        fixed_width = atoi(fw);
+        if (fixed_width < 8 || fixed_width > 32) {
+            std::cerr << "TKSPMV_FIXED_WIDTH must be in [8, 32]" << std::endl;
+            return 1;
+        }
+        precision = TKSPMV_FIXED;
+    }
 
     int index_base = -1;
     if (const char *ib = getenv("TKSPMV_INDEX_BASE")) {
@@ -160,7 +172,7 @@ int main(int argc, char *argv[]) {
             const size_t slash = path.find_last_of('/');
             cache_path = std::string(dir) + "/" + (slash == std::string::npos ? path : path.substr(slash + 1)) + "." +
                          std::to_string((long long)sb.st_size) + (options.ignore_matrix_values ? ".v" : "") + (options.use_half_precision_gpu ? ".h" : "") +
-                         (index_base >= 0 ? ".b" + std::to_string(index_base) : "") + ".tkspmv";
+                         (fixed_width ? ".w" + std::to_string(fixed_width) : "") + (index_base >= 0 ? ".b" + std::to_string(index_base) : "") + ".tkspmv";
             if (tkspmv_packed_load(cache_path.c_str(), &cached) != TKSPMV_OK) cached = nullptr;
         }
     }
@@ -217,7 +229,7 @@ int main(int argc, char *argv[]) {
     }
 
     auto start_4 = clock_type::now();
-    SpMV spmv(coo, rows, cols, vec.data(), top_k_value, debug, cached, cached ? std::string() : cache_path, precision);
+    SpMV spmv(coo, rows, cols, vec.data(), top_k_value, debug, cached, cached ? std::string() : cache_path, precision, fixed_width);
     if (cached) tkspmv_packed_free(cached);
     auto gpu_setup_time = chrono::duration_cast<chrono::milliseconds>(clock_type::now() - start_4).count();
     if (debug) std::cout << "gpu setup time=" << gpu_setup_time << " ms" << std::endl;

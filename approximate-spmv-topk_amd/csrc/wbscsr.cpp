@@ -36,9 +36,11 @@ uint32_t fill_partitions(const std::vector<uint32_t> &len, uint64_t cap, std::ve
 
 std::string pack_wbscsr(uint32_t rows, uint32_t cols, uint64_t nnz, const uint32_t *row, const uint32_t *col,
                         const float *val, Precision precision, uint32_t C, uint32_t n_partitions_hint,
-                        uint32_t min_packets_per_partition, PackedMatrix &out, int &kind) {
+                        uint32_t min_packets_per_partition, PackedMatrix &out, int &kind, uint32_t fixed_width) {
     kind = 1;
     if (C != 4 && C != 8) return "nnz_per_lane must be 4 or 8";
+    if (precision == Precision::FIXED ? (fixed_width < 8 || fixed_width > 32) : fixed_width != 0)
+        return "fixed_width must be in [8, 32] for fixed-point values (and 0 otherwise)";
     if (cols == 0 || cols > MAX_COLS) return "cols must be in [1, 16384]";
     if (nnz > 0 && (!row || !col)) return "row/col arrays are NULL";
     if (n_partitions_hint == 0) n_partitions_hint = 1;
@@ -49,6 +51,7 @@ std::string pack_wbscsr(uint32_t rows, uint32_t cols, uint64_t nnz, const uint32
     out.cols = cols;
     out.nnz = nnz;
     out.precision = precision;
+    out.fixed_width = fixed_width;
     out.C = C;
     out.packet_entries = WAVE * C;
     out.packet_bytes = out.packet_entries * (value_bytes(precision) + 2);
@@ -156,6 +159,9 @@ std::string pack_wbscsr(uint32_t rows, uint32_t cols, uint64_t nnz, const uint32
                 } else if (precision == Precision::F16) {
                     const uint16_t hv = to_half(v);
                     std::memcpy(pkt + (size_t)slot * 2, &hv, 2);
+                } else if (precision == Precision::FIXED) {
+                    const uint32_t q = to_fixed(v, fixed_width);
+                    std::memcpy(pkt + (size_t)slot * 4, &q, 4);
                 } else {
                     pkt[slot] = to_q1_7(v);
                 }
@@ -190,6 +196,10 @@ void decode_wbscsr(const PackedMatrix &pm, std::vector<uint32_t> &row, std::vect
                     uint16_t hv;
                     std::memcpy(&hv, pkt + (size_t)s * 2, 2);
                     v = from_half(hv);
+                } else if (pm.precision == Precision::FIXED) {
+                    uint32_t q;
+                    std::memcpy(&q, pkt + (size_t)s * 4, 4);
+                    v = from_fixed(q);
                 } else {
                     v = from_q1_7(pkt[s]);
                 }
@@ -215,7 +225,8 @@ struct FileHeader {  // 128 bytes, little endian (the only byte order this code 
     uint32_t rows, cols;
     uint64_t nnz, packed_entries, placeholders;
     uint64_t payload_bytes, checksum;  // FNV-1a 64 over the payload
-    uint8_t pad[128 - 8 - 10 * 4 - 5 * 8];
+    uint32_t fixed_width;              // Precision::FIXED only (0 otherwise; files written before it existed read as 0)
+    uint8_t pad[128 - 8 - 11 * 4 - 5 * 8];
 };
 static_assert(sizeof(FileHeader) == 128, "header layout");
 const char MAGIC[8] = {'T', 'K', 'S', 'P', 'M', 'V', '1', '\0'};
@@ -253,6 +264,7 @@ std::string save_packed(const PackedMatrix &pm, const char *path) {
     std::memcpy(hd.magic, MAGIC, 8);
     hd.version = 1;
     hd.precision = (uint32_t)pm.precision;
+    hd.fixed_width = pm.fixed_width;
     hd.C = pm.C;
     hd.packet_entries = pm.packet_entries;
     hd.packet_bytes = pm.packet_bytes;
@@ -298,7 +310,8 @@ std::string load_packed(const char *path, PackedMatrix &pm) {
     if (std::memcmp(hd.magic, MAGIC, 8) != 0) return fail("not a .tkspmv file (bad magic)");
     if (hd.version != 1) return fail("unsupported .tkspmv version");
     if ((hd.precision != (uint32_t)Precision::F32 && hd.precision != (uint32_t)Precision::Q1_7 &&
-         hd.precision != (uint32_t)Precision::F16) ||
+         hd.precision != (uint32_t)Precision::F16 && hd.precision != (uint32_t)Precision::FIXED) ||
+        (hd.precision == (uint32_t)Precision::FIXED ? (hd.fixed_width < 8 || hd.fixed_width > 32) : hd.fixed_width != 0) ||
         (hd.C != 4 && hd.C != 8) ||
         hd.packet_entries != 64 * hd.C ||
         hd.packet_bytes != hd.packet_entries * (value_bytes((Precision)hd.precision) + 2) ||
@@ -311,6 +324,7 @@ std::string load_packed(const char *path, PackedMatrix &pm) {
     out.cols = hd.cols;
     out.nnz = hd.nnz;
     out.precision = (Precision)hd.precision;
+    out.fixed_width = hd.fixed_width;
     out.C = hd.C;
     out.packet_entries = hd.packet_entries;
     out.packet_bytes = hd.packet_bytes;

@@ -7,7 +7,8 @@
 //   * a PACKET holds PE = 64 * C consecutive entries of the row-sorted matrix (C = entries per lane, 4 or 8);
 //     lane l of the wave owns entries [l*C, l*C+C) so every lane loads 16 contiguous bytes of values
 //     (global_load_dwordx4 => 1 KiB per wave instruction) and 8 (C=4) or 16 (C=8) bytes of column words;
-//   * packet bytes: [PE values (fp32, or u8 for Q1.7)] [PE x u16 column words], packets are 128-B aligned;
+//   * packet bytes: [PE values (fp32, fp16, u8 for Q1.7, or u32 for generic fixed point)] [PE x u16 column words],
+//     packets are 128-B aligned;
 //   * a column word is  bit0 = ROW_END (this entry is the last of its row; the reference stores 4-bit
 //     cumulative row-end offsets + the xf bit instead), bit1 = SKIP (placeholder entry of an empty row:
 //     keeps row counting implicit, never becomes a candidate), bits 15..2 = column (reference: 10 bits),
@@ -40,12 +41,16 @@ inline uint32_t slot_to_index(uint32_t s, uint32_t C) {
     return (j >> 2) * (WAVE * 4) + lane * 4 + (j & 3);
 }
 
-enum class Precision : int32_t { F32 = 0, Q1_7 = 1, F16 = 3 };  // value type in the packet stream
+// value type in the packet stream; FIXED = unsigned fixed point of `fixed_width` bits (1 integer bit), one u32 per value
+enum class Precision : int32_t { F32 = 0, Q1_7 = 1, F16 = 3, FIXED = 4 };
 
-inline uint32_t value_bytes(Precision p) { return p == Precision::F32 ? 4u : (p == Precision::F16 ? 2u : 1u); }
+inline uint32_t value_bytes(Precision p) {
+    return (p == Precision::F32 || p == Precision::FIXED) ? 4u : (p == Precision::F16 ? 2u : 1u);
+}
 // Value type of the stream for a tkspmv_precision (TKSPMV_Q1_7 and TKSPMV_Q1_7_WIDE share the Q1.7 stream).
 inline Precision stream_precision(int32_t api_precision) {
-    return api_precision == 0 ? Precision::F32 : (api_precision == 3 ? Precision::F16 : Precision::Q1_7);
+    return api_precision == 0 ? Precision::F32
+                              : (api_precision == 3 ? Precision::F16 : (api_precision == 4 ? Precision::FIXED : Precision::Q1_7));
 }
 
 // IEEE binary16 <-> binary32, round to nearest even, overflow to infinity (the CUDA comparator's half mode converts
@@ -104,10 +109,26 @@ inline uint8_t to_q1_7(float v) {
 }
 inline float from_q1_7(uint32_t q) { return (float)q * (1.0f / 128.0f); }
 
+// Unsigned fixed point of W bits with 1 integer bit (restating ap_ufixed<W,1,AP_TRN_ZERO>, fpga_types.hpp:20, for the
+// reference's FIXED_WIDTH builds: 20/21/25/26/32 bits, types.hpp:20, test_spmv_topk.py:42-47), kept LEFT-ALIGNED in a
+// u32: bit 31 is the integer bit, the W-1 fraction bits follow, the low 32-W bits are zero (so every width shares one
+// Q1.31 arithmetic: products are masked back to W bits, sums wrap at 2.0 by the u32 wrap). Truncation toward zero;
+// conversion from float saturates at the top of the range (the HLS type would wrap; inputs are expected in [0, 2)).
+inline uint32_t fixed_mask(uint32_t W) { return ~((1u << (32u - W)) - 1u); }  // the top W bits
+inline uint32_t to_fixed(float v, uint32_t W) {
+    if (!(v > 0.0f)) return 0u;                       // negative, zero, NaN
+    const float s = v * (float)(1u << (W - 1u));      // exact (power of two)
+    const float top = W == 32u ? 4294967296.0f : (float)(1u << W);
+    const uint32_t q = s >= top ? (W == 32u ? 0xFFFFFFFFu : (1u << W) - 1u) : (uint32_t)s;  // truncation
+    return q << (32u - W);
+}
+inline float from_fixed(uint32_t q) { return (float)q * (1.0f / 2147483648.0f); }
+
 struct PackedMatrix {
     uint32_t rows = 0, cols = 0;
     uint64_t nnz = 0;
     Precision precision = Precision::F32;
+    uint32_t fixed_width = 0;     // Precision::FIXED: bits per value (8..32); 0 otherwise
     uint32_t C = 4;               // entries per lane
     uint32_t packet_entries = 0;  // 64*C
     uint32_t packet_bytes = 0;    // packet_entries*(value_bytes+2)
@@ -130,9 +151,9 @@ struct PackedMatrix {
 // kind: 0 ok, 1 invalid, 2 not sorted.
 std::string pack_wbscsr(uint32_t rows, uint32_t cols, uint64_t nnz, const uint32_t *row, const uint32_t *col,
                         const float *val, Precision precision, uint32_t C, uint32_t n_partitions_hint,
-                        uint32_t min_packets_per_partition, PackedMatrix &out, int &kind);
+                        uint32_t min_packets_per_partition, PackedMatrix &out, int &kind, uint32_t fixed_width = 0);
 
-// Inverse of pack (placeholders and padding dropped). Values come back as float (Q1.7 decoded).
+// Inverse of pack (placeholders and padding dropped). Values come back as float (fp16 / fixed point decoded).
 void decode_wbscsr(const PackedMatrix &pm, std::vector<uint32_t> &row, std::vector<uint32_t> &col,
                    std::vector<float> &val);
 

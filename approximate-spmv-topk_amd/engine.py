@@ -18,9 +18,10 @@ from . import _lib
 class SpMV:
     def __init__(self, x, y, val, num_rows, num_cols, num_nnz=None, vec=None, k=20, debug=0, *, device=-1,
                  first_row=0, min_score=0.0, partitions=1, k_per_partition=0, precision=_lib.F32, waves_per_cu=0,
-                 threads_per_wg=0, nnz_per_lane=0, stream_replicas=0):
+                 threads_per_wg=0, nnz_per_lane=0, stream_replicas=0, fixed_width=0):
         """x, y, val: row-sorted COO (row ids, column ids, values) as the FPGA host passes them
-        (host_spmv_bscsr.cpp:585); val=None means all ones (-v)."""
+        (host_spmv_bscsr.cpp:585); val=None means all ones (-v). precision=FIXED: the FPGA's fixed-point real_type of
+        `fixed_width` bits (8..32; 0 = 32, the reference's FIXED_WIDTH default, types.hpp:20)."""
         self._h = C.c_void_p()
         row = np.ascontiguousarray(x, dtype=np.uint32)
         col = np.ascontiguousarray(y, dtype=np.uint32)
@@ -35,6 +36,7 @@ class SpMV:
         d.device, d.first_row, d.min_score = int(device), int(first_row), float(min_score)
         d.waves_per_cu, d.threads_per_wg, d.nnz_per_lane = int(waves_per_cu), int(threads_per_wg), int(nnz_per_lane)
         d.stream_replicas = int(stream_replicas)
+        d.fixed_width = int(fixed_width)
         _lib.check(_lib.lib().tkspmv_create(C.byref(self._h), C.byref(d)))
         self.k = int(k)
         self.num_rows, self.num_cols, self.num_nnz = int(num_rows), int(num_cols), nnz
@@ -46,7 +48,7 @@ class SpMV:
     def from_packed(cls, packed, k=20, debug=0, *, vec=None, device=-1, first_row=0, min_score=0.0, precision=None,
                     stream_replicas=0):
         """Engine straight from a packed matrix (host.Packed, e.g. Packed.load("matrix.tkspmv")): no MatrixMarket
-        parsing, no packing. precision: None = the packed value type (F32 / Q1_7), or Q1_7_WIDE for Q1.7 values."""
+        parsing, no packing. precision: None = the packed value type (F32 / Q1_7 / F16 / FIXED), or Q1_7_WIDE for Q1.7 values."""
         self = cls.__new__(cls)
         self._h = C.c_void_p()
         info = packed.info()

@@ -101,9 +101,10 @@ def matrix_name(rows, cols, nnz, dist):
     return f"matrix_{rows}_{cols}_{nnz}_{dist}.mtx"
 
 
-def result_name(rows, cols, dist, nnz, k, niter, tag="mi355x"):
-    """Result file name in the reference's pattern (test_spmv_topk.py:73,80): {t}_{s}_{c}_{d}_{n}_..._{K}_{NITER}.csv"""
-    return f"{tag}_{rows}_{cols}_{dist}_{nnz}_f32_{k}_{niter}.csv"
+def result_name(rows, cols, dist, nnz, k, niter, tag="mi355x", bits="f32"):
+    """Result file name in the reference's pattern (test_spmv_topk.py:73,80): {t}_{s}_{c}_{d}_{n}_{bits}_..._{K}_{NITER}.csv;
+    bits = "f32", "f16" or e.g. "20b" for a fixed-point width, where the reference writes its FPGA build's bit width."""
+    return f"{tag}_{rows}_{cols}_{dist}_{nnz}_{bits}_{k}_{niter}.csv"
 
 
 def default_exe():

@@ -108,7 +108,7 @@ class Options:
 class Packed:
     """Host-side packed (wave-BSCSR) matrix, for layout tests: decode(pack(A)) == A."""
 
-    def __init__(self, m, k=100, nnz_per_lane=4, n_wave_partitions=4096, precision=_lib.F32):
+    def __init__(self, m, k=100, nnz_per_lane=4, n_wave_partitions=4096, precision=_lib.F32, fixed_width=0):
         self._h = C.c_void_p()
         self._row = np.ascontiguousarray(m.row, dtype=np.uint32)
         self._col = np.ascontiguousarray(m.col, dtype=np.uint32)
@@ -118,7 +118,7 @@ class Packed:
         d.row = self._row.ctypes.data_as(C.POINTER(C.c_uint32))
         d.col = self._col.ctypes.data_as(C.POINTER(C.c_uint32))
         d.val = self._val.ctypes.data_as(C.POINTER(C.c_float))
-        d.k, d.precision, d.nnz_per_lane = k, precision, nnz_per_lane
+        d.k, d.precision, d.nnz_per_lane, d.fixed_width = k, precision, nnz_per_lane, fixed_width
         _lib.check(_lib.lib().tkspmv_pack(C.byref(d), n_wave_partitions, C.byref(self._h)))
         self.nnz = int(d.nnz)
 

@@ -59,8 +59,14 @@ typedef enum {
                         (the FPGA's ap_ufixed<FIXED_WIDTH,1> real_type with FIXED_WIDTH = 8), see DESIGN.md */
     TKSPMV_Q1_7_WIDE = 2, /* Q1.7 values and products, x block-scaled by a power of two per query, exact (non-wrapping)
                              accumulation: the same 3 B/nnz stream with usable ranking quality */
-    TKSPMV_F16 = 3        /* fp16 values (round to nearest even), fp32 x, fp32 products and sums: 4 B/nnz. The CUDA
+    TKSPMV_F16 = 3,       /* fp16 values (round to nearest even), fp32 x, fp32 products and sums: 4 B/nnz. The CUDA
                              comparator's half mode (-a, host_spmv_topk_csr_gpu.cu:132-136,152-160) */
+    TKSPMV_FIXED = 4      /* the FPGA's real_type for any FIXED_WIDTH (types.hpp:20; builds tested by the reference:
+                             20/21/25/26/32 bits, test_spmv_topk.py:42-47): ap_ufixed<W,1,AP_TRN_ZERO> with
+                             W = desc.fixed_width in [8, 32] -- values, x, every product and every partial sum truncated
+                             to W-1 fraction bits, sums wrap at 2.0 (fpga_types.hpp:20,
+                             spmv_bscsr_top_k_multicore.hpp:121-141). Values travel as one u32 each (6 B/nnz); ranking and
+                             output use the fixed-point score converted to fp32. W = 8 reproduces TKSPMV_Q1_7. */
 } tkspmv_precision;
 
 typedef struct tkspmv_engine tkspmv_t;
@@ -87,7 +93,9 @@ typedef struct {
     int32_t nnz_per_lane;     /* 4 or 8 entries per lane per packet */
     int32_t stream_replicas;  /* measurement aid: keep R copies of the packet stream in HBM and rotate them per query so
                                  that consecutive queries cannot be served from the 256 MiB Infinity Cache; 0/1 = off */
-    int32_t reserved[4];
+    int32_t fixed_width;      /* TKSPMV_FIXED: bits per value, 8..32 (0 => 32, the reference's default FIXED_WIDTH,
+                                 types.hpp:20); must be 0 for the other precisions */
+    int32_t reserved[3];
 } tkspmv_desc;
 
 typedef struct {
@@ -105,7 +113,8 @@ typedef struct {
     uint32_t lds_bytes;
     int32_t k, partitions, k_per_partition, precision, device;
     uint32_t num_cus;
-    uint32_t reserved[7];
+    uint32_t fixed_width;         /* TKSPMV_FIXED: bits per value; 0 otherwise */
+    uint32_t reserved[6];
 } tkspmv_info;
 
 typedef struct {

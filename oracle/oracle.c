@@ -152,6 +152,38 @@ void oracle_q17_scores(const uint32_t *row, const uint32_t *col, const float *va
     }
 }
 
+/* Generic width W (see oracle.h): plain W-bit integers (right-aligned), 64-bit products. */
+static inline uint64_t to_fixed_w(float v, uint32_t W) {
+    if (!(v > 0.0f)) return 0;
+    const double d = (double)v * (double)(1ull << (W - 1)); /* exact */
+    const double top = (double)(1ull << W);
+    if (d >= top) return (1ull << W) - 1ull; /* saturation (stated deviation, as for Q1.7) */
+    return (uint64_t)d;                      /* truncation toward zero (AP_TRN_ZERO) */
+}
+int oracle_fixed_scores(const uint32_t *row, const uint32_t *col, const float *val, uint64_t nnz, const float *vec,
+                        uint32_t rows, uint32_t W, float *y, uint8_t *present) {
+    if (W < 8 || W > 32) return -1;
+    memset(y, 0, (size_t)rows * sizeof(float));
+    if (present) memset(present, 0, rows);
+    const uint64_t mask = (1ull << W) - 1ull;
+    const float unit = ldexpf(1.0f, -(int)(W - 1));
+    uint64_t i = 0;
+    while (i < nnz) {
+        uint32_t r = row[i];
+        uint64_t acc = 0;
+        while (i < nnz && row[i] == r) {
+            const uint64_t p = ((to_fixed_w(val[i], W) * to_fixed_w(vec[col[i]], W)) >> (W - 1)) & mask; /* product in real_type */
+            acc = (acc + p) & mask;                                                                       /* sum in real_type */
+            i++;
+        }
+        if (r < rows) {
+            y[r] = (float)(uint32_t)acc * unit; /* u32 -> fp32 rounds to nearest even; the scaling is exact */
+            if (present) present[r] = 1;
+        }
+    }
+    return 0;
+}
+
 int oracle_q17_wide_scores(const uint32_t *row, const uint32_t *col, const float *val, uint64_t nnz, const float *vec,
                            uint32_t cols, uint32_t rows, float *y, uint8_t *present) {
     memset(y, 0, (size_t)rows * sizeof(float));

@@ -43,6 +43,16 @@ void oracle_scores_f64(const uint32_t *row, const uint32_t *col, const float *va
  * parity unpinned; the GPU path is checked bit for bit against THIS integer model. y[r] = wrapped_sum / 128. */
 void oracle_q17_scores(const uint32_t *row, const uint32_t *col, const float *val, uint64_t nnz, const float *vec,
                        uint32_t rows, float *y, uint8_t *present);
+/* The same arithmetic for any FIXED_WIDTH W in [8, 32] (reference default 32, src/common/types.hpp:20; the builds its
+ * driver lists are 20/21/25/26/32 bits, test_spmv_topk.py:42-47): real_type = ap_ufixed<W,1,AP_TRN_ZERO>
+ * (fpga_types.hpp:20): values and x truncated to W-1 fraction bits (saturating, as above), every product truncated to
+ * W-1 fraction bits and wrapped at 2.0 (the assignment to real_type, spmv_bscsr_top_k_multicore.hpp:121-125), sums wrap
+ * at 2.0 (:133-141). y[r] = (float)wrapped_sum * 2^-(W-1): the u32 -> fp32 conversion rounds to nearest even (W > 24
+ * does not fit the mantissa); the engine ranks on these fp32 scores, where the FPGA ranks on the fixed-point words
+ * (they can differ only between scores equal to 24 bits). Parity unpinned like Q1.7. W = 8 reproduces
+ * oracle_q17_scores. Returns 0, or -1 for a W out of range. */
+int oracle_fixed_scores(const uint32_t *row, const uint32_t *col, const float *val, uint64_t nnz, const float *vec,
+                        uint32_t rows, uint32_t W, float *y, uint8_t *present);
 /* TKSPMV_Q1_7_WIDE (this repository's own variant, no reference counterpart): Q1.7 values; x scaled by 2^s, s the
  * largest integer in [0,15] with max(x) * 2^s <= 255/128, then truncated to Q1.7; products truncated to 7 fraction
  * bits WITHOUT wrap; sums exact. y[r] = sum / (128 * 2^s). Returns s. */

@@ -96,6 +96,16 @@ def q17_scores(row, col, val, vec, rows):
     return y[:rows], present[:rows]
 
 
+def fixed_scores(row, col, val, vec, rows, width):
+    row, col, val, vec = _u32(row), _u32(col), _f32(val), _f32(vec)
+    y = np.zeros(max(rows, 1), dtype=np.float32)
+    present = np.zeros(max(rows, 1), dtype=np.uint8)
+    rc = oracle().oracle_fixed_scores(_p(row, u32p), _p(col, u32p), _p(val, f32p), C.c_uint64(row.shape[0]),
+                                      _p(vec, f32p), C.c_uint32(rows), C.c_uint32(width), _p(y, f32p), _p(present, u8p))
+    assert rc == 0, "fixed width out of range"
+    return y[:rows], present[:rows]
+
+
 def q17_wide_scores(row, col, val, vec, rows):
     row, col, val, vec = _u32(row), _u32(col), _f32(val), _f32(vec)
     y = np.zeros(max(rows, 1), dtype=np.float32)

@@ -194,6 +194,68 @@ def test_packed_file_round_trip_is_bit_identical(pkg, tmp_path, precision):
     assert np.array_equal(ra, rb) and np.array_equal(ca, cb) and np.array_equal(va, vb)
 
 
+# ---- generic fixed point (TKSPMV_FIXED: the FPGA's real_type for any FIXED_WIDTH) ---------------------------------------
+@pytest.mark.parametrize("width", [8, 20, 21, 25, 26, 32])
+def test_fixed_point_values_are_truncated_to_the_width(pkg, tmp_path, width):
+    """ap_ufixed<W,1,AP_TRN_ZERO> (fpga_types.hpp:20): W-1 fraction bits, truncation toward zero, values in [0, 2);
+    the packer saturates above the range. decode(pack(A)) gives floor(v * 2^(W-1)) / 2^(W-1); the width survives a
+    .tkspmv round trip."""
+    rng = np.random.RandomState(width)
+    n = 4000
+    vals = np.concatenate([rng.rand(n - 6).astype(np.float32) * np.float32(1.999),
+                           np.array([0.0, 1.0, 1.5, 2.0, 3.7, 1e-9], dtype=np.float32)])
+    m = pkg.CooMatrix(n, 8, np.arange(n, dtype=np.uint32), np.zeros(n, dtype=np.uint32), vals)
+    p = pkg.Packed(m, n_wave_partitions=16, precision=pkg.FIXED, fixed_width=width)
+    info = p.info()
+    assert info["precision"] == pkg.FIXED and info["fixed_width"] == width
+    r, c, v = p.decode()
+    scale = 2.0 ** (width - 1)
+    want = np.minimum(np.floor(vals.astype(np.float64) * scale), 2.0 ** width - 1) / scale
+    assert np.array_equal(r, m.row)
+    assert np.array_equal(v, want.astype(np.float32))  # (u32 -> fp32 rounds to nearest even; so does this cast)
+    path = tmp_path / "f.tkspmv"
+    p.save(path)
+    q = pkg.Packed.load(path)
+    assert q.info()["fixed_width"] == width and q.info()["precision"] == pkg.FIXED
+    assert np.array_equal(q.raw()[0], p.raw()[0])
+
+
+def test_fixed_width_is_validated(pkg):
+    m = pkg.generate_matrix(100, 64, 5, "uniform", 1)
+    for kw in (dict(precision=pkg.FIXED, fixed_width=7), dict(precision=pkg.FIXED, fixed_width=33),
+               dict(precision=pkg.F32, fixed_width=20), dict(precision=pkg.Q1_7, fixed_width=8)):
+        with pytest.raises(pkg.TkspmvError) as ei:
+            pkg.Packed(m, n_wave_partitions=4, **kw)
+        assert ei.value.status == pkg._lib.ERR_INVALID, kw
+
+
+def test_fixed_point_model_known_answers(oracle):
+    """The integer model of real_type on hand-computed cases: exact products, truncation of a product, wrap of a
+    product at 2.0, wrap of a sum at 2.0, saturation of an input -- and width 8 equals the Q1.7 model."""
+    row = np.array([0, 1, 2, 2, 3, 4], dtype=np.uint32)
+    col = np.array([0, 1, 0, 0, 2, 3], dtype=np.uint32)
+    val = np.array([0.5, 1.5, 1.0, 1.0, 0.75, 5.0], dtype=np.float32)
+    x = np.array([1.0, 1.5, 2.0 ** -19, 0.5], dtype=np.float32)
+    y, present = oracle.fixed_scores(row, col, val, x, 5, 20)
+    assert present.tolist() == [1, 1, 1, 1, 1]
+    assert y[0] == 0.5              # 0.5 * 1.0
+    assert y[1] == 0.25             # 1.5 * 1.5 = 2.25 wraps at 2.0
+    assert y[2] == 0.0              # 1.0 + 1.0 wraps at 2.0
+    assert y[3] == 0.0              # 0.75 * 2^-19 = 1.5 * 2^-20 is below one unit of 2^-19... truncated to 0
+    assert y[4] == np.float32((2.0 ** 20 - 1) / 2.0 ** 19 * 0.5 - 2.0 ** -19 * 0.5)  # 5.0 saturates at 2 - 2^-19; product truncated
+    y25, _ = oracle.fixed_scores(row, col, val, x, 5, 25)
+    assert y25[3] == np.float32(0.75 * 2.0 ** -19)  # representable with 24 fraction bits
+    rng = np.random.RandomState(5)
+    n = 20000
+    r = np.sort(rng.randint(0, 900, n)).astype(np.uint32)
+    c = rng.randint(0, 64, n).astype(np.uint32)
+    v = (rng.rand(n) * 2.2).astype(np.float32)
+    xx = (rng.rand(64) * 1.9).astype(np.float32)
+    y8, p8 = oracle.fixed_scores(r, c, v, xx, 900, 8)
+    yq, pq = oracle.q17_scores(r, c, v, xx, 900)
+    assert np.array_equal(y8, yq) and np.array_equal(p8, pq)
+
+
 def test_packed_file_rejects_damage(pkg, tmp_path):
     m = pkg.generate_matrix(500, 64, 8, "uniform", 3)
     p = pkg.Packed(m, n_wave_partitions=8)

@@ -30,6 +30,9 @@ ap.add_argument("--matrix-folder", default=os.path.join(ROOT, "gpurun_out", "mat
 ap.add_argument("--out-folder", default=os.path.join(ROOT, "gpurun_out", "results", time.strftime("%Y_%m_%d_%H_%M_%S")))
 ap.add_argument("--cache", action="store_true", help="keep packed matrices next to the MatrixMarket files (TKSPMV_CACHE_DIR)")
 ap.add_argument("--seed", type=int, default=1)
+ap.add_argument("--bits", nargs="+", default=["f32"],
+                help="value types to run: f32, f16 (the executable's -a) or a fixed-point width such as 20b, 25b, 32b "
+                     "(the reference's FPGA builds, test_spmv_topk.py:42-47; TKSPMV_FIXED_WIDTH)")
 a = ap.parse_args()
 
 mod = _pkg.load()
@@ -41,22 +44,23 @@ os.makedirs(a.out_folder, exist_ok=True)
 env = dict(os.environ, TKSPMV_SEED=str(a.seed))
 if a.cache:
     env["TKSPMV_CACHE_DIR"] = a.matrix_folder
-grid = [(s, c, d, n) for s in a.rows for c in a.cols for d in a.dist for n in a.nnz]
+grid = [(s, c, d, n, b) for s in a.rows for c in a.cols for d in a.dist for n in a.nnz for b in a.bits]
 table = []
-for i, (s, c, d, n) in enumerate(grid):
+for i, (s, c, d, n, bits) in enumerate(grid):
     mtx = os.path.join(a.matrix_folder, ex.matrix_name(s, c, n, d))
     if not os.path.exists(mtx):
-        mod.write_mtx(mtx, mod.generate_matrix(s, c, n, d, a.seed + i), index_base=1)
-    out = os.path.join(a.out_folder, ex.result_name(s, c, d, n, a.k, a.niter))
-    cmd = [ex.default_exe(), "-t", str(a.niter), "-m", mtx, "-k", str(a.k), "-r"]
+        mod.write_mtx(mtx, mod.generate_matrix(s, c, n, d, a.seed + i // len(a.bits)), index_base=1)
+    out = os.path.join(a.out_folder, ex.result_name(s, c, d, n, a.k, a.niter, bits=bits))
+    cmd = [ex.default_exe(), "-t", str(a.niter), "-m", mtx, "-k", str(a.k), "-r"] + (["-a"] if bits == "f16" else [])
+    run_env = dict(env, TKSPMV_FIXED_WIDTH=bits[:-1]) if bits.endswith("b") else env
     print(f"running {i + 1}/{len(grid)}: {' '.join(cmd)} > {out}", flush=True)
-    r = subprocess.run(cmd, capture_output=True, text=True, env=env)
+    r = subprocess.run(cmd, capture_output=True, text=True, env=run_env)
     if r.returncode != 0:
         print("  failed:", r.stderr.strip() or r.stdout.strip()[-300:])
         continue
     open(out, "w").write(r.stdout)
     acc = ex.accuracy(ex.read_result_csv(out), thresholds=[t for t in ex.THRESHOLDS if t <= a.k])
-    acc.update(rows=s, cols=c, dist=d, nnz=n, k=a.k, file=os.path.basename(out))
+    acc.update(rows=s, cols=c, dist=d, nnz=n, k=a.k, bits=bits, file=os.path.basename(out))
     table.append(acc)
     ts = [t for t in (1, 8, 50, 100) if f"prec_{t}" in acc]
     print("  " + "  ".join(f"prec@{t} {acc[f'prec_{t}']:.3f} tau@{t} {acc[f'kendall_{t}']:.3f} ndcg@{t} {acc[f'ndcg_{t}']:.4f}" for t in ts[-2:])
