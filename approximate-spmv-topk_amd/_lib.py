@@ -28,7 +28,7 @@ class Desc(C.Structure):
         ("k", C.c_int32), ("partitions", C.c_int32), ("k_per_partition", C.c_int32), ("precision", C.c_int32),
         ("device", C.c_int32), ("first_row", C.c_uint32), ("min_score", C.c_float),
         ("waves_per_cu", C.c_int32), ("threads_per_wg", C.c_int32), ("nnz_per_lane", C.c_int32),
-        ("stream_replicas", C.c_int32), ("fixed_width", C.c_int32), ("reserved", C.c_int32 * 3),
+        ("stream_replicas", C.c_int32), ("fixed_width", C.c_int32), ("multi_q", C.c_int32), ("reserved", C.c_int32 * 2),
     ]
 
 
@@ -39,7 +39,8 @@ class Info(C.Structure):
         ("packet_entries", C.c_uint32), ("n_wave_partitions", C.c_uint32), ("packets_per_partition", C.c_uint32),
         ("grid", C.c_uint32), ("block", C.c_uint32), ("n_groups", C.c_uint32), ("lds_bytes", C.c_uint32),
         ("k", C.c_int32), ("partitions", C.c_int32), ("k_per_partition", C.c_int32), ("precision", C.c_int32),
-        ("device", C.c_int32), ("num_cus", C.c_uint32), ("fixed_width", C.c_uint32), ("reserved", C.c_uint32 * 6),
+        ("device", C.c_int32), ("num_cus", C.c_uint32), ("fixed_width", C.c_uint32), ("multi_q", C.c_uint32), ("reserved0", C.c_uint32), ("multi_bytes", C.c_uint64),
+        ("reserved", C.c_uint32 * 2),
     ]
 
     def as_dict(self):
@@ -78,9 +79,9 @@ class OptionsC(C.Structure):
 EXPORTED_SYMBOLS = [
     "tkspmv_create", "tkspmv_destroy", "tkspmv_get_info", "tkspmv_set_query", "tkspmv_set_query_device",
     "tkspmv_run", "tkspmv_enqueue", "tkspmv_enqueue_many", "tkspmv_enqueue_batch", "tkspmv_synchronize", "tkspmv_read", "tkspmv_result_device", "tkspmv_scores", "tkspmv_debug_trace",
-    "tkspmv_time_queries", "tkspmv_profile", "tkspmv_last_error", "tkspmv_device_count", "tkspmv_mtx_read", "tkspmv_mtx_free",
+    "tkspmv_time_queries", "tkspmv_enqueue_multi", "tkspmv_time_multi", "tkspmv_profile", "tkspmv_last_error", "tkspmv_device_count", "tkspmv_mtx_read", "tkspmv_mtx_free",
     "tkspmv_mtx_write", "tkspmv_sample_vector", "tkspmv_generate", "tkspmv_options_parse", "tkspmv_pack",
-    "tkspmv_packed_info", "tkspmv_packed_decode", "tkspmv_packed_raw", "tkspmv_packed_free", "tkspmv_wave_partitions", "tkspmv_packed_save", "tkspmv_packed_load",
+    "tkspmv_sell_roundtrip", "tkspmv_packed_info", "tkspmv_packed_decode", "tkspmv_packed_raw", "tkspmv_packed_free", "tkspmv_wave_partitions", "tkspmv_packed_save", "tkspmv_packed_load",
     "tkspmv_create_packed",
     "tkspmv_dist_unique_id", "tkspmv_dist_create", "tkspmv_dist_set_batch", "tkspmv_dist_enqueue", "tkspmv_dist_run_many",
     "tkspmv_dist_synchronize", "tkspmv_dist_read", "tkspmv_dist_destroy", "tkspmv_dist_last_error",
@@ -118,6 +119,8 @@ def lib():
     L.tkspmv_scores.argtypes = [vp, f32p]
     L.tkspmv_debug_trace.argtypes = [vp, C.POINTER(C.c_uint64), C.c_uint64, C.POINTER(C.c_uint64)]
     L.tkspmv_time_queries.argtypes = [vp, vp, C.c_int32, C.c_int32, C.POINTER(C.c_double)]
+    L.tkspmv_enqueue_multi.argtypes = [vp, vp, C.c_int32, vp, vp, vp]
+    L.tkspmv_time_multi.argtypes = [vp, vp, C.c_int32, C.c_int32, C.POINTER(C.c_double)]
     L.tkspmv_profile.argtypes = [vp, vp, C.c_int32, C.c_int32, C.POINTER(Timing)]
     L.tkspmv_mtx_read.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(Coo)]
     L.tkspmv_mtx_free.argtypes = [C.POINTER(Coo)]

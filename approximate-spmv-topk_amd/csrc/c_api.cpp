@@ -8,6 +8,7 @@
 #include "engine.hpp"
 #include "host_utils.hpp"
 #include "wbscsr.hpp"
+#include "wsell.hpp"
 
 using namespace tkspmv;
 
@@ -93,6 +94,12 @@ int tkspmv_debug_trace(tkspmv_t *h, uint64_t *host, uint64_t max_words, uint64_t
     if (st != TKSPMV_OK) g_err = err;
     if (words) *words = w;
     return st;
+}
+int tkspmv_enqueue_multi(tkspmv_t *h, const float *dev_xs, int32_t count, uint32_t *dev_idx, float *dev_val, void *stream) {
+    ENGINE_CALL(enqueue_multi(dev_xs, count, dev_idx, dev_val, stream, err))
+}
+int tkspmv_time_multi(tkspmv_t *h, const float *dev_xs, int32_t n_x, int32_t iters, double *ns_per_query) {
+    ENGINE_CALL(time_multi(dev_xs, n_x, iters, ns_per_query, err))
 }
 int tkspmv_time_queries(tkspmv_t *h, const float *dev_xs, int32_t n_x, int32_t iters, double *ns_per_query) {
     ENGINE_CALL(time_queries(dev_xs, n_x, iters, ns_per_query, err))
@@ -242,6 +249,33 @@ int tkspmv_packed_raw(const tkspmv_packed *p, const void **packets, uint64_t *pa
 }
 
 void tkspmv_packed_free(tkspmv_packed *p) { delete p; }
+
+int tkspmv_sell_roundtrip(const tkspmv_desc *d, uint32_t n_wave_partitions_hint, uint32_t *row, uint32_t *col, float *val,
+                          uint64_t *n, uint64_t *info) {
+    if (!d || !n) return fail(TKSPMV_ERR_INVALID, "NULL argument");
+    SellMatrix sm;
+    const std::string err = pack_wsell(d->rows, d->cols, d->nnz, d->row, d->col, d->val,
+                                       n_wave_partitions_hint ? n_wave_partitions_hint : 4088u, sm);
+    if (!err.empty()) return fail(TKSPMV_ERR_INVALID, err);
+    std::vector<uint32_t> r, c;
+    std::vector<float> v;
+    decode_wsell(sm, r, c, v);
+    *n = r.size();
+    if (row) std::memcpy(row, r.data(), r.size() * 4);
+    if (col) std::memcpy(col, c.data(), c.size() * 4);
+    if (val) std::memcpy(val, v.data(), v.size() * 4);
+    if (info) {
+        uint32_t most = 0;
+        for (uint32_t pc : sm.part_count) most = std::max(most, pc);
+        info[0] = sm.n_slices;
+        info[1] = sm.n_chunks;
+        info[2] = sm.padded_entries;
+        info[3] = sm.part_first.size();
+        info[4] = sm.stream_bytes();
+        info[5] = most;
+    }
+    return TKSPMV_OK;
+}
 
 int tkspmv_packed_save(const tkspmv_packed *p, const char *path) {
     if (!p || !path) return fail(TKSPMV_ERR_INVALID, "NULL argument");

@@ -28,6 +28,7 @@
 #include <vector>
 
 #include "engine.hpp"
+#include "wsell.hpp"
 
 namespace tkspmv {
 
@@ -179,6 +180,9 @@ struct SelectParams {
     uint32_t n_groups_pub;
     uint32_t use_gmax;  // n_sets != 0 and n_groups_pub >= k
     unsigned long long *scratch;  // [n_wg*WG_SLOTS + ovf_cap] composite keys (general path)
+    // Multi-query kernel: candidates carry their POSITION in the wave-sliced ELL stream (slice * 64 + lane) instead of a
+    // row id; the selection, off the streaming waves' path, looks the row ids up here. NULL: candidates carry row ids.
+    const uint32_t *pos_to_row;
     unsigned long long *stats;    // [0] += candidates, [1] += queries, [2] = max candidates, [3] += general-path runs
 };
 
@@ -239,6 +243,13 @@ __device__ __forceinline__ void select_body(const SelectParams &P, const uint32_
         mine[u] = ~0ull;
         if (f < n_slots) mine[u] = ld_agent(&P.wg_cand[f]);
     }
+    if (P.pos_to_row) {
+#pragma unroll
+        for (uint32_t u = 0; u < SEL_PER_THREAD; ++u) {
+            const uint32_t pos = (uint32_t)(mine[u] >> 32);
+            if (pos != SLOT_INVALID) mine[u] = pack_cand((uint32_t)mine[u], P.pos_to_row[pos]);
+        }
+    }
     // The reducer servers keep the k-th largest published maximum in tau_g: a valid lower bound of the k-th best
     // score (slightly stale, never too high). It prunes what was appended while the threshold was converging.
     const uint32_t thr = P.use_gmax ? __hip_atomic_load(P.tau_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
@@ -290,8 +301,9 @@ __device__ __forceinline__ void select_body(const SelectParams &P, const uint32_
     }
     for (uint32_t i0 = 0; i0 < novf; i0 += nthreads) {  // wave-uniform trip count
         const uint32_t i = i0 + tid;
-        const unsigned long long v = i < novf ? ld_agent(&P.ovf_cand[i]) : 0ull;
+        unsigned long long v = i < novf ? ld_agent(&P.ovf_cand[i]) : 0ull;
         const bool keep = i < novf && order_key(__uint_as_float((uint32_t)v)) >= thr;
+        if (keep && P.pos_to_row) v = pack_cand((uint32_t)v, P.pos_to_row[(uint32_t)(v >> 32)]);
         const uint64_t bm = __ballot(keep);
         uint32_t base = 0;
         if (lane == 0 && bm) base = atomicAdd(&S.total, (uint32_t)__popcll(bm));
@@ -403,7 +415,7 @@ __device__ __forceinline__ float dpp_zero(float src) {
         float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, src), CTRL, ROW_MASK, 0xF, true));
 }
 constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114, DPP_ROW_SHR8 = 0x118;
-constexpr int DPP_WAVE_SHR1 = 0x138, DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143;
+constexpr int DPP_WAVE_SHL1 = 0x130, DPP_WAVE_SHR1 = 0x138, DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143;
 
 // Wave-wide maximum with DPP (result uniform, returned through an SGPR).
 template <int CTRL, int ROW_MASK>
@@ -1211,22 +1223,24 @@ struct BatchIO {
     uint32_t *out_idx;
     float *out_val;
 };
-struct BatchParams {
-    uint32_t n_q;
-    uint32_t *tickets;  // [BATCH_MAX] counters, 32 words apart
-    // exchange-state set 0 and the distance (in elements) to the next set
+// Exchange-state sets are allocated as one block per field: set s = set 0 plus s strides.
+struct SetAddr {
     uint32_t *gmax0, *tau_g0, *ovf_count0;
     unsigned long long *wg_cand0, *ovf_cand0, *scratch;
     float *unit_inv0;
     uint32_t gmax_stride, word_stride, cand_stride;
     uint64_t ovf_stride;
-    BatchIO io[BATCH_MAX];
     __device__ __forceinline__ uint32_t *gmax(uint32_t q) const { return gmax0 + (size_t)q * gmax_stride; }
     __device__ __forceinline__ uint32_t *tau_g(uint32_t q) const { return tau_g0 + (size_t)q * word_stride; }
     __device__ __forceinline__ uint32_t *ovf_count(uint32_t q) const { return ovf_count0 + (size_t)q * word_stride; }
     __device__ __forceinline__ float *unit_inv(uint32_t q) const { return unit_inv0 + (size_t)q * word_stride; }
     __device__ __forceinline__ unsigned long long *wg_cand(uint32_t q) const { return wg_cand0 + (size_t)q * cand_stride; }
     __device__ __forceinline__ unsigned long long *ovf_cand(uint32_t q) const { return ovf_cand0 + (size_t)q * ovf_stride; }
+};
+struct BatchParams : SetAddr {
+    uint32_t n_q;
+    uint32_t *tickets;  // [BATCH_MAX] counters, 32 words apart
+    BatchIO io[BATCH_MAX];
 };
 
 template <int XCOLS, int C = 4>
@@ -1644,6 +1658,396 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0, co
 #undef TKSPMV_REQUEST
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Multi-query kernel: Q queries per pass over the matrix. The reference streams the matrix once per
+// query vector (one x per run: host_spmv_bscsr.cpp:602-622, spmv_bscsr_top_k_multicore.cpp:87-140); here a chunk that
+// has been loaded serves up to Q queries before the next one. It streams the wave-sliced ELL copy of the matrix
+// (wsell.hpp): one lane owns one row, so a non-zero costs one LDS read, one multiply and one add per query and there is
+// no cross-lane scan (measured first on the wave-BSCSR stream: there the segmented scan, ~12 VALU instructions per
+// non-zero and query, made 4 queries per pass SLOWER per query than one query per pass -- 28 us against 21 us).
+// Row sums are accumulated in the row's own entry order = the order of the reference's gold: bit-identical scores.
+// Q copies of x in LDS, Q accumulators per lane, Q thresholds, Q private candidate lists per wave, Q exchange-state
+// sets. Launch structure = deferred selection: workgroup 0 selects the top-k lists of the PREVIOUS group of queries
+// while workgroups 1.. stream the current one. Cold start of the threshold exchange: the scores of a wave's first
+// slices (one float per lane, slice and query) wait in registers and are judged at the end of the partition.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int MULTI_Q_MAX = 8;
+// entries of a wave's private candidate list, per query (LDS: 8 waves x Q lists)
+template <int Q>
+struct MultiGeom {
+    static constexpr uint32_t WAVE_CAP = Q <= 4 ? 128u : 64u;
+    // Slices whose scores a wave can hold back in registers (one float per lane, slice and query) while no threshold has
+    // arrived yet
+    static constexpr int HOLD = Q <= 2 ? 6 : (Q <= 4 ? 4 : 2);
+};
+struct MultiGroup {  // a group of queries sharing one pass; their exchange-state sets are set0 .. set0 + n_q - 1
+    uint32_t n_q, set0;
+    BatchIO io[MULTI_Q_MAX];
+};
+struct MultiParams {
+    SetAddr A;
+    MultiGroup cur, prev;  // prev.n_q == 0: no selection owed
+    unsigned long long *scratch0;  // general-path scratch of selector q: scratch0 + q * scratch_stride
+    uint64_t scratch_stride;
+    const uint32_t *part_slice0;  // [n_parts] first slice of every partition
+};
+template <int Q>
+struct MultiLds {
+    union {
+        struct {
+            float x[Q][SELL_XCOLS + 8];  // + the two padding slots (wsell.hpp)
+            uint2 cand[8][Q][MultiGeom<Q>::WAVE_CAP];
+        } w;
+        SelectShared sel;  // selector workgroup only
+    } u;
+    uint32_t misc[Q][MISC_WORDS];
+};
+
+__device__ __forceinline__ SelectParams select_params_of_set(const SelectParams &SP0, const SetAddr &A, uint32_t set,
+                                                             const BatchIO &io) {
+    SelectParams S = SP0;
+    S.wg_cand = A.wg_cand(set);
+    S.ovf_cand = A.ovf_cand(set);
+    S.ovf_count = A.ovf_count(set);
+    S.gmax = A.gmax(set);
+    S.tau_g = A.tau_g(set);
+    S.scratch = A.scratch;
+    S.unit_inv_in = nullptr;
+    S.out_idx = io.out_idx;
+    S.out_val = io.out_val;
+    return S;
+}
+
+// The selections still owed to the last group of a sequence (one after the other: they share the general path's scratch).
+__global__ void __launch_bounds__(SEL_THREADS) select_group_kernel(const SelectParams SP0, const SetAddr A, const MultiGroup G) {
+    __shared__ SelectShared S;
+    for (uint32_t q = 0; q < G.n_q; ++q) {
+        const SelectParams P = select_params_of_set(SP0, A, G.set0 + q, G.io[q]);
+        select_body(P, threadIdx.x, blockDim.x, S);
+        __syncthreads();
+    }
+}
+
+// Candidate path of the multi-query kernel: one finished row per lane. Same
+// list discipline as offer_candidates: private list, compaction against the current threshold when full, what still
+// does not fit goes to the query's overflow list with one atomic per wave.
+template <uint32_t WAVE_CAP>
+__device__ __forceinline__ void offer_rows(const SetAddr &A, uint32_t set, uint32_t ovf_cap, float score, uint32_t pos_of_slice,
+                                           float tau, uint32_t lane, uint32_t grp_local, bool publishes, uint2 *wcand,
+                                           uint32_t &wcnt, uint32_t *misc, unsigned long long *dbg = nullptr) {
+    // The candidate's id is its position in the stream; the selection translates it (SelectParams::pos_to_row), so this
+    // path touches no global memory unless a list overflows. Lanes without a row (and the leading lanes of a row that
+    // spans several) hold -inf.
+    const uint32_t r = pos_of_slice + lane;
+    const bool pass = score >= tau && score > -__builtin_huge_valf();
+    const uint64_t pb = __ballot(pass);
+    if (pb == 0ull) return;
+    const uint32_t total = (uint32_t)__popcll(pb);
+    const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(pb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pb, 0u));
+    const float wmax = wave_max(pass ? score : -__builtin_huge_valf());
+    if (lane == 0 && publishes)
+        (void)__hip_atomic_fetch_max(&misc[MISC_GRPMAX + grp_local], order_key(wmax), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (dbg && lane == 0) {  // TKSPMV_STATS=1
+        atomicAdd(&dbg[0], 1ull);
+        atomicAdd(&dbg[1], (unsigned long long)total);
+        if (tau <= 0.0f) atomicAdd(&dbg[2], (unsigned long long)total);
+    }
+    if (wcnt + total > WAVE_CAP) wcnt = compact_list<WAVE_CAP / 64u>(wcand, wcnt, tau, lane);
+    const uint32_t base = wcnt;
+    const uint32_t first_ovf = base < WAVE_CAP ? WAVE_CAP : base;
+    uint32_t gbase = 0u;
+    if (base + total > WAVE_CAP) {
+        if (dbg && lane == 0) atomicAdd(&dbg[3], (unsigned long long)(base + total - first_ovf));
+        if (lane == 0) gbase = atomicAdd(A.ovf_count(set), base + total - first_ovf);
+        gbase = __builtin_amdgcn_readfirstlane(gbase);
+    }
+    if (pass) {
+        const uint32_t pos = base + slot;
+        if (pos < WAVE_CAP) {
+            wcand[pos] = make_uint2(__float_as_uint(score), r);
+        } else {
+            const uint32_t gp = gbase + (pos - first_ovf);
+            if (gp < ovf_cap) st_agent(&A.ovf_cand(set)[gp], pack_cand(__float_as_uint(score), r));
+        }
+    }
+    wcnt = base + total < WAVE_CAP ? base + total : WAVE_CAP;
+}
+
+template <int Q>
+__global__ void __launch_bounds__(576, 6) multi_kernel(const StreamParams P0, const SelectParams SP0, const MultiParams M) {
+    constexpr int C = 4, NBUF = 3, DEFER_S = MultiGeom<Q>::HOLD;
+    constexpr uint32_t MULTI_WAVE_CAP = MultiGeom<Q>::WAVE_CAP;
+    __shared__ MultiLds<Q> L;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (blockIdx.x < (uint32_t)MULTI_Q_MAX) {
+        // selector workgroups: workgroup q selects query q of the previous group (all of them at once: one after the other
+        // in ONE workgroup they took longer than the pass they ride in)
+        if (blockIdx.x < M.prev.n_q) {
+            SelectParams S = select_params_of_set(SP0, M.A, M.prev.set0 + blockIdx.x, M.prev.io[blockIdx.x]);
+            S.scratch = M.scratch0 + (size_t)blockIdx.x * M.scratch_stride;
+            select_body(S, tid, blockDim.x, L.u.sel);
+        }
+        return;
+    }
+    const uint32_t bid = blockIdx.x - (uint32_t)MULTI_Q_MAX, n_wg = gridDim.x - (uint32_t)MULTI_Q_MAX;
+    const uint32_t nwaves = (blockDim.x >> 6) - 1u;  // streaming waves
+    const bool is_server = (wave == nwaves);
+    const uint32_t nq = M.cur.n_q < (uint32_t)Q ? M.cur.n_q : (uint32_t)Q;
+    const uint32_t set0 = M.cur.set0;
+    const uint32_t grp_local = is_server ? 0u : wave * P0.gpw / nwaves;
+    const bool publishes = (bid * P0.gpw + grp_local) < P0.n_groups_pub;
+    const bool reducer = bid < P0.n_reducers;
+    const float min_units = P0.min_score;  // fp32 values only: one score unit is 1.0
+    // Every server wave outranks the streaming waves here: with several queries per chunk those hardly ever wait for
+    // memory, and a server at a lower priority does not get to publish its workgroup's maxima (or to fetch the threshold)
+    // before most of the pass is over. The servers sleep between rounds, so they take few issue slots.
+    if (is_server) __builtin_amdgcn_s_setprio(3);
+    else __builtin_amdgcn_s_setprio(TKSPMV_STREAM_PRIO);
+
+    // This wave's partition of the wave-sliced ELL stream; its first chunks are requested before x is staged.
+    uint32_t p0 = 0, np = 0, slice = 0;
+    {
+        const uint32_t part = is_server ? P0.n_parts : wave * n_wg + bid;
+        if (part < P0.n_parts) {
+            p0 = P0.part_first[part];
+            np = P0.part_count[part];
+            slice = M.part_slice0[part];
+        }
+    }
+    const uint8_t *pk = M.cur.io[0].packets + (size_t)p0 * P0.packet_bytes;
+    Pkt<C, 0> buf[NBUF];
+#pragma unroll
+    for (int u = 0; u < NBUF - 1; ++u) {
+        if (np > 0u) {
+            const uint32_t iu = ((uint32_t)u < np) ? (uint32_t)u : (np - 1u);
+            load_packet<C, 0>(pk + (size_t)iu * P0.packet_bytes, lane, buf[u]);
+        }
+    }
+
+    for (uint32_t i = tid; i < (uint32_t)Q * MISC_WORDS; i += blockDim.x)
+        (&L.misc[0][0])[i] = (i % MISC_WORDS) == (uint32_t)MISC_TAU ? __float_as_uint(min_units) : 0u;
+    for (uint32_t q = 0; q < nq; ++q) {
+        const float *xg = M.cur.io[q].x;
+        for (uint32_t i = tid; i < SELL_XCOLS; i += blockDim.x) L.u.w.x[q][i] = (i < P0.cols) ? xg[i] : 0.0f;
+        if (tid == 0) {
+            L.u.w.x[q][SELL_PAD_NEUTRAL] = -0.0f;
+            L.u.w.x[q][SELL_PAD_ONE] = 1.0f;
+        }
+    }
+    __syncthreads();
+
+    if (is_server) {
+        // Threshold exchange of all nq queries at once: lane l serves (query l / 8, local group l % 8), so a round costs one
+        // store and one load round trip however many queries share the pass (query by query, a round took nq round trips
+        // and a threshold needed three rounds -- publish, reduce, fetch -- to reach a workgroup: most of the pass). Each
+        // reducer workgroup searches the k-th largest maximum of ONE query per round (~2.5 us).
+        const uint32_t q_l = lane >> 3, g_l = lane & 7u;
+        const bool q_ok = q_l < nq;
+        uint32_t *mp_l = L.misc[q_ok ? q_l : 0u];
+        const uint32_t grp = bid * P0.gpw + g_l;
+        const bool pub_lane = q_ok && g_l < P0.gpw && grp < P0.n_groups_pub;
+        uint32_t *gmax_l = M.A.gmax(set0 + (q_ok ? q_l : 0u));
+        uint32_t *tau_g_l = M.A.tau_g(set0 + (q_ok ? q_l : 0u));
+        const uint32_t rq = bid % nq;  // the query this workgroup reduces (if it is a reducer)
+        auto publish_all = [&]() __attribute__((always_inline)) {
+            if (pub_lane) {
+                const uint32_t key = lds_load(&mp_l[MISC_GRPMAX + g_l]);
+                if (key > mp_l[MISC_PUBLISHED + g_l]) {
+                    mp_l[MISC_PUBLISHED + g_l] = key;
+                    __hip_atomic_store(&gmax_l[grp], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // single writer per slot
+                }
+            }
+        };
+        for (;;) {
+            publish_all();
+            if (reducer) {
+                StreamParams P = P0;
+                P.gmax = M.A.gmax(set0 + rq);
+                TauRegs tr_;
+                tau_issue(P, lane, tr_);
+                const float t = tau_from_maxima(P, tr_, min_units);
+                if (lane == 0 && t > min_units)
+                    __hip_atomic_fetch_max(M.A.tau_g(set0 + rq), order_key(t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (q_ok && g_l == 0u) {
+                const uint32_t kx = __hip_atomic_load(tau_g_l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const float t = kx ? key_to_float(kx) : min_units;
+                const float cur_tau = __uint_as_float(lds_load(&mp_l[MISC_TAU]));
+                if (t > cur_tau) __hip_atomic_store(&mp_l[MISC_TAU], __float_as_uint(t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            // every streaming wave counts itself out and none of them waits for this wave: the loop always ends
+            if (__builtin_amdgcn_readfirstlane(lds_load(&L.misc[0][MISC_DONE])) >= nwaves) break;
+            __builtin_amdgcn_s_sleep(8);
+        }
+        publish_all();  // the workgroup's complete maxima (fire and forget)
+        return;
+    }
+
+    // ---- streaming waves ---------------------------------------------------------------------------------------
+    float acc[Q];              // this lane's row of the current slice, one running sum per query
+    float held[DEFER_S][Q];    // scores of the partition's first slices, judged at the end
+    uint32_t wcnt[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        acc[q] = 0.0f;
+        wcnt[q] = 0u;
+#pragma unroll
+        for (int d = 0; d < DEFER_S; ++d) held[d][q] = -__builtin_huge_valf();
+    }
+    // true while some query of the pass has no threshold yet (its LDS word still holds the minimum score)
+    auto no_tau = [&]() __attribute__((always_inline)) -> bool {
+        bool missing = false;
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+            if ((uint32_t)q < nq) missing = missing || lds_load(&L.misc[q][MISC_TAU]) == __float_as_uint(min_units);
+        return missing;
+    };
+    bool gave_up = false;
+    uint32_t n_done = 0u;  // slices finished by this wave
+    uint32_t n_held = 0u;  // of which held back (the first n_held of the partition)
+    for (uint32_t i0 = 0; i0 < np; i0 += NBUF) {
+#pragma unroll
+        for (int u = 0; u < NBUF; ++u) {
+            const uint32_t i = i0 + (uint32_t)u;
+            if (i >= np) break;
+            const Pkt<C, 0> &cur = buf[u];
+            {  // unconditional (index clamped): a fixed number of younger loads => counted vmcnt
+                const uint32_t ia = (i + (NBUF - 1) < np) ? (i + (NBUF - 1)) : (np - 1u);
+                load_packet<C, 0>(pk + (size_t)ia * P0.packet_bytes, lane, buf[(u + NBUF - 1) % NBUF]);
+            }
+            uint32_t off[C];
+#pragma unroll
+            for (int j = 0; j < C; ++j) {
+                const uint32_t word = cur.cw[j >> 1];
+                off[j] = (j & 1) ? ((word >> 16) & 0xFFFCu) : (word & 0xFFFCu);  // byte offset of x[col]
+            }
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                if ((uint32_t)q < nq) {
+                    const unsigned char *xb = reinterpret_cast<const unsigned char *>(L.u.w.x[q]);
+#pragma unroll
+                    for (int j = 0; j < C; ++j)
+                        acc[q] = __fadd_rn(acc[q], __fmul_rn(cur.v[j], *reinterpret_cast<const float *>(xb + off[j])));
+                }
+            }
+            if (__builtin_amdgcn_readfirstlane(cur.cw[0]) & 1u) {  // last chunk of the slice: 64 rows are complete
+                // A row of more than 64 entries spans adjacent lanes (segment index in the flag bits of this chunk, wsell.hpp):
+                // its segment sums are added left to right and the score ends up on its last lane; rare.
+                const uint32_t depth = ((cur.cw[0] >> 16) & 3u) | ((cur.cw[1] & 3u) << 2) | (((cur.cw[1] >> 16) & 3u) << 4);
+                if (__ballot(depth != 0u) != 0ull) {
+                    for (uint32_t d = 1; d < 64u; ++d) {
+                        if (__ballot(depth == d) == 0ull) break;
+#pragma unroll
+                        for (int q = 0; q < Q; ++q) {
+                            const float left = dpp_zero<DPP_WAVE_SHR1, 0xF>(acc[q]);
+                            acc[q] = (depth == d) ? __fadd_rn(left, acc[q]) : acc[q];
+                        }
+                    }
+                    const uint32_t depth_right = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)depth, DPP_WAVE_SHL1, 0xF, 0xF, true);
+#pragma unroll
+                    for (int q = 0; q < Q; ++q) acc[q] = depth_right != 0u ? -__builtin_huge_valf() : acc[q];  // not the row's last lane
+                }
+                // Hold the slice back while no threshold has arrived (cold start of the exchange) and registers are left;
+                // only the partition's leading slices are held, so that their slice numbers stay implicit.
+                if (n_held == n_done && n_held < (uint32_t)DEFER_S && no_tau()) {
+                    ++n_held;
+#pragma unroll
+                    for (int q = 0; q < Q; ++q) {
+                        if ((uint32_t)q < nq) {
+#pragma unroll
+                            for (int d = 0; d < DEFER_S; ++d) held[d][q] = (n_done == (uint32_t)d) ? acc[q] : held[d][q];
+                            const float wmax = wave_max(acc[q]);
+                            if (lane == 0 && publishes && wmax >= min_units)
+                                (void)__hip_atomic_fetch_max(&L.misc[q][MISC_GRPMAX + grp_local], order_key(wmax), __ATOMIC_RELAXED,
+                                                             __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                    }
+                } else {
+                    // Nothing is judged without a threshold: 64 rows per slice and query would all pass, fill the list and
+                    // pour into the overflow list. With several queries per chunk the pass is bound by instruction issue, so
+                    // a wave that waits here leaves its issue slots to the others; bounded, so that progress never depends
+                    // on the exchange.
+                    if (P0.tau_possible && !gave_up && no_tau()) {
+                        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                        while (no_tau() && __builtin_amdgcn_s_memrealtime() - t0 < FLUSH_TAU_WAIT) __builtin_amdgcn_s_sleep(8);
+                        gave_up = no_tau();  // one bounded wait per pass: a threshold that cannot form must not cost one per slice
+                        if (P0.dbg && lane == 0) {
+                            atomicAdd(&P0.dbg[8], 1ull);
+                            atomicAdd(&P0.dbg[9], __builtin_amdgcn_s_memrealtime() - t0);
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < Q; ++q) {
+                        if ((uint32_t)q < nq) {
+                            const float tau = __uint_as_float(lds_load(&L.misc[q][MISC_TAU]));
+                            if (__any(acc[q] >= tau) && !(P0.dbg_flags & 2u))
+                                offer_rows<MULTI_WAVE_CAP>(M.A, set0 + q, P0.ovf_cap, acc[q], (slice + n_done) * 64u, tau,
+                                                           lane, grp_local, publishes, L.u.w.cand[wave][q], wcnt[q], L.misc[q], P0.dbg);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < Q; ++q) acc[q] = 0.0f;
+                ++n_done;
+            }
+        }
+    }
+    // The held slices. A short partition (small matrix) gets here before any threshold exists: give the exchange a moment,
+    // bounded, and only where a threshold can form at all.
+    if (np > 0u) {
+        if (P0.tau_possible && !gave_up) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            while (no_tau() && __builtin_amdgcn_s_memrealtime() - t0 < FLUSH_TAU_WAIT) __builtin_amdgcn_s_sleep(4);
+        }
+#pragma unroll
+        for (int d = 0; d < DEFER_S; ++d) {
+            if ((uint32_t)d < n_held) {
+#pragma unroll
+                for (int q = 0; q < Q; ++q) {
+                    if ((uint32_t)q < nq) {
+                        const float tau = __uint_as_float(lds_load(&L.misc[q][MISC_TAU]));
+                        if (__any(held[d][q] >= tau) && !(P0.dbg_flags & 2u))
+                            offer_rows<MULTI_WAVE_CAP>(M.A, set0 + q, P0.ovf_cap, held[d][q], (slice + (uint32_t)d) * 64u, tau,
+                                                       lane, grp_local, publishes, L.u.w.cand[wave][q], wcnt[q], L.misc[q],
+                                                       P0.dbg ? P0.dbg + 4 : nullptr);
+                    }
+                }
+            }
+        }
+    }
+    if (lane == 0) atomicAdd(&L.misc[0][MISC_DONE], 1u);
+
+    // ---- flush: what still clears the final threshold leaves the wave's lists (first survivor to the wave's slot,
+    // further ones to the query's overflow list); complete at the end of the launch, selected by the next launch.
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        if ((uint32_t)q < nq) {
+            const float tau = __uint_as_float(lds_load(&L.misc[q][MISC_TAU]));
+            ListScan<MULTI_WAVE_CAP / 64u> LS;
+            const uint32_t surv = scan_list<MULTI_WAVE_CAP / 64u>(L.u.w.cand[wave][q], wcnt[q], tau, lane, LS);
+            if (surv != 0u) {
+                uint32_t gbase = 0u;
+                if (surv > 1u) {
+                    if (lane == 0) gbase = atomicAdd(M.A.ovf_count(set0 + q), surv - 1u);
+                    gbase = __builtin_amdgcn_readfirstlane(gbase);
+                }
+                unsigned long long *slot = M.A.wg_cand(set0 + q) + (size_t)bid * WG_SLOTS + wave;
+                unsigned long long *ovf = M.A.ovf_cand(set0 + q);
+#pragma unroll
+                for (uint32_t e = 0; e < MULTI_WAVE_CAP / 64u; ++e) {
+                    if (LS.keep[e]) {
+                        const unsigned long long v = pack_cand(LS.e[e].x, LS.e[e].y);
+                        if (LS.pos[e] == 0u) st_agent(slot, v);
+                        else if (gbase + LS.pos[e] - 1u < P0.ovf_cap) st_agent(&ovf[gbase + LS.pos[e] - 1u], v);
+                    }
+                }
+            }
+        }
+    }
+}
+
 // Empty kernel with the stream kernel's geometry: calibrates what an event bracket adds around one launch.
 __global__ void __launch_bounds__(576) null_kernel(const uint32_t *p) {
     if (p == nullptr && threadIdx.x == 123456u) __builtin_trap();
@@ -1696,6 +2100,19 @@ struct EngineImpl {
     bool fused = true;
     bool can_defer = false;
     bool can_batch = false;         // batch kernel usable (exchange on, x double-buffered in LDS, 4 entries per lane)
+    // Multi-query passes (multi_kernel, desc.multi_q): fp32 values, <= 1024 columns, exchange on. multi_q queries share one
+    // pass over the wave-sliced ELL copy of the matrix (wsell.hpp); a group's selection is owed to the next launch (or to
+    // drain()). Groups alternate between the exchange-state sets [0, MULTI_Q_MAX) and [MULTI_Q_MAX, 2 * MULTI_Q_MAX).
+    bool can_multi = false;
+    int multi_q = 0;
+    uint8_t *d_sell_packets = nullptr;
+    std::vector<uint8_t *> d_sell_replicas;
+    uint32_t *d_sell_rows = nullptr, *d_sell_part_first = nullptr, *d_sell_part_count = nullptr, *d_sell_part_slice0 = nullptr;
+    uint32_t sell_parts = 0;
+    uint64_t sell_bytes = 0;
+    unsigned long long *d_multi_scratch = nullptr;  // [MULTI_Q_MAX] general-path scratches (the selectors of a group run at once)
+    mutable MultiGroup pending_group{};
+    mutable int multi_parity = 0;
     uint32_t *d_tickets = nullptr;  // [BATCH_MAX] x 32 words
     uint32_t groups_with_rows = 0;  // publishing groups that own at least one wave partition
     uint32_t n_reducers = 0;  // TKSPMV_REDUCERS (tuning): workgroups whose server derives tau from all maxima itself
@@ -1779,9 +2196,81 @@ struct EngineImpl {
     }
     // The selection still owed to the last deferred launch, as its own small kernel.
     void drain(hipStream_t s) const {
-        if (!pending) return;
-        launch_select(pending_idx, pending_val, s, pending_set);
-        pending = false;
+        if (pending) {
+            launch_select(pending_idx, pending_val, s, pending_set);
+            pending = false;
+        }
+        if (pending_group.n_q != 0u) {
+            SelectParams S = select_params(nullptr, nullptr, 0);
+            S.pos_to_row = d_sell_rows;
+            hipLaunchKernelGGL(select_group_kernel, dim3(1), dim3(SEL_THREADS), 0, s, S, set_addr(0), pending_group);
+            pending_group.n_q = 0u;
+        }
+    }
+    SetAddr set_addr(int s0) const {
+        SetAddr A{};
+        A.gmax0 = st[s0].gmax;
+        A.tau_g0 = st[s0].tau_g;
+        A.ovf_count0 = st[s0].ovf_count;
+        A.wg_cand0 = st[s0].wg_cand;
+        A.ovf_cand0 = st[s0].ovf;
+        A.scratch = st[s0].scratch;
+        A.unit_inv0 = st[s0].unit_inv;
+        A.gmax_stride = GMAX_WORDS;
+        A.word_stride = STATE_WORD_STRIDE;
+        A.cand_stride = grid * WG_SLOTS;
+        A.ovf_stride = ovf_cap;
+        return A;
+    }
+    // n <= multi_q queries in ONE pass over the matrix; their selection is owed (pending_group) to the next multi launch
+    // or to drain().
+    void launch_multi(const float *const *xs, uint32_t *const *out_idx, float *const *out_val, int n, hipStream_t s) const {
+        if (pending) {  // a deferred single-query selection uses sets 0/1: settle it first
+            launch_select(pending_idx, pending_val, s, pending_set);
+            pending = false;
+        }
+        StreamParams P = stream_params(xs[0], 0);
+        P.fused = 0u;
+        P.part_first = d_sell_part_first;
+        P.part_count = d_sell_part_count;
+        P.n_parts = sell_parts;
+        P.packet_bytes = SellMatrix::PACKET_BYTES;
+        P.pkt_row = nullptr;
+        MultiParams M{};
+        M.A = set_addr(0);
+        M.part_slice0 = d_sell_part_slice0;
+        M.scratch0 = d_multi_scratch;
+        M.scratch_stride = (uint64_t)grid * WG_SLOTS + ovf_cap;
+        M.prev = pending_group;
+        M.cur.n_q = (uint32_t)n;
+        M.cur.set0 = (uint32_t)(multi_parity * MULTI_Q_MAX);
+        const uint8_t *pk = d_sell_replicas.empty() ? d_sell_packets : d_sell_replicas[launch_counter % d_sell_replicas.size()];
+        for (int q = 0; q < n; ++q) {
+            BatchIO &Q = M.cur.io[q];
+            Q.x = xs[q];
+            Q.packets = pk;
+            Q.out_idx = out_idx[q];
+            Q.out_val = out_val[q];
+        }
+        ++launch_counter;
+        SelectParams S = select_params(nullptr, nullptr, 0);
+        S.pos_to_row = d_sell_rows;
+        if (multi_q <= 1) hipLaunchKernelGGL(multi_kernel<1>, dim3(grid), dim3(block + 64), 0, s, P, S, M);
+        else if (multi_q <= 2) hipLaunchKernelGGL(multi_kernel<2>, dim3(grid), dim3(block + 64), 0, s, P, S, M);
+        else if (multi_q <= 4) hipLaunchKernelGGL(multi_kernel<4>, dim3(grid), dim3(block + 64), 0, s, P, S, M);
+        else hipLaunchKernelGGL(multi_kernel<8>, dim3(grid), dim3(block + 64), 0, s, P, S, M);
+        pending_group = M.cur;
+        multi_parity ^= 1;
+    }
+    // A sequence of queries in passes of multi_q; complete in stream order when this returns. Engines without the
+    // multi-query kernel run the ordinary back-to-back sequence.
+    void launch_multi_sequence(const float *const *xs, uint32_t *const *out_idx, float *const *out_val, int n, hipStream_t s) const {
+        if (!can_multi) {
+            launch_sequence(xs, out_idx, out_val, n, s);
+            return;
+        }
+        for (int i = 0; i < n; i += multi_q) launch_multi(xs + i, out_idx + i, out_val + i, std::min(multi_q, n - i), s);
+        drain(s);
     }
     // One query, its result complete in stream order right after these launches: the stream kernel and, unless
     // fused into its tail, the select kernel.
@@ -1808,17 +2297,7 @@ struct EngineImpl {
         BatchParams B{};
         B.n_q = (uint32_t)n;
         B.tickets = d_tickets;
-        B.gmax0 = st[0].gmax;
-        B.tau_g0 = st[0].tau_g;
-        B.ovf_count0 = st[0].ovf_count;
-        B.wg_cand0 = st[0].wg_cand;
-        B.ovf_cand0 = st[0].ovf;
-        B.scratch = st[0].scratch;
-        B.unit_inv0 = st[0].unit_inv;
-        B.gmax_stride = GMAX_WORDS;
-        B.word_stride = STATE_WORD_STRIDE;
-        B.cand_stride = grid * WG_SLOTS;
-        B.ovf_stride = ovf_cap;
+        static_cast<SetAddr &>(B) = set_addr(0);
         for (int q = 0; q < n; ++q) {
             BatchIO &Q = B.io[q];
             Q.x = xs[q];
@@ -1951,6 +2430,12 @@ Engine::~Engine() {
             if (b) (void)hipFree(b);
     }
     for (size_t r = 1; r < m.d_replicas.size(); ++r) (void)hipFree(m.d_replicas[r]);
+    for (size_t r = 1; r < m.d_sell_replicas.size(); ++r) (void)hipFree(m.d_sell_replicas[r]);
+    {
+        void *sb[] = {m.d_sell_packets, m.d_sell_rows, m.d_sell_part_first, m.d_sell_part_count, m.d_sell_part_slice0, m.d_multi_scratch};
+        for (void *b : sb)
+            if (b) (void)hipFree(b);
+    }
     if (m.ev0) (void)hipEventDestroy(m.ev0);
     if (m.ev1) (void)hipEventDestroy(m.ev1);
     if (m.ev2) (void)hipEventDestroy(m.ev2);
@@ -2157,11 +2642,63 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
     if (const char *f = getenv("TKSPMV_DEFER")) m.can_defer = m.can_defer && atoi(f) != 0;
     m.can_batch = m.can_defer && m.n_sets != 0u && m.xcols <= 1024u && (C == 4u || (C == 8u && d.precision == TKSPMV_F32));  // larger x: two workgroups no longer fit a CU
     if (const char *f = getenv("TKSPMV_BATCH")) m.can_batch = m.can_batch && atoi(f) != 0;
+    // Multi-query passes (desc.multi_q; TKSPMV_MULTI_Q overrides): a second copy of the matrix in the wave-sliced ELL layout.
+    {
+        int mq = d.multi_q;
+        if (const char *f = getenv("TKSPMV_MULTI_Q")) mq = atoi(f);
+        if (mq != 0 && mq != 1 && mq != 2 && mq != 4 && mq != 8) {
+            err = "multi_q must be 0 (off), 1, 2, 4 or 8";
+            return TKSPMV_ERR_INVALID;
+        }
+        m.multi_q = mq;
+        m.can_multi = mq > 0 && m.can_defer && m.n_sets != 0u && d.cols <= SELL_XCOLS && d.precision == TKSPMV_F32 && m.pm.nnz > 0 &&
+                      m.grid > 2u * (uint32_t)MULTI_Q_MAX;
+    }
+    if (m.can_multi) {
+        // the first MULTI_Q_MAX workgroups of a multi-query launch are its selectors, the others stream
+        const uint32_t n_multi_waves = (m.grid - (uint32_t)MULTI_Q_MAX) * waves_per_wg;
+        SellMatrix sm;
+        std::string perr;
+        if (prepacked) {  // no COO at hand: decode the packed matrix
+            std::vector<uint32_t> r, c;
+            std::vector<float> v;
+            decode_wbscsr(*prepacked, r, c, v);
+            perr = pack_wsell(d.rows, d.cols, r.size(), r.data(), c.data(), v.data(), n_multi_waves, sm);
+        } else {
+            perr = pack_wsell(d.rows, d.cols, d.nnz, d.row, d.col, d.val, n_multi_waves, sm);
+        }
+        if (!perr.empty()) {
+            err = perr;
+            return TKSPMV_ERR_INVALID;
+        }
+        m.sell_parts = (uint32_t)sm.part_first.size();
+        m.sell_bytes = sm.stream_bytes() + sm.slice_rows.size() * 4 + (uint64_t)m.sell_parts * 12;
+        HIP_TRY(hipMalloc((void **)&m.d_sell_packets, std::max<size_t>(sm.stream_bytes(), 256)));
+        HIP_TRY(hipMemcpy(m.d_sell_packets, sm.packets.data(), sm.stream_bytes(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc((void **)&m.d_sell_rows, sm.slice_rows.size() * 4));
+        HIP_TRY(hipMemcpy(m.d_sell_rows, sm.slice_rows.data(), sm.slice_rows.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc((void **)&m.d_sell_part_first, (size_t)m.sell_parts * 4));
+        HIP_TRY(hipMalloc((void **)&m.d_sell_part_count, (size_t)m.sell_parts * 4));
+        HIP_TRY(hipMalloc((void **)&m.d_sell_part_slice0, (size_t)m.sell_parts * 4));
+        HIP_TRY(hipMemcpy(m.d_sell_part_first, sm.part_first.data(), (size_t)m.sell_parts * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(m.d_sell_part_count, sm.part_count.data(), (size_t)m.sell_parts * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(m.d_sell_part_slice0, sm.part_slice0.data(), (size_t)m.sell_parts * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc((void **)&m.d_multi_scratch, (size_t)MULTI_Q_MAX * ((size_t)m.grid * WG_SLOTS + std::max<uint32_t>(d.rows, 1u)) * 8));
+        if (d.stream_replicas > 1) {
+            m.d_sell_replicas.push_back(m.d_sell_packets);
+            for (int r = 1; r < d.stream_replicas; ++r) {
+                uint8_t *p = nullptr;
+                HIP_TRY(hipMalloc((void **)&p, sm.stream_bytes()));
+                HIP_TRY(hipMemcpy(p, m.d_sell_packets, sm.stream_bytes(), hipMemcpyDeviceToDevice));
+                m.d_sell_replicas.push_back(p);
+            }
+        }
+    }
     HIP_TRY(malloc_exchange((void **)&m.d_tickets, BATCH_MAX * 32 * 4));
     HIP_TRY(hipMemset(m.d_tickets, 0, BATCH_MAX * 32 * 4));
     {
         // Exchange-state sets: one block per field, set s at s strides (the batch kernel addresses them that way).
-        const int n_sets_alloc = m.can_batch ? EngineImpl::N_STATE : (m.can_defer ? 2 : 1);
+        const int n_sets_alloc = (m.can_batch || m.can_multi) ? EngineImpl::N_STATE : (m.can_defer ? 2 : 1);
         const size_t ns = (size_t)n_sets_alloc;
         EngineImpl::ExState &E0 = m.st[0];
         HIP_TRY(malloc_exchange((void **)&E0.gmax, ns * EngineImpl::GMAX_WORDS * 4));
@@ -2215,6 +2752,8 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
     m.info.k_per_partition = d.k_per_partition > 0 ? d.k_per_partition : d.k;
     m.info.device = dev;
     m.info.num_cus = num_cus;
+    m.info.multi_q = m.can_multi ? (uint32_t)m.multi_q : 0u;
+    m.info.multi_bytes = m.can_multi ? m.sell_bytes : 0u;
     HIP_TRY(hipDeviceSynchronize());
     return TKSPMV_OK;
 }
@@ -2353,6 +2892,61 @@ int Engine::enqueue_list(const float *const *dev_xs, uint32_t *const *dev_idx, f
     HIP_TRY(hipSetDevice(m.device));
     m.launch_sequence(dev_xs, dev_idx, dev_val, count, s);
     HIP_TRY(hipGetLastError());
+    m.ran = true;
+    return TKSPMV_OK;
+}
+
+int Engine::enqueue_multi(const float *dev_xs, int32_t count, uint32_t *dev_idx, float *dev_val, void *stream,
+                          std::string &err) {
+    EngineImpl &m = *impl_;
+    if (!dev_xs || count < 0 || (dev_idx == nullptr) != (dev_val == nullptr)) {
+        err = "bad arguments to enqueue_multi";
+        return TKSPMV_ERR_INVALID;
+    }
+    hipStream_t s = stream ? (hipStream_t)stream : m.stream;
+    HIP_TRY(hipSetDevice(m.device));
+    std::vector<const float *> xs;
+    std::vector<uint32_t *> oi;
+    std::vector<float *> ov;
+    sequence_lists(m, dev_xs, count > 0 ? count : 1, count, dev_idx ? dev_idx : m.d_out_idx, dev_val ? dev_val : m.d_out_val,
+                   dev_idx ? (size_t)m.desc.k : 0, xs, oi, ov);
+    m.launch_multi_sequence(xs.data(), oi.data(), ov.data(), count, s);
+    HIP_TRY(hipGetLastError());
+    m.ran = true;
+    return TKSPMV_OK;
+}
+
+int Engine::time_multi(const float *dev_xs, int32_t n_x, int32_t iters, double *ns_per_query, std::string &err) {
+    EngineImpl &m = *impl_;
+    if (!dev_xs || n_x < 1 || iters < 1 || !ns_per_query) {
+        err = "bad arguments to time_multi";
+        return TKSPMV_ERR_INVALID;
+    }
+    HIP_TRY(hipSetDevice(m.device));
+    HIP_TRY(hipStreamSynchronize(m.stream));
+    HIP_TRY(hipEventRecord(m.ev0, m.stream));
+    {
+        std::vector<const float *> xs;
+        std::vector<uint32_t *> oi;
+        std::vector<float *> ov;
+        sequence_lists(m, dev_xs, n_x, iters, m.d_out_idx, m.d_out_val, 0, xs, oi, ov);
+        m.launch_multi_sequence(xs.data(), oi.data(), ov.data(), iters, m.stream);
+    }
+    HIP_TRY(hipEventRecord(m.ev1, m.stream));
+    HIP_TRY(hipEventSynchronize(m.ev1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, m.ev0, m.ev1));
+    *ns_per_query = (double)ms * 1e6 / iters;
+    if (m.collect_stats) {  // TKSPMV_STATS=1: candidate-path counters of the multi-query kernel, per query
+        unsigned long long st[32];
+        HIP_TRY(hipMemcpy(st, m.d_stats, sizeof(st), hipMemcpyDeviceToHost));
+        const double n = (double)iters;
+        fprintf(stderr, "[tkspmv multi stats per query] judged slices: offers %.1f rows %.1f (tau<=0: %.1f) overflowed %.1f | held slices: offers %.1f rows %.1f "
+                        "(tau<=0: %.1f) overflowed %.1f | waits %.1f, %.2f us each\n",
+                st[4] / n, st[5] / n, st[6] / n, st[7] / n, st[8] / n, st[9] / n, st[10] / n, st[11] / n, st[12] / n,
+                st[12] ? st[13] * 0.01 / st[12] : 0.0);
+        HIP_TRY(hipMemset(m.d_stats, 0, 32 * 8));
+    }
     m.ran = true;
     return TKSPMV_OK;
 }

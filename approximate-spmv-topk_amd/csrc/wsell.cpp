@@ -1,0 +1,205 @@
+// wsell.cpp -- host packer / decoder of the wave-sliced ELL layout (see wsell.hpp).
+#include "wsell.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+namespace tkspmv {
+
+std::string pack_wsell(uint32_t rows, uint32_t cols, uint64_t nnz, const uint32_t *row, const uint32_t *col, const float *val,
+                       uint32_t n_partitions_hint, SellMatrix &out) {
+    if (cols == 0 || cols > SELL_XCOLS) return "the multi-query layout is built for at most 1024 columns";
+    if (nnz > 0 && (!row || !col)) return "row/col arrays are NULL";
+    if (n_partitions_hint == 0) n_partitions_hint = 1;
+    out = SellMatrix();
+    out.rows = rows;
+    out.cols = cols;
+    out.nnz = nnz;
+    if (nnz == 0) return "";
+    for (uint64_t i = 1; i < nnz; ++i)
+        if (row[i] < row[i - 1]) return "COO rows are not sorted in non-decreasing order";
+    const uint32_t last_row = row[nnz - 1];
+    if (last_row >= rows) return "row id out of range (>= rows)";
+    std::vector<uint32_t> len((size_t)last_row + 1, 0u);
+    for (uint64_t i = 0; i < nnz; ++i) {
+        if (col[i] >= cols) return "column id out of range (>= cols)";
+        ++len[row[i]];
+    }
+    std::vector<uint64_t> start(len.size() + 1, 0);
+    uint32_t max_len = 0;
+    for (size_t r = 0; r < len.size(); ++r) {
+        start[r + 1] = start[r] + len[r];
+        max_len = std::max(max_len, len[r]);
+    }
+    // Units = non-empty rows; a row of more than SELL_SEG entries takes ceil(len / SELL_SEG) adjacent lanes (its length
+    // class is SELL_SEG). Units by length class, longest first, ties by row id (counting sort).
+    const uint32_t max_class = std::min(max_len, SELL_SEG);
+    std::vector<uint64_t> bucket((size_t)max_class + 2, 0);
+    for (uint32_t L : len) {
+        if (!L) continue;
+        if ((L + SELL_SEG - 1) / SELL_SEG > 64u) return "a row is too long for the multi-query layout (more than 4096 entries)";
+        ++bucket[max_class - std::min(L, SELL_SEG) + 1];
+    }
+    for (size_t b = 1; b < bucket.size(); ++b) bucket[b] += bucket[b - 1];
+    const uint64_t n_ne = bucket[max_class];  // rows with at least one entry
+    std::vector<uint32_t> order(n_ne);
+    for (uint32_t r = 0; r < (uint32_t)len.size(); ++r)
+        if (len[r]) order[bucket[max_class - std::min(len[r], SELL_SEG)]++] = r;
+
+    // Slices: 64 lanes filled in that order; a multi-lane row never straddles two slices (lanes left over stay empty).
+    struct Lane {
+        uint32_t row, first, n, depth;  // entries [first, first + n) of `row`; depth = index of the segment in its row
+        bool tail;                      // last segment of its row: the lane that ends up with the row's score
+    };
+    std::vector<Lane> lanes;             // 64 per slice, row == SELL_NO_ROW: lane without a row
+    std::vector<uint32_t> slice_chunks;  // chunks of every slice
+    {
+        uint32_t used = 64;  // lanes used in the open slice (64: none open)
+        for (uint64_t u = 0; u < n_ne; ++u) {
+            const uint32_t r = order[u], L = len[r], nseg = (L + SELL_SEG - 1) / SELL_SEG;
+            if (used + nseg > 64u) {
+                if (used < 64u) lanes.resize(lanes.size() + (64u - used), Lane{SELL_NO_ROW, 0, 0, 0, false});
+                slice_chunks.push_back((std::min(L, SELL_SEG) + 3) / 4);  // the slice's first lane is its longest
+                used = 0;
+            }
+            for (uint32_t g = 0; g < nseg; ++g)
+                lanes.push_back(Lane{r, g * SELL_SEG, std::min(SELL_SEG, L - g * SELL_SEG), g, g + 1 == nseg});
+            used += nseg;
+        }
+        if (used < 64u) lanes.resize(lanes.size() + (64u - used), Lane{SELL_NO_ROW, 0, 0, 0, false});
+    }
+    if (slice_chunks.size() > 0x7FFFFFFFull) return "matrix too large";
+    const uint32_t n_slices = (uint32_t)slice_chunks.size();
+    uint64_t n_chunks = 0;
+    for (uint32_t c : slice_chunks) n_chunks += c;
+    if (n_chunks > 0xFFFFFFFFull) return "matrix too large (chunk count overflows 32 bits)";
+
+    // Slices to wave partitions, longest processing time first: the slices come longest first; each goes to the partition
+    // holding the fewest chunks so far (ties: lowest partition). No slice is longer than 16 chunks, so the partitions end
+    // up within a slice of each other, and every partition gets long and short rows alike (equally strong group maxima
+    // for the threshold exchange).
+    const uint32_t P = std::min<uint32_t>(n_partitions_hint, n_slices);
+    std::vector<std::vector<uint32_t>> part_slices(P);
+    {
+        std::vector<std::pair<uint64_t, uint32_t>> heap;  // (chunks so far, partition): min-heap
+        heap.reserve(P);
+        for (uint32_t p = 0; p < P; ++p) heap.emplace_back(0, p);
+        auto cmp = [](const std::pair<uint64_t, uint32_t> &a, const std::pair<uint64_t, uint32_t> &b) { return a > b; };
+        std::make_heap(heap.begin(), heap.end(), cmp);
+        for (uint32_t s = 0; s < n_slices; ++s) {
+            std::pop_heap(heap.begin(), heap.end(), cmp);
+            auto &top = heap.back();
+            part_slices[top.second].push_back(s);
+            top.first += slice_chunks[s];
+            std::push_heap(heap.begin(), heap.end(), cmp);
+        }
+    }
+    out.n_slices = n_slices;
+    out.n_chunks = (uint32_t)n_chunks;
+    out.padded_entries = n_chunks * 256;
+    out.packets.assign((size_t)n_chunks * SellMatrix::PACKET_BYTES, 0);
+    out.slice_rows.assign((size_t)n_slices * 64, SELL_NO_ROW);
+    out.part_first.resize(P);
+    out.part_count.resize(P);
+    out.part_slice0.resize(P);
+
+    const float neg_inf = -std::numeric_limits<float>::infinity();
+    uint32_t chunk = 0, slice_out = 0;
+    for (uint32_t p = 0; p < P; ++p) {
+        out.part_first[p] = chunk;
+        out.part_slice0[p] = slice_out;
+        for (uint32_t s : part_slices[p]) {
+            const uint32_t nc = slice_chunks[s];
+            for (uint32_t l = 0; l < 64; ++l) {
+                const Lane &ln = lanes[(size_t)s * 64 + l];
+                const bool have = ln.row != SELL_NO_ROW;
+                if (have && ln.tail) out.slice_rows[(size_t)slice_out * 64 + l] = ln.row;
+                for (uint32_t c = 0; c < nc; ++c) {
+                    uint8_t *pkt = out.packets.data() + (size_t)(chunk + c) * SellMatrix::PACKET_BYTES;
+                    for (uint32_t j = 0; j < 4; ++j) {
+                        const uint32_t e = 4 * c + j;
+                        float v;
+                        uint16_t cw;
+                        if (have && e < ln.n) {
+                            const uint64_t src = start[ln.row] + ln.first + e;
+                            v = val ? val[src] : 1.0f;
+                            cw = (uint16_t)(col[src] << 2);
+                        } else if (!have && e == 0) {
+                            v = neg_inf;  // a lane without a row: its sum is -inf
+                            cw = (uint16_t)(SELL_PAD_ONE << 2);
+                        } else {
+                            v = 0.0f;  // (+0.0) * (-0.0) = -0.0: leaves every sum as it is
+                            cw = (uint16_t)(SELL_PAD_NEUTRAL << 2);
+                        }
+                        if (c + 1 == nc) {  // flags of the slice's last chunk
+                            if (j == 0) cw |= SELL_LAST_CHUNK;
+                            if (j >= 1) cw |= (uint16_t)((ln.depth >> (2 * (j - 1))) & 3u);  // segment index, 2 bits per word
+                        }
+                        std::memcpy(pkt + ((size_t)l * 4 + j) * 4, &v, 4);
+                        std::memcpy(pkt + 1024 + ((size_t)l * 4 + j) * 2, &cw, 2);
+                    }
+                }
+            }
+            chunk += nc;
+            ++slice_out;
+        }
+        out.part_count[p] = chunk - out.part_first[p];
+    }
+    return "";
+}
+
+void decode_wsell(const SellMatrix &sm, std::vector<uint32_t> &row, std::vector<uint32_t> &col, std::vector<float> &val) {
+    row.clear();
+    col.clear();
+    val.clear();
+    for (size_t p = 0; p < sm.part_first.size(); ++p) {
+        uint32_t slice = sm.part_slice0[p];
+        uint32_t c0 = sm.part_first[p];
+        const uint32_t c_end = c0 + sm.part_count[p];
+        while (c0 < c_end) {
+            uint32_t nc = 1;  // chunks of this slice: up to the one flagged as last
+            for (;; ++nc) {
+                uint16_t cw;
+                std::memcpy(&cw, sm.packets.data() + (size_t)(c0 + nc - 1) * SellMatrix::PACKET_BYTES + 1024, 2);
+                if (cw & SELL_LAST_CHUNK) break;
+            }
+            // segment index of every lane (flags of the last chunk); a lane with segment index d > 0 continues the row of
+            // the lane to its left, the row id sits on the row's last lane
+            uint32_t depth[64], owner[64];
+            const uint8_t *last = sm.packets.data() + (size_t)(c0 + nc - 1) * SellMatrix::PACKET_BYTES;
+            for (uint32_t l = 0; l < 64; ++l) {
+                uint16_t w[4];
+                std::memcpy(w, last + 1024 + (size_t)l * 8, 8);
+                depth[l] = (w[1] & 3u) | ((w[2] & 3u) << 2) | ((w[3] & 3u) << 4);
+            }
+            for (int l = 63; l >= 0; --l) {
+                const uint32_t r = sm.slice_rows[(size_t)slice * 64 + l];
+                owner[l] = (r != SELL_NO_ROW) ? r : ((l < 63 && depth[l + 1] != 0) ? owner[l + 1] : SELL_NO_ROW);
+            }
+            for (uint32_t l = 0; l < 64; ++l) {
+                const uint32_t r = owner[l];
+                if (r == SELL_NO_ROW) continue;
+                for (uint32_t c = 0; c < nc; ++c) {
+                    const uint8_t *pkt = sm.packets.data() + (size_t)(c0 + c) * SellMatrix::PACKET_BYTES;
+                    for (uint32_t j = 0; j < 4; ++j) {
+                        uint16_t cw;
+                        float v;
+                        std::memcpy(&cw, pkt + 1024 + ((size_t)l * 4 + j) * 2, 2);
+                        std::memcpy(&v, pkt + ((size_t)l * 4 + j) * 4, 4);
+                        const uint32_t cc = cw >> 2;
+                        if (cc >= SELL_XCOLS) continue;  // padding
+                        row.push_back(r);
+                        col.push_back(cc);
+                        val.push_back(v);
+                    }
+                }
+            }
+            c0 += nc;
+            ++slice;
+        }
+    }
+}
+
+}  // namespace tkspmv

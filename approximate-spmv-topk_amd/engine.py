@@ -18,7 +18,7 @@ from . import _lib
 class SpMV:
     def __init__(self, x, y, val, num_rows, num_cols, num_nnz=None, vec=None, k=20, debug=0, *, device=-1,
                  first_row=0, min_score=0.0, partitions=1, k_per_partition=0, precision=_lib.F32, waves_per_cu=0,
-                 threads_per_wg=0, nnz_per_lane=0, stream_replicas=0, fixed_width=0):
+                 threads_per_wg=0, nnz_per_lane=0, stream_replicas=0, fixed_width=0, multi_q=0):
         """x, y, val: row-sorted COO (row ids, column ids, values) as the FPGA host passes them
         (host_spmv_bscsr.cpp:585); val=None means all ones (-v). precision=FIXED: the FPGA's fixed-point real_type of
         `fixed_width` bits (8..32; 0 = 32, the reference's FIXED_WIDTH default, types.hpp:20)."""
@@ -37,6 +37,7 @@ class SpMV:
         d.waves_per_cu, d.threads_per_wg, d.nnz_per_lane = int(waves_per_cu), int(threads_per_wg), int(nnz_per_lane)
         d.stream_replicas = int(stream_replicas)
         d.fixed_width = int(fixed_width)
+        d.multi_q = int(multi_q)
         _lib.check(_lib.lib().tkspmv_create(C.byref(self._h), C.byref(d)))
         self.k = int(k)
         self.num_rows, self.num_cols, self.num_nnz = int(num_rows), int(num_cols), nnz
@@ -46,7 +47,7 @@ class SpMV:
 
     @classmethod
     def from_packed(cls, packed, k=20, debug=0, *, vec=None, device=-1, first_row=0, min_score=0.0, precision=None,
-                    stream_replicas=0):
+                    stream_replicas=0, multi_q=0):
         """Engine straight from a packed matrix (host.Packed, e.g. Packed.load("matrix.tkspmv")): no MatrixMarket
         parsing, no packing. precision: None = the packed value type (F32 / Q1_7 / F16 / FIXED), or Q1_7_WIDE for Q1.7 values."""
         self = cls.__new__(cls)
@@ -58,6 +59,7 @@ class SpMV:
         d.precision = info["precision"] if precision is None else precision
         d.device, d.first_row, d.min_score = int(device), int(first_row), float(min_score)
         d.stream_replicas = int(stream_replicas)
+        d.multi_q = int(multi_q)
         _lib.check(_lib.lib().tkspmv_create_packed(C.byref(self._h), packed._h, C.byref(d)))
         self.k = int(k)
         self.num_rows, self.num_cols, self.num_nnz = info["rows"], info["cols"], info["nnz"]
@@ -116,6 +118,20 @@ class SpMV:
                                                    C.c_void_p(int(dev_idx)) if dev_idx else None,
                                                    C.c_void_p(int(dev_val)) if dev_val else None,
                                                    C.c_void_p(int(stream))))
+
+    def enqueue_multi(self, dev_xs, count, dev_idx=0, dev_val=0, stream=0):
+        """enqueue_batch with several queries per pass over the matrix (info()["multi_q"] of them share every packet that
+        is loaded); same arguments, same results bit for bit. No host sync."""
+        _lib.check(_lib.lib().tkspmv_enqueue_multi(self._h, C.c_void_p(int(dev_xs)), int(count),
+                                                   C.c_void_p(int(dev_idx)) if dev_idx else None,
+                                                   C.c_void_p(int(dev_val)) if dev_val else None,
+                                                   C.c_void_p(int(stream))))
+
+    def time_multi(self, dev_xs, n_x, iters):
+        """ns per query of `iters` queries through the multi-query path (one hipEvent pair around the sequence)."""
+        ns = C.c_double()
+        _lib.check(_lib.lib().tkspmv_time_multi(self._h, C.c_void_p(int(dev_xs)), int(n_x), int(iters), C.byref(ns)))
+        return ns.value
 
     def synchronize(self):
         _lib.check(_lib.lib().tkspmv_synchronize(self._h))

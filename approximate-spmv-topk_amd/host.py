@@ -105,6 +105,29 @@ class Options:
                        bool(o.use_half_precision_gpu), o.block_size_1d, o.block_size_2d, o.num_blocks)
 
 
+def sell_roundtrip(m, n_wave_partitions=4088):
+    """Packs m into the wave-sliced ELL layout of the multi-query kernel and decodes it again (layout tests):
+    (row, col, val, info) with the entries grouped by row, rows in stream order; info = dict of the layout's sizes."""
+    row = np.ascontiguousarray(m.row, dtype=np.uint32)
+    col = np.ascontiguousarray(m.col, dtype=np.uint32)
+    val = np.ascontiguousarray(m.val, dtype=np.float32)
+    d = _lib.Desc()
+    d.rows, d.cols, d.nnz = m.rows, m.cols, row.shape[0]
+    d.row = row.ctypes.data_as(C.POINTER(C.c_uint32))
+    d.col = col.ctypes.data_as(C.POINTER(C.c_uint32))
+    d.val = val.ctypes.data_as(C.POINTER(C.c_float))
+    nn = max(int(d.nnz), 1)
+    orow, ocol, oval = np.empty(nn, np.uint32), np.empty(nn, np.uint32), np.empty(nn, np.float32)
+    n = C.c_uint64()
+    info = (C.c_uint64 * 6)()
+    _lib.check(_lib.lib().tkspmv_sell_roundtrip(
+        C.byref(d), int(n_wave_partitions), orow.ctypes.data_as(C.POINTER(C.c_uint32)), ocol.ctypes.data_as(C.POINTER(C.c_uint32)),
+        oval.ctypes.data_as(C.POINTER(C.c_float)), C.byref(n), info))
+    n = int(n.value)
+    keys = ("slices", "chunks", "padded_entries", "partitions", "stream_bytes", "most_chunks_per_partition")
+    return orow[:n], ocol[:n], oval[:n], dict(zip(keys, (int(v) for v in info)))
+
+
 class Packed:
     """Host-side packed (wave-BSCSR) matrix, for layout tests: decode(pack(A)) == A."""
 

@@ -95,7 +95,9 @@ typedef struct {
                                  that consecutive queries cannot be served from the 256 MiB Infinity Cache; 0/1 = off */
     int32_t fixed_width;      /* TKSPMV_FIXED: bits per value, 8..32 (0 => 32, the reference's default FIXED_WIDTH,
                                  types.hpp:20); must be 0 for the other precisions */
-    int32_t reserved[3];
+    int32_t multi_q;          /* queries per matrix pass of tkspmv_enqueue_multi: 0 = off (default), 1, 2, 4 or 8. When set, the
+                                 engine keeps a second copy of the matrix in the wave-sliced ELL layout (info.multi_bytes) */
+    int32_t reserved[2];
 } tkspmv_desc;
 
 typedef struct {
@@ -114,7 +116,10 @@ typedef struct {
     int32_t k, partitions, k_per_partition, precision, device;
     uint32_t num_cus;
     uint32_t fixed_width;         /* TKSPMV_FIXED: bits per value; 0 otherwise */
-    uint32_t reserved[6];
+    uint32_t multi_q;             /* queries per matrix pass of tkspmv_enqueue_multi; 0 = this engine has no multi-query kernel */
+    uint32_t reserved0;
+    uint64_t multi_bytes;         /* bytes of the wave-sliced ELL copy the multi-query kernel streams (0 without it) */
+    uint32_t reserved[2];
 } tkspmv_info;
 
 typedef struct {
@@ -155,6 +160,18 @@ int tkspmv_enqueue_many(tkspmv_t *e, const float *dev_xs, int32_t n_x, int32_t c
  * dev_val + i * k (both NULL => engine-owned buffers, last query wins). Same launch scheme as enqueue_many. */
 int tkspmv_enqueue_batch(tkspmv_t *e, const float *dev_xs, int32_t count, uint32_t *dev_idx, float *dev_val,
                          void *stream);
+/* Several queries per pass over the matrix (an extension: the reference streams its matrix once per
+ * query vector, host_spmv_bscsr.cpp:602-622). Same arguments and result contract as tkspmv_enqueue_batch. Needs
+ * desc.multi_q != 0 at create time: info.multi_q queries share every chunk of the wave-sliced ELL copy of the matrix that
+ * is loaded (x is held multi_q times in LDS; every query has its own accumulators, threshold, candidate lists and
+ * exchange state). One lane owns one row and sums it in the row's own entry order, i.e. in the order of the reference's
+ * gold (gold_algorithms.hpp:188-246): scores are bit-identical to the gold's sequential fp32 sums (tkspmv_run's differ
+ * from those in the last bits: its sums follow the packet layout). Engines without the kernel (info.multi_q == 0:
+ * desc.multi_q = 0, reduced precisions, more than 1024 columns, fewer publishing groups than k) run the ordinary
+ * back-to-back sequence. */
+int tkspmv_enqueue_multi(tkspmv_t *e, const float *dev_xs, int32_t count, uint32_t *dev_idx, float *dev_val, void *stream);
+/* tkspmv_time_queries for the multi-query path: *ns_per_query = time of the whole sequence / iters. */
+int tkspmv_time_multi(tkspmv_t *e, const float *dev_xs, int32_t n_x, int32_t iters, double *ns_per_query);
 int tkspmv_synchronize(tkspmv_t *e);
 
 /* Copy back the k results of the last completed query, sorted by (score desc, row desc)
@@ -251,6 +268,11 @@ int tkspmv_packed_decode(const tkspmv_packed *p, uint32_t *row, uint32_t *col, f
 int tkspmv_packed_raw(const tkspmv_packed *p, const void **packets, uint64_t *packet_bytes, const uint32_t **pkt_row,
                       const uint32_t **part_first, const uint32_t **part_count, uint32_t *n_parts);
 void tkspmv_packed_free(tkspmv_packed *p);
+/* The same for the wave-sliced ELL layout of the multi-query kernel (wsell.hpp): packs desc's COO for
+ * n_wave_partitions_hint waves and decodes it again into caller arrays sized >= nnz (entries grouped by row, rows in
+ * stream order). info[0..5] = slices, chunks, padded entries, partitions, stream bytes, most chunks in one partition. */
+int tkspmv_sell_roundtrip(const tkspmv_desc *desc, uint32_t n_wave_partitions_hint, uint32_t *row, uint32_t *col, float *val,
+                          uint64_t *n, uint64_t *info);
 
 /* ---- packed-matrix cache ------------------------------------------------------------------------
  * The reference parses the MatrixMarket text (utils.hpp:380-388, minutes at 10^7 rows) and packs

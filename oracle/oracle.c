@@ -123,6 +123,33 @@ void oracle_scores_f64(const uint32_t *row, const uint32_t *col, const float *va
     }
 }
 
+/* The multi-query kernel's order (wsell.hpp): a row is summed sequentially in segments of `seg` entries, the segment sums
+ * are added left to right. seg >= the longest row: oracle_scores_f32_seq. */
+void oracle_scores_f32_segmented(const uint32_t *row, const uint32_t *col, const float *val, uint64_t nnz, const float *vec,
+                                 uint32_t rows, uint32_t seg, float *y, uint8_t *present) {
+    memset(y, 0, (size_t)rows * sizeof(float));
+    if (present) memset(present, 0, rows);
+    uint64_t i = 0;
+    while (i < nnz) {
+        const uint32_t r = row[i];
+        float total = 0.0f;
+        uint32_t n_seg = 0;
+        while (i < nnz && row[i] == r) {
+            float s = 0.0f;
+            for (uint32_t e = 0; e < seg && i < nnz && row[i] == r; ++e, ++i) {
+                const float p = val[i] * vec[col[i]];
+                s = s + p;
+            }
+            total = n_seg == 0 ? s : total + s;
+            ++n_seg;
+        }
+        if (r < rows) {
+            y[r] = total;
+            if (present) present[r] = 1;
+        }
+    }
+}
+
 /* ------------------------------------------------------------------------------------------------------------
  * Q1.7 integer model (see oracle.h). Integer arithmetic is associative, so the summation order is irrelevant.
  * ---------------------------------------------------------------------------------------------------------- */

@@ -78,6 +78,15 @@ def scores_f32_seq(row, col, val, vec, rows):
     return y[:rows], present[:rows]
 
 
+def scores_f32_segmented(row, col, val, vec, rows, seg=64):
+    row, col, val, vec = _u32(row), _u32(col), _f32(val), _f32(vec)
+    y = np.zeros(max(rows, 1), dtype=np.float32)
+    present = np.zeros(max(rows, 1), dtype=np.uint8)
+    oracle().oracle_scores_f32_segmented(_p(row, u32p), _p(col, u32p), _p(val, f32p), C.c_uint64(row.shape[0]), _p(vec, f32p),
+                                         C.c_uint32(rows), C.c_uint32(seg), _p(y, f32p), _p(present, u8p))
+    return y[:rows], present[:rows]
+
+
 def scores_f64(row, col, val, vec, rows):
     row, col, val, vec = _u32(row), _u32(col), _f32(val), _f32(vec)
     y = np.zeros(max(rows, 1), dtype=np.float64)

@@ -558,6 +558,134 @@ def test_native_sharded_step_single_rank(pkg, oracle, monkeypatch, force_nccl):
     eng.close()
 
 
+# ---- several queries per pass over the matrix (tkspmv_enqueue_multi) -------------------------------------
+@pytest.mark.parametrize("mq", [1, 2, 4, 8])
+@pytest.mark.parametrize("rows,k,nq", [(70000, 100, 11), (1000000, 100, 9), (3000, 8, 5), (200000, 1, 4), (40000, 500, 6)])
+def test_multi_query_passes_are_bit_identical_to_the_gold_order(pkg, oracle, mq, rows, k, nq):
+    """The multi-query kernel sums every row in its own entry order -- the gold's sequential fp32 order; rows of more
+    than 64 entries in segments of 64 -- so each query's list must equal, bit for bit, the exact selection over
+    oracle_scores_f32_segmented. Groups of multi_q queries
+    share a pass, the last group is partial, consecutive calls alternate the state-set halves; the one-query-per-pass
+    path must agree with it on the index set (its scores follow the packet order: last-bit differences)."""
+    import torch
+    m = pkg.generate_matrix(rows, 1024, 20, "gamma", 77)
+    xs = np.stack([pkg.create_sample_vector(1024, True, False, True, 300 + i) for i in range(nq)])
+    xs[1] *= np.float32(0.01)  # queries of one pass with very different score scales: thresholds must not mix
+    dxs = torch.from_numpy(xs).cuda()
+    eng = pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, k=k, device=0, stream_replicas=2, multi_q=mq)
+    assert eng.info()["multi_q"] == mq and eng.info()["multi_bytes"] > 6 * m.nnz
+    want = []
+    for q in range(nq):
+        y, present = oracle.scores_f32_segmented(m.row, m.col, m.val, xs[q], m.rows)
+        want.append(oracle.select_topk(y, present, k))
+    out_i = torch.full((nq, k), -1, dtype=torch.int32, device="cuda")
+    out_v = torch.full((nq, k), -1.0, dtype=torch.float32, device="cuda")
+    for rep in range(3):
+        out_i.fill_(-1)
+        out_v.fill_(-1.0)
+        eng.enqueue_multi(dxs.data_ptr(), nq, out_i.data_ptr(), out_v.data_ptr())
+        eng.synchronize()
+        for q in range(nq):
+            ei, ev = want[q]
+            assert np.array_equal(out_i[q].cpu().numpy().view(np.uint32), ei), (rep, q)
+            assert np.array_equal(out_v[q].cpu().numpy().view(np.uint32), ev.view(np.uint32)), (rep, q)
+    # engine-owned buffers: the last query wins; the other entry points still work right after
+    eng.enqueue_multi(dxs.data_ptr(), nq)
+    val, idx = eng.read_result()
+    assert np.array_equal(idx, want[nq - 1][0]) and np.array_equal(val, want[nq - 1][1])
+    eng.enqueue_batch(dxs.data_ptr(), nq, out_i.data_ptr(), out_v.data_ptr())
+    eng.synchronize()
+    eng.reset_device(dxs[0].data_ptr())
+    eng()
+    val, idx = eng.read_result()
+    for q, (i_, v_) in ((2, (out_i[2].cpu().numpy().view(np.uint32), out_v[2].cpu().numpy())), (0, (idx, val))):
+        ei, ev = want[q]
+        if k < rows and len(np.unique(ev)) == k:
+            assert len(set(i_.tolist()) ^ set(ei.tolist())) <= 2  # a K-th-boundary near-tie may swap
+            assert np.allclose(np.sort(v_), np.sort(ev), rtol=1e-5)
+    eng.close()
+
+
+def test_multi_query_scores_are_the_reference_golds(pkg, oracle):
+    """Against the gold itself (spmv_coo_gold_top_k + sort_tuples restated; the reference's own when oracle/_ref is
+    present): same rows in the same order; score BITS equal for every row of at most 64 entries (longer rows are summed
+    in segments: within 1e-6 relative)."""
+    import torch
+    m = pkg.generate_matrix(300000, 1024, 20, "gamma", 12)
+    lens = np.bincount(m.row, minlength=m.rows)
+    xs = np.stack([pkg.create_sample_vector(1024, True, False, True, 70 + i) for i in range(4)])
+    dxs = torch.from_numpy(xs).cuda()
+    eng = pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, k=100, device=0, multi_q=4)
+    out_i = torch.zeros((4, 100), dtype=torch.int32, device="cuda")
+    out_v = torch.zeros((4, 100), dtype=torch.float32, device="cuda")
+    eng.enqueue_multi(dxs.data_ptr(), 4, out_i.data_ptr(), out_v.data_ptr())
+    eng.synchronize()
+    n_bit_equal = 0
+    for q in range(4):
+        gi, gv = oracle.gold_topk(m.row, m.col, m.val, xs[q], 100)
+        if oracle.have_ref():
+            ri, rv = oracle.ref_gold_topk(m.row, m.col, m.val, xs[q], 100)
+            assert np.array_equal(ri, gi) and np.array_equal(rv, gv)
+        assert len(np.unique(gv)) == 100 and np.all(gv > 0)
+        hi, hv = out_i[q].cpu().numpy().view(np.uint32), out_v[q].cpu().numpy()
+        assert set(hi.tolist()) == set(gi.tolist())
+        assert np.allclose(hv, gv, rtol=1e-6, atol=0)
+        pos = {int(r): j for j, r in enumerate(gi)}
+        for j, r in enumerate(hi):
+            if lens[r] <= 64:
+                assert hv[j].view(np.uint32) == gv[pos[int(r)]].view(np.uint32), (q, int(r))
+                n_bit_equal += 1
+    assert n_bit_equal >= 20  # (the best rows of a normalised matrix are mostly its long rows)
+    eng.close()
+
+
+def test_multi_query_edge_cases(pkg, oracle):
+    """Signed values and negative min_score (lanes without a row must never surface), empty rows, k > rows, duplicates."""
+    import torch
+    rng = np.random.RandomState(3)
+    lens = ([0, 3, 1, 0, 40, 300, 2, 7] * 40)[:-3]
+    row = np.repeat(np.arange(len(lens)), lens).astype(np.uint32)
+    col = rng.randint(0, 100, row.shape[0]).astype(np.uint32)
+    val = (rng.rand(row.shape[0]).astype(np.float32) - np.float32(0.5))
+    m = pkg.CooMatrix(len(lens), 100, row, col, val)
+    xs = (rng.rand(3, 100).astype(np.float32) - np.float32(0.5))
+    dxs = torch.from_numpy(xs).cuda()
+    for k, min_score in ((16, -10.0), (400, -10.0), (16, 0.0)):
+        eng = pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, k=k, device=0, multi_q=2, min_score=min_score)
+        out_i = torch.zeros((3, k), dtype=torch.int32, device="cuda")
+        out_v = torch.zeros((3, k), dtype=torch.float32, device="cuda")
+        eng.enqueue_multi(dxs.data_ptr(), 3, out_i.data_ptr(), out_v.data_ptr())
+        eng.synchronize()
+        for q in range(3):
+            y, present = oracle.scores_f32_segmented(m.row, m.col, m.val, xs[q], m.rows)
+            ei, ev = oracle.select_topk(y, present, k, min_score)
+            assert np.array_equal(out_i[q].cpu().numpy().view(np.uint32), ei), (k, min_score, q)
+            assert np.array_equal(out_v[q].cpu().numpy().view(np.uint32), ev.view(np.uint32)), (k, min_score, q)
+        eng.close()
+
+
+def test_multi_query_falls_back_where_the_kernel_does_not_apply(pkg):
+    """Wide x (or multi_q = 0): info.multi_q == 0 and enqueue_multi runs the ordinary sequence, same results as run()."""
+    import torch
+    m = pkg.generate_matrix(30000, 2000, 20, "gamma", 5)
+    xs = np.stack([pkg.create_sample_vector(2000, True, False, True, 40 + i) for i in range(5)])
+    dxs = torch.from_numpy(xs).cuda()
+    eng = pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, k=50, device=0, multi_q=4)
+    assert eng.info()["multi_q"] == 0 and eng.info()["multi_bytes"] == 0
+    out_i = torch.zeros((5, 50), dtype=torch.int32, device="cuda")
+    out_v = torch.zeros((5, 50), dtype=torch.float32, device="cuda")
+    eng.enqueue_multi(dxs.data_ptr(), 5, out_i.data_ptr(), out_v.data_ptr())
+    eng.synchronize()
+    for q in range(5):
+        eng.reset_device(dxs[q].data_ptr())
+        eng()
+        val, idx = eng.read_result()
+        assert np.array_equal(out_i[q].cpu().numpy().view(np.uint32), idx) and np.array_equal(out_v[q].cpu().numpy(), val)
+    eng.close()
+    with pytest.raises(pkg.TkspmvError):
+        pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, k=50, device=0, multi_q=3)
+
+
 # ---- batches: the selection of query i rides inside the launch of query i+1 (deferred selection) ----------------------
 @pytest.mark.parametrize("precision", ["F32", "Q1_7", "Q1_7_WIDE", "F16"])
 @pytest.mark.parametrize("defer", ["1", "0"])

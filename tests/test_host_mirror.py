@@ -256,6 +256,48 @@ def test_fixed_point_model_known_answers(oracle):
     assert np.array_equal(y8, yq) and np.array_equal(p8, pq)
 
 
+# ---- wave-sliced ELL layout of the multi-query kernel (wsell.hpp) ------------------------------------------------------
+@pytest.mark.parametrize("rows,cols,nnz,dist,parts", [(5000, 1024, 20, "gamma", 64), (700, 64, 6, "uniform", 4088),
+                                                       (64, 16, 3, "uniform", 1), (130, 1024, 40, "gamma", 3)])
+def test_sliced_ell_round_trip(pkg, rows, cols, nnz, dist, parts):
+    """decode(pack(A)) gives every row back with its entries in their original order (duplicates kept, padding dropped),
+    rows sorted by length inside the stream; partitions are balanced; padding stays small."""
+    m = pkg.generate_matrix(rows, cols, nnz, dist, 4)
+    r, c, v, info = pkg.sell_roundtrip(m, parts)
+    assert r.shape[0] == m.nnz
+    order = np.argsort(r, kind="stable")  # back to row-major; stable keeps the order inside a row
+    assert np.array_equal(r[order], m.row) and np.array_equal(c[order], m.col)
+    assert np.array_equal(v[order].view(np.uint32), m.val.view(np.uint32))
+    lens = np.bincount(m.row)
+    n_lanes = int(np.ceil(lens[lens > 0] / 64).sum())  # a row of more than 64 entries takes several lanes
+    assert (n_lanes + 63) // 64 <= info["slices"] <= (n_lanes + 63) // 64 + 2 and info["partitions"] == min(parts, info["slices"])
+    assert info["padded_entries"] == info["chunks"] * 256 and info["stream_bytes"] == info["chunks"] * 1536
+    if rows >= 5000:
+        assert info["padded_entries"] < 1.15 * m.nnz  # sorted rows: what is lost is mostly the rounding to 4 entries
+        assert info["most_chunks_per_partition"] <= info["chunks"] / info["partitions"] + 16  # within one slice of the mean
+
+
+def test_sliced_ell_edge_cases(pkg):
+    """Empty rows vanish (they can never be candidates), a single row, a row longer than any chunk, one column."""
+    rng = np.random.RandomState(1)
+    lens = [0, 5, 0, 0, 1, 700, 2, 0]
+    row = np.repeat(np.arange(len(lens)), lens).astype(np.uint32)
+    col = rng.randint(0, 40, row.shape[0]).astype(np.uint32)
+    val = rng.rand(row.shape[0]).astype(np.float32)
+    m = pkg.CooMatrix(len(lens), 40, row, col, val)
+    r, c, v, info = pkg.sell_roundtrip(m, 16)
+    assert info["slices"] == 1 and info["chunks"] == 16 and info["partitions"] == 1  # 700 entries = 11 lanes of 64, + 3 rows
+    assert r.tolist()[:700] == [5] * 700  # the longest rows lead
+    order = np.argsort(r, kind="stable")
+    assert np.array_equal(r[order], row) and np.array_equal(c[order], col) and np.array_equal(v[order], val)
+    empty = pkg.CooMatrix(10, 8, np.zeros(0, np.uint32), np.zeros(0, np.uint32), np.zeros(0, np.float32))
+    r, c, v, info = pkg.sell_roundtrip(empty, 4)
+    assert r.shape[0] == 0 and info["chunks"] == 0
+    wide = pkg.generate_matrix(100, 2000, 5, "uniform", 1)
+    with pytest.raises(pkg.TkspmvError):
+        pkg.sell_roundtrip(wide, 4)
+
+
 def test_packed_file_rejects_damage(pkg, tmp_path):
     m = pkg.generate_matrix(500, 64, 8, "uniform", 3)
     p = pkg.Packed(m, n_wave_partitions=8)
