@@ -44,6 +44,10 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--queries", type=int, default=64, help="distinct query vectors resident in HBM")
     ap.add_argument("--skip-warm", action="store_true", help="skip the cache-warm leg (homogeneous launches for rocprofv3)")
+    ap.add_argument("--multi-q", type=int, nargs="*", default=[4, 8],
+                    help="queries per matrix pass of the multi-query leg (reported beside the headline; empty = skip)")
+    ap.add_argument("--multi-only", type=int, default=0,
+                    help="profiler runs: launch nothing but the multi-query path with this many queries per pass")
     return ap.parse_args()
 
 
@@ -81,6 +85,33 @@ def cpu_baseline(mod, m, xs, k, seconds):
         out["reference_gold_ms_per_query"] = 1e3 * (time.perf_counter() - t1) / reps
         out["reference_gold_note"] = "spmv_coo_gold_top_k + sort_tuples compiled from the reference headers, 1 thread"
     return out
+
+
+def multi_query_leg(mod, m, dxs, a, device, alg_bytes):
+    """Extension, reported beside the headline: several queries share each pass over the matrix
+    (tkspmv_enqueue_multi: the wave-sliced ELL copy, one row per lane). Same synthetic matrix and query vectors, cache-
+    defeated rotation; every query still gets its exact top-k. Time = one hipEvent pair around the whole sequence."""
+    out = []
+    for q in a.multi_q:
+        eng = mod.SpMV(m.row, m.col, m.val, m.rows, m.cols, k=a.k, device=device, stream_replicas=a.replicas, multi_q=q)
+        info = eng.info()
+        if info["multi_q"] != q:
+            eng.close()
+            continue
+        n = max(a.steps // (8 * q) * (8 * q), 8 * q)
+        eng.time_multi(dxs.data_ptr(), a.queries, n)
+        ns = min(eng.time_multi(dxs.data_ptr(), a.queries, n) for _ in range(3))
+        out.append({"queries_per_pass": q, "value": 1e9 / ns, "unit": "queries/s", "us_per_query": ns / 1e3,
+                    "us_per_pass": ns * q / 1e3, "queries_timed": n,
+                    "stream_bytes_per_pass": int(info["multi_bytes"]),
+                    "hbm_GBps_of_the_pass": info["multi_bytes"] / (ns * q),
+                    "per_query_algorithmic_GBps": alg_bytes / ns})
+        eng.close()
+    return {"kernel": "tkspmv::multi_kernel<Q> over the wave-sliced ELL copy of the matrix (one row per lane; exact top-k "
+                      "per query, scores in the gold's sequential fp32 order)",
+            "note": "a pass is bound by LDS reads and instruction issue, not by HBM: per-query algorithmic GB/s is not an "
+                    "HBM figure here and is not compared with the roofline",
+            "runs": out}
 
 
 def main():
@@ -124,6 +155,18 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    if not multi and a.multi_only:
+        # profiler aid: nothing but multi-query passes (warmup + steps queries), then one JSON line about them
+        eng.close()
+        eng = mod.SpMV(m.row, m.col, m.val, m.rows, m.cols, k=a.k, device=local_rank, stream_replicas=a.replicas,
+                       multi_q=a.multi_only)
+        eng.time_multi(dxs.data_ptr(), a.queries, a.warmup)
+        ns = eng.time_multi(dxs.data_ptr(), a.queries, a.steps)
+        print(json.dumps({"metric": "queries_per_sec", "mode": "multi_only", "queries_per_pass": a.multi_only,
+                          "value": 1e9 / ns, "us_per_query": ns / 1e3, "us_per_pass": ns * a.multi_only / 1e3,
+                          "steps": a.steps, "warmup": a.warmup}))
+        eng.close()
+        return
     if not multi:
         # ---- N = 1: K queries back to back on the engine stream -------------------------------------------------
         eng.enqueue_many(dxs.data_ptr(), a.queries, a.warmup)
@@ -164,6 +207,8 @@ def main():
                                   "Infinity Cache, not comparable with the HBM roofline"}
         units = a.steps
         extra = {"cache_warm": cache_warm}
+        if not a.skip_warm and a.multi_q:
+            extra["multi_query"] = multi_query_leg(mod, m, dxs, a, local_rank, alg_bytes)
         if "stream_kernel_ns" in prof:
             extra["kernels_us"] = {"query_back_to_back": prof["query_ns"] / 1e3,
                                    "single_query_fused_launch_with_event_bracket": prof["stream_kernel_ns"] / 1e3,

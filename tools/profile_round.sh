@@ -2,7 +2,8 @@
 # Round-end measurement on the GPU box (run from the repository root through gpurun):
 #   bash tools/profile_round.sh r01
 # 1. plain bench line; 2. the same command under rocprofv3 --kernel-trace --stats; 3. separate --pmc passes for the
-# memory-side counters (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE do not fit one pass; no trace domains with --pmc).
+# memory-side counters (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE do not fit one pass; no trace domains with --pmc);
+# 4. the multi-query path alone (8 and 4 queries per pass) under --kernel-trace --stats.
 # Everything lands in gpurun_out/prof_<tag>/; tools/summarize_profile.py turns it into the files kept under profiles/.
 set -u
 TAG=${1:-r01}
@@ -16,6 +17,9 @@ i=0
 for counters in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
     i=$((i + 1))
     rocprofv3 --pmc $counters --kernel-trace --output-format csv -d "$OUT/pmc$i" -- python3 "$REPO/bench.py" --steps 320 --warmup 32 --cpu-seconds 0 --skip-warm > "$OUT/pmc$i.json" 2> "$OUT/pmc$i.err"
+done
+for q in 8 4; do
+    rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/mtrace$q" -- python3 "$REPO/bench.py" --multi-only $q --steps 2048 --warmup 256 > "$OUT/multi$q.json" 2> "$OUT/mtrace$q.err"
 done
 cd "$REPO"
 python3 tools/summarize_profile.py "$OUT" "$TAG"

@@ -2,6 +2,7 @@
 """Condenses one tools/profile_round.sh run into the small files kept under profiles/:
   <tag>_kernel_stats.csv, <tag>_domain_stats.csv  (rocprofv3 --kernel-trace --stats, verbatim)
   <tag>_bench_plain.json, <tag>_bench_under_rocprofv3.json
+  <tag>_multi{8,4}_kernel_stats.csv, <tag>_multi{8,4}_under_rocprofv3.json  (the multi-query path alone)
   <tag>_pmc_summary.json   per-launch means of the counters for the stream kernel
   pmc_traffic.json         HBM-side bytes per launch (FETCH_SIZE doubled: gfx950 correction of MI355X_MICROARCH.md)
 Written next to the raw output (gpurun_out/prof_<tag>/summary/); copy that directory's content into profiles/."""
@@ -33,6 +34,16 @@ for src, name in (("bench_plain.json", f"{tag}_bench_plain.json"),
         lines = [l for l in open(p).read().splitlines() if l.startswith("{")]
         if lines:
             open(os.path.join(dst, name), "w").write(lines[-1] + "\n")
+
+for q in (8, 4):  # the multi-query path alone: per-kernel summary + the JSON line of that profiled run
+    src = find(f"mtrace{q}/**/*kernel_stats.csv")
+    if src:
+        shutil.copy(src, os.path.join(dst, f"{tag}_multi{q}_kernel_stats.csv"))
+    p = os.path.join(out, f"multi{q}.json")
+    if os.path.exists(p):
+        lines = [l for l in open(p).read().splitlines() if l.startswith("{")]
+        if lines:
+            open(os.path.join(dst, f"{tag}_multi{q}_under_rocprofv3.json"), "w").write(lines[-1] + "\n")
 
 summary = {}
 for d in sorted(glob.glob(os.path.join(out, "pmc*"))):
