@@ -2920,6 +2920,7 @@ int Engine::enqueue_list(const float *const *dev_xs, uint32_t *const *dev_idx, f
 int Engine::enqueue_multi(const float *dev_xs, int32_t count, uint32_t *dev_idx, float *dev_val, void *stream,
                           std::string &err) {
     EngineImpl &m = *impl_;
+    if (!dev_xs && count == 1) dev_xs = m.d_x_cur;  // the vector installed by tkspmv_set_query / set_query_device
     if (!dev_xs || count < 0 || (dev_idx == nullptr) != (dev_val == nullptr)) {
         err = "bad arguments to enqueue_multi";
         return TKSPMV_ERR_INVALID;

@@ -120,9 +120,10 @@ class SpMV:
                                                    C.c_void_p(int(stream))))
 
     def enqueue_multi(self, dev_xs, count, dev_idx=0, dev_val=0, stream=0):
-        """enqueue_batch with several queries per pass over the matrix (info()["multi_q"] of them share every packet that
-        is loaded); same arguments, same results bit for bit. No host sync."""
-        _lib.check(_lib.lib().tkspmv_enqueue_multi(self._h, C.c_void_p(int(dev_xs)), int(count),
+        """enqueue_batch with several queries per pass over the matrix (info()["multi_q"] of them share every chunk that
+        is loaded; engine created with multi_q > 0). Same arguments; dev_xs = 0 with count = 1: the vector installed by
+        reset(). No host sync."""
+        _lib.check(_lib.lib().tkspmv_enqueue_multi(self._h, C.c_void_p(int(dev_xs)) if dev_xs else None, int(count),
                                                    C.c_void_p(int(dev_idx)) if dev_idx else None,
                                                    C.c_void_p(int(dev_val)) if dev_val else None,
                                                    C.c_void_p(int(stream))))

@@ -921,3 +921,34 @@ def test_batch_corner_counts_and_a_long_run(pkg, oracle):
     val, idx = eng.read_result()
     assert np.array_equal(idx, single[(20000 - 1) % nx][1]) and np.array_equal(val, single[(20000 - 1) % nx][0])
     eng.close()
+
+
+def test_multi_query_small_counts_and_k_above_the_publishing_groups(pkg, oracle):
+    """count = 0 and 1; k too large for a threshold to form (exchange off: no multi-query kernel, the sequence runs)."""
+    import torch
+    m = pkg.generate_matrix(50000, 512, 20, "uniform", 9)
+    xs = np.stack([pkg.create_sample_vector(512, True, False, True, 5 + i) for i in range(2)])
+    dxs = torch.from_numpy(xs).cuda()
+    eng = pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, k=10, device=0, multi_q=8)
+    out_i = torch.full((2, 10), -1, dtype=torch.int32, device="cuda")
+    out_v = torch.full((2, 10), -1.0, dtype=torch.float32, device="cuda")
+    eng.enqueue_multi(dxs.data_ptr(), 0, out_i.data_ptr(), out_v.data_ptr())
+    eng.synchronize()
+    assert int(out_i.min()) == -1 and int(out_i.max()) == -1
+    eng.enqueue_multi(dxs.data_ptr(), 1, out_i.data_ptr(), out_v.data_ptr())
+    eng.synchronize()
+    y, present = oracle.scores_f32_segmented(m.row, m.col, m.val, xs[0], m.rows)
+    ei, ev = oracle.select_topk(y, present, 10)
+    assert np.array_equal(out_i[0].cpu().numpy().view(np.uint32), ei) and np.array_equal(out_v[0].cpu().numpy(), ev)
+    assert int(out_i[1].max()) == -1
+    eng.close()
+    big = pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, k=1024, device=0, multi_q=4)
+    if big.info()["n_groups"] == 0:  # fewer publishing groups than k
+        assert big.info()["multi_q"] == 0
+    oi = torch.zeros((2, 1024), dtype=torch.int32, device="cuda")
+    ov = torch.zeros((2, 1024), dtype=torch.float32, device="cuda")
+    big.enqueue_multi(dxs.data_ptr(), 2, oi.data_ptr(), ov.data_ptr())
+    big.synchronize()
+    v = ov[1].cpu().numpy()
+    assert np.all(v[:-1] >= v[1:]) and len(set(oi[1].cpu().numpy().tolist())) == 1024
+    big.close()
