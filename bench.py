@@ -277,11 +277,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         prof = eng.profile(dxs.data_ptr(), a.queries, 200)
-        kernel_ns = prof["query_ns"]
+        kernel_ns = eng.time_queries(dxs.data_ptr(), a.queries, min(max(a.steps, 50), 500))  # as at N = 1
         units = a.steps * world
         extra = {"global_queries_per_sec": a.steps / elapsed,
                  "kernels_us": {"stream": prof["stream_kernel_ns"] / 1e3, "select": prof["select_kernel_ns"] / 1e3,
-                                "query_back_to_back": prof["query_ns"] / 1e3},
+                                "query_back_to_back": kernel_ns / 1e3},
                  "exchange": exchange}
 
     if rank == 0:
