@@ -18,8 +18,11 @@ for counters in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
     i=$((i + 1))
     rocprofv3 --pmc $counters --kernel-trace --output-format csv -d "$OUT/pmc$i" -- python3 "$REPO/bench.py" --steps 320 --warmup 32 --cpu-seconds 0 --skip-warm > "$OUT/pmc$i.json" 2> "$OUT/pmc$i.err"
 done
+# (one chain of launches, so that a launch's duration is the time of its pass; bench.py's figure overlaps two chains)
+export TKSPMV_MULTI_CHAINS=1
 for q in 8 4; do
     rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/mtrace$q" -- python3 "$REPO/bench.py" --multi-only $q --steps 2048 --warmup 256 > "$OUT/multi$q.json" 2> "$OUT/mtrace$q.err"
 done
+unset TKSPMV_MULTI_CHAINS
 cd "$REPO"
 python3 tools/summarize_profile.py "$OUT" "$TAG"
