@@ -108,7 +108,8 @@ def multi_query_leg(mod, m, dxs, a, device, alg_bytes):
                     "per_query_algorithmic_GBps": alg_bytes / ns})
         eng.close()
     return {"kernel": "tkspmv::multi_kernel<Q> over the wave-sliced ELL copy of the matrix (one row per lane; exact top-k "
-                      "per query, scores in the gold's sequential fp32 order)",
+                      "per query, scores in the gold's sequential fp32 order); a sequence runs as two independent chains of "
+                      "launches on two streams (one launch = one pass of one chain)",
             "note": "a pass is bound by LDS reads and instruction issue, not by HBM: per-query algorithmic GB/s is not an "
                     "HBM figure here and is not compared with the roofline",
             "runs": out}
