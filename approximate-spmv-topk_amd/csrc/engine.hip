@@ -1720,11 +1720,17 @@ __device__ __forceinline__ SelectParams select_params_of_set(const SelectParams 
     return S;
 }
 
-// The selections still owed to the last group of a sequence (one after the other: they share the general path's scratch).
-__global__ void __launch_bounds__(SEL_THREADS) select_group_kernel(const SelectParams SP0, const SetAddr A, const MultiGroup G) {
+// The selections still owed to the last group of a sequence: one workgroup per query, each with its own general-path
+// scratch. Queries that share a result buffer (the engine-owned pair: "the last query wins") are selected one after the
+// other by workgroup 0 instead.
+__global__ void __launch_bounds__(SEL_THREADS) select_group_kernel(const SelectParams SP0, const SetAddr A, const MultiGroup G,
+                                                                   unsigned long long *scratch0, uint64_t scratch_stride,
+                                                                   uint32_t serial) {
     __shared__ SelectShared S;
-    for (uint32_t q = 0; q < G.n_q; ++q) {
-        const SelectParams P = select_params_of_set(SP0, A, G.set0 + q, G.io[q]);
+    const uint32_t q0 = serial ? 0u : blockIdx.x, q1 = serial ? G.n_q : blockIdx.x + 1u;
+    for (uint32_t q = q0; q < q1 && q < G.n_q; ++q) {
+        SelectParams P = select_params_of_set(SP0, A, G.set0 + q, G.io[q]);
+        P.scratch = scratch0 + (size_t)q * scratch_stride;
         select_body(P, threadIdx.x, blockDim.x, S);
         __syncthreads();
     }
@@ -2241,7 +2247,11 @@ struct EngineImpl {
         if (pending_group[c].n_q == 0u) return;
         SelectParams S = select_params(nullptr, nullptr, 0);
         S.pos_to_row = d_sell_rows;
-        hipLaunchKernelGGL(select_group_kernel, dim3(1), dim3(SEL_THREADS), 0, s, S, set_addr(0), pending_group[c]);
+        const MultiGroup &G = pending_group[c];
+        const bool serial = G.n_q > 1u && G.io[0].out_idx == G.io[1].out_idx;
+        hipLaunchKernelGGL(select_group_kernel, dim3(serial ? 1u : G.n_q), dim3(SEL_THREADS), 0, s, S, set_addr(0), G,
+                           d_multi_scratch + (size_t)c * MULTI_Q_MAX * ((uint64_t)grid * WG_SLOTS + ovf_cap),
+                           (uint64_t)grid * WG_SLOTS + ovf_cap, serial ? 1u : 0u);
         pending_group[c].n_q = 0u;
     }
     SetAddr set_addr(int s0) const {
