@@ -242,11 +242,12 @@ static int dist_flush(Dist &d) {
     const int b = (int)(d.flushes & 1);
     const int n_q = d.fill;
     {
-        // The local step of the whole batch as ONE back-to-back sequence (the engine's batch kernel when available):
-        // its launch overhead is paid once per exchange batch, like the collective's.
+        // The local step of the whole batch as ONE back-to-back sequence (the engine's batch kernel when available; passes
+        // of several queries each when the engine was created with desc.multi_q): its launch overhead is paid once per
+        // exchange batch, like the collective's.
         if (d.flushes >= 2) DHIP(hipStreamWaitEvent(d.compute, d.ev_merge[b], 0));  // buffer set b is free again
         std::string err;
-        int st = d.engine->enqueue_list(d.pend_x, d.pend_idx, d.pend_val, n_q, d.compute, err);
+        int st = d.engine->enqueue_multi_list(d.pend_x, d.pend_idx, d.pend_val, n_q, d.compute, err);
         if (st != TKSPMV_OK) return dfail(st, err);
     }
     DHIP(hipEventRecord(d.ev_comp[b], d.compute));

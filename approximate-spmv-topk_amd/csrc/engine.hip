@@ -2987,6 +2987,21 @@ int Engine::enqueue_multi(const float *dev_xs, int32_t count, uint32_t *dev_idx,
     return TKSPMV_OK;
 }
 
+int Engine::enqueue_multi_list(const float *const *dev_xs, uint32_t *const *dev_idx, float *const *dev_val, int32_t count,
+                               void *stream, std::string &err) {
+    EngineImpl &m = *impl_;
+    if (!dev_xs || !dev_idx || !dev_val || count < 0) {
+        err = "bad arguments to enqueue_multi_list";
+        return TKSPMV_ERR_INVALID;
+    }
+    hipStream_t s = stream ? (hipStream_t)stream : m.stream;
+    HIP_TRY(hipSetDevice(m.device));
+    m.launch_multi_sequence(dev_xs, dev_idx, dev_val, count, s);
+    HIP_TRY(hipGetLastError());
+    m.ran = true;
+    return TKSPMV_OK;
+}
+
 int Engine::time_multi(const float *dev_xs, int32_t n_x, int32_t iters, double *ns_per_query, std::string &err) {
     EngineImpl &m = *impl_;
     if (!dev_xs || n_x < 1 || iters < 1 || !ns_per_query) {

@@ -30,6 +30,9 @@ class Engine {
     // Queries in passes of several per matrix pass (multi_kernel); same contract as enqueue_batch.
     int enqueue_multi(const float *dev_xs, int32_t count, uint32_t *dev_idx, float *dev_val, void *stream, std::string &err);
     int time_multi(const float *dev_xs, int32_t n_x, int32_t iters, double *ns_per_query, std::string &err);
+    // enqueue_list through the multi-query path when the engine has one (desc.multi_q), else the ordinary sequence
+    int enqueue_multi_list(const float *const *dev_xs, uint32_t *const *dev_idx, float *const *dev_val, int32_t count,
+                           void *stream, std::string &err);
     // A back-to-back sequence given as lists of device pointers (count entries each); complete in stream order.
     int enqueue_list(const float *const *dev_xs, uint32_t *const *dev_idx, float *const *dev_val, int32_t count,
                      void *stream, std::string &err);

@@ -204,7 +204,8 @@ int tkspmv_device_count(void);
  * local + first_row at :415). One level up: every rank owns an engine over its row shard (desc.first_row = first
  * global row), per query the local fused kernel, ONE RCCL all-gather of k (row, score) pairs per rank and a merge
  * kernel. Queries are exchanged in batches (default 32, TKSPMV_DIST_BATCH / tkspmv_dist_set_batch; 1 = every query on
- * its own): the local step of a batch is launched as one back-to-back sequence when the batch closes, then one
+ * its own): the local step of a batch is launched as one back-to-back sequence when the batch closes (passes of several
+ * queries each if the engine was created with desc.multi_q), then one
  * all-gather and one merge launch per batch on a side stream, overlapping the local step of the next batch (two buffer
  * sets). synchronize / read flush an open batch; a query vector passed to tkspmv_dist_enqueue must stay valid until then. Every rank must issue the same call sequence. RCCL is
  * loaded with dlopen inside tkspmv_dist_create / tkspmv_dist_unique_id: TKSPMV_ERR_UNSUPPORTED if it cannot be loaded. */

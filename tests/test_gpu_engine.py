@@ -559,8 +559,9 @@ def test_native_merge_kernel_matches_python_merge(pkg):
         assert np.array_equal(ov.cpu().numpy(), ev.cpu().numpy())
 
 
+@pytest.mark.parametrize("multi_q", [0, 4])
 @pytest.mark.parametrize("force_nccl", [False, True])
-def test_native_sharded_step_single_rank(pkg, oracle, monkeypatch, force_nccl):
+def test_native_sharded_step_single_rank(pkg, oracle, monkeypatch, force_nccl, multi_q):
     """world = 1: the pipelined native step (and, forced, a one-rank RCCL communicator with a real ncclAllGather)
     must return exactly what the engine returns, for a stream of queries."""
     import torch
@@ -571,7 +572,8 @@ def test_native_sharded_step_single_rank(pkg, oracle, monkeypatch, force_nccl):
     m = pkg.generate_matrix(80000, 1024, 20, "gamma", 17)
     xs = np.stack([pkg.create_sample_vector(1024, True, False, True, 900 + i) for i in range(6)])
     dxs = torch.from_numpy(xs).cuda()
-    eng = pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, k=100, device=0, first_row=5000)
+    # multi_q = 4: the local step of an exchange batch runs as passes of four queries each
+    eng = pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, k=100, device=0, first_row=5000, multi_q=multi_q)
     nat = dmod.NativeShardedSpMV(eng, torch.device("cuda", 0))
     nat.set_batch(4)  # reads at q = 2 flush a partial batch, q = 5 lands in the middle of the next one
     for q in range(6):
