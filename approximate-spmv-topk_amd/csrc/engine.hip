@@ -2714,6 +2714,12 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
             err = "multi_q must be 0 (off), 1, 2, 4 or 8";
             return TKSPMV_ERR_INVALID;
         }
+        // 8 queries per pass need 91 registers: one workgroup per CU, i.e. only half of the streaming workgroups (and of the
+        // publishing groups) are resident at a time. A threshold is the k-th largest of the published maxima: with k above
+        // a quarter of the groups it cannot form before the first half of the grid is done (measured at k = 500: every
+        // wave ran into its bounded wait and then poured its rows into the overflow list, 2 ms per query). Such engines
+        // run 4 queries per pass instead (two workgroups per CU, all groups resident).
+        if (mq == 8 && (uint32_t)d.k * 4u > m.n_groups_pub) mq = 4;
         m.multi_q = mq;
         m.can_multi = mq > 0 && m.can_defer && m.n_sets != 0u && d.cols <= SELL_XCOLS && d.precision == TKSPMV_F32 && m.pm.nnz > 0 &&
                       m.grid > 2u * (uint32_t)MULTI_Q_MAX;

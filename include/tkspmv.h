@@ -96,7 +96,9 @@ typedef struct {
     int32_t fixed_width;      /* TKSPMV_FIXED: bits per value, 8..32 (0 => 32, the reference's default FIXED_WIDTH,
                                  types.hpp:20); must be 0 for the other precisions */
     int32_t multi_q;          /* queries per matrix pass of tkspmv_enqueue_multi: 0 = off (default), 1, 2, 4 or 8. When set, the
-                                 engine keeps a second copy of the matrix in the wave-sliced ELL layout (info.multi_bytes) */
+                                 engine keeps a second copy of the matrix in the wave-sliced ELL layout (info.multi_bytes);
+                                 info.multi_q tells what the engine uses (8 becomes 4 when k exceeds a quarter of the
+                                 threshold groups, 0 when the kernel does not apply) */
     int32_t reserved[2];
 } tkspmv_desc;
 
