@@ -1936,17 +1936,28 @@ __global__ void __launch_bounds__(576, Q >= 8 ? 4 : 6) multi_kernel(const Stream
                 off[j] = (j & 1) ? ((word >> 16) & 0xFFFCu) : (word & 0xFFFCu);  // byte offset of x[col]
             }
             if (IL) {
+                // Two queries per VALU instruction: v_pk_mul_f32 / v_pk_add_f32 work on a pair of fp32 lanes each, every
+                // product and every sum rounded on its own exactly like the scalar forms (the file is built with
+                // -ffp-contract=off: no fused multiply-add is formed).
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
                 const unsigned char *xb = reinterpret_cast<const unsigned char *>(L.u.w.x);
+                f32x2 a2[Q >= 2 ? Q / 2 : 1];
+#pragma unroll
+                for (int h = 0; h < Q / 2; ++h) a2[h] = f32x2{acc[2 * h], acc[2 * h + 1]};
 #pragma unroll
                 for (int j = 0; j < C; ++j) {
+                    const f32x2 vv = {cur.v[j], cur.v[j]};
 #pragma unroll
                     for (int h = 0; h < Q / 4; ++h) {
                         const float4 xv = *reinterpret_cast<const float4 *>(xb + off[j] * (uint32_t)Q + 16u * (uint32_t)h);
-                        acc[4 * h + 0] = __fadd_rn(acc[4 * h + 0], __fmul_rn(cur.v[j], xv.x));
-                        acc[4 * h + 1] = __fadd_rn(acc[4 * h + 1], __fmul_rn(cur.v[j], xv.y));
-                        acc[4 * h + 2] = __fadd_rn(acc[4 * h + 2], __fmul_rn(cur.v[j], xv.z));
-                        acc[4 * h + 3] = __fadd_rn(acc[4 * h + 3], __fmul_rn(cur.v[j], xv.w));
+                        a2[2 * h + 0] = a2[2 * h + 0] + vv * f32x2{xv.x, xv.y};
+                        a2[2 * h + 1] = a2[2 * h + 1] + vv * f32x2{xv.z, xv.w};
                     }
+                }
+#pragma unroll
+                for (int h = 0; h < Q / 2; ++h) {
+                    acc[2 * h] = a2[h].x;
+                    acc[2 * h + 1] = a2[h].y;
                 }
             } else {
 #pragma unroll
@@ -2135,7 +2146,7 @@ struct EngineImpl {
     uint8_t *d_sell_packets = nullptr;
     std::vector<uint8_t *> d_sell_replicas;
     uint32_t *d_sell_rows = nullptr, *d_sell_part_first = nullptr, *d_sell_part_count = nullptr, *d_sell_part_slice0 = nullptr;
-    uint32_t sell_parts = 0;
+    uint32_t sell_parts = 0, multi_stream_waves = 8;
     uint64_t sell_bytes = 0;
     uint32_t *d_multi_out_idx = nullptr;  // [2 * MULTI_Q_MAX][k] results of tkspmv_time_multi
     float *d_multi_out_val = nullptr;
@@ -2302,10 +2313,11 @@ struct EngineImpl {
         ++launch_counter;
         SelectParams S = select_params(nullptr, nullptr, 0);
         S.pos_to_row = d_sell_rows;
-        if (multi_q <= 1) hipLaunchKernelGGL(multi_kernel<1>, dim3(grid), dim3(block + 64), 0, s, P, S, M);
-        else if (multi_q <= 2) hipLaunchKernelGGL(multi_kernel<2>, dim3(grid), dim3(block + 64), 0, s, P, S, M);
-        else if (multi_q <= 4) hipLaunchKernelGGL(multi_kernel<4>, dim3(grid), dim3(block + 64), 0, s, P, S, M);
-        else hipLaunchKernelGGL(multi_kernel<8>, dim3(grid), dim3(block + 64), 0, s, P, S, M);
+        const dim3 mblock(multi_stream_waves * 64u + 64u);
+        if (multi_q <= 1) hipLaunchKernelGGL(multi_kernel<1>, dim3(grid), mblock, 0, s, P, S, M);
+        else if (multi_q <= 2) hipLaunchKernelGGL(multi_kernel<2>, dim3(grid), mblock, 0, s, P, S, M);
+        else if (multi_q <= 4) hipLaunchKernelGGL(multi_kernel<4>, dim3(grid), mblock, 0, s, P, S, M);
+        else hipLaunchKernelGGL(multi_kernel<8>, dim3(grid), mblock, 0, s, P, S, M);
         pending_group[chain] = M.cur;
         multi_parity[chain] ^= 1;
     }
@@ -2714,11 +2726,10 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
             err = "multi_q must be 0 (off), 1, 2, 4 or 8";
             return TKSPMV_ERR_INVALID;
         }
-        // 8 queries per pass need 91 registers: one workgroup per CU, i.e. only half of the streaming workgroups (and of the
-        // publishing groups) are resident at a time. A threshold is the k-th largest of the published maxima: with k above
-        // a quarter of the groups it cannot form before the first half of the grid is done (measured at k = 500: every
-        // wave ran into its bounded wait and then poured its rows into the overflow list, 2 ms per query). Such engines
-        // run 4 queries per pass instead (two workgroups per CU, all groups resident).
+        // A threshold is the k-th largest of the published group maxima. With k above a quarter of the groups it forms late
+        // and stays weak; with 8 queries per pass the private lists are half as long (64 entries) and the held slices
+        // fewer: measured at k = 500 (while that kernel still ran one workgroup per CU) every wave ran into its bounded
+        // wait and then poured its rows into the overflow list, 2 ms per query. Such engines run 4 queries per pass.
         if (mq == 8 && (uint32_t)d.k * 4u > m.n_groups_pub) mq = 4;
         m.multi_q = mq;
         m.can_multi = mq > 0 && m.can_defer && m.n_sets != 0u && d.cols <= SELL_XCOLS && d.precision == TKSPMV_F32 && m.pm.nnz > 0 &&
@@ -2726,7 +2737,10 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
     }
     if (m.can_multi) {
         // the first MULTI_Q_MAX workgroups of a multi-query launch are its selectors, the others stream
-        const uint32_t n_multi_waves = (m.grid - (uint32_t)MULTI_Q_MAX) * waves_per_wg;
+        // 8 queries per pass need 91 registers: with 9 waves per workgroup only one workgroup fits a CU (the dispatcher wants
+        // 6 waves on one SIMD for two); with 8 waves -- 7 streaming + the server -- two fit at up to 128 registers.
+        m.multi_stream_waves = (m.multi_q >= 8 && waves_per_wg == 8u) ? 7u : waves_per_wg;
+        const uint32_t n_multi_waves = (m.grid - (uint32_t)MULTI_Q_MAX) * m.multi_stream_waves;
         SellMatrix sm;
         std::string perr;
         if (prepacked) {  // no COO at hand: decode the packed matrix
