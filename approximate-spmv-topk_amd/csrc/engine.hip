@@ -1678,7 +1678,7 @@ struct MultiGeom {
     static constexpr uint32_t WAVE_CAP = Q <= 4 ? 128u : 64u;
     // Slices whose scores a wave can hold back in registers (one float per lane, slice and query) while no threshold has
     // arrived yet
-    static constexpr int HOLD = Q <= 2 ? 6 : (Q <= 4 ? 4 : 2);
+    static constexpr int HOLD = Q <= 2 ? 6 : 4;
 };
 struct MultiGroup {  // a group of queries sharing one pass; their exchange-state sets are set0 .. set0 + n_q - 1
     uint32_t n_q, set0;
