@@ -1665,11 +1665,16 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0, co
 // (wsell.hpp): one lane owns one row, so a non-zero costs one LDS read, one multiply and one add per query and there is
 // no cross-lane scan (measured first on the wave-BSCSR stream: there the segmented scan, ~12 VALU instructions per
 // non-zero and query, made 4 queries per pass SLOWER per query than one query per pass -- 28 us against 21 us).
-// Row sums are accumulated in the row's own entry order = the order of the reference's gold: bit-identical scores.
+// Row sums are accumulated in the row's own entry order = the order of the reference's gold (rows of more than 64
+// entries: in segments of 64): bit-identical scores.
 // Q copies of x in LDS, Q accumulators per lane, Q thresholds, Q private candidate lists per wave, Q exchange-state
-// sets. Launch structure = deferred selection: workgroup 0 selects the top-k lists of the PREVIOUS group of queries
-// while workgroups 1.. stream the current one. Cold start of the threshold exchange: the scores of a wave's first
-// slices (one float per lane, slice and query) wait in registers and are judged at the end of the partition.
+// sets. Launch structure = deferred selection: workgroups 0..7 select the top-k lists of the PREVIOUS group of queries
+// (one query each) while workgroups 8.. stream the current one; a sequence runs as two independent chains of such
+// launches on two streams. Cold start of the threshold exchange: the scores of a wave's leading slices (one float per
+// lane, slice and query) wait in registers while no threshold has arrived, and are judged at the end of the partition;
+// beyond that a wave waits (once, bounded) rather than judge 64 rows per slice without a threshold.
+// Workgroup size: 8 streaming waves + the server; for Q = 8 (91 registers) 7 + the server, so that two workgroups fit a
+// CU (the host packs the stream for that many partitions).
 // ------------------------------------------------------------------------------------------------------------
 constexpr int MULTI_Q_MAX = 8;
 // entries of a wave's private candidate list, per query (LDS: 8 waves x Q lists)
