@@ -2737,8 +2737,10 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
         // wait and then poured its rows into the overflow list, 2 ms per query. Such engines run 4 queries per pass.
         if (mq == 8 && (uint32_t)d.k * 4u > m.n_groups_pub) mq = 4;
         m.multi_q = mq;
+        // (k above half of the groups: the threshold is next to useless -- k = 1000 on 1024 groups measured 3.6 ms per query
+        // through the multi-query kernel against 0.2 ms one query per pass; such engines keep the ordinary sequence)
         m.can_multi = mq > 0 && m.can_defer && m.n_sets != 0u && d.cols <= SELL_XCOLS && d.precision == TKSPMV_F32 && m.pm.nnz > 0 &&
-                      m.grid > 2u * (uint32_t)MULTI_Q_MAX;
+                      m.grid > 2u * (uint32_t)MULTI_Q_MAX && (uint32_t)d.k * 2u <= m.n_groups_pub;
     }
     if (m.can_multi) {
         // the first MULTI_Q_MAX workgroups of a multi-query launch are its selectors, the others stream

@@ -608,8 +608,9 @@ def test_multi_query_passes_are_bit_identical_to_the_gold_order(pkg, oracle, mq,
     xs[1] *= np.float32(0.01)  # queries of one pass with very different score scales: thresholds must not mix
     dxs = torch.from_numpy(xs).cuda()
     eng = pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, k=k, device=0, stream_replicas=2, multi_q=mq)
-    # (8 queries per pass fall back to 4 when k exceeds a quarter of the threshold groups)
-    assert eng.info()["multi_q"] == (4 if mq == 8 and 4 * k > eng.info()["n_groups"] else mq)
+    # (8 queries per pass fall back to 4 when k exceeds a quarter of the threshold groups; no multi-query kernel above half)
+    ng = eng.info()["n_groups"]
+    assert eng.info()["multi_q"] == (0 if 2 * k > ng else (4 if mq == 8 and 4 * k > ng else mq))
     assert eng.info()["multi_bytes"] > 6 * m.nnz
     want = []
     for q in range(nq):
