@@ -24,6 +24,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <string>
 #include <vector>
 
@@ -2091,6 +2092,120 @@ __global__ void __launch_bounds__(576, Q >= 8 ? 4 : 6) multi_kernel(const Stream
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Large k: scores + radix select. The threshold exchange needs k well below the number of publishing groups (at most
+// 1024); beyond that the k-th largest group maximum is a weak bound (k = 500: 96 us per query, k = 1000: 207 us) and
+// for k = 1023, 1024 it cannot form at all (every row becomes a candidate: 33 ms). Such engines take the reference GPU
+// host's route (host_spmv_topk_csr_gpu.cu:171-231: full y, then a selection over all rows), with a selection that is
+// not a sort: the SpMV-only variant of the stream kernel writes every row's score, four 8-bit histogram passes over the
+// order keys find the k-th largest key T exactly, a filter pass appends the rows with key >= T (k of them plus ties) to
+// the overflow list, and the ordinary selection kernel ranks those (score desc, row desc). Rows below min_score and
+// rows without entries (their score slot keeps -inf) never count.
+// ------------------------------------------------------------------------------------------------------------
+struct RadixParams {
+    const float *scores;  // [rows]; -inf where a row has no entry
+    uint32_t rows, k;
+    uint32_t kmin;        // order key of min_score: keys below it are not eligible
+    uint32_t *hist;       // [4][256], zeroed before the first pass
+    unsigned long long *ovf_cand;
+    uint32_t *ovf_count;
+    uint32_t ovf_cap;
+};
+constexpr uint32_t RADIX_THREADS = 1024;
+
+// From the histograms of passes 0 .. n_pass-1: the key prefix decided so far and how many keys of the next pass's bins
+// are still wanted. Called by wave 0; take_all: fewer eligible keys than k exist (every eligible row is a result).
+__device__ __forceinline__ void radix_decide(const RadixParams &R, int n_pass, uint32_t lane, uint32_t &prefix, uint32_t &k_rem,
+                                             bool &take_all) {
+    prefix = 0u;
+    k_rem = R.k;
+    take_all = false;
+    for (int q = 0; q < n_pass; ++q) {
+        uint32_t h[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) h[j] = __hip_atomic_load(&R.hist[q * 256 + 4 * (int)lane + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t tot = h[0] + h[1] + h[2] + h[3];
+        uint32_t above = tot;  // inclusive suffix sum over lanes >= this one ...
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = (uint32_t)__shfl_down((int)above, d);
+            above += (lane + (uint32_t)d < 64u) ? o : 0u;
+        }
+        above -= tot;  // ... made exclusive: keys in the bins of higher lanes
+        uint32_t hit_bin = 0xFFFFFFFFu, hit_above = 0u;
+        uint32_t c = above;
+#pragma unroll
+        for (int j = 3; j >= 0; --j) {  // bins from the top
+            if (hit_bin == 0xFFFFFFFFu && c < k_rem && c + h[j] >= k_rem) {
+                hit_bin = 4u * lane + (uint32_t)j;
+                hit_above = c;
+            }
+            c += h[j];
+        }
+        const uint64_t hb = __ballot(hit_bin != 0xFFFFFFFFu);
+        if (hb == 0ull) {  // fewer than k_rem keys left (only possible in pass 0: the bins of a later pass hold >= k_rem)
+            take_all = true;
+            return;
+        }
+        const int src = __builtin_ctzll(hb);
+        const uint32_t bin = (uint32_t)__shfl((int)hit_bin, src);
+        k_rem -= (uint32_t)__shfl((int)hit_above, src);
+        prefix = (prefix << 8) | bin;
+    }
+}
+
+__global__ void __launch_bounds__(RADIX_THREADS) radix_hist_kernel(const RadixParams R, const int pass) {
+    __shared__ uint32_t lh[256];
+    __shared__ uint32_t sh_prefix, sh_take_all;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    if (tid < 256u) lh[tid] = 0u;
+    if (tid < 64u) {
+        uint32_t prefix, k_rem;
+        bool take_all;
+        radix_decide(R, pass, lane, prefix, k_rem, take_all);
+        if (tid == 0u) {
+            sh_prefix = prefix;
+            sh_take_all = take_all ? 1u : 0u;
+        }
+    }
+    __syncthreads();
+    if (sh_take_all) return;
+    const uint32_t prefix = sh_prefix, shift = 24u - 8u * (uint32_t)pass;
+    for (uint32_t i = blockIdx.x * RADIX_THREADS + tid; i < R.rows; i += gridDim.x * RADIX_THREADS) {
+        const uint32_t key = order_key(R.scores[i]);
+        if (key >= R.kmin && (pass == 0 || (key >> (shift + 8u)) == prefix)) atomicAdd(&lh[(key >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (tid < 256u && lh[tid] != 0u) atomicAdd(&R.hist[pass * 256 + (int)tid], lh[tid]);
+}
+
+__global__ void __launch_bounds__(RADIX_THREADS) radix_filter_kernel(const RadixParams R) {
+    __shared__ uint32_t sh_thr;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    if (tid < 64u) {
+        uint32_t prefix, k_rem;
+        bool take_all;
+        radix_decide(R, 4, lane, prefix, k_rem, take_all);
+        if (tid == 0u) sh_thr = (take_all || prefix < R.kmin) ? R.kmin : prefix;
+    }
+    __syncthreads();
+    const uint32_t thr = sh_thr;
+    const uint32_t n_iter = (R.rows + gridDim.x * RADIX_THREADS - 1u) / (gridDim.x * RADIX_THREADS);  // uniform trip count
+    for (uint32_t it = 0; it < n_iter; ++it) {
+        const uint32_t i = (it * gridDim.x + blockIdx.x) * RADIX_THREADS + tid;
+        const float sc = i < R.rows ? R.scores[i] : -__builtin_huge_valf();
+        const bool keep = i < R.rows && order_key(sc) >= thr;
+        const uint64_t bm = __ballot(keep);
+        uint32_t base = 0u;
+        if (lane == 0u && bm) base = atomicAdd(R.ovf_count, (uint32_t)__popcll(bm));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (keep) {
+            const uint32_t pos = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
+            if (pos < R.ovf_cap) R.ovf_cand[pos] = pack_cand(__float_as_uint(sc), i);
+        }
+    }
+}
+
 // Empty kernel with the stream kernel's geometry: calibrates what an event bracket adds around one launch.
 __global__ void __launch_bounds__(576) null_kernel(const uint32_t *p) {
     if (p == nullptr && threadIdx.x == 123456u) __builtin_trap();
@@ -2148,6 +2263,10 @@ struct EngineImpl {
     // drain()). Groups alternate between the exchange-state sets [0, MULTI_Q_MAX) and [MULTI_Q_MAX, 2 * MULTI_Q_MAX).
     bool can_multi = false;
     int multi_q = 0;
+    // Large k (see radix_hist_kernel): every query = scores kernel + radix select + the selection kernel
+    bool use_radix = false;
+    float *d_rscores = nullptr;   // [rows], -inf where a row has no entry (never written by the scores kernel)
+    uint32_t *d_rhist = nullptr;  // [4][256]
     uint8_t *d_sell_packets = nullptr;
     std::vector<uint8_t *> d_sell_replicas;
     uint32_t *d_sell_rows = nullptr, *d_sell_part_first = nullptr, *d_sell_part_count = nullptr, *d_sell_part_slice0 = nullptr;
@@ -2351,6 +2470,10 @@ struct EngineImpl {
     // fused into its tail, the select kernel.
     void launch_query(const float *x, uint32_t *out_idx, float *out_val, hipStream_t s) const {
         drain(s);
+        if (use_radix) {
+            launch_query_radix(x, out_idx, out_val, s);
+            return;
+        }
         launch_stream(x, out_idx, out_val, s);
         if (!fused) launch_select(out_idx, out_val, s);
     }
@@ -2449,8 +2572,33 @@ struct EngineImpl {
         ++launch_counter;
         hipLaunchKernelGGL(kernel_for(false), dim3(grid), dim3(block + 64), 0, s, P, S);
     }
-    void launch_scores(const float *x, hipStream_t s) const {
+    void launch_query_radix(const float *x, uint32_t *out_idx, float *out_val, hipStream_t s) const {
+        launch_scores(x, s, d_rscores);
+        RadixParams R{};
+        R.scores = d_rscores;
+        R.rows = desc.rows;
+        R.k = (uint32_t)desc.k;
+        {  // order key of min_score (the device function's host twin)
+            uint32_t u;
+            std::memcpy(&u, &desc.min_score, 4);
+            R.kmin = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+        }
+        R.hist = d_rhist;
+        R.ovf_cand = st[0].ovf;
+        R.ovf_count = st[0].ovf_count;
+        R.ovf_cap = ovf_cap;
+        (void)hipMemsetAsync(d_rhist, 0, 4 * 256 * 4, s);
+        const uint32_t rgrid = std::max(1u, std::min(256u, (desc.rows + RADIX_THREADS * 4u - 1u) / (RADIX_THREADS * 4u)));
+        for (int pass = 0; pass < 4; ++pass) hipLaunchKernelGGL(radix_hist_kernel, dim3(rgrid), dim3(RADIX_THREADS), 0, s, R, pass);
+        hipLaunchKernelGGL(radix_filter_kernel, dim3(rgrid), dim3(RADIX_THREADS), 0, s, R);
+        SelectParams S = select_params(out_idx, out_val, 0);
+        S.use_gmax = 0u;  // no threshold word in this path
+        S.out_scale = 1.0f;  // the scores kernel already wrote final scores
+        hipLaunchKernelGGL(select_kernel, dim3(1), dim3(SEL_THREADS), 0, s, S);
+    }
+    void launch_scores(const float *x, hipStream_t s, float *dst = nullptr) const {
         StreamParams P = stream_params(x);
+        if (dst) P.scores = dst;
         SelectParams S = select_params(d_out_idx, d_out_val);
         hipLaunchKernelGGL(kernel_for(true), dim3(grid), dim3(block + 64), 0, s, P, S);
     }
@@ -2507,7 +2655,7 @@ Engine::~Engine() {
     for (size_t r = 1; r < m.d_replicas.size(); ++r) (void)hipFree(m.d_replicas[r]);
     for (size_t r = 1; r < m.d_sell_replicas.size(); ++r) (void)hipFree(m.d_sell_replicas[r]);
     {
-        void *sb[] = {m.d_sell_packets, m.d_sell_rows, m.d_sell_part_first, m.d_sell_part_count, m.d_sell_part_slice0, m.d_multi_scratch, m.d_multi_out_idx, m.d_multi_out_val};
+        void *sb[] = {m.d_sell_packets, m.d_sell_rows, m.d_sell_part_first, m.d_sell_part_count, m.d_sell_part_slice0, m.d_multi_scratch, m.d_multi_out_idx, m.d_multi_out_val, m.d_rscores, m.d_rhist};
         for (void *b : sb)
             if (b) (void)hipFree(b);
     }
@@ -2723,6 +2871,19 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
     if (const char *f = getenv("TKSPMV_DEFER")) m.can_defer = m.can_defer && atoi(f) != 0;
     m.can_batch = m.can_defer && m.n_sets != 0u && m.xcols <= 1024u && (C == 4u || (C == 8u && d.precision == TKSPMV_F32));  // larger x: two workgroups no longer fit a CU
     if (const char *f = getenv("TKSPMV_BATCH")) m.can_batch = m.can_batch && atoi(f) != 0;
+    // Large k: the scores + radix-select path wherever the threshold exchange is off or next to useless (k above
+    // 3/8 of the publishing groups: measured cross-over on the BASELINE matrix, tools/k_probe.py). TKSPMV_RADIX=0/1 forces.
+    m.use_radix = m.n_sets == 0u || (uint64_t)d.k * 8u > (uint64_t)m.n_groups_pub * 3u;
+    if (const char *f = getenv("TKSPMV_RADIX")) m.use_radix = atoi(f) != 0;
+    if (m.use_radix) {
+        m.can_defer = m.can_batch = false;
+        m.fused = false;
+        const size_t n = std::max<size_t>(d.rows, 1);
+        HIP_TRY(hipMalloc((void **)&m.d_rscores, n * 4));
+        std::vector<float> ninf(n, -std::numeric_limits<float>::infinity());
+        HIP_TRY(hipMemcpy(m.d_rscores, ninf.data(), n * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc((void **)&m.d_rhist, 4 * 256 * 4));
+    }
     // Multi-query passes (desc.multi_q; TKSPMV_MULTI_Q overrides): a second copy of the matrix in the wave-sliced ELL layout.
     {
         int mq = d.multi_q;
@@ -2739,7 +2900,7 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
         m.multi_q = mq;
         // (k above half of the groups: the threshold is next to useless -- k = 1000 on 1024 groups measured 3.6 ms per query
         // through the multi-query kernel against 0.2 ms one query per pass; such engines keep the ordinary sequence)
-        m.can_multi = mq > 0 && m.can_defer && m.n_sets != 0u && d.cols <= SELL_XCOLS && d.precision == TKSPMV_F32 && m.pm.nnz > 0 &&
+        m.can_multi = mq > 0 && !m.use_radix && m.can_defer && m.n_sets != 0u && d.cols <= SELL_XCOLS && d.precision == TKSPMV_F32 && m.pm.nnz > 0 &&
                       m.grid > 2u * (uint32_t)MULTI_Q_MAX && (uint32_t)d.k * 2u <= m.n_groups_pub;
     }
     if (m.can_multi) {
@@ -3235,9 +3396,10 @@ int Engine::profile(const float *dev_xs, int32_t n_x, int32_t iters, tkspmv_timi
         for (int i = 0; i < iters; ++i) {
             const float *x = dev_xs + (size_t)(i % n_x) * stride;
             HIP_TRY(hipEventRecord(evs[2 * i], m.stream));
-            m.launch_stream(x, m.d_out_idx, m.d_out_val, m.stream);
+            if (m.use_radix) m.launch_query(x, m.d_out_idx, m.d_out_val, m.stream);  // (scores + radix select + selection)
+            else m.launch_stream(x, m.d_out_idx, m.d_out_val, m.stream);
             HIP_TRY(hipEventRecord(evs[2 * i + 1], m.stream));
-            if (!m.fused) m.launch_select(m.d_out_idx, m.d_out_val, m.stream);
+            if (!m.fused && !m.use_radix) m.launch_select(m.d_out_idx, m.d_out_val, m.stream);
         }
         HIP_TRY(hipEventRecord(evs[2 * iters], m.stream));
         HIP_TRY(hipEventSynchronize(evs[2 * iters]));
@@ -3274,7 +3436,7 @@ int Engine::profile(const float *dev_xs, int32_t n_x, int32_t iters, tkspmv_timi
             HIP_TRY(hipEventRecord(evs[2 * i], m.stream));
             hipLaunchKernelGGL(null_kernel, dim3(m.grid), dim3(m.block + 64), 0, m.stream, m.st[0].gmax);
             HIP_TRY(hipEventRecord(evs[2 * i + 1], m.stream));
-            if (!m.fused) m.launch_select(m.d_out_idx, m.d_out_val, m.stream);
+            if (!m.fused && !m.use_radix) m.launch_select(m.d_out_idx, m.d_out_val, m.stream);
         }
         HIP_TRY(hipStreamSynchronize(m.stream));
         for (int i = 0; i < n; ++i) {

@@ -990,3 +990,42 @@ def test_multi_query_small_counts_and_k_above_the_publishing_groups(pkg, oracle)
     v = ov[1].cpu().numpy()
     assert np.all(v[:-1] >= v[1:]) and len(set(oi[1].cpu().numpy().tolist())) == 1024
     big.close()
+
+
+# ---- large k: scores + radix select -------------------------------------------------------------------------------------
+@pytest.mark.parametrize("k", [400, 1000, 1023, 1024])
+@pytest.mark.parametrize("rows,cols,nnz,seed", [(200000, 1024, 20, 3), (1500, 64, 6, 4), (60000, 3000, 30, 5)])
+def test_large_k_radix_select_path(pkg, oracle, k, rows, cols, nnz, seed):
+    """k above 3/8 of the publishing groups (or above all of them: no threshold can form): the engine scores every row and
+    selects by radix. Bit-exact against the packed-order oracle + exact selection, min_score respected, k > rows padded."""
+    m = pkg.generate_matrix(rows, cols, nnz, "gamma", seed)
+    for min_score in (0.0, 0.05):
+        eng = pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, k=k, device=0, min_score=min_score)
+        for q in range(2):
+            x = pkg.create_sample_vector(cols, True, False, True, 20 * seed + q)
+            eng.reset(x)
+            eng()
+            val, idx = eng.read_result()
+            ei, ev = _expected(pkg, oracle, m, x, k, eng, min_score)
+            assert np.array_equal(idx, ei), (k, min_score, q)
+            assert np.array_equal(val.view(np.uint32), ev.view(np.uint32))
+        eng.close()
+
+
+def test_large_k_radix_select_ties_and_batches(pkg, oracle):
+    """Massive ties at the k-th score (all values 1, -v mode: scores are small integers) and the batch entry points."""
+    import torch
+    m = pkg.generate_matrix(50000, 256, 6, "uniform", 2)
+    ones = np.ones_like(m.val)
+    xs = np.stack([np.full(256, 0.5, dtype=np.float32), pkg.create_sample_vector(256, True, False, True, 9)])
+    dxs = torch.from_numpy(xs).cuda()
+    eng = pkg.SpMV(m.row, m.col, ones, m.rows, m.cols, k=800, device=0)
+    out_i = torch.zeros((2, 800), dtype=torch.int32, device="cuda")
+    out_v = torch.zeros((2, 800), dtype=torch.float32, device="cuda")
+    eng.enqueue_batch(dxs.data_ptr(), 2, out_i.data_ptr(), out_v.data_ptr())
+    eng.synchronize()
+    mm = pkg.CooMatrix(m.rows, m.cols, m.row, m.col, ones)
+    for q in range(2):
+        ei, ev = _expected(pkg, oracle, mm, xs[q], 800, eng)
+        assert np.array_equal(out_i[q].cpu().numpy().view(np.uint32), ei) and np.array_equal(out_v[q].cpu().numpy(), ev)
+    eng.close()
