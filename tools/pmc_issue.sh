@@ -1,0 +1,24 @@
+#!/bin/bash
+# Instruction-issue and LDS counters of the streaming kernels (run from the repository root through gpurun):
+#   bash tools/pmc_issue.sh r01
+# Separate rocprofv3 --pmc passes (few counters each; no trace domains besides --kernel-trace) over the headline path
+# (batch kernel) and the multi-query path (8 and 4 queries per pass, one chain). tools/summarize_pmc_issue.py sums the
+# counters per kernel into profiles/<tag>_pmc_issue.json.
+set -u
+TAG=${1:-r01}
+REPO=$PWD
+OUT=$REPO/gpurun_out/pmc_issue_$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+export TKSPMV_MULTI_CHAINS=1
+i=0
+for counters in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD" \
+                "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS" "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM GRBM_GUI_ACTIVE"; do
+    i=$((i + 1))
+    rocprofv3 --pmc $counters --kernel-trace --output-format csv -d "$OUT/batch$i" -- python3 "$REPO/bench.py" --steps 320 --warmup 32 --cpu-seconds 0 --skip-warm > "$OUT/batch$i.json" 2> "$OUT/batch$i.err"
+    for q in 8 4; do
+        rocprofv3 --pmc $counters --kernel-trace --output-format csv -d "$OUT/multi${q}_$i" -- python3 "$REPO/bench.py" --multi-only $q --steps 320 --warmup 32 > "$OUT/multi${q}_$i.json" 2> "$OUT/multi${q}_$i.err"
+    done
+done
+cd "$REPO"
+python3 tools/summarize_pmc_issue.py "$OUT" "$TAG"

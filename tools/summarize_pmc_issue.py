@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Sums the counters collected by tools/pmc_issue.sh per streaming kernel (all dispatches of the run) and derives a few
+ratios: VALU / LDS / scalar / VMEM issue activity per wave cycle, LDS bank-conflict share, instructions per launch."""
+import csv
+import glob
+import json
+import os
+import sys
+
+out, tag = sys.argv[1], sys.argv[2]
+res = {}
+for d in sorted(glob.glob(os.path.join(out, "*"))):
+    if not os.path.isdir(d):
+        continue
+    run = os.path.basename(d).rsplit("_", 1)[0] if os.path.basename(d).startswith("multi") else "batch"
+    want = "multi_kernel" if run.startswith("multi") else "batch_kernel"
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        launches = set()
+        for row in csv.DictReader(open(f)):
+            if want not in row.get("Kernel_Name", ""):
+                continue
+            r = res.setdefault(run, {})
+            r[row["Counter_Name"]] = r.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+            launches.add(row["Dispatch_Id"])
+        if launches:
+            res.setdefault(run, {})["launches"] = len(launches)
+for run, r in res.items():
+    wc = r.get("SQ_WAVE_CYCLES")
+    if wc:
+        for k in ("SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_SCA", "SQ_ACTIVE_INST_VMEM", "SQ_ACTIVE_INST_ANY",
+                  "SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS"):
+            if k in r:
+                r[k + "_per_wave_cycle"] = r[k] / wc
+    if r.get("SQ_LDS_IDX_ACTIVE"):
+        r["lds_bank_conflict_share"] = r.get("SQ_LDS_BANK_CONFLICT", 0.0) / r["SQ_LDS_IDX_ACTIVE"]
+    if r.get("SQ_BUSY_CYCLES") and r.get("SQ_ACTIVE_INST_VALU"):
+        r["valu_active_per_busy_cycle"] = r["SQ_ACTIVE_INST_VALU"] / r["SQ_BUSY_CYCLES"]
+dst = os.path.join(os.path.dirname(os.path.abspath(out.rstrip("/"))), "..", "profiles", f"{tag}_pmc_issue.json")
+dst = os.path.normpath(dst)
+json.dump(res, open(dst, "w"), indent=1, sort_keys=True)
+print(json.dumps(res, indent=1, sort_keys=True))
