@@ -1521,18 +1521,28 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0, co
 
     Pkt<C, VT> buf[NBUF];
     uint32_t rbs[NBUF];
-    uint32_t qa = 0u, ja = 0u;  // next packet to request: (query, packet of the partition)
-    const uint8_t *pk_a = B.io[0].packets + (size_t)p0 * P0.packet_bytes;  // partition base in the stream copy of query qa
+    // Next packet to request: a running pointer into the stream copy of its query, a running pointer into pkt_row, and two
+    // down-counters (requests left in the query, requests left in the launch): per request two pointer increments and a
+    // compare; no multiply, nothing re-read from the kernel arguments (measured with rocprofv3 --pmc: the kernel issued
+    // as many scalar as vector instructions, ~100 per packet, a third of them in this bookkeeping).
+    uint32_t qa = 0u;
+    const size_t part_off = (size_t)p0 * P0.packet_bytes;
+    const uint8_t *pk_a = B.io[0].packets + part_off;
+    const uint32_t *row_a = P0.pkt_row + p0;
+    uint32_t left_q = np, left_all = np * nq;
 #define TKSPMV_REQUEST(dst, rb_dst)                                                                                   \
     do {                                                                                                              \
-        load_packet<C, VT>(pk_a + (size_t)ja * P0.packet_bytes, lane, dst);                                           \
-        rb_dst = P0.pkt_row[p0 + ja];                                                                                 \
-        if (!(qa + 1u == nq && ja + 1u == np)) { /* past the end: the last packet is requested again (counted vmcnt) */ \
-            ++ja;                                                                                                     \
-            if (ja == np) {                                                                                           \
-                ja = 0u;                                                                                              \
+        load_packet<C, VT>(pk_a, lane, dst);                                                                          \
+        rb_dst = *row_a;                                                                                              \
+        if (left_all > 1u) { /* past the end: the last packet is requested again (counted vmcnt) */                    \
+            --left_all;                                                                                               \
+            pk_a += P0.packet_bytes;                                                                                  \
+            ++row_a;                                                                                                  \
+            if (--left_q == 0u) {                                                                                     \
+                left_q = np;                                                                                          \
                 ++qa;                                                                                                 \
-                pk_a = B.io[qa].packets + (size_t)p0 * P0.packet_bytes;                                                \
+                pk_a = B.io[qa].packets + part_off;                                                                   \
+                row_a = P0.pkt_row + p0;                                                                              \
             }                                                                                                         \
         }                                                                                                             \
     } while (0)
@@ -1541,7 +1551,6 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0, co
     rbs[NBUF - 1] = 0u;
 
     uint32_t qc = 0u, jc = 0u;  // packet being reduced
-    uint32_t first_tau_pkt = 0xFFu;  // tracing: packet at which this query's threshold was first seen
     float carry = 0.0f, min_units = 0.0f;
     uint32_t wcnt = 0u;
     uint32_t *mp = L.misc[0];
@@ -1569,10 +1578,8 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0, co
                 P.ovf_count = B.ovf_count(qc);
                 carry = 0.0f;
                 wcnt = 0u;
-                first_tau_pkt = 0xFFu;
             }
             const float tau = __uint_as_float(lds_load(&mp[MISC_TAU]));
-            if (trw && first_tau_pkt == 0xFFu && tau > min_units) first_tau_pkt = jc;
             const RowSums<C> R = reduce_packet<C, QM>(cur, carry, xq, P0.fixed_mask);
             if (jc < DEFER_B && P0.n_sets != 0u) {
                 uint32_t fl = 0u;
@@ -1646,7 +1653,7 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0, co
                 if (lane == 0) atomicAdd(&mp[MISC_DONE], 1u);
                 if (trw && lane == 0 && TRSLOT(qc) < 3u) {
                     trw[4 + TRSLOT(qc)] = __builtin_amdgcn_s_memrealtime();
-                    trw[7] = (TRSLOT(qc) == 0u ? 0ull : trw[7]) | ((unsigned long long)(((surv > 0xFFu ? 0xFFu : surv) << 8) | first_tau_pkt) << (16u * TRSLOT(qc))) |
+                    trw[7] = (TRSLOT(qc) == 0u ? 0ull : trw[7]) | ((unsigned long long)(((surv > 0xFFu ? 0xFFu : surv) << 8) | 0xFFu) << (16u * TRSLOT(qc))) |
                              ((unsigned long long)(tau3 <= min_units ? 1u : 0u) << (48u + TRSLOT(qc)));
                 }
                 ++qc;
@@ -1923,6 +1930,8 @@ __global__ void __launch_bounds__(576, Q >= 8 ? 4 : 6) multi_kernel(const Stream
         return missing;
     };
     bool gave_up = false;
+    // chunk the next prefetch reads: NBUF - 2 ahead of the last one requested above (a running pointer: no multiply per chunk)
+    const uint8_t *pk_ahead = pk + (size_t)(np > (uint32_t)(NBUF - 2) ? (uint32_t)(NBUF - 2) : (np > 0u ? np - 1u : 0u)) * P0.packet_bytes;
     uint32_t n_done = 0u;  // slices finished by this wave
     uint32_t n_held = 0u;  // of which held back (the first n_held of the partition)
     for (uint32_t i0 = 0; i0 < np; i0 += NBUF) {
@@ -1931,9 +1940,9 @@ __global__ void __launch_bounds__(576, Q >= 8 ? 4 : 6) multi_kernel(const Stream
             const uint32_t i = i0 + (uint32_t)u;
             if (i >= np) break;
             const Pkt<C, 0> &cur = buf[u];
-            {  // unconditional (index clamped): a fixed number of younger loads => counted vmcnt
-                const uint32_t ia = (i + (NBUF - 1) < np) ? (i + (NBUF - 1)) : (np - 1u);
-                load_packet<C, 0>(pk + (size_t)ia * P0.packet_bytes, lane, buf[(u + NBUF - 1) % NBUF]);
+            {  // unconditional (pointer clamped to the last chunk): a fixed number of younger loads => counted vmcnt
+                if (i + (NBUF - 1) < np) pk_ahead += P0.packet_bytes;
+                load_packet<C, 0>(pk_ahead, lane, buf[(u + NBUF - 1) % NBUF]);
             }
             uint32_t off[C];
 #pragma unroll
