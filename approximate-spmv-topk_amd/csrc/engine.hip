@@ -2181,8 +2181,11 @@ __global__ void __launch_bounds__(RADIX_THREADS) radix_hist_kernel(const RadixPa
     if (sh_take_all) return;
     const uint32_t prefix = sh_prefix, shift = 24u - 8u * (uint32_t)pass;
     for (uint32_t i = blockIdx.x * RADIX_THREADS + tid; i < R.rows; i += gridDim.x * RADIX_THREADS) {
-        const uint32_t key = order_key(R.scores[i]);
-        if (key >= R.kmin && (pass == 0 || (key >> (shift + 8u)) == prefix)) atomicAdd(&lh[(key >> shift) & 255u], 1u);
+        const float sc = R.scores[i];
+        const uint32_t key = order_key(sc);
+        // (a row without entries keeps -inf in its slot and is never eligible, whatever min_score is)
+        if (key >= R.kmin && sc > -__builtin_huge_valf() && (pass == 0 || (key >> (shift + 8u)) == prefix))
+            atomicAdd(&lh[(key >> shift) & 255u], 1u);
     }
     __syncthreads();
     if (tid < 256u && lh[tid] != 0u) atomicAdd(&R.hist[pass * 256 + (int)tid], lh[tid]);
@@ -2203,7 +2206,7 @@ __global__ void __launch_bounds__(RADIX_THREADS) radix_filter_kernel(const Radix
     for (uint32_t it = 0; it < n_iter; ++it) {
         const uint32_t i = (it * gridDim.x + blockIdx.x) * RADIX_THREADS + tid;
         const float sc = i < R.rows ? R.scores[i] : -__builtin_huge_valf();
-        const bool keep = i < R.rows && order_key(sc) >= thr;
+        const bool keep = i < R.rows && order_key(sc) >= thr && sc > -__builtin_huge_valf();
         const uint64_t bm = __ballot(keep);
         uint32_t base = 0u;
         if (lane == 0u && bm) base = atomicAdd(R.ovf_count, (uint32_t)__popcll(bm));
