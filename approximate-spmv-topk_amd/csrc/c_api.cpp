@@ -204,7 +204,7 @@ int tkspmv_pack(const tkspmv_desc *d, uint32_t n_wave_partitions_hint, tkspmv_pa
     *out = nullptr;
     tkspmv_packed *p = new tkspmv_packed();
     int kind = 0;
-    uint32_t C = d->nnz_per_lane > 0 ? (uint32_t)d->nnz_per_lane : 4u;
+    uint32_t C = entries_per_lane_of(*d);
     const Precision sp = stream_precision(d->precision);
     std::string err = pack_wbscsr(d->rows, d->cols, d->nnz, d->row, d->col, d->val, sp, C,
                                   n_wave_partitions_hint ? n_wave_partitions_hint : 4096u, 4, p->pm, kind,

@@ -823,9 +823,13 @@ struct StreamLds {
 #define TKSPMV_NBUF 3
 #endif
 template <int C, bool SCORES, int XCOLS, int QM = 0, int NBUF = TKSPMV_NBUF>
-__global__ void __launch_bounds__(576, 5) stream_kernel(const StreamParams P, const SelectParams SP) {
+__global__ void __launch_bounds__(576, (C == 8 && !SCORES) ? 6 : 5) stream_kernel(const StreamParams P, const SelectParams SP) {
     constexpr bool Q8 = QM == 1 || QM == 2;  // x staged as Q1.7 integers
     constexpr int VT = value_type_of(QM);
+    // Deferred packets live in registers (C row sums + C / 2 flag words each): with 8 entries per lane one packet is held,
+    // not three -- the same number of rows as two 4-entry packets, and the kernel stays at 80 registers (two workgroups
+    // per CU; with three it needed 96 and a single query took 57 us instead of 36).
+    constexpr int DEFER_C = C == 8 ? 1 : DEFER;
     __shared__ StreamLds<XCOLS> L;
     float *x_lds = L.u.w.x;
     uint2 *cand = L.u.w.cand;
@@ -986,10 +990,10 @@ __global__ void __launch_bounds__(576, 5) stream_kernel(const StreamParams P, co
         const uint8_t *pk = P.packets + (size_t)p0 * P.packet_bytes;
         float carry = 0.0f;
 
-        RowSums<C> st[DEFER];  // deferred packets
-        uint32_t st_rb[DEFER];
+        RowSums<C> st[DEFER_C];  // deferred packets
+        uint32_t st_rb[DEFER_C];
 #pragma unroll
-        for (int d = 0; d < DEFER; ++d) {
+        for (int d = 0; d < DEFER_C; ++d) {
             st[d].best_any = -__builtin_huge_valf();
             st_rb[d] = 0u;
 #pragma unroll
@@ -1050,10 +1054,10 @@ __global__ void __launch_bounds__(576, 5) stream_kernel(const StreamParams P, co
                     }
                 }
             } else {
-                if (i < (uint32_t)DEFER && P.n_sets != 0u) {
+                if (i < (uint32_t)DEFER_C && P.n_sets != 0u) {
                     // Cold start of the threshold exchange: keep the sums in registers, only feed the maxima.
 #pragma unroll
-                    for (int d = 0; d < DEFER; ++d) {
+                    for (int d = 0; d < DEFER_C; ++d) {
                         if (i == (uint32_t)d) {
                             st[d] = R;
                             st_rb[d] = rb_cur;
@@ -1087,7 +1091,7 @@ __global__ void __launch_bounds__(576, 5) stream_kernel(const StreamParams P, co
             const float tau =
                 __uint_as_float(__hip_atomic_load(&misc[MISC_TAU], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
 #pragma unroll
-            for (int d = 0; d < DEFER; ++d) {
+            for (int d = 0; d < DEFER_C; ++d) {
                 if (np > (uint32_t)d && __any(st[d].best_any >= tau))
                     offer_candidates<C, QM, ListGeom<XCOLS>::WAVE_CAP>(P, st[d], st_rb[d], tau, lane, grp_local, publishes, wcand, wcnt, misc);
             }
@@ -2573,7 +2577,7 @@ struct EngineImpl {
             if (xcols <= 4096) return scores ? &stream_kernel<4, true, 4096, 2> : &stream_kernel<4, false, 4096, 2>;
             return scores ? &stream_kernel<4, true, 16384, 2> : &stream_kernel<4, false, 16384, 2>;
         }
-        if (c8) return scores ? &stream_kernel<8, true, 1024> : &stream_kernel<8, false, 1024>;
+        if (c8) return scores ? &stream_kernel<8, true, 1024, 0, 2> : &stream_kernel<8, false, 1024, 0, 2>;  // (two packet buffers: 3 KB packets)
         if (xcols <= 1024) return scores ? &stream_kernel<4, true, 1024> : &stream_kernel<4, false, 1024>;
         if (xcols <= 4096) return scores ? &stream_kernel<4, true, 4096> : &stream_kernel<4, false, 4096>;
         return scores ? &stream_kernel<4, true, 16384> : &stream_kernel<4, false, 16384>;
@@ -2762,7 +2766,7 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
         err = "launch geometry too large: waves_per_cu * num_cus / waves_per_wg must be <= 1024 workgroups";
         return TKSPMV_ERR_INVALID;
     }
-    const uint32_t C = d.nnz_per_lane > 0 ? (uint32_t)d.nnz_per_lane : 4u;
+    const uint32_t C = entries_per_lane_of(d);
 
     int kind = 0;
     // Deferred selection gives workgroup 0 of a back-to-back launch to the previous query's selection: one

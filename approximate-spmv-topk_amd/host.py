@@ -131,7 +131,7 @@ def sell_roundtrip(m, n_wave_partitions=4088):
 class Packed:
     """Host-side packed (wave-BSCSR) matrix, for layout tests: decode(pack(A)) == A."""
 
-    def __init__(self, m, k=100, nnz_per_lane=4, n_wave_partitions=4096, precision=_lib.F32, fixed_width=0):
+    def __init__(self, m, k=100, nnz_per_lane=0, n_wave_partitions=4096, precision=_lib.F32, fixed_width=0):
         self._h = C.c_void_p()
         self._row = np.ascontiguousarray(m.row, dtype=np.uint32)
         self._col = np.ascontiguousarray(m.col, dtype=np.uint32)

@@ -90,7 +90,7 @@ typedef struct {
     /* tuning knobs, 0 = auto */
     int32_t waves_per_cu;
     int32_t threads_per_wg;
-    int32_t nnz_per_lane;     /* 4 or 8 entries per lane per packet */
+    int32_t nnz_per_lane;     /* 4 or 8 entries per lane per packet; 0 = 4 */
     int32_t stream_replicas;  /* measurement aid: keep R copies of the packet stream in HBM and rotate them per query so
                                  that consecutive queries cannot be served from the 256 MiB Infinity Cache; 0/1 = off */
     int32_t fixed_width;      /* TKSPMV_FIXED: bits per value, 8..32 (0 => 32, the reference's default FIXED_WIDTH,

@@ -67,8 +67,9 @@ def test_full_scores_bit_exact(pkg, oracle):
     eng = _engine(pkg, m, 100, x)
     y = eng.scores()
     info = eng.info()
-    packed = pkg.Packed(m, k=100, nnz_per_lane=4, n_wave_partitions=info["grid"] * info["block"] // 64)
-    yp, present = oracle.packed_scores(packed.raw(), x, m.rows, 4)
+    C = info["packet_entries"] // 64
+    packed = pkg.Packed(m, k=100, nnz_per_lane=C, n_wave_partitions=info["grid"] * info["block"] // 64)
+    yp, present = oracle.packed_scores(packed.raw(), x, m.rows, C)
     assert present.all()
     assert np.array_equal(y.view(np.uint32), yp.view(np.uint32))
     ys, _ = oracle.scores_f32_seq(m.row, m.col, m.val, x, m.rows)
