@@ -58,8 +58,9 @@ void fill_info(const PackedMatrix &pm, int k, tkspmv_info *out);
 uint64_t algorithmic_bytes(uint64_t nnz, uint32_t rows, uint32_t cols, uint32_t value_bytes, int k);
 int device_count();
 // Entries per lane and packet: desc.nnz_per_lane, by default 4. (8, where those kernels exist -- fp32 values, at most
-// 1024 columns -- measured 19.9 against 20.7 us per query on the BASELINE matrix, back to back, but 170 against 57 us at
-// 3M rows and 188 against 9 us at 10k rows: its batch kernel is tuned at one size only and stays opt-in.)
+// 1024 columns -- is opt-in: 3-4 % faster on the BASELINE matrix in short probes, 10-15 % slower in bench.py's
+// conditions (64 query vectors, 4 stream copies), 3x slower at 2-3M rows, where its longer partitions overflow the
+// private candidate lists.)
 inline uint32_t entries_per_lane_of(const tkspmv_desc &d) {
     return d.nnz_per_lane > 0 ? (uint32_t)d.nnz_per_lane : 4u;
 }
