@@ -1557,6 +1557,8 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0, co
     uint32_t qc = 0u, jc = 0u;  // packet being reduced
     float carry = 0.0f, min_units = 0.0f;
     uint32_t wcnt = 0u;
+    bool waited = false;  // this wave has used its bounded wait for a threshold in the current query
+    const bool long_partition = np * (uint32_t)(C / 4) >= 28u;  // ~14 rows finish per 256 entries: > 1.5 lists per query
     uint32_t *mp = L.misc[0];
     const float *xq = L.u.w.x[0];
     StreamParams P = P0;
@@ -1582,6 +1584,7 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0, co
                 P.ovf_count = B.ovf_count(qc);
                 carry = 0.0f;
                 wcnt = 0u;
+                waited = false;
             }
             const float tau = __uint_as_float(lds_load(&mp[MISC_TAU]));
             const RowSums<C> R = reduce_packet<C, QM>(cur, carry, xq, P0.fixed_mask);
@@ -1599,7 +1602,22 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0, co
                     (void)__hip_atomic_fetch_max(&mp[MISC_GRPMAX + grp_local], order_key(wmax), __ATOMIC_RELAXED,
                                                  __HIP_MEMORY_SCOPE_WORKGROUP);
             } else if (__any(R.best_any >= tau) && !(P0.dbg_flags & 2u)) {
-                offer_candidates<C, QM, WAVE_CAP>(P, R, rb_cur, tau, lane, grp_local, publishes, wcand, wcnt, mp);
+                float tau_now = tau;
+                // Long partitions only (more rows per wave and query than its list holds: from ~1.5M rows on 256 CUs). A
+                // wave that runs ahead of its workgroup's exchange has no threshold yet: every row passes, and once the
+                // list is nearly full the rest would pour into the query's overflow list. It is ahead of the others anyway:
+                // it waits for the threshold instead, bounded, once per query (2M rows: 40.4 against 42.1 us per query, 3M:
+                // 58.5 against 60.7). On shorter partitions the list holds a whole query's rows and the wait only costs
+                // the overlap of consecutive queries (1M rows, bench.py's conditions: 3-10 % slower), hence the condition.
+                if (long_partition && wcnt + 2u * 64u > WAVE_CAP && tau <= min_units && P0.tau_possible && !waited) {
+                    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                    while (lds_load(&mp[MISC_TAU]) == __float_as_uint(min_units) && __builtin_amdgcn_s_memrealtime() - t0 < BATCH_TAU_WAIT)
+                        __builtin_amdgcn_s_sleep(4);
+                    waited = true;
+                    tau_now = __uint_as_float(lds_load(&mp[MISC_TAU]));
+                }
+                if (tau_now == tau || __any(R.best_any >= tau_now))
+                    offer_candidates<C, QM, WAVE_CAP>(P, R, rb_cur, tau_now, lane, grp_local, publishes, wcand, wcnt, mp);
             }
             if (jc + 1u == np) {  // the query ends for this wave
                 if (P0.n_sets != 0u) {
