@@ -1,5 +1,6 @@
 """Several queries per pass over the matrix (tkspmv_enqueue_multi) on BASELINE configs[1] (1M x 1024, 20 nnz/row, K=100,
-cache-defeated rotation): time per query for TKSPMV_MULTI_Q = 2, 4, 8 next to the one-query-per-pass batch kernel."""
+cache-defeated rotation): time per query for 1, 2, 4, 8 queries per pass (MQ="0 1 2 4 8"; 0 = the one-query-per-pass
+batch kernel). TKSPMV_STATS=1 adds the candidate-path counters, TKSPMV_MULTI_CHAINS=1 runs one chain of launches."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
