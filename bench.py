@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--queries", type=int, default=64, help="distinct query vectors resident in HBM")
     ap.add_argument("--nnz-per-lane", type=int, default=0, help="entries per lane and packet (0 = the engine's default)")
+    ap.add_argument("--waves-per-cu", type=int, default=0, help="streaming waves per CU (0 = the engine's default)")
+    ap.add_argument("--threads-per-wg", type=int, default=0, help="streaming threads per workgroup (0 = the engine's default)")
     ap.add_argument("--skip-warm", action="store_true", help="skip the cache-warm leg (homogeneous launches for rocprofv3)")
     ap.add_argument("--multi-q", type=int, nargs="*", default=[4, 8],
                     help="queries per matrix pass of the multi-query leg (reported beside the headline; empty = skip)")
@@ -146,7 +148,8 @@ def main():
     xs = np.stack([mod.create_sample_vector(a.cols, True, False, True, 1000 + i) for i in range(a.queries)])
     dxs = torch.from_numpy(xs).to(dev)
     eng = mod.SpMV(m.row, m.col, m.val, m.rows, m.cols, k=a.k, device=local_rank, first_row=rank * a.rows,
-                   stream_replicas=a.replicas, nnz_per_lane=a.nnz_per_lane)
+                   stream_replicas=a.replicas, nnz_per_lane=a.nnz_per_lane, waves_per_cu=a.waves_per_cu,
+                   threads_per_wg=a.threads_per_wg)
     info = eng.info()
     alg_bytes = info["algorithmic_bytes"]
 
