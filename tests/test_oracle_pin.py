@@ -135,3 +135,29 @@ def test_oracle_against_live_reference(pkg, oracle):
             ri, rv = oracle.ref_gold_topk(m.row, m.col, m.val, x, k)
             oi, ov = oracle.gold_topk(m.row, m.col, m.val, x, k)
             assert np.array_equal(ri, oi) and np.array_equal(rv.view(np.uint32), ov.view(np.uint32))
+
+
+def test_segmented_order_is_the_gold_order_for_short_rows(pkg, oracle):
+    """oracle_scores_f32_segmented (the multi-query kernel's summation order) restates the gold's sequential fp32 sum
+    for every row of at most `seg` entries; longer rows are the left-to-right sum of their segment sums."""
+    m = pkg.generate_matrix(20000, 1024, 20, "gamma", 6)
+    x = pkg.create_sample_vector(1024, True, False, True, 3)
+    lens = np.bincount(m.row, minlength=m.rows)
+    assert lens.max() > 64  # the matrix has rows of both kinds
+    y_seq, p_seq = oracle.scores_f32_seq(m.row, m.col, m.val, x, m.rows)
+    y_seg, p_seg = oracle.scores_f32_segmented(m.row, m.col, m.val, x, m.rows, 64)
+    assert np.array_equal(p_seq, p_seg)
+    short = lens <= 64
+    assert np.array_equal(y_seq[short].view(np.uint32), y_seg[short].view(np.uint32))
+    assert np.allclose(y_seq, y_seg, rtol=1e-6, atol=0)
+    y_all, _ = oracle.scores_f32_segmented(m.row, m.col, m.val, x, m.rows, int(lens.max()))
+    assert np.array_equal(y_all.view(np.uint32), y_seq.view(np.uint32))
+    # a long row by hand: segments of 3
+    row = np.zeros(8, np.uint32)
+    col = np.arange(8, dtype=np.uint32)
+    val = np.array([0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8], np.float32)
+    xx = np.ones(8, np.float32)
+    y3, _ = oracle.scores_f32_segmented(row, col, val, xx, 1, 3)
+    f = np.float32
+    want = f(f(f(f(f(0.1) + f(0.2)) + f(0.3)) + f(f(f(0.4) + f(0.5)) + f(0.6))) + f(f(0.7) + f(0.8)))
+    assert y3[0].view(np.uint32) == want.view(np.uint32)
