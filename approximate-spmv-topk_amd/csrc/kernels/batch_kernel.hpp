@@ -1,0 +1,504 @@
+// kernels/batch_kernel.hpp -- batch_kernel: up to 32 queries per launch, one pass over the wave-BSCSR stream per query (the headline path).
+// Part of engine.hip (one translation unit: included there in this order; device code only).
+#pragma once
+#include "stream_kernel.hpp"
+
+namespace tkspmv {
+
+// ------------------------------------------------------------------------------------------------------------
+// Batch kernel: up to BATCH_MAX queries in ONE launch. Measured on the single-query kernel: a launch costs ~6.5 us
+// beyond its steady-state streaming (launch turnaround, first-touch latency of every launch, end skew), and the
+// streaming loop alone runs at ~6.4 TB/s once it is going (TKSPMV_DBG_REPEAT experiment). Here every streaming wave
+// walks its partition once per query with ONE continuous packet prefetch pipeline across query boundaries; nobody
+// waits for another workgroup:
+//   * workgroups 1..grid-1 stream; per query the workgroup's server wave stages x into one of two LDS buffers
+//     (x of query q+1 while the streaming waves are still in q), serves the threshold exchange of the newest query
+//     through that query's own exchange-state set, and, when its 8 streaming waves have counted themselves out of a
+//     query, copies their staged survivors to the query's slots, drains ITS stores and adds the workgroup's ticket
+//     (release). Streaming waves never wait for global memory they do not need: their survivors go to LDS.
+//   * workgroup 0 is the selector: for q = 0, 1, ... it waits until all tickets of q are in (acquire) and runs
+//     select_body on q's state. It waits for the streaming workgroups; none of them ever waits for it or for each
+//     other, so there is no cycle even if not all workgroups are resident at once.
+// Waits inside a streaming workgroup are on its own LDS flags (x staged / waves done), set by waves of the same
+// workgroup that never block on anything but memory.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int BATCH_MAX = 32;
+constexpr uint32_t STG_N = 8;  // survivors a wave can stage per query (64 lanes = 8 waves x 8 when the server copies)
+#ifndef TKSPMV_ALL_SERVERS_PRIO
+#define TKSPMV_ALL_SERVERS_PRIO 0
+#endif
+#ifndef TKSPMV_TAU_WAIT
+#define TKSPMV_TAU_WAIT 3000
+#endif
+constexpr unsigned long long BATCH_TAU_WAIT = TKSPMV_TAU_WAIT;  // x 10 ns (s_memrealtime runs at 100 MHz)
+constexpr int MISC_XREADY = 2, MISC_MINU = 3;  // batch kernel only: x staged for query (value - 1); min score in units
+
+// Per query only what differs from query to query travels in the kernel arguments (32 bytes); the exchange-state set of
+// query q is set 0 plus q strides (the sets are allocated as one block per field), so the argument block stays small (64 queries would fit the 4 KiB limit; 32 are used: longer batches measured no faster).
+struct BatchIO {
+    const float *x;
+    const uint8_t *packets;
+    uint32_t *out_idx;
+    float *out_val;
+};
+// Exchange-state sets are allocated as one block per field: set s = set 0 plus s strides.
+struct SetAddr {
+    uint32_t *gmax0, *tau_g0, *ovf_count0;
+    unsigned long long *wg_cand0, *ovf_cand0, *scratch;
+    float *unit_inv0;
+    uint32_t gmax_stride, word_stride, cand_stride;
+    uint64_t ovf_stride;
+    __device__ __forceinline__ uint32_t *gmax(uint32_t q) const { return gmax0 + (size_t)q * gmax_stride; }
+    __device__ __forceinline__ uint32_t *tau_g(uint32_t q) const { return tau_g0 + (size_t)q * word_stride; }
+    __device__ __forceinline__ uint32_t *ovf_count(uint32_t q) const { return ovf_count0 + (size_t)q * word_stride; }
+    __device__ __forceinline__ float *unit_inv(uint32_t q) const { return unit_inv0 + (size_t)q * word_stride; }
+    __device__ __forceinline__ unsigned long long *wg_cand(uint32_t q) const { return wg_cand0 + (size_t)q * cand_stride; }
+    __device__ __forceinline__ unsigned long long *ovf_cand(uint32_t q) const { return ovf_cand0 + (size_t)q * ovf_stride; }
+};
+struct BatchParams : SetAddr {
+    uint32_t n_q;
+    uint32_t *tickets;  // [BATCH_MAX] counters, 32 words apart
+    BatchIO io[BATCH_MAX];
+};
+
+template <int XCOLS, int C = 4>
+struct BatchLds {
+    union {
+        struct {
+            float x[2][XCOLS];                           // query vector, double-buffered by query parity
+            uint2 cand[ListGeom<XCOLS>::CAND_CAP];       // private candidate lists of the streaming waves
+        } w;
+        SelectShared sel;  // selector workgroup only
+    } u;
+    uint32_t misc[2][MISC_WORDS];                        // per query parity
+    unsigned long long stg[2][8][STG_N];                 // survivors staged by the streaming waves
+    uint32_t stg_cnt[2][8];
+    // Deferred packets (threshold exchange cold start) wait here, not in registers: row sums and packed row flags per
+    // lane. No register cost, so more packets can be deferred (5 while x is small) and fewer rows are appended before
+    // the threshold has arrived.
+#ifndef TKSPMV_DEFER_B
+#define TKSPMV_DEFER_B 2
+#endif
+    static constexpr int DEFER_B = C == 8 ? 1 : (XCOLS <= 1024 ? TKSPMV_DEFER_B : 2);
+    float4 drs[8][DEFER_B][C / 4][64];
+    uint32_t dfl[8][DEFER_B][64];
+    uint32_t drb[8][DEFER_B];
+};
+
+__device__ __forceinline__ uint32_t lds_load(const uint32_t *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+template <int C, int XCOLS, int QM>
+__global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0, const SelectParams SP0, const BatchParams B) {
+    constexpr bool Q8 = QM == 1 || QM == 2;  // x staged as Q1.7 integers
+    constexpr int VT = value_type_of(QM);
+    constexpr int NBUF = C == 8 ? 2 : 3;  // packets of 8 entries per lane are twice as large: one ahead is as many bytes
+    constexpr uint32_t WAVE_CAP = ListGeom<XCOLS>::WAVE_CAP;
+    __shared__ BatchLds<XCOLS, C> L;
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t nwaves = (blockDim.x >> 6) - 1u;  // streaming waves
+    const bool is_server = (wave == nwaves);
+    const uint32_t nq = B.n_q;
+
+    if (blockIdx.x == 0u) {
+        // ---- selector workgroup ------------------------------------------------------------------------------
+        const uint32_t n_stream = gridDim.x - 1u;
+        for (uint32_t q = 0; q < nq; ++q) {
+            if (tid == 0) {
+                uint32_t *t = B.tickets + 32u * q;
+                // Polled with a compare-and-swap (which also resets the counter for the next launch): atomics execute
+                // at the device-wide coherence point, whereas a load -- even agent-scope -- can keep hitting a stale
+                // copy of the line in this XCD's L2 (seen: 33 ms on an otherwise idle L2).
+                while (atomicCAS(t, n_stream, 0u) != n_stream) __builtin_amdgcn_s_sleep(32);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            __syncthreads();
+            SelectParams S = SP0;
+            S.wg_cand = B.wg_cand(q);
+            S.ovf_cand = B.ovf_cand(q);
+            S.ovf_count = B.ovf_count(q);
+            S.gmax = B.gmax(q);
+            S.tau_g = B.tau_g(q);
+            S.scratch = B.scratch;
+            S.unit_inv_in = B.unit_inv(q);
+            S.out_idx = B.io[q].out_idx;
+            S.out_val = B.io[q].out_val;
+            select_body(S, tid, blockDim.x, L.u.sel);
+            __syncthreads();
+            if (P0.trace && tid == 0 && q < 8u) P0.trace[q] = __builtin_amdgcn_s_memrealtime();
+        }
+        return;
+    }
+    const uint32_t bid = blockIdx.x - 1u, n_wg = gridDim.x - 1u;
+    // traced queries: the first, the middle and the last of the batch
+#define TRSLOT(q) ((q) == 0u ? 0u : ((q) == nq / 2u ? 1u : ((q) + 1u == nq ? 2u : 9u)))
+    unsigned long long *trw = P0.trace ? P0.trace + ((size_t)blockIdx.x * 9u + wave) * 8u : nullptr;
+    if (trw && lane == 0) trw[0] = __builtin_amdgcn_s_memrealtime();
+    if (tid < 2u * MISC_WORDS) (&L.misc[0][0])[tid] = 0u;
+    if (tid < 16u) (&L.stg_cnt[0][0])[tid] = 0u;
+    __syncthreads();
+    const uint32_t grp_local = is_server ? 0u : wave * P0.gpw / nwaves;
+    const bool publishes = (bid * P0.gpw + grp_local) < P0.n_groups_pub;
+    const bool reducer = bid < P0.n_reducers;
+    // Streaming waves that own a partition (wave w streams partition w * n_wg + bid): only they take part in the
+    // per-query protocol. Waves without one leave at once -- spinning at stream priority on every query's x flag, six of
+    // them per workgroup on a small matrix, they starved the server wave (585 us per query at 50k rows).
+    uint32_t n_active = 0;
+    for (uint32_t w = 0; w < nwaves; ++w) {  // the very test the waves apply to themselves below
+        const uint32_t pw = w * n_wg + bid;
+        if (pw < P0.n_parts && P0.part_count[pw] != 0u) ++n_active;
+    }
+
+    if (is_server) {
+        // ---- server wave: x staging, threshold exchange of the newest query, finalisation of the oldest -------
+        // The reducers' search must not starve: in a batch the streaming waves (priority 2) never pause, and a reducer at
+        // the default priority got ONE pass per query (traced), i.e. the threshold arrived when the query was over.
+#if TKSPMV_ALL_SERVERS_PRIO
+        __builtin_amdgcn_s_setprio(3);
+#else
+        if (reducer) __builtin_amdgcn_s_setprio(3);
+#endif
+        uint32_t staged = 0u, tail = 0u;
+        float inv_unit_q[2] = {1.0f, 1.0f}, min_units_q[2] = {0.0f, 0.0f};
+        unsigned long long dbg_first_duty = 0ull;
+        uint32_t dbg_iters = 0u;
+        for (;;) {
+            if (staged < nq && staged - tail < 2u) {
+                const uint32_t par = staged & 1u;
+                const float *xg = B.io[staged].x;
+                float x_scale = 1.0f, unit_scale = 1.0f;
+                if (QM == 2) {
+                    float lm = 0.0f;
+#pragma unroll 1
+                    for (uint32_t b0 = 0; b0 < (uint32_t)XCOLS; b0 += 1024u) {  // 16 loads in flight per lane
+                        float r[16];
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) {
+                            const uint32_t i = b0 + lane + 64u * (uint32_t)u;
+                            r[u] = (i < P0.cols) ? xg[i] : 0.0f;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) lm = fmaxf(lm, r[u]);
+                    }
+                    const float xmax = wave_max(lm);
+                    int sh = 0;
+                    if (xmax > 0.0f) {
+                        const float ratio = 1.9921875f / xmax;
+                        sh = (int)((__float_as_uint(ratio) >> 23) & 255u) - 127;
+                        sh = sh < 0 ? 0 : (sh > 15 ? 15 : sh);
+                    }
+                    x_scale = (float)(1u << sh);
+                    unit_scale = 128.0f * x_scale;
+                } else if (QM == 1) {
+                    unit_scale = 128.0f;
+                } else if (QM == 4) {
+                    unit_scale = 2147483648.0f;
+                }
+                inv_unit_q[par] = 1.0f / unit_scale;
+                min_units_q[par] = P0.min_score * unit_scale;
+                float *xl = L.u.w.x[par];
+#pragma unroll 1
+                for (uint32_t b0 = 0; b0 < (uint32_t)XCOLS; b0 += 1024u) {  // 16 loads in flight per lane
+                    float r[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) {
+                        const uint32_t i = b0 + lane + 64u * (uint32_t)u;
+                        r[u] = (i < P0.cols) ? xg[i] : 0.0f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) {
+                        const uint32_t i = b0 + lane + 64u * (uint32_t)u;
+                        if (Q8)
+                            reinterpret_cast<uint32_t *>(xl)[i] = to_q1_7_dev(r[u] * x_scale);
+                        else if (QM == 4)
+                            reinterpret_cast<uint32_t *>(xl)[i] = to_fixed_dev(r[u], P0.fixed_width) >> (P0.fixed_width <= 24u ? 8 : 0);
+                        else
+                            xl[i] = r[u];
+                    }
+                }
+                uint32_t *mp = L.misc[par];
+                if (lane < (uint32_t)MISC_WORDS && lane != (uint32_t)MISC_XREADY) mp[lane] = 0u;
+                if (lane < 8u) L.stg_cnt[par][lane] = 0u;
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                if (lane == 0) {
+                    mp[MISC_TAU] = __float_as_uint(min_units_q[par]);
+                    mp[MISC_MINU] = __float_as_uint(min_units_q[par]);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_store(&mp[MISC_XREADY], staged + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (trw && lane == 0 && TRSLOT(staged) < 3u) trw[1 + TRSLOT(staged)] = __builtin_amdgcn_s_memrealtime();
+                ++staged;
+            }
+            // Threshold exchange of the query this workgroup's waves are streaming: the oldest unfinished one until
+            // half of the waves have left it, then the next (whose waves need a threshold most).
+            if (P0.n_sets != 0u && !(P0.dbg_flags & 4u)) {
+                uint32_t hq = tail;
+                if (tail + 1u < staged &&
+                    2u * __builtin_amdgcn_readfirstlane(lds_load(&L.misc[tail & 1u][MISC_DONE])) >= n_active)
+                    hq = tail + 1u;
+                {
+                    const uint32_t sq = hq;
+                    StreamParams P = P0;
+                    P.gmax = B.gmax(sq);
+                    P.tau_g = B.tau_g(sq);
+                    uint32_t *mp = L.misc[sq & 1u];
+                    const float min_units = min_units_q[sq & 1u];
+                    publish_group_max(P, bid, lane, mp);
+                    float t;
+                    if (reducer) {
+                        TauRegs tr_;
+                        tau_issue(P, lane, tr_);
+                        t = tau_from_maxima(P, tr_, min_units);
+                        if (lane == 0 && t > min_units)
+                            __hip_atomic_fetch_max(P.tau_g, order_key(t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } else {
+                        const uint32_t kx = __hip_atomic_load(P.tau_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        t = kx ? key_to_float(kx) : min_units;
+                    }
+                    if (lane == 0) {
+                        const float cur_tau = __uint_as_float(lds_load(&mp[MISC_TAU]));
+                        if (t > cur_tau)
+                            __hip_atomic_store(&mp[MISC_TAU], __float_as_uint(t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (trw && TRSLOT(sq) == 1u) {
+                            if (t > cur_tau && cur_tau <= min_units) trw[7] = __builtin_amdgcn_s_memrealtime();  // first threshold
+                            if (dbg_first_duty == 0ull) dbg_first_duty = __builtin_amdgcn_s_memrealtime();
+                            ++dbg_iters;
+                        }
+                    }
+                }
+            }
+            // finalise the oldest query once its streaming waves have all counted themselves out
+            {
+                const uint32_t tp = tail & 1u;
+                uint32_t *mp = L.misc[tp];
+                if (tail < staged && __builtin_amdgcn_readfirstlane(lds_load(&mp[MISC_DONE])) >= n_active) {
+                    asm volatile("" ::: "memory");
+                    StreamParams P = P0;
+                    P.gmax = B.gmax(tail);
+                    if (P0.n_sets != 0u) publish_group_max(P, bid, lane, mp);  // complete maxima (fire and forget)
+                    if (P0.dbg && lane == 0) {  // TKSPMV_STATS=1
+                        atomicAdd(&P0.dbg[0], (unsigned long long)mp[MISC_SLOW_CNT]);
+                        atomicAdd(&P0.dbg[1], (unsigned long long)mp[MISC_CAND_CNT]);
+                    }
+                    // lane l copies entry (l % 8) of wave (l / 8): the first goes to the wave's slot, others to the
+                    // query's overflow list
+                    const uint32_t w = lane >> 3, e = lane & 7u;
+                    const uint32_t cnt = L.stg_cnt[tp][w];
+                    const bool have = e < cnt;
+                    const unsigned long long v = have ? L.stg[tp][w][e] : 0ull;
+                    const bool extra = have && e > 0u;
+                    const uint64_t bm = __ballot(extra);
+                    uint32_t gbase = 0u;
+                    if (bm) {
+                        if (lane == 0) gbase = atomicAdd(B.ovf_count(tail), (uint32_t)__popcll(bm));
+                        gbase = __builtin_amdgcn_readfirstlane(gbase);
+                    }
+                    if (have && e == 0u) st_agent(B.wg_cand(tail) + (size_t)bid * WG_SLOTS + w, v);
+                    if (extra) {
+                        const uint32_t gp = gbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
+                        if (gp < P0.ovf_cap) st_agent(&B.ovf_cand(tail)[gp], v);
+                    }
+                    if (bid == 0u && lane == 0)
+                        __hip_atomic_store(B.unit_inv(tail), inv_unit_q[tp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    // Hand-off as in the fused tail (cdna_hip_programming.md Guideline 16): everything above is a
+                    // write-through (sc1) store; drain them, then a RELAXED agent-scope add. A release-ordered atomic
+                    // would write back the whole L2 (buffer_wbl2) once per workgroup and query: measured 4 ms/query.
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (lane == 0)
+                        (void)__hip_atomic_fetch_add(B.tickets + 32u * tail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (trw && lane == 0 && TRSLOT(tail) < 3u) trw[4 + TRSLOT(tail)] = __builtin_amdgcn_s_memrealtime();
+                    if (trw && lane == 0 && TRSLOT(tail) == 1u) {
+                        trw[3] = dbg_first_duty;
+                        trw[6] = dbg_iters;  // (overwritten by the last query's finalise stamp; read when nq is small only)
+                    }
+                    ++tail;
+                }
+            }
+            if (tail == nq) break;
+            if (reducer) __builtin_amdgcn_s_sleep(TKSPMV_REDUCER_SLEEP);
+            else __builtin_amdgcn_s_sleep(8);
+        }
+        return;
+    }
+
+    // ---- streaming waves ---------------------------------------------------------------------------------------
+    __builtin_amdgcn_s_setprio(TKSPMV_STREAM_PRIO);
+    const uint32_t part = wave * n_wg + bid;
+    uint32_t p0 = 0, np = 0;
+    if (part < P0.n_parts) {
+        p0 = P0.part_first[part];
+        np = P0.part_count[part];
+    }
+    uint2 *wcand = L.u.w.cand + wave * WAVE_CAP;
+    if (np == 0u) return;  // no partition (n_active does not count this wave)
+
+    Pkt<C, VT> buf[NBUF];
+    uint32_t rbs[NBUF];
+    // Next packet to request: a running pointer into the stream copy of its query, a running pointer into pkt_row, and two
+    // down-counters (requests left in the query, requests left in the launch): per request two pointer increments and a
+    // compare; no multiply, nothing re-read from the kernel arguments (measured with rocprofv3 --pmc: the kernel issued
+    // as many scalar as vector instructions, ~100 per packet, a third of them in this bookkeeping).
+    uint32_t qa = 0u;
+    const size_t part_off = (size_t)p0 * P0.packet_bytes;
+    const uint8_t *pk_a = B.io[0].packets + part_off;
+    const uint32_t *row_a = P0.pkt_row + p0;
+    uint32_t left_q = np, left_all = np * nq;
+#define TKSPMV_REQUEST(dst, rb_dst)                                                                                   \
+    do {                                                                                                              \
+        load_packet<C, VT>(pk_a, lane, dst);                                                                          \
+        rb_dst = *row_a;                                                                                              \
+        if (left_all > 1u) { /* past the end: the last packet is requested again (counted vmcnt) */                    \
+            --left_all;                                                                                               \
+            pk_a += P0.packet_bytes;                                                                                  \
+            ++row_a;                                                                                                  \
+            if (--left_q == 0u) {                                                                                     \
+                left_q = np;                                                                                          \
+                ++qa;                                                                                                 \
+                pk_a = B.io[qa].packets + part_off;                                                                   \
+                row_a = P0.pkt_row + p0;                                                                              \
+            }                                                                                                         \
+        }                                                                                                             \
+    } while (0)
+#pragma unroll
+    for (int u = 0; u < NBUF - 1; ++u) TKSPMV_REQUEST(buf[u], rbs[u]);
+    rbs[NBUF - 1] = 0u;
+
+    uint32_t qc = 0u, jc = 0u;  // packet being reduced
+    float carry = 0.0f, min_units = 0.0f;
+    uint32_t wcnt = 0u;
+    bool waited = false;  // this wave has used its bounded wait for a threshold in the current query
+    const bool long_partition = np * (uint32_t)(C / 4) >= 28u;  // ~14 rows finish per 256 entries: > 1.5 lists per query
+    uint32_t *mp = L.misc[0];
+    const float *xq = L.u.w.x[0];
+    StreamParams P = P0;
+    constexpr uint32_t DEFER_B = (uint32_t)BatchLds<XCOLS, C>::DEFER_B;
+    static_assert(C == 4 || C == 8, "the batch kernel is built for 4 or 8 entries per lane");
+
+    const uint32_t total = np * nq;
+    for (uint32_t i0 = 0; i0 < total; i0 += NBUF) {
+#pragma unroll
+        for (int u = 0; u < NBUF; ++u) {
+            if (i0 + (uint32_t)u >= total) break;
+            const Pkt<C, VT> &cur = buf[u];
+            const uint32_t rb_cur = rbs[u];
+            TKSPMV_REQUEST(buf[(u + NBUF - 1) % NBUF], rbs[(u + NBUF - 1) % NBUF]);
+            if (jc == 0u) {  // a new query starts: its x must have been staged
+                mp = L.misc[qc & 1u];
+                xq = L.u.w.x[qc & 1u];
+                while (lds_load(&mp[MISC_XREADY]) != qc + 1u) __builtin_amdgcn_s_sleep(2);
+                asm volatile("" ::: "memory");
+                min_units = __uint_as_float(lds_load(&mp[MISC_MINU]));
+                if (trw && lane == 0 && TRSLOT(qc) < 3u) trw[1 + TRSLOT(qc)] = __builtin_amdgcn_s_memrealtime();
+                P.ovf_cand = B.ovf_cand(qc);
+                P.ovf_count = B.ovf_count(qc);
+                carry = 0.0f;
+                wcnt = 0u;
+                waited = false;
+            }
+            const float tau = __uint_as_float(lds_load(&mp[MISC_TAU]));
+            const RowSums<C> R = reduce_packet<C, QM>(cur, carry, xq, P0.fixed_mask);
+            if (jc < DEFER_B && P0.n_sets != 0u) {
+                uint32_t fl = 0u;
+#pragma unroll
+                for (int h = 0; h < C / 4; ++h) {
+                    L.drs[wave][jc][h][lane] = make_float4(R.rs[4 * h], R.rs[4 * h + 1], R.rs[4 * h + 2], R.rs[4 * h + 3]);
+                    fl |= ((R.cw[2 * h] & 0x00030003u) << (4 * h)) | ((R.cw[2 * h + 1] & 0x00030003u) << (4 * h + 2));
+                }
+                L.dfl[wave][jc][lane] = fl;
+                if (lane == 0) L.drb[wave][jc] = rb_cur;
+                const float wmax = wave_max(lane_best<C, QM>(R));
+                if (lane == 0 && publishes && wmax >= min_units)
+                    (void)__hip_atomic_fetch_max(&mp[MISC_GRPMAX + grp_local], order_key(wmax), __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else if (__any(R.best_any >= tau) && !(P0.dbg_flags & 2u)) {
+                float tau_now = tau;
+                // Long partitions only (more rows per wave and query than its list holds: from ~1.5M rows on 256 CUs). A
+                // wave that runs ahead of its workgroup's exchange has no threshold yet: every row passes, and once the
+                // list is nearly full the rest would pour into the query's overflow list. It is ahead of the others anyway:
+                // it waits for the threshold instead, bounded, once per query (2M rows: 40.4 against 42.1 us per query, 3M:
+                // 58.5 against 60.7). On shorter partitions the list holds a whole query's rows and the wait only costs
+                // the overlap of consecutive queries (1M rows, bench.py's conditions: 3-10 % slower), hence the condition.
+                if (long_partition && wcnt + 2u * 64u > WAVE_CAP && tau <= min_units && P0.tau_possible && !waited) {
+                    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                    while (lds_load(&mp[MISC_TAU]) == __float_as_uint(min_units) && __builtin_amdgcn_s_memrealtime() - t0 < BATCH_TAU_WAIT)
+                        __builtin_amdgcn_s_sleep(4);
+                    waited = true;
+                    tau_now = __uint_as_float(lds_load(&mp[MISC_TAU]));
+                }
+                if (tau_now == tau || __any(R.best_any >= tau_now))
+                    offer_candidates<C, QM, WAVE_CAP>(P, R, rb_cur, tau_now, lane, grp_local, publishes, wcand, wcnt, mp);
+            }
+            if (jc + 1u == np) {  // the query ends for this wave
+                if (P0.n_sets != 0u) {
+                    // A workgroup that runs ahead of the others can get here before any threshold exists for this
+                    // query; judging now would keep (and dump to global memory) every row it has seen. Give the
+                    // exchange a moment -- bounded: after BATCH_TAU_WAIT the wave goes on without a threshold, so
+                    // progress never depends on other workgroups being resident.
+                    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                    while (P0.tau_possible && lds_load(&mp[MISC_TAU]) == __float_as_uint(min_units) && !(P0.dbg_flags & 4u) &&
+                           __builtin_amdgcn_s_memrealtime() - t0 < BATCH_TAU_WAIT)
+                        __builtin_amdgcn_s_sleep(4);
+                    const float tau2 = __uint_as_float(lds_load(&mp[MISC_TAU]));
+                    const uint32_t nd = np < DEFER_B ? np : DEFER_B;
+                    for (uint32_t d = 0; d < nd; ++d) {
+                        const uint32_t c = L.dfl[wave][d][lane];
+                        RowSums<C> S;
+#pragma unroll
+                        for (int h = 0; h < C / 4; ++h) {
+                            const float4 v = L.drs[wave][d][h][lane];
+                            S.rs[4 * h] = v.x;
+                            S.rs[4 * h + 1] = v.y;
+                            S.rs[4 * h + 2] = v.z;
+                            S.rs[4 * h + 3] = v.w;
+                            S.cw[2 * h] = (c >> (4 * h)) & 0x00030003u;
+                            S.cw[2 * h + 1] = (c >> (4 * h + 2)) & 0x00030003u;
+                        }
+                        float best = -__builtin_huge_valf();
+#pragma unroll
+                        for (int j = 0; j < C; ++j) best = (S.end(j) && S.rs[j] > best) ? S.rs[j] : best;
+                        S.best_any = best;
+                        const uint32_t rb_d = __builtin_amdgcn_readfirstlane(L.drb[wave][d]);
+                        if (__any(best >= tau2))
+                            offer_candidates<C, QM, WAVE_CAP>(P, S, rb_d, tau2, lane, grp_local, publishes, wcand, wcnt, mp);
+                    }
+                }
+                const float tau3 = __uint_as_float(lds_load(&mp[MISC_TAU]));
+                ListScan<WAVE_CAP / 64u> LS;
+                const uint32_t surv = scan_list<WAVE_CAP / 64u>(wcand, wcnt, tau3, lane, LS);
+                uint32_t gbase = 0u;
+                if (surv > STG_N) {  // rare: more survivors than the staging area holds go to global memory directly
+                    if (lane == 0) gbase = atomicAdd(P.ovf_count, surv - STG_N);
+                    gbase = __builtin_amdgcn_readfirstlane(gbase);
+                }
+#pragma unroll
+                for (uint32_t e = 0; e < WAVE_CAP / 64u; ++e) {
+                    if (LS.keep[e]) {
+                        const unsigned long long v = pack_cand(LS.e[e].x, LS.e[e].y);
+                        if (LS.pos[e] < STG_N) L.stg[qc & 1u][wave][LS.pos[e]] = v;
+                        else if (gbase + LS.pos[e] - STG_N < P0.ovf_cap) st_agent(&P.ovf_cand[gbase + LS.pos[e] - STG_N], v);
+                    }
+                }
+                if (surv > STG_N) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // those stores precede the ticket
+                if (lane == 0) L.stg_cnt[qc & 1u][wave] = surv < STG_N ? surv : STG_N;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) atomicAdd(&mp[MISC_DONE], 1u);
+                if (trw && lane == 0 && TRSLOT(qc) < 3u) {
+                    trw[4 + TRSLOT(qc)] = __builtin_amdgcn_s_memrealtime();
+                    trw[7] = (TRSLOT(qc) == 0u ? 0ull : trw[7]) | ((unsigned long long)(((surv > 0xFFu ? 0xFFu : surv) << 8) | 0xFFu) << (16u * TRSLOT(qc))) |
+                             ((unsigned long long)(tau3 <= min_units ? 1u : 0u) << (48u + TRSLOT(qc)));
+                }
+                ++qc;
+                jc = 0u;
+            } else {
+                ++jc;
+            }
+        }
+    }
+#undef TKSPMV_REQUEST
+}
+
+}  // namespace tkspmv

@@ -1,0 +1,136 @@
+// kernels/common.hpp -- Device helpers shared by every kernel: order keys, kernel parameter blocks, packet loads, fixed-point conversions.
+// Part of engine.hip (one translation unit: included there in this order; device code only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace tkspmv {
+
+// ------------------------------------------------------------------------------------------------------------
+// Device helpers
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t order_key(float f) {  // monotone float -> u32; 0 is "nothing"
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key_to_float(uint32_t k) {
+    uint32_t u = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+    return __uint_as_float(u);
+}
+
+struct StreamParams {
+    const uint8_t *packets;
+    const uint32_t *pkt_row;
+    const uint32_t *part_first;
+    const uint32_t *part_count;
+    const float *x;
+    uint32_t n_parts, cols, packet_bytes;
+    uint32_t n_sets;        // 0 => threshold exchange disabled (fewer publishing groups than k), else 1
+    uint32_t k;
+    uint32_t n_groups_pub;  // groups [0, n_groups_pub) publish maxima (<= 1024)
+    uint32_t gpw;           // groups per workgroup
+    float min_score;
+    uint32_t fixed_width, fixed_mask;  // TKSPMV_FIXED: bits per value and the mask of the top fixed_width bits
+    uint32_t *gmax;  // [MAX_GM*64] order keys of the group maxima (zero beyond n_groups_pub)
+    uint32_t *tau_g; // one word: order key of the broadcast threshold (monotone, atomic max)
+    uint32_t tau_possible;  // 1: at least k publishing groups own rows, so a threshold can form (else nobody waits for one)
+    uint32_t n_reducers;  // workgroups [0, n_reducers) reduce gmax -> tau_g; the others only read tau_g
+    unsigned long long *wg_cand;  // [grid][WG_SLOTS] packed {score bits | row << 32}; unused slots: row SLOT_INVALID
+    unsigned long long *ovf_cand;
+    uint32_t *ovf_count;
+    uint32_t ovf_cap;
+    uint32_t fused;  // 1: the last workgroup to finish runs the selection (no second launch)
+    // 1: deferred selection. Workgroup 0 of this launch selects the PREVIOUS query's top-k (its survivors sit in
+    // the other exchange-state set, complete and visible since that launch ended) and exits; workgroups 1..grid-1
+    // stream the current query and end with the flush. No ticket, no second launch, nothing on the critical path.
+    uint32_t deferred;
+    float *unit_inv_out;  // 1 / (score units per 1.0) of this query, for a selection that runs in a later launch
+    float *scores;  // SCORES variant only
+    uint32_t dbg_flags;       // ablation switches (TKSPMV_DBG_FLAGS): 1 no publish, 2 no offers, 4 no tau duty, 8 no flush
+    const uint8_t *rep_packets[4];  // experiment (TKSPMV_DBG_REPEAT): stream copies the repeats rotate over
+    uint32_t dbg_repeat;            // experiment: passes over the partition within ONE launch (0/1 = normal)
+    unsigned long long *trace;   // optional (TKSPMV_TRACE=1): per-wave s_memrealtime stamps, [grid+1][9 waves][8]
+    unsigned long long *stamps;  // optional (TKSPMV_STAMPS=1): s_memtime stamps of the selection tail, last workgroup
+    unsigned long long *dbg;  // optional counters (TKSPMV_STATS=1): [0] slow-path executions, [1] appended rows
+};
+
+constexpr int MISC_CAND_CNT = 0, MISC_TAU = 1, MISC_DONE = 5, MISC_XMAX = 6, MISC_SLOW_CNT = 7,
+              MISC_GRPMAX = 8 /* [8] */, MISC_PUBLISHED = 16 /* [8] */, MISC_WORDS = 32;  // <= 8 groups per workgroup
+// Private candidate list of a streaming wave (entries in LDS): 256 while x is small, 128 when x itself takes 64 KiB
+// (two workgroups must still fit the CU's 160 KiB).
+template <int XCOLS>
+struct ListGeom {
+    static constexpr uint32_t WAVE_CAP = XCOLS <= 1024 ? 256u : 128u;
+    static constexpr uint32_t CAND_CAP = 8u * WAVE_CAP;  // per workgroup: up to 8 streaming waves
+};
+constexpr uint32_t WG_SLOTS = 8;              // fixed result slots every workgroup writes (no count round trip)
+constexpr uint32_t SLOT_INVALID = 0xFFFFFFFFu;  // row id of an unused slot
+
+// One lane's share of a packet. VT = value type of the stream: 0 = C fp32 values; 1 = C Q1.7 values packed four to a
+// dword; 2 = C fp16 values packed two to a dword.
+// QM (kernel template parameter): 0 = fp32, 1 = Q1.7 strict (8-bit wrapping sums, the FPGA's real_type), 2 = Q1.7 values
+// with x block-scaled by a power of two per query and exact wide accumulation, 3 = fp16 values, fp32 x, fp32 arithmetic
+// (the CUDA comparator's half mode, -a: host_spmv_topk_csr_gpu.cu:132-136,152-160), 4 = fixed point of W bits (the
+// FPGA's real_type for any FIXED_WIDTH): values and x as left-aligned Q1.31 words, integer products and sums.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+constexpr int value_type_of(int QM) { return QM == 3 ? 2 : ((QM == 1 || QM == 2) ? 1 : 0); }  // QM 4: one u32 per value, loaded like fp32
+
+// The packet stream is read once per query: nontemporal loads (a plain read kernel over the same bytes gains 12 %
+// from them when the stream comes from HBM, tools/stream_probe.hip).
+template <int C, int VT>
+struct Pkt {
+    float v[VT == 0 ? C : 1];
+    uint32_t vq[VT == 1 ? C / 4 : (VT == 2 ? C / 2 : 1)];
+    uint32_t cw[C / 2];
+};
+
+template <int C, int VT>
+__device__ __forceinline__ void load_packet(const uint8_t *__restrict__ pk, uint32_t lane, Pkt<C, VT> &o) {
+#pragma unroll
+    for (int q = 0; q < C / 4; ++q) {
+        if (VT == 1) {
+            o.vq[VT == 1 ? q : 0] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(pk + q * 256 + lane * 4));
+            const u32x2 c = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(pk + C * 64 + q * 512 + lane * 8));
+            o.cw[2 * q + 0] = c.x;
+            o.cw[2 * q + 1] = c.y;
+        } else if (VT == 2) {
+            const u32x2 hv = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(pk + q * 512 + lane * 8));
+            o.vq[VT == 2 ? 2 * q + 0 : 0] = hv.x;
+            o.vq[VT == 2 ? 2 * q + 1 : 0] = hv.y;
+            const u32x2 c = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(pk + C * 128 + q * 512 + lane * 8));
+            o.cw[2 * q + 0] = c.x;
+            o.cw[2 * q + 1] = c.y;
+        } else {
+            const f32x4 f = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(pk + q * 1024 + lane * 16));
+            o.v[VT == 0 ? 4 * q + 0 : 0] = f.x;
+            o.v[VT == 0 ? 4 * q + 1 : 0] = f.y;
+            o.v[VT == 0 ? 4 * q + 2 : 0] = f.z;
+            o.v[VT == 0 ? 4 * q + 3 : 0] = f.w;
+            const u32x2 c = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(pk + C * 256 + q * 512 + lane * 8));
+            o.cw[2 * q + 0] = c.x;
+            o.cw[2 * q + 1] = c.y;
+        }
+    }
+}
+
+// Q1.7 helpers (restating ap_ufixed<8,1,AP_TRN_ZERO>, fpga_types.hpp:20: 1 integer + 7 fraction bits, truncation).
+// Conversion from float saturates at the top of the range (the HLS type would wrap there; inputs are expected in
+// [0, 2)). Products are truncated to Q1.7 and wrap to 8 bits; sums wrap to 8 bits (mod 2.0).
+__device__ __forceinline__ uint32_t to_q1_7_dev(float v) {
+    const float s = fminf(fmaxf(v * 128.0f, 0.0f), 255.0f);  // NaN -> 0
+    return (uint32_t)s;                                       // truncation
+}
+// Generic width (wbscsr.hpp to_fixed): W bits, 1 integer bit, left-aligned in a u32; truncation, saturation at the top.
+__device__ __forceinline__ uint32_t to_fixed_dev(float v, uint32_t W) {
+    if (!(v > 0.0f)) return 0u;
+    const float s = v * (float)(1u << (W - 1u));
+    const float top = W == 32u ? 4294967296.0f : (float)(1u << W);
+    const uint32_t q = s >= top ? (W == 32u ? 0xFFFFFFFFu : (1u << W) - 1u) : (uint32_t)s;
+    return q << (32u - W);
+}
+__device__ __forceinline__ float q17_wrap(float units) {  // units = exact integer sum held in fp32
+    return (float)(((uint32_t)units) & 255u);
+}
+
+}  // namespace tkspmv

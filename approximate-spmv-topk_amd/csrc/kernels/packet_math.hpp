@@ -1,0 +1,390 @@
+// kernels/packet_math.hpp -- Per-packet arithmetic of the wave-BSCSR kernels: DPP helpers, threshold exchange helpers, products, in-lane segmented sums, the clipped cross-lane scan, the candidate path.
+// Part of engine.hip (one translation unit: included there in this order; device code only).
+#pragma once
+#include "select.hpp"
+
+namespace tkspmv {
+
+// DPP lane movement (gfx950 keeps the GFX9 controls): lanes without a valid source receive 0.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_zero(float src) {
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, src), CTRL, ROW_MASK, 0xF, true));
+}
+constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114, DPP_ROW_SHR8 = 0x118;
+constexpr int DPP_WAVE_SHL1 = 0x130, DPP_WAVE_SHR1 = 0x138, DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143;
+
+// Wave-wide maximum with DPP (result uniform, returned through an SGPR).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_keep(float v) {  // lanes without a valid source keep their own value
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v),
+                                                                 CTRL, ROW_MASK, 0xF, false));
+}
+__device__ __forceinline__ float wave_max(float v) {
+    v = fmaxf(v, dpp_keep<DPP_ROW_SHR1, 0xF>(v));
+    v = fmaxf(v, dpp_keep<DPP_ROW_SHR2, 0xF>(v));
+    v = fmaxf(v, dpp_keep<DPP_ROW_SHR4, 0xF>(v));
+    v = fmaxf(v, dpp_keep<DPP_ROW_SHR8, 0xF>(v));
+    v = fmaxf(v, dpp_keep<DPP_ROW_BCAST15, 0xA>(v));
+    v = fmaxf(v, dpp_keep<DPP_ROW_BCAST31, 0xC>(v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+    auto mv = [](uint32_t a, uint32_t b) { return b < a ? b : a; };
+    v = mv(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_ROW_SHR1, 0xF, 0xF, false));
+    v = mv(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_ROW_SHR2, 0xF, 0xF, false));
+    v = mv(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_ROW_SHR4, 0xF, 0xF, false));
+    v = mv(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_ROW_SHR8, 0xF, 0xF, false));
+    v = mv(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_ROW_BCAST15, 0xA, 0xF, false));
+    v = mv(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_ROW_BCAST31, 0xC, 0xF, false));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// Threshold exchange, reader side. One wave: (1) issue the loads of the published maxima early, (2) much later
+// stage them in LDS and reduce: tau = min over sets of (max over the set's groups).
+struct TauRegs {
+    uint32_t k[MAX_GM];
+};
+__device__ __forceinline__ void tau_issue(const StreamParams &P, uint32_t lane, TauRegs &t) {
+    // gmax is allocated with MAX_GM * 64 entries (zero beyond n_groups_pub), so no bounds predicate is needed;
+    // whole 256-B rows beyond the used part are skipped with a uniform branch.
+#pragma unroll
+    for (int i = 0; i < MAX_GM; ++i) {
+        t.k[i] = 0u;
+        if (64u * i < P.n_groups_pub)
+            t.k[i] = __hip_atomic_load(&P.gmax[lane + 64u * i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+// tau = (lower bound within 2^-8 relative of) the k-th largest published maximum: the maxima are scores of distinct
+// rows, so k of them at or above tau prove that the k-th best score overall is at least tau.
+__device__ __forceinline__ float tau_from_maxima(const StreamParams &P, const TauRegs &t, const float min_units) {
+    const uint32_t rows_used = (P.n_groups_pub + 63u) >> 6;
+    uint32_t key;
+    if (rows_used <= 1) key = kth_largest_prefix<1, 17>(t.k, P.k);
+    else if (rows_used <= 2) key = kth_largest_prefix<2, 17>(t.k, P.k);
+    else if (rows_used <= 4) key = kth_largest_prefix<4, 17>(t.k, P.k);
+    else if (rows_used <= 8) key = kth_largest_prefix<8, 17>(t.k, P.k);
+    else key = kth_largest_prefix<16, 17>(t.k, P.k);
+    float tau = min_units;
+    if (key != 0u) {
+        const float f = key_to_float(key);
+        tau = f > tau ? f : tau;
+    }
+    return tau;
+}
+
+// Writer side: lanes 0..gpw-1 of the calling wave push the workgroup's group maxima (kept in LDS) to gmax.
+__device__ __forceinline__ void publish_group_max(const StreamParams &P, uint32_t bid, uint32_t lane, uint32_t *misc) {
+    if (lane < P.gpw) {
+        const uint32_t g = bid * P.gpw + lane;
+        const uint32_t key = misc[MISC_GRPMAX + lane];
+        if (g < P.n_groups_pub && key > misc[MISC_PUBLISHED + lane]) {
+            misc[MISC_PUBLISHED + lane] = key;
+            // single writer per slot (this workgroup): a write-through store, no memory-side read-modify-write
+            __hip_atomic_store(&P.gmax[g], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// The fused streaming kernel
+// ------------------------------------------------------------------------------------------------------------
+// ---- single-instruction helpers ---------------------------------------------------------------------------------
+// hipcc turns mask arithmetic back into v_cmp + v_cndmask (+ s_nop hazards); these keep it at one VALU op each.
+// All are plain VGPR -> VGPR VALU operations (no hazard besides the DPP one noted at `tail` below).
+template <int BIT>
+__device__ __forceinline__ uint32_t bit_mask(uint32_t w) {  // all ones iff bit BIT of w is set
+    uint32_t r;
+    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(r) : "v"(w), "n"(BIT));
+    return r;
+}
+__device__ __forceinline__ float mask_select(uint32_t m, float if_set, float if_clear) {  // bitwise m ? a : b
+    float r;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(m), "v"(if_set), "v"(if_clear));
+    return r;
+}
+__device__ __forceinline__ float mask_clear(uint32_t m, float a) {  // a where m is clear, +0.0 where set
+    float r;
+    asm("v_bfi_b32 %0, %1, 0, %2" : "=v"(r) : "v"(m), "v"(a));
+    return r;
+}
+__device__ __forceinline__ float max3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+// Finished-row sums of one packet as seen by one lane. The flags stay where they are, in the packet's column
+// words: entry j -> word j/2, bits 16*(j&1) (ROW_END) and 16*(j&1)+1 (SKIP).
+template <int C>
+struct RowSums {
+    float rs[C];
+    uint32_t cw[C / 2];
+    float best_any;  // max over the lane's row ends, placeholders included: only the hot-path trigger uses it
+    __device__ __forceinline__ bool end(int j) const { return (cw[j >> 1] >> (16 * (j & 1))) & 1u; }
+    __device__ __forceinline__ bool valid(int j) const { return ((cw[j >> 1] >> (16 * (j & 1))) & 3u) == 1u; }
+};
+
+// Products, in-lane segmented sums, cross-lane segmented scan. Updates the packet carry.
+// Arithmetic (mirrored statement for statement by oracle_packed_scores in oracle/oracle.c):
+//   p_j = v_j * x[col_j];  p_0 += carry on lane 0;  s_0 = p_0,  s_j = (end_{j-1} ? +0 : s_{j-1}) + p_j
+//   tail = end_{C-1} ? +0 : s_{C-1};   head = s at the lane's first row end
+//   vv = clipped Kogge-Stone scan of tail over the 64 lanes (never across a lane that holds a row end)
+//   row sum at the lane's first row end = vv[lane-1] + head, at its later row ends = s_j; carry' = vv[63]
+// The reduction proper, from the C products of a lane (p) and its column words (cwv).
+// INT: the C "floats" (and the carry) hold u32 fixed-point words; every sum is an integer add (wrapping at 2^32 = 2.0 in
+// Q1.31: the reference's real_type sums wrap the same way), lane movement and masking are bitwise either way. At the end
+// the row sums are converted to fp32 (round to nearest even, what C's (float)u32 does) so that thresholds, candidate
+// lists and the selection see ordinary floats: "score units" of 2^-31.
+template <bool INT>
+__device__ __forceinline__ float add_rn(float a, float b) {
+    if (INT) return __uint_as_float(__float_as_uint(a) + __float_as_uint(b));
+    return __fadd_rn(a, b);
+}
+template <int C, bool INT = false>
+__device__ __forceinline__ RowSums<C> reduce_core(float (&p)[C], const uint32_t (&cwv)[C / 2], float &carry) {
+    uint32_t m[C];  // all-ones where entry j ends a row
+#pragma unroll
+    for (int j = 0; j < C; ++j) m[j] = (j & 1) ? bit_mask<16>(cwv[j >> 1]) : bit_mask<0>(cwv[j >> 1]);
+    p[0] = __builtin_amdgcn_inverse_ballot_w64(1ull) ? add_rn<INT>(p[0], carry) : p[0];  // lane 0 only
+
+    float s[C];
+    uint32_t o[C];  // o_j = m_0 | ... | m_j
+    s[0] = p[0];
+    o[0] = m[0];
+#pragma unroll
+    for (int j = 1; j < C; ++j) {
+        s[j] = add_rn<INT>(mask_clear(m[j - 1], s[j - 1]), p[j]);
+        o[j] = o[j - 1] | m[j];
+    }
+    float head = s[C - 1];
+#pragma unroll
+    for (int j = C - 2; j >= 0; --j) head = mask_select(m[j], s[j], head);
+    float tail;
+    // (the DPP instruction that reads `tail` next needs two wait states after a VALU write; the compiler does
+    //  not look inside asm, hence the explicit s_nop)
+    asm("v_bfi_b32 %0, %1, 0, %2\n\ts_nop 1" : "=v"(tail) : "v"(m[C - 1]), "v"(s[C - 1]));
+
+    // Lane masks of the clipped scan, computed once on the scalar unit from H = lanes holding a row end:
+    //   M_d  : no row end in lanes (l-d, l]                     (steps row_shr:1,2,4,8)
+    //   P16  : no row end in [first lane of l's 16-lane row, l]  (step row_bcast:15)
+    //   P32  : no row end in [first lane of l's 32-lane half, l] (step row_bcast:31)
+    const uint64_t H = __ballot(o[C - 1] != 0u);
+    const uint64_t M1 = ~H;
+    const uint64_t M2 = M1 & ((M1 << 1) | 0x1ull);
+    const uint64_t M4 = M2 & ((M2 << 2) | 0x3ull);
+    const uint64_t M8 = M4 & ((M4 << 4) | 0xFull);
+    uint64_t P16 = M1 & ((M1 << 1) | 0x0001000100010001ull);
+    P16 &= (P16 << 2) | 0x0003000300030003ull;
+    P16 &= (P16 << 4) | 0x000F000F000F000Full;
+    P16 &= (P16 << 8) | 0x00FF00FF00FF00FFull;
+    // upper row of each half also needs the whole lower row clear: bit 15 / 47 of P16
+    const uint64_t low_clear = ((P16 >> 15) & 0x0000000100000001ull) * 0xFFFF0000ull;
+    const uint64_t P32 = P16 & (low_clear | 0x0000FFFF0000FFFFull);
+
+    float vv = tail;
+    {
+        float t;
+        t = add_rn<INT>(vv, dpp_zero<DPP_ROW_SHR1, 0xF>(vv));
+        vv = __builtin_amdgcn_inverse_ballot_w64(M1) ? t : vv;
+        t = add_rn<INT>(vv, dpp_zero<DPP_ROW_SHR2, 0xF>(vv));
+        vv = __builtin_amdgcn_inverse_ballot_w64(M2) ? t : vv;
+        t = add_rn<INT>(vv, dpp_zero<DPP_ROW_SHR4, 0xF>(vv));
+        vv = __builtin_amdgcn_inverse_ballot_w64(M4) ? t : vv;
+        t = add_rn<INT>(vv, dpp_zero<DPP_ROW_SHR8, 0xF>(vv));
+        vv = __builtin_amdgcn_inverse_ballot_w64(M8) ? t : vv;
+        t = add_rn<INT>(vv, dpp_zero<DPP_ROW_BCAST15, 0xA>(vv));  // lane 15 -> row 1, lane 47 -> row 3
+        vv = __builtin_amdgcn_inverse_ballot_w64(P16) ? t : vv;
+        t = add_rn<INT>(vv, dpp_zero<DPP_ROW_BCAST31, 0xC>(vv));  // lane 31 -> rows 2 and 3
+        vv = __builtin_amdgcn_inverse_ballot_w64(P32) ? t : vv;
+    }
+    const float cin = dpp_zero<DPP_WAVE_SHR1, 0xF>(vv);  // lane l-1's inclusive sum; 0 for lane 0
+    const float S = add_rn<INT>(cin, head);
+    carry = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, vv), 63));
+
+    RowSums<C> out;
+    out.rs[0] = S;  // if entry 0 ends a row it is the lane's first row end
+#pragma unroll
+    for (int j = 1; j < C; ++j) out.rs[j] = mask_select(o[j - 1], s[j], S);  // an earlier end in the lane => s_j
+    if (INT) {
+#pragma unroll
+        for (int j = 0; j < C; ++j) out.rs[j] = (float)__float_as_uint(out.rs[j]);  // fixed-point word -> score units
+    }
+#pragma unroll
+    for (int j = 0; j < C / 2; ++j) out.cw[j] = cwv[j];
+    const float NEG_INF = -__builtin_huge_valf();
+    float e[C];
+#pragma unroll
+    for (int j = 0; j < C; ++j) e[j] = mask_select(m[j], out.rs[j], NEG_INF);
+    float best = max3(e[0], e[1], e[2]);
+#pragma unroll
+    for (int j = 3; j < C; j += 2) best = max3(best, e[j], (j + 1 < C) ? e[j + 1] : NEG_INF);
+    out.best_any = best;
+    return out;
+}
+
+// Products from a packet and the x vector staged in LDS, then the reduction.
+template <int C, int QM>
+__device__ __forceinline__ RowSums<C> reduce_packet(const Pkt<C, value_type_of(QM)> &cur, float &carry, const float *x_lds,
+                                                    const uint32_t fixed_mask = 0u) {
+    constexpr int VT = value_type_of(QM);
+    float p[C];
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+        const uint32_t word = cur.cw[j >> 1];
+        const uint32_t off = (j & 1) ? ((word >> 16) & 0xFFFCu) : (word & 0xFFFCu);  // byte offset of x[col]
+        if (VT == 1) {
+            // x is staged as Q1.7 integers; product truncated to Q1.7 and wrapped to 8 bits, exact in fp32
+            const uint32_t xq = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const unsigned char *>(x_lds) + off);
+            const uint32_t vq = (cur.vq[VT == 1 ? (j >> 2) : 0] >> (8 * (j & 3))) & 255u;
+            // both factors are below 2^8: the 24-bit multiply is exact (and full rate; v_mul_lo_u32 is quarter rate)
+            const uint32_t t = __umul24(vq, xq);
+            p[j] = (float)(QM == 2 ? (t >> 7) : ((t >> 7) & 255u));  // wide mode: no wrap
+        } else if (VT == 2) {
+            const float xv = *reinterpret_cast<const float *>(reinterpret_cast<const unsigned char *>(x_lds) + off);
+            const uint32_t hw = cur.vq[VT == 2 ? (j >> 1) : 0];
+            const _Float16 hv = __builtin_bit_cast(_Float16, (uint16_t)((j & 1) ? (hw >> 16) : (hw & 0xFFFFu)));
+            p[j] = __fmul_rn((float)hv, xv);  // the conversion is exact
+        } else if (QM == 4) {
+            // both factors are Q1.31 words: the 64-bit product is Q2.62; bits 31..62 are the product in Q1.31 (its integer
+            // part wrapped to one bit, like an assignment to real_type), masked down to the W-1 fraction bits kept
+            const uint32_t xq = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const unsigned char *>(x_lds) + off);
+            const uint32_t vq = __float_as_uint(cur.v[VT == 0 ? j : 0]);
+            if (fixed_mask & 0xFFu) {
+                p[j] = __uint_as_float(__builtin_amdgcn_alignbit(__umulhi(vq, xq), vq * xq, 31) & fixed_mask);
+            } else {
+                // W <= 24: the low 8 bits of every word are zero and x was staged shifted down by 8, so both factors are
+                // 24-bit integers (Q1.23) and the full-rate 24-bit multipliers give the 48-bit product (Q2.46), of which
+                // bits 15..46 are the product in Q1.31 (v_mul_lo/hi_u32 run at quarter rate)
+                uint32_t hi;
+                const uint32_t v24 = vq >> 8;
+                asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(hi) : "v"(v24), "v"(xq));
+                p[j] = __uint_as_float(__builtin_amdgcn_alignbit(hi, __umul24(v24, xq), 15) & fixed_mask);
+            }
+        } else {
+            const float xv = *reinterpret_cast<const float *>(reinterpret_cast<const unsigned char *>(x_lds) + off);
+            p[j] = __fmul_rn(cur.v[VT == 0 ? j : 0], xv);
+        }
+    }
+    return reduce_core<C, QM == 4>(p, cur.cw, carry);
+}
+
+template <int C, int QM>
+__device__ __forceinline__ float row_score(const RowSums<C> &R, int j) {  // strict Q1.7: the 8-bit wrap of the row sum
+    return QM == 1 ? q17_wrap(R.rs[j]) : R.rs[j];
+}
+template <int C, int QM>
+__device__ __forceinline__ float lane_best(const RowSums<C> &R) {  // placeholders excluded
+    float best = -__builtin_huge_valf();
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+        const float sc = row_score<C, QM>(R, j);
+        best = (R.valid(j) && sc > best) ? sc : best;
+    }
+    return best;
+}
+
+// Number of row ends in lower lanes (=> row id of this lane's first row end is rb + that).
+template <int C>
+__device__ __forceinline__ uint32_t ends_below(const RowSums<C> &R) {
+    uint32_t below = 0;
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+        const uint64_t b = __ballot(R.end(j));
+        below += __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+    }
+    return below;
+}
+
+// Filter a wave's private candidate list against the threshold: lane l holds entries l, l+64, ... (EPL per lane);
+// keep[] / pos[] tell which survive and where they go in the compacted order. Returns the number kept.
+template <uint32_t EPL>
+struct ListScan {
+    uint2 e[EPL];
+    uint32_t pos[EPL];
+    bool keep[EPL];
+};
+template <uint32_t EPL>
+__device__ __forceinline__ uint32_t scan_list(const uint2 *wcand, uint32_t n, float tau, uint32_t lane, ListScan<EPL> &L) {
+    uint32_t total = 0;
+#pragma unroll
+    for (uint32_t u = 0; u < EPL; ++u) {
+        const uint32_t i = lane + 64u * u;
+        L.e[u] = make_uint2(0u, 0u);
+        if (i < n) L.e[u] = wcand[i];
+        L.keep[u] = i < n && __uint_as_float(L.e[u].x) >= tau;
+        const uint64_t b = __ballot(L.keep[u]);
+        L.pos[u] = total + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+        total += (uint32_t)__popcll(b);
+    }
+    return total;
+}
+// Drop what the (risen) threshold has made obsolete. All reads are issued before any write (LDS executes a wave's
+// instructions in order), so writing the kept entries to the front cannot clobber an entry still to be read.
+template <uint32_t EPL>
+__device__ __forceinline__ uint32_t compact_list(uint2 *wcand, uint32_t n, float tau, uint32_t lane) {
+    ListScan<EPL> L;
+    const uint32_t kept = scan_list<EPL>(wcand, n, tau, lane, L);
+#pragma unroll
+    for (uint32_t u = 0; u < EPL; ++u)
+        if (L.keep[u]) wcand[L.pos[u]] = L.e[u];
+    return kept;
+}
+
+// Candidate path (rare once tau has converged). Every streaming wave owns a private list of WAVE_CAP entries in LDS
+// (its length lives in an SGPR: no atomic, no other wave involved). A full list is first compacted against the
+// current threshold; only what still does not fit goes to the shared overflow list in global memory, with ONE
+// atomic per wave and packet. One LDS atomic raises the group maximum (the server wave pushes it to global memory).
+template <int C, int QM, uint32_t WAVE_CAP>
+__device__ __forceinline__ void offer_candidates(const StreamParams &P, const RowSums<C> &R, uint32_t rb, float tau,
+                                                 uint32_t lane, uint32_t grp_local, bool publishes, uint2 *wcand,
+                                                 uint32_t &wcnt, uint32_t *misc) {
+    bool pass[C];
+    uint32_t slot[C];
+    uint32_t total = 0;
+    const uint32_t below = ends_below<C>(R);
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+        pass[j] = R.valid(j) && row_score<C, QM>(R, j) >= tau;
+        const uint64_t pb = __ballot(pass[j]);
+        slot[j] = total + __builtin_amdgcn_mbcnt_hi((uint32_t)(pb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pb, 0u));
+        total += (uint32_t)__popcll(pb);
+    }
+    const float best = lane_best<C, QM>(R);
+    const float wmax = wave_max(best >= tau ? best : -__builtin_huge_valf());
+    if (total == 0u) return;  // only placeholders of empty rows tripped the trigger
+    if (lane == 0) {
+        if (publishes)
+            (void)__hip_atomic_fetch_max(&misc[MISC_GRPMAX + grp_local], order_key(wmax), __ATOMIC_RELAXED,
+                                         __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (P.dbg) {  // TKSPMV_STATS=1: summed into global memory when the wave finishes
+            atomicAdd(&misc[MISC_SLOW_CNT], 1u);
+            atomicAdd(&misc[MISC_CAND_CNT], total);
+        }
+    }
+    if (wcnt + total > WAVE_CAP) wcnt = compact_list<WAVE_CAP / 64u>(wcand, wcnt, tau, lane);
+    const uint32_t base = wcnt;
+    const uint32_t first_ovf = base < WAVE_CAP ? WAVE_CAP : base;  // list position of the first overflowing row
+    uint32_t gbase = 0u;
+    if (base + total > WAVE_CAP) {
+        if (lane == 0) gbase = atomicAdd(P.ovf_count, base + total - first_ovf);
+        gbase = __builtin_amdgcn_readfirstlane(gbase);
+    }
+    uint32_t r = rb + below;
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+        if (pass[j]) {
+            const uint32_t pos = base + slot[j];
+            if (pos < WAVE_CAP) {
+                wcand[pos] = make_uint2(__float_as_uint(row_score<C, QM>(R, j)), r);
+            } else {
+                const uint32_t gp = gbase + (pos - first_ovf);
+                if (gp < P.ovf_cap) st_agent(&P.ovf_cand[gp], pack_cand(__float_as_uint(row_score<C, QM>(R, j)), r));
+            }
+        }
+        r += R.end(j) ? 1u : 0u;
+    }
+    wcnt = base + total < WAVE_CAP ? base + total : WAVE_CAP;
+}
+
+}  // namespace tkspmv
