@@ -171,13 +171,14 @@ __device__ __forceinline__ RowSums<C> reduce_core(float (&p)[C], const uint32_t 
     //   P32  : no row end in [first lane of l's 32-lane half, l] (step row_bcast:31)
     const uint64_t H = __ballot(o[C - 1] != 0u);
     const uint64_t M1 = ~H;
-    const uint64_t M2 = M1 & ((M1 << 1) | 0x1ull);
-    const uint64_t M4 = M2 & ((M2 << 2) | 0x3ull);
-    const uint64_t M8 = M4 & ((M4 << 4) | 0xFull);
-    uint64_t P16 = M1 & ((M1 << 1) | 0x0001000100010001ull);
-    P16 &= (P16 << 2) | 0x0003000300030003ull;
-    P16 &= (P16 << 4) | 0x000F000F000F000Full;
-    P16 &= (P16 << 8) | 0x00FF00FF00FF00FFull;
+    // One doubling chain serves all steps: its links are clipped at the start of every 16-lane row (the constants fill the
+    // bits shifted in there), which is what P16 needs; for the row_shr steps the clipping is immaterial, because the
+    // lanes it concerns (lane % 16 < d) receive 0 from the DPP shift whatever their mask says. (A separate unclipped
+    // chain for M2, M4, M8 cost nine more scalar instructions per packet.)
+    const uint64_t M2 = M1 & ((M1 << 1) | 0x0001000100010001ull);
+    const uint64_t M4 = M2 & ((M2 << 2) | 0x0003000300030003ull);
+    const uint64_t M8 = M4 & ((M4 << 4) | 0x000F000F000F000Full);
+    const uint64_t P16 = M8 & ((M8 << 8) | 0x00FF00FF00FF00FFull);
     // upper row of each half also needs the whole lower row clear: bit 15 / 47 of P16
     const uint64_t low_clear = ((P16 >> 15) & 0x0000000100000001ull) * 0xFFFF0000ull;
     const uint64_t P32 = P16 & (low_clear | 0x0000FFFF0000FFFFull);
