@@ -8,6 +8,7 @@ set -u
 TAG=${1:-r01}
 REPO=$PWD
 OUT=$REPO/gpurun_out/pmc_issue_$TAG
+rm -rf "$OUT"  # (a summary must never mix two runs)
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 export TKSPMV_MULTI_CHAINS=1
@@ -21,4 +22,4 @@ for counters in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INS
     done
 done
 cd "$REPO"
-python3 tools/summarize_pmc_issue.py "$OUT" "$TAG"
+python3 tools/summarize_pmc_issue.py "$OUT" "$TAG"  # -> profiles/ and $OUT/summary/ (copy the latter when run through gpurun)

@@ -9,6 +9,7 @@ set -u
 TAG=${1:-r01}
 REPO=$PWD
 OUT=$REPO/gpurun_out/prof_$TAG
+rm -rf "$OUT"  # (a summary must never mix two runs)
 mkdir -p "$OUT"
 python3 bench.py --steps 3000 --warmup 300 > "$OUT/bench_plain.json" 2> "$OUT/bench_plain.err"
 cd /tmp && export TMPDIR=/tmp

@@ -38,4 +38,6 @@ for run, r in res.items():
 dst = os.path.join(os.path.dirname(os.path.abspath(out.rstrip("/"))), "..", "profiles", f"{tag}_pmc_issue.json")
 dst = os.path.normpath(dst)
 json.dump(res, open(dst, "w"), indent=1, sort_keys=True)
+os.makedirs(os.path.join(out, "summary"), exist_ok=True)  # gpurun brings back gpurun_out/ only: a copy travels with the raw files
+json.dump(res, open(os.path.join(out, "summary", f"{tag}_pmc_issue.json"), "w"), indent=1, sort_keys=True)
 print(json.dumps(res, indent=1, sort_keys=True))
