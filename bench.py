@@ -282,9 +282,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         multi_dist = None
-        if a.multi_q and os.environ.get("TKSPMV_DIST", "native") == "native":
+        if a.multi_q and os.environ.get("TKSPMV_DIST", "native") == "native" and os.environ.get("TKSPMV_BENCH_DIST_MULTI") == "1":
             # Extension, beside the headline and never part of `value`: the same step with the local passes serving 8
-            # queries each (engines created with multi_q). Any rank failing makes every rank skip it.
+            # queries each (engines created with multi_q). Opt-in (TKSPMV_BENCH_DIST_MULTI=1): it has only been run with one
+            # rank (TKSPMV_BENCH_FORCE_DIST=1, 145-165 k queries/s), and nothing untested may stand between the scaling
+            # run and its JSON line. Any rank failing to set it up makes every rank skip it.
             try:
                 q = max(a.multi_q)
                 meng = mod.SpMV(m.row, m.col, m.val, m.rows, m.cols, k=a.k, device=local_rank, first_row=rank * a.rows,
