@@ -10,6 +10,7 @@ LIB_PATH = os.environ.get("TKSPMV_LIB") or os.path.join(_HERE, "libtkspmv.so")  
 
 OK, ERR_INVALID, ERR_NOT_SORTED, ERR_DEVICE, ERR_NOMEM, ERR_IO, ERR_UNSUPPORTED, ERR_STATE = range(8)
 F32, Q1_7, Q1_7_WIDE, F16, FIXED = 0, 1, 2, 3, 4
+IMPL_STREAM, IMPL_ROW_PER_LANE, IMPL_SCORES_SELECT = 0, 1, 2
 MAX_COLS = 16384
 MAX_K = 1024
 
@@ -28,7 +29,7 @@ class Desc(C.Structure):
         ("k", C.c_int32), ("partitions", C.c_int32), ("k_per_partition", C.c_int32), ("precision", C.c_int32),
         ("device", C.c_int32), ("first_row", C.c_uint32), ("min_score", C.c_float),
         ("waves_per_cu", C.c_int32), ("threads_per_wg", C.c_int32), ("nnz_per_lane", C.c_int32),
-        ("stream_replicas", C.c_int32), ("fixed_width", C.c_int32), ("multi_q", C.c_int32), ("reserved", C.c_int32 * 2),
+        ("stream_replicas", C.c_int32), ("fixed_width", C.c_int32), ("multi_q", C.c_int32), ("impl", C.c_int32), ("reserved", C.c_int32 * 1),
     ]
 
 
@@ -80,11 +81,11 @@ EXPORTED_SYMBOLS = [
     "tkspmv_create", "tkspmv_destroy", "tkspmv_get_info", "tkspmv_set_query", "tkspmv_set_query_device",
     "tkspmv_run", "tkspmv_enqueue", "tkspmv_enqueue_many", "tkspmv_enqueue_batch", "tkspmv_synchronize", "tkspmv_read", "tkspmv_result_device", "tkspmv_scores", "tkspmv_debug_trace",
     "tkspmv_time_queries", "tkspmv_enqueue_multi", "tkspmv_time_multi", "tkspmv_profile", "tkspmv_last_error", "tkspmv_device_count", "tkspmv_mtx_read", "tkspmv_mtx_free",
-    "tkspmv_mtx_write", "tkspmv_sample_vector", "tkspmv_generate", "tkspmv_options_parse", "tkspmv_pack",
+    "tkspmv_mtx_write", "tkspmv_sample_vector", "tkspmv_generate", "tkspmv_generate_rows", "tkspmv_generate_degrees", "tkspmv_options_parse", "tkspmv_pack",
     "tkspmv_sell_roundtrip", "tkspmv_packed_info", "tkspmv_packed_decode", "tkspmv_packed_raw", "tkspmv_packed_free", "tkspmv_wave_partitions", "tkspmv_packed_save", "tkspmv_packed_load",
     "tkspmv_create_packed",
     "tkspmv_dist_unique_id", "tkspmv_dist_create", "tkspmv_dist_set_batch", "tkspmv_dist_enqueue", "tkspmv_dist_run_many",
-    "tkspmv_dist_synchronize", "tkspmv_dist_read", "tkspmv_dist_destroy", "tkspmv_dist_last_error",
+    "tkspmv_dist_synchronize", "tkspmv_dist_time_exchange", "tkspmv_dist_read", "tkspmv_dist_destroy", "tkspmv_dist_last_error",
     "tkspmv_merge_topk",
 ]
 
@@ -129,6 +130,8 @@ def lib():
                                    C.c_int32]
     L.tkspmv_sample_vector.argtypes = [f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
     L.tkspmv_generate.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32, C.c_uint64, C.POINTER(Coo)]
+    L.tkspmv_generate_rows.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32, C.c_uint64, C.POINTER(Coo)]
+    L.tkspmv_generate_degrees.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32, C.c_uint64, u32p]
     L.tkspmv_options_parse.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.POINTER(OptionsC)]
     L.tkspmv_pack.argtypes = [C.POINTER(Desc), C.c_uint32, C.POINTER(vp)]
     L.tkspmv_packed_info.argtypes = [vp, C.POINTER(Info)]
@@ -148,6 +151,7 @@ def lib():
     L.tkspmv_dist_enqueue.argtypes = [vp, vp]
     L.tkspmv_dist_run_many.argtypes = [vp, vp, C.c_int32, C.c_int32]
     L.tkspmv_dist_synchronize.argtypes = [vp]
+    L.tkspmv_dist_time_exchange.argtypes = [vp, C.c_int32, C.POINTER(C.c_double)]
     L.tkspmv_dist_read.argtypes = [vp, u32p, f32p, C.POINTER(C.c_int32)]
     L.tkspmv_dist_destroy.argtypes = [vp]
     L.tkspmv_dist_destroy.restype = None

@@ -12,9 +12,6 @@
 
 using namespace tkspmv;
 
-struct tkspmv_engine {
-    Engine *e;
-};
 struct tkspmv_packed {
     PackedMatrix pm;
     int k;
@@ -177,6 +174,27 @@ int tkspmv_generate(uint32_t rows, uint32_t cols, uint32_t avg_nnz, int32_t dist
         return fail(TKSPMV_ERR_NOMEM, "out of memory");
     }
     return coo_to_c(m, out);
+}
+
+int tkspmv_generate_rows(uint32_t row_begin, uint32_t row_end, uint32_t cols, uint32_t avg_nnz, int32_t dist, uint64_t seed,
+                         tkspmv_coo *out) {
+    if (!out || cols == 0 || avg_nnz == 0 || row_end < row_begin) return fail(TKSPMV_ERR_INVALID, "bad arguments");
+    if (dist != DIST_UNIFORM && dist != DIST_GAMMA) return fail(TKSPMV_ERR_INVALID, "dist must be 0 (uniform) or 1 (gamma)");
+    CooMatrix m;
+    try {
+        generate_matrix_rows(row_begin, row_end, cols, avg_nnz, dist, seed, m);
+    } catch (const std::bad_alloc &) {
+        return fail(TKSPMV_ERR_NOMEM, "out of memory");
+    }
+    return coo_to_c(m, out);
+}
+
+int tkspmv_generate_degrees(uint32_t row_begin, uint32_t row_end, uint32_t avg_nnz, int32_t dist, uint64_t seed,
+                            uint32_t *deg) {
+    if (!deg || avg_nnz == 0 || row_end < row_begin) return fail(TKSPMV_ERR_INVALID, "bad arguments");
+    if (dist != DIST_UNIFORM && dist != DIST_GAMMA) return fail(TKSPMV_ERR_INVALID, "dist must be 0 (uniform) or 1 (gamma)");
+    generate_degrees(row_begin, row_end, avg_nnz, dist, seed, deg);
+    return TKSPMV_OK;
 }
 
 int tkspmv_options_parse(int argc, char **argv, tkspmv_options *out) {

@@ -9,6 +9,7 @@
 // code, not a crash (bench.py then falls back to torch.distributed for the exchange).
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
 
 #include <cstdlib>
 #include <cstring>
@@ -20,18 +21,15 @@
 
 namespace tkspmv {
 
-// ---- minimal RCCL surface (rccl.h: ncclGetUniqueId, ncclCommInitRank, ncclAllGather, ncclCommDestroy) ---------------
-struct NcclUniqueId {
-    char internal[128];
-};
-typedef void *nccl_comm_t;
+// ---- RCCL, loaded at run time. Types and signatures come from rccl.h itself (decltype of its declarations): nothing of
+// its ABI is restated here; only the symbols are resolved with dlsym instead of at link time. --------------------------
 struct Rccl {
     void *handle = nullptr;
-    int (*GetUniqueId)(NcclUniqueId *) = nullptr;
-    int (*CommInitRank)(nccl_comm_t *, int, NcclUniqueId, int) = nullptr;
-    int (*AllGather)(const void *, void *, size_t, int /*dtype*/, nccl_comm_t, hipStream_t) = nullptr;
-    int (*CommDestroy)(nccl_comm_t) = nullptr;
-    const char *(*GetErrorString)(int) = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
     bool load(std::string &err) {
         if (handle) return true;
         const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
@@ -43,20 +41,21 @@ struct Rccl {
             err = std::string("cannot load RCCL: ") + dlerror();
             return false;
         }
-        GetUniqueId = (int (*)(NcclUniqueId *))dlsym(handle, "ncclGetUniqueId");
-        CommInitRank = (int (*)(nccl_comm_t *, int, NcclUniqueId, int))dlsym(handle, "ncclCommInitRank");
-        AllGather = (int (*)(const void *, void *, size_t, int, nccl_comm_t, hipStream_t))dlsym(handle, "ncclAllGather");
-        CommDestroy = (int (*)(nccl_comm_t))dlsym(handle, "ncclCommDestroy");
-        GetErrorString = (const char *(*)(int))dlsym(handle, "ncclGetErrorString");
+        GetUniqueId = reinterpret_cast<decltype(GetUniqueId)>(dlsym(handle, "ncclGetUniqueId"));
+        CommInitRank = reinterpret_cast<decltype(CommInitRank)>(dlsym(handle, "ncclCommInitRank"));
+        AllGather = reinterpret_cast<decltype(AllGather)>(dlsym(handle, "ncclAllGather"));
+        CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(handle, "ncclCommDestroy"));
+        GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(handle, "ncclGetErrorString"));
         if (!GetUniqueId || !CommInitRank || !AllGather || !CommDestroy) {
             err = "RCCL is missing an expected symbol";
+            handle = nullptr;
             return false;
         }
         return true;
     }
 };
 static Rccl g_rccl;
-constexpr int NCCL_INT32 = 2;  // ncclInt32 / ncclInt
+static_assert(sizeof(ncclUniqueId) == 128, "tkspmv_dist_unique_id ships 128 bytes");
 
 // ---- merge kernel ------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t order_key_d(float f) {
@@ -109,9 +108,10 @@ struct Dist {
     Engine *engine = nullptr;
     int device = 0, rank = 0, world = 1, k = 0;
     bool use_nccl = false;  // world > 1, or TKSPMV_DIST_FORCE_NCCL=1 (exercises the RCCL calls with one rank)
-    nccl_comm_t comm = nullptr;
+    ncclComm_t comm = nullptr;
     hipStream_t compute = nullptr, comm_stream = nullptr;
     hipEvent_t ev_comp[2] = {nullptr, nullptr}, ev_merge[2] = {nullptr, nullptr};
+    hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;  // tkspmv_dist_time_exchange
     // Queries are exchanged in batches of up to `batch`: one all-gather and one merge launch per batch, so the
     // collective's latency and the host's enqueue cost are paid once per batch. Two buffer sets alternate.
     int batch = MAX_BATCH;
@@ -135,9 +135,6 @@ using namespace tkspmv;
 struct tkspmv_dist {
     Dist d;
 };
-struct tkspmv_engine {  // same definition as in c_api.cpp
-    Engine *e;
-};
 
 static thread_local std::string g_dist_err;
 static int dfail(int code, const std::string &msg) {
@@ -152,15 +149,17 @@ static int dfail(int code, const std::string &msg) {
 
 extern "C" {
 
+void tkspmv_dist_destroy(tkspmv_dist_t *h);
+
 const char *tkspmv_dist_last_error(void) { return g_dist_err.c_str(); }
 
 int tkspmv_dist_unique_id(uint8_t *out128) {
     if (!out128) return dfail(TKSPMV_ERR_INVALID, "NULL argument");
     std::string err;
     if (!g_rccl.load(err)) return dfail(TKSPMV_ERR_UNSUPPORTED, err);
-    NcclUniqueId id;
-    int rc = g_rccl.GetUniqueId(&id);
-    if (rc != 0) return dfail(TKSPMV_ERR_DEVICE, "ncclGetUniqueId failed");
+    ncclUniqueId id;
+    const ncclResult_t rc = g_rccl.GetUniqueId(&id);
+    if (rc != ncclSuccess) return dfail(TKSPMV_ERR_DEVICE, "ncclGetUniqueId failed");
     std::memcpy(out128, id.internal, 128);
     return TKSPMV_OK;
 }
@@ -188,44 +187,83 @@ int tkspmv_dist_create(tkspmv_dist_t **out, tkspmv_t *engine, const uint8_t *id1
     d.rank = rank;
     d.world = world;
     d.k = info.k;
-    DHIP(hipSetDevice(d.device));
+    // every failure below releases what has been created so far (communicator, streams, events, buffers)
+    auto bail = [&](int code, const std::string &msg) {
+        tkspmv_dist_destroy(h);
+        return dfail(code, msg);
+    };
+#define DHIP_OR_BAIL(expr)                                                                                    \
+    do {                                                                                                      \
+        hipError_t _e = (expr);                                                                               \
+        if (_e != hipSuccess) return bail(TKSPMV_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+    DHIP_OR_BAIL(hipSetDevice(d.device));
     d.use_nccl = world > 1 || getenv("TKSPMV_DIST_FORCE_NCCL") != nullptr;
     if (d.use_nccl) {
-        if (!id128) {
-            delete h;
-            return dfail(TKSPMV_ERR_INVALID, "world > 1 needs the unique id of rank 0");
-        }
+        if (!id128) return bail(TKSPMV_ERR_INVALID, "world > 1 needs the unique id of rank 0");
         std::string err;
-        if (!g_rccl.load(err)) {
-            delete h;
-            return dfail(TKSPMV_ERR_UNSUPPORTED, err);
-        }
-        NcclUniqueId id;
+        if (!g_rccl.load(err)) return bail(TKSPMV_ERR_UNSUPPORTED, err);
+        ncclUniqueId id;
         std::memcpy(id.internal, id128, 128);
-        int rc = g_rccl.CommInitRank(&d.comm, world, id, rank);
-        if (rc != 0) {
-            delete h;
-            return dfail(TKSPMV_ERR_DEVICE, std::string("ncclCommInitRank failed: ") +
-                                                (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?"));
+        const ncclResult_t rc = g_rccl.CommInitRank(&d.comm, world, id, rank);
+        if (rc != ncclSuccess) {
+            d.comm = nullptr;
+            return bail(TKSPMV_ERR_DEVICE, std::string("ncclCommInitRank failed: ") +
+                                               (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?"));
         }
     }
     if (const char *e = getenv("TKSPMV_DIST_BATCH")) d.batch = atoi(e);
     if (d.batch < 1) d.batch = 1;
     if (d.batch > MAX_BATCH) d.batch = MAX_BATCH;
-    DHIP(hipStreamCreateWithFlags(&d.compute, hipStreamNonBlocking));
-    DHIP(hipStreamCreateWithFlags(&d.comm_stream, hipStreamNonBlocking));
+    DHIP_OR_BAIL(hipStreamCreateWithFlags(&d.compute, hipStreamNonBlocking));
+    DHIP_OR_BAIL(hipStreamCreateWithFlags(&d.comm_stream, hipStreamNonBlocking));
+    DHIP_OR_BAIL(hipEventCreate(&d.ev_t0));
+    DHIP_OR_BAIL(hipEventCreate(&d.ev_t1));
     for (int b = 0; b < 2; ++b) {
-        DHIP(hipEventCreateWithFlags(&d.ev_comp[b], hipEventDisableTiming));
-        DHIP(hipEventCreateWithFlags(&d.ev_merge[b], hipEventDisableTiming));
-        DHIP(hipMalloc((void **)&d.local[b], (size_t)MAX_BATCH * 2 * d.k * 4));
-        DHIP(hipMalloc((void **)&d.gathered[b], (size_t)world * MAX_BATCH * 2 * d.k * 4));
-        DHIP(hipMalloc((void **)&d.out_idx[b], (size_t)MAX_BATCH * d.k * 4));
-        DHIP(hipMalloc((void **)&d.out_val[b], (size_t)MAX_BATCH * d.k * 4));
-        DHIP(hipMemset(d.out_idx[b], 0, (size_t)MAX_BATCH * d.k * 4));
-        DHIP(hipMemset(d.out_val[b], 0, (size_t)MAX_BATCH * d.k * 4));
+        DHIP_OR_BAIL(hipEventCreateWithFlags(&d.ev_comp[b], hipEventDisableTiming));
+        DHIP_OR_BAIL(hipEventCreateWithFlags(&d.ev_merge[b], hipEventDisableTiming));
+        DHIP_OR_BAIL(hipMalloc((void **)&d.local[b], (size_t)MAX_BATCH * 2 * d.k * 4));
+        DHIP_OR_BAIL(hipMalloc((void **)&d.gathered[b], (size_t)world * MAX_BATCH * 2 * d.k * 4));
+        DHIP_OR_BAIL(hipMalloc((void **)&d.out_idx[b], (size_t)MAX_BATCH * d.k * 4));
+        DHIP_OR_BAIL(hipMalloc((void **)&d.out_val[b], (size_t)MAX_BATCH * d.k * 4));
+        DHIP_OR_BAIL(hipMemset(d.local[b], 0, (size_t)MAX_BATCH * 2 * d.k * 4));
+        DHIP_OR_BAIL(hipMemset(d.out_idx[b], 0, (size_t)MAX_BATCH * d.k * 4));
+        DHIP_OR_BAIL(hipMemset(d.out_val[b], 0, (size_t)MAX_BATCH * d.k * 4));
     }
-    DHIP(hipDeviceSynchronize());
+    DHIP_OR_BAIL(hipDeviceSynchronize());
+#undef DHIP_OR_BAIL
     *out = h;
+    return TKSPMV_OK;
+}
+
+// The exchange step alone (collective: every rank calls it with the same arguments): `iters` times the all-gather of one
+// full batch (batch x 2k words per rank) and the merge launch, back to back on the communication stream, one hipEvent pair
+// around them. bench.py reports it beside the whole step (which overlaps the exchange with the next batch's local kernels).
+int tkspmv_dist_time_exchange(tkspmv_dist_t *h, int32_t iters, double *ns_per_exchange) {
+    if (!h || iters < 1 || !ns_per_exchange) return dfail(TKSPMV_ERR_INVALID, "bad arguments");
+    Dist &d = h->d;
+    if (d.fill != 0) return dfail(TKSPMV_ERR_STATE, "a batch is open: synchronize first");
+    DHIP(hipSetDevice(d.device));
+    DHIP(hipStreamSynchronize(d.compute));
+    DHIP(hipStreamSynchronize(d.comm_stream));
+    const int n_q = d.batch;
+    DHIP(hipEventRecord(d.ev_t0, d.comm_stream));
+    for (int i = 0; i < iters; ++i) {
+        if (d.use_nccl) {
+            const ncclResult_t rc = g_rccl.AllGather(d.local[0], d.gathered[0], (size_t)n_q * 2 * d.k, ncclInt32, d.comm, d.comm_stream);
+            if (rc != ncclSuccess) return dfail(TKSPMV_ERR_DEVICE, "ncclAllGather failed");
+        } else {
+            DHIP(hipMemcpyAsync(d.gathered[0], d.local[0], (size_t)n_q * 2 * d.k * 4, hipMemcpyDeviceToDevice, d.comm_stream));
+        }
+        hipLaunchKernelGGL(merge_kernel, dim3(n_q), dim3(MERGE_THREADS), 0, d.comm_stream, d.gathered[0], (uint32_t)d.world,
+                           (uint32_t)d.k, d.out_idx[0], d.out_val[0]);
+    }
+    DHIP(hipGetLastError());
+    DHIP(hipEventRecord(d.ev_t1, d.comm_stream));
+    DHIP(hipEventSynchronize(d.ev_t1));
+    float ms = 0;
+    DHIP(hipEventElapsedTime(&ms, d.ev_t0, d.ev_t1));
+    *ns_per_exchange = (double)ms * 1e6 / iters;
     return TKSPMV_OK;
 }
 
@@ -253,8 +291,9 @@ static int dist_flush(Dist &d) {
     DHIP(hipEventRecord(d.ev_comp[b], d.compute));
     DHIP(hipStreamWaitEvent(d.comm_stream, d.ev_comp[b], 0));
     if (d.use_nccl) {
-        int rc = g_rccl.AllGather(d.local[b], d.gathered[b], (size_t)n_q * 2 * d.k, NCCL_INT32, d.comm, d.comm_stream);
-        if (rc != 0) return dfail(TKSPMV_ERR_DEVICE, "ncclAllGather failed");
+        const ncclResult_t rc = g_rccl.AllGather(d.local[b], d.gathered[b], (size_t)n_q * 2 * d.k, ncclInt32, d.comm, d.comm_stream);
+        if (rc != ncclSuccess)
+            return dfail(TKSPMV_ERR_DEVICE, std::string("ncclAllGather failed: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?"));
     } else {
         DHIP(hipMemcpyAsync(d.gathered[b], d.local[b], (size_t)n_q * 2 * d.k * 4, hipMemcpyDeviceToDevice, d.comm_stream));
     }
@@ -329,6 +368,8 @@ void tkspmv_dist_destroy(tkspmv_dist_t *h) {
     if (d.compute) (void)hipStreamSynchronize(d.compute);
     if (d.comm_stream) (void)hipStreamSynchronize(d.comm_stream);
     if (d.comm && g_rccl.CommDestroy) g_rccl.CommDestroy(d.comm);
+    if (d.ev_t0) (void)hipEventDestroy(d.ev_t0);
+    if (d.ev_t1) (void)hipEventDestroy(d.ev_t1);
     for (int b = 0; b < 2; ++b) {
         if (d.ev_comp[b]) (void)hipEventDestroy(d.ev_comp[b]);
         if (d.ev_merge[b]) (void)hipEventDestroy(d.ev_merge[b]);

@@ -304,6 +304,10 @@ struct EngineImpl {
     // One query, its result complete in stream order right after these launches: the stream kernel and, unless
     // fused into its tail, the select kernel.
     void launch_query(const float *x, uint32_t *out_idx, float *out_val, hipStream_t s) const {
+        if (desc.impl == TKSPMV_IMPL_ROW_PER_LANE && can_multi) {  // the row-per-lane variant, one query per pass
+            launch_multi_sequence(&x, &out_idx, &out_val, 1, s);
+            return;
+        }
         drain(s);
         if (use_radix) {
             launch_query_radix(x, out_idx, out_val, s);
@@ -435,6 +439,7 @@ struct EngineImpl {
         StreamParams P = stream_params(x);
         if (dst) P.scores = dst;
         SelectParams S = select_params(d_out_idx, d_out_val);
+        ++launch_counter;  // the stream copies rotate per query here too (cache-defeat mode)
         hipLaunchKernelGGL(kernel_for(true), dim3(grid), dim3(block + 64), 0, s, P, S);
     }
     void launch_select(uint32_t *out_idx, float *out_val, hipStream_t s, int set = 0) const {
@@ -531,6 +536,10 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
     if (d.precision != TKSPMV_F32 && d.precision != TKSPMV_Q1_7 && d.precision != TKSPMV_Q1_7_WIDE &&
         d.precision != TKSPMV_F16 && d.precision != TKSPMV_FIXED) {
         err = "unknown precision";
+        return TKSPMV_ERR_INVALID;
+    }
+    if (d.impl != TKSPMV_IMPL_STREAM && d.impl != TKSPMV_IMPL_ROW_PER_LANE && d.impl != TKSPMV_IMPL_SCORES_SELECT) {
+        err = "unknown impl (0 = stream, 1 = row per lane, 2 = scores + select)";
         return TKSPMV_ERR_INVALID;
     }
     if (d.precision == TKSPMV_FIXED ? (d.fixed_width != 0 && (d.fixed_width < 8 || d.fixed_width > 32)) : d.fixed_width != 0) {
@@ -708,7 +717,7 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
     if (const char *f = getenv("TKSPMV_BATCH")) m.can_batch = m.can_batch && atoi(f) != 0;
     // Large k: the scores + radix-select path wherever the threshold exchange is off or next to useless (k above
     // 3/8 of the publishing groups: measured cross-over on the BASELINE matrix, tools/k_probe.py). TKSPMV_RADIX=0/1 forces.
-    m.use_radix = m.n_sets == 0u || (uint64_t)d.k * 8u > (uint64_t)m.n_groups_pub * 3u;
+    m.use_radix = m.n_sets == 0u || (uint64_t)d.k * 8u > (uint64_t)m.n_groups_pub * 3u || d.impl == TKSPMV_IMPL_SCORES_SELECT;
     if (const char *f = getenv("TKSPMV_RADIX")) m.use_radix = atoi(f) != 0;
     if (m.use_radix) {
         m.can_defer = m.can_batch = false;
@@ -722,6 +731,7 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
     // Multi-query passes (desc.multi_q; TKSPMV_MULTI_Q overrides): a second copy of the matrix in the wave-sliced ELL layout.
     {
         int mq = d.multi_q;
+        if (d.impl == TKSPMV_IMPL_ROW_PER_LANE && mq == 0) mq = 1;
         if (const char *f = getenv("TKSPMV_MULTI_Q")) mq = atoi(f);
         if (mq != 0 && mq != 1 && mq != 2 && mq != 4 && mq != 8) {
             err = "multi_q must be 0 (off), 1, 2, 4 or 8";
@@ -733,16 +743,20 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
         // wait and then poured its rows into the overflow list, 2 ms per query. Such engines run 4 queries per pass.
         if (mq == 8 && (uint32_t)d.k * 4u > m.n_groups_pub) mq = 4;
         m.multi_q = mq;
-        // (k above half of the groups: the threshold is next to useless -- k = 1000 on 1024 groups measured 3.6 ms per query
-        // through the multi-query kernel against 0.2 ms one query per pass; such engines keep the ordinary sequence)
-        m.can_multi = mq > 0 && !m.use_radix && m.can_defer && m.n_sets != 0u && d.cols <= SELL_XCOLS && d.precision == TKSPMV_F32 && m.pm.nnz > 0 &&
-                      m.grid > 2u * (uint32_t)MULTI_Q_MAX && (uint32_t)d.k * 2u <= m.n_groups_pub;
-    }
-    if (m.can_multi) {
-        // the first MULTI_Q_MAX workgroups of a multi-query launch are its selectors, the others stream
         // 8 queries per pass need 91 registers: with 9 waves per workgroup only one workgroup fits a CU (the dispatcher wants
         // 6 waves on one SIMD for two); with 8 waves -- 7 streaming + the server -- two fit at up to 128 registers.
         m.multi_stream_waves = (m.multi_q >= 8 && waves_per_wg == 8u) ? 7u : waves_per_wg;
+        // (k above half of the groups: the threshold is next to useless -- k = 1000 on 1024 groups measured 3.6 ms per query
+        // through the multi-query kernel against 0.2 ms one query per pass; such engines keep the ordinary sequence)
+        // The selector workgroups of a multi-query launch have multi_stream_waves * 64 + 64 threads and hold SEL_PER_THREAD
+        // slots each in registers: every slot of the grid must fit (with 7 streaming waves that is 4096 slots = 512
+        // workgroups, fewer than the 576 the ordinary launch geometry allows).
+        m.can_multi = mq > 0 && !m.use_radix && m.can_defer && m.n_sets != 0u && d.cols <= SELL_XCOLS && d.precision == TKSPMV_F32 && m.pm.nnz > 0 &&
+                      m.grid > 2u * (uint32_t)MULTI_Q_MAX && (uint32_t)d.k * 2u <= m.n_groups_pub &&
+                      (uint64_t)m.grid * WG_SLOTS <= (uint64_t)SEL_PER_THREAD * (m.multi_stream_waves * 64u + 64u);
+    }
+    if (m.can_multi) {
+        // the first MULTI_Q_MAX workgroups of a multi-query launch are its selectors, the others stream
         const uint32_t n_multi_waves = (m.grid - (uint32_t)MULTI_Q_MAX) * m.multi_stream_waves;
         SellMatrix sm;
         std::string perr;

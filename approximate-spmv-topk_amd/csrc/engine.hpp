@@ -74,3 +74,8 @@ inline uint32_t fixed_width_of(const tkspmv_desc &d) {
 int wave_partitions_for(const tkspmv_desc &desc, uint32_t *out, std::string &err);
 
 }  // namespace tkspmv
+
+// The opaque handle of the C ABI (include/tkspmv.h: `typedef struct tkspmv_engine tkspmv_t`). Defined once, here.
+struct tkspmv_engine {
+    tkspmv::Engine *e;
+};

@@ -11,6 +11,7 @@
 #include <cstring>
 #include <numeric>
 #include <random>
+#include <thread>
 
 namespace tkspmv {
 
@@ -417,38 +418,28 @@ struct Rng {
 };
 }  // namespace
 
-void generate_matrix(uint32_t rows, uint32_t cols, uint32_t avg_nnz, int dist, uint64_t seed, CooMatrix &out) {
-    out = CooMatrix();
-    out.rows = rows;
-    out.cols = cols;
-    out.index_base = 0;
-    std::vector<uint32_t> deg(rows);
-    uint64_t total = 0;
-    for (uint32_t r = 0; r < rows; ++r) {
-        Rng g(seed, (uint64_t)r * 2);
-        uint32_t d;
-        if (dist == DIST_UNIFORM) {
-            uint32_t lo = avg_nnz / 2, hi = (uint32_t)(avg_nnz * 1.5);  // randint(min, max + 1) => inclusive
-            d = lo + g.below(hi - lo + 1);
-        } else {
-            // Gamma(shape=3, scale=avg/3) as an Erlang-3 variate; np.maximum(int(.), 1)
-            double u = g.uniform_open() * g.uniform_open() * g.uniform_open();
-            double x = -std::log(u) * ((double)avg_nnz / 3.0);
-            d = (uint32_t)x;
-            if (d < 1) d = 1;
-        }
-        deg[r] = d;
-        total += d;
+namespace {
+uint32_t row_degree(uint32_t r, uint32_t avg_nnz, int dist, uint64_t seed) {
+    Rng g(seed, (uint64_t)r * 2);
+    if (dist == DIST_UNIFORM) {
+        uint32_t lo = avg_nnz / 2, hi = (uint32_t)(avg_nnz * 1.5);  // randint(min, max + 1) => inclusive
+        return lo + g.below(hi - lo + 1);
     }
-    out.row.resize(total);
-    out.col.resize(total);
-    out.val.resize(total);
-    uint64_t pos = 0;
+    // Gamma(shape=3, scale=avg/3) as an Erlang-3 variate; np.maximum(int(.), 1)
+    double u = g.uniform_open() * g.uniform_open() * g.uniform_open();
+    double x = -std::log(u) * ((double)avg_nnz / 3.0);
+    uint32_t d = (uint32_t)x;
+    return d < 1 ? 1u : d;
+}
+// Rows [r0, r1) of the matrix into out_* at the positions their degrees give; row ids are written as r - row_base.
+void fill_rows(uint32_t r0, uint32_t r1, uint32_t cols, uint64_t seed, const uint32_t *deg, const uint64_t *pos_of,
+               uint32_t row_base, uint32_t *orow, uint32_t *ocol, float *oval) {
     std::vector<uint32_t> cbuf;
     std::vector<double> vbuf;
-    for (uint32_t r = 0; r < rows; ++r) {
+    for (uint32_t r = r0; r < r1; ++r) {
         Rng g(seed, (uint64_t)r * 2 + 1);
-        uint32_t d = deg[r];
+        const uint32_t d = deg[r - row_base];
+        uint64_t pos = pos_of[r - row_base];
         cbuf.resize(d);
         vbuf.resize(d);
         for (uint32_t j = 0; j < d; ++j) cbuf[j] = g.below(cols);  // with replacement => duplicates happen
@@ -458,14 +449,71 @@ void generate_matrix(uint32_t rows, uint32_t cols, uint32_t avg_nnz, int dist, u
             vbuf[j] = g.uniform();
             n2 += vbuf[j] * vbuf[j];
         }
-        double inv = n2 > 0 ? 1.0 / std::sqrt(n2) : 0.0;
+        const double inv = n2 > 0 ? 1.0 / std::sqrt(n2) : 0.0;
         for (uint32_t j = 0; j < d; ++j, ++pos) {
-            out.row[pos] = r;
-            out.col[pos] = cbuf[j];
-            out.val[pos] = (float)(vbuf[j] * inv);
+            orow[pos] = r - row_base;
+            ocol[pos] = cbuf[j];
+            oval[pos] = (float)(vbuf[j] * inv);
         }
     }
-    out.num_rows_coo = rows;
+}
+unsigned host_threads() {
+    unsigned n = std::thread::hardware_concurrency();
+    if (const char *e = getenv("TKSPMV_HOST_THREADS")) n = (unsigned)atoi(e);
+    return n < 1 ? 1u : (n > 64 ? 64u : n);
+}
+template <class F>
+void parallel_rows(uint32_t r0, uint32_t r1, F f) {
+    const unsigned nt = (r1 - r0) < 65536u ? 1u : host_threads();
+    if (nt == 1) {
+        f(r0, r1);
+        return;
+    }
+    std::vector<std::thread> th;
+    const uint64_t n = r1 - r0;
+    for (unsigned t = 0; t < nt; ++t) {
+        const uint32_t a = r0 + (uint32_t)(n * t / nt), b = r0 + (uint32_t)(n * (t + 1) / nt);
+        if (a < b) th.emplace_back([=]() { f(a, b); });
+    }
+    for (auto &t : th) t.join();
+}
+}  // namespace
+
+// Every row has its own PRNG streams (degree: stream 2r, content: stream 2r + 1), so any row range of the matrix can be
+// generated on its own, in any order and on any number of threads, with identical results.
+void generate_degrees(uint32_t row_begin, uint32_t row_end, uint32_t avg_nnz, int dist, uint64_t seed, uint32_t *deg) {
+    parallel_rows(row_begin, row_end, [=](uint32_t a, uint32_t b) {
+        for (uint32_t r = a; r < b; ++r) deg[r - row_begin] = row_degree(r, avg_nnz, dist, seed);
+    });
+}
+
+void generate_matrix_rows(uint32_t row_begin, uint32_t row_end, uint32_t cols, uint32_t avg_nnz, int dist, uint64_t seed,
+                          CooMatrix &out) {
+    out = CooMatrix();
+    const uint32_t n = row_end > row_begin ? row_end - row_begin : 0u;
+    out.rows = n;
+    out.cols = cols;
+    out.index_base = 0;
+    std::vector<uint32_t> deg(n);
+    generate_degrees(row_begin, row_begin + n, avg_nnz, dist, seed, deg.data());
+    std::vector<uint64_t> pos(n + 1, 0);
+    for (uint32_t i = 0; i < n; ++i) pos[i + 1] = pos[i] + deg[i];
+    const uint64_t total = pos[n];
+    out.row.resize(total);
+    out.col.resize(total);
+    out.val.resize(total);
+    uint32_t *orow = out.row.data(), *ocol = out.col.data();
+    float *oval = out.val.data();
+    const uint32_t *dp = deg.data();
+    const uint64_t *pp = pos.data();
+    parallel_rows(row_begin, row_begin + n, [=](uint32_t a, uint32_t b) {
+        fill_rows(a, b, cols, seed, dp, pp, row_begin, orow, ocol, oval);
+    });
+    out.num_rows_coo = n;
+}
+
+void generate_matrix(uint32_t rows, uint32_t cols, uint32_t avg_nnz, int dist, uint64_t seed, CooMatrix &out) {
+    generate_matrix_rows(0, rows, cols, avg_nnz, dist, seed, out);
 }
 
 // =====================================================================================================

@@ -65,6 +65,12 @@ void sample_vector(float *vec, int size, bool random, bool sum_to_one, bool norm
 // ---- synthetic matrices --------------------------------------------------------------------------------
 enum Distribution { DIST_UNIFORM = 0, DIST_GAMMA = 1 };
 void generate_matrix(uint32_t rows, uint32_t cols, uint32_t avg_nnz, int dist, uint64_t seed, CooMatrix &out);
+// Rows [row_begin, row_end) of the same matrix, with LOCAL row ids (r - row_begin): what a rank of a row-sharded job
+// builds (every row has its own PRNG streams, so a slice equals the corresponding rows of the whole matrix).
+void generate_matrix_rows(uint32_t row_begin, uint32_t row_end, uint32_t cols, uint32_t avg_nnz, int dist, uint64_t seed,
+                          CooMatrix &out);
+// Row lengths only (cheap): what nnz-balanced shard bounds are computed from.
+void generate_degrees(uint32_t row_begin, uint32_t row_end, uint32_t avg_nnz, int dist, uint64_t seed, uint32_t *deg);
 
 // ---- evaluation -----------------------------------------------------------------------------------------
 void sort_tuples(size_t n, uint32_t *idx, float *val);  // value desc, ties idx desc

@@ -361,7 +361,20 @@ std::string load_packed(const char *path, PackedMatrix &pm) {
         if ((uint64_t)out.part_first[p] + out.part_count[p] > hd.n_packets) return "partition table out of range";
     }
     for (uint32_t p = 0; p < hd.n_packets; ++p) {
-        if (out.pkt_row[p] > hd.rows) return "packet row table out of range";
+        if (out.pkt_row[p] >= hd.rows) return "packet row table out of range";
+    }
+    // column ids: the kernels read x[col] from LDS without a bounds check
+    if (hd.cols == 0 || hd.cols > MAX_COLS) return "column count out of range";
+    {
+        const size_t vbytes = (size_t)hd.packet_entries * value_bytes((Precision)hd.precision);
+        for (uint32_t p = 0; p < hd.n_packets; ++p) {
+            const uint8_t *cwp = out.packets.data() + (size_t)p * hd.packet_bytes + vbytes;
+            for (uint32_t s = 0; s < hd.packet_entries; ++s) {
+                uint16_t cw;
+                std::memcpy(&cw, cwp + (size_t)s * 2, 2);
+                if ((uint32_t)(cw >> COLW_COL_SHIFT) >= hd.cols) return "column id out of range in the packet stream";
+            }
+        }
     }
     pm = std::move(out);
     return "";

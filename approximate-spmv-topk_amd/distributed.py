@@ -35,6 +35,37 @@ def shard_bounds_by_nnz(row, rows, world):
     return [(bounds[i], bounds[i + 1]) for i in range(world)]
 
 
+def shard_bounds_from_degrees(deg, world):
+    """The same cut as shard_bounds_by_nnz, from the row lengths alone (deg[r] = entries of row r): the row that holds
+    entry number nnz * r / world starts shard r. Lets every rank of a row-sharded job derive all shard bounds without
+    any rank holding the matrix (bench.py --gpus N, BASELINE configs[3])."""
+    deg = np.asarray(deg, dtype=np.int64)
+    rows = int(deg.shape[0])
+    ends = np.cumsum(deg)  # ends[r] = entries in rows [0, r]
+    nnz = int(ends[-1]) if rows else 0
+    bounds = [0]
+    for r in range(1, world):
+        if nnz == 0:
+            bounds.append((rows * r) // world)
+            continue
+        target = min((nnz * r) // world, nnz - 1)
+        cut_row = int(np.searchsorted(ends, target, side="right"))  # row containing entry `target`
+        bounds.append(min(max(cut_row, bounds[-1]), rows))
+    bounds.append(rows)
+    return [(bounds[i], bounds[i + 1]) for i in range(world)]
+
+
+def generate_shard(total_rows, cols, avg_nnz, distribution, seed, rank, world):
+    """Rank `rank`'s shard of the synthetic total_rows-row matrix, cut by nnz into `world` contiguous row ranges: returns
+    (CooMatrix with local row ids, (r0, r1), global nnz). Only the row lengths of the whole matrix are computed; the
+    shard's entries are generated in place (every row has its own PRNG streams, host_utils.cpp)."""
+    from . import host
+    deg = host.generate_degrees(0, total_rows, avg_nnz, distribution, seed)
+    bounds = shard_bounds_from_degrees(deg, world)
+    r0, r1 = bounds[rank]
+    return host.generate_matrix_rows(r0, r1, cols, avg_nnz, distribution, seed), (r0, r1), int(deg.sum(dtype=np.int64))
+
+
 def shard_coo(row, col, val, r0, r1):
     """Entries of rows [r0, r1), with local row ids."""
     row = np.asarray(row)
@@ -146,6 +177,12 @@ class NativeShardedSpMV:
 
     def synchronize(self):
         self._lib.check_dist(self._lib.lib().tkspmv_dist_synchronize(self._h))
+
+    def time_exchange(self, iters):
+        """ns per exchange of one full batch (all-gather + merge launch alone; collective: every rank calls it)."""
+        ns = self._C.c_double()
+        self._lib.check_dist(self._lib.lib().tkspmv_dist_time_exchange(self._h, int(iters), self._C.byref(ns)))
+        return ns.value
 
     def read(self):
         C = self._C

@@ -18,7 +18,7 @@ from . import _lib
 class SpMV:
     def __init__(self, x, y, val, num_rows, num_cols, num_nnz=None, vec=None, k=20, debug=0, *, device=-1,
                  first_row=0, min_score=0.0, partitions=1, k_per_partition=0, precision=_lib.F32, waves_per_cu=0,
-                 threads_per_wg=0, nnz_per_lane=0, stream_replicas=0, fixed_width=0, multi_q=0):
+                 threads_per_wg=0, nnz_per_lane=0, stream_replicas=0, fixed_width=0, multi_q=0, impl=0):
         """x, y, val: row-sorted COO (row ids, column ids, values) as the FPGA host passes them
         (host_spmv_bscsr.cpp:585); val=None means all ones (-v). precision=FIXED: the FPGA's fixed-point real_type of
         `fixed_width` bits (8..32; 0 = 32, the reference's FIXED_WIDTH default, types.hpp:20)."""
@@ -38,6 +38,7 @@ class SpMV:
         d.stream_replicas = int(stream_replicas)
         d.fixed_width = int(fixed_width)
         d.multi_q = int(multi_q)
+        d.impl = int(impl)
         _lib.check(_lib.lib().tkspmv_create(C.byref(self._h), C.byref(d)))
         self.k = int(k)
         self.num_rows, self.num_cols, self.num_nnz = int(num_rows), int(num_cols), nnz

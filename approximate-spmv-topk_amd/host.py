@@ -78,6 +78,24 @@ def generate_matrix(rows, cols, avg_nnz, distribution="gamma", seed=1):
     return _coo_from_c(c)
 
 
+def generate_matrix_rows(row_begin, row_end, cols, avg_nnz, distribution="gamma", seed=1):
+    """Rows [row_begin, row_end) of generate_matrix(rows >= row_end, ...) with LOCAL row ids: a rank's shard of a
+    row-sharded job, built without the whole matrix ever existing in the process."""
+    dist = {"uniform": 0, "gamma": 1}[distribution]
+    c = _lib.Coo()
+    _lib.check(_lib.lib().tkspmv_generate_rows(row_begin, row_end, cols, avg_nnz, dist, seed, C.byref(c)))
+    return _coo_from_c(c)
+
+
+def generate_degrees(row_begin, row_end, avg_nnz, distribution="gamma", seed=1):
+    """Row lengths of rows [row_begin, row_end) of the generated matrix (uint32 array)."""
+    dist = {"uniform": 0, "gamma": 1}[distribution]
+    deg = np.empty(max(row_end - row_begin, 1), dtype=np.uint32)
+    _lib.check(_lib.lib().tkspmv_generate_degrees(row_begin, row_end, avg_nnz, dist, seed,
+                                                  deg.ctypes.data_as(C.POINTER(C.c_uint32))))
+    return deg[:row_end - row_begin]
+
+
 @dataclass
 class Options:
     matrix_path: str

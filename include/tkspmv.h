@@ -69,6 +69,18 @@ typedef enum {
                              output use the fixed-point score converted to fp32. W = 8 reproduces TKSPMV_Q1_7. */
 } tkspmv_precision;
 
+/* Engine variants, the counterpart of the reference's -i/--gpu_impl selector (options.hpp:35, enum GPU_IMPL {CSR,
+ * CSR_LIGHTSPMV, COO}: three ways of running the same query on the GPU). All return identical index lists; scores may
+ * differ in the last bits (summation order). */
+typedef enum {
+    TKSPMV_IMPL_STREAM = 0,        /* default: fused streaming kernel over wave-BSCSR packets (batch kernel for sequences) */
+    TKSPMV_IMPL_ROW_PER_LANE = 1,  /* one row per lane over the wave-sliced ELL copy (the multi-query kernel with one query
+                                      per pass; scores in the gold's summation order). Engines it does not apply to
+                                      (reduced precisions, > 1024 columns, ...) run the default. */
+    TKSPMV_IMPL_SCORES_SELECT = 2  /* full y = A.x, then an exact radix select over all rows: the structure of the
+                                      reference's GPU host (cusparseSpMV + sort, host_spmv_topk_csr_gpu.cu:171-231) */
+} tkspmv_impl;
+
 typedef struct tkspmv_engine tkspmv_t;
 
 /* Engine descriptor. Caller owns row/col/val; they are only read during tkspmv_create
@@ -99,7 +111,8 @@ typedef struct {
                                  engine keeps a second copy of the matrix in the wave-sliced ELL layout (info.multi_bytes);
                                  info.multi_q tells what the engine uses (8 becomes 4 when k exceeds a quarter of the
                                  threshold groups, 0 when the kernel does not apply) */
-    int32_t reserved[2];
+    int32_t impl;             /* tkspmv_impl; 0 = default */
+    int32_t reserved[1];
 } tkspmv_desc;
 
 typedef struct {
@@ -222,6 +235,10 @@ int tkspmv_dist_run_many(tkspmv_dist_t *d, const float *dev_xs, int32_t n_x, int
 int tkspmv_dist_synchronize(tkspmv_dist_t *d);
 /* merged (global) top-k of the most recently enqueued query (host buffers of k entries); waits for it */
 int tkspmv_dist_read(tkspmv_dist_t *d, uint32_t *idx, float *val, int32_t *n);
+/* The exchange step alone, for measurement (collective: every rank calls it with the same arguments): `iters` times the
+ * all-gather of one full batch (batch x 2k words per rank) + the merge launch, back to back on the communication stream,
+ * one hipEvent pair around them. */
+int tkspmv_dist_time_exchange(tkspmv_dist_t *d, int32_t iters, double *ns_per_exchange);
 void tkspmv_dist_destroy(tkspmv_dist_t *d);
 const char *tkspmv_dist_last_error(void);
 /* The merge step alone: dev_gathered = [world][2][k] u32 (row ids, then score bits) -> k best, sort_tuples order. */
@@ -252,6 +269,14 @@ int tkspmv_sample_vector(float *vec, int32_t size, int32_t random, int32_t sum_t
 
 /* Synthetic matrix with the distributions of create_matrices.py (dist: 0 = uniform, 1 = gamma). Own PRNG. */
 int tkspmv_generate(uint32_t rows, uint32_t cols, uint32_t avg_nnz, int32_t dist, uint64_t seed, tkspmv_coo *out);
+/* Rows [row_begin, row_end) of that matrix with LOCAL row ids (row - row_begin): every row has its own PRNG streams, so a
+ * slice equals the corresponding rows of the whole matrix -- what one rank of a row-sharded job builds (BASELINE configs[3]:
+ * 10M rows over 8 GPUs; the 10M-row COO never exists in one process). tkspmv_generate_degrees: the row lengths alone
+ * (deg[row_end - row_begin]), from which nnz-balanced shard bounds are computed without generating any entry. */
+int tkspmv_generate_rows(uint32_t row_begin, uint32_t row_end, uint32_t cols, uint32_t avg_nnz, int32_t dist, uint64_t seed,
+                         tkspmv_coo *out);
+int tkspmv_generate_degrees(uint32_t row_begin, uint32_t row_end, uint32_t avg_nnz, int32_t dist, uint64_t seed,
+                            uint32_t *deg);
 
 typedef struct {
     char matrix_path[1024];

@@ -713,3 +713,54 @@ void oracle_cpu_global_topk(const double *scores, const uint8_t *kept, uint32_t 
     }
     free(h);
 }
+
+/* The CPU baseline timed natively (bench.py's cpu_baseline leg; SURVEY.md 8(d): fp64 and fp32 variants, SpMV-only and
+ * SpMV + global top-k, median of >= 10 runs after warm-ups): `warm` untimed + `reps` timed queries, query i uses
+ * xs + (i % n_x) * cols. All buffers are allocated once outside the timed region; like sparse_dot_topn_threaded
+ * (test_cpu.py:104, n_jobs threads per call) the threads are created per query. use_f32: values, x and sums in float
+ * (v32 / xs32), the global top-k then runs over the float scores widened to double (part of its time). */
+#include <time.h>
+static double now_ms(void) {
+    struct timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return (double)t.tv_sec * 1e3 + (double)t.tv_nsec * 1e-6;
+}
+int oracle_cpu_bench(const uint64_t *ptr, const uint32_t *idx, const double *v64, const float *v32, uint32_t rows,
+                     const double *xs64, const float *xs32, int n_x, uint32_t cols, int k, int n_threads, int warm, int reps,
+                     int use_f32, double *spmv_ms /* reps */, double *total_ms /* reps */) {
+    if (n_x < 1 || reps < 1 || k < 1) return 1;
+    double *scores = (double *)malloc((size_t)(rows ? rows : 1) * sizeof(double));
+    float *scores_f = (float *)malloc((size_t)(rows ? rows : 1) * sizeof(float));
+    uint8_t *kept = (uint8_t *)malloc((size_t)(rows ? rows : 1));
+    uint32_t *ri = (uint32_t *)malloc((size_t)k * sizeof(uint32_t));
+    double *rv = (double *)malloc((size_t)k * sizeof(double));
+    if (!scores || !scores_f || !kept || !ri || !rv) {
+        free(scores); free(scores_f); free(kept); free(ri); free(rv);
+        return 2;
+    }
+    int rc = 0;
+    for (int i = 0; i < warm + reps && rc == 0; i++) {
+        const double t0 = now_ms();
+        if (use_f32) {
+            rc = oracle_cpu_spmv_f32(ptr, idx, v32, rows, xs32 + (size_t)(i % n_x) * cols, n_threads, scores_f);
+        } else {
+            rc = oracle_cpu_topn(ptr, idx, v64, rows, xs64 + (size_t)(i % n_x) * cols, 0.0, n_threads, scores, kept);
+        }
+        const double t1 = now_ms();
+        if (use_f32) {
+            for (uint32_t r = 0; r < rows; r++) {
+                scores[r] = (double)scores_f[r];
+                kept[r] = scores_f[r] > 0.0f;
+            }
+        }
+        oracle_cpu_global_topk(scores, kept, rows, k, ri, rv);
+        const double t2 = now_ms();
+        if (i >= warm) {
+            spmv_ms[i - warm] = t1 - t0;
+            total_ms[i - warm] = t2 - t0;
+        }
+    }
+    free(scores); free(scores_f); free(kept); free(ri); free(rv);
+    return rc;
+}
+

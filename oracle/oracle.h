@@ -99,6 +99,12 @@ void oracle_cpu_global_topk(const double *scores, const uint8_t *kept, uint32_t 
 int oracle_cpu_spmv_f32(const uint64_t *ptr, const uint32_t *idx, const float *v, uint32_t rows, const float *x,
                         int n_threads, float *scores);
 
+/* bench.py's cpu_baseline leg, timed natively: `warm` untimed + `reps` timed queries (query i = xs + (i % n_x) * cols),
+ * per query the threaded SpMV (fp64: oracle_cpu_topn; use_f32: oracle_cpu_spmv_f32) and the global top-k; times in ms. */
+int oracle_cpu_bench(const uint64_t *ptr, const uint32_t *idx, const double *v64, const float *v32, uint32_t rows,
+                     const double *xs64, const float *xs32, int n_x, uint32_t cols, int k, int n_threads, int warm, int reps,
+                     int use_f32, double *spmv_ms, double *total_ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -209,6 +209,22 @@ def cpu_spmv_f32(ptr, idx, v32, rows, x, n_threads=1):
     return scores[:rows]
 
 
+def cpu_bench(ptr, idx, v64, rows, xs, k, n_threads, warm, reps, use_f32=False):
+    """(spmv_ms[reps], total_ms[reps]) of the CPU baseline, timed inside the C library (buffers preallocated)."""
+    xs64 = np.ascontiguousarray(xs, dtype=np.float64)
+    xs32 = np.ascontiguousarray(xs, dtype=np.float32)
+    v64 = np.ascontiguousarray(v64, dtype=np.float64)
+    v32 = np.ascontiguousarray(v64, dtype=np.float32)
+    a = np.zeros(reps, dtype=np.float64)
+    b = np.zeros(reps, dtype=np.float64)
+    rc = oracle().oracle_cpu_bench(_p(ptr, u64p), _p(idx, u32p), _p(v64, f64p), _p(v32, f32p), C.c_uint32(rows),
+                                   _p(xs64, f64p), _p(xs32, f32p), C.c_int(xs64.shape[0]), C.c_uint32(xs64.shape[1]),
+                                   C.c_int(k), C.c_int(n_threads), C.c_int(warm), C.c_int(reps), C.c_int(int(use_f32)),
+                                   _p(a, f64p), _p(b, f64p))
+    assert rc == 0
+    return a, b
+
+
 # ---- reference wrappers (only in the build container, where oracle/_ref was compiled) --------------------
 def ref_gold_topk(row, col, val, vec, k, sort=True):
     row, col, val, vec = _u32(row), _u32(col), _f32(val), _f32(vec)

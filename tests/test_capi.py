@@ -79,5 +79,10 @@ def test_executable_reports_errors_like_the_reference(pkg, tmp_path):
         g = pkg.generate_matrix(200, 64, 6, "gamma", 1)
         p = tmp_path / "ok.mtx"
         pkg.write_mtx(str(p), g, index_base=1)
+        # a one-based file (generator output) read zero-based, the reference's compiled-in behaviour and the default here:
+        # the reference then reads x out of bounds; this executable says what is wrong
         r = subprocess.run([exe, "-m", str(p), "-k", "8", "-t", "1"], capture_output=True, text=True)
+        assert r.returncode == 1 and "TKSPMV_INDEX_BASE=1" in r.stderr
+        r = subprocess.run([exe, "-m", str(p), "-k", "8", "-t", "1"], capture_output=True, text=True,
+                           env=dict(os.environ, TKSPMV_INDEX_BASE="1"))
         assert r.returncode == 1 and "no HIP device" in r.stderr

@@ -272,7 +272,10 @@ def test_drop_in_executable_csv(pkg, oracle, tmp_path):
     g = pkg.generate_matrix(10000, 1024, 20, "gamma", 1)  # BASELINE configs[0] shape, generator output format
     p = tmp_path / "matrix_10000_1024_20_gamma.mtx"
     pkg.write_mtx(str(p), g, index_base=1)
-    env = dict(os.environ, TKSPMV_SEED="5")
+    # read zero-based (the reference's compiled-in behaviour, the default): the one-based file is refused with a hint
+    r = subprocess.run([exe, "-t", "1", "-m", str(p), "-k", "100"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 1 and "TKSPMV_INDEX_BASE=1" in r.stderr
+    env = dict(os.environ, TKSPMV_SEED="5", TKSPMV_INDEX_BASE="1")
     r = subprocess.run([exe, "-t", "4", "-m", str(p), "-k", "100", "-i", "0", "-r"], capture_output=True, text=True,
                        env=env, timeout=300)
     assert r.returncode == 0, r.stderr

@@ -30,6 +30,7 @@ ap.add_argument("--matrix-folder", default=os.path.join(ROOT, "gpurun_out", "mat
 ap.add_argument("--out-folder", default=os.path.join(ROOT, "gpurun_out", "results", time.strftime("%Y_%m_%d_%H_%M_%S")))
 ap.add_argument("--cache", action="store_true", help="keep packed matrices next to the MatrixMarket files (TKSPMV_CACHE_DIR)")
 ap.add_argument("--seed", type=int, default=1)
+ap.add_argument("--impl", type=int, default=0, help="engine variant passed as -i (0 streaming kernel, 1 row per lane, 2 scores + select)")
 ap.add_argument("--bits", nargs="+", default=["f32"],
                 help="value types to run: f32, f16 (the executable's -a) or a fixed-point width such as 20b, 25b, 32b "
                      "(the reference's FPGA builds, test_spmv_topk.py:42-47; TKSPMV_FIXED_WIDTH)")
@@ -41,7 +42,9 @@ ex = import_module("approximate_spmv_topk_amd.experiments")
 
 os.makedirs(a.matrix_folder, exist_ok=True)
 os.makedirs(a.out_folder, exist_ok=True)
-env = dict(os.environ, TKSPMV_SEED=str(a.seed))
+# matrices are written zero-based (the reference driver's ZERO_INDEXED = True, test_spmv_topk.py:26-35); "auto" also accepts
+# one-based files left in the matrix folder by create_matrices.py
+env = dict(os.environ, TKSPMV_SEED=str(a.seed), TKSPMV_INDEX_BASE="auto")
 if a.cache:
     env["TKSPMV_CACHE_DIR"] = a.matrix_folder
 grid = [(s, c, d, n, b) for s in a.rows for c in a.cols for d in a.dist for n in a.nnz for b in a.bits]
@@ -49,9 +52,9 @@ table = []
 for i, (s, c, d, n, bits) in enumerate(grid):
     mtx = os.path.join(a.matrix_folder, ex.matrix_name(s, c, n, d))
     if not os.path.exists(mtx):
-        mod.write_mtx(mtx, mod.generate_matrix(s, c, n, d, a.seed + i // len(a.bits)), index_base=1)
+        mod.write_mtx(mtx, mod.generate_matrix(s, c, n, d, a.seed + i // len(a.bits)), index_base=0)
     out = os.path.join(a.out_folder, ex.result_name(s, c, d, n, a.k, a.niter, bits=bits))
-    cmd = [ex.default_exe(), "-t", str(a.niter), "-m", mtx, "-k", str(a.k), "-r"] + (["-a"] if bits == "f16" else [])
+    cmd = [ex.default_exe(), "-t", str(a.niter), "-m", mtx, "-k", str(a.k), "-i", str(a.impl), "-r"] + (["-a"] if bits == "f16" else [])
     run_env = dict(env, TKSPMV_FIXED_WIDTH=bits[:-1]) if bits.endswith("b") else env
     print(f"running {i + 1}/{len(grid)}: {' '.join(cmd)} > {out}", flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True, env=run_env)
