@@ -273,7 +273,8 @@ int tkspmv_sell_roundtrip(const tkspmv_desc *d, uint32_t n_wave_partitions_hint,
     if (!d || !n) return fail(TKSPMV_ERR_INVALID, "NULL argument");
     SellMatrix sm;
     const std::string err = pack_wsell(d->rows, d->cols, d->nnz, d->row, d->col, d->val,
-                                       n_wave_partitions_hint ? n_wave_partitions_hint : 4088u, sm);
+                                       n_wave_partitions_hint ? n_wave_partitions_hint : 4088u, sm,
+                                       d->precision == TKSPMV_Q1_7_F32 ? SellValues::Q1_7_RND : SellValues::F32);
     if (!err.empty()) return fail(TKSPMV_ERR_INVALID, err);
     std::vector<uint32_t> r, c;
     std::vector<float> v;
@@ -335,8 +336,11 @@ int tkspmv_create_packed(tkspmv_t **out, const tkspmv_packed *p, const tkspmv_de
     if (stream_precision(desc->precision) != p->pm.precision)
         d.precision = p->pm.precision == Precision::F32
                           ? TKSPMV_F32
-                          : (p->pm.precision == Precision::F16 ? TKSPMV_F16
-                                                               : (p->pm.precision == Precision::FIXED ? TKSPMV_FIXED : TKSPMV_Q1_7));
+                          : (p->pm.precision == Precision::F16
+                                 ? TKSPMV_F16
+                                 : (p->pm.precision == Precision::FIXED
+                                        ? TKSPMV_FIXED
+                                        : (p->pm.precision == Precision::Q1_7_RND ? TKSPMV_Q1_7_F32 : TKSPMV_Q1_7)));
     d.fixed_width = (int32_t)p->pm.fixed_width;  // a property of the packed values
     d.nnz_per_lane = (int32_t)p->pm.C;
     std::string err;

@@ -105,7 +105,8 @@ struct EngineImpl {
     uint8_t *d_sell_packets = nullptr;
     std::vector<uint8_t *> d_sell_replicas;
     uint32_t *d_sell_rows = nullptr, *d_sell_part_first = nullptr, *d_sell_part_count = nullptr, *d_sell_part_slice0 = nullptr;
-    uint32_t sell_parts = 0, multi_stream_waves = 8;
+    uint32_t sell_parts = 0, multi_stream_waves = 8, sell_packet_bytes = 1536;
+    bool sell_byte_values = false;  // TKSPMV_Q1_7_F32: 768-byte chunks of Q1.7 bytes
     uint64_t sell_bytes = 0;
     uint32_t *d_multi_out_idx = nullptr;  // [2 * MULTI_Q_MAX][k] results of tkspmv_time_multi
     float *d_multi_out_val = nullptr;
@@ -251,7 +252,7 @@ struct EngineImpl {
         P.part_first = d_sell_part_first;
         P.part_count = d_sell_part_count;
         P.n_parts = sell_parts;
-        P.packet_bytes = SellMatrix::PACKET_BYTES;
+        P.packet_bytes = sell_packet_bytes;
         P.pkt_row = nullptr;
         MultiParams M{};
         M.A = set_addr(0);
@@ -273,10 +274,11 @@ struct EngineImpl {
         SelectParams S = select_params(nullptr, nullptr, 0);
         S.pos_to_row = d_sell_rows;
         const dim3 mblock(multi_stream_waves * 64u + 64u);
-        if (multi_q <= 1) hipLaunchKernelGGL(multi_kernel<1>, dim3(grid), mblock, 0, s, P, S, M);
-        else if (multi_q <= 2) hipLaunchKernelGGL(multi_kernel<2>, dim3(grid), mblock, 0, s, P, S, M);
-        else if (multi_q <= 4) hipLaunchKernelGGL(multi_kernel<4>, dim3(grid), mblock, 0, s, P, S, M);
-        else hipLaunchKernelGGL(multi_kernel<8>, dim3(grid), mblock, 0, s, P, S, M);
+        typedef void (*multi_fn)(const StreamParams, const SelectParams, const MultiParams);
+        const int qi = multi_q <= 1 ? 0 : (multi_q <= 2 ? 1 : (multi_q <= 4 ? 2 : 3));
+        static const multi_fn fns[2][4] = {{&multi_kernel<1, 0>, &multi_kernel<2, 0>, &multi_kernel<4, 0>, &multi_kernel<8, 0>},
+                                           {&multi_kernel<1, 1>, &multi_kernel<2, 1>, &multi_kernel<4, 1>, &multi_kernel<8, 1>}};
+        hipLaunchKernelGGL(fns[sell_byte_values ? 1 : 0][qi], dim3(grid), mblock, 0, s, P, S, M);
         pending_group[chain] = M.cur;
         multi_parity[chain] ^= 1;
     }
@@ -322,6 +324,7 @@ struct EngineImpl {
         if (desc.precision == TKSPMV_Q1_7_WIDE) return &batch_kernel<4, 1024, 2>;
         if (desc.precision == TKSPMV_F16) return &batch_kernel<4, 1024, 3>;
         if (desc.precision == TKSPMV_FIXED) return &batch_kernel<4, 1024, 4>;
+        if (desc.precision == TKSPMV_Q1_7_F32) return &batch_kernel<4, 1024, 5>;
         if (info.packet_entries == 512) return &batch_kernel<8, 1024, 0>;
         return &batch_kernel<4, 1024, 0>;
     }
@@ -394,6 +397,11 @@ struct EngineImpl {
             if (xcols <= 1024) return scores ? &stream_kernel<4, true, 1024, 4> : &stream_kernel<4, false, 1024, 4>;
             if (xcols <= 4096) return scores ? &stream_kernel<4, true, 4096, 4> : &stream_kernel<4, false, 4096, 4>;
             return scores ? &stream_kernel<4, true, 16384, 4> : &stream_kernel<4, false, 16384, 4>;
+        }
+        if (desc.precision == TKSPMV_Q1_7_F32) {
+            if (xcols <= 1024) return scores ? &stream_kernel<4, true, 1024, 5> : &stream_kernel<4, false, 1024, 5>;
+            if (xcols <= 4096) return scores ? &stream_kernel<4, true, 4096, 5> : &stream_kernel<4, false, 4096, 5>;
+            return scores ? &stream_kernel<4, true, 16384, 5> : &stream_kernel<4, false, 16384, 5>;
         }
         if (desc.precision == TKSPMV_Q1_7_WIDE) {
             if (xcols <= 1024) return scores ? &stream_kernel<4, true, 1024, 2> : &stream_kernel<4, false, 1024, 2>;
@@ -534,7 +542,7 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
         return TKSPMV_ERR_INVALID;
     }
     if (d.precision != TKSPMV_F32 && d.precision != TKSPMV_Q1_7 && d.precision != TKSPMV_Q1_7_WIDE &&
-        d.precision != TKSPMV_F16 && d.precision != TKSPMV_FIXED) {
+        d.precision != TKSPMV_F16 && d.precision != TKSPMV_FIXED && d.precision != TKSPMV_Q1_7_F32) {
         err = "unknown precision";
         return TKSPMV_ERR_INVALID;
     }
@@ -751,7 +759,8 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
         // The selector workgroups of a multi-query launch have multi_stream_waves * 64 + 64 threads and hold SEL_PER_THREAD
         // slots each in registers: every slot of the grid must fit (with 7 streaming waves that is 4096 slots = 512
         // workgroups, fewer than the 576 the ordinary launch geometry allows).
-        m.can_multi = mq > 0 && !m.use_radix && m.can_defer && m.n_sets != 0u && d.cols <= SELL_XCOLS && d.precision == TKSPMV_F32 && m.pm.nnz > 0 &&
+        m.can_multi = mq > 0 && !m.use_radix && m.can_defer && m.n_sets != 0u && d.cols <= SELL_XCOLS &&
+                      (d.precision == TKSPMV_F32 || d.precision == TKSPMV_Q1_7_F32) && m.pm.nnz > 0 &&
                       m.grid > 2u * (uint32_t)MULTI_Q_MAX && (uint32_t)d.k * 2u <= m.n_groups_pub &&
                       (uint64_t)m.grid * WG_SLOTS <= (uint64_t)SEL_PER_THREAD * (m.multi_stream_waves * 64u + 64u);
     }
@@ -760,14 +769,17 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
         const uint32_t n_multi_waves = (m.grid - (uint32_t)MULTI_Q_MAX) * m.multi_stream_waves;
         SellMatrix sm;
         std::string perr;
-        if (prepacked) {  // no COO at hand: decode the packed matrix
+        const SellValues sv = d.precision == TKSPMV_Q1_7_F32 ? SellValues::Q1_7_RND : SellValues::F32;
+        if (prepacked) {  // no COO at hand: decode the packed matrix (byte values decode to exactly representable floats)
             std::vector<uint32_t> r, c;
             std::vector<float> v;
             decode_wbscsr(*prepacked, r, c, v);
-            perr = pack_wsell(d.rows, d.cols, r.size(), r.data(), c.data(), v.data(), n_multi_waves, sm);
+            perr = pack_wsell(d.rows, d.cols, r.size(), r.data(), c.data(), v.data(), n_multi_waves, sm, sv);
         } else {
-            perr = pack_wsell(d.rows, d.cols, d.nnz, d.row, d.col, d.val, n_multi_waves, sm);
+            perr = pack_wsell(d.rows, d.cols, d.nnz, d.row, d.col, d.val, n_multi_waves, sm, sv);
         }
+        m.sell_packet_bytes = sm.packet_bytes;
+        m.sell_byte_values = sv == SellValues::Q1_7_RND;
         if (!perr.empty()) {
             err = perr;
             return TKSPMV_ERR_INVALID;

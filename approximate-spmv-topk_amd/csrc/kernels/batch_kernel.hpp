@@ -217,7 +217,7 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0, co
                         else if (QM == 4)
                             reinterpret_cast<uint32_t *>(xl)[i] = to_fixed_dev(r[u], P0.fixed_width) >> (P0.fixed_width <= 24u ? 8 : 0);
                         else
-                            xl[i] = r[u];
+                            xl[i] = QM == 5 ? r[u] * Q17_UNIT : r[u];
                     }
                 }
                 uint32_t *mp = L.misc[par];

@@ -74,7 +74,24 @@ constexpr uint32_t SLOT_INVALID = 0xFFFFFFFFu;  // row id of an unused slot
 // FPGA's real_type for any FIXED_WIDTH): values and x as left-aligned Q1.31 words, integer products and sums.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-constexpr int value_type_of(int QM) { return QM == 3 ? 2 : ((QM == 1 || QM == 2) ? 1 : 0); }  // QM 4: one u32 per value, loaded like fp32
+// QM 5 = Q1.7 values (rounded to nearest) dequantised to fp32 (v_cvt_f32_ubyteN: one VALU per entry), fp32 x held in LDS
+// pre-scaled by 2^-7 (exact), fp32 products and sums: the byte stream of the Q1.7 modes with the arithmetic of the fp32
+// path (TKSPMV_Q1_7_F32, BASELINE configs[4]).
+constexpr int value_type_of(int QM) { return QM == 3 ? 2 : ((QM == 1 || QM == 2 || QM == 5) ? 1 : 0); }  // QM 4: one u32 per value, loaded like fp32
+// Byte b (0..3) of a dword as a float: v_cvt_f32_ubyte0..3.
+template <int B>
+__device__ __forceinline__ float ubyte_to_float(uint32_t w) {
+    float r;
+    if (B == 0) asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(r) : "v"(w));
+    else if (B == 1) asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(r) : "v"(w));
+    else if (B == 2) asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(r) : "v"(w));
+    else asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(r) : "v"(w));
+    return r;
+}
+__device__ __forceinline__ float ubyte_to_float(uint32_t w, int b) {
+    return b == 0 ? ubyte_to_float<0>(w) : (b == 1 ? ubyte_to_float<1>(w) : (b == 2 ? ubyte_to_float<2>(w) : ubyte_to_float<3>(w)));
+}
+constexpr float Q17_UNIT = 0.0078125f;  // 2^-7
 
 // The packet stream is read once per query: nontemporal loads (a plain read kernel over the same bytes gains 12 %
 // from them when the stream comes from HBM, tools/stream_probe.hip).

@@ -25,6 +25,9 @@ namespace tkspmv {
 // CU (the host packs the stream for that many partitions).
 // ------------------------------------------------------------------------------------------------------------
 constexpr int MULTI_Q_MAX = 8;
+#ifndef TKSPMV_SELL_BYTE_NBUF
+#define TKSPMV_SELL_BYTE_NBUF 5
+#endif
 // entries of a wave's private candidate list, per query (LDS: 8 waves x Q lists)
 template <int Q>
 struct MultiGeom {
@@ -134,9 +137,19 @@ __device__ __forceinline__ void offer_rows(const SetAddr &A, uint32_t set, uint3
     wcnt = base + total < WAVE_CAP ? base + total : WAVE_CAP;
 }
 
-template <int Q>
+// The value of entry j of a lane's chunk as a float: fp32 chunks hold it; byte chunks (VT = 1, Q1.7 rounded to nearest,
+// TKSPMV_Q1_7_F32) convert it with one v_cvt_f32_ubyteN -- x in LDS is pre-scaled by 2^-7, so the product is the same
+// fp32 number as (byte / 128) * x.
+template <int VT>
+__device__ __forceinline__ float chunk_value(const Pkt<4, VT> &p, int j) {
+    if (VT == 1) return ubyte_to_float(p.vq[0], j);
+    return p.v[VT == 0 ? j : 0];
+}
+
+// VT: 0 = fp32 chunks (1536 B), 1 = byte chunks (768 B; four of them in flight behind the one being reduced instead of two).
+template <int Q, int VT = 0>
 __global__ void __launch_bounds__(576, Q >= 8 ? 4 : 6) multi_kernel(const StreamParams P0, const SelectParams SP0, const MultiParams M) {
-    constexpr int C = 4, NBUF = 3, DEFER_S = MultiGeom<Q>::HOLD;
+    constexpr int C = 4, NBUF = VT == 1 ? TKSPMV_SELL_BYTE_NBUF : 3, DEFER_S = MultiGeom<Q>::HOLD;
     constexpr uint32_t MULTI_WAVE_CAP = MultiGeom<Q>::WAVE_CAP;
     __shared__ MultiLds<Q> L;
     const uint32_t tid = threadIdx.x;
@@ -178,12 +191,12 @@ __global__ void __launch_bounds__(576, Q >= 8 ? 4 : 6) multi_kernel(const Stream
         }
     }
     const uint8_t *pk = M.cur.io[0].packets + (size_t)p0 * P0.packet_bytes;
-    Pkt<C, 0> buf[NBUF];
+    Pkt<C, VT> buf[NBUF];
 #pragma unroll
     for (int u = 0; u < NBUF - 1; ++u) {
         if (np > 0u) {
             const uint32_t iu = ((uint32_t)u < np) ? (uint32_t)u : (np - 1u);
-            load_packet<C, 0>(pk + (size_t)iu * P0.packet_bytes, lane, buf[u]);
+            load_packet<C, VT>(pk + (size_t)iu * P0.packet_bytes, lane, buf[u]);
         }
     }
 
@@ -195,10 +208,11 @@ __global__ void __launch_bounds__(576, Q >= 8 ? 4 : 6) multi_kernel(const Stream
     };
     for (uint32_t q = 0; q < (uint32_t)Q; ++q) {  // queries beyond nq (a partial group): zeros, their sums are never looked at
         const float *xg = M.cur.io[q < nq ? q : 0u].x;
-        for (uint32_t i = tid; i < SELL_XCOLS; i += blockDim.x) x_slot(q, i) = (i < P0.cols && q < nq) ? xg[i] : 0.0f;
+        for (uint32_t i = tid; i < SELL_XCOLS; i += blockDim.x)
+            x_slot(q, i) = (i < P0.cols && q < nq) ? (VT == 1 ? xg[i] * Q17_UNIT : xg[i]) : 0.0f;
         if (tid == 0) {
             x_slot(q, SELL_PAD_NEUTRAL) = -0.0f;
-            x_slot(q, SELL_PAD_ONE) = 1.0f;
+            x_slot(q, SELL_PAD_ONE) = VT == 1 ? -__builtin_huge_valf() : 1.0f;  // byte chunks: a lane without a row starts with byte 1
         }
     }
     __syncthreads();
@@ -279,10 +293,10 @@ __global__ void __launch_bounds__(576, Q >= 8 ? 4 : 6) multi_kernel(const Stream
         for (int u = 0; u < NBUF; ++u) {
             const uint32_t i = i0 + (uint32_t)u;
             if (i >= np) break;
-            const Pkt<C, 0> &cur = buf[u];
+            const Pkt<C, VT> &cur = buf[u];
             {  // unconditional (pointer clamped to the last chunk): a fixed number of younger loads => counted vmcnt
                 if (i + (NBUF - 1) < np) pk_ahead += P0.packet_bytes;
-                load_packet<C, 0>(pk_ahead, lane, buf[(u + NBUF - 1) % NBUF]);
+                load_packet<C, VT>(pk_ahead, lane, buf[(u + NBUF - 1) % NBUF]);
             }
             uint32_t off[C];
 #pragma unroll
@@ -301,7 +315,8 @@ __global__ void __launch_bounds__(576, Q >= 8 ? 4 : 6) multi_kernel(const Stream
                 for (int h = 0; h < Q / 2; ++h) a2[h] = f32x2{acc[2 * h], acc[2 * h + 1]};
 #pragma unroll
                 for (int j = 0; j < C; ++j) {
-                    const f32x2 vv = {cur.v[j], cur.v[j]};
+                    const float vj = chunk_value<VT>(cur, j);
+                    const f32x2 vv = {vj, vj};
 #pragma unroll
                     for (int h = 0; h < Q / 4; ++h) {
                         const float4 xv = *reinterpret_cast<const float4 *>(xb + off[j] * (uint32_t)Q + 16u * (uint32_t)h);
@@ -321,7 +336,7 @@ __global__ void __launch_bounds__(576, Q >= 8 ? 4 : 6) multi_kernel(const Stream
                         const unsigned char *xb = reinterpret_cast<const unsigned char *>(L.u.w.x + (size_t)q * (SELL_XCOLS + 8u));
 #pragma unroll
                         for (int j = 0; j < C; ++j)
-                            acc[q] = __fadd_rn(acc[q], __fmul_rn(cur.v[j], *reinterpret_cast<const float *>(xb + off[j])));
+                            acc[q] = __fadd_rn(acc[q], __fmul_rn(chunk_value<VT>(cur, j), *reinterpret_cast<const float *>(xb + off[j])));
                     }
                 }
             }

@@ -234,7 +234,11 @@ __device__ __forceinline__ RowSums<C> reduce_packet(const Pkt<C, value_type_of(Q
     for (int j = 0; j < C; ++j) {
         const uint32_t word = cur.cw[j >> 1];
         const uint32_t off = (j & 1) ? ((word >> 16) & 0xFFFCu) : (word & 0xFFFCu);  // byte offset of x[col]
-        if (VT == 1) {
+        if (QM == 5) {
+            // x is staged as fp32 scaled by 2^-7: byte * (x / 128), one conversion and one multiply per entry
+            const float xv = *reinterpret_cast<const float *>(reinterpret_cast<const unsigned char *>(x_lds) + off);
+            p[j] = __fmul_rn(ubyte_to_float(cur.vq[VT == 1 ? (j >> 2) : 0], j & 3), xv);
+        } else if (VT == 1) {
             // x is staged as Q1.7 integers; product truncated to Q1.7 and wrapped to 8 bits, exact in fp32
             const uint32_t xq = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const unsigned char *>(x_lds) + off);
             const uint32_t vq = (cur.vq[VT == 1 ? (j >> 2) : 0] >> (8 * (j & 3))) & 255u;

@@ -149,7 +149,7 @@ __global__ void __launch_bounds__(576, (C == 8 && !SCORES) ? 6 : 5) stream_kerne
         else if (QM == 4)  // W <= 24: as a 24-bit integer (see reduce_packet)
             reinterpret_cast<uint32_t *>(x_lds)[i] = to_fixed_dev(xv, P.fixed_width) >> (P.fixed_width <= 24u ? 8 : 0);
         else
-            x_lds[i] = xv;
+            x_lds[i] = QM == 5 ? xv * Q17_UNIT : xv;
     }
     if (tid == 0) misc[MISC_TAU] = __float_as_uint(min_units);
     __syncthreads();

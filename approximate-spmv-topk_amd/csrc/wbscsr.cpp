@@ -162,6 +162,8 @@ std::string pack_wbscsr(uint32_t rows, uint32_t cols, uint64_t nnz, const uint32
                 } else if (precision == Precision::FIXED) {
                     const uint32_t q = to_fixed(v, fixed_width);
                     std::memcpy(pkt + (size_t)slot * 4, &q, 4);
+                } else if (precision == Precision::Q1_7_RND) {
+                    pkt[slot] = to_q1_7_rnd(v);
                 } else {
                     pkt[slot] = to_q1_7(v);
                 }
@@ -310,7 +312,8 @@ std::string load_packed(const char *path, PackedMatrix &pm) {
     if (std::memcmp(hd.magic, MAGIC, 8) != 0) return fail("not a .tkspmv file (bad magic)");
     if (hd.version != 1) return fail("unsupported .tkspmv version");
     if ((hd.precision != (uint32_t)Precision::F32 && hd.precision != (uint32_t)Precision::Q1_7 &&
-         hd.precision != (uint32_t)Precision::F16 && hd.precision != (uint32_t)Precision::FIXED) ||
+         hd.precision != (uint32_t)Precision::F16 && hd.precision != (uint32_t)Precision::FIXED &&
+         hd.precision != (uint32_t)Precision::Q1_7_RND) ||
         (hd.precision == (uint32_t)Precision::FIXED ? (hd.fixed_width < 8 || hd.fixed_width > 32) : hd.fixed_width != 0) ||
         (hd.C != 4 && hd.C != 8) ||
         hd.packet_entries != 64 * hd.C ||

@@ -1,6 +1,8 @@
 // wsell.cpp -- host packer / decoder of the wave-sliced ELL layout (see wsell.hpp).
 #include "wsell.hpp"
 
+#include "wbscsr.hpp"
+
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -9,7 +11,7 @@
 namespace tkspmv {
 
 std::string pack_wsell(uint32_t rows, uint32_t cols, uint64_t nnz, const uint32_t *row, const uint32_t *col, const float *val,
-                       uint32_t n_partitions_hint, SellMatrix &out) {
+                       uint32_t n_partitions_hint, SellMatrix &out, SellValues values) {
     if (cols == 0 || cols > SELL_XCOLS) return "the multi-query layout is built for at most 1024 columns";
     if (nnz > 0 && (!row || !col)) return "row/col arrays are NULL";
     if (n_partitions_hint == 0) n_partitions_hint = 1;
@@ -17,6 +19,10 @@ std::string pack_wsell(uint32_t rows, uint32_t cols, uint64_t nnz, const uint32_
     out.rows = rows;
     out.cols = cols;
     out.nnz = nnz;
+    out.values = values;
+    const uint32_t vb = (uint32_t)values;
+    const uint32_t PB = 256u * (vb + 2u);
+    out.packet_bytes = PB;
     if (nnz == 0) return "";
     for (uint64_t i = 1; i < nnz; ++i)
         if (row[i] < row[i - 1]) return "COO rows are not sorted in non-decreasing order";
@@ -99,7 +105,7 @@ std::string pack_wsell(uint32_t rows, uint32_t cols, uint64_t nnz, const uint32_
     out.n_slices = n_slices;
     out.n_chunks = (uint32_t)n_chunks;
     out.padded_entries = n_chunks * 256;
-    out.packets.assign((size_t)n_chunks * SellMatrix::PACKET_BYTES, 0);
+    out.packets.assign((size_t)n_chunks * PB, 0);
     out.slice_rows.assign((size_t)n_slices * 64, SELL_NO_ROW);
     out.part_first.resize(P);
     out.part_count.resize(P);
@@ -117,28 +123,33 @@ std::string pack_wsell(uint32_t rows, uint32_t cols, uint64_t nnz, const uint32_
                 const bool have = ln.row != SELL_NO_ROW;
                 if (have && ln.tail) out.slice_rows[(size_t)slice_out * 64 + l] = ln.row;
                 for (uint32_t c = 0; c < nc; ++c) {
-                    uint8_t *pkt = out.packets.data() + (size_t)(chunk + c) * SellMatrix::PACKET_BYTES;
+                    uint8_t *pkt = out.packets.data() + (size_t)(chunk + c) * PB;
                     for (uint32_t j = 0; j < 4; ++j) {
                         const uint32_t e = 4 * c + j;
                         float v;
+                        uint8_t qv;  // byte values
                         uint16_t cw;
                         if (have && e < ln.n) {
                             const uint64_t src = start[ln.row] + ln.first + e;
                             v = val ? val[src] : 1.0f;
+                            qv = to_q1_7_rnd(v);
                             cw = (uint16_t)(col[src] << 2);
                         } else if (!have && e == 0) {
                             v = neg_inf;  // a lane without a row: its sum is -inf
+                            qv = 1;       // (byte values: the PAD_ONE slot holds -inf)
                             cw = (uint16_t)(SELL_PAD_ONE << 2);
                         } else {
                             v = 0.0f;  // (+0.0) * (-0.0) = -0.0: leaves every sum as it is
+                            qv = 0;
                             cw = (uint16_t)(SELL_PAD_NEUTRAL << 2);
                         }
                         if (c + 1 == nc) {  // flags of the slice's last chunk
                             if (j == 0) cw |= SELL_LAST_CHUNK;
                             if (j >= 1) cw |= (uint16_t)((ln.depth >> (2 * (j - 1))) & 3u);  // segment index, 2 bits per word
                         }
-                        std::memcpy(pkt + ((size_t)l * 4 + j) * 4, &v, 4);
-                        std::memcpy(pkt + 1024 + ((size_t)l * 4 + j) * 2, &cw, 2);
+                        if (vb == 4u) std::memcpy(pkt + ((size_t)l * 4 + j) * 4, &v, 4);
+                        else pkt[(size_t)l * 4 + j] = qv;
+                        std::memcpy(pkt + 256u * vb + ((size_t)l * 4 + j) * 2, &cw, 2);
                     }
                 }
             }
@@ -154,6 +165,7 @@ void decode_wsell(const SellMatrix &sm, std::vector<uint32_t> &row, std::vector<
     row.clear();
     col.clear();
     val.clear();
+    const uint32_t vb = (uint32_t)sm.values, PB = sm.packet_bytes, CW0 = 256u * vb;
     for (size_t p = 0; p < sm.part_first.size(); ++p) {
         uint32_t slice = sm.part_slice0[p];
         uint32_t c0 = sm.part_first[p];
@@ -162,16 +174,16 @@ void decode_wsell(const SellMatrix &sm, std::vector<uint32_t> &row, std::vector<
             uint32_t nc = 1;  // chunks of this slice: up to the one flagged as last
             for (;; ++nc) {
                 uint16_t cw;
-                std::memcpy(&cw, sm.packets.data() + (size_t)(c0 + nc - 1) * SellMatrix::PACKET_BYTES + 1024, 2);
+                std::memcpy(&cw, sm.packets.data() + (size_t)(c0 + nc - 1) * PB + CW0, 2);
                 if (cw & SELL_LAST_CHUNK) break;
             }
             // segment index of every lane (flags of the last chunk); a lane with segment index d > 0 continues the row of
             // the lane to its left, the row id sits on the row's last lane
             uint32_t depth[64], owner[64];
-            const uint8_t *last = sm.packets.data() + (size_t)(c0 + nc - 1) * SellMatrix::PACKET_BYTES;
+            const uint8_t *last = sm.packets.data() + (size_t)(c0 + nc - 1) * PB;
             for (uint32_t l = 0; l < 64; ++l) {
                 uint16_t w[4];
-                std::memcpy(w, last + 1024 + (size_t)l * 8, 8);
+                std::memcpy(w, last + CW0 + (size_t)l * 8, 8);
                 depth[l] = (w[1] & 3u) | ((w[2] & 3u) << 2) | ((w[3] & 3u) << 4);
             }
             for (int l = 63; l >= 0; --l) {
@@ -182,12 +194,13 @@ void decode_wsell(const SellMatrix &sm, std::vector<uint32_t> &row, std::vector<
                 const uint32_t r = owner[l];
                 if (r == SELL_NO_ROW) continue;
                 for (uint32_t c = 0; c < nc; ++c) {
-                    const uint8_t *pkt = sm.packets.data() + (size_t)(c0 + c) * SellMatrix::PACKET_BYTES;
+                    const uint8_t *pkt = sm.packets.data() + (size_t)(c0 + c) * PB;
                     for (uint32_t j = 0; j < 4; ++j) {
                         uint16_t cw;
                         float v;
-                        std::memcpy(&cw, pkt + 1024 + ((size_t)l * 4 + j) * 2, 2);
-                        std::memcpy(&v, pkt + ((size_t)l * 4 + j) * 4, 4);
+                        std::memcpy(&cw, pkt + CW0 + ((size_t)l * 4 + j) * 2, 2);
+                        if (vb == 4u) std::memcpy(&v, pkt + ((size_t)l * 4 + j) * 4, 4);
+                        else v = from_q1_7(pkt[(size_t)l * 4 + j]);
                         const uint32_t cc = cw >> 2;
                         if (cc >= SELL_XCOLS) continue;  // padding
                         row.push_back(r);

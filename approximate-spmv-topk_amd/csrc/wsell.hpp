@@ -43,23 +43,29 @@ constexpr uint32_t SELL_PAD_ONE = SELL_XCOLS + 1;      // LDS slot holding 1.0f
 constexpr uint32_t SELL_NO_ROW = 0xFFFFFFFFu;
 constexpr uint16_t SELL_LAST_CHUNK = 0x0001u;
 
+// Value type of the chunks: fp32 (1536-byte chunks) or Q1.7 bytes rounded to nearest (768-byte chunks: [64 lanes x 4 u8]
+// [64 lanes x 4 u16 column words]; TKSPMV_Q1_7_F32). With byte values the kernel's LDS copy of x is pre-scaled by 2^-7 and
+// a lane without a row starts with (byte 1, column PAD_ONE) where that slot holds -inf instead of (value -inf, slot 1.0f).
+enum class SellValues : uint32_t { F32 = 4, Q1_7_RND = 1 };  // = bytes per value
+
 struct SellMatrix {
     uint32_t rows = 0, cols = 0;
     uint64_t nnz = 0;
     uint32_t n_slices = 0, n_chunks = 0;
+    SellValues values = SellValues::F32;
+    uint32_t packet_bytes = 1536;           // 256 * (bytes per value + 2)
     uint64_t padded_entries = 0;            // n_chunks * 256
-    std::vector<uint8_t> packets;           // n_chunks * 1536
+    std::vector<uint8_t> packets;           // n_chunks * packet_bytes
     std::vector<uint32_t> slice_rows;       // [n_slices][64], stream order
     std::vector<uint32_t> part_first;       // [n_parts] first chunk
     std::vector<uint32_t> part_count;       // [n_parts] chunks
     std::vector<uint32_t> part_slice0;      // [n_parts] index of the partition's first slice (stream order)
-    static constexpr uint32_t PACKET_BYTES = 1536;
-    uint64_t stream_bytes() const { return (uint64_t)n_chunks * PACKET_BYTES; }
+    uint64_t stream_bytes() const { return (uint64_t)n_chunks * packet_bytes; }
 };
 
 // Packs a row-sorted COO (validated like pack_wbscsr). Returns an empty string on success.
 std::string pack_wsell(uint32_t rows, uint32_t cols, uint64_t nnz, const uint32_t *row, const uint32_t *col, const float *val,
-                       uint32_t n_partitions_hint, SellMatrix &out);
+                       uint32_t n_partitions_hint, SellMatrix &out, SellValues values = SellValues::F32);
 
 // Inverse (tests): the rows in stream order with their entries (padding dropped).
 void decode_wsell(const SellMatrix &sm, std::vector<uint32_t> &row, std::vector<uint32_t> &col, std::vector<float> &val);

@@ -61,6 +61,12 @@ typedef enum {
                              accumulation: the same 3 B/nnz stream with usable ranking quality */
     TKSPMV_F16 = 3,       /* fp16 values (round to nearest even), fp32 x, fp32 products and sums: 4 B/nnz. The CUDA
                              comparator's half mode (-a, host_spmv_topk_csr_gpu.cu:132-136,152-160) */
+    TKSPMV_Q1_7_F32 = 5,  /* BASELINE configs[4] done properly: values stored as Q1.7 bytes (ap_ufixed<8,1,AP_RND,AP_SAT>: rounded
+                             to nearest, 3 B/nnz with the column word), x in fp32, fp32 products and sums -- the reduced-
+                             precision VALUE STREAM of the FPGA design (fpga_types.hpp:16-23) with the arithmetic of the fp32
+                             path. The only error is the quantisation of the values: precision@100 against the fp32 gold 0.97
+                             on configs[4] (host_spmv_bscsr.cpp:646-650 is the reference's acceptance metric). Scores are bit-
+                             identical to the fp32 engine's on the de-quantised values. */
     TKSPMV_FIXED = 4      /* the FPGA's real_type for any FIXED_WIDTH (types.hpp:20; builds tested by the reference:
                              20/21/25/26/32 bits, test_spmv_topk.py:42-47): ap_ufixed<W,1,AP_TRN_ZERO> with
                              W = desc.fixed_width in [8, 32] -- values, x, every product and every partial sum truncated

@@ -358,6 +358,21 @@ void oracle_round_values_to_half(const float *in, float *out, uint64_t n) {
     for (uint64_t i = 0; i < n; i++) out[i] = oracle_half_to_float(oracle_float_to_half(in[i]));
 }
 
+/* values rounded to Q1.7 (nearest, ties up, saturating at 255/128: ap_ufixed<8,1,AP_RND,AP_SAT>) and back: the value
+ * stream of TKSPMV_Q1_7_F32. (byte / 128) * x and byte * (x / 128) are the same fp32 number wherever nothing underflows,
+ * so the fp32 oracles run on these values model that precision. */
+void oracle_round_values_to_q17(const float *in, float *out, uint64_t n) {
+    for (uint64_t i = 0; i < n; i++) {
+        float v = in[i];
+        uint32_t q = 0;
+        if (v > 0.0f) {
+            float s = v * 128.0f + 0.5f;
+            q = s >= 255.0f ? 255u : (uint32_t)s;
+        }
+        out[i] = (float)q * 0.0078125f;
+    }
+}
+
 void oracle_packed_scores(const uint8_t *packets, uint64_t packet_bytes, const uint32_t *pkt_row,
                           const uint32_t *part_first, const uint32_t *part_count, uint32_t n_parts, uint32_t C,
                           const float *x, uint32_t rows, float *y, uint8_t *present) {
@@ -384,7 +399,10 @@ void oracle_packed_scores(const uint8_t *packets, uint64_t packet_bytes, const u
                     uint32_t at = (j >> 2) * 256 + l * 4 + (j & 3);
                     uint16_t w = cws[at];
                     float xv = x[w >> 2];
-                    p[j] = (vb == 2u ? oracle_half_to_float(hvals[at]) : vals[at]) * xv;
+                    if (vb == 1u) /* Q1.7 bytes, fp32 arithmetic (TKSPMV_Q1_7_F32): byte * (x * 2^-7), as the kernel does */
+                        p[j] = (float)pk[at] * (xv * 0.0078125f);
+                    else
+                        p[j] = (vb == 2u ? oracle_half_to_float(hvals[at]) : vals[at]) * xv;
                     e[l][j] = w & 1u;
                     skip[l][j] = w & 2u;
                 }

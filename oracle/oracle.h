@@ -99,6 +99,9 @@ void oracle_cpu_global_topk(const double *scores, const uint8_t *kept, uint32_t 
 int oracle_cpu_spmv_f32(const uint64_t *ptr, const uint32_t *idx, const float *v, uint32_t rows, const float *x,
                         int n_threads, float *scores);
 
+/* values rounded to Q1.7 bytes (nearest, saturating) and back: the value stream of TKSPMV_Q1_7_F32 */
+void oracle_round_values_to_q17(const float *in, float *out, uint64_t n);
+
 /* bench.py's cpu_baseline leg, timed natively: `warm` untimed + `reps` timed queries (query i = xs + (i % n_x) * cols),
  * per query the threaded SpMV (fp64: oracle_cpu_topn; use_f32: oracle_cpu_spmv_f32) and the global top-k; times in ms. */
 int oracle_cpu_bench(const uint64_t *ptr, const uint32_t *idx, const double *v64, const float *v32, uint32_t rows,

@@ -158,6 +158,14 @@ def round_to_half(values):
     return out
 
 
+def round_to_q17(values):
+    """values rounded to Q1.7 bytes (nearest, ties up, saturating) and back: the value stream of TKSPMV_Q1_7_F32."""
+    v = _f32(values)
+    out = np.empty_like(v)
+    oracle().oracle_round_values_to_q17(_p(v, f32p), _p(out, f32p), C.c_uint64(v.shape[0]))
+    return out
+
+
 def sample_vector(size, sum_to_one=False, norm_one=True, seed=1):
     v = np.zeros(size, dtype=np.float32)
     oracle().oracle_sample_vector(_p(v, f32p), C.c_int(size), C.c_int(int(sum_to_one)), C.c_int(int(norm_one)),
