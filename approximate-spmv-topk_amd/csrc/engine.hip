@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -72,6 +73,17 @@ struct EngineImpl {
     uint32_t *d_pkt_row = nullptr, *d_part_first = nullptr, *d_part_count = nullptr;
     float *d_x = nullptr;
     const float *d_x_cur = nullptr;
+    // Low-latency host boundary of the reference loop (reset -> operator() -> read_result, host_spmv_bscsr.cpp:602-632):
+    // set_query copies x into pinned host memory and enqueues the 4 KiB upload without waiting for it; run() launches the
+    // fused kernel, whose selection tail also writes the k results and an epoch flag to pinned host memory, and polls that
+    // flag; read() copies from the pinned block. No stream synchronisation, no device-to-host copy on the critical path.
+    float *h_x = nullptr;            // pinned staging copy of x
+    uint32_t *h_res = nullptr;       // pinned: [k] row ids, [k] score bits, [2k] epoch flag
+    uint32_t *h_res_dev = nullptr;   // the same block as the device sees it
+    mutable uint32_t host_epoch = 0;
+    mutable bool last_on_host = false;  // the most recent result is complete in h_res
+    bool x_pending = false;             // an upload from h_x may still be in flight
+    int host_path = 1;                  // TKSPMV_HOST_PATH=0: the plain path (stream synchronisation + copies)
     // Exchange state of one query in flight (published maxima, threshold word, survivor slots, overflow list).
     // Two sets: with deferred selection, launch q+1 streams into one set while its workgroup 0 selects query q from
     // the other. Everything else uses set 0.
@@ -199,6 +211,8 @@ struct EngineImpl {
         S.use_gmax = (n_sets != 0u && n_groups_pub >= (uint32_t)desc.k) ? 1u : 0u;
         S.scratch = E.scratch;
         S.stats = collect_stats ? d_stats : nullptr;
+        S.host_out = nullptr;
+        S.host_epoch = 0u;
         return S;
     }
     // The selection still owed to the last deferred launch, as its own small kernel.
@@ -413,9 +427,13 @@ struct EngineImpl {
         if (xcols <= 4096) return scores ? &stream_kernel<4, true, 4096> : &stream_kernel<4, false, 4096>;
         return scores ? &stream_kernel<4, true, 16384> : &stream_kernel<4, false, 16384>;
     }
-    void launch_stream(const float *x, uint32_t *out_idx, float *out_val, hipStream_t s) const {
+    void launch_stream(const float *x, uint32_t *out_idx, float *out_val, hipStream_t s, bool to_host = false) const {
         StreamParams P = stream_params(x);
         SelectParams S = select_params(out_idx, out_val);
+        if (to_host) {
+            S.host_out = h_res_dev;
+            S.host_epoch = ++host_epoch;
+        }
         ++launch_counter;
         hipLaunchKernelGGL(kernel_for(false), dim3(grid), dim3(block + 64), 0, s, P, S);
     }
@@ -500,6 +518,8 @@ Engine::~Engine() {
         for (void *b : eb)
             if (b) (void)hipFree(b);
     }
+    if (m.h_x) (void)hipHostFree(m.h_x);
+    if (m.h_res) (void)hipHostFree(m.h_res);
     for (size_t r = 1; r < m.d_replicas.size(); ++r) (void)hipFree(m.d_replicas[r]);
     for (size_t r = 1; r < m.d_sell_replicas.size(); ++r) (void)hipFree(m.d_sell_replicas[r]);
     {
@@ -706,6 +726,17 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
     std::vector<uint32_t>().swap(m.pm.pkt_row);
 
     HIP_TRY(hipMalloc((void **)&m.d_x, (size_t)d.cols * 4));
+    if (const char *f = getenv("TKSPMV_HOST_PATH")) m.host_path = atoi(f);
+    if (m.host_path) {  // pinned staging copy of x and the host-visible result block (optional: the plain path needs neither)
+        if (hipHostMalloc((void **)&m.h_x, (size_t)d.cols * 4, hipHostMallocDefault) != hipSuccess) m.h_x = nullptr;
+        if (hipHostMalloc((void **)&m.h_res, ((size_t)2 * d.k + 16) * 4, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+            hipHostGetDevicePointer((void **)&m.h_res_dev, m.h_res, 0) != hipSuccess) {
+            if (m.h_res) (void)hipHostFree(m.h_res);
+            m.h_res = m.h_res_dev = nullptr;
+        }
+        (void)hipGetLastError();
+        if (m.h_res) std::memset(m.h_res, 0, ((size_t)2 * d.k + 16) * 4);
+    }
     HIP_TRY(hipMalloc((void **)&m.d_out_idx, (size_t)d.k * 4));
     HIP_TRY(hipMalloc((void **)&m.d_out_val, (size_t)d.k * 4));
     HIP_TRY(hipMalloc((void **)&m.d_stats, 32 * 8));
@@ -912,8 +943,16 @@ int Engine::set_query(const float *host_x, double *elapsed_ns, std::string &err)
     }
     auto t0 = std::chrono::high_resolution_clock::now();
     HIP_TRY(hipSetDevice(m.device));
-    HIP_TRY(hipMemcpyAsync(m.d_x, host_x, (size_t)m.desc.cols * 4, hipMemcpyHostToDevice, m.stream));
-    HIP_TRY(hipStreamSynchronize(m.stream));
+    if (m.host_path && m.h_x) {
+        // (an earlier upload from the staging copy must have been consumed before it is overwritten)
+        if (m.x_pending) HIP_TRY(hipStreamSynchronize(m.stream));
+        std::memcpy(m.h_x, host_x, (size_t)m.desc.cols * 4);
+        HIP_TRY(hipMemcpyAsync(m.d_x, m.h_x, (size_t)m.desc.cols * 4, hipMemcpyHostToDevice, m.stream));
+        m.x_pending = true;
+    } else {
+        HIP_TRY(hipMemcpyAsync(m.d_x, host_x, (size_t)m.desc.cols * 4, hipMemcpyHostToDevice, m.stream));
+        HIP_TRY(hipStreamSynchronize(m.stream));
+    }
     m.d_x_cur = m.d_x;
     m.have_query = true;
     if (elapsed_ns)
@@ -945,6 +984,7 @@ int Engine::enqueue(const float *dev_x, uint32_t *dev_idx, float *dev_val, void 
     m.launch_query(x, dev_idx ? dev_idx : m.d_out_idx, dev_val ? dev_val : m.d_out_val, s);
     HIP_TRY(hipGetLastError());
     m.ran = true;
+    m.last_on_host = false;
     return TKSPMV_OK;
 }
 
@@ -977,6 +1017,7 @@ int Engine::enqueue_many(const float *dev_xs, int32_t n_x, int32_t count, void *
     m.launch_sequence(xs.data(), oi.data(), ov.data(), count, s);
     HIP_TRY(hipGetLastError());
     m.ran = true;
+    m.last_on_host = false;
     return TKSPMV_OK;
 }
 
@@ -997,6 +1038,7 @@ int Engine::enqueue_batch(const float *dev_xs, int32_t count, uint32_t *dev_idx,
     m.launch_sequence(xs.data(), oi.data(), ov.data(), count, s);
     HIP_TRY(hipGetLastError());
     m.ran = true;
+    m.last_on_host = false;
     return TKSPMV_OK;
 }
 
@@ -1012,6 +1054,7 @@ int Engine::enqueue_list(const float *const *dev_xs, uint32_t *const *dev_idx, f
     m.launch_sequence(dev_xs, dev_idx, dev_val, count, s);
     HIP_TRY(hipGetLastError());
     m.ran = true;
+    m.last_on_host = false;
     return TKSPMV_OK;
 }
 
@@ -1033,6 +1076,7 @@ int Engine::enqueue_multi(const float *dev_xs, int32_t count, uint32_t *dev_idx,
     m.launch_multi_sequence(xs.data(), oi.data(), ov.data(), count, s);
     HIP_TRY(hipGetLastError());
     m.ran = true;
+    m.last_on_host = false;
     return TKSPMV_OK;
 }
 
@@ -1048,6 +1092,7 @@ int Engine::enqueue_multi_list(const float *const *dev_xs, uint32_t *const *dev_
     m.launch_multi_sequence(dev_xs, dev_idx, dev_val, count, s);
     HIP_TRY(hipGetLastError());
     m.ran = true;
+    m.last_on_host = false;
     return TKSPMV_OK;
 }
 
@@ -1090,6 +1135,7 @@ int Engine::time_multi(const float *dev_xs, int32_t n_x, int32_t iters, double *
         HIP_TRY(hipMemset(m.d_stats, 0, 32 * 8));
     }
     m.ran = true;
+    m.last_on_host = false;
     return TKSPMV_OK;
 }
 
@@ -1104,6 +1150,7 @@ int Engine::enqueue_deferred(const float *dev_x, uint32_t *dev_idx, float *dev_v
     m.launch_deferred(dev_x, dev_idx ? dev_idx : m.d_out_idx, dev_val ? dev_val : m.d_out_val, s);
     HIP_TRY(hipGetLastError());
     m.ran = true;
+    m.last_on_host = false;
     return TKSPMV_OK;
 }
 
@@ -1123,15 +1170,49 @@ int Engine::run(double *kernel_ns, std::string &err) {
         return TKSPMV_ERR_STATE;
     }
     HIP_TRY(hipSetDevice(m.device));
-    HIP_TRY(hipEventRecord(m.ev0, m.stream));
-    m.launch_query(m.d_x_cur, m.d_out_idx, m.d_out_val, m.stream);
+    // The fused single launch can hand its result to the host itself (see h_res); the other launch schemes (radix select,
+    // row per lane, unfused selection) complete in stream order and are waited for with the event.
+    const bool to_host = m.host_path && m.h_res && m.fused && !m.use_radix && !(m.desc.impl == TKSPMV_IMPL_ROW_PER_LANE && m.can_multi);
+    if (kernel_ns) HIP_TRY(hipEventRecord(m.ev0, m.stream));
+    if (to_host) {
+        m.drain(m.stream);
+        m.launch_stream(m.d_x_cur, m.d_out_idx, m.d_out_val, m.stream, true);
+    } else {
+        m.launch_query(m.d_x_cur, m.d_out_idx, m.d_out_val, m.stream);
+    }
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(m.ev1, m.stream));
-    HIP_TRY(hipEventSynchronize(m.ev1));
-    float ms = 0;
-    HIP_TRY(hipEventElapsedTime(&ms, m.ev0, m.ev1));
-    if (kernel_ns) *kernel_ns = (double)ms * 1e6;
+    if (kernel_ns) HIP_TRY(hipEventRecord(m.ev1, m.stream));
+    bool seen = false;
+    if (to_host) {
+        volatile uint32_t *flag = m.h_res + 2 * (size_t)m.desc.k;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (uint64_t spins = 0;; ++spins) {
+            if (*flag == m.host_epoch) {
+                seen = true;
+                break;
+            }
+            __builtin_ia32_pause();
+            if ((spins & 0xFFFFu) == 0xFFFFu && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) break;  // never hang on the flag
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+    }
+    if (!seen) HIP_TRY(hipStreamSynchronize(m.stream));
+    m.x_pending = false;  // the kernel has read x: the staging copy is free again
+    if (kernel_ns) {
+        if (seen) {  // the kernel is in its last instructions: the end event follows within a microsecond or two
+            hipError_t q;
+            while ((q = hipEventQuery(m.ev1)) == hipErrorNotReady) __builtin_ia32_pause();
+            if (q != hipSuccess) {
+                err = std::string("hipEventQuery failed: ") + hipGetErrorString(q);
+                return TKSPMV_ERR_DEVICE;
+            }
+        }
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, m.ev0, m.ev1));
+        *kernel_ns = (double)ms * 1e6;
+    }
     m.ran = true;
+    m.last_on_host = seen;
     return TKSPMV_OK;
 }
 
@@ -1148,8 +1229,15 @@ int Engine::read(uint32_t *idx, float *val, int32_t *n, std::string &err) {
         err = "no query has been run";
         return TKSPMV_ERR_STATE;
     }
+    if (m.last_on_host) {  // tkspmv_run left the result in pinned host memory
+        if (idx) std::memcpy(idx, m.h_res, (size_t)m.desc.k * 4);
+        if (val) std::memcpy(val, m.h_res + m.desc.k, (size_t)m.desc.k * 4);
+        if (n) *n = m.desc.k;
+        return TKSPMV_OK;
+    }
     HIP_TRY(hipSetDevice(m.device));
     HIP_TRY(hipStreamSynchronize(m.stream));
+    m.x_pending = false;
     if (idx) HIP_TRY(hipMemcpy(idx, m.d_out_idx, (size_t)m.desc.k * 4, hipMemcpyDeviceToHost));
     if (val) HIP_TRY(hipMemcpy(val, m.d_out_val, (size_t)m.desc.k * 4, hipMemcpyDeviceToHost));
     if (n) *n = m.desc.k;
@@ -1214,6 +1302,7 @@ int Engine::time_queries(const float *dev_xs, int32_t n_x, int32_t iters, double
     HIP_TRY(hipEventElapsedTime(&ms, m.ev0, m.ev1));
     *ns_per_query = (double)ms * 1e6 / iters;
     m.ran = true;
+    m.last_on_host = false;
     return TKSPMV_OK;
 }
 
@@ -1326,6 +1415,7 @@ int Engine::profile(const float *dev_xs, int32_t n_x, int32_t iters, tkspmv_timi
                 (long long)(st[5] - st[0]), (long long)(st[6] - st[0]), (long long)(st[7] - st[0]));
     }
     m.ran = true;
+    m.last_on_host = false;
     return TKSPMV_OK;
 }
 

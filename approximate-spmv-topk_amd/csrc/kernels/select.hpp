@@ -30,6 +30,11 @@ struct SelectParams {
     // row id; the selection, off the streaming waves' path, looks the row ids up here. NULL: candidates carry row ids.
     const uint32_t *pos_to_row;
     unsigned long long *stats;    // [0] += candidates, [1] += queries, [2] = max candidates, [3] += general-path runs
+    // Low-latency result hand-over of tkspmv_run (NULL: off): the k results are ALSO written to host-visible memory --
+    // host_out[0..k) row ids, [k..2k) score bits -- followed by host_out[2k] = host_epoch, which the host polls. No
+    // device-to-host copy, no stream synchronisation on the host's critical path.
+    uint32_t *host_out;
+    uint32_t host_epoch;
 };
 
 constexpr int MAX_GM = 16;  // n_groups_pub <= 1024 => at most 16 published maxima per lane
@@ -217,14 +222,29 @@ __device__ __forceinline__ void select_body(const SelectParams &P, const uint32_
         }
         for (uint32_t d = 1; d < G; d <<= 1) r += (uint32_t)__shfl_xor((int)r, (int)d);
         if (active && part == 0u && r < P.k) {
-            P.out_idx[r] = (uint32_t)(kx & 0xFFFFFFFFull) + P.first_row;
-            P.out_val[r] = key_to_float((uint32_t)(kx >> 32)) * out_scale;
+            const uint32_t oi = (uint32_t)(kx & 0xFFFFFFFFull) + P.first_row;
+            const float ov = key_to_float((uint32_t)(kx >> 32)) * out_scale;
+            P.out_idx[r] = oi;
+            P.out_val[r] = ov;
+            if (P.host_out) {  // system-scope stores: written through to host memory
+                __hip_atomic_store(&P.host_out[r], oi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(&P.host_out[P.k + r], __float_as_uint(ov), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
     }
     if (stamps && tid == 0) stamps[6] = __builtin_amdgcn_s_memtime();  // ranked
     for (uint32_t r = n_sel + tid; r < P.k; r += nthreads) {
         P.out_idx[r] = 0u;
         P.out_val[r] = 0.0f;
+        if (P.host_out) {
+            __hip_atomic_store(&P.host_out[r], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&P.host_out[P.k + r], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    if (P.host_out) {  // every writer drains its stores, the workgroup meets, one thread raises the flag
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(&P.host_out[2u * P.k], P.host_epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     // Reset the exchange state for the next query (this is the last consumer of the query on the stream); last, so
     // that no barrier above has to wait for these stores. Slots: only the ones that held a survivor need a store

@@ -39,20 +39,23 @@ std::string pack_wsell(uint32_t rows, uint32_t cols, uint64_t nnz, const uint32_
         start[r + 1] = start[r] + len[r];
         max_len = std::max(max_len, len[r]);
     }
-    // Units = non-empty rows; a row of more than SELL_SEG entries takes ceil(len / SELL_SEG) adjacent lanes (its length
-    // class is SELL_SEG). Units by length class, longest first, ties by row id (counting sort).
-    const uint32_t max_class = std::min(max_len, SELL_SEG);
+    // Units = non-empty rows; a row of more than SELL_SEG entries takes several adjacent lanes, cut into EQUAL segments
+    // (sell_segment_length: a 80-entry row becomes 40 + 40, not 64 + 16 padded to 64) and its length class is that segment
+    // length, so it sorts among the ordinary rows of that length. Units by length class, longest first, ties by row id
+    // (counting sort).
+    uint32_t max_class = 0;
+    for (uint32_t L : len) max_class = std::max(max_class, sell_segment_length(L));
     std::vector<uint64_t> bucket((size_t)max_class + 2, 0);
     for (uint32_t L : len) {
         if (!L) continue;
         if ((L + SELL_SEG - 1) / SELL_SEG > 64u) return "a row is too long for the multi-query layout (more than 4096 entries)";
-        ++bucket[max_class - std::min(L, SELL_SEG) + 1];
+        ++bucket[max_class - sell_segment_length(L) + 1];
     }
     for (size_t b = 1; b < bucket.size(); ++b) bucket[b] += bucket[b - 1];
     const uint64_t n_ne = bucket[max_class];  // rows with at least one entry
     std::vector<uint32_t> order(n_ne);
     for (uint32_t r = 0; r < (uint32_t)len.size(); ++r)
-        if (len[r]) order[bucket[max_class - std::min(len[r], SELL_SEG)]++] = r;
+        if (len[r]) order[bucket[max_class - sell_segment_length(len[r])]++] = r;
 
     // Slices: 64 lanes filled in that order; a multi-lane row never straddles two slices (lanes left over stay empty).
     struct Lane {
@@ -64,14 +67,14 @@ std::string pack_wsell(uint32_t rows, uint32_t cols, uint64_t nnz, const uint32_
     {
         uint32_t used = 64;  // lanes used in the open slice (64: none open)
         for (uint64_t u = 0; u < n_ne; ++u) {
-            const uint32_t r = order[u], L = len[r], nseg = (L + SELL_SEG - 1) / SELL_SEG;
+            const uint32_t r = order[u], L = len[r], slen = sell_segment_length(L), nseg = (L + slen - 1) / slen;
             if (used + nseg > 64u) {
                 if (used < 64u) lanes.resize(lanes.size() + (64u - used), Lane{SELL_NO_ROW, 0, 0, 0, false});
-                slice_chunks.push_back((std::min(L, SELL_SEG) + 3) / 4);  // the slice's first lane is its longest
+                slice_chunks.push_back((slen + 3) / 4);  // the slice's first lane is its longest
                 used = 0;
             }
             for (uint32_t g = 0; g < nseg; ++g)
-                lanes.push_back(Lane{r, g * SELL_SEG, std::min(SELL_SEG, L - g * SELL_SEG), g, g + 1 == nseg});
+                lanes.push_back(Lane{r, g * slen, std::min(slen, L - g * slen), g, g + 1 == nseg});
             used += nseg;
         }
         if (used < 64u) lanes.resize(lanes.size() + (64u - used), Lane{SELL_NO_ROW, 0, 0, 0, false});

@@ -14,9 +14,10 @@
 //     (only the very last slice can have some) starts with (value -inf, column PAD_ONE): that slot holds 1.0f, the
 //     lane's sum is -inf, it never passes a threshold and never raises a published maximum;
 //   * a lane holds at most SELL_SEG = 64 entries (16 chunks), so no slice is longer than a wave's share of the matrix and
-//     the partitions can be balanced: a LONGER row (0.35 % of the rows of the BASELINE matrix) is cut into segments of 64
-//     entries on ADJACENT lanes of one slice; when the slice ends, the segment sums are added left to right
-//     (((s0 + s1) + s2) ...) and the row's score lands on its last lane;
+//     the partitions can be balanced: a LONGER row (0.35 % of the rows of the BASELINE matrix, 10 % at 40 entries per row)
+//     is cut into equal segments of sell_segment_length(len) <= 64 entries on ADJACENT lanes of one slice (80 entries =
+//     40 + 40: cut at 64 the second lane would carry 16 entries and 48 of padding -- 20 % of configs[4]'s stream); when
+//     the slice ends, the segment sums are added left to right (((s0 + s1) + s2) ...) and the score lands on the last lane;
 //   * column word: bits 15..2 = column (so word & 0xFFFC is the LDS byte offset of x[col]). The two low bits are flags in
 //     the LAST chunk of a slice only: bit 0 of every lane's first word = "last chunk of its slice" (wave-uniform); the
 //     low two bits of words 1, 2, 3 = the lane's segment index (0 for an ordinary row), 2 bits each;
@@ -42,6 +43,13 @@ constexpr uint32_t SELL_PAD_NEUTRAL = SELL_XCOLS;      // LDS slot holding -0.0f
 constexpr uint32_t SELL_PAD_ONE = SELL_XCOLS + 1;      // LDS slot holding 1.0f
 constexpr uint32_t SELL_NO_ROW = 0xFFFFFFFFu;
 constexpr uint16_t SELL_LAST_CHUNK = 0x0001u;
+// Entries per lane of a row of `len` entries: the row itself up to SELL_SEG; a longer row is cut into ceil(len / SELL_SEG)
+// nearly equal segments, rounded up to whole chunks of 4 (the last segment takes what is left).
+inline uint32_t sell_segment_length(uint32_t len) {
+    if (len <= SELL_SEG) return len;
+    const uint32_t nseg = (len + SELL_SEG - 1) / SELL_SEG;
+    return ((len + nseg - 1) / nseg + 3u) & ~3u;
+}
 
 // Value type of the chunks: fp32 (1536-byte chunks) or Q1.7 bytes rounded to nearest (768-byte chunks: [64 lanes x 4 u8]
 // [64 lanes x 4 u16 column words]; TKSPMV_Q1_7_F32). With byte values the kernel's LDS copy of x is pre-scaled by 2^-7 and

@@ -123,8 +123,15 @@ void oracle_scores_f64(const uint32_t *row, const uint32_t *col, const float *va
     }
 }
 
-/* The multi-query kernel's order (wsell.hpp): a row is summed sequentially in segments of `seg` entries, the segment sums
- * are added left to right. seg >= the longest row: oracle_scores_f32_seq. */
+/* The row-per-lane kernels' order (wsell.hpp): a row of at most `seg` entries is summed sequentially -- the gold's order;
+ * a longer row is cut into ceil(len / seg) nearly equal segments (their length rounded up to a multiple of 4, the last one
+ * taking what is left), each summed sequentially, and the segment sums are added left to right.
+ * seg >= the longest row: oracle_scores_f32_seq. */
+static uint32_t segment_length(uint32_t len, uint32_t seg) {
+    if (len <= seg) return len;
+    const uint32_t nseg = (len + seg - 1) / seg;
+    return ((len + nseg - 1) / nseg + 3u) & ~3u;
+}
 void oracle_scores_f32_segmented(const uint32_t *row, const uint32_t *col, const float *val, uint64_t nnz, const float *vec,
                                  uint32_t rows, uint32_t seg, float *y, uint8_t *present) {
     memset(y, 0, (size_t)rows * sizeof(float));
@@ -132,11 +139,14 @@ void oracle_scores_f32_segmented(const uint32_t *row, const uint32_t *col, const
     uint64_t i = 0;
     while (i < nnz) {
         const uint32_t r = row[i];
+        uint64_t end = i;
+        while (end < nnz && row[end] == r) ++end;
+        const uint32_t slen = segment_length((uint32_t)(end - i), seg);
         float total = 0.0f;
         uint32_t n_seg = 0;
-        while (i < nnz && row[i] == r) {
+        while (i < end) {
             float s = 0.0f;
-            for (uint32_t e = 0; e < seg && i < nnz && row[i] == r; ++e, ++i) {
+            for (uint32_t e = 0; e < slen && i < end; ++e, ++i) {
                 const float p = val[i] * vec[col[i]];
                 s = s + p;
             }

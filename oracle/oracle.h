@@ -32,8 +32,9 @@ void oracle_gold_topk_sorted(const uint32_t *row, const uint32_t *col, const flo
 /* Row scores. present[r] = 1 iff row r has at least one entry. y arrays have `rows` elements. */
 void oracle_scores_f32_seq(const uint32_t *row, const uint32_t *col, const float *val, uint64_t nnz, const float *vec,
                            uint32_t rows, float *y, uint8_t *present); /* gold's sequential fp32 order */
-/* Order of the multi-query kernel (approximate-spmv-topk_amd/csrc/wsell.hpp): like the gold's sequential fp32 sum for rows
- * of at most `seg` entries; a longer row is summed in segments of `seg` entries whose sums are added left to right. */
+/* Order of the row-per-lane kernels (approximate-spmv-topk_amd/csrc/wsell.hpp): the gold's sequential fp32 sum for rows of
+ * at most `seg` entries; a longer row is cut into ceil(len / seg) nearly equal segments (their length rounded up to a
+ * multiple of 4, the last one taking what is left), summed sequentially each, and the sums are added left to right. */
 void oracle_scores_f32_segmented(const uint32_t *row, const uint32_t *col, const float *val, uint64_t nnz, const float *vec,
                                  uint32_t rows, uint32_t seg, float *y, uint8_t *present);
 void oracle_scores_f64(const uint32_t *row, const uint32_t *col, const float *val, uint64_t nnz, const float *vec,

@@ -139,7 +139,8 @@ def test_oracle_against_live_reference(pkg, oracle):
 
 def test_segmented_order_is_the_gold_order_for_short_rows(pkg, oracle):
     """oracle_scores_f32_segmented (the multi-query kernel's summation order) restates the gold's sequential fp32 sum
-    for every row of at most `seg` entries; longer rows are the left-to-right sum of their segment sums."""
+    for every row of at most `seg` entries; a longer row is cut into ceil(len / seg) nearly equal segments (length rounded
+    up to a multiple of 4) whose sums are added left to right."""
     m = pkg.generate_matrix(20000, 1024, 20, "gamma", 6)
     x = pkg.create_sample_vector(1024, True, False, True, 3)
     lens = np.bincount(m.row, minlength=m.rows)
@@ -152,12 +153,12 @@ def test_segmented_order_is_the_gold_order_for_short_rows(pkg, oracle):
     assert np.allclose(y_seq, y_seg, rtol=1e-6, atol=0)
     y_all, _ = oracle.scores_f32_segmented(m.row, m.col, m.val, x, m.rows, int(lens.max()))
     assert np.array_equal(y_all.view(np.uint32), y_seq.view(np.uint32))
-    # a long row by hand: segments of 3
+    # a long row by hand: 8 entries with seg = 3 -> ceil(8 / 3) = 3 segments of ceil(8 / 3) = 3, rounded up to 4: 4 + 4
     row = np.zeros(8, np.uint32)
     col = np.arange(8, dtype=np.uint32)
     val = np.array([0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8], np.float32)
     xx = np.ones(8, np.float32)
     y3, _ = oracle.scores_f32_segmented(row, col, val, xx, 1, 3)
     f = np.float32
-    want = f(f(f(f(f(0.1) + f(0.2)) + f(0.3)) + f(f(f(0.4) + f(0.5)) + f(0.6))) + f(f(0.7) + f(0.8)))
+    want = f(f(f(f(f(0.1) + f(0.2)) + f(0.3)) + f(0.4)) + f(f(f(f(0.5) + f(0.6)) + f(0.7)) + f(0.8)))
     assert y3[0].view(np.uint32) == want.view(np.uint32)
