@@ -5,6 +5,7 @@
 #include <string>
 
 #include "../../include/tkspmv.h"
+#include "device_pack.hpp"
 #include "engine.hpp"
 #include "host_utils.hpp"
 #include "wbscsr.hpp"
@@ -232,6 +233,31 @@ int tkspmv_pack(const tkspmv_desc *d, uint32_t n_wave_partitions_hint, tkspmv_pa
         return fail(kind == 2 ? TKSPMV_ERR_NOT_SORTED : TKSPMV_ERR_INVALID, err);
     }
     p->k = d->k;
+    *out = p;
+    return TKSPMV_OK;
+}
+
+int tkspmv_pack_device(const tkspmv_desc *d, uint32_t n_wave_partitions_hint, tkspmv_packed **out, double *ms) {
+    if (!d || !out) return fail(TKSPMV_ERR_INVALID, "NULL argument");
+    *out = nullptr;
+    if (device_count() < 1) return fail(TKSPMV_ERR_DEVICE, "no HIP device available (the device packer needs one)");
+    std::string serr;
+    if (use_device(d->device, serr) != TKSPMV_OK) return fail(TKSPMV_ERR_DEVICE, serr);
+    DevicePacked dp;
+    int kind = 0;
+    std::string err = pack_wbscsr_device(d->rows, d->cols, d->nnz, d->row, d->col, d->val, stream_precision(d->precision),
+                                         entries_per_lane_of(*d), n_wave_partitions_hint ? n_wave_partitions_hint : 4096u, 4,
+                                         fixed_width_of(*d), dp, kind);
+    if (err.empty()) err = download_device_packed(dp);
+    free_device_packed(dp);
+    if (!err.empty()) return fail(kind == 2 ? TKSPMV_ERR_NOT_SORTED : (err.find("failed:") != std::string::npos ? TKSPMV_ERR_DEVICE : TKSPMV_ERR_INVALID), err);
+    tkspmv_packed *p = new tkspmv_packed();
+    p->pm = std::move(dp.meta);
+    p->k = d->k;
+    if (ms) {
+        ms[0] = dp.upload_ms;
+        ms[1] = dp.kernels_ms;
+    }
     *out = p;
     return TKSPMV_OK;
 }

@@ -29,6 +29,7 @@
 #include <string>
 #include <vector>
 
+#include "device_pack.hpp"
 #include "engine.hpp"
 #include "wsell.hpp"
 
@@ -84,6 +85,9 @@ struct EngineImpl {
     mutable bool last_on_host = false;  // the most recent result is complete in h_res
     bool x_pending = false;             // an upload from h_x may still be in flight
     int host_path = 1;                  // TKSPMV_HOST_PATH=0: the plain path (stream synchronisation + copies)
+    float *h_x_dev = nullptr;           // h_x as the device sees it (TKSPMV_HOST_X=direct: kernels read x from host memory)
+    bool host_x_direct = false;
+    bool run_events = true;             // TKSPMV_RUN_EVENTS=0 (experiment): tkspmv_run reports host-clock time, no events
     // Exchange state of one query in flight (published maxima, threshold word, survivor slots, overflow list).
     // Two sets: with deferred selection, launch q+1 streams into one set while its workgroup 0 selects query q from
     // the other. Everything else uses set 0.
@@ -140,6 +144,9 @@ struct EngineImpl {
     uint32_t grid = 0, block = 0, gpw = 1, n_sets = 0, n_groups_pub = 0, cand_cap = 0, ovf_cap = 0, lds_bytes = 0,
              xcols = 1024;
     bool collect_stats = false;
+    // TKSPMV_TRACE / TKSPMV_STATS / TKSPMV_STAMPS / TKSPMV_DBG_FLAGS / TKSPMV_DBG_REPEAT: launch the instantiations that
+    // carry the tracing and ablation hooks (fp32 values, 4 entries per lane, <= 1024 columns; elsewhere the hooks do not exist)
+    bool dbg_kernels = false;
     bool q8 = false;
     bool collect_stamps = false;
     unsigned long long *d_trace = nullptr;  // TKSPMV_TRACE=1: 4 launches x [grid+1][9][8] stamps
@@ -148,6 +155,8 @@ struct EngineImpl {
     uint32_t dbg_repeat = 0;
     bool have_query = false;
     bool ran = false;
+    bool packed_on_device = false;  // the stream was built by device_pack.hip
+    uint32_t pack_us = 0;           // time of the packing step of tkspmv_create (upload of the COO included when on the device)
 
     StreamParams stream_params(const float *x, int set = 0) const {
         StreamParams P{};
@@ -340,7 +349,7 @@ struct EngineImpl {
         if (desc.precision == TKSPMV_FIXED) return &batch_kernel<4, 1024, 4>;
         if (desc.precision == TKSPMV_Q1_7_F32) return &batch_kernel<4, 1024, 5>;
         if (info.packet_entries == 512) return &batch_kernel<8, 1024, 0>;
-        return &batch_kernel<4, 1024, 0>;
+        return dbg_kernels ? &batch_kernel<4, 1024, 0, true> : &batch_kernel<4, 1024, 0>;
     }
     // n <= BATCH_MAX queries in one launch of the batch kernel; results complete in stream order after the launch.
     void launch_batch(const float *const *xs, uint32_t *const *out_idx, float *const *out_val, int n, hipStream_t s) const {
@@ -423,6 +432,7 @@ struct EngineImpl {
             return scores ? &stream_kernel<4, true, 16384, 2> : &stream_kernel<4, false, 16384, 2>;
         }
         if (c8) return scores ? &stream_kernel<8, true, 1024, 0, 2> : &stream_kernel<8, false, 1024, 0, 2>;  // (two packet buffers: 3 KB packets)
+        if (xcols <= 1024 && dbg_kernels && !scores) return &stream_kernel<4, false, 1024, 0, TKSPMV_NBUF, true>;
         if (xcols <= 1024) return scores ? &stream_kernel<4, true, 1024> : &stream_kernel<4, false, 1024>;
         if (xcols <= 4096) return scores ? &stream_kernel<4, true, 4096> : &stream_kernel<4, false, 4096>;
         return scores ? &stream_kernel<4, true, 16384> : &stream_kernel<4, false, 16384>;
@@ -501,6 +511,11 @@ int device_count() {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
+}
+
+int use_device(int device, std::string &err) {
+    if (device >= 0) HIP_TRY(hipSetDevice(device));
+    return TKSPMV_OK;
 }
 
 Engine::~Engine() {
@@ -650,13 +665,31 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
         m.pm = q;  // copy: the engine drops its host copy of the stream after the upload
         m.desc.nnz = q.nnz;
     } else {
-        std::string perr = pack_wbscsr(d.rows, d.cols, d.nnz, d.row, d.col, d.val,
-                                       stream_precision(d.precision), C, n_stream_waves, 4,
-                                       m.pm, kind, fixed_width_of(d));
+        // The packer runs on the device by default (device_pack.hip: same bytes as the host packer, which stays available
+        // with TKSPMV_DEVICE_PACK=0 and serves tkspmv_pack / the .tkspmv files).
+        bool on_device = d.nnz > 0;
+        if (const char *f = getenv("TKSPMV_DEVICE_PACK")) on_device = on_device && atoi(f) != 0;
+        const auto t_pack = std::chrono::steady_clock::now();
+        std::string perr;
+        if (on_device) {
+            DevicePacked dp;
+            perr = pack_wbscsr_device(d.rows, d.cols, d.nnz, d.row, d.col, d.val, stream_precision(d.precision), C,
+                                      n_stream_waves, 4, fixed_width_of(d), dp, kind);
+            if (perr.empty()) {
+                m.pm = std::move(dp.meta);
+                m.d_packets = dp.d_packets;
+                m.d_pkt_row = dp.d_pkt_row;
+                m.packed_on_device = true;
+            }
+        } else {
+            perr = pack_wbscsr(d.rows, d.cols, d.nnz, d.row, d.col, d.val, stream_precision(d.precision), C, n_stream_waves, 4,
+                               m.pm, kind, fixed_width_of(d));
+        }
         if (!perr.empty()) {
             err = perr;
-            return kind == 2 ? TKSPMV_ERR_NOT_SORTED : TKSPMV_ERR_INVALID;
+            return kind == 2 ? TKSPMV_ERR_NOT_SORTED : (perr.find("failed:") != std::string::npos ? TKSPMV_ERR_DEVICE : TKSPMV_ERR_INVALID);
         }
+        m.pack_us = (uint32_t)std::min<long long>(std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_pack).count(), 0xFFFFFFFFll);
     }
     fill_info(m.pm, d.k, &m.info);
 
@@ -700,14 +733,16 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
     HIP_TRY(hipEventCreate(&m.ev2));
 
     const size_t stream_bytes = std::max<size_t>(m.pm.stream_bytes(), 256);
-    HIP_TRY(hipMalloc((void **)&m.d_packets, stream_bytes));
-    HIP_TRY(hipMalloc((void **)&m.d_pkt_row, std::max<size_t>(m.pm.pkt_row.size(), 1) * 4));
+    if (!m.packed_on_device) {  // (the device packer has left the stream and its row table in HBM already)
+        HIP_TRY(hipMalloc((void **)&m.d_packets, stream_bytes));
+        HIP_TRY(hipMalloc((void **)&m.d_pkt_row, std::max<size_t>(m.pm.pkt_row.size(), 1) * 4));
+        if (m.pm.stream_bytes())
+            HIP_TRY(hipMemcpy(m.d_packets, m.pm.packets.data(), m.pm.stream_bytes(), hipMemcpyHostToDevice));
+        if (!m.pm.pkt_row.empty())
+            HIP_TRY(hipMemcpy(m.d_pkt_row, m.pm.pkt_row.data(), m.pm.pkt_row.size() * 4, hipMemcpyHostToDevice));
+    }
     HIP_TRY(hipMalloc((void **)&m.d_part_first, std::max<size_t>(m.pm.part_first.size(), 1) * 4));
     HIP_TRY(hipMalloc((void **)&m.d_part_count, std::max<size_t>(m.pm.part_count.size(), 1) * 4));
-    if (m.pm.stream_bytes())
-        HIP_TRY(hipMemcpy(m.d_packets, m.pm.packets.data(), m.pm.stream_bytes(), hipMemcpyHostToDevice));
-    if (!m.pm.pkt_row.empty())
-        HIP_TRY(hipMemcpy(m.d_pkt_row, m.pm.pkt_row.data(), m.pm.pkt_row.size() * 4, hipMemcpyHostToDevice));
     if (!m.pm.part_first.empty()) {
         HIP_TRY(hipMemcpy(m.d_part_first, m.pm.part_first.data(), m.pm.part_first.size() * 4, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(m.d_part_count, m.pm.part_count.data(), m.pm.part_count.size() * 4, hipMemcpyHostToDevice));
@@ -728,7 +763,14 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
     HIP_TRY(hipMalloc((void **)&m.d_x, (size_t)d.cols * 4));
     if (const char *f = getenv("TKSPMV_HOST_PATH")) m.host_path = atoi(f);
     if (m.host_path) {  // pinned staging copy of x and the host-visible result block (optional: the plain path needs neither)
-        if (hipHostMalloc((void **)&m.h_x, (size_t)d.cols * 4, hipHostMallocDefault) != hipSuccess) m.h_x = nullptr;
+        if (const char *f = getenv("TKSPMV_HOST_X")) m.host_x_direct = std::string(f) == "direct" || std::string(f) == "direct_nc";
+        if (const char *f = getenv("TKSPMV_RUN_EVENTS")) m.run_events = atoi(f) != 0;
+        {
+            const char *f = getenv("TKSPMV_HOST_X");
+            const unsigned flags = (f && std::string(f) == "direct_nc") ? (hipHostMallocMapped | hipHostMallocNonCoherent) : hipHostMallocMapped;
+            if (hipHostMalloc((void **)&m.h_x, (size_t)d.cols * 4, flags) != hipSuccess) m.h_x = nullptr;
+            if (m.h_x && hipHostGetDevicePointer((void **)&m.h_x_dev, m.h_x, 0) != hipSuccess) m.host_x_direct = false;
+        }
         if (hipHostMalloc((void **)&m.h_res, ((size_t)2 * d.k + 16) * 4, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
             hipHostGetDevicePointer((void **)&m.h_res_dev, m.h_res, 0) != hipSuccess) {
             if (m.h_res) (void)hipHostFree(m.h_res);
@@ -885,6 +927,10 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
     }
     HIP_TRY(hipMemset(m.d_out_idx, 0, (size_t)d.k * 4));
     HIP_TRY(hipMemset(m.d_out_val, 0, (size_t)d.k * 4));
+    m.dbg_kernels = m.collect_stats || m.collect_stamps || m.d_trace != nullptr || m.dbg_flags != 0u || m.dbg_repeat != 0u;
+    if (m.dbg_kernels && (d.precision != TKSPMV_F32 || C != 4u || m.xcols > 1024u))
+        fprintf(stderr, "[tkspmv] tracing / statistics hooks exist in the fp32, 4-entries-per-lane, <= 1024-column kernels only: "
+                        "this engine runs without them\n");
 
     if (getenv("TKSPMV_DEBUG_OCC")) {
         int n1 = -1, n2 = -1;
@@ -904,6 +950,8 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
     m.info.num_cus = num_cus;
     m.info.multi_q = m.can_multi ? (uint32_t)m.multi_q : 0u;
     m.info.multi_bytes = m.can_multi ? m.sell_bytes : 0u;
+    m.info.pack_us = m.pack_us;
+    m.info.pack_on_device = m.packed_on_device ? 1u : 0u;
     HIP_TRY(hipDeviceSynchronize());
     return TKSPMV_OK;
 }
@@ -947,8 +995,13 @@ int Engine::set_query(const float *host_x, double *elapsed_ns, std::string &err)
         // (an earlier upload from the staging copy must have been consumed before it is overwritten)
         if (m.x_pending) HIP_TRY(hipStreamSynchronize(m.stream));
         std::memcpy(m.h_x, host_x, (size_t)m.desc.cols * 4);
-        HIP_TRY(hipMemcpyAsync(m.d_x, m.h_x, (size_t)m.desc.cols * 4, hipMemcpyHostToDevice, m.stream));
+        if (!m.host_x_direct) HIP_TRY(hipMemcpyAsync(m.d_x, m.h_x, (size_t)m.desc.cols * 4, hipMemcpyHostToDevice, m.stream));
         m.x_pending = true;
+        m.d_x_cur = m.host_x_direct ? m.h_x_dev : m.d_x;
+        m.have_query = true;
+        if (elapsed_ns)
+            *elapsed_ns = (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::high_resolution_clock::now() - t0).count();
+        return TKSPMV_OK;
     } else {
         HIP_TRY(hipMemcpyAsync(m.d_x, host_x, (size_t)m.desc.cols * 4, hipMemcpyHostToDevice, m.stream));
         HIP_TRY(hipStreamSynchronize(m.stream));
@@ -1173,7 +1226,9 @@ int Engine::run(double *kernel_ns, std::string &err) {
     // The fused single launch can hand its result to the host itself (see h_res); the other launch schemes (radix select,
     // row per lane, unfused selection) complete in stream order and are waited for with the event.
     const bool to_host = m.host_path && m.h_res && m.fused && !m.use_radix && !(m.desc.impl == TKSPMV_IMPL_ROW_PER_LANE && m.can_multi);
-    if (kernel_ns) HIP_TRY(hipEventRecord(m.ev0, m.stream));
+    const bool events = kernel_ns && (m.run_events || !to_host);
+    const auto t_host0 = std::chrono::steady_clock::now();
+    if (events) HIP_TRY(hipEventRecord(m.ev0, m.stream));
     if (to_host) {
         m.drain(m.stream);
         m.launch_stream(m.d_x_cur, m.d_out_idx, m.d_out_val, m.stream, true);
@@ -1181,7 +1236,7 @@ int Engine::run(double *kernel_ns, std::string &err) {
         m.launch_query(m.d_x_cur, m.d_out_idx, m.d_out_val, m.stream);
     }
     HIP_TRY(hipGetLastError());
-    if (kernel_ns) HIP_TRY(hipEventRecord(m.ev1, m.stream));
+    if (events) HIP_TRY(hipEventRecord(m.ev1, m.stream));
     bool seen = false;
     if (to_host) {
         volatile uint32_t *flag = m.h_res + 2 * (size_t)m.desc.k;
@@ -1198,7 +1253,8 @@ int Engine::run(double *kernel_ns, std::string &err) {
     }
     if (!seen) HIP_TRY(hipStreamSynchronize(m.stream));
     m.x_pending = false;  // the kernel has read x: the staging copy is free again
-    if (kernel_ns) {
+    if (kernel_ns && !events) *kernel_ns = (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_host0).count();
+    if (events) {
         if (seen) {  // the kernel is in its last instructions: the end event follows within a microsecond or two
             hipError_t q;
             while ((q = hipEventQuery(m.ev1)) == hipErrorNotReady) __builtin_ia32_pause();

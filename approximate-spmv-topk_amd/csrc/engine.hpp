@@ -57,6 +57,7 @@ class Engine {
 void fill_info(const PackedMatrix &pm, int k, tkspmv_info *out);
 uint64_t algorithmic_bytes(uint64_t nnz, uint32_t rows, uint32_t cols, uint32_t value_bytes, int k);
 int device_count();
+int use_device(int device, std::string &err);  // hipSetDevice(device), or the current device for -1
 // Entries per lane and packet: desc.nnz_per_lane, by default 4. (8, where those kernels exist -- fp32 values, at most
 // 1024 columns -- is opt-in: 3-4 % faster on the BASELINE matrix in short probes, 10-15 % slower in bench.py's
 // conditions (64 query vectors, 4 stream copies), 3x slower at 2-3M rows, where its longer partitions overflow the

@@ -89,8 +89,19 @@ __device__ __forceinline__ uint32_t lds_load(const uint32_t *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-template <int C, int XCOLS, int QM>
-__global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0, const SelectParams SP0, const BatchParams B) {
+// DBG = false (production): the tracing / statistics / ablation hooks of StreamParams (trace, dbg, dbg_flags) are compiled
+// out -- no per-packet compare of a tracing word or an ablation flag, and the scalar registers they held are free. The
+// engine launches the DBG = true instantiation only when TKSPMV_TRACE / TKSPMV_STATS / TKSPMV_DBG_FLAGS ask for it.
+template <int C, int XCOLS, int QM, bool DBG = false>
+__global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg, const SelectParams SP0, const BatchParams B) {
+    StreamParams P0 = P0_arg;
+    if (!DBG) {
+        P0.trace = nullptr;
+        P0.dbg = nullptr;
+        P0.stamps = nullptr;
+        P0.dbg_flags = 0u;
+        P0.dbg_repeat = 0u;
+    }
     constexpr bool Q8 = QM == 1 || QM == 2;  // x staged as Q1.7 integers
     constexpr int VT = value_type_of(QM);
     constexpr int NBUF = C == 8 ? 2 : 3;  // packets of 8 entries per lane are twice as large: one ahead is as many bytes

@@ -244,7 +244,9 @@ __device__ __forceinline__ void select_body(const SelectParams &P, const uint32_
     if (P.host_out) {  // every writer drains its stores, the workgroup meets, one thread raises the flag
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0) __hip_atomic_store(&P.host_out[2u * P.k], P.host_epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        // (relaxed: the result stores above are system-scope write-through stores already drained by their writers; a
+        //  release here would write back the whole L2 first)
+        if (tid == 0) __hip_atomic_store(&P.host_out[2u * P.k], P.host_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     // Reset the exchange state for the next query (this is the last consumer of the query on the stream); last, so
     // that no barrier above has to wait for these stores. Slots: only the ones that held a survivor need a store

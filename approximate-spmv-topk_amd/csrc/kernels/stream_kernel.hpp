@@ -36,8 +36,17 @@ struct StreamLds {
 #ifndef TKSPMV_NBUF
 #define TKSPMV_NBUF 3
 #endif
-template <int C, bool SCORES, int XCOLS, int QM = 0, int NBUF = TKSPMV_NBUF>
-__global__ void __launch_bounds__(576, (C == 8 && !SCORES) ? 6 : 5) stream_kernel(const StreamParams P, const SelectParams SP) {
+// DBG = false (production): tracing / statistics / ablation hooks compiled out (see batch_kernel).
+template <int C, bool SCORES, int XCOLS, int QM = 0, int NBUF = TKSPMV_NBUF, bool DBG = false>
+__global__ void __launch_bounds__(576, (C == 8 && !SCORES) ? 6 : 5) stream_kernel(const StreamParams P_arg, const SelectParams SP) {
+    StreamParams P = P_arg;
+    if (!DBG) {
+        P.trace = nullptr;
+        P.dbg = nullptr;
+        P.stamps = nullptr;
+        P.dbg_flags = 0u;
+        P.dbg_repeat = 0u;
+    }
     constexpr bool Q8 = QM == 1 || QM == 2;  // x staged as Q1.7 integers
     constexpr int VT = value_type_of(QM);
     // Deferred packets live in registers (C row sums + C / 2 flag words each): with 8 entries per lane one packet is held,

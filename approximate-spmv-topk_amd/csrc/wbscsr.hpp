@@ -26,6 +26,14 @@
 #include <string>
 #include <vector>
 
+// The conversions and the slot arithmetic below are shared, source for source, by the host packer (wbscsr.cpp) and the
+// device packer (device_pack.hip): one definition, so the two cannot drift apart.
+#if defined(__HIP__)
+#define TKSPMV_HD __host__ __device__
+#else
+#define TKSPMV_HD
+#endif
+
 namespace tkspmv {
 
 constexpr uint16_t COLW_ROW_END = 0x0001u;
@@ -36,7 +44,7 @@ constexpr uint32_t WAVE = 64;
 
 // Position of stream slot s (0..PE-1, row-major order of the matrix) inside a packet: lane = s / C owns
 // C consecutive slots; they are stored in planes of 4.
-inline uint32_t slot_to_index(uint32_t s, uint32_t C) {
+TKSPMV_HD inline uint32_t slot_to_index(uint32_t s, uint32_t C) {
     uint32_t lane = s / C, j = s % C;
     return (j >> 2) * (WAVE * 4) + lane * 4 + (j & 3);
 }
@@ -45,7 +53,7 @@ inline uint32_t slot_to_index(uint32_t s, uint32_t C) {
 // Q1_7 = truncated (ap_ufixed<8,1,AP_TRN_ZERO>), Q1_7_RND = rounded to nearest (ap_ufixed<8,1,AP_RND>): same bytes per value.
 enum class Precision : int32_t { F32 = 0, Q1_7 = 1, F16 = 3, FIXED = 4, Q1_7_RND = 5 };
 
-inline uint32_t value_bytes(Precision p) {
+TKSPMV_HD inline uint32_t value_bytes(Precision p) {
     return (p == Precision::F32 || p == Precision::FIXED) ? 4u : (p == Precision::F16 ? 2u : 1u);
 }
 // Value type of the stream for a tkspmv_precision (TKSPMV_Q1_7 and TKSPMV_Q1_7_WIDE share the truncated Q1.7 stream;
@@ -62,9 +70,9 @@ inline Precision stream_precision(int32_t api_precision) {
 
 // IEEE binary16 <-> binary32, round to nearest even, overflow to infinity (the CUDA comparator's half mode converts
 // its values the same way: host_spmv_topk_csr_gpu.cu:132-136,152-160 with __float2half).
-inline uint16_t to_half(float f) {
+TKSPMV_HD inline uint16_t to_half(float f) {
     uint32_t x;
-    std::memcpy(&x, &f, 4);
+    __builtin_memcpy(&x, &f, 4);
     const uint16_t sign = (uint16_t)((x >> 16) & 0x8000u);
     x &= 0x7FFFFFFFu;
     if (x >= 0x7F800000u) return (uint16_t)(sign | (x > 0x7F800000u ? 0x7E00u : 0x7C00u));  // NaN / infinity
@@ -108,7 +116,7 @@ inline float from_half(uint16_t hbits) {
 
 // Unsigned fixed point with 1 integer and 7 fraction bits, truncation toward zero and saturation at the
 // top of the range when converting from float (restating ap_ufixed<8,1,AP_TRN_ZERO>, fpga_types.hpp:20).
-inline uint8_t to_q1_7(float v) {
+TKSPMV_HD inline uint8_t to_q1_7(float v) {
     if (!(v > 0.0f)) return 0;
     float s = v * 128.0f;
     if (s >= 255.0f) return 255;
@@ -118,7 +126,7 @@ inline float from_q1_7(uint32_t q) { return (float)q * (1.0f / 128.0f); }
 // The same format rounded to nearest, ties up, saturating (ap_ufixed<8,1,AP_RND,AP_SAT>): the value stream of
 // TKSPMV_Q1_7_F32, whose arithmetic is fp32 -- there the quantisation of the values is the only error, and rounding
 // halves it (precision@100 against the fp32 gold on BASELINE configs[4]: 0.97 rounded, 0.94 truncated).
-inline uint8_t to_q1_7_rnd(float v) {
+TKSPMV_HD inline uint8_t to_q1_7_rnd(float v) {
     if (!(v > 0.0f)) return 0;
     const float s = v * 128.0f + 0.5f;  // exact for |v| < 2^16 (one binade of slack below 2^24)
     if (s >= 255.0f) return 255;
@@ -130,8 +138,8 @@ inline uint8_t to_q1_7_rnd(float v) {
 // u32: bit 31 is the integer bit, the W-1 fraction bits follow, the low 32-W bits are zero (so every width shares one
 // Q1.31 arithmetic: products are masked back to W bits, sums wrap at 2.0 by the u32 wrap). Truncation toward zero;
 // conversion from float saturates at the top of the range (the HLS type would wrap; inputs are expected in [0, 2)).
-inline uint32_t fixed_mask(uint32_t W) { return ~((1u << (32u - W)) - 1u); }  // the top W bits
-inline uint32_t to_fixed(float v, uint32_t W) {
+TKSPMV_HD inline uint32_t fixed_mask(uint32_t W) { return ~((1u << (32u - W)) - 1u); }  // the top W bits
+TKSPMV_HD inline uint32_t to_fixed(float v, uint32_t W) {
     if (!(v > 0.0f)) return 0u;                       // negative, zero, NaN
     const float s = v * (float)(1u << (W - 1u));      // exact (power of two)
     const float top = W == 32u ? 4294967296.0f : (float)(1u << W);

@@ -149,7 +149,10 @@ def sell_roundtrip(m, n_wave_partitions=4088):
 class Packed:
     """Host-side packed (wave-BSCSR) matrix, for layout tests: decode(pack(A)) == A."""
 
-    def __init__(self, m, k=100, nnz_per_lane=0, n_wave_partitions=4096, precision=_lib.F32, fixed_width=0):
+    def __init__(self, m, k=100, nnz_per_lane=0, n_wave_partitions=4096, precision=_lib.F32, fixed_width=0, on_device=False,
+                 device=-1):
+        """on_device=True: packed by the HIP kernels of csrc/device_pack.hip (needs a GPU) instead of the host packer; the
+        result is copied back, so decode() / raw() / save() work alike. self.pack_ms = (upload, kernels) then."""
         self._h = C.c_void_p()
         self._row = np.ascontiguousarray(m.row, dtype=np.uint32)
         self._col = np.ascontiguousarray(m.col, dtype=np.uint32)
@@ -160,7 +163,14 @@ class Packed:
         d.col = self._col.ctypes.data_as(C.POINTER(C.c_uint32))
         d.val = self._val.ctypes.data_as(C.POINTER(C.c_float))
         d.k, d.precision, d.nnz_per_lane, d.fixed_width = k, precision, nnz_per_lane, fixed_width
-        _lib.check(_lib.lib().tkspmv_pack(C.byref(d), n_wave_partitions, C.byref(self._h)))
+        d.device = device
+        self.pack_ms = None
+        if on_device:
+            ms = (C.c_double * 2)()
+            _lib.check(_lib.lib().tkspmv_pack_device(C.byref(d), n_wave_partitions, C.byref(self._h), ms))
+            self.pack_ms = (ms[0], ms[1])
+        else:
+            _lib.check(_lib.lib().tkspmv_pack(C.byref(d), n_wave_partitions, C.byref(self._h)))
         self.nnz = int(d.nnz)
 
     @classmethod

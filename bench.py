@@ -3,25 +3,34 @@
 
   python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
 
-A "step" is one query: one pass of the Top-K SpMV hot path over the whole matrix for a fresh dense vector x. The
-queries are issued back to back on one stream (tkspmv_enqueue_many: the engine launches its batch kernel once per 32
-queries; every query still streams the whole matrix and is selected exactly).
-Workload at N=1 = BASELINE.json configs[1]: 1M x 1024, 20 nnz/row (gamma), K=100, fp32, synthetic (own seeded
-generator restating create_matrices.py's distributions). All inputs (packed matrix, 64 query vectors) are
-resident in HBM before the timed region; results stay in HBM.
+A "step" is one query: one pass of the Top-K SpMV hot path over the whole matrix for a fresh dense vector x, its exact
+top-K selected on the device. Queries are issued back to back on one stream (the engine launches its batch kernel once per
+32 queries; every query still streams the whole matrix). All inputs are resident in HBM before the timed region; results
+stay in HBM. The timed region is bracketed by a barrier + device synchronisation on both sides AND by a hipEvent pair on the
+engine's stream (`roofline` uses the events, `value` the host clock).
 
-`value` is measured in CACHE-DEFEATED mode: the engine keeps 4 copies of the 118 MB packet stream and rotates
-them per query, so no query can be served from the 256 MiB Infinity Cache and the roofline fraction is an honest
-HBM fraction. The steady-state number for ONE matrix (which fits the Infinity Cache) is reported as `cache_warm`.
+N = 1 (default): BASELINE.json configs[1] -- 1M x 1024, gamma 20 nnz/row, K = 100, fp32, synthetic (own seeded generator
+restating create_matrices.py's distributions). `value` is measured CACHE-DEFEATED: the engine keeps 4 copies of the 118 MB
+packet stream and rotates them per query, so no query is served from the 256 MiB Infinity Cache and the roofline fraction
+is an honest HBM fraction. Beside the headline the line carries: `parity_checked` (the last timed query against the CPU
+oracle), `timing` (median / p95 over >= 30 repetitions, first 2 dropped: the reference's hygiene,
+host_spmv_bscsr.cpp:699), `single_query` (the literal reference loop: one reset -> operator() -> read_result at a time),
+`configs` (BASELINE configs[2] and configs[4]), `cache_warm`, `multi_query`, `cpu_baseline` (fp64 and fp32).
 
-N > 1 (weak scaling): every rank owns a 1M-row shard of an (N x 1M)-row matrix; per step each rank runs its local
-engine, then ONE RCCL all-gather of K (row, score) pairs per rank and the merge (32 steps per exchange, pipelined). `value` = N * steps / time
-(1M-row-shard queries per second, whole job); `global_queries_per_sec` = steps / time.
+N > 1, or --total-rows R at any N: BASELINE.json configs[3] -- ONE R-row matrix (default 10M x 1024, gamma 20 nnz/row,
+seed 4) cut into N contiguous row shards balanced by nnz; every rank builds only its own shard (same generator seed
+everywhere), runs its engine with global row ids, and per query the ranks exchange K (row, score) pairs with ONE RCCL
+all-gather (32 queries per exchange, on a side stream) followed by a merge kernel. STRONG scaling: `value` = global queries
+per second = steps / max-over-ranks time. The exchange must be the native one (csrc/dist.hip); without it the run fails
+loudly unless TKSPMV_DIST=torch asks for the torch.distributed exchange.
 """
 import argparse
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -40,47 +49,68 @@ def parse():
     ap.add_argument("--cols", type=int, default=1024)
     ap.add_argument("--nnz", type=int, default=20)
     ap.add_argument("--k", type=int, default=100)
+    ap.add_argument("--total-rows", type=int, default=0,
+                    help="row-sharded workload (BASELINE configs[3]): rows of the ONE matrix cut across the ranks; "
+                         "default 10000000 when --gpus > 1, off (configs[1]) at --gpus 1")
     ap.add_argument("--replicas", type=int, default=4, help="packet-stream copies rotated per query (cache defeat)")
+    ap.add_argument("--reps", type=int, default=32, help="repetitions of the timed batch for median / p95 (first 2 dropped)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--queries", type=int, default=64, help="distinct query vectors resident in HBM")
     ap.add_argument("--nnz-per-lane", type=int, default=0, help="entries per lane and packet (0 = the engine's default)")
     ap.add_argument("--waves-per-cu", type=int, default=0, help="streaming waves per CU (0 = the engine's default)")
     ap.add_argument("--threads-per-wg", type=int, default=0, help="streaming threads per workgroup (0 = the engine's default)")
-    ap.add_argument("--skip-warm", action="store_true", help="skip the cache-warm leg (homogeneous launches for rocprofv3)")
+    ap.add_argument("--skip-warm", action="store_true",
+                    help="profiler runs: nothing but the headline queries (no side legs, homogeneous launches for rocprofv3)")
     ap.add_argument("--multi-q", type=int, nargs="*", default=[4, 8],
                     help="queries per matrix pass of the multi-query leg (reported beside the headline; empty = skip)")
     ap.add_argument("--multi-only", type=int, default=0,
                     help="profiler runs: launch nothing but the multi-query path with this many queries per pass")
+    ap.add_argument("--traffic", choices=["auto", "live", "static", "off"], default="auto",
+                    help="roofline.traffic: a live rocprofv3 --pmc pass over a child run (auto: when rocprofv3 is on PATH), "
+                         "or the figure committed under profiles/ (labelled static)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # the child of the live traffic pass
     return ap.parse_args()
 
 
+def pct(v, p):
+    import numpy as np
+    return float(np.percentile(np.asarray(v, dtype=np.float64), p))
+
+
+# ---- CPU baseline --------------------------------------------------------------------------------------
 def cpu_baseline(mod, m, xs, k, seconds):
-    """The reference's CPU path restated (oracle/oracle.c: sparse_dot_topn's threaded kernel for an N x 1
-    right-hand side, fp64, n_jobs = all host threads) + the global top-k a user does next. Bounded sample."""
+    """The reference's CPU path restated (oracle/oracle.c: sparse_dot_topn's threaded kernel for an N x 1 right-hand side,
+    test_cpu.py:99-105) + the global top-k a user does next, timed natively on the host cores: fp64 (what the reference
+    runs) and fp32 variants, SpMV-only and SpMV + top-k, median of >= 10 runs after 2 warm-ups. Bounded sample."""
     import numpy as np
     import oracle_lib as O
-    cores = os.cpu_count() or 1
+    hw = os.cpu_count() or 1
     ptr, idx, v = O.coo_to_csr_f64(m.row, m.col, m.val, m.rows)
-    n = 0
-    t_spmv = 0.0
-    t0 = time.perf_counter()
-    while True:
-        x = xs[n % xs.shape[0]].astype(np.float64)
-        a = time.perf_counter()
-        scores, kept = O.cpu_topn(ptr, idx, v, m.rows, x, 0.0, cores)
-        b = time.perf_counter()
-        O.cpu_global_topk(scores, kept, k)
-        t_spmv += b - a
-        n += 1
-        if time.perf_counter() - t0 >= seconds and n >= 3:
-            break
-    total = time.perf_counter() - t0
-    out = {"value": n / total, "unit": "queries/s", "cores": cores, "kind": "port",
-           "sample": f"{n} queries on the same {m.rows}x{m.cols} matrix ({m.nnz} nnz): fp64 CSR row-block-threaded "
-                     f"SpMV (sparse_dot_topn restated) + global top-{k}; {total:.1f} s of wall time",
-           "spmv_only_ms": 1e3 * t_spmv / n, "ms_per_query": 1e3 * total / n}
-    # the reference's own gold (single thread), when oracle/_ref was built in the build container
-    if O.have_ref():
+    t_start = time.perf_counter()
+    # thread count: the reference used n_jobs = 40 on 80 hardware threads; here the fastest of a few candidates
+    cands = sorted({t for t in (8, 16, 32, 64, 128, hw) if t <= hw}) or [1]
+    best_t, best = cands[0], float("inf")
+    for t in cands:
+        _, tot = O.cpu_bench(ptr, idx, v, m.rows, xs, k, t, 1, 3)
+        if float(np.median(tot)) < best:
+            best_t, best = t, float(np.median(tot))
+    out = {"unit": "queries/s", "cores": best_t, "host_threads": hw, "kind": "port"}
+    budget = max(seconds - (time.perf_counter() - t_start), 2.0)
+    n_total = 0
+    for name, f32 in (("fp64", False), ("fp32", True)):
+        reps = int(min(max(10, (budget / 2) / max(best * 1e-3, 1e-4)), 400))
+        sp, tot = O.cpu_bench(ptr, idx, v, m.rows, xs, k, best_t, 2, reps, use_f32=f32)
+        n_total += reps + 2
+        out[name] = {"runs": reps, "spmv_only_ms_median": float(np.median(sp)), "spmv_topk_ms_median": float(np.median(tot)),
+                     "spmv_topk_ms_p95": pct(tot, 95), "queries_per_sec": 1e3 / float(np.median(tot))}
+    out["value"] = out["fp64"]["queries_per_sec"]
+    out["ms_per_query"] = out["fp64"]["spmv_topk_ms_median"]
+    out["spmv_only_ms"] = out["fp64"]["spmv_only_ms_median"]
+    out["sample"] = (f"{n_total} queries on the same {m.rows}x{m.cols} matrix ({m.nnz} nnz), {best_t} threads (fastest of "
+                     f"{cands}): CSR row-block-threaded SpMV (sparse_dot_topn restated, threads created per query as the "
+                     f"package does) + global top-{k}; fp64 = the reference's precision (value), fp32 beside it; medians; "
+                     f"{time.perf_counter() - t_start:.1f} s of wall time")
+    if O.have_ref():  # the reference's own gold (single thread), when oracle/_ref was built in the build container
         reps, t1 = 0, time.perf_counter()
         while reps < 3:
             O.ref_gold_topk(m.row, m.col, m.val, xs[reps % xs.shape[0]], k)
@@ -90,6 +120,105 @@ def cpu_baseline(mod, m, xs, k, seconds):
     return out
 
 
+# ---- parity of a result against the oracle ----------------------------------------------------------------------------
+def check_parity(mod, m, x, k, idx, val, eng=None, bit_exact=True):
+    """The north-star bar for one query: same index set as the CPU gold (only k-th-boundary near-ties, <= 2e-6 relative in
+    fp64, may differ -- counted), scores within 1e-4 relative; and, with the engine at hand, bit for bit against the
+    order-matched oracle on the engine's own packing."""
+    import numpy as np
+    import oracle_lib as O
+    out = {"tolerance": "same index set as the gold (k-th-boundary near-ties <= 2e-6 rel. counted), scores within 1e-4 rel."}
+    gi, gv = O.gold_topk(m.row, m.col, m.val, x, k)
+    swaps, ok = 0, True
+    if set(idx.tolist()) != set(gi.tolist()):
+        y64, _ = O.scores_f64(m.row, m.col, m.val, x, m.rows)
+        kth = np.sort(y64)[-k]
+        diff = set(idx.tolist()) ^ set(gi.tolist())
+        ok = all(abs(y64[r] - kth) <= 2e-6 * kth for r in diff)
+        swaps = len(diff) // 2
+    ok = ok and bool(np.allclose(np.sort(val)[::-1], np.sort(gv)[::-1], rtol=1e-4, atol=0)) and bool(np.all(val[:-1] >= val[1:]))
+    out.update(vs_gold=ok, boundary_tie_swaps=swaps)
+    if eng is not None and bit_exact:
+        info = eng.info()
+        C = info["packet_entries"] // 64
+        packed = mod.Packed(m, k=k, nnz_per_lane=C, n_wave_partitions=info["grid"] * info["block"] // 64)
+        yp, present = O.packed_scores(packed.raw(), x, m.rows, C)
+        ei, ev = O.select_topk(yp, present, k, 0.0, info.get("first_row", 0))
+        out["bit_exact_vs_order_matched_oracle"] = bool(np.array_equal(idx, ei) and np.array_equal(val.view(np.uint32), ev.view(np.uint32)))
+        ok = ok and out["bit_exact_vs_order_matched_oracle"]
+    return ok, out
+
+
+# ---- live HBM traffic (rocprofv3 --pmc over a child run) --------------------------------------------------------------------
+def pmc_child(a):
+    """What the counter passes profile: the headline engine and nothing but `steps` headline queries."""
+    import numpy as np
+    import torch
+    import _pkg
+    mod = _pkg.load()
+    m = mod.generate_matrix(a.rows, a.cols, a.nnz, "gamma", 2)
+    xs = np.stack([mod.create_sample_vector(a.cols, True, False, True, 1000 + i) for i in range(a.queries)])
+    dxs = torch.from_numpy(xs).cuda()
+    eng = mod.SpMV(m.row, m.col, m.val, m.rows, m.cols, k=a.k, device=0, stream_replicas=a.replicas,
+                   nnz_per_lane=a.nnz_per_lane, waves_per_cu=a.waves_per_cu, threads_per_wg=a.threads_per_wg)
+    eng.time_queries(dxs.data_ptr(), a.queries, a.steps)
+    eng.close()
+
+
+def live_traffic(a, n_queries=128):
+    """HBM bytes per query of the headline kernel from two rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE do not fit one
+    pass; no trace domain beside --kernel-trace), each over a child run of `n_queries` headline queries. MI355X_MICROARCH.md:
+    FETCH_SIZE is tallied in KiB at 64 B per 128-B request on gfx950 (doubled here); WRITE_SIZE reads bytes exactly.
+    Returns (bytes_per_query, detail) or (None, reason)."""
+    import csv
+    import glob
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None, "rocprofv3 not on PATH"
+    got = {}
+    tmp = tempfile.mkdtemp(prefix="tkspmv_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "--", sys.executable,
+                   os.path.join(ROOT, "bench.py"), "--pmc-child", "--steps", str(n_queries), "--rows", str(a.rows), "--cols",
+                   str(a.cols), "--nnz", str(a.nnz), "--k", str(a.k), "--replicas", str(a.replicas), "--queries", str(a.queries),
+                   "--nnz-per-lane", str(a.nnz_per_lane), "--waves-per-cu", str(a.waves_per_cu), "--threads-per-wg",
+                   str(a.threads_per_wg)]
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=240)
+            if r.returncode != 0:
+                return None, f"rocprofv3 --pmc {counter} failed (rc {r.returncode}): {(r.stderr or r.stdout)[-200:]}"
+            total, launches = 0.0, set()
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if "batch_kernel" in row.get("Kernel_Name", "") and row.get("Counter_Name") == counter:
+                        total += float(row["Counter_Value"])
+                        launches.add(row["Dispatch_Id"])
+            if not launches:
+                return None, f"no batch_kernel rows in the {counter} pass"
+            got[counter] = total / n_queries
+        fetch = got["FETCH_SIZE"] * 1024.0 * 2.0
+        write = got["WRITE_SIZE"] * 1024.0
+        return fetch + write, {"fetch_bytes_corrected": fetch, "write_bytes": write, "queries_profiled": n_queries,
+                               "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes over a child run of "
+                                         "this workload; FETCH_SIZE x 1024 x 2 (gfx950 correction) + WRITE_SIZE x 1024, summed "
+                                         "over the batch-kernel launches and divided by the queries they served"}
+    except Exception as e:  # noqa: BLE001 -- a failed counter pass must never cost the bench line
+        return None, f"{type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def static_traffic():
+    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(p) as f:
+            return json.load(f).get("stream_kernel_hbm_bytes_per_launch")
+    except Exception:  # noqa: BLE001
+        return None
+
+
+# ---- side legs (N = 1) -------------------------------------------------------------------------------------------------------
 def multi_query_leg(mod, m, dxs, a, device, alg_bytes):
     """Extension, reported beside the headline: several queries share each pass over the matrix
     (tkspmv_enqueue_multi: the wave-sliced ELL copy, one row per lane). Same synthetic matrix and query vectors, cache-
@@ -118,8 +247,307 @@ def multi_query_leg(mod, m, dxs, a, device, alg_bytes):
             "runs": out}
 
 
+def single_query_leg(mod, m, xs, dxs, a, device, eng, alg_bytes):
+    """The literal loop of the reference's hosts (host_spmv_bscsr.cpp:602-632): ONE query in flight -- reset(vec),
+    operator()(), read_result() -- through tkspmv_set_query / tkspmv_run / tkspmv_read on host buffers. kernel_us = the
+    hipEvent bracket tkspmv_run returns (the reference's hw_exec_time: device time of one fused launch, rotating stream
+    copies), end_to_end_us = host clock around the three calls (hw_full_exec_time + reset). >= 30 runs, first 2 dropped."""
+    import numpy as np
+    n = max(a.reps, 30) + 2
+    kern, e2e = [], []
+    for i in range(n):
+        x = xs[i % xs.shape[0]]
+        t0 = time.perf_counter()
+        eng.reset(x)
+        ns = eng()
+        val, idx = eng.read_result()
+        e2e.append((time.perf_counter() - t0) * 1e6)
+        kern.append(ns / 1e3)
+    ok, par = check_parity(mod, m, xs[(n - 1) % xs.shape[0]], a.k, idx, val, eng)
+    kern, e2e = kern[2:], e2e[2:]
+    med = float(np.median(kern))
+    return {"kernel": "tkspmv::stream_kernel<4,false,1024,0,3> (one fused launch per query: stream, flush, in-launch selection)",
+            "runs": len(kern), "dropped": 2, "kernel_us": med, "kernel_us_p95": pct(kern, 95), "frac": alg_bytes / (med * 1e3) / HBM_PEAK_GBS,
+            "end_to_end_us": float(np.median(e2e)), "end_to_end_us_p95": pct(e2e, 95), "parity_checked": ok,
+            "note": "kernel_us includes the hipEvent bracket (~6 us around an empty kernel of the same geometry); rocprofv3 "
+                    "--kernel-trace durations of the same launches are committed under profiles/"}
+
+
+def config_legs(mod, a, device):
+    """BASELINE.json configs[2] and configs[4] at their own sizes, each with its roofline fraction (and, for the reduced
+    precision, the reference's acceptance metric: precision@K against the fp32 gold)."""
+    import numpy as np
+    import torch
+    import oracle_lib as O
+    out = []
+    # configs[2]: 1M x 1024, 20 nnz/row, K = 8, 32 row partitions (SPMV_PARTITIONS = 32, K lists of 8: host_spmv_bscsr.cpp:133-141)
+    m = mod.generate_matrix(1000000, 1024, 20, "gamma", 2)
+    xs = np.stack([mod.create_sample_vector(1024, True, False, True, 1000 + i) for i in range(16)])
+    dxs = torch.from_numpy(xs).to(torch.device("cuda", device))
+    eng = mod.SpMV(m.row, m.col, m.val, m.rows, m.cols, k=8, device=device, partitions=32, k_per_partition=8,
+                   stream_replicas=a.replicas)
+    info = eng.info()
+    eng.time_queries(dxs.data_ptr(), 16, 64)
+    ns = min(eng.time_queries(dxs.data_ptr(), 16, 512) for _ in range(3))
+    val, idx = eng.read_result()
+    ok, _ = check_parity(mod, m, xs[511 % 16], 8, idx, val, eng)
+    out.append({"workload": "configs[2]: 1000000x1024 gamma nnz/row=20, K=8, 32 row partitions x K=8 lists (exact: k <= K per partition)",
+                "kernel_us": ns / 1e3, "algorithmic_bytes": int(info["algorithmic_bytes"]),
+                "roofline": {"bound": "hbm", "achieved": info["algorithmic_bytes"] / ns, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": info["algorithmic_bytes"] / ns / HBM_PEAK_GBS},
+                "parity_checked": ok})
+    eng.close()
+    del eng, m
+    # configs[4]: 1M x 512, 40 nnz/row, K = 100, int8 values: Q1.7 bytes (rounded), fp32 x, fp32 accumulate
+    m = mod.generate_matrix(1000000, 512, 40, "gamma", 5)
+    xs = np.stack([mod.create_sample_vector(512, True, False, True, 1000 + i) for i in range(16)])
+    dxs = torch.from_numpy(xs).to(torch.device("cuda", device))
+    eng = mod.SpMV(m.row, m.col, m.val, m.rows, m.cols, k=a.k, device=device, precision=mod.Q1_7_F32, multi_q=1,
+                   stream_replicas=a.replicas)
+    info = eng.info()
+    eng.time_multi(dxs.data_ptr(), 16, 64)
+    ns = min(eng.time_multi(dxs.data_ptr(), 16, 512) for _ in range(3))
+    out_i = torch.zeros(4, a.k, dtype=torch.int32, device=dxs.device)
+    out_v = torch.zeros(4, a.k, dtype=torch.float32, device=dxs.device)
+    torch.cuda.synchronize()
+    eng.enqueue_multi(dxs.data_ptr(), 4, out_i.data_ptr(), out_v.data_ptr())
+    eng.synchronize()
+    vq = O.round_to_q17(m.val)
+    prec, exact = [], True
+    for q in range(4):
+        gi, _ = O.gold_topk(m.row, m.col, m.val, xs[q], a.k)
+        idx = out_i[q].cpu().numpy().view(np.uint32)
+        prec.append(len(set(idx.tolist()) & set(gi.tolist())) / a.k)
+        y, present = O.scores_f32_segmented(m.row, m.col, vq, xs[q], m.rows)
+        ei, ev = O.select_topk(y, present, a.k)
+        exact = exact and bool(np.array_equal(idx, ei) and np.array_equal(out_v[q].cpu().numpy().view(np.uint32), ev.view(np.uint32)))
+    out.append({"workload": f"configs[4]: 1000000x512 gamma nnz/row=40 (nnz={info['nnz']}), K={a.k}, Q1.7 byte values (rounded to "
+                            "nearest), fp32 x, fp32 accumulate; one query per pass over the row-per-lane byte stream, cache-defeated",
+                "dtype": "u8 values / f32 arithmetic", "kernel": "tkspmv::multi_kernel<1,1>",
+                "kernel_us": ns / 1e3, "algorithmic_bytes": int(info["algorithmic_bytes"]), "stream_bytes": int(info["multi_bytes"]),
+                "roofline": {"bound": "hbm", "achieved": info["algorithmic_bytes"] / ns, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": info["algorithmic_bytes"] / ns / HBM_PEAK_GBS},
+                "precision_at_100": float(np.mean(prec)), "precision_at_100_min": float(min(prec)),
+                "parity_checked": exact,
+                "parity_note": "bit-exact against the order-matched oracle on the de-quantised values (parity unpinned against "
+                               "the reference: ap_fixed needs Xilinx headers); precision is against the fp32 gold"})
+    eng.close()
+    return out
+
+
+# ---- N = 1: BASELINE configs[1] ---------------------------------------------------------------------------------------------
+def bench_single(a, mod, torch, np, dev, local_rank):
+    m = mod.generate_matrix(a.rows, a.cols, a.nnz, "gamma", 2)
+    xs = np.stack([mod.create_sample_vector(a.cols, True, False, True, 1000 + i) for i in range(a.queries)])
+    dxs = torch.from_numpy(xs).to(dev)
+    if a.multi_only:
+        # profiler aid: nothing but multi-query passes (warmup + steps queries), then one JSON line about them
+        eng = mod.SpMV(m.row, m.col, m.val, m.rows, m.cols, k=a.k, device=local_rank, stream_replicas=a.replicas,
+                       multi_q=a.multi_only)
+        eng.time_multi(dxs.data_ptr(), a.queries, a.warmup)
+        ns = eng.time_multi(dxs.data_ptr(), a.queries, a.steps)
+        print(json.dumps({"metric": "queries_per_sec", "mode": "multi_only", "queries_per_pass": a.multi_only,
+                          "value": 1e9 / ns, "us_per_query": ns / 1e3, "us_per_pass": ns * a.multi_only / 1e3,
+                          "steps": a.steps, "warmup": a.warmup}))
+        eng.close()
+        return
+    eng = mod.SpMV(m.row, m.col, m.val, m.rows, m.cols, k=a.k, device=local_rank, stream_replicas=a.replicas,
+                   nnz_per_lane=a.nnz_per_lane, waves_per_cu=a.waves_per_cu, threads_per_wg=a.threads_per_wg)
+    info = eng.info()
+    alg_bytes = info["algorithmic_bytes"]
+    # ---- warm-up, then EXACTLY `steps` queries between two device synchronisations (+ a hipEvent pair on the engine stream)
+    if a.warmup > 0:
+        eng.enqueue_many(dxs.data_ptr(), a.queries, a.warmup)
+    eng.synchronize()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    kernel_ns = eng.time_queries(dxs.data_ptr(), a.queries, a.steps)  # enqueue + event pair + wait for the end event
+    eng.synchronize()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    # ---- parity of the last timed query against the oracle
+    val, idx = eng.read_result()
+    parity_ok, parity = check_parity(mod, m, xs[(a.steps - 1) % a.queries], a.k, idx, val, eng)
+    # ---- repetitions (reference hygiene: >= 30 runs, first 2 dropped, host_spmv_bscsr.cpp:699)
+    n_rep = min(max(a.steps, 32), 512)
+    reps = [eng.time_queries(dxs.data_ptr(), a.queries, n_rep) / 1e3 for _ in range(max(a.reps, 30) + 2)][2:]
+    timing = {"repetitions": len(reps), "dropped": 2, "queries_per_repetition": n_rep,
+              "kernel_us_median": pct(reps, 50), "kernel_us_p95": pct(reps, 95), "kernel_us_mean": float(np.mean(reps)),
+              "frac_at_median": alg_bytes / (pct(reps, 50) * 1e3) / HBM_PEAK_GBS}
+    extra = {"parity_checked": parity_ok, "parity": parity, "timing": timing}
+    if not a.skip_warm:
+        extra["single_query"] = single_query_leg(mod, m, xs, dxs, a, local_rank, eng, alg_bytes)
+        prof = eng.profile(dxs.data_ptr(), a.queries, 100)
+        extra["kernels_us"] = {"query_back_to_back": prof["query_ns"] / 1e3,
+                               "single_query_fused_launch_with_event_bracket": prof["stream_kernel_ns"] / 1e3,
+                               "event_bracket_around_an_empty_kernel": prof["event_bracket_ns"] / 1e3,
+                               "spmv_only_variant": prof["scores_kernel_ns"] / 1e3}
+        # same matrix every query (fits the Infinity Cache): the steady state of a deployed single-matrix service
+        warm = mod.SpMV(m.row, m.col, m.val, m.rows, m.cols, k=a.k, device=local_rank)
+        warm.enqueue_many(dxs.data_ptr(), a.queries, max(a.warmup, 32))
+        warm.synchronize()
+        t1 = time.perf_counter()
+        warm_ns = warm.time_queries(dxs.data_ptr(), a.queries, max(a.steps, 64))
+        warm_elapsed = time.perf_counter() - t1
+        warm.close()
+        extra["cache_warm"] = {"value": max(a.steps, 64) / warm_elapsed, "unit": "queries/s", "kernel_us": warm_ns / 1e3,
+                               "achieved_GBps": alg_bytes / warm_ns,
+                               "note": "one matrix (118 MB packed) re-read every query: served largely by the 256 MiB "
+                                       "Infinity Cache, not comparable with the HBM roofline"}
+        if a.multi_q:
+            extra["multi_query"] = multi_query_leg(mod, m, dxs, a, local_rank, alg_bytes)
+    eng.close()
+    if not a.skip_warm:
+        extra["configs"] = config_legs(mod, a, local_rank)
+    # ---- HBM traffic of the headline kernel
+    traffic, source, detail = None, "off", None
+    if a.traffic in ("auto", "live") and not a.skip_warm:
+        traffic, detail = live_traffic(a)
+        source = "live" if traffic is not None else "static"
+        if traffic is None:
+            detail = {"live_pass": detail}
+    if traffic is None and a.traffic != "off":
+        traffic, source = static_traffic(), "static"
+    line = {
+        "metric": "queries_per_sec", "value": a.steps / elapsed, "unit": "queries/s", "n_gpus": 1,
+        "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{a.rows}x{a.cols} gamma nnz/row={a.nnz} (nnz={info['nnz']}) K={a.k} fp32, "
+                               f"queries back to back on one stream, cache-defeated ({a.replicas} rotating stream copies)",
+                   "rows": a.rows, "cols": a.cols, "nnz": int(info["nnz"]), "k": a.k, "parallelism": "single GPU",
+                   "launch": {"grid": info["grid"], "block": info["block"] + 64,
+                              "wave_partitions": info["n_wave_partitions"], "packet_entries": info["packet_entries"]}},
+        "roofline": {"bound": "hbm", "achieved": alg_bytes / kernel_ns, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": alg_bytes / kernel_ns / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": source,
+                     "traffic_detail": detail,
+                     "kernel": "tkspmv::batch_kernel<4,1024,0> (up to 32 queries per launch; figures are per query)",
+                     "algorithmic_bytes": int(alg_bytes), "kernel_us": kernel_ns / 1e3,
+                     "method": "one hipEvent pair on the engine stream around the timed region's back-to-back launches, "
+                               "duration = event time / steps. A launch of the batch kernel streams the matrix once per "
+                               "query for up to 32 queries (one continuous prefetch pipeline per wave) and selects each "
+                               "query's top-k in its selector workgroup; rocprofv3's average launch duration / queries per "
+                               "launch agrees (profiles/README.md). `timing` repeats the measurement (median, p95)."},
+    }
+    line.update(extra)
+    if a.cpu_seconds > 0:
+        line["cpu_baseline"] = cpu_baseline(mod, m, xs, a.k, a.cpu_seconds)
+    print(json.dumps(line))
+
+
+# ---- row-sharded: BASELINE configs[3] ---------------------------------------------------------------------------------------
+def bench_sharded(a, mod, torch, np, dev, local_rank, rank, world):
+    from importlib import import_module
+    dist = import_module("torch.distributed")
+    dmod = import_module("approximate_spmv_topk_amd.distributed")
+    total_rows = a.total_rows or 10000000
+    seed = 4  # SURVEY 8(d), cfg 4
+    shard, (r0, r1), total_nnz = dmod.generate_shard(total_rows, a.cols, a.nnz, "gamma", seed, rank, world)
+    xs = np.stack([mod.create_sample_vector(a.cols, True, False, True, 1000 + i) for i in range(a.queries)])
+    dxs = torch.from_numpy(xs).to(dev)
+    eng = mod.SpMV(shard.row, shard.col, shard.val, shard.rows, shard.cols, k=a.k, device=local_rank, first_row=r0,
+                   stream_replicas=a.replicas, nnz_per_lane=a.nnz_per_lane, waves_per_cu=a.waves_per_cu,
+                   threads_per_wg=a.threads_per_wg)
+    info = eng.info()
+    multi = dist.is_initialized()
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if multi:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    use_torch = os.environ.get("TKSPMV_DIST", "native") == "torch"
+    native = None
+    if not use_torch:
+        # The native exchange (RCCL all-gather + merge kernel, csrc/dist.hip) or nothing: a scaling run must not quietly
+        # measure a different exchange. TKSPMV_DIST=torch asks for the torch.distributed exchange explicitly.
+        try:
+            native = dmod.NativeShardedSpMV(eng, dev)
+        except Exception as e:  # noqa: BLE001
+            print(f"[rank {rank}] the native RCCL exchange is unavailable: {e}\n"
+                  f"          (set TKSPMV_DIST=torch to measure the torch.distributed exchange instead)", file=sys.stderr)
+            sys.exit(3)
+    if native is not None:
+        native.run_many(dxs.data_ptr(), a.queries, a.warmup)
+        native.synchronize()
+        sync_all()
+        t0 = time.perf_counter()
+        native.run_many(dxs.data_ptr(), a.queries, a.steps)
+        native.synchronize()
+        sync_all()
+        elapsed = time.perf_counter() - t0
+        val, idx = native.read()  # merged (global) top-k of the last timed query
+        exchange_ns = native.time_exchange(20)
+        exchange = {"kind": "native: RCCL ncclAllGather of 2*K int32 per rank and query + merge kernel, 32 queries per exchange, on a "
+                            "side stream overlapping the next batch's local kernels (csrc/dist.hip)",
+                    "us_per_exchange_batch": exchange_ns / 1e3, "queries_per_exchange": 32,
+                    "note": "the exchange alone, back to back (all-gather + merge launch); inside the step it overlaps the local kernels"}
+        native.close()
+    else:
+        sh = dmod.ShardedTopK(a.k, dev)
+        idx_v, val_v = sh.local_views()
+        stream = torch.cuda.current_stream().cuda_stream
+
+        def step(i):
+            eng.enqueue(dxs[i % a.queries].data_ptr(), idx_v.data_ptr(), val_v.data_ptr(), stream)
+            return sh.step()
+
+        for i in range(a.warmup):
+            step(i)
+        sync_all()
+        t0 = time.perf_counter()
+        for i in range(a.steps):
+            ei, ev = step(i)
+        sync_all()
+        elapsed = time.perf_counter() - t0
+        idx, val = ei.cpu().numpy().astype(np.uint32), ev.cpu().numpy()
+        exchange = {"kind": "torch.distributed all_gather_into_tensor of 2*K int32 per rank + on-device merge, every step "
+                            "(TKSPMV_DIST=torch)"}
+    kernel_ns = eng.time_queries(dxs.data_ptr(), a.queries, min(max(a.steps, 64), 512))  # this rank's local kernel alone
+    per_rank = [{"rank": rank, "rows": r1 - r0, "first_row": r0, "nnz": int(info["nnz"]), "kernel_us": kernel_ns / 1e3,
+                 "algorithmic_bytes": int(info["algorithmic_bytes"]),
+                 "frac": info["algorithmic_bytes"] / kernel_ns / HBM_PEAK_GBS}]
+    if multi:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        gathered = [None] * world
+        dist.all_gather_object(gathered, per_rank[0])
+        per_rank = gathered
+    parity_ok, parity = None, None
+    if rank == 0:
+        # the merged result of the last timed query against the gold over the WHOLE matrix (built here, outside the timed
+        # region, on rank 0 only)
+        whole = mod.generate_matrix(total_rows, a.cols, a.nnz, "gamma", seed)
+        assert whole.nnz == total_nnz
+        parity_ok, parity = check_parity(mod, whole, xs[(a.steps - 1) % a.queries], a.k, idx, val, None, bit_exact=False)
+        del whole
+        slowest = max(per_rank, key=lambda r: r["kernel_us"])
+        line = {
+            "metric": "queries_per_sec", "value": a.steps / elapsed, "unit": "queries/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[3]: ONE {total_rows}x{a.cols} gamma nnz/row={a.nnz} matrix (nnz={total_nnz}) "
+                                   f"K={a.k} fp32, row-sharded by nnz over {world} GPU(s), per query one RCCL all-gather of K pairs "
+                                   f"per rank + merge; queries back to back, cache-defeated ({a.replicas} rotating stream copies)",
+                       "rows": total_rows, "cols": a.cols, "nnz": total_nnz, "k": a.k, "n_shards": world,
+                       "parallelism": f"row-shard x{world}"},
+            "roofline": {"bound": "hbm", "achieved": slowest["algorithmic_bytes"] / (slowest["kernel_us"] * 1e3), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": slowest["frac"], "traffic": None,
+                         "kernel": "tkspmv::batch_kernel<4,1024,0> on the slowest rank's shard (per query)",
+                         "algorithmic_bytes": slowest["algorithmic_bytes"], "kernel_us": slowest["kernel_us"],
+                         "method": "per rank: one hipEvent pair around a batch of back-to-back local launches, no exchange"},
+            "per_rank": per_rank, "exchange": exchange, "parity_checked": parity_ok, "parity": parity,
+        }
+        print(json.dumps(line))
+    eng.close()
+
+
 def main():
     a = parse()
+    if a.pmc_child:
+        pmc_child(a)
+        return
     import numpy as np
     import torch
     import _pkg
@@ -136,238 +564,21 @@ def main():
         sys.exit(2)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    # TKSPMV_BENCH_FORCE_DIST=1 under torch.distributed.run with ONE rank takes the N > 1 code path (a one-rank
+    # TKSPMV_BENCH_FORCE_DIST=1 under torch.distributed.run with ONE rank takes the process-group code path (a one-rank
     # RCCL communicator): the way to exercise that path on a single-GPU box.
     multi = world > 1 or (os.environ.get("TKSPMV_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
     if multi:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
-
-    # ---- workload: rank r owns shard r (own seed); N=1 is BASELINE configs[1] -----------------------------------
-    m = mod.generate_matrix(a.rows, a.cols, a.nnz, "gamma", 2 + rank)
-    xs = np.stack([mod.create_sample_vector(a.cols, True, False, True, 1000 + i) for i in range(a.queries)])
-    dxs = torch.from_numpy(xs).to(dev)
-    eng = mod.SpMV(m.row, m.col, m.val, m.rows, m.cols, k=a.k, device=local_rank, first_row=rank * a.rows,
-                   stream_replicas=a.replicas, nnz_per_lane=a.nnz_per_lane, waves_per_cu=a.waves_per_cu,
-                   threads_per_wg=a.threads_per_wg)
-    info = eng.info()
-    alg_bytes = info["algorithmic_bytes"]
-
-    def sync_all():
-        torch.cuda.synchronize()
+    try:
+        if multi or a.total_rows:
+            bench_sharded(a, mod, torch, np, dev, local_rank, rank, world)
+        else:
+            bench_single(a, mod, torch, np, dev, local_rank)
+    finally:
         if multi:
             import torch.distributed as dist
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    if not multi and a.multi_only:
-        # profiler aid: nothing but multi-query passes (warmup + steps queries), then one JSON line about them
-        eng.close()
-        eng = mod.SpMV(m.row, m.col, m.val, m.rows, m.cols, k=a.k, device=local_rank, stream_replicas=a.replicas,
-                       multi_q=a.multi_only)
-        eng.time_multi(dxs.data_ptr(), a.queries, a.warmup)
-        ns = eng.time_multi(dxs.data_ptr(), a.queries, a.steps)
-        print(json.dumps({"metric": "queries_per_sec", "mode": "multi_only", "queries_per_pass": a.multi_only,
-                          "value": 1e9 / ns, "us_per_query": ns / 1e3, "us_per_pass": ns * a.multi_only / 1e3,
-                          "steps": a.steps, "warmup": a.warmup}))
-        eng.close()
-        return
-    if not multi:
-        # ---- N = 1: K queries back to back on the engine stream -------------------------------------------------
-        eng.enqueue_many(dxs.data_ptr(), a.queries, a.warmup)
-        eng.synchronize()
-        sync_all()
-        t0 = time.perf_counter()
-        eng.enqueue_many(dxs.data_ptr(), a.queries, a.steps)
-        eng.synchronize()
-        sync_all()
-        elapsed = time.perf_counter() - t0
-        # kernel-level timing (hipEvents on the engine stream), same rotation. --skip-warm (profiler runs) launches
-        # nothing but the queries themselves, so the rocprofv3 per-kernel average is that of the timed launches.
-        n_prof = min(max(a.steps, 50), 500)
-        if a.skip_warm:
-            prof = {"query_ns": eng.time_queries(dxs.data_ptr(), a.queries, n_prof)}
-        else:
-            prof = eng.profile(dxs.data_ptr(), a.queries, n_prof)
-        # sanity: the last query's result against the oracle order of scores
-        val, idx = eng.read_result()
-        assert np.all(val[:-1] >= val[1:]) and len(set(idx.tolist())) == a.k
-        # same matrix every query (fits the Infinity Cache): the steady state of a deployed single-matrix service
-        cache_warm = None
-        if not a.skip_warm:
-            warm = mod.SpMV(m.row, m.col, m.val, m.rows, m.cols, k=a.k, device=local_rank)
-            warm.enqueue_many(dxs.data_ptr(), a.queries, a.warmup)
-            warm.synchronize()
-            t1 = time.perf_counter()
-            warm.enqueue_many(dxs.data_ptr(), a.queries, a.steps)
-            warm.synchronize()
-            warm_elapsed = time.perf_counter() - t1
-            warm_ns = warm.time_queries(dxs.data_ptr(), a.queries, n_prof)
-            warm.close()
-            cache_warm = {"value": a.steps / warm_elapsed, "unit": "queries/s",
-                          "ms_per_step": 1e3 * warm_elapsed / a.steps,
-                          "kernel_us": warm_ns / 1e3,
-                          "achieved_GBps": alg_bytes / warm_ns,
-                          "note": "one matrix (118 MB packed) re-read every query: served largely by the 256 MiB "
-                                  "Infinity Cache, not comparable with the HBM roofline"}
-        units = a.steps
-        extra = {"cache_warm": cache_warm}
-        if not a.skip_warm and a.multi_q:
-            extra["multi_query"] = multi_query_leg(mod, m, dxs, a, local_rank, alg_bytes)
-        if "stream_kernel_ns" in prof:
-            extra["kernels_us"] = {"query_back_to_back": prof["query_ns"] / 1e3,
-                                   "single_query_fused_launch_with_event_bracket": prof["stream_kernel_ns"] / 1e3,
-                                   "spmv_only_variant": prof["scores_kernel_ns"] / 1e3}
-        kernel_ns = prof["query_ns"]  # launches back to back, no gaps => batch time / queries = kernel time per query
-    else:
-        # ---- N > 1: local engine -> all-gather of K pairs -> merge, per step ---------------------------------------
-        import torch.distributed as dist
-        from importlib import import_module
-        dmod = import_module("approximate_spmv_topk_amd.distributed")
-        native = None
-        if os.environ.get("TKSPMV_DIST", "native") == "native":
-            try:  # native RCCL exchange (csrc/dist.hip); any rank failing makes every rank fall back
-                native = dmod.NativeShardedSpMV(eng, dev)
-                ok = torch.ones(1, device=dev)
-            except Exception as e:  # noqa: BLE001
-                print(f"[rank {rank}] native exchange unavailable ({e}); using torch.distributed", file=sys.stderr)
-                ok = torch.zeros(1, device=dev)
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if ok.item() == 0 and native is not None:
-                native.close()
-                native = None
-        if native is not None:
-            native.run_many(dxs.data_ptr(), a.queries, a.warmup)
-            native.synchronize()
-            sync_all()
-            t0 = time.perf_counter()
-            native.run_many(dxs.data_ptr(), a.queries, a.steps)
-            native.synchronize()
-            sync_all()
-            elapsed = time.perf_counter() - t0
-            exchange = ("native: RCCL ncclAllGather of 2*K int32 per rank and query + merge kernel, 32 queries per exchange, on "
-                        "a side stream overlapping the next batch's local kernel (csrc/dist.hip)")
-            # outside the timed region: the last query again through torch.distributed's all-gather + torch merge
-            val_n, idx_n = native.read()
-            native.close()
-            sh = dmod.ShardedTopK(a.k, dev)
-            idx_v, val_v = sh.local_views()
-            eng.enqueue(dxs[(a.steps - 1) % a.queries].data_ptr(), idx_v.data_ptr(), val_v.data_ptr(),
-                        torch.cuda.current_stream().cuda_stream)
-            ei, ev = sh.step()
-            same = (np.array_equal(ei.cpu().numpy().astype(np.uint32), idx_n)
-                    and np.array_equal(ev.cpu().numpy(), val_n))
-            exchange += "; cross-check against the torch.distributed exchange: " + ("identical" if same else "MISMATCH")
-            if not same:
-                print(f"[rank {rank}] native exchange result differs from the torch.distributed exchange", file=sys.stderr)
-        else:
-            sh = dmod.ShardedTopK(a.k, dev)
-            idx_v, val_v = sh.local_views()
-            stream = torch.cuda.current_stream().cuda_stream
-
-            def step(i):
-                eng.enqueue(dxs[i % a.queries].data_ptr(), idx_v.data_ptr(), val_v.data_ptr(), stream)
-                return sh.step()
-
-            for i in range(a.warmup):
-                step(i)
-            sync_all()
-            t0 = time.perf_counter()
-            for i in range(a.steps):
-                step(i)
-            sync_all()
-            elapsed = time.perf_counter() - t0
-            exchange = "torch.distributed all_gather_into_tensor of 2*K int32 per rank + on-device merge, every step"
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        multi_dist = None
-        if a.multi_q and os.environ.get("TKSPMV_DIST", "native") == "native" and os.environ.get("TKSPMV_BENCH_DIST_MULTI") == "1":
-            # Extension, beside the headline and never part of `value`: the same step with the local passes serving 8
-            # queries each (engines created with multi_q). Opt-in (TKSPMV_BENCH_DIST_MULTI=1): it has only been run with one
-            # rank (TKSPMV_BENCH_FORCE_DIST=1, 145-165 k queries/s), and nothing untested may stand between the scaling
-            # run and its JSON line. Any rank failing to set it up makes every rank skip it.
-            try:
-                q = max(a.multi_q)
-                meng = mod.SpMV(m.row, m.col, m.val, m.rows, m.cols, k=a.k, device=local_rank, first_row=rank * a.rows,
-                                stream_replicas=a.replicas, multi_q=q)
-                mnat = dmod.NativeShardedSpMV(meng, dev)
-                ok = torch.ones(1, device=dev)
-            except Exception as e:  # noqa: BLE001
-                print(f"[rank {rank}] multi-query distributed leg unavailable ({e})", file=sys.stderr)
-                meng = mnat = None
-                ok = torch.zeros(1, device=dev)
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if ok.item() != 0:
-                mnat.run_many(dxs.data_ptr(), a.queries, a.warmup)
-                mnat.synchronize()
-                sync_all()
-                t1 = time.perf_counter()
-                mnat.run_many(dxs.data_ptr(), a.queries, a.steps)
-                mnat.synchronize()
-                sync_all()
-                tm = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
-                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-                multi_dist = {"queries_per_pass": q, "value": a.steps * world / float(tm.item()), "unit": "queries/s",
-                              "global_queries_per_sec": a.steps / float(tm.item()),
-                              "note": "the same sharded step, local passes serving several queries each (tkspmv_enqueue_multi "
-                                      "inside tkspmv_dist_*); extension, not part of `value`"}
-            if mnat is not None:
-                mnat.close()
-            if meng is not None:
-                meng.close()
-        prof = eng.profile(dxs.data_ptr(), a.queries, 200)
-        kernel_ns = eng.time_queries(dxs.data_ptr(), a.queries, min(max(a.steps, 50), 500))  # as at N = 1
-        units = a.steps * world
-        extra = {"global_queries_per_sec": a.steps / elapsed,
-                 "kernels_us": {"stream": prof["stream_kernel_ns"] / 1e3, "select": prof["select_kernel_ns"] / 1e3,
-                                "query_back_to_back": kernel_ns / 1e3},
-                 "exchange": exchange}
-        if multi_dist:
-            extra["multi_query"] = multi_dist
-
-    if rank == 0:
-        line = {
-            "metric": "queries_per_sec", "value": units / elapsed, "unit": "queries/s", "n_gpus": world,
-            "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{a.rows}x{a.cols} gamma nnz/row={a.nnz} (nnz={info['nnz']}) K={a.k} fp32, "
-                                   f"queries back to back on one stream, cache-defeated ({a.replicas} rotating stream copies)"
-                                   + (f", {world} row shards of {a.rows} rows, RCCL all-gather of K pairs" if world > 1 else ""),
-                       "rows": a.rows, "cols": a.cols, "nnz": int(info["nnz"]), "k": a.k,
-                       "parallelism": f"row-shard x{world}" if world > 1 else "single GPU",
-                       "launch": {"grid": info["grid"], "block": info["block"] + 64,
-                                  "wave_partitions": info["n_wave_partitions"], "packet_entries": info["packet_entries"]}},
-            "roofline": {"bound": "hbm", "achieved": alg_bytes / kernel_ns, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": alg_bytes / kernel_ns / HBM_PEAK_GBS, "traffic": _traffic_from_profiles(),
-                         "kernel": "tkspmv::batch_kernel<4,1024,0> (up to 32 queries per launch; figures are per query)",
-                         "algorithmic_bytes": int(alg_bytes),
-                         "kernel_us": kernel_ns / 1e3,
-                         "method": "one hipEvent pair on the engine stream around a batch of back-to-back launches, "
-                                   "duration = batch time / queries. A launch of the batch kernel streams the matrix once "
-                                   "per query for up to 32 queries (one continuous prefetch pipeline per wave) and selects "
-                                   "each query's top-k in its selector workgroup; rocprofv3's average launch duration / 32 "
-                                   "agrees (profiles/README.md)"},
-        }
-        line.update(extra)
-        if world == 1 and a.cpu_seconds > 0:
-            line["cpu_baseline"] = cpu_baseline(mod, m, xs, a.k, a.cpu_seconds)
-        print(json.dumps(line))
-    eng.close()
-    if multi:
-        import torch.distributed as dist
-        dist.destroy_process_group()
-
-
-def _traffic_from_profiles():
-    """HBM bytes per launch of the stream kernel from the rocprofv3 --pmc pass committed under profiles/
-    (FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 correction); None when no such pass has been recorded."""
-    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    try:
-        with open(p) as f:
-            return json.load(f).get("stream_kernel_hbm_bytes_per_launch")
-    except Exception:
-        return None
+            dist.destroy_process_group()
 
 
 if __name__ == "__main__":

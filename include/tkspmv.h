@@ -140,7 +140,8 @@ typedef struct {
     uint32_t multi_q;             /* queries per matrix pass of tkspmv_enqueue_multi; 0 = this engine has no multi-query kernel */
     uint32_t reserved0;
     uint64_t multi_bytes;         /* bytes of the wave-sliced ELL copy the multi-query kernel streams (0 without it) */
-    uint32_t reserved[2];
+    uint32_t pack_us;             /* tkspmv_create: microseconds spent packing (on the device: upload of the COO included) */
+    uint32_t pack_on_device;      /* 1: the stream was packed by the device packer (default), 0: by the host packer */
 } tkspmv_info;
 
 typedef struct {
@@ -302,6 +303,10 @@ int tkspmv_packed_decode(const tkspmv_packed *p, uint32_t *row, uint32_t *col, f
 int tkspmv_packed_raw(const tkspmv_packed *p, const void **packets, uint64_t *packet_bytes, const uint32_t **pkt_row,
                       const uint32_t **part_first, const uint32_t **part_count, uint32_t *n_parts);
 void tkspmv_packed_free(tkspmv_packed *p);
+/* The DEVICE packer (what tkspmv_create uses by default): packs desc's COO with HIP kernels on desc->device
+ * and copies the result back into a tkspmv_packed, so that it can be compared byte for byte with tkspmv_pack's
+ * (tkspmv_packed_raw) or saved. ms[0] = upload of the COO, ms[1] = packing kernels (ms may be NULL). Needs a GPU. */
+int tkspmv_pack_device(const tkspmv_desc *desc, uint32_t n_wave_partitions_hint, tkspmv_packed **out, double *ms);
 /* The same for the wave-sliced ELL layout of the multi-query kernel (wsell.hpp): packs desc's COO for
  * n_wave_partitions_hint waves and decodes it again into caller arrays sized >= nnz (entries grouped by row, rows in
  * stream order). info[0..5] = slices, chunks, padded entries, partitions, stream bytes, most chunks in one partition. */
