@@ -116,6 +116,7 @@ struct EngineImpl {
     int multi_q = 0;
     // Large k (see radix_hist_kernel): every query = scores kernel + radix select + the selection kernel
     bool use_radix = false;
+    bool approx_parts = false;    // partitions > 1 with k > k_per_partition: the reference's lossy per-partition lists
     float *d_rscores = nullptr;   // [rows], -inf where a row has no entry (never written by the scores kernel)
     uint32_t *d_rhist = nullptr;  // [4][256]
     uint8_t *d_sell_packets = nullptr;
@@ -462,10 +463,23 @@ struct EngineImpl {
         R.ovf_cand = st[0].ovf;
         R.ovf_count = st[0].ovf_count;
         R.ovf_cap = ovf_cap;
-        (void)hipMemsetAsync(d_rhist, 0, 4 * 256 * 4, s);
-        const uint32_t rgrid = std::max(1u, std::min(256u, (desc.rows + RADIX_THREADS * 4u - 1u) / (RADIX_THREADS * 4u)));
-        for (int pass = 0; pass < 4; ++pass) hipLaunchKernelGGL(radix_hist_kernel, dim3(rgrid), dim3(RADIX_THREADS), 0, s, R, pass);
-        hipLaunchKernelGGL(radix_filter_kernel, dim3(rgrid), dim3(RADIX_THREADS), 0, s, R);
+        if (approx_parts) {
+            PartitionParams Q{};
+            Q.scores = d_rscores;
+            Q.rows = desc.rows;
+            Q.per = (desc.rows + (uint32_t)desc.partitions - 1u) / (uint32_t)desc.partitions;  // ceil(N / P): host_spmv_bscsr.cpp:136
+            Q.k_part = (uint32_t)(desc.k_per_partition > 0 ? desc.k_per_partition : desc.k);
+            Q.kmin = R.kmin;
+            Q.ovf_cand = R.ovf_cand;
+            Q.ovf_count = R.ovf_count;
+            Q.ovf_cap = ovf_cap;
+            hipLaunchKernelGGL(partition_topk_kernel, dim3((uint32_t)desc.partitions), dim3(RADIX_THREADS), 0, s, Q);
+        } else {
+            (void)hipMemsetAsync(d_rhist, 0, 4 * 256 * 4, s);
+            const uint32_t rgrid = std::max(1u, std::min(256u, (desc.rows + RADIX_THREADS * 4u - 1u) / (RADIX_THREADS * 4u)));
+            for (int pass = 0; pass < 4; ++pass) hipLaunchKernelGGL(radix_hist_kernel, dim3(rgrid), dim3(RADIX_THREADS), 0, s, R, pass);
+            hipLaunchKernelGGL(radix_filter_kernel, dim3(rgrid), dim3(RADIX_THREADS), 0, s, R);
+        }
         SelectParams S = select_params(out_idx, out_val, 0);
         S.use_gmax = 0u;  // no threshold word in this path
         S.out_scale = 1.0f;  // the scores kernel already wrote final scores
@@ -597,13 +611,15 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
     if (d.partitions > 1) {
         // The reference keeps k_per_partition (its compile-time K) candidates per row partition and merges them on
         // the host (host_spmv_bscsr.cpp:399-448). For k <= k_per_partition the union of the per-partition lists
-        // contains the global top-k, so the partitioned result IS the exact one computed here. The lossy regime
-        // (k > k_per_partition) is an accuracy knob of the FPGA design that is not reproduced.
+        // contains the global top-k, so the partitioned result IS the exact one computed by the ordinary kernels. With
+        // k > k_per_partition (the FPGA design's lossy regime: 32 partitions x K = 8 lists answering k = 100) the engine
+        // reproduces the reference's approximate union: partition_topk_kernel.
         const int kpp = d.k_per_partition > 0 ? d.k_per_partition : d.k;
-        if (d.k > kpp) {
-            err = "partitions > 1 with k > k_per_partition (the reference's lossy regime) is not implemented";
-            return TKSPMV_ERR_UNSUPPORTED;
+        if (kpp > TKSPMV_MAX_K || d.partitions > 65535) {
+            err = "partitions must be <= 65535 and k_per_partition <= 1024";
+            return TKSPMV_ERR_INVALID;
         }
+        m.approx_parts = d.k > kpp;
     }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
@@ -800,6 +816,7 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
     // 3/8 of the publishing groups: measured cross-over on the BASELINE matrix, tools/k_probe.py). TKSPMV_RADIX=0/1 forces.
     m.use_radix = m.n_sets == 0u || (uint64_t)d.k * 8u > (uint64_t)m.n_groups_pub * 3u || d.impl == TKSPMV_IMPL_SCORES_SELECT;
     if (const char *f = getenv("TKSPMV_RADIX")) m.use_radix = atoi(f) != 0;
+    if (m.approx_parts) m.use_radix = true;  // scores, then the per-partition selection instead of the radix select
     if (m.use_radix) {
         m.can_defer = m.can_batch = false;
         m.fused = false;

@@ -122,4 +122,84 @@ __global__ void __launch_bounds__(RADIX_THREADS) radix_filter_kernel(const Radix
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// The FPGA design's K-lists-per-partition approximation ("approximation C"): the reference cuts the rows
+// into SPMV_PARTITIONS ranges (p = row / ceil(N / P), host_spmv_bscsr.cpp:133-141), every core keeps only K candidates
+// (types.hpp:49) and the host merges the P x K of them (host_spmv_bscsr.cpp:399-448); a row of the true top-k that is
+// not among the K best of its partition is lost (topk_errors.py:29-42 models the loss). Engines created with
+// partitions = P and k > k_per_partition reproduce exactly that: the SpMV-only kernel writes every score, one workgroup
+// per partition selects the k_per_partition best rows of its range EXACTLY (score desc, row desc) and appends them to the
+// candidate list, and the ordinary selection kernel ranks the union.
+// ------------------------------------------------------------------------------------------------------------
+struct PartitionParams {
+    const float *scores;  // [rows]; -inf where a row has no entry
+    uint32_t rows, per, k_part;
+    uint32_t kmin;        // order key of min_score
+    unsigned long long *ovf_cand;
+    uint32_t *ovf_count;
+    uint32_t ovf_cap;
+};
+
+__global__ void __launch_bounds__(RADIX_THREADS) partition_topk_kernel(const PartitionParams R) {
+    __shared__ uint32_t cnt;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t a = blockIdx.x * R.per;
+    const uint32_t b = (a + R.per < R.rows && a + R.per > a) ? a + R.per : R.rows;
+    if (a >= b) return;
+    // number of rows of the range for which pred(key, row) holds (uniform result)
+    auto count = [&](auto pred) -> uint32_t {
+        if (tid == 0) cnt = 0u;
+        __syncthreads();
+        uint32_t c = 0;
+        for (uint32_t i = a + tid; i < b; i += RADIX_THREADS) {
+            const float sc = R.scores[i];
+            const uint32_t key = order_key(sc);
+            c += (key >= R.kmin && sc > -__builtin_huge_valf() && pred(key, i)) ? 1u : 0u;
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) c += (uint32_t)__shfl_xor((int)c, d);
+        if (lane == 0 && c) atomicAdd(&cnt, c);
+        __syncthreads();
+        const uint32_t r = cnt;
+        __syncthreads();
+        return r;
+    };
+    // T = the k_part-th largest eligible key of the range (bisection on the key bits); fewer eligible rows: all of them
+    uint32_t T = R.kmin, R0 = a;
+    const uint32_t eligible = count([](uint32_t, uint32_t) { return true; });
+    if (eligible > R.k_part) {
+        uint32_t prefix = 0u;
+        for (int bit = 31; bit >= 0; --bit) {
+            const uint32_t trial = prefix | (1u << bit);
+            if (count([trial](uint32_t key, uint32_t) { return key >= trial; }) >= R.k_part) prefix = trial;
+        }
+        T = prefix;
+        const uint32_t n_gt = count([T](uint32_t key, uint32_t) { return key > T; });
+        const uint32_t n_eq = count([T](uint32_t key, uint32_t) { return key == T; });
+        const uint32_t need = R.k_part - n_gt;  // >= 1
+        if (n_eq > need) {  // equal scores across the cut: the higher row ids win (sort_tuples order)
+            uint32_t rp = 0u;
+            for (int bit = 31; bit >= 0; --bit) {
+                const uint32_t trial = rp | (1u << bit);
+                if (count([T, trial](uint32_t key, uint32_t row) { return key == T && row >= trial; }) >= need) rp = trial;
+            }
+            R0 = rp;
+        }
+    }
+    for (uint32_t i0 = a; i0 < b; i0 += RADIX_THREADS) {  // uniform trip count
+        const uint32_t i = i0 + tid;
+        const float sc = i < b ? R.scores[i] : -__builtin_huge_valf();
+        const uint32_t key = order_key(sc);
+        const bool keep = i < b && sc > -__builtin_huge_valf() && key >= R.kmin && (key > T || (key == T && i >= R0));
+        const uint64_t bm = __ballot(keep);
+        uint32_t base = 0u;
+        if (lane == 0u && bm) base = atomicAdd(R.ovf_count, (uint32_t)__popcll(bm));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (keep) {
+            const uint32_t pos = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
+            if (pos < R.ovf_cap) R.ovf_cand[pos] = pack_cand(__float_as_uint(sc), i);
+        }
+    }
+}
+
 }  // namespace tkspmv

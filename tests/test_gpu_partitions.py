@@ -1,0 +1,116 @@
+"""The FPGA design's K-lists-per-partition approximation (SURVEY.md 2.4 "approximation C"; f4's accuracy knob).
+
+Reference: rows are cut into SPMV_PARTITIONS ranges, p = row / ceil(N / P) (src/fpga/src/host_spmv_bscsr.cpp:133-141);
+every core returns K candidates (src/common/types.hpp:49); the host adds first_row, merges and sorts them
+(host_spmv_bscsr.cpp:399-448) and main() scores the first k of the union with precision = |hw ∩ sw| / k (:646-650).
+src/resources/python/topk_errors.py:29-43 gives a closed form for the expected precision of that scheme.
+
+Engines created with partitions = P and k > k_per_partition reproduce it exactly: bit for bit against a CPU model built
+from the order-matched oracle, and statistically against the reference's closed form (restated below, not imported: the
+script runs a Monte-Carlo experiment at import time)."""
+import math
+from fractions import Fraction
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def closed_form_approx(n, b, k, partition_k):  # topk_errors.py:29-39
+    if k <= partition_k:
+        return 1
+    if partition_k * b < k:
+        return 0
+    denom = math.comb(n, k)
+    delta = 0
+    for i in range(partition_k + 1, min(n // b, k)):
+        delta += math.comb(n // b, i)
+    return 1 - Fraction(b * delta, denom)
+
+
+def closed_form_precision_estimation(n, b, k, partition_k):  # topk_errors.py:42-43
+    return float(np.mean([float(closed_form_approx(n, b, k_i, partition_k)) for k_i in range(1, k + 1)]))
+
+
+def _model(oracle, yp, present, rows, P, k_part, k, first_row=0):
+    """Per-partition exact top-k_part (score desc, row desc), union, top-k of the union, (0, 0.0) padding."""
+    per = (rows + P - 1) // P
+    ci, cv = [], []
+    for p in range(P):
+        a, b = p * per, min((p + 1) * per, rows)
+        if a >= b:
+            continue
+        n_ok = int((present[a:b].astype(bool) & (yp[a:b] >= 0)).sum())
+        pi, pv = oracle.select_topk(yp[a:b], present[a:b], k_part, 0.0, first_row=a)
+        ci += pi[:min(n_ok, k_part)].tolist()
+        cv += pv[:min(n_ok, k_part)].tolist()
+    ci, cv = np.array(ci, np.int64), np.array(cv, np.float32)
+    order = np.lexsort((-ci, -cv.astype(np.float64)))[:k]
+    idx = np.zeros(k, np.uint32)
+    val = np.zeros(k, np.float32)
+    idx[:len(order)] = ci[order] + first_row
+    val[:len(order)] = cv[order]
+    return idx, val
+
+
+@pytest.mark.parametrize("rows,P,k_part,k", [(1000000, 32, 8, 100), (1000000, 8, 8, 100), (200000, 16, 8, 50), (5000, 7, 3, 40)])
+def test_lossy_partitions_match_the_model_and_the_closed_form(pkg, oracle, rows, P, k_part, k):
+    m = pkg.generate_matrix(rows, 1024, 20, "gamma", 2)
+    eng = pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, k=k, device=0, partitions=P, k_per_partition=k_part)
+    info = eng.info()
+    assert info["partitions"] == P and info["k_per_partition"] == k_part
+    C = info["packet_entries"] // 64
+    packed = pkg.Packed(m, k=k, nnz_per_lane=C, n_wave_partitions=info["grid"] * info["block"] // 64)
+    assert packed.info()["n_wave_partitions"] == info["n_wave_partitions"]
+    raw = packed.raw()
+    n_q = 12 if rows >= 1000000 else 6
+    prec = []
+    for q in range(n_q):
+        x = pkg.create_sample_vector(1024, True, False, True, 900 + q)
+        eng.reset(x)
+        eng()
+        val, idx = eng.read_result()
+        if q < 3:  # bit for bit against the model on the order-matched scores
+            yp, present = oracle.packed_scores(raw, x, m.rows, C)
+            ei, ev = _model(oracle, yp, present, m.rows, P, k_part, k)
+            assert np.array_equal(idx, ei), f"query {q}: index list differs from the partition model"
+            assert np.array_equal(val.view(np.uint32), ev.view(np.uint32))
+        gi, _ = oracle.gold_topk(m.row, m.col, m.val, x, k)
+        n_real = min(k, P * k_part)
+        prec.append(len(set(idx[:n_real].tolist()) & set(gi.tolist())) / k)  # host_spmv_bscsr.cpp:646-650
+        assert np.all(val[n_real:] == 0) and np.all(idx[n_real:] == 0)  # fewer candidates than k: (0, 0.0) behind them
+    measured = float(np.mean(prec))
+    closed = closed_form_precision_estimation(rows, P, k, k_part)
+    print(f"\n[{rows} rows, {P} partitions x K = {k_part}, k = {k}] precision against the exact top-k: measured {measured:.3f} "
+          f"over {n_q} queries, closed form (topk_errors.py) {closed:.3f}")
+    assert abs(measured - closed) <= 0.05
+    eng.close()
+
+
+def test_partitions_with_ties_batches_and_first_row(pkg, oracle):
+    """Equal scores across a partition's cut (unit values, constant x): the higher row ids win, as sort_tuples orders them;
+    batches run the same path; first_row offsets the ids."""
+    import torch
+    rows, P, k_part, k = 3000, 10, 4, 30
+    r = np.repeat(np.arange(rows, dtype=np.uint32), 3)
+    c = np.tile(np.array([1, 5, 9], np.uint32), rows)
+    m = pkg.CooMatrix(rows, 16, r, c, np.ones(3 * rows, np.float32))
+    x = np.full(16, 0.25, np.float32)
+    eng = pkg.SpMV(m.row, m.col, None, m.rows, m.cols, vec=x, k=k, device=0, partitions=P, k_per_partition=k_part, first_row=1000)
+    eng()
+    val, idx = eng.read_result()
+    per = (rows + P - 1) // P
+    want = sorted([min((p + 1) * per, rows) - 1 - j + 1000 for p in range(P) for j in range(k_part)], reverse=True)[:k]
+    assert idx.tolist() == want and np.all(val == 0.75)
+    xs = np.stack([x, 2 * x, 3 * x])
+    dxs = torch.from_numpy(xs).cuda()
+    out_i = torch.zeros(3, k, dtype=torch.int32, device="cuda")
+    out_v = torch.zeros(3, k, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    eng.enqueue_batch(dxs.data_ptr(), 3, out_i.data_ptr(), out_v.data_ptr())
+    eng.synchronize()
+    for q in range(3):
+        assert out_i[q].cpu().numpy().view(np.uint32).tolist() == want
+        assert np.all(out_v[q].cpu().numpy() == np.float32(0.75 * (q + 1)))
+    eng.close()
