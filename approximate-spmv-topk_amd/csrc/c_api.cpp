@@ -224,7 +224,7 @@ int tkspmv_pack(const tkspmv_desc *d, uint32_t n_wave_partitions_hint, tkspmv_pa
     tkspmv_packed *p = new tkspmv_packed();
     int kind = 0;
     uint32_t C = entries_per_lane_of(*d);
-    const Precision sp = stream_precision(d->precision);
+    const Precision sp = stream_precision_of(*d);
     std::string err = pack_wbscsr(d->rows, d->cols, d->nnz, d->row, d->col, d->val, sp, C,
                                   n_wave_partitions_hint ? n_wave_partitions_hint : 4096u, 4, p->pm, kind,
                                   fixed_width_of(*d));
@@ -245,7 +245,7 @@ int tkspmv_pack_device(const tkspmv_desc *d, uint32_t n_wave_partitions_hint, tk
     if (use_device(d->device, serr) != TKSPMV_OK) return fail(TKSPMV_ERR_DEVICE, serr);
     DevicePacked dp;
     int kind = 0;
-    std::string err = pack_wbscsr_device(d->rows, d->cols, d->nnz, d->row, d->col, d->val, stream_precision(d->precision),
+    std::string err = pack_wbscsr_device(d->rows, d->cols, d->nnz, d->row, d->col, d->val, stream_precision_of(*d),
                                          entries_per_lane_of(*d), n_wave_partitions_hint ? n_wave_partitions_hint : 4096u, 4,
                                          fixed_width_of(*d), dp, kind);
     if (err.empty()) err = download_device_packed(dp);
@@ -359,12 +359,13 @@ int tkspmv_create_packed(tkspmv_t **out, const tkspmv_packed *p, const tkspmv_de
     d.cols = p->pm.cols;
     d.nnz = p->pm.nnz;
     // desc.precision chooses among the arithmetic modes of the packed value type (only Q1.7 has two)
-    if (stream_precision(desc->precision) != p->pm.precision)
+    const bool fixed_either = desc->precision == TKSPMV_FIXED && (p->pm.precision == Precision::FIXED || p->pm.precision == Precision::FIXED20);
+    if (!fixed_either && stream_precision(desc->precision) != p->pm.precision)
         d.precision = p->pm.precision == Precision::F32
                           ? TKSPMV_F32
                           : (p->pm.precision == Precision::F16
                                  ? TKSPMV_F16
-                                 : (p->pm.precision == Precision::FIXED
+                                 : ((p->pm.precision == Precision::FIXED || p->pm.precision == Precision::FIXED20)
                                         ? TKSPMV_FIXED
                                         : (p->pm.precision == Precision::Q1_7_RND ? TKSPMV_Q1_7_F32 : TKSPMV_Q1_7)));
     d.fixed_width = (int32_t)p->pm.fixed_width;  // a property of the packed values

@@ -262,6 +262,10 @@ __device__ __forceinline__ void place(const ScatterParams &P, uint32_t r, unsign
     uint8_t *pkt = P.packets + (size_t)pk * P.packet_bytes;
     // the first row that ends in a packet is the row of its first entry (wbscsr.cpp)
     if (ss == 0u) P.pkt_row[pk] = r;
+    if ((Precision)P.precision == Precision::FIXED20) {
+        *reinterpret_cast<uint32_t *>(pkt + (size_t)slot * 4) = fixed20_word(to_fixed(v, P.fixed_width), (uint32_t)(cw >> COLW_COL_SHIFT), cw & 3u);
+        return;
+    }
     switch ((Precision)P.precision) {
         case Precision::F32: *reinterpret_cast<float *>(pkt + (size_t)slot * 4) = v; break;
         case Precision::F16: *reinterpret_cast<uint16_t *>(pkt + (size_t)slot * 2) = to_half(v); break;
@@ -330,8 +334,9 @@ std::string pack_wbscsr_device(uint32_t rows, uint32_t cols, uint64_t nnz, const
                                uint32_t min_packets_per_partition, uint32_t fixed_width, DevicePacked &out, int &kind) {
     kind = 1;
     if (C != 4 && C != 8) return "nnz_per_lane must be 4 or 8";
-    if (precision == Precision::FIXED ? (fixed_width < 8 || fixed_width > 32) : fixed_width != 0)
-        return "fixed_width must be in [8, 32] for fixed-point values (and 0 otherwise)";
+    if (precision == Precision::FIXED20 ? (fixed_width < 8 || fixed_width > FIXED20_MAX_WIDTH || cols > FIXED20_MAX_COLS)
+                                        : (precision == Precision::FIXED ? (fixed_width < 8 || fixed_width > 32) : fixed_width != 0))
+        return "fixed_width must be in [8, 32] for fixed-point values (bit-packed: at most 20 bits and 1024 columns) and 0 otherwise";
     if (cols == 0 || cols > MAX_COLS) return "cols must be in [1, 16384]";
     if (nnz > 0 && (!row || !col)) return "row/col arrays are NULL";
     if (n_partitions_hint == 0) n_partitions_hint = 1;

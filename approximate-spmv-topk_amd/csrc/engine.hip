@@ -169,7 +169,7 @@ struct EngineImpl {
         P.x = x;
         P.n_parts = (uint32_t)info.n_wave_partitions;
         P.cols = desc.cols;
-        P.packet_bytes = info.packet_entries * (value_bytes(stream_precision(desc.precision)) + 2u);
+        P.packet_bytes = pm.packet_bytes;
         P.n_sets = n_sets;
         P.k = (uint32_t)desc.k;
         P.n_groups_pub = n_groups_pub;
@@ -347,7 +347,7 @@ struct EngineImpl {
         if (desc.precision == TKSPMV_Q1_7) return &batch_kernel<4, 1024, 1>;
         if (desc.precision == TKSPMV_Q1_7_WIDE) return &batch_kernel<4, 1024, 2>;
         if (desc.precision == TKSPMV_F16) return &batch_kernel<4, 1024, 3>;
-        if (desc.precision == TKSPMV_FIXED) return &batch_kernel<4, 1024, 4>;
+        if (desc.precision == TKSPMV_FIXED) return pm.precision == Precision::FIXED20 ? &batch_kernel<4, 1024, 6> : &batch_kernel<4, 1024, 4>;
         if (desc.precision == TKSPMV_Q1_7_F32) return &batch_kernel<4, 1024, 5>;
         if (info.packet_entries == 512) return &batch_kernel<8, 1024, 0>;
         return dbg_kernels ? &batch_kernel<4, 1024, 0, true> : &batch_kernel<4, 1024, 0>;
@@ -417,6 +417,8 @@ struct EngineImpl {
             if (xcols <= 4096) return scores ? &stream_kernel<4, true, 4096, 3> : &stream_kernel<4, false, 4096, 3>;
             return scores ? &stream_kernel<4, true, 16384, 3> : &stream_kernel<4, false, 16384, 3>;
         }
+        if (desc.precision == TKSPMV_FIXED && pm.precision == Precision::FIXED20)  // bit-packed: at most 1024 columns
+            return scores ? &stream_kernel<4, true, 1024, 6> : &stream_kernel<4, false, 1024, 6>;
         if (desc.precision == TKSPMV_FIXED) {
             if (xcols <= 1024) return scores ? &stream_kernel<4, true, 1024, 4> : &stream_kernel<4, false, 1024, 4>;
             if (xcols <= 4096) return scores ? &stream_kernel<4, true, 4096, 4> : &stream_kernel<4, false, 4096, 4>;
@@ -664,7 +666,8 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
         // A matrix packed earlier (tkspmv_pack / a .tkspmv file): it must describe the same problem and must not have
         // more partitions than this launch geometry has streaming waves (the batch kernel gives every wave one).
         const PackedMatrix &q = *prepacked;
-        if (q.rows != d.rows || q.cols != d.cols || q.precision != stream_precision(d.precision) ||
+        const bool fixed_either = d.precision == TKSPMV_FIXED && (q.precision == Precision::FIXED || q.precision == Precision::FIXED20);
+        if (q.rows != d.rows || q.cols != d.cols || (!fixed_either && q.precision != stream_precision(d.precision)) ||
             q.C != C || q.fixed_width != fixed_width_of(d)) {
             err = "the packed matrix does not match the descriptor (rows, cols, precision or entries per lane)";
             return TKSPMV_ERR_INVALID;
@@ -689,7 +692,7 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
         std::string perr;
         if (on_device) {
             DevicePacked dp;
-            perr = pack_wbscsr_device(d.rows, d.cols, d.nnz, d.row, d.col, d.val, stream_precision(d.precision), C,
+            perr = pack_wbscsr_device(d.rows, d.cols, d.nnz, d.row, d.col, d.val, stream_precision_of(d), C,
                                       n_stream_waves, 4, fixed_width_of(d), dp, kind);
             if (perr.empty()) {
                 m.pm = std::move(dp.meta);
@@ -698,7 +701,7 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
                 m.packed_on_device = true;
             }
         } else {
-            perr = pack_wbscsr(d.rows, d.cols, d.nnz, d.row, d.col, d.val, stream_precision(d.precision), C, n_stream_waves, 4,
+            perr = pack_wbscsr(d.rows, d.cols, d.nnz, d.row, d.col, d.val, stream_precision_of(d), C, n_stream_waves, 4,
                                m.pm, kind, fixed_width_of(d));
         }
         if (!perr.empty()) {

@@ -77,7 +77,9 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 // QM 5 = Q1.7 values (rounded to nearest) dequantised to fp32 (v_cvt_f32_ubyteN: one VALU per entry), fp32 x held in LDS
 // pre-scaled by 2^-7 (exact), fp32 products and sums: the byte stream of the Q1.7 modes with the arithmetic of the fp32
 // path (TKSPMV_Q1_7_F32, BASELINE configs[4]).
-constexpr int value_type_of(int QM) { return QM == 3 ? 2 : ((QM == 1 || QM == 2 || QM == 5) ? 1 : 0); }  // QM 4: one u32 per value, loaded like fp32
+// QM 6 = fixed point of at most 20 bits, bit-packed (wbscsr.hpp FIXED20): one dword per entry carrying value, column and
+// flags; the arithmetic is QM 4's with both factors as 20-bit integers.
+constexpr int value_type_of(int QM) { return QM == 6 ? 3 : (QM == 3 ? 2 : ((QM == 1 || QM == 2 || QM == 5) ? 1 : 0)); }  // QM 4: one u32 per value, loaded like fp32
 // Byte b (0..3) of a dword as a float: v_cvt_f32_ubyte0..3.
 template <int B>
 __device__ __forceinline__ float ubyte_to_float(uint32_t w) {
@@ -97,7 +99,7 @@ constexpr float Q17_UNIT = 0.0078125f;  // 2^-7
 // from them when the stream comes from HBM, tools/stream_probe.hip).
 template <int C, int VT>
 struct Pkt {
-    float v[VT == 0 ? C : 1];
+    float v[(VT == 0 || VT == 3) ? C : 1];  // VT 3: the packed dwords (value | column | flags); cw stays unused
     uint32_t vq[VT == 1 ? C / 4 : (VT == 2 ? C / 2 : 1)];
     uint32_t cw[C / 2];
 };
@@ -106,7 +108,13 @@ template <int C, int VT>
 __device__ __forceinline__ void load_packet(const uint8_t *__restrict__ pk, uint32_t lane, Pkt<C, VT> &o) {
 #pragma unroll
     for (int q = 0; q < C / 4; ++q) {
-        if (VT == 1) {
+        if (VT == 3) {
+            const f32x4 f = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(pk + q * 1024 + lane * 16));
+            o.v[VT == 3 ? 4 * q + 0 : 0] = f.x;
+            o.v[VT == 3 ? 4 * q + 1 : 0] = f.y;
+            o.v[VT == 3 ? 4 * q + 2 : 0] = f.z;
+            o.v[VT == 3 ? 4 * q + 3 : 0] = f.w;
+        } else if (VT == 1) {
             o.vq[VT == 1 ? q : 0] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(pk + q * 256 + lane * 4));
             const u32x2 c = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(pk + C * 64 + q * 512 + lane * 8));
             o.cw[2 * q + 0] = c.x;

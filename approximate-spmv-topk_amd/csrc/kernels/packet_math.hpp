@@ -230,6 +230,24 @@ __device__ __forceinline__ RowSums<C> reduce_packet(const Pkt<C, value_type_of(Q
                                                     const uint32_t fixed_mask = 0u) {
     constexpr int VT = value_type_of(QM);
     float p[C];
+    if (QM == 6) {
+        // Bit-packed fixed point: word = value (bits 31..12, the top 20 bits of its Q1.31 word) | column << 2 | flags. x is
+        // staged as a 20-bit integer (Q1.19); both factors fit the full-rate 24-bit multipliers; the 40-bit product is
+        // Q2.38, of which bits 38..7 are the product in Q1.31 (integer part wrapped to one bit), masked to the width.
+        uint32_t cwv[C / 2];
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            const uint32_t w = __float_as_uint(cur.v[VT == 3 ? j : 0]);
+            const uint32_t xq = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const unsigned char *>(x_lds) + (w & 0xFFCu));
+            uint32_t v20, hi;
+            asm("v_bfe_u32 %0, %1, 12, 20" : "=v"(v20) : "v"(w));
+            asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(hi) : "v"(v20), "v"(xq));
+            p[j] = __uint_as_float(__builtin_amdgcn_alignbit(hi, __umul24(v20, xq), 7) & fixed_mask);
+            if (j & 1) cwv[j >> 1] |= (w & 3u) << 16;
+            else cwv[j >> 1] = w & 3u;
+        }
+        return reduce_core<C, true>(p, cwv, carry);
+    }
 #pragma unroll
     for (int j = 0; j < C; ++j) {
         const uint32_t word = cur.cw[j >> 1];
@@ -271,7 +289,7 @@ __device__ __forceinline__ RowSums<C> reduce_packet(const Pkt<C, value_type_of(Q
             p[j] = __fmul_rn(cur.v[VT == 0 ? j : 0], xv);
         }
     }
-    return reduce_core<C, QM == 4>(p, cur.cw, carry);
+    return reduce_core<C, QM == 4>(p, cur.cw, carry);  // (QM 6 returned above)
 }
 
 template <int C, int QM>

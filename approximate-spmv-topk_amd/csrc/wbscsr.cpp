@@ -39,8 +39,9 @@ std::string pack_wbscsr(uint32_t rows, uint32_t cols, uint64_t nnz, const uint32
                         uint32_t min_packets_per_partition, PackedMatrix &out, int &kind, uint32_t fixed_width) {
     kind = 1;
     if (C != 4 && C != 8) return "nnz_per_lane must be 4 or 8";
-    if (precision == Precision::FIXED ? (fixed_width < 8 || fixed_width > 32) : fixed_width != 0)
-        return "fixed_width must be in [8, 32] for fixed-point values (and 0 otherwise)";
+    if (precision == Precision::FIXED20 ? (fixed_width < 8 || fixed_width > FIXED20_MAX_WIDTH || cols > FIXED20_MAX_COLS)
+                                        : (precision == Precision::FIXED ? (fixed_width < 8 || fixed_width > 32) : fixed_width != 0))
+        return "fixed_width must be in [8, 32] for fixed-point values (bit-packed: at most 20 bits and 1024 columns) and 0 otherwise";
     if (cols == 0 || cols > MAX_COLS) return "cols must be in [1, 16384]";
     if (nnz > 0 && (!row || !col)) return "row/col arrays are NULL";
     if (n_partitions_hint == 0) n_partitions_hint = 1;
@@ -154,6 +155,11 @@ std::string pack_wbscsr(uint32_t rows, uint32_t cols, uint64_t nnz, const uint32
                 // Rows are contiguous, so the first row that ENDS in a packet is the row of its first entry
                 // (if that row does not end here, no row does and the value is unused).
                 if (stream_slot == 0) prow[pk] = r;
+                if (precision == Precision::FIXED20) {  // value, column and flags in one dword; no column-word region
+                    const uint32_t w = fixed20_word(to_fixed(v, fixed_width), (uint32_t)(cw >> COLW_COL_SHIFT), cw & 3u);
+                    std::memcpy(pkt + (size_t)slot * 4, &w, 4);
+                    continue;
+                }
                 if (precision == Precision::F32) {
                     std::memcpy(pkt + (size_t)slot * 4, &v, 4);
                 } else if (precision == Precision::F16) {
@@ -190,9 +196,17 @@ void decode_wbscsr(const PackedMatrix &pm, std::vector<uint32_t> &row, std::vect
             for (uint32_t ss = 0; ss < PE && rows_left; ++ss) {
                 const uint32_t s = slot_to_index(ss, pm.C);
                 uint16_t cw;
-                std::memcpy(&cw, pkt + (size_t)PE * vb + (size_t)s * 2, 2);
                 float v;
-                if (pm.precision == Precision::F32) {
+                if (pm.precision == Precision::FIXED20) {
+                    uint32_t w;
+                    std::memcpy(&w, pkt + (size_t)s * 4, 4);
+                    cw = (uint16_t)(w & 0xFFFu);
+                    v = from_fixed(w & 0xFFFFF000u);
+                } else {
+                    std::memcpy(&cw, pkt + (size_t)PE * vb + (size_t)s * 2, 2);
+                }
+                if (pm.precision == Precision::FIXED20) {
+                } else if (pm.precision == Precision::F32) {
                     std::memcpy(&v, pkt + (size_t)s * 4, 4);
                 } else if (pm.precision == Precision::F16) {
                     uint16_t hv;
@@ -313,8 +327,10 @@ std::string load_packed(const char *path, PackedMatrix &pm) {
     if (hd.version != 1) return fail("unsupported .tkspmv version");
     if ((hd.precision != (uint32_t)Precision::F32 && hd.precision != (uint32_t)Precision::Q1_7 &&
          hd.precision != (uint32_t)Precision::F16 && hd.precision != (uint32_t)Precision::FIXED &&
-         hd.precision != (uint32_t)Precision::Q1_7_RND) ||
-        (hd.precision == (uint32_t)Precision::FIXED ? (hd.fixed_width < 8 || hd.fixed_width > 32) : hd.fixed_width != 0) ||
+         hd.precision != (uint32_t)Precision::Q1_7_RND && hd.precision != (uint32_t)Precision::FIXED20) ||
+        (hd.precision == (uint32_t)Precision::FIXED20
+             ? (hd.fixed_width < 8 || hd.fixed_width > FIXED20_MAX_WIDTH || hd.cols > FIXED20_MAX_COLS)
+             : (hd.precision == (uint32_t)Precision::FIXED ? (hd.fixed_width < 8 || hd.fixed_width > 32) : hd.fixed_width != 0)) ||
         (hd.C != 4 && hd.C != 8) ||
         hd.packet_entries != 64 * hd.C ||
         hd.packet_bytes != hd.packet_entries * (value_bytes((Precision)hd.precision) + 2) ||
@@ -374,7 +390,13 @@ std::string load_packed(const char *path, PackedMatrix &pm) {
             const uint8_t *cwp = out.packets.data() + (size_t)p * hd.packet_bytes + vbytes;
             for (uint32_t s = 0; s < hd.packet_entries; ++s) {
                 uint16_t cw;
-                std::memcpy(&cw, cwp + (size_t)s * 2, 2);
+                if (hd.precision == (uint32_t)Precision::FIXED20) {
+                    uint32_t w;
+                    std::memcpy(&w, out.packets.data() + (size_t)p * hd.packet_bytes + (size_t)s * 4, 4);
+                    cw = (uint16_t)(w & 0xFFFu);
+                } else {
+                    std::memcpy(&cw, cwp + (size_t)s * 2, 2);
+                }
                 if ((uint32_t)(cw >> COLW_COL_SHIFT) >= hd.cols) return "column id out of range in the packet stream";
             }
         }

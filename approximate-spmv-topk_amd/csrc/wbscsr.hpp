@@ -22,6 +22,7 @@
 //     32 partitions -> HBM channels becomes n_CU * waves_per_CU partitions -> waves.
 #pragma once
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -51,14 +52,28 @@ TKSPMV_HD inline uint32_t slot_to_index(uint32_t s, uint32_t C) {
 
 // value type in the packet stream; FIXED = unsigned fixed point of `fixed_width` bits (1 integer bit), one u32 per value
 // Q1_7 = truncated (ap_ufixed<8,1,AP_TRN_ZERO>), Q1_7_RND = rounded to nearest (ap_ufixed<8,1,AP_RND>): same bytes per value.
-enum class Precision : int32_t { F32 = 0, Q1_7 = 1, F16 = 3, FIXED = 4, Q1_7_RND = 5 };
+// FIXED20 = fixed point of at most 20 bits with at most 1024 columns, ONE DWORD PER ENTRY (the reference's point at 20 / 25
+// bits is more entries per 512-bit transaction: B = 15 at 20 bits against 11 at 32, types.hpp:57-79): bits 31..12 = the
+// value (the top 20 bits of the left-aligned Q1.31 word of wbscsr's fixed-point type), bits 11..2 = the column -- so
+// (word & 0xFFC) is the LDS byte offset of x[col] -- and bits 1..0 = the ROW_END / SKIP flags of a column word. A packet
+// is [64 * C dwords] = 4 B per entry; there is no separate column-word region.
+enum class Precision : int32_t { F32 = 0, Q1_7 = 1, F16 = 3, FIXED = 4, Q1_7_RND = 5, FIXED20 = 6 };
+constexpr uint32_t FIXED20_MAX_WIDTH = 20, FIXED20_MAX_COLS = 1024;
 
+// bytes of a packet per entry, minus the 2 of a column word (FIXED20: 20-bit value + 10-bit column + 2 flags in 4 bytes)
 TKSPMV_HD inline uint32_t value_bytes(Precision p) {
-    return (p == Precision::F32 || p == Precision::FIXED) ? 4u : (p == Precision::F16 ? 2u : 1u);
+    return (p == Precision::F32 || p == Precision::FIXED) ? 4u : ((p == Precision::F16 || p == Precision::FIXED20) ? 2u : 1u);
+}
+TKSPMV_HD inline uint32_t fixed20_word(uint32_t q_left_aligned, uint32_t col, uint32_t flags) {
+    return (q_left_aligned & 0xFFFFF000u) | (col << 2) | flags;
 }
 // Value type of the stream for a tkspmv_precision (TKSPMV_Q1_7 and TKSPMV_Q1_7_WIDE share the truncated Q1.7 stream;
 // TKSPMV_Q1_7_F32 streams Q1.7 values rounded to nearest).
-inline Precision stream_precision(int32_t api_precision) {
+inline Precision stream_precision(int32_t api_precision, uint32_t fixed_width = 0, uint32_t cols = 0) {
+    // narrow fixed point with few columns travels bit-packed (TKSPMV_FIXED_UNPACKED=1 keeps one u32 per value + a column word)
+    if (api_precision == 4 && fixed_width >= 8 && fixed_width <= FIXED20_MAX_WIDTH && cols >= 1 && cols <= FIXED20_MAX_COLS &&
+        getenv("TKSPMV_FIXED_UNPACKED") == nullptr)
+        return Precision::FIXED20;
     switch (api_precision) {
         case 0: return Precision::F32;
         case 3: return Precision::F16;

@@ -32,6 +32,14 @@ def _sync_torch_first(fn):
 @pytest.fixture(scope="session")
 def pkg():
     import _pkg
+    try:
+        # torch brings its own HIP runtime; it must initialise BEFORE libtkspmv.so's (the image's ROCm) touches the device,
+        # or torch later reports "No HIP GPUs are available" (seen when a test created an engine before its first .cuda())
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
     mod = _pkg.load()
     for name in ("enqueue", "enqueue_many", "enqueue_batch", "enqueue_multi", "time_queries", "time_multi"):
         fn = getattr(mod.SpMV, name, None)

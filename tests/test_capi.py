@@ -60,7 +60,8 @@ def test_argument_validation_before_device(pkg):
     for kw, status in ((dict(k=0), pkg._lib.ERR_INVALID), (dict(k=2000), pkg._lib.ERR_INVALID),
                        (dict(k=8, precision=pkg.Q1_7, nnz_per_lane=8), pkg._lib.ERR_UNSUPPORTED),
                        (dict(k=8, precision=7), pkg._lib.ERR_INVALID),
-                       (dict(k=100, partitions=32, k_per_partition=8), pkg._lib.ERR_UNSUPPORTED)):
+                       (dict(k=8, impl=9), pkg._lib.ERR_INVALID),
+                       (dict(k=100, partitions=70000, k_per_partition=8), pkg._lib.ERR_INVALID)):
         with pytest.raises(pkg.TkspmvError) as e:
             pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, **kw)
         assert e.value.status == status, kw

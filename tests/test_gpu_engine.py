@@ -474,6 +474,57 @@ def test_fixed_point_full_size_precision_against_the_fp32_gold(pkg, oracle, widt
     eng.close()
 
 
+@pytest.mark.parametrize("width", [8, 16, 20])
+def test_narrow_fixed_point_travels_bit_packed(pkg, oracle, monkeypatch, width):
+    """W <= 20 bits and <= 1024 columns: one dword per entry (20-bit value | 10-bit column | 2 flags), 4 B/nnz -- the
+    reference's reason for narrow types is more entries per transaction (types.hpp:57-79: B = 15 at 20 bits, 11 at 32).
+    Same bits as the one-u32-per-value stream (TKSPMV_FIXED_UNPACKED=1) and as the integer model; wider words or more
+    columns keep 6 B/nnz."""
+    import torch
+    m = pkg.generate_matrix(120000, 1024, 20, "gamma", 12)
+    xs = np.stack([pkg.create_sample_vector(1024, True, False, True, 40 + i) for i in range(4)])
+    xs[1] *= np.float32(25.0)  # sums wrap at 2.0
+    eng = pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, k=100, device=0, precision=pkg.FIXED, fixed_width=width)
+    info = eng.info()
+    assert info["packed_bytes"] < 4.1 * m.nnz + 8 * m.rows and info["algorithmic_bytes"] == 4 * m.nnz + 4 * m.rows + 2 * 1024 + 800
+    monkeypatch.setenv("TKSPMV_FIXED_UNPACKED", "1")
+    wide = pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, k=100, device=0, precision=pkg.FIXED, fixed_width=width)
+    monkeypatch.delenv("TKSPMV_FIXED_UNPACKED")
+    assert wide.info()["packed_bytes"] > 5.9 * m.nnz
+    for q in range(2):
+        y, present = oracle.fixed_scores(m.row, m.col, m.val, xs[q], m.rows, width)
+        ei, ev = oracle.select_topk(y, present, 100)
+        for e in (eng, wide):
+            e.reset(xs[q])
+            e()
+            val, idx = e.read_result()
+            assert np.array_equal(idx, ei) and np.array_equal(val.view(np.uint32), ev.view(np.uint32))
+        assert np.array_equal(eng.scores().view(np.uint32), y.view(np.uint32))
+    dxs = torch.from_numpy(xs).cuda()
+    out_i = torch.zeros(4, 100, dtype=torch.int32, device="cuda")
+    out_v = torch.zeros(4, 100, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    eng.enqueue_batch(dxs.data_ptr(), 4, out_i.data_ptr(), out_v.data_ptr())  # the batch kernel on the packed stream
+    eng.synchronize()
+    for q in range(4):
+        y, present = oracle.fixed_scores(m.row, m.col, m.val, xs[q], m.rows, width)
+        ei, ev = oracle.select_topk(y, present, 100)
+        assert np.array_equal(out_i[q].cpu().numpy().view(np.uint32), ei) and np.array_equal(out_v[q].cpu().numpy().view(np.uint32), ev.view(np.uint32))
+    eng.close()
+    wide.close()
+    # 21 bits, or more than 1024 columns: one u32 per value + a column word
+    for w, cols in ((21, 1024), (20, 3000)):
+        mm = pkg.generate_matrix(5000, cols, 20, "gamma", 3)
+        e = pkg.SpMV(mm.row, mm.col, mm.val, mm.rows, mm.cols, k=10, device=0, precision=pkg.FIXED, fixed_width=w)
+        assert e.info()["packed_bytes"] > 5.9 * mm.nnz
+        e.close()
+    # the packed stream round-trips through the packer's decoder and the .tkspmv file format
+    p = pkg.Packed(m, k=100, nnz_per_lane=4, n_wave_partitions=4088, precision=pkg.FIXED, fixed_width=width)
+    r, c, v = p.decode()
+    assert np.array_equal(r, m.row) and np.array_equal(c, m.col)
+    assert np.array_equal(v, np.minimum(np.floor(m.val.astype(np.float64) * 2 ** (width - 1)), 2 ** width - 1).astype(np.float32) / np.float32(2 ** (width - 1)))
+
+
 def test_fixed_point_batch_equals_single_queries(pkg):
     import torch
     m = pkg.generate_matrix(70000, 1024, 20, "gamma", 31)
