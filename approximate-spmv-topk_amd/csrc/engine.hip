@@ -85,6 +85,20 @@ struct EngineImpl {
     mutable bool last_on_host = false;  // the most recent result is complete in h_res
     bool x_pending = false;             // an upload from h_x may still be in flight
     int host_path = 1;                  // TKSPMV_HOST_PATH=0: the plain path (stream synchronisation + copies)
+    // Resident kernel (desc.impl = TKSPMV_IMPL_RESIDENT; batch_kernel<.., RESIDENT = true>): one launch that stays on the
+    // GPU and serves tkspmv_run queries as the host submits them through pinned memory -- see BatchParams.
+    struct ResidentCtl {
+        volatile uint32_t request;  // host -> device: epoch of the newest submitted query, or RESIDENT_QUIT
+        uint32_t pad0[31];
+        volatile uint32_t exited;   // device -> host: 1 once the kernel has left (quit request or idle timeout)
+        uint32_t pad1[31];
+    };
+    ResidentCtl *h_ctl = nullptr, *h_ctl_dev = nullptr;
+    uint32_t *d_xr = nullptr, *d_dev_epoch = nullptr;
+    hipStream_t rstream = nullptr;
+    bool resident_capable = false;
+    mutable bool resident_running = false;
+    bool x_on_host_only = false;        // set_query left x in h_x without uploading it (resident engines): see ensure_x
     float *h_x_dev = nullptr;           // h_x as the device sees it (TKSPMV_HOST_X=direct: kernels read x from host memory)
     bool host_x_direct = false;
     bool run_events = true;             // TKSPMV_RUN_EVENTS=0 (experiment): tkspmv_run reports host-clock time, no events
@@ -499,6 +513,61 @@ struct EngineImpl {
         S.unit_inv_in = st[set].unit_inv;  // written by the (unfused) stream kernel of that query
         hipLaunchKernelGGL(select_kernel, dim3(1), dim3(SEL_THREADS), 0, s, S);
     }
+    // ---- resident kernel -------------------------------------------------------------------------------------------------
+    hipError_t start_resident() const {
+        hipError_t e = hipMemsetAsync(d_dev_epoch, 0, 64, rstream);
+        if (e != hipSuccess) return e;
+        h_ctl->exited = 0u;
+        h_ctl->request = host_epoch;  // nothing pending: the next query is host_epoch + 1
+        std::atomic_thread_fence(std::memory_order_seq_cst);
+        StreamParams P = stream_params(nullptr, 0);
+        P.fused = 0u;
+        SelectParams S = select_params(d_out_idx, d_out_val, 0);
+        S.host_out = h_res_dev;
+        BatchParams B{};
+        static_cast<SetAddr &>(B) = set_addr(0);
+        B.n_q = 0u;
+        B.tickets = d_tickets;
+        B.io[0].out_idx = d_out_idx;
+        B.io[0].out_val = d_out_val;
+        B.host_request = const_cast<const uint32_t *>(&h_ctl_dev->request);
+        B.host_exited = const_cast<uint32_t *>(&h_ctl_dev->exited);
+        B.host_x = h_x_dev;
+        B.xr = d_xr;
+        B.dev_epoch = d_dev_epoch;
+        B.epoch0 = host_epoch;
+        B.idle_ticks = resident_idle_ticks;
+        B.n_replicas = d_replicas.empty() ? 1u : (uint32_t)std::min<size_t>(d_replicas.size(), 8);
+        for (uint32_t r = 0; r < 8u; ++r) B.replicas[r] = d_replicas.empty() ? d_packets : d_replicas[r % d_replicas.size()];
+        hipLaunchKernelGGL((batch_kernel<4, 1024, 0, false, true>), dim3(grid), dim3(block + 64), 0, rstream, P, S, B);
+        e = hipGetLastError();
+        resident_running = e == hipSuccess;
+        return e;
+    }
+    // Ask the resident kernel to leave and wait for it (bounded: it also leaves by itself after its idle timeout).
+    hipError_t stop_resident() const {
+        if (!resident_running) return hipSuccess;
+        h_ctl->request = RESIDENT_QUIT;
+        std::atomic_thread_fence(std::memory_order_seq_cst);
+        const hipError_t e = hipStreamSynchronize(rstream);
+        resident_running = false;
+        return e;
+    }
+    uint32_t resident_idle_ticks = 10000000u;  // 100 ms without a query: the kernel leaves (relaunched on demand)
+    // x of the last tkspmv_set_query into device memory, if a resident engine left it in pinned memory only
+    hipError_t ensure_x() {
+        if (!x_on_host_only) return hipSuccess;
+        x_on_host_only = false;
+        x_pending = true;
+        return hipMemcpyAsync(d_x, h_x, (size_t)desc.cols * 4, hipMemcpyHostToDevice, stream);
+    }
+    // Every entry point other than set_query / run / read: the resident kernel must have left (it shares the exchange
+    // state and would compete for the whole GPU), and x must be where the launch schemes expect it.
+    hipError_t leave_resident_mode() {
+        hipError_t e = stop_resident();
+        if (e != hipSuccess) return e;
+        return ensure_x();
+    }
 };
 
 uint64_t algorithmic_bytes(uint64_t nnz, uint32_t rows, uint32_t cols, uint32_t vbytes, int k) {
@@ -519,7 +588,8 @@ void fill_info(const PackedMatrix &pm, int k, tkspmv_info *out) {
     out->n_wave_partitions = (uint32_t)pm.part_first.size();
     out->packets_per_partition = pm.packets_per_partition;
     out->k = k;
-    out->precision = (int32_t)pm.precision;
+    // (the bit-packed narrow fixed-point stream is a layout of TKSPMV_FIXED, not a precision of the API)
+    out->precision = pm.precision == Precision::FIXED20 ? (int32_t)Precision::FIXED : (int32_t)pm.precision;
     out->fixed_width = pm.fixed_width;
 }
 
@@ -538,6 +608,7 @@ Engine::~Engine() {
     if (!impl_) return;
     EngineImpl &m = *impl_;
     (void)hipSetDevice(m.device);
+    (void)m.stop_resident();  // before anything is freed (hipFree would wait for it, then free what it reads)
     if (m.stream) (void)hipStreamSynchronize(m.stream);
     void *bufs[] = {m.d_packets, m.d_pkt_row, m.d_part_first, m.d_part_count, m.d_x,
                     m.d_out_idx, m.d_out_val, m.d_scores,     m.d_stats,      m.d_done, m.d_trace, m.d_tickets};
@@ -549,6 +620,10 @@ Engine::~Engine() {
         for (void *b : eb)
             if (b) (void)hipFree(b);
     }
+    if (m.rstream) (void)hipStreamDestroy(m.rstream);
+    if (m.h_ctl) (void)hipHostFree((void *)m.h_ctl);
+    if (m.d_xr) (void)hipFree(m.d_xr);
+    if (m.d_dev_epoch) (void)hipFree(m.d_dev_epoch);
     if (m.h_x) (void)hipHostFree(m.h_x);
     if (m.h_res) (void)hipHostFree(m.h_res);
     for (size_t r = 1; r < m.d_replicas.size(); ++r) (void)hipFree(m.d_replicas[r]);
@@ -597,8 +672,8 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
         err = "unknown precision";
         return TKSPMV_ERR_INVALID;
     }
-    if (d.impl != TKSPMV_IMPL_STREAM && d.impl != TKSPMV_IMPL_ROW_PER_LANE && d.impl != TKSPMV_IMPL_SCORES_SELECT) {
-        err = "unknown impl (0 = stream, 1 = row per lane, 2 = scores + select)";
+    if (d.impl != TKSPMV_IMPL_STREAM && d.impl != TKSPMV_IMPL_ROW_PER_LANE && d.impl != TKSPMV_IMPL_SCORES_SELECT && d.impl != TKSPMV_IMPL_RESIDENT) {
+        err = "unknown impl (0 = stream, 1 = row per lane, 2 = scores + select, 3 = resident)";
         return TKSPMV_ERR_INVALID;
     }
     if (d.precision == TKSPMV_FIXED ? (d.fixed_width != 0 && (d.fixed_width < 8 || d.fixed_width > 32)) : d.fixed_width != 0) {
@@ -906,6 +981,19 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
             }
         }
     }
+    m.resident_capable = d.impl == TKSPMV_IMPL_RESIDENT && m.can_batch && d.precision == TKSPMV_F32 && C == 4u && m.xcols <= 1024u &&
+                         m.h_res != nullptr && m.h_x != nullptr && m.h_x_dev != nullptr;
+    if (m.resident_capable) {
+        HIP_TRY(hipHostMalloc((void **)&m.h_ctl, sizeof(EngineImpl::ResidentCtl), hipHostMallocMapped | hipHostMallocCoherent));
+        std::memset((void *)m.h_ctl, 0, sizeof(EngineImpl::ResidentCtl));
+        HIP_TRY(hipHostGetDevicePointer((void **)&m.h_ctl_dev, m.h_ctl, 0));
+        HIP_TRY(malloc_exchange((void **)&m.d_xr, 2 * 1024 * 4));
+        HIP_TRY(hipMemset(m.d_xr, 0, 2 * 1024 * 4));
+        HIP_TRY(malloc_exchange((void **)&m.d_dev_epoch, 64));
+        HIP_TRY(hipMemset(m.d_dev_epoch, 0, 64));
+        HIP_TRY(hipStreamCreateWithFlags(&m.rstream, hipStreamNonBlocking));
+        if (const char *f = getenv("TKSPMV_RESIDENT_IDLE_MS")) m.resident_idle_ticks = (uint32_t)std::max(1, atoi(f)) * 100000u;
+    }
     HIP_TRY(malloc_exchange((void **)&m.d_tickets, BATCH_MAX * 32 * 4));
     HIP_TRY(hipMemset(m.d_tickets, 0, BATCH_MAX * 32 * 4));
     {
@@ -960,6 +1048,7 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
         fprintf(stderr, "[tkspmv] workgroups per CU by the runtime's occupancy calculator: stream kernel %d, batch kernel %d; LDS per CU %zu\n",
                 n1, n2, (size_t)prop.maxSharedMemoryPerMultiProcessor);
     }
+    m.info.precision = d.precision;  // the API's enum (fill_info reports the value type of the stream)
     m.info.grid = m.grid;
     m.info.block = m.block;
     m.info.n_groups = m.n_sets ? m.n_groups_pub : 0;
@@ -1015,8 +1104,12 @@ int Engine::set_query(const float *host_x, double *elapsed_ns, std::string &err)
         // (an earlier upload from the staging copy must have been consumed before it is overwritten)
         if (m.x_pending) HIP_TRY(hipStreamSynchronize(m.stream));
         std::memcpy(m.h_x, host_x, (size_t)m.desc.cols * 4);
-        if (!m.host_x_direct) HIP_TRY(hipMemcpyAsync(m.d_x, m.h_x, (size_t)m.desc.cols * 4, hipMemcpyHostToDevice, m.stream));
-        m.x_pending = true;
+        // resident engines: the kernel fetches x from the pinned copy itself; the upload happens only if another entry
+        // point needs x in device memory (ensure_x)
+        m.x_on_host_only = m.resident_capable;
+        if (!m.host_x_direct && !m.x_on_host_only)
+            HIP_TRY(hipMemcpyAsync(m.d_x, m.h_x, (size_t)m.desc.cols * 4, hipMemcpyHostToDevice, m.stream));
+        m.x_pending = !m.x_on_host_only;
         m.d_x_cur = m.host_x_direct ? m.h_x_dev : m.d_x;
         m.have_query = true;
         if (elapsed_ns)
@@ -1041,6 +1134,7 @@ int Engine::set_query_device(const float *dev_x, std::string &err) {
         return TKSPMV_ERR_INVALID;
     }
     impl_->d_x_cur = dev_x;
+    impl_->x_on_host_only = false;
     impl_->have_query = true;
     return TKSPMV_OK;
 }
@@ -1054,6 +1148,7 @@ int Engine::enqueue(const float *dev_x, uint32_t *dev_idx, float *dev_val, void 
     }
     hipStream_t s = stream ? (hipStream_t)stream : m.stream;
     HIP_TRY(hipSetDevice(m.device));
+    HIP_TRY(m.leave_resident_mode());
     m.launch_query(x, dev_idx ? dev_idx : m.d_out_idx, dev_val ? dev_val : m.d_out_val, s);
     HIP_TRY(hipGetLastError());
     m.ran = true;
@@ -1083,6 +1178,7 @@ int Engine::enqueue_many(const float *dev_xs, int32_t n_x, int32_t count, void *
     }
     hipStream_t s = stream ? (hipStream_t)stream : m.stream;
     HIP_TRY(hipSetDevice(m.device));
+    HIP_TRY(m.leave_resident_mode());
     std::vector<const float *> xs;
     std::vector<uint32_t *> oi;
     std::vector<float *> ov;
@@ -1103,6 +1199,7 @@ int Engine::enqueue_batch(const float *dev_xs, int32_t count, uint32_t *dev_idx,
     }
     hipStream_t s = stream ? (hipStream_t)stream : m.stream;
     HIP_TRY(hipSetDevice(m.device));
+    HIP_TRY(m.leave_resident_mode());
     std::vector<const float *> xs;
     std::vector<uint32_t *> oi;
     std::vector<float *> ov;
@@ -1124,6 +1221,7 @@ int Engine::enqueue_list(const float *const *dev_xs, uint32_t *const *dev_idx, f
     }
     hipStream_t s = stream ? (hipStream_t)stream : m.stream;
     HIP_TRY(hipSetDevice(m.device));
+    HIP_TRY(m.leave_resident_mode());
     m.launch_sequence(dev_xs, dev_idx, dev_val, count, s);
     HIP_TRY(hipGetLastError());
     m.ran = true;
@@ -1141,6 +1239,7 @@ int Engine::enqueue_multi(const float *dev_xs, int32_t count, uint32_t *dev_idx,
     }
     hipStream_t s = stream ? (hipStream_t)stream : m.stream;
     HIP_TRY(hipSetDevice(m.device));
+    HIP_TRY(m.leave_resident_mode());
     std::vector<const float *> xs;
     std::vector<uint32_t *> oi;
     std::vector<float *> ov;
@@ -1162,6 +1261,7 @@ int Engine::enqueue_multi_list(const float *const *dev_xs, uint32_t *const *dev_
     }
     hipStream_t s = stream ? (hipStream_t)stream : m.stream;
     HIP_TRY(hipSetDevice(m.device));
+    HIP_TRY(m.leave_resident_mode());
     m.launch_multi_sequence(dev_xs, dev_idx, dev_val, count, s);
     HIP_TRY(hipGetLastError());
     m.ran = true;
@@ -1176,6 +1276,7 @@ int Engine::time_multi(const float *dev_xs, int32_t n_x, int32_t iters, double *
         return TKSPMV_ERR_INVALID;
     }
     HIP_TRY(hipSetDevice(m.device));
+    HIP_TRY(m.leave_resident_mode());
     HIP_TRY(hipStreamSynchronize(m.stream));
     HIP_TRY(hipEventRecord(m.ev0, m.stream));
     {
@@ -1220,6 +1321,7 @@ int Engine::enqueue_deferred(const float *dev_x, uint32_t *dev_idx, float *dev_v
     }
     hipStream_t s = stream ? (hipStream_t)stream : m.stream;
     HIP_TRY(hipSetDevice(m.device));
+    HIP_TRY(m.leave_resident_mode());
     m.launch_deferred(dev_x, dev_idx ? dev_idx : m.d_out_idx, dev_val ? dev_val : m.d_out_val, s);
     HIP_TRY(hipGetLastError());
     m.ran = true;
@@ -1231,6 +1333,7 @@ int Engine::drain(void *stream, std::string &err) {
     EngineImpl &m = *impl_;
     hipStream_t s = stream ? (hipStream_t)stream : m.stream;
     HIP_TRY(hipSetDevice(m.device));
+    HIP_TRY(m.leave_resident_mode());
     m.drain(s);
     HIP_TRY(hipGetLastError());
     return TKSPMV_OK;
@@ -1243,6 +1346,50 @@ int Engine::run(double *kernel_ns, std::string &err) {
         return TKSPMV_ERR_STATE;
     }
     HIP_TRY(hipSetDevice(m.device));
+    if (m.resident_capable && m.x_on_host_only) {
+        // ---- resident kernel: submit through pinned memory, poll the result flag ----------------------------------------
+        if (!m.resident_running || m.h_ctl->exited) {
+            if (m.resident_running) HIP_TRY(hipStreamSynchronize(m.rstream));
+            m.drain(m.stream);
+            HIP_TRY(hipStreamSynchronize(m.stream));  // the sets and result buffers are shared with the other launch schemes
+            HIP_TRY(m.start_resident());
+        }
+        const uint32_t epoch = ++m.host_epoch;
+        std::atomic_thread_fence(std::memory_order_release);  // x (h_x) before the request
+        m.h_ctl->request = epoch;
+        volatile uint32_t *flag = m.h_res + 2 * (size_t)m.desc.k;
+        const auto t0 = std::chrono::steady_clock::now();
+        bool seen = false;
+        for (uint64_t spins = 0;; ++spins) {
+            if (*flag == epoch) {
+                seen = true;
+                break;
+            }
+            __builtin_ia32_pause();
+            if ((spins & 0x3FFu) == 0x3FFu) {
+                if (m.h_ctl->exited && *flag != epoch) {
+                    // the kernel's idle timeout fired just before this request: start it again, the request stands
+                    HIP_TRY(hipStreamSynchronize(m.rstream));
+                    --m.host_epoch;  // start_resident numbers the next query host_epoch + 1 = epoch
+                    HIP_TRY(m.start_resident());
+                    m.host_epoch = epoch;
+                    m.h_ctl->request = epoch;
+                }
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) break;  // never hang on the flag
+            }
+        }
+        if (!seen) {
+            (void)m.stop_resident();
+            err = "the resident kernel did not answer within 5 s";
+            return TKSPMV_ERR_DEVICE;
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        if (kernel_ns) *kernel_ns = (double)m.h_res[2 * (size_t)m.desc.k + 1] * 10.0;  // device time of the query (100 MHz ticks)
+        m.ran = true;
+        m.last_on_host = true;
+        return TKSPMV_OK;
+    }
+    HIP_TRY(m.leave_resident_mode());
     // The fused single launch can hand its result to the host itself (see h_res); the other launch schemes (radix select,
     // row per lane, unfused selection) complete in stream order and are waited for with the event.
     const bool to_host = m.host_path && m.h_res && m.fused && !m.use_radix && !(m.desc.impl == TKSPMV_IMPL_ROW_PER_LANE && m.can_multi);
@@ -1294,6 +1441,7 @@ int Engine::run(double *kernel_ns, std::string &err) {
 
 int Engine::synchronize(std::string &err) {
     HIP_TRY(hipSetDevice(impl_->device));
+    HIP_TRY(impl_->leave_resident_mode());
     impl_->drain(impl_->stream);
     HIP_TRY(hipStreamSynchronize(impl_->stream));
     return TKSPMV_OK;
@@ -1327,6 +1475,7 @@ int Engine::read_trace(unsigned long long *host, size_t max_words, size_t *words
         return TKSPMV_ERR_STATE;
     }
     HIP_TRY(hipSetDevice(m.device));
+    HIP_TRY(m.leave_resident_mode());
     HIP_TRY(hipDeviceSynchronize());
     const size_t n = std::min(max_words, m.trace_words * 4);
     HIP_TRY(hipMemcpy(host, m.d_trace, n * 8, hipMemcpyDeviceToHost));
@@ -1347,6 +1496,7 @@ int Engine::scores(float *host_y, std::string &err) {
         return TKSPMV_ERR_STATE;
     }
     HIP_TRY(hipSetDevice(m.device));
+    HIP_TRY(m.leave_resident_mode());
     if (!m.d_scores) HIP_TRY(hipMalloc((void **)&m.d_scores, std::max<size_t>(m.desc.rows, 1) * 4));
     HIP_TRY(hipMemsetAsync(m.d_scores, 0, std::max<size_t>(m.desc.rows, 1) * 4, m.stream));
     m.launch_scores(m.d_x_cur, m.stream);
@@ -1363,6 +1513,7 @@ int Engine::time_queries(const float *dev_xs, int32_t n_x, int32_t iters, double
         return TKSPMV_ERR_INVALID;
     }
     HIP_TRY(hipSetDevice(m.device));
+    HIP_TRY(m.leave_resident_mode());
     HIP_TRY(hipStreamSynchronize(m.stream));
     HIP_TRY(hipEventRecord(m.ev0, m.stream));
     {
@@ -1390,6 +1541,7 @@ int Engine::profile(const float *dev_xs, int32_t n_x, int32_t iters, tkspmv_timi
     }
     std::memset(out, 0, sizeof(*out));
     HIP_TRY(hipSetDevice(m.device));
+    HIP_TRY(m.leave_resident_mode());
     HIP_TRY(hipStreamSynchronize(m.stream));
     unsigned long long st0[8], st1[8];
     HIP_TRY(hipMemcpy(st0, m.d_stats, sizeof(st0), hipMemcpyDeviceToHost));

@@ -59,7 +59,25 @@ struct BatchParams : SetAddr {
     uint32_t n_q;
     uint32_t *tickets;  // [BATCH_MAX] counters, 32 words apart
     BatchIO io[BATCH_MAX];
+    // ---- resident mode (RESIDENT = true; tkspmv_run with desc.impl = TKSPMV_IMPL_RESIDENT) -------------------------------
+    // ONE launch serves queries as the host submits them: no launch, no copy engine, no stream synchronisation per query.
+    // The host writes x into pinned memory and raises `request` (an epoch counter); the doorman -- wave 0 of the selector
+    // workgroup, idle between selections anyway -- polls it, copies x into one of two device-side buffers and publishes the
+    // query number in `dev_epoch`, which the server waves poll; the query then runs exactly like a query of a batch (its
+    // exchange-state set is q mod BATCH_MAX, its stream copy q mod n_replicas); the selection writes the k results and the
+    // epoch to pinned host memory (SelectParams::host_out), where the host polls. The kernel leaves when the host asks
+    // (request = RESIDENT_QUIT) or when no request has arrived for idle_ticks: every wait of every wave ends with it.
+    const uint32_t *host_request;  // pinned host word: epoch of the newest submitted query, or RESIDENT_QUIT
+    uint32_t *host_exited;         // pinned host word: set to 1 when the kernel has left
+    const float *host_x;           // pinned host copy of x (XCOLS floats)
+    uint32_t *xr;                  // fine-grained device memory: [2][XCOLS] query vectors as the doorman copied them
+    uint32_t *dev_epoch;           // fine-grained device word: queries published so far (local numbering), or RESIDENT_QUIT
+    uint32_t epoch0;               // host epoch of local query q is epoch0 + q + 1
+    uint32_t idle_ticks;           // x 10 ns
+    uint32_t n_replicas;
+    const uint8_t *replicas[8];
 };
+constexpr uint32_t RESIDENT_QUIT = 0xFFFFFFFFu;
 
 template <int XCOLS, int C = 4>
 struct BatchLds {
@@ -92,7 +110,7 @@ __device__ __forceinline__ uint32_t lds_load(const uint32_t *p) {
 // DBG = false (production): the tracing / statistics / ablation hooks of StreamParams (trace, dbg, dbg_flags) are compiled
 // out -- no per-packet compare of a tracing word or an ablation flag, and the scalar registers they held are free. The
 // engine launches the DBG = true instantiation only when TKSPMV_TRACE / TKSPMV_STATS / TKSPMV_DBG_FLAGS ask for it.
-template <int C, int XCOLS, int QM, bool DBG = false>
+template <int C, int XCOLS, int QM, bool DBG = false, bool RESIDENT = false>
 __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg, const SelectParams SP0, const BatchParams B) {
     StreamParams P0 = P0_arg;
     if (!DBG) {
@@ -113,31 +131,84 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t nwaves = (blockDim.x >> 6) - 1u;  // streaming waves
     const bool is_server = (wave == nwaves);
-    const uint32_t nq = B.n_q;
+    const uint32_t nq = RESIDENT ? 0xFFFFFFF0u : B.n_q;
+    // exchange-state set / ticket counter of query q (resident: the sets are reused round robin -- one query is in flight)
+    auto set_of = [](uint32_t q) -> uint32_t { return RESIDENT ? q % (uint32_t)BATCH_MAX : q; };
 
     if (blockIdx.x == 0u) {
         // ---- selector workgroup ------------------------------------------------------------------------------
         const uint32_t n_stream = gridDim.x - 1u;
         for (uint32_t q = 0; q < nq; ++q) {
+            unsigned long long t_seen = 0ull;
+            if (RESIDENT) {
+                // doorman: wait for the host to submit query q (bounded), fetch its x, publish it to the server waves
+                if (wave == 0u) {
+                    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                    uint32_t quit = 0u;
+                    for (;;) {
+                        const uint32_t r = __hip_atomic_load(B.host_request, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        if (r == RESIDENT_QUIT) {
+                            quit = 1u;
+                            break;
+                        }
+                        if ((int32_t)(r - (B.epoch0 + q + 1u)) >= 0) break;
+                        if (__builtin_amdgcn_s_memrealtime() - t0 > (unsigned long long)B.idle_ticks) {
+                            quit = 1u;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(8);
+                    }
+                    t_seen = __builtin_amdgcn_s_memrealtime();
+                    if (!quit) {
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // x was written before the request
+                        uint32_t *dst = B.xr + (size_t)(q & 1u) * XCOLS;
+                        uint32_t r[XCOLS / 64];
+#pragma unroll
+                        for (int u = 0; u < XCOLS / 64; ++u) {
+                            const uint32_t i = lane + 64u * (uint32_t)u;
+                            r[u] = i < P0.cols ? __hip_atomic_load(reinterpret_cast<const uint32_t *>(B.host_x) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0u;
+                        }
+#pragma unroll
+                        for (int u = 0; u < XCOLS / 64; ++u)
+                            __hip_atomic_store(&dst[lane + 64u * (uint32_t)u], r[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    }
+                    if (lane == 0) {
+                        __hip_atomic_store(B.dev_epoch, quit ? RESIDENT_QUIT : q + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        L.u.sel.last = quit;
+                    }
+                }
+                __syncthreads();
+                if (L.u.sel.last) {
+                    if (tid == 0) __hip_atomic_store(B.host_exited, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    return;
+                }
+                __syncthreads();
+            }
             if (tid == 0) {
-                uint32_t *t = B.tickets + 32u * q;
+                uint32_t *t = B.tickets + 32u * set_of(q);
                 // Polled with a compare-and-swap (which also resets the counter for the next launch): atomics execute
                 // at the device-wide coherence point, whereas a load -- even agent-scope -- can keep hitting a stale
                 // copy of the line in this XCD's L2 (seen: 33 ms on an otherwise idle L2).
-                while (atomicCAS(t, n_stream, 0u) != n_stream) __builtin_amdgcn_s_sleep(32);
+                while (atomicCAS(t, n_stream, 0u) != n_stream) __builtin_amdgcn_s_sleep(RESIDENT ? 4 : 32);
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             }
             __syncthreads();
             SelectParams S = SP0;
-            S.wg_cand = B.wg_cand(q);
-            S.ovf_cand = B.ovf_cand(q);
-            S.ovf_count = B.ovf_count(q);
-            S.gmax = B.gmax(q);
-            S.tau_g = B.tau_g(q);
+            S.wg_cand = B.wg_cand(set_of(q));
+            S.ovf_cand = B.ovf_cand(set_of(q));
+            S.ovf_count = B.ovf_count(set_of(q));
+            S.gmax = B.gmax(set_of(q));
+            S.tau_g = B.tau_g(set_of(q));
             S.scratch = B.scratch;
-            S.unit_inv_in = B.unit_inv(q);
-            S.out_idx = B.io[q].out_idx;
-            S.out_val = B.io[q].out_val;
+            S.unit_inv_in = B.unit_inv(set_of(q));
+            S.out_idx = B.io[RESIDENT ? 0u : q].out_idx;
+            S.out_val = B.io[RESIDENT ? 0u : q].out_val;
+            if (RESIDENT) {
+                S.host_epoch = B.epoch0 + q + 1u;  // (host_out comes with SP0)
+                S.wt_reset = 1u;                   // the sets are reused within this launch: resets must be written through
+                S.t_seen = t_seen;                 // (wave 0 holds it; thread 0 reports the query's device time)
+            }
             select_body(S, tid, blockDim.x, L.u.sel);
             __syncthreads();
             if (P0.trace && tid == 0 && q < 8u) P0.trace[q] = __builtin_amdgcn_s_memrealtime();
@@ -174,13 +245,39 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
         if (reducer) __builtin_amdgcn_s_setprio(3);
 #endif
         uint32_t staged = 0u, tail = 0u;
+        uint32_t published = RESIDENT ? 0u : nq;  // queries whose x is available (resident: as the doorman publishes them)
         float inv_unit_q[2] = {1.0f, 1.0f}, min_units_q[2] = {0.0f, 0.0f};
         unsigned long long dbg_first_duty = 0ull;
         uint32_t dbg_iters = 0u;
         for (;;) {
-            if (staged < nq && staged - tail < 2u) {
+            if (RESIDENT && tail == staged) {
+                // Nothing in flight in this workgroup: look for the next query (only then: 512 servers polling one word
+                // while the matrix streams would take bandwidth from the stream). RESIDENT_QUIT: tell the streaming waves
+                // -- they wait on the x flags -- and leave.
+                const uint32_t e = __hip_atomic_load(B.dev_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (e == RESIDENT_QUIT) {
+                    if (lane == 0) {
+                        __hip_atomic_store(&L.misc[0][MISC_XREADY], RESIDENT_QUIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_store(&L.misc[1][MISC_XREADY], RESIDENT_QUIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                    return;
+                }
+                published = e;
+                if (published == staged) {
+                    __builtin_amdgcn_s_sleep(16);
+                    continue;
+                }
+            }
+            if (staged < nq && staged < published && staged - tail < 2u) {
                 const uint32_t par = staged & 1u;
-                const float *xg = B.io[staged].x;
+                const float *xg = RESIDENT ? reinterpret_cast<const float *>(B.xr + (size_t)par * XCOLS) : B.io[staged].x;
+                // (resident: the two device-side copies of x are rewritten in place query after query; they live in fine-
+                //  grained memory and are read with agent-scope loads, so no cache can serve a previous query's x)
+                auto x_at = [&](uint32_t i) __attribute__((always_inline)) -> float {
+                    if (RESIDENT)
+                        return __uint_as_float(__hip_atomic_load(reinterpret_cast<const uint32_t *>(xg) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    return xg[i];
+                };
                 float x_scale = 1.0f, unit_scale = 1.0f;
                 if (QM == 2) {
                     float lm = 0.0f;
@@ -190,7 +287,7 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
 #pragma unroll
                         for (int u = 0; u < 16; ++u) {
                             const uint32_t i = b0 + lane + 64u * (uint32_t)u;
-                            r[u] = (i < P0.cols) ? xg[i] : 0.0f;
+                            r[u] = (i < P0.cols) ? x_at(i) : 0.0f;
                         }
 #pragma unroll
                         for (int u = 0; u < 16; ++u) lm = fmaxf(lm, r[u]);
@@ -218,7 +315,7 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
 #pragma unroll
                     for (int u = 0; u < 16; ++u) {
                         const uint32_t i = b0 + lane + 64u * (uint32_t)u;
-                        r[u] = (i < P0.cols) ? xg[i] : 0.0f;
+                        r[u] = (i < P0.cols) ? x_at(i) : 0.0f;
                     }
 #pragma unroll
                     for (int u = 0; u < 16; ++u) {
@@ -256,8 +353,8 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
                 {
                     const uint32_t sq = hq;
                     StreamParams P = P0;
-                    P.gmax = B.gmax(sq);
-                    P.tau_g = B.tau_g(sq);
+                    P.gmax = B.gmax(set_of(sq));
+                    P.tau_g = B.tau_g(set_of(sq));
                     uint32_t *mp = L.misc[sq & 1u];
                     const float min_units = min_units_q[sq & 1u];
                     publish_group_max(P, bid, lane, mp);
@@ -291,7 +388,7 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
                 if (tail < staged && __builtin_amdgcn_readfirstlane(lds_load(&mp[MISC_DONE])) >= n_active) {
                     asm volatile("" ::: "memory");
                     StreamParams P = P0;
-                    P.gmax = B.gmax(tail);
+                    P.gmax = B.gmax(set_of(tail));
                     if (P0.n_sets != 0u) publish_group_max(P, bid, lane, mp);  // complete maxima (fire and forget)
                     if (P0.dbg && lane == 0) {  // TKSPMV_STATS=1
                         atomicAdd(&P0.dbg[0], (unsigned long long)mp[MISC_SLOW_CNT]);
@@ -307,22 +404,22 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
                     const uint64_t bm = __ballot(extra);
                     uint32_t gbase = 0u;
                     if (bm) {
-                        if (lane == 0) gbase = atomicAdd(B.ovf_count(tail), (uint32_t)__popcll(bm));
+                        if (lane == 0) gbase = atomicAdd(B.ovf_count(set_of(tail)), (uint32_t)__popcll(bm));
                         gbase = __builtin_amdgcn_readfirstlane(gbase);
                     }
-                    if (have && e == 0u) st_agent(B.wg_cand(tail) + (size_t)bid * WG_SLOTS + w, v);
+                    if (have && e == 0u) st_agent(B.wg_cand(set_of(tail)) + (size_t)bid * WG_SLOTS + w, v);
                     if (extra) {
                         const uint32_t gp = gbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
-                        if (gp < P0.ovf_cap) st_agent(&B.ovf_cand(tail)[gp], v);
+                        if (gp < P0.ovf_cap) st_agent(&B.ovf_cand(set_of(tail))[gp], v);
                     }
                     if (bid == 0u && lane == 0)
-                        __hip_atomic_store(B.unit_inv(tail), inv_unit_q[tp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(B.unit_inv(set_of(tail)), inv_unit_q[tp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     // Hand-off as in the fused tail (cdna_hip_programming.md Guideline 16): everything above is a
                     // write-through (sc1) store; drain them, then a RELAXED agent-scope add. A release-ordered atomic
                     // would write back the whole L2 (buffer_wbl2) once per workgroup and query: measured 4 ms/query.
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     if (lane == 0)
-                        (void)__hip_atomic_fetch_add(B.tickets + 32u * tail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        (void)__hip_atomic_fetch_add(B.tickets + 32u * set_of(tail), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (trw && lane == 0 && TRSLOT(tail) < 3u) trw[4 + TRSLOT(tail)] = __builtin_amdgcn_s_memrealtime();
                     if (trw && lane == 0 && TRSLOT(tail) == 1u) {
                         trw[3] = dbg_first_duty;
@@ -357,9 +454,9 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
     // as many scalar as vector instructions, ~100 per packet, a third of them in this bookkeeping).
     uint32_t qa = 0u;
     const size_t part_off = (size_t)p0 * P0.packet_bytes;
-    const uint8_t *pk_a = B.io[0].packets + part_off;
+    const uint8_t *pk_a = (RESIDENT ? B.replicas[0] : B.io[0].packets) + part_off;
     const uint32_t *row_a = P0.pkt_row + p0;
-    uint32_t left_q = np, left_all = np * nq;
+    uint32_t left_q = np, left_all = RESIDENT ? 0xFFFFFFFFu : np * nq;
 #define TKSPMV_REQUEST(dst, rb_dst)                                                                                   \
     do {                                                                                                              \
         load_packet<C, VT>(pk_a, lane, dst);                                                                          \
@@ -371,7 +468,7 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
             if (--left_q == 0u) {                                                                                     \
                 left_q = np;                                                                                          \
                 ++qa;                                                                                                 \
-                pk_a = B.io[qa].packets + part_off;                                                                   \
+                pk_a = (RESIDENT ? B.replicas[qa % B.n_replicas] : B.io[qa].packets) + part_off;                     \
                 row_a = P0.pkt_row + p0;                                                                              \
             }                                                                                                         \
         }                                                                                                             \
@@ -391,23 +488,28 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
     constexpr uint32_t DEFER_B = (uint32_t)BatchLds<XCOLS, C>::DEFER_B;
     static_assert(C == 4 || C == 8, "the batch kernel is built for 4 or 8 entries per lane");
 
-    const uint32_t total = np * nq;
-    for (uint32_t i0 = 0; i0 < total; i0 += NBUF) {
+    const uint32_t total = RESIDENT ? 0xFFFFFFFFu : np * nq;
+    for (uint32_t i0 = 0; RESIDENT || i0 < total; i0 += NBUF) {  // (resident: left through the quit signal below)
 #pragma unroll
         for (int u = 0; u < NBUF; ++u) {
-            if (i0 + (uint32_t)u >= total) break;
+            if (!RESIDENT && i0 + (uint32_t)u >= total) break;
             const Pkt<C, VT> &cur = buf[u];
             const uint32_t rb_cur = rbs[u];
             TKSPMV_REQUEST(buf[(u + NBUF - 1) % NBUF], rbs[(u + NBUF - 1) % NBUF]);
             if (jc == 0u) {  // a new query starts: its x must have been staged
                 mp = L.misc[qc & 1u];
                 xq = L.u.w.x[qc & 1u];
-                while (lds_load(&mp[MISC_XREADY]) != qc + 1u) __builtin_amdgcn_s_sleep(2);
+                for (;;) {
+                    const uint32_t xr_ = lds_load(&mp[MISC_XREADY]);
+                    if (xr_ == qc + 1u) break;
+                    if (RESIDENT && xr_ == RESIDENT_QUIT) return;  // the kernel is leaving (host request or idle timeout)
+                    __builtin_amdgcn_s_sleep(2);
+                }
                 asm volatile("" ::: "memory");
                 min_units = __uint_as_float(lds_load(&mp[MISC_MINU]));
                 if (trw && lane == 0 && TRSLOT(qc) < 3u) trw[1 + TRSLOT(qc)] = __builtin_amdgcn_s_memrealtime();
-                P.ovf_cand = B.ovf_cand(qc);
-                P.ovf_count = B.ovf_count(qc);
+                P.ovf_cand = B.ovf_cand(set_of(qc));
+                P.ovf_count = B.ovf_count(set_of(qc));
                 carry = 0.0f;
                 wcnt = 0u;
                 waited = false;

@@ -35,6 +35,12 @@ struct SelectParams {
     // device-to-host copy, no stream synchronisation on the host's critical path.
     uint32_t *host_out;
     uint32_t host_epoch;
+    // Resident kernel: the exchange-state sets are reused WITHIN one launch, so the resets at the end of a selection must be
+    // written through (no kernel boundary flushes them) and drained BEFORE the host learns that the query is complete (it
+    // may submit the next one at once). t_seen: s_memrealtime stamp of the moment the query was seen on the device;
+    // host_out[2k + 1] receives the device time of the query in 10 ns ticks.
+    uint32_t wt_reset;
+    unsigned long long t_seen;
 };
 
 constexpr int MAX_GM = 16;  // n_groups_pub <= 1024 => at most 16 published maxima per lane
@@ -241,27 +247,44 @@ __device__ __forceinline__ void select_body(const SelectParams &P, const uint32_
             __hip_atomic_store(&P.host_out[P.k + r], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
-    if (P.host_out) {  // every writer drains its stores, the workgroup meets, one thread raises the flag
+    auto raise_host_flag = [&]() __attribute__((always_inline)) {
+        // every writer drains its stores, the workgroup meets, one thread raises the flag (relaxed: the stores before it are
+        // write-through stores already drained by their writers; a release would write back the whole L2 first)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        // (relaxed: the result stores above are system-scope write-through stores already drained by their writers; a
-        //  release here would write back the whole L2 first)
-        if (tid == 0) __hip_atomic_store(&P.host_out[2u * P.k], P.host_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+        if (tid == 0) {
+            if (P.wt_reset)
+                __hip_atomic_store(&P.host_out[2u * P.k + 1u], (uint32_t)(__builtin_amdgcn_s_memrealtime() - P.t_seen), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&P.host_out[2u * P.k], P.host_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    };
+    if (P.host_out && !P.wt_reset) raise_host_flag();
     // Reset the exchange state for the next query (this is the last consumer of the query on the stream); last, so
     // that no barrier above has to wait for these stores. Slots: only the ones that held a survivor need a store
     // (the stream kernel writes a slot only when it has one).
 #pragma unroll
     for (uint32_t u = 0; u < SEL_PER_THREAD; ++u) {
         const uint32_t f = tid + u * nthreads;
-        if (f < n_slots && (uint32_t)(mine[u] >> 32) != SLOT_INVALID) P.wg_cand[f] = pack_cand(0u, SLOT_INVALID);
+        if (f < n_slots && (uint32_t)(mine[u] >> 32) != SLOT_INVALID) {
+            if (P.wt_reset) st_agent(&P.wg_cand[f], pack_cand(0u, SLOT_INVALID));
+            else P.wg_cand[f] = pack_cand(0u, SLOT_INVALID);
+        }
     }
-    for (uint32_t i = tid; i < P.n_groups_pub; i += nthreads) P.gmax[i] = 0u;
+    for (uint32_t i = tid; i < P.n_groups_pub; i += nthreads) {
+        if (P.wt_reset) __hip_atomic_store(&P.gmax[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else P.gmax[i] = 0u;
+    }
     if (tid == 0) {
-        *P.ovf_count = 0u;
-        *P.tau_g = 0u;
+        if (P.wt_reset) {
+            __hip_atomic_store(P.ovf_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(P.tau_g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            *P.ovf_count = 0u;
+            *P.tau_g = 0u;
+        }
         for (uint32_t c = 0; c < 9u; ++c) P.done_count[32u * c] = 0u;
     }
+    if (P.host_out && P.wt_reset) raise_host_flag();
     if (tid == 0 && P.stats) {  // TKSPMV_STATS=1 only: four dependent global read-modify-writes
         P.stats[0] += total;
         P.stats[1] += 1ull;
