@@ -358,7 +358,7 @@ __device__ __forceinline__ uint32_t compact_list(uint2 *wcand, uint32_t n, float
 // (its length lives in an SGPR: no atomic, no other wave involved). A full list is first compacted against the
 // current threshold; only what still does not fit goes to the shared overflow list in global memory, with ONE
 // atomic per wave and packet. One LDS atomic raises the group maximum (the server wave pushes it to global memory).
-template <int C, int QM, uint32_t WAVE_CAP>
+template <int C, int QM, uint32_t WAVE_CAP, bool STATS = true>
 __device__ __forceinline__ void offer_candidates(const StreamParams &P, const RowSums<C> &R, uint32_t rb, float tau,
                                                  uint32_t lane, uint32_t grp_local, bool publishes, uint2 *wcand,
                                                  uint32_t &wcnt, uint32_t *misc) {
@@ -380,7 +380,7 @@ __device__ __forceinline__ void offer_candidates(const StreamParams &P, const Ro
         if (publishes)
             (void)__hip_atomic_fetch_max(&misc[MISC_GRPMAX + grp_local], order_key(wmax), __ATOMIC_RELAXED,
                                          __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (P.dbg) {  // TKSPMV_STATS=1: summed into global memory when the wave finishes
+        if (STATS && P.dbg) {  // TKSPMV_STATS=1: summed into global memory when the wave finishes
             atomicAdd(&misc[MISC_SLOW_CNT], 1u);
             atomicAdd(&misc[MISC_CAND_CNT], total);
         }

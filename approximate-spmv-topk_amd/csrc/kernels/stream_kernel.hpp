@@ -38,15 +38,13 @@ struct StreamLds {
 #endif
 // DBG = false (production): tracing / statistics / ablation hooks compiled out (see batch_kernel).
 template <int C, bool SCORES, int XCOLS, int QM = 0, int NBUF = TKSPMV_NBUF, bool DBG = false>
-__global__ void __launch_bounds__(576, (C == 8 && !SCORES) ? 6 : 5) stream_kernel(const StreamParams P_arg, const SelectParams SP) {
-    StreamParams P = P_arg;
-    if (!DBG) {
-        P.trace = nullptr;
-        P.dbg = nullptr;
-        P.stamps = nullptr;
-        P.dbg_flags = 0u;
-        P.dbg_repeat = 0u;
-    }
+__global__ void __launch_bounds__(576, (C == 8 && !SCORES) ? 6 : 5) stream_kernel(const StreamParams P, const SelectParams SP) {
+    // (constants, not a modified copy of P: a copy that is passed on by reference ends up in scratch memory)
+    const uint32_t dbg_flags = DBG ? P.dbg_flags : 0u;
+    const uint32_t dbg_repeat = DBG ? P.dbg_repeat : 0u;
+    unsigned long long *const dbg_trace = DBG ? P.trace : nullptr;
+    unsigned long long *const dbg_stamps = DBG ? P.stamps : nullptr;
+    unsigned long long *const dbg_counters = DBG ? P.dbg : nullptr;
     constexpr bool Q8 = QM == 1 || QM == 2;  // x staged as Q1.7 integers
     constexpr int VT = value_type_of(QM);
     // Deferred packets live in registers (C row sums + C / 2 flag words each): with 8 entries per lane one packet is held,
@@ -64,7 +62,7 @@ __global__ void __launch_bounds__(576, (C == 8 && !SCORES) ? 6 : 5) stream_kerne
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     uint32_t bid = blockIdx.x, n_wg = gridDim.x;  // streaming workgroup id / count
     // TKSPMV_TRACE=1: 100 MHz wall-clock stamps per wave (kept in SGPRs, written once at the very end)
-    unsigned long long *tr = (!SCORES && P.trace) ? P.trace + ((size_t)blockIdx.x * 9u + wave) * 8u : nullptr;
+    unsigned long long *tr = (!SCORES && dbg_trace) ? dbg_trace + ((size_t)blockIdx.x * 9u + wave) * 8u : nullptr;
     unsigned long long tr0 = 0, tr1 = 0, tr2 = 0, tr3 = 0, tr4 = 0;
     if (tr) tr0 = __builtin_amdgcn_s_memrealtime();
     if (!SCORES && P.deferred) {
@@ -167,9 +165,9 @@ __global__ void __launch_bounds__(576, (C == 8 && !SCORES) ? 6 : 5) stream_kerne
     if (tr) tr1 = __builtin_amdgcn_s_memrealtime();
 
     if (is_server) {
-        if (!SCORES && P.n_sets != 0u && !(P.dbg_flags & 4u)) {
+        if (!SCORES && P.n_sets != 0u && !(dbg_flags & 4u)) {
             for (;;) {
-                if (!(P.dbg_flags & 1u)) publish_group_max(P, bid, lane, misc);
+                if (!(dbg_flags & 1u)) publish_group_max(P, bid, lane, misc);
                 // Only a few servers read all published maxima (many readers of those 16 lines slow the whole
                 // stream down: measured); the others read the one word the reducers keep up to date.
                 float t;
@@ -231,7 +229,7 @@ __global__ void __launch_bounds__(576, (C == 8 && !SCORES) ? 6 : 5) stream_kerne
         // NBUF): copying a freshly loaded buffer into another would wait for the youngest load and drain the
         // prefetch queue every iteration.
         const uint32_t np_one = np;
-        if (P.dbg_repeat > 1u) np *= P.dbg_repeat;  // experiment: what a persistent multi-query kernel would stream
+        if (dbg_repeat > 1u) np *= dbg_repeat;  // experiment: what a persistent multi-query kernel would stream
         uint32_t ia_cur = NBUF - 1 < np_one ? NBUF - 1 : 0u, ia_rep = 0u;
         for (uint32_t i0 = 0; i0 < np; i0 += NBUF) {
 #pragma unroll
@@ -247,7 +245,7 @@ __global__ void __launch_bounds__(576, (C == 8 && !SCORES) ? 6 : 5) stream_kerne
                 // compiler wait with a counted vmcnt instead of vmcnt(0).
                 uint32_t ia = (i + (NBUF - 1) < np) ? (i + (NBUF - 1)) : (np - 1);
                 const uint8_t *pk_a = pk;
-                if (P.dbg_repeat > 1u) {
+                if (dbg_repeat > 1u) {
                     ia = ia_cur;
                     pk_a = P.rep_packets[ia_rep & 3u] + (size_t)p0 * P.packet_bytes;
                     if (i + (NBUF - 1) < np) {
@@ -292,8 +290,8 @@ __global__ void __launch_bounds__(576, (C == 8 && !SCORES) ? 6 : 5) stream_kerne
                     if (lane == 0 && publishes && wmax >= min_units)
                         (void)__hip_atomic_fetch_max(&misc[MISC_GRPMAX + grp_local], order_key(wmax), __ATOMIC_RELAXED,
                                                      __HIP_MEMORY_SCOPE_WORKGROUP);
-                } else if (__any(R.best_any >= tau) && !(P.dbg_flags & 2u)) {
-                    offer_candidates<C, QM, ListGeom<XCOLS>::WAVE_CAP>(P, R, rb_cur, tau, lane, grp_local, publishes, wcand, wcnt, misc);
+                } else if (__any(R.best_any >= tau) && !(dbg_flags & 2u)) {
+                    offer_candidates<C, QM, ListGeom<XCOLS>::WAVE_CAP, DBG>(P, R, rb_cur, tau, lane, grp_local, publishes, wcand, wcnt, misc);
                 }
             }
             }
@@ -318,16 +316,16 @@ __global__ void __launch_bounds__(576, (C == 8 && !SCORES) ? 6 : 5) stream_kerne
 #pragma unroll
             for (int d = 0; d < DEFER_C; ++d) {
                 if (np > (uint32_t)d && __any(st[d].best_any >= tau))
-                    offer_candidates<C, QM, ListGeom<XCOLS>::WAVE_CAP>(P, st[d], st_rb[d], tau, lane, grp_local, publishes, wcand, wcnt, misc);
+                    offer_candidates<C, QM, ListGeom<XCOLS>::WAVE_CAP, DBG>(P, st[d], st_rb[d], tau, lane, grp_local, publishes, wcand, wcnt, misc);
             }
         }
     }
 
     if (SCORES) return;
     if (tr) tr4 = __builtin_amdgcn_s_memrealtime();
-    const unsigned long long ts_stream_end = P.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
+    const unsigned long long ts_stream_end = dbg_stamps ? __builtin_amdgcn_s_memtime() : 0ull;
     if (!is_server && lane == 0) atomicAdd(&misc[MISC_DONE], 1u);
-    if (P.dbg_flags & 8u) return;
+    if (dbg_flags & 8u) return;
 
     // ---- flush: every wave on its own, no workgroup synchronisation. What still clears the (now much tighter)
     // threshold leaves the wave's private list: the first survivor to this wave's fixed slot, further ones to the
@@ -355,9 +353,9 @@ __global__ void __launch_bounds__(576, (C == 8 && !SCORES) ? 6 : 5) stream_kerne
                 }
             }
         }
-        if (P.dbg && lane == 0 && wave == 0u) {  // TKSPMV_STATS=1 (approximate: waves still running are not counted)
-            atomicAdd(&P.dbg[0], (unsigned long long)misc[MISC_SLOW_CNT]);
-            atomicAdd(&P.dbg[1], (unsigned long long)misc[MISC_CAND_CNT]);
+        if (dbg_counters && lane == 0 && wave == 0u) {  // TKSPMV_STATS=1 (approximate: waves still running are not counted)
+            atomicAdd(&dbg_counters[0], (unsigned long long)misc[MISC_SLOW_CNT]);
+            atomicAdd(&dbg_counters[1], (unsigned long long)misc[MISC_CAND_CNT]);
         }
     }
     if (tr && lane == 0) {
@@ -378,10 +376,10 @@ __global__ void __launch_bounds__(576, (C == 8 && !SCORES) ? 6 : 5) stream_kerne
     // Hand-off (cdna_hip_programming.md Guideline 16): every storing wave drains its write-through stores, the
     // workgroup barrier orders them before ONE agent-scope ticket add; the workgroup whose add came last takes an
     // agent-scope acquire, a barrier, and only then loads what the others stored.
-    const unsigned long long ts_flush_issued = P.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
+    const unsigned long long ts_flush_issued = dbg_stamps ? __builtin_amdgcn_s_memtime() : 0ull;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    const unsigned long long ts_flush_done = P.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
+    const unsigned long long ts_flush_done = dbg_stamps ? __builtin_amdgcn_s_memtime() : 0ull;
     if (tid == 0) {
         // Two-level ticket: 8 group counters (blockIdx % 8) and a top counter, each on its own 128-B line, so the
         // workgroups that finish together do not serialise on one word. Which workgroups share a group is
@@ -397,22 +395,22 @@ __global__ void __launch_bounds__(576, (C == 8 && !SCORES) ? 6 : 5) stream_kerne
                 __hip_atomic_fetch_add(&SP.done_count[32u * 8u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             last = (t2 == n_groups - 1u) ? 1u : 0u;
         }
-        if (last && !(P.dbg_flags & 32u)) {
+        if (last && !(dbg_flags & 32u)) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         sel_sh.last = last;
     }
     __syncthreads();
-    const unsigned long long ts_ticket = P.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
-    if (sel_sh.last && !(P.dbg_flags & 16u)) select_body(SP, tid, blockDim.x, sel_sh, P.dbg_flags, P.stamps, inv_unit);
-    if (P.stamps && sel_sh.last && tid == 0) {
-        P.stamps[0] = ts_stream_end;
-        P.stamps[1] = ts_flush_issued;
-        P.stamps[2] = ts_flush_done;
-        P.stamps[3] = ts_ticket;
-        P.stamps[7] = __builtin_amdgcn_s_memtime();
-        P.stamps[8] = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long ts_ticket = dbg_stamps ? __builtin_amdgcn_s_memtime() : 0ull;
+    if (sel_sh.last && !(dbg_flags & 16u)) select_body(SP, tid, blockDim.x, sel_sh, dbg_flags, dbg_stamps, inv_unit);
+    if (dbg_stamps && sel_sh.last && tid == 0) {
+        dbg_stamps[0] = ts_stream_end;
+        dbg_stamps[1] = ts_flush_issued;
+        dbg_stamps[2] = ts_flush_done;
+        dbg_stamps[3] = ts_ticket;
+        dbg_stamps[7] = __builtin_amdgcn_s_memtime();
+        dbg_stamps[8] = __builtin_amdgcn_s_memrealtime();
     }
 }
 

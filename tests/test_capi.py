@@ -87,3 +87,20 @@ def test_executable_reports_errors_like_the_reference(pkg, tmp_path):
         r = subprocess.run([exe, "-m", str(p), "-k", "8", "-t", "1"], capture_output=True, text=True,
                            env=dict(os.environ, TKSPMV_INDEX_BASE="1"))
         assert r.returncode == 1 and "no HIP device" in r.stderr
+
+
+def test_reference_side_host_program_builds_against_the_reference_headers(pkg):
+    """oracle/ref_host_mi355x.cpp -- `struct SpMV` bound to the C ABI inside a main() written with
+    the reference's own Options / readMtx / coo_t / create_sample_vector / spmv_coo_gold_top_k / sort_tuples -- compiles with
+    plain g++ against the headers where they lie under /root/reference (`make ref`) and links libtkspmv.so. Without a GPU the
+    program stops where the engine is created, loudly."""
+    if not os.path.isdir("/root/reference"):
+        pytest.skip("the reference tree is only present in the build container")
+    r = subprocess.run(["make", "-C", ROOT, "ref"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    exe = os.path.join(ROOT, "oracle", "_ref", "host_spmv_topk_mi355x")
+    assert os.path.exists(exe)
+    if pkg.device_count() == 0:
+        r = subprocess.run([exe, "-m", os.path.join(ROOT, "tests", "golden", "small_0indexed.mtx"), "-k", "8", "-t", "1"],
+                           capture_output=True, text=True)
+        assert r.returncode == 1 and "no HIP device" in r.stderr

@@ -333,6 +333,21 @@ def test_drop_in_executable_csv(pkg, oracle, tmp_path):
     assert r.returncode == 1 and "TKSPMV_FIXED_WIDTH" in r.stderr
 
 
+def test_reference_side_host_program(pkg):
+    """oracle/_ref/host_spmv_topk_mi355x (built in the build container from oracle/ref_host_mi355x.cpp against the
+    reference's OWN headers: its Options, readMtx, coo_t, create_sample_vector, gold and checks around this engine's C ABI,
+    INTEGRATION.md section 2) runs the reference's flow end to end: every iteration's list equals the reference gold's."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "host_spmv_topk_mi355x")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref was not built (no reference tree at build time)")
+    for impl in ("0", "1", "2", "3"):
+        r = subprocess.run([exe, "-m", os.path.join(GOLD, "small_0indexed.mtx"), "-k", "20", "-t", "4", "-i", impl],
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (impl, r.stdout[-500:], r.stderr[-500:])
+        lines = [ln.split(",") for ln in r.stdout.strip().split("\n") if ln and ln[0].isdigit()]
+        assert len(lines) == 4 and all(float(f[4]) == 1.0 and int(f[2]) == 0 for f in lines), (impl, r.stdout)
+
+
 # ---- BASELINE configs[4]: Q1.7 fixed-point values ("FIXED_WIDTH-style" reduced precision) ----------------------------
 @pytest.mark.parametrize("rows,cols,nnz,k,seed", [(3000, 512, 40, 100, 1), (60000, 512, 40, 100, 2),
                                                   (20000, 1024, 20, 8, 3), (5000, 3000, 30, 50, 4)])

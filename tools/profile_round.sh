@@ -3,7 +3,8 @@
 #   bash tools/profile_round.sh r01
 # 1. plain bench line; 2. the same command under rocprofv3 --kernel-trace --stats; 3. separate --pmc passes for the
 # memory-side counters (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE do not fit one pass; no trace domains with --pmc);
-# 4. the multi-query path alone (8 and 4 queries per pass) under --kernel-trace --stats.
+# 4. the multi-query path alone (8 and 4 queries per pass) under --kernel-trace --stats; 5. single fused launches
+# (tkspmv_run) under --kernel-trace --stats; 6. configs[4] (Q1.7 bytes, fp32 arithmetic) under --kernel-trace --stats.
 # Everything lands in gpurun_out/prof_<tag>/; tools/summarize_profile.py turns it into the files kept under profiles/.
 set -u
 TAG=${1:-r01}
@@ -24,6 +25,12 @@ export TKSPMV_MULTI_CHAINS=1
 for q in 8 4; do
     rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/mtrace$q" -- python3 "$REPO/bench.py" --multi-only $q --steps 2048 --warmup 256 > "$OUT/multi$q.json" 2> "$OUT/mtrace$q.err"
 done
+unset TKSPMV_MULTI_CHAINS
+# 5. the literal reference loop: single fused launches (tkspmv_run), one query at a time
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/single" -- python3 "$REPO/tools/single_probe.py" --plain 200 > "$OUT/single.log" 2> "$OUT/single.err"
+# 6. BASELINE configs[4]: Q1.7 byte values with fp32 arithmetic, one query per pass over the row-per-lane byte stream (one chain)
+export TKSPMV_MULTI_CHAINS=1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/q17f" -- python3 "$REPO/tools/q17f_probe.py" --only > "$OUT/q17f.log" 2> "$OUT/q17f.err"
 unset TKSPMV_MULTI_CHAINS
 cd "$REPO"
 python3 tools/summarize_profile.py "$OUT" "$TAG"

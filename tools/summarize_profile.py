@@ -45,6 +45,14 @@ for q in (8, 4):  # the multi-query path alone: per-kernel summary + the JSON li
         if lines:
             open(os.path.join(dst, f"{tag}_multi{q}_under_rocprofv3.json"), "w").write(lines[-1] + "\n")
 
+for sub, name in (("single", f"{tag}_single_query_kernel_stats.csv"), ("q17f", f"{tag}_config4_q17f32_kernel_stats.csv")):
+    src = find(f"{sub}/**/*kernel_stats.csv")
+    if src:
+        shutil.copy(src, os.path.join(dst, name))
+    log = os.path.join(out, f"{sub}.log")
+    if os.path.exists(log):
+        shutil.copy(log, os.path.join(dst, name.replace("_kernel_stats.csv", ".log")))
+
 summary = {}
 for d in sorted(glob.glob(os.path.join(out, "pmc*"))):
     if not os.path.isdir(d):
