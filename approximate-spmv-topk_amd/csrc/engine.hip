@@ -99,6 +99,8 @@ struct EngineImpl {
     bool resident_capable = false;
     mutable bool resident_running = false;
     bool x_on_host_only = false;        // set_query left x in h_x without uploading it (resident engines): see ensure_x
+    bool resident_stats = false;
+    double rs_n = 0, rs_host = 0, rs_dev = 0, rs_pub = 0, rs_tick = 0;
     float *h_x_dev = nullptr;           // h_x as the device sees it (TKSPMV_HOST_X=direct: kernels read x from host memory)
     bool host_x_direct = false;
     bool run_events = true;             // TKSPMV_RUN_EVENTS=0 (experiment): tkspmv_run reports host-clock time, no events
@@ -609,6 +611,10 @@ Engine::~Engine() {
     EngineImpl &m = *impl_;
     (void)hipSetDevice(m.device);
     (void)m.stop_resident();  // before anything is freed (hipFree would wait for it, then free what it reads)
+    if (m.resident_stats && m.rs_n > 0)
+        fprintf(stderr, "[tkspmv resident, %.0f queries, us] host: request -> flag seen %.2f | device: request seen -> x published %.2f, "
+                        "-> every workgroup delivered %.2f, -> flag raised %.2f\n",
+                m.rs_n, m.rs_host / m.rs_n / 1e3, m.rs_pub / m.rs_n / 1e3, m.rs_tick / m.rs_n / 1e3, m.rs_dev / m.rs_n / 1e3);
     if (m.stream) (void)hipStreamSynchronize(m.stream);
     void *bufs[] = {m.d_packets, m.d_pkt_row, m.d_part_first, m.d_part_count, m.d_x,
                     m.d_out_idx, m.d_out_val, m.d_scores,     m.d_stats,      m.d_done, m.d_trace, m.d_tickets};
@@ -992,6 +998,7 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
         HIP_TRY(malloc_exchange((void **)&m.d_dev_epoch, 64));
         HIP_TRY(hipMemset(m.d_dev_epoch, 0, 64));
         HIP_TRY(hipStreamCreateWithFlags(&m.rstream, hipStreamNonBlocking));
+        m.resident_stats = getenv("TKSPMV_RESIDENT_STATS") != nullptr;
         if (const char *f = getenv("TKSPMV_RESIDENT_IDLE_MS")) m.resident_idle_ticks = (uint32_t)std::max(1, atoi(f)) * 100000u;
     }
     HIP_TRY(malloc_exchange((void **)&m.d_tickets, BATCH_MAX * 32 * 4));
@@ -1385,6 +1392,15 @@ int Engine::run(double *kernel_ns, std::string &err) {
         }
         std::atomic_thread_fence(std::memory_order_acquire);
         if (kernel_ns) *kernel_ns = (double)m.h_res[2 * (size_t)m.desc.k + 1] * 10.0;  // device time of the query (100 MHz ticks)
+        if (m.resident_stats) {  // TKSPMV_RESIDENT_STATS=1: where a resident query's time goes (printed when the engine is destroyed)
+            const double host_ns = (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+            const uint32_t *hr = m.h_res + 2 * (size_t)m.desc.k;
+            m.rs_n += 1.0;
+            m.rs_host += host_ns;
+            m.rs_dev += hr[1] * 10.0;
+            m.rs_pub += hr[2] * 10.0;
+            m.rs_tick += hr[3] * 10.0;
+        }
         m.ran = true;
         m.last_on_host = true;
         return TKSPMV_OK;

@@ -176,6 +176,8 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
                     if (lane == 0) {
                         __hip_atomic_store(B.dev_epoch, quit ? RESIDENT_QUIT : q + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         L.u.sel.last = quit;
+                        if (!quit && SP0.host_out)  // diagnostics: ticks from "request seen" to "x published"
+                            __hip_atomic_store(&SP0.host_out[2u * SP0.k + 2u], (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_seen), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     }
                 }
                 __syncthreads();
@@ -192,6 +194,8 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
                 // copy of the line in this XCD's L2 (seen: 33 ms on an otherwise idle L2).
                 while (atomicCAS(t, n_stream, 0u) != n_stream) __builtin_amdgcn_s_sleep(RESIDENT ? 4 : 32);
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                if (RESIDENT && SP0.host_out)  // diagnostics: ticks from "request seen" to "every workgroup has delivered"
+                    __hip_atomic_store(&SP0.host_out[2u * SP0.k + 3u], (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_seen), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
             __syncthreads();
             SelectParams S = SP0;
