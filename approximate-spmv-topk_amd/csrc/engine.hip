@@ -125,6 +125,11 @@ struct EngineImpl {
     bool fused = true;
     bool can_defer = false;
     bool can_batch = false;         // batch kernel usable (exchange on, x double-buffered in LDS, 4 entries per lane)
+    // Queries per launch of the batch kernel = exchange-state sets allocated. Every set carries an overflow list that must be
+    // able to hold EVERY row (a degenerate query -- x = 0, all scores equal -- makes every row a candidate, and the result
+    // must still be exact), 8 B per row: 32 sets up to 4M rows (256 MB at 1M rows); larger matrices get fewer sets so that
+    // the lists stay within 1 GiB -- their queries are long, the launch overhead per query matters proportionally less.
+    int batch_max = BATCH_MAX;
     // Multi-query passes (multi_kernel, desc.multi_q): fp32 values, <= 1024 columns, exchange on. multi_q queries share one
     // pass over the wave-sliced ELL copy of the matrix (wsell.hpp); a group's selection is owed to the next launch (or to
     // drain()). Groups alternate between the exchange-state sets [0, MULTI_Q_MAX) and [MULTI_Q_MAX, 2 * MULTI_Q_MAX).
@@ -396,7 +401,7 @@ struct EngineImpl {
             drain(s);
             return;
         }
-        for (int i = 0; i < n; i += BATCH_MAX) launch_batch(xs + i, out_idx + i, out_val + i, std::min(BATCH_MAX, n - i), s);
+        for (int i = 0; i < n; i += batch_max) launch_batch(xs + i, out_idx + i, out_val + i, std::min(batch_max, n - i), s);
     }
     // One query of a back-to-back sequence: its selection runs inside the NEXT deferred launch (or in drain()).
     void launch_deferred(const float *x, uint32_t *out_idx, float *out_val, hipStream_t s) const {
@@ -1005,7 +1010,12 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
     HIP_TRY(hipMemset(m.d_tickets, 0, BATCH_MAX * 32 * 4));
     {
         // Exchange-state sets: one block per field, set s at s strides (the batch kernel addresses them that way).
-        const int n_sets_alloc = (m.can_batch || m.can_multi) ? EngineImpl::N_STATE : (m.can_defer ? 2 : 1);
+        if (m.can_batch && !m.can_multi && !m.resident_capable) {
+            const uint64_t per_set = (uint64_t)m.ovf_cap * 8u;
+            m.batch_max = (int)std::max<uint64_t>(4, std::min<uint64_t>(BATCH_MAX, (1ull << 30) / std::max<uint64_t>(per_set, 1)));
+        }
+        if (const char *f = getenv("TKSPMV_BATCH_MAX")) m.batch_max = std::max(1, std::min(BATCH_MAX, atoi(f)));
+        const int n_sets_alloc = (m.can_multi || m.resident_capable) ? EngineImpl::N_STATE : (m.can_batch ? m.batch_max : (m.can_defer ? 2 : 1));
         const size_t ns = (size_t)n_sets_alloc;
         EngineImpl::ExState &E0 = m.st[0];
         HIP_TRY(malloc_exchange((void **)&E0.gmax, ns * EngineImpl::GMAX_WORDS * 4));
