@@ -24,6 +24,23 @@ for d in sorted(glob.glob(os.path.join(out, "*"))):
             launches.add(row["Dispatch_Id"])
         if launches:
             res.setdefault(run, {})["launches"] = len(launches)
+# queries each profiled run served (from the JSON line it printed): counters per query
+for run in list(res):
+    n = None
+    for f in sorted(glob.glob(os.path.join(out, ("batch" if run == "batch" else run + "_") + "*.json"))):
+        try:
+            j = json.loads([l for l in open(f).read().splitlines() if l.startswith("{")][-1])
+            n = j["warmup"] + j["steps"]
+            if "timing" in j:  # the headline run repeats its timed batch (repetitions + 2 dropped ones)
+                n += (j["timing"]["repetitions"] + j["timing"]["dropped"]) * j["timing"]["queries_per_repetition"]
+            break
+        except Exception:  # noqa: BLE001
+            pass
+    if n:
+        res[run]["queries"] = n
+        for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD"):
+            if k in res[run]:
+                res[run][k + "_per_query"] = res[run][k] / n
 for run, r in res.items():
     wc = r.get("SQ_WAVE_CYCLES")
     if wc:
