@@ -580,7 +580,8 @@ def main():
     mod = _pkg.load()
 
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # (TKSPMV_BENCH_DEVICE / TKSPMV_BENCH_PG: rehearsal aids -- several ranks on ONE GPU, process group over gloo)
+    local_rank = int(os.environ.get("TKSPMV_BENCH_DEVICE", os.environ.get("LOCAL_RANK", "0")))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if a.gpus != world and world == 1 and a.gpus > 1:
         print("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)", file=sys.stderr)
@@ -595,7 +596,10 @@ def main():
     multi = world > 1 or (os.environ.get("TKSPMV_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
     if multi:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if os.environ.get("TKSPMV_BENCH_PG") == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     try:
         if multi or a.total_rows:
             bench_sharded(a, mod, torch, np, dev, local_rank, rank, world)
