@@ -5,11 +5,11 @@ marshals pointers. There is no CPU fallback.
 """
 from . import _lib
 from ._lib import TkspmvError, F32, Q1_7, Q1_7_WIDE, F16, FIXED, Q1_7_F32, MAX_COLS, MAX_K
-from .host import CooMatrix, Options, Packed, create_sample_vector, generate_degrees, generate_matrix, generate_matrix_rows, read_mtx, sell_roundtrip, write_mtx
+from .host import CooMatrix, Options, Packed, create_sample_vector, generate_degrees, generate_matrix, generate_matrix_rows, read_mtx, sell_pack_device_check, sell_roundtrip, write_mtx
 from .engine import SpMV, topk_spmv
 
 __all__ = ["SpMV", "topk_spmv", "CooMatrix", "Options", "Packed", "create_sample_vector", "generate_matrix", "generate_matrix_rows", "generate_degrees",
-           "read_mtx", "write_mtx", "sell_roundtrip", "TkspmvError", "F32", "Q1_7", "Q1_7_WIDE", "F16", "FIXED", "Q1_7_F32", "MAX_COLS", "MAX_K"]
+           "read_mtx", "write_mtx", "sell_roundtrip", "sell_pack_device_check", "TkspmvError", "F32", "Q1_7", "Q1_7_WIDE", "F16", "FIXED", "Q1_7_F32", "MAX_COLS", "MAX_K"]
 
 
 def device_count():

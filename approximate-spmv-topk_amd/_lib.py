@@ -40,7 +40,7 @@ class Info(C.Structure):
         ("packet_entries", C.c_uint32), ("n_wave_partitions", C.c_uint32), ("packets_per_partition", C.c_uint32),
         ("grid", C.c_uint32), ("block", C.c_uint32), ("n_groups", C.c_uint32), ("lds_bytes", C.c_uint32),
         ("k", C.c_int32), ("partitions", C.c_int32), ("k_per_partition", C.c_int32), ("precision", C.c_int32),
-        ("device", C.c_int32), ("num_cus", C.c_uint32), ("fixed_width", C.c_uint32), ("multi_q", C.c_uint32), ("reserved0", C.c_uint32), ("multi_bytes", C.c_uint64),
+        ("device", C.c_int32), ("num_cus", C.c_uint32), ("fixed_width", C.c_uint32), ("multi_q", C.c_uint32), ("multi_pack_us", C.c_uint32), ("multi_bytes", C.c_uint64),
         ("pack_us", C.c_uint32), ("pack_on_device", C.c_uint32),
     ]
 
@@ -82,7 +82,7 @@ EXPORTED_SYMBOLS = [
     "tkspmv_run", "tkspmv_enqueue", "tkspmv_enqueue_many", "tkspmv_enqueue_batch", "tkspmv_synchronize", "tkspmv_read", "tkspmv_result_device", "tkspmv_scores", "tkspmv_debug_trace",
     "tkspmv_time_queries", "tkspmv_enqueue_multi", "tkspmv_time_multi", "tkspmv_profile", "tkspmv_last_error", "tkspmv_device_count", "tkspmv_mtx_read", "tkspmv_mtx_free",
     "tkspmv_mtx_write", "tkspmv_sample_vector", "tkspmv_generate", "tkspmv_generate_rows", "tkspmv_generate_degrees", "tkspmv_options_parse", "tkspmv_pack", "tkspmv_pack_device",
-    "tkspmv_sell_roundtrip", "tkspmv_packed_info", "tkspmv_packed_decode", "tkspmv_packed_raw", "tkspmv_packed_free", "tkspmv_wave_partitions", "tkspmv_packed_save", "tkspmv_packed_load",
+    "tkspmv_sell_roundtrip", "tkspmv_sell_pack_device_check", "tkspmv_packed_info", "tkspmv_packed_decode", "tkspmv_packed_raw", "tkspmv_packed_free", "tkspmv_wave_partitions", "tkspmv_packed_save", "tkspmv_packed_load",
     "tkspmv_create_packed",
     "tkspmv_dist_unique_id", "tkspmv_dist_create", "tkspmv_dist_set_batch", "tkspmv_dist_enqueue", "tkspmv_dist_run_many",
     "tkspmv_dist_synchronize", "tkspmv_dist_time_exchange", "tkspmv_dist_read", "tkspmv_dist_destroy", "tkspmv_dist_last_error",

@@ -1,5 +1,6 @@
 // c_api.cpp -- extern "C" surface declared in include/tkspmv.h (plain pointers and sizes only).
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <new>
 #include <string>
@@ -318,6 +319,43 @@ int tkspmv_sell_roundtrip(const tkspmv_desc *d, uint32_t n_wave_partitions_hint,
         info[3] = sm.part_first.size();
         info[4] = sm.stream_bytes();
         info[5] = most;
+    }
+    return TKSPMV_OK;
+}
+
+int tkspmv_sell_pack_device_check(const tkspmv_desc *d, uint32_t n_wave_partitions_hint, uint64_t *info, double *ms) {
+    if (!d || !info) return fail(TKSPMV_ERR_INVALID, "NULL argument");
+    if (device_count() < 1) return fail(TKSPMV_ERR_DEVICE, "no HIP device available (the device packer needs one)");
+    std::string serr;
+    if (use_device(d->device, serr) != TKSPMV_OK) return fail(TKSPMV_ERR_DEVICE, serr);
+    const uint32_t hint = n_wave_partitions_hint ? n_wave_partitions_hint : 4088u;
+    const SellValues sv = d->precision == TKSPMV_Q1_7_F32 ? SellValues::Q1_7_RND : SellValues::F32;
+    SellMatrix host;
+    const auto t0 = std::chrono::steady_clock::now();
+    const std::string herr = pack_wsell(d->rows, d->cols, d->nnz, d->row, d->col, d->val, hint, host, sv);
+    const auto t1 = std::chrono::steady_clock::now();
+    DeviceSell ds;
+    std::string derr = pack_wsell_device(d->rows, d->cols, d->nnz, d->row, d->col, d->val, hint, sv, nullptr, nullptr, ds);
+    if (herr != derr) {
+        free_device_sell(ds);
+        return fail(TKSPMV_ERR_STATE, "the two packers disagree on the input: host '" + herr + "', device '" + derr + "'");
+    }
+    if (!herr.empty()) return fail(TKSPMV_ERR_INVALID, herr);
+    derr = download_device_sell(ds);
+    free_device_sell(ds);
+    if (!derr.empty()) return fail(TKSPMV_ERR_DEVICE, derr);
+    const SellMatrix &dev = ds.meta;
+    info[0] = (host.n_slices == dev.n_slices && host.n_chunks == dev.n_chunks && host.packet_bytes == dev.packet_bytes &&
+               host.padded_entries == dev.padded_entries && host.packets == dev.packets && host.slice_rows == dev.slice_rows &&
+               host.part_first == dev.part_first && host.part_count == dev.part_count && host.part_slice0 == dev.part_slice0)
+                  ? 1u : 0u;
+    info[1] = host.stream_bytes();
+    info[2] = host.n_chunks;
+    if (ms) {
+        ms[0] = std::chrono::duration<double, std::milli>(t1 - t0).count();
+        ms[1] = ds.plan_ms;
+        ms[2] = ds.upload_ms;
+        ms[3] = ds.kernels_ms;
     }
     return TKSPMV_OK;
 }

@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "device_pack.hpp"
+#include "wsell.hpp"
 
 namespace tkspmv {
 
@@ -468,6 +469,10 @@ std::string pack_wbscsr_device(uint32_t rows, uint32_t cols, uint64_t nnz, const
     out.kernels_ms = std::chrono::duration<double, std::milli>(t_end - t_uploaded).count();
     out.d_packets = static_cast<uint8_t *>(d_packets.release());
     out.d_pkt_row = static_cast<uint32_t *>(d_pkt_row.release());
+    if (out.keep_coo) {  // the caller goes on to pack_wsell_device with the same COO
+        out.d_col = static_cast<uint32_t *>(d_col.release());
+        out.d_val = static_cast<float *>(d_val.release());
+    }
     kind = 0;
     return "";
 }
@@ -486,8 +491,151 @@ std::string download_device_packed(DevicePacked &dp) {
 void free_device_packed(DevicePacked &dp) {
     if (dp.d_packets) (void)hipFree(dp.d_packets);
     if (dp.d_pkt_row) (void)hipFree(dp.d_pkt_row);
+    if (dp.d_col) (void)hipFree(dp.d_col);
+    if (dp.d_val) (void)hipFree(dp.d_val);
     dp.d_packets = nullptr;
     dp.d_pkt_row = nullptr;
+    dp.d_col = nullptr;
+    dp.d_val = nullptr;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// The wave-sliced ELL layout (wsell.hpp). The layout decisions depend on the row lengths alone (length classes, the
+// slices, their longest-first deal to the partitions): plan_wsell makes them on the host in a few passes over the row
+// ids, exactly as the host packer does. What costs the host packer its time is the fill -- 256 slots per chunk, every
+// one a scattered copy -- and that is one kernel here: a wave per slice, lane l writes the 16 (or 4) value bytes and
+// the 8 column-word bytes of its slots in every chunk of the slice, reading its row's entries from the COO in HBM.
+// Same bytes as fill_wsell_host.
+// ------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct SellLaneRec {         // one lane of one slice, in STREAM order
+    unsigned long long src;  // COO offset of the lane's first entry
+    uint32_t n;              // entries of the lane (0: none)
+    uint32_t info;           // bits 0..7: index of the segment in its row; bit 31: lane without a row
+};
+struct SellScatterParams {
+    const uint32_t *col;
+    const float *val;  // NULL: every value is 1.0
+    const SellLaneRec *lanes;
+    const uint32_t *chunk0, *n_chunks_of;
+    uint8_t *packets;
+    uint32_t n_slices, vb, packet_bytes;
+};
+
+__global__ void __launch_bounds__(64) sell_scatter_kernel(const SellScatterParams P) {
+    const uint32_t so = blockIdx.x, l = threadIdx.x;
+    const SellLaneRec ln = P.lanes[(size_t)so * 64 + l];
+    const uint32_t nc = P.n_chunks_of[so], chunk = P.chunk0[so];
+    const bool have = (ln.info >> 31) == 0u;
+    const uint32_t depth = ln.info & 255u;
+    for (uint32_t c = 0; c < nc; ++c) {
+        uint8_t *pkt = P.packets + (size_t)(chunk + c) * P.packet_bytes;
+        float v[4];
+        uint8_t qv[4];
+        uint16_t cw[4];
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) {
+            const uint32_t e = 4 * c + j;
+            if (have && e < ln.n) {
+                v[j] = P.val ? P.val[ln.src + e] : 1.0f;
+                qv[j] = to_q1_7_rnd(v[j]);
+                cw[j] = (uint16_t)(P.col[ln.src + e] << 2);
+            } else if (!have && e == 0) {
+                v[j] = -__builtin_huge_valf();
+                qv[j] = 1;
+                cw[j] = (uint16_t)(SELL_PAD_ONE << 2);
+            } else {
+                v[j] = 0.0f;
+                qv[j] = 0;
+                cw[j] = (uint16_t)(SELL_PAD_NEUTRAL << 2);
+            }
+            if (c + 1 == nc) {
+                if (j == 0) cw[j] |= SELL_LAST_CHUNK;
+                if (j >= 1) cw[j] |= (uint16_t)((depth >> (2 * (j - 1))) & 3u);
+            }
+        }
+        if (P.vb == 4u) *reinterpret_cast<float4 *>(pkt + (size_t)l * 16) = make_float4(v[0], v[1], v[2], v[3]);
+        else *reinterpret_cast<uint32_t *>(pkt + (size_t)l * 4) = (uint32_t)qv[0] | ((uint32_t)qv[1] << 8) | ((uint32_t)qv[2] << 16) | ((uint32_t)qv[3] << 24);
+        *reinterpret_cast<uint2 *>(pkt + 256u * P.vb + (size_t)l * 8) =
+            make_uint2((uint32_t)cw[0] | ((uint32_t)cw[1] << 16), (uint32_t)cw[2] | ((uint32_t)cw[3] << 16));
+    }
+}
+
+}  // namespace
+
+std::string pack_wsell_device(uint32_t rows, uint32_t cols, uint64_t nnz, const uint32_t *row, const uint32_t *col,
+                              const float *val, uint32_t n_partitions_hint, SellValues values, const uint32_t *d_col_in,
+                              const float *d_val_in, DeviceSell &out) {
+    const auto t0 = std::chrono::steady_clock::now();
+    out.d_packets = nullptr;
+    SellPlan plan;
+    const std::string perr = plan_wsell(rows, cols, nnz, row, col, n_partitions_hint, values, plan, out.meta);
+    if (!perr.empty() || nnz == 0) return perr;
+    const SellMatrix &sm = out.meta;
+    std::vector<SellLaneRec> recs((size_t)sm.n_slices * 64);
+    for (uint32_t so = 0; so < sm.n_slices; ++so) {
+        const SellLane *src = plan.lanes.data() + (size_t)plan.stream_slice[so] * 64;
+        SellLaneRec *dst = recs.data() + (size_t)so * 64;
+        for (uint32_t l = 0; l < 64; ++l) {
+            const SellLane &ln = src[l];
+            if (ln.row == SELL_NO_ROW) dst[l] = SellLaneRec{0ull, 0u, 0x80000000u};
+            else dst[l] = SellLaneRec{plan.start[ln.row] + ln.first, ln.n, ln.depth & 255u};
+        }
+    }
+    const auto t1 = std::chrono::steady_clock::now();
+    DevBuf d_col, d_val, d_recs, d_chunk0, d_nc, d_packets;
+    const uint32_t *dc = d_col_in;
+    const float *dv = d_val_in;
+    if (!dc) {  // the COO is not in HBM yet
+        DP_TRY(hipMalloc(&d_col.p, nnz * 4));
+        DP_TRY(hipMemcpy(d_col.p, col, nnz * 4, hipMemcpyHostToDevice));
+        dc = d_col.as<uint32_t>();
+        if (val) {
+            DP_TRY(hipMalloc(&d_val.p, nnz * 4));
+            DP_TRY(hipMemcpy(d_val.p, val, nnz * 4, hipMemcpyHostToDevice));
+            dv = d_val.as<float>();
+        }
+    }
+    if (!val) dv = nullptr;
+    DP_TRY(hipMalloc(&d_recs.p, recs.size() * sizeof(SellLaneRec)));
+    DP_TRY(hipMemcpy(d_recs.p, recs.data(), recs.size() * sizeof(SellLaneRec), hipMemcpyHostToDevice));
+    DP_TRY(hipMalloc(&d_chunk0.p, (size_t)sm.n_slices * 4));
+    DP_TRY(hipMemcpy(d_chunk0.p, plan.chunk0.data(), (size_t)sm.n_slices * 4, hipMemcpyHostToDevice));
+    DP_TRY(hipMalloc(&d_nc.p, (size_t)sm.n_slices * 4));
+    DP_TRY(hipMemcpy(d_nc.p, plan.n_chunks_of.data(), (size_t)sm.n_slices * 4, hipMemcpyHostToDevice));
+    DP_TRY(hipMalloc(&d_packets.p, std::max<size_t>(sm.stream_bytes(), 256)));
+    const auto t2 = std::chrono::steady_clock::now();
+    SellScatterParams S{};
+    S.col = dc;
+    S.val = dv;
+    S.lanes = d_recs.as<SellLaneRec>();
+    S.chunk0 = d_chunk0.as<uint32_t>();
+    S.n_chunks_of = d_nc.as<uint32_t>();
+    S.packets = d_packets.as<uint8_t>();
+    S.n_slices = sm.n_slices;
+    S.vb = (uint32_t)sm.values;
+    S.packet_bytes = sm.packet_bytes;
+    hipLaunchKernelGGL(sell_scatter_kernel, dim3(sm.n_slices), dim3(64), 0, 0, S);
+    DP_TRY(hipGetLastError());
+    DP_TRY(hipDeviceSynchronize());
+    const auto t3 = std::chrono::steady_clock::now();
+    out.plan_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    out.upload_ms = std::chrono::duration<double, std::milli>(t2 - t1).count();
+    out.kernels_ms = std::chrono::duration<double, std::milli>(t3 - t2).count();
+    out.d_packets = static_cast<uint8_t *>(d_packets.release());
+    return "";
+}
+
+std::string download_device_sell(DeviceSell &ds) {
+    ds.meta.packets.resize(ds.meta.stream_bytes());
+    if (ds.meta.stream_bytes()) DP_TRY(hipMemcpy(ds.meta.packets.data(), ds.d_packets, ds.meta.stream_bytes(), hipMemcpyDeviceToHost));
+    return "";
+}
+
+void free_device_sell(DeviceSell &ds) {
+    if (ds.d_packets) (void)hipFree(ds.d_packets);
+    ds.d_packets = nullptr;
 }
 
 }  // namespace tkspmv

@@ -178,6 +178,9 @@ struct EngineImpl {
     bool have_query = false;
     bool ran = false;
     bool packed_on_device = false;  // the stream was built by device_pack.hip
+    uint32_t sell_pack_us = 0;      // packing of the wave-sliced ELL copy (multi-query engines)
+    uint32_t *d_coo_col = nullptr;  // the COO's columns and values, kept in HBM between the two device packers (create only)
+    float *d_coo_val = nullptr;
     uint32_t pack_us = 0;           // time of the packing step of tkspmv_create (upload of the COO included when on the device)
 
     StreamParams stream_params(const float *x, int set = 0) const {
@@ -640,7 +643,7 @@ Engine::~Engine() {
     for (size_t r = 1; r < m.d_replicas.size(); ++r) (void)hipFree(m.d_replicas[r]);
     for (size_t r = 1; r < m.d_sell_replicas.size(); ++r) (void)hipFree(m.d_sell_replicas[r]);
     {
-        void *sb[] = {m.d_sell_packets, m.d_sell_rows, m.d_sell_part_first, m.d_sell_part_count, m.d_sell_part_slice0, m.d_multi_scratch, m.d_multi_out_idx, m.d_multi_out_val, m.d_rscores, m.d_rhist};
+        void *sb[] = {m.d_coo_col, m.d_coo_val, m.d_sell_packets, m.d_sell_rows, m.d_sell_part_first, m.d_sell_part_count, m.d_sell_part_slice0, m.d_multi_scratch, m.d_multi_out_idx, m.d_multi_out_val, m.d_rscores, m.d_rhist};
         for (void *b : sb)
             if (b) (void)hipFree(b);
     }
@@ -778,12 +781,16 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
         std::string perr;
         if (on_device) {
             DevicePacked dp;
+            // (a multi-query engine packs the same COO a second time below: leave its columns and values in HBM until then)
+            dp.keep_coo = d.cols <= SELL_XCOLS && (d.multi_q != 0 || d.impl == TKSPMV_IMPL_ROW_PER_LANE || getenv("TKSPMV_MULTI_Q"));
             perr = pack_wbscsr_device(d.rows, d.cols, d.nnz, d.row, d.col, d.val, stream_precision_of(d), C,
                                       n_stream_waves, 4, fixed_width_of(d), dp, kind);
             if (perr.empty()) {
                 m.pm = std::move(dp.meta);
                 m.d_packets = dp.d_packets;
                 m.d_pkt_row = dp.d_pkt_row;
+                m.d_coo_col = dp.d_col;
+                m.d_coo_val = dp.d_val;
                 m.packed_on_device = true;
             }
         } else {
@@ -948,25 +955,34 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
         const uint32_t n_multi_waves = (m.grid - (uint32_t)MULTI_Q_MAX) * m.multi_stream_waves;
         SellMatrix sm;
         std::string perr;
+        const auto t_sell = std::chrono::steady_clock::now();
         const SellValues sv = d.precision == TKSPMV_Q1_7_F32 ? SellValues::Q1_7_RND : SellValues::F32;
         if (prepacked) {  // no COO at hand: decode the packed matrix (byte values decode to exactly representable floats)
             std::vector<uint32_t> r, c;
             std::vector<float> v;
             decode_wbscsr(*prepacked, r, c, v);
             perr = pack_wsell(d.rows, d.cols, r.size(), r.data(), c.data(), v.data(), n_multi_waves, sm, sv);
+        } else if (m.packed_on_device) {  // plan on the host, fill on the device (device_pack.hip; same bytes)
+            DeviceSell ds;
+            perr = pack_wsell_device(d.rows, d.cols, d.nnz, d.row, d.col, d.val, n_multi_waves, sv, m.d_coo_col, m.d_coo_val, ds);
+            sm = std::move(ds.meta);
+            m.d_sell_packets = ds.d_packets;
         } else {
             perr = pack_wsell(d.rows, d.cols, d.nnz, d.row, d.col, d.val, n_multi_waves, sm, sv);
         }
+        m.sell_pack_us = (uint32_t)std::min<long long>(std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_sell).count(), 0xFFFFFFFFll);
         m.sell_packet_bytes = sm.packet_bytes;
         m.sell_byte_values = sv == SellValues::Q1_7_RND;
         if (!perr.empty()) {
             err = perr;
-            return TKSPMV_ERR_INVALID;
+            return perr.find("failed:") != std::string::npos ? TKSPMV_ERR_DEVICE : TKSPMV_ERR_INVALID;
         }
         m.sell_parts = (uint32_t)sm.part_first.size();
         m.sell_bytes = sm.stream_bytes() + sm.slice_rows.size() * 4 + (uint64_t)m.sell_parts * 12;
-        HIP_TRY(hipMalloc((void **)&m.d_sell_packets, std::max<size_t>(sm.stream_bytes(), 256)));
-        HIP_TRY(hipMemcpy(m.d_sell_packets, sm.packets.data(), sm.stream_bytes(), hipMemcpyHostToDevice));
+        if (!m.d_sell_packets) {
+            HIP_TRY(hipMalloc((void **)&m.d_sell_packets, std::max<size_t>(sm.stream_bytes(), 256)));
+            HIP_TRY(hipMemcpy(m.d_sell_packets, sm.packets.data(), sm.stream_bytes(), hipMemcpyHostToDevice));
+        }
         HIP_TRY(hipMalloc((void **)&m.d_sell_rows, sm.slice_rows.size() * 4));
         HIP_TRY(hipMemcpy(m.d_sell_rows, sm.slice_rows.data(), sm.slice_rows.size() * 4, hipMemcpyHostToDevice));
         HIP_TRY(hipMalloc((void **)&m.d_sell_part_first, (size_t)m.sell_parts * 4));
@@ -992,6 +1008,10 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
             }
         }
     }
+    if (m.d_coo_col) (void)hipFree(m.d_coo_col);
+    if (m.d_coo_val) (void)hipFree(m.d_coo_val);
+    m.d_coo_col = nullptr;
+    m.d_coo_val = nullptr;
     m.resident_capable = d.impl == TKSPMV_IMPL_RESIDENT && m.can_batch && d.precision == TKSPMV_F32 && C == 4u && m.xcols <= 1024u &&
                          m.h_res != nullptr && m.h_x != nullptr && m.h_x_dev != nullptr;
     if (m.resident_capable) {
@@ -1077,6 +1097,7 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
     m.info.multi_q = m.can_multi ? (uint32_t)m.multi_q : 0u;
     m.info.multi_bytes = m.can_multi ? m.sell_bytes : 0u;
     m.info.pack_us = m.pack_us;
+    m.info.multi_pack_us = m.sell_pack_us;
     m.info.pack_on_device = m.packed_on_device ? 1u : 0u;
     HIP_TRY(hipDeviceSynchronize());
     return TKSPMV_OK;

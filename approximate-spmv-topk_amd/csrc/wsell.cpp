@@ -10,12 +10,13 @@
 
 namespace tkspmv {
 
-std::string pack_wsell(uint32_t rows, uint32_t cols, uint64_t nnz, const uint32_t *row, const uint32_t *col, const float *val,
-                       uint32_t n_partitions_hint, SellMatrix &out, SellValues values) {
+std::string plan_wsell(uint32_t rows, uint32_t cols, uint64_t nnz, const uint32_t *row, const uint32_t *col,
+                       uint32_t n_partitions_hint, SellValues values, SellPlan &plan, SellMatrix &out) {
     if (cols == 0 || cols > SELL_XCOLS) return "the multi-query layout is built for at most 1024 columns";
     if (nnz > 0 && (!row || !col)) return "row/col arrays are NULL";
     if (n_partitions_hint == 0) n_partitions_hint = 1;
     out = SellMatrix();
+    plan = SellPlan();
     out.rows = rows;
     out.cols = cols;
     out.nnz = nnz;
@@ -33,12 +34,9 @@ std::string pack_wsell(uint32_t rows, uint32_t cols, uint64_t nnz, const uint32_
         if (col[i] >= cols) return "column id out of range (>= cols)";
         ++len[row[i]];
     }
-    std::vector<uint64_t> start(len.size() + 1, 0);
-    uint32_t max_len = 0;
-    for (size_t r = 0; r < len.size(); ++r) {
-        start[r + 1] = start[r] + len[r];
-        max_len = std::max(max_len, len[r]);
-    }
+    std::vector<uint64_t> &start = plan.start;
+    start.assign(len.size() + 1, 0);
+    for (size_t r = 0; r < len.size(); ++r) start[r + 1] = start[r] + len[r];
     // Units = non-empty rows; a row of more than SELL_SEG entries takes several adjacent lanes, cut into EQUAL segments
     // (sell_segment_length: a 80-entry row becomes 40 + 40, not 64 + 16 padded to 64) and its length class is that segment
     // length, so it sorts among the ordinary rows of that length. Units by length class, longest first, ties by row id
@@ -58,26 +56,22 @@ std::string pack_wsell(uint32_t rows, uint32_t cols, uint64_t nnz, const uint32_
         if (len[r]) order[bucket[max_class - sell_segment_length(len[r])]++] = r;
 
     // Slices: 64 lanes filled in that order; a multi-lane row never straddles two slices (lanes left over stay empty).
-    struct Lane {
-        uint32_t row, first, n, depth;  // entries [first, first + n) of `row`; depth = index of the segment in its row
-        bool tail;                      // last segment of its row: the lane that ends up with the row's score
-    };
-    std::vector<Lane> lanes;             // 64 per slice, row == SELL_NO_ROW: lane without a row
-    std::vector<uint32_t> slice_chunks;  // chunks of every slice
+    std::vector<SellLane> &lanes = plan.lanes;  // 64 per slice, row == SELL_NO_ROW: lane without a row
+    std::vector<uint32_t> slice_chunks;         // chunks of every slice
     {
         uint32_t used = 64;  // lanes used in the open slice (64: none open)
         for (uint64_t u = 0; u < n_ne; ++u) {
             const uint32_t r = order[u], L = len[r], slen = sell_segment_length(L), nseg = (L + slen - 1) / slen;
             if (used + nseg > 64u) {
-                if (used < 64u) lanes.resize(lanes.size() + (64u - used), Lane{SELL_NO_ROW, 0, 0, 0, false});
+                if (used < 64u) lanes.resize(lanes.size() + (64u - used), SellLane{SELL_NO_ROW, 0, 0, 0, 0});
                 slice_chunks.push_back((slen + 3) / 4);  // the slice's first lane is its longest
                 used = 0;
             }
             for (uint32_t g = 0; g < nseg; ++g)
-                lanes.push_back(Lane{r, g * slen, std::min(slen, L - g * slen), g, g + 1 == nseg});
+                lanes.push_back(SellLane{r, g * slen, std::min(slen, L - g * slen), g, g + 1 == nseg ? 1u : 0u});
             used += nseg;
         }
-        if (used < 64u) lanes.resize(lanes.size() + (64u - used), Lane{SELL_NO_ROW, 0, 0, 0, false});
+        if (used < 64u) lanes.resize(lanes.size() + (64u - used), SellLane{SELL_NO_ROW, 0, 0, 0, 0});
     }
     if (slice_chunks.size() > 0x7FFFFFFFull) return "matrix too large";
     const uint32_t n_slices = (uint32_t)slice_chunks.size();
@@ -108,59 +102,83 @@ std::string pack_wsell(uint32_t rows, uint32_t cols, uint64_t nnz, const uint32_
     out.n_slices = n_slices;
     out.n_chunks = (uint32_t)n_chunks;
     out.padded_entries = n_chunks * 256;
-    out.packets.assign((size_t)n_chunks * PB, 0);
     out.slice_rows.assign((size_t)n_slices * 64, SELL_NO_ROW);
     out.part_first.resize(P);
     out.part_count.resize(P);
     out.part_slice0.resize(P);
-
-    const float neg_inf = -std::numeric_limits<float>::infinity();
+    // stream order: a partition's slices are contiguous; slice `so` of the stream is slice stream_slice[so] of the sorted order
+    plan.stream_slice.resize(n_slices);
+    plan.chunk0.resize(n_slices);
+    plan.n_chunks_of.resize(n_slices);
     uint32_t chunk = 0, slice_out = 0;
     for (uint32_t p = 0; p < P; ++p) {
         out.part_first[p] = chunk;
         out.part_slice0[p] = slice_out;
         for (uint32_t s : part_slices[p]) {
-            const uint32_t nc = slice_chunks[s];
+            plan.stream_slice[slice_out] = s;
+            plan.chunk0[slice_out] = chunk;
+            plan.n_chunks_of[slice_out] = slice_chunks[s];
             for (uint32_t l = 0; l < 64; ++l) {
-                const Lane &ln = lanes[(size_t)s * 64 + l];
-                const bool have = ln.row != SELL_NO_ROW;
-                if (have && ln.tail) out.slice_rows[(size_t)slice_out * 64 + l] = ln.row;
-                for (uint32_t c = 0; c < nc; ++c) {
-                    uint8_t *pkt = out.packets.data() + (size_t)(chunk + c) * PB;
-                    for (uint32_t j = 0; j < 4; ++j) {
-                        const uint32_t e = 4 * c + j;
-                        float v;
-                        uint8_t qv;  // byte values
-                        uint16_t cw;
-                        if (have && e < ln.n) {
-                            const uint64_t src = start[ln.row] + ln.first + e;
-                            v = val ? val[src] : 1.0f;
-                            qv = to_q1_7_rnd(v);
-                            cw = (uint16_t)(col[src] << 2);
-                        } else if (!have && e == 0) {
-                            v = neg_inf;  // a lane without a row: its sum is -inf
-                            qv = 1;       // (byte values: the PAD_ONE slot holds -inf)
-                            cw = (uint16_t)(SELL_PAD_ONE << 2);
-                        } else {
-                            v = 0.0f;  // (+0.0) * (-0.0) = -0.0: leaves every sum as it is
-                            qv = 0;
-                            cw = (uint16_t)(SELL_PAD_NEUTRAL << 2);
-                        }
-                        if (c + 1 == nc) {  // flags of the slice's last chunk
-                            if (j == 0) cw |= SELL_LAST_CHUNK;
-                            if (j >= 1) cw |= (uint16_t)((ln.depth >> (2 * (j - 1))) & 3u);  // segment index, 2 bits per word
-                        }
-                        if (vb == 4u) std::memcpy(pkt + ((size_t)l * 4 + j) * 4, &v, 4);
-                        else pkt[(size_t)l * 4 + j] = qv;
-                        std::memcpy(pkt + 256u * vb + ((size_t)l * 4 + j) * 2, &cw, 2);
-                    }
-                }
+                const SellLane &ln = lanes[(size_t)s * 64 + l];
+                if (ln.row != SELL_NO_ROW && ln.tail) out.slice_rows[(size_t)slice_out * 64 + l] = ln.row;
             }
-            chunk += nc;
+            chunk += slice_chunks[s];
             ++slice_out;
         }
         out.part_count[p] = chunk - out.part_first[p];
     }
+    return "";
+}
+
+void fill_wsell_host(const SellPlan &plan, const uint32_t *col, const float *val, SellMatrix &out) {
+    const uint32_t vb = (uint32_t)out.values, PB = out.packet_bytes;
+    out.packets.assign((size_t)out.n_chunks * PB, 0);
+    const float neg_inf = -std::numeric_limits<float>::infinity();
+    for (uint32_t so = 0; so < out.n_slices; ++so) {
+        const uint32_t s = plan.stream_slice[so], nc = plan.n_chunks_of[so], chunk = plan.chunk0[so];
+        for (uint32_t l = 0; l < 64; ++l) {
+            const SellLane &ln = plan.lanes[(size_t)s * 64 + l];
+            const bool have = ln.row != SELL_NO_ROW;
+            for (uint32_t c = 0; c < nc; ++c) {
+                uint8_t *pkt = out.packets.data() + (size_t)(chunk + c) * PB;
+                for (uint32_t j = 0; j < 4; ++j) {
+                    const uint32_t e = 4 * c + j;
+                    float v;
+                    uint8_t qv;  // byte values
+                    uint16_t cw;
+                    if (have && e < ln.n) {
+                        const uint64_t src = plan.start[ln.row] + ln.first + e;
+                        v = val ? val[src] : 1.0f;
+                        qv = to_q1_7_rnd(v);
+                        cw = (uint16_t)(col[src] << 2);
+                    } else if (!have && e == 0) {
+                        v = neg_inf;  // a lane without a row: its sum is -inf
+                        qv = 1;       // (byte values: the PAD_ONE slot holds -inf)
+                        cw = (uint16_t)(SELL_PAD_ONE << 2);
+                    } else {
+                        v = 0.0f;  // (+0.0) * (-0.0) = -0.0: leaves every sum as it is
+                        qv = 0;
+                        cw = (uint16_t)(SELL_PAD_NEUTRAL << 2);
+                    }
+                    if (c + 1 == nc) {  // flags of the slice's last chunk
+                        if (j == 0) cw |= SELL_LAST_CHUNK;
+                        if (j >= 1) cw |= (uint16_t)((ln.depth >> (2 * (j - 1))) & 3u);  // segment index, 2 bits per word
+                    }
+                    if (vb == 4u) std::memcpy(pkt + ((size_t)l * 4 + j) * 4, &v, 4);
+                    else pkt[(size_t)l * 4 + j] = qv;
+                    std::memcpy(pkt + 256u * vb + ((size_t)l * 4 + j) * 2, &cw, 2);
+                }
+            }
+        }
+    }
+}
+
+std::string pack_wsell(uint32_t rows, uint32_t cols, uint64_t nnz, const uint32_t *row, const uint32_t *col, const float *val,
+                       uint32_t n_partitions_hint, SellMatrix &out, SellValues values) {
+    SellPlan plan;
+    const std::string err = plan_wsell(rows, cols, nnz, row, col, n_partitions_hint, values, plan, out);
+    if (!err.empty() || nnz == 0) return err;
+    fill_wsell_host(plan, col, val, out);
     return "";
 }
 

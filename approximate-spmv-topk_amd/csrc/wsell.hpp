@@ -71,6 +71,25 @@ struct SellMatrix {
     uint64_t stream_bytes() const { return (uint64_t)n_chunks * packet_bytes; }
 };
 
+// The layout decisions of a pack -- which segment of which row sits on which lane of which slice, and where every slice
+// lies in the stream -- without the nnz-sized fill: shared by the host packer (fill_wsell_host) and the device packer
+// (device_pack.hip: sell_scatter_kernel), so the two produce the same bytes by construction of everything but the fill.
+struct SellLane {
+    uint32_t row, first, n, depth;  // entries [first, first + n) of `row`; depth = index of the segment in its row
+    uint32_t tail;                  // 1: last segment of its row (the lane that ends up with the row's score)
+};
+struct SellPlan {
+    std::vector<uint64_t> start;         // [rows + 1] offset of every row's entries in the COO
+    std::vector<SellLane> lanes;         // 64 per slice, in the SORTED slice order; row == SELL_NO_ROW: lane without a row
+    std::vector<uint32_t> stream_slice;  // [n_slices] sorted-order index of the slice at stream position so
+    std::vector<uint32_t> chunk0;        // [n_slices] first chunk of the slice at stream position so
+    std::vector<uint32_t> n_chunks_of;   // [n_slices] its chunk count
+};
+// Fills out everything of `out` but `packets` (validated like pack_wbscsr). Returns an empty string on success.
+std::string plan_wsell(uint32_t rows, uint32_t cols, uint64_t nnz, const uint32_t *row, const uint32_t *col,
+                       uint32_t n_partitions_hint, SellValues values, SellPlan &plan, SellMatrix &out);
+void fill_wsell_host(const SellPlan &plan, const uint32_t *col, const float *val, SellMatrix &out);
+
 // Packs a row-sorted COO (validated like pack_wbscsr). Returns an empty string on success.
 std::string pack_wsell(uint32_t rows, uint32_t cols, uint64_t nnz, const uint32_t *row, const uint32_t *col, const float *val,
                        uint32_t n_partitions_hint, SellMatrix &out, SellValues values = SellValues::F32);

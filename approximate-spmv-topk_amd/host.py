@@ -146,6 +146,25 @@ def sell_roundtrip(m, n_wave_partitions=4088):
     return orow[:n], ocol[:n], oval[:n], dict(zip(keys, (int(v) for v in info)))
 
 
+def sell_pack_device_check(m, n_wave_partitions=4088, precision=_lib.F32, device=-1):
+    """Packs m into the wave-sliced ELL layout on the host and with the device packer (needs a GPU) and compares the two
+    byte for byte: dict(identical, stream_bytes, chunks, host_ms, plan_ms, upload_ms, fill_ms)."""
+    row = np.ascontiguousarray(m.row, dtype=np.uint32)
+    col = np.ascontiguousarray(m.col, dtype=np.uint32)
+    val = np.ascontiguousarray(m.val, dtype=np.float32)
+    d = _lib.Desc()
+    d.rows, d.cols, d.nnz = m.rows, m.cols, row.shape[0]
+    d.precision, d.device = int(precision), int(device)
+    d.row = row.ctypes.data_as(C.POINTER(C.c_uint32))
+    d.col = col.ctypes.data_as(C.POINTER(C.c_uint32))
+    d.val = val.ctypes.data_as(C.POINTER(C.c_float))
+    info = (C.c_uint64 * 3)()
+    ms = (C.c_double * 4)()
+    _lib.check(_lib.lib().tkspmv_sell_pack_device_check(C.byref(d), int(n_wave_partitions), info, ms))
+    return {"identical": bool(info[0]), "stream_bytes": int(info[1]), "chunks": int(info[2]), "host_ms": ms[0],
+            "plan_ms": ms[1], "upload_ms": ms[2], "fill_ms": ms[3]}
+
+
 class Packed:
     """Host-side packed (wave-BSCSR) matrix, for layout tests: decode(pack(A)) == A."""
 

@@ -146,7 +146,7 @@ typedef struct {
     uint32_t num_cus;
     uint32_t fixed_width;         /* TKSPMV_FIXED: bits per value; 0 otherwise */
     uint32_t multi_q;             /* queries per matrix pass of tkspmv_enqueue_multi; 0 = this engine has no multi-query kernel */
-    uint32_t reserved0;
+    uint32_t multi_pack_us;       /* tkspmv_create: microseconds spent packing the wave-sliced ELL copy (0 without it) */
     uint64_t multi_bytes;         /* bytes of the wave-sliced ELL copy the multi-query kernel streams (0 without it) */
     uint32_t pack_us;             /* tkspmv_create: microseconds spent packing (on the device: upload of the COO included) */
     uint32_t pack_on_device;      /* 1: the stream was packed by the device packer (default), 0: by the host packer */
@@ -320,6 +320,11 @@ int tkspmv_pack_device(const tkspmv_desc *desc, uint32_t n_wave_partitions_hint,
  * stream order). info[0..5] = slices, chunks, padded entries, partitions, stream bytes, most chunks in one partition. */
 int tkspmv_sell_roundtrip(const tkspmv_desc *desc, uint32_t n_wave_partitions_hint, uint32_t *row, uint32_t *col, float *val,
                           uint64_t *n, uint64_t *info);
+/* Packs desc's COO into that layout twice -- on the host and with the device packer tkspmv_create uses (plan on the
+ * host, fill kernel on desc->device) -- and compares the two byte for byte, side tables included.
+ * info[0] = 1 if identical, info[1] = stream bytes, info[2] = chunks; ms[0] = host packer, ms[1..3] = device packer:
+ * plan, uploads (the COO included), fill kernel (ms may be NULL). Needs a GPU. */
+int tkspmv_sell_pack_device_check(const tkspmv_desc *desc, uint32_t n_wave_partitions_hint, uint64_t *info, double *ms);
 
 /* ---- packed-matrix cache ------------------------------------------------------------------------
  * The reference parses the MatrixMarket text (utils.hpp:380-388, minutes at 10^7 rows) and packs

@@ -106,3 +106,68 @@ def test_full_size_identical_and_engine_uses_the_device_packer(pkg, oracle, monk
     print(f"[tkspmv_create, packing step] on the device {res[0][2] / 1e3:.0f} ms, on the host {res[1][2] / 1e3:.0f} ms")
     gi, gv = oracle.gold_topk(m.row, m.col, m.val, x, 100)
     assert set(res[0][1].tolist()) == set(gi.tolist())
+
+
+# ---- the wave-sliced ELL layout of the multi-query kernel (wsell.cpp / device_pack.hip: sell_scatter_kernel) -------------
+@pytest.mark.parametrize("precision", ["F32", "Q1_7_F32"])
+@pytest.mark.parametrize("rows,cols,nnz,dist,seed,hint", [(20000, 1024, 20, "gamma", 1, 4088), (3000, 512, 40, "uniform", 2, 4088),
+                                                          (150000, 300, 25, "gamma", 3, 512), (700, 64, 5, "uniform", 4, 4088)])
+def test_sell_layout_packs_identically(pkg, precision, rows, cols, nnz, dist, seed, hint):
+    m = pkg.generate_matrix(rows, cols, nnz, dist, seed)
+    r = pkg.sell_pack_device_check(m, hint, precision=getattr(pkg, precision))
+    assert r["identical"] and r["chunks"] > 0 and r["stream_bytes"] == r["chunks"] * (1536 if precision == "F32" else 768)
+
+
+@pytest.mark.parametrize("precision", ["F32", "Q1_7_F32"])
+@pytest.mark.parametrize("name,lens,cols,hint", [
+    ("empty rows and rows of several lanes", [0, 3, 0, 0, 700, 1, 0, 256, 257, 0, 5, 64, 65, 80] * 30, 128, 64),
+    ("one row", [17], 32, 4088),
+    ("one entry", [1], 1, 4088),
+    ("leading and trailing empty rows", [0, 0, 0, 4, 9, 0, 0], 16, 8),
+    ("a row of 4096 entries (64 lanes) among small ones", [2] * 500 + [4096] + [2] * 500, 512, 32),
+    ("many tiny rows", [1] * 20000, 64, 4088),
+    ("more partitions than slices", [5] * 100, 64, 4088),
+])
+def test_sell_edge_layouts_pack_identically(pkg, precision, name, lens, cols, hint):
+    m = _coo(pkg, lens, cols, seed=len(lens))
+    assert pkg.sell_pack_device_check(m, hint, precision=getattr(pkg, precision))["identical"]
+
+
+def test_sell_errors_match_the_host_packer(pkg):
+    m = _coo(pkg, [3, 4, 5], 16)
+    for bad, what in ((pkg.CooMatrix(3, 16, m.row[::-1].copy(), m.col, m.val), "not sorted"),
+                      (pkg.CooMatrix(3, 8, m.row, m.col, m.val), "column id"),
+                      (pkg.CooMatrix(2, 16, m.row, m.col, m.val), "row id"),
+                      (_coo(pkg, [2, 5000, 2], 512), "too long")):
+        with pytest.raises(pkg.TkspmvError) as e:
+            pkg.sell_pack_device_check(bad, 64)
+        assert e.value.status == pkg._lib.ERR_INVALID and what in e.value.message
+
+
+def test_sell_full_size_identical_and_multi_query_engine_uses_it(pkg, oracle, monkeypatch):
+    """BASELINE configs[1]'s matrix in the row-per-lane layout: identical bytes and both packers' times; a multi-query
+    engine built either way returns the same bits."""
+    m = pkg.generate_matrix(1000000, 1024, 20, "gamma", 2)
+    r = pkg.sell_pack_device_check(m, 4088)
+    assert r["identical"]
+    print(f"\n[row-per-lane layout, 1M x 1024, {r['stream_bytes'] / 1e6:.0f} MB] host packer {r['host_ms']:.0f} ms; device packer: plan "
+          f"{r['plan_ms']:.0f} ms + uploads (COO included) {r['upload_ms']:.0f} ms + fill kernel {r['fill_ms']:.1f} ms")
+    import torch
+    rng = np.random.RandomState(5)
+    X = rng.rand(8, 1024).astype(np.float32)
+    dxs = torch.from_numpy(X).cuda()
+    res = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("TKSPMV_DEVICE_PACK", flag)
+        eng = pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, vec=X[0], k=100, device=0, multi_q=4)
+        assert eng.info()["pack_on_device"] == int(flag) and eng.info()["multi_q"] == 4
+        out_i = torch.full((8, 100), -1, dtype=torch.int32, device="cuda")
+        out_v = torch.full((8, 100), -1.0, dtype=torch.float32, device="cuda")
+        eng.enqueue_multi(dxs.data_ptr(), 8, out_i.data_ptr(), out_v.data_ptr())
+        eng.synchronize()
+        res.append((out_i.cpu().numpy(), out_v.cpu().numpy(), eng.info()["multi_pack_us"]))
+        eng.close()
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1].view(np.uint32), res[1][1].view(np.uint32))
+    print(f"[tkspmv_create, packing of the row-per-lane copy] device path {res[0][2] / 1e3:.0f} ms, host path {res[1][2] / 1e3:.0f} ms")
+    gi, gv = oracle.gold_topk(m.row, m.col, m.val, X[3], 100)
+    assert set(res[0][0][3].tolist()) == set(gi.tolist())
