@@ -103,6 +103,9 @@ int tkspmv_time_multi(tkspmv_t *h, const float *dev_xs, int32_t n_x, int32_t ite
 int tkspmv_time_queries(tkspmv_t *h, const float *dev_xs, int32_t n_x, int32_t iters, double *ns_per_query) {
     ENGINE_CALL(time_queries(dev_xs, n_x, iters, ns_per_query, err))
 }
+int tkspmv_time_stream_read(tkspmv_t *h, int32_t passes, double *ns_per_pass) {
+    ENGINE_CALL(time_stream_read(passes, ns_per_pass, err))
+}
 int tkspmv_profile(tkspmv_t *h, const float *dev_xs, int32_t n_x, int32_t iters, tkspmv_timing *out) {
     ENGINE_CALL(profile(dev_xs, n_x, iters, out, err))
 }

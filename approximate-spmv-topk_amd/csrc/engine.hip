@@ -40,6 +40,7 @@
 #include "kernels/batch_kernel.hpp"
 #include "kernels/multi_kernel.hpp"
 #include "kernels/radix_select.hpp"
+#include "kernels/read_probe.hpp"
 
 namespace tkspmv {
 
@@ -1580,6 +1581,68 @@ int Engine::time_queries(const float *dev_xs, int32_t n_x, int32_t iters, double
     return TKSPMV_OK;
 }
 
+int Engine::time_stream_read(int32_t passes, double *ns_per_pass, std::string &err) {
+    EngineImpl &m = *impl_;
+    if (passes < 1 || !ns_per_pass) {
+        err = "bad arguments to time_stream_read";
+        return TKSPMV_ERR_INVALID;
+    }
+    if (m.pm.n_packets == 0) {
+        *ns_per_pass = 0.0;
+        return TKSPMV_OK;
+    }
+    HIP_TRY(hipSetDevice(m.device));
+    HIP_TRY(m.leave_resident_mode());
+    const uint32_t stream_block = m.block;  // the streaming waves of a workgroup (the server wave of a sequence launch aside)
+    ReadProbeParams R{};
+    R.n_replicas = m.d_replicas.empty() ? 1u : (uint32_t)std::min<size_t>(m.d_replicas.size(), 8);
+    for (uint32_t r = 0; r < 8u; ++r) R.replicas[r] = m.d_replicas.empty() ? m.d_packets : m.d_replicas[r % m.d_replicas.size()];
+    R.part_first = m.d_part_first;
+    R.part_count = m.d_part_count;
+    R.n_parts = (uint32_t)m.pm.part_first.size();
+    R.n_pass = (uint32_t)passes;
+    uint32_t *sink = nullptr;
+    HIP_TRY(hipMalloc((void **)&sink, (size_t)m.grid * 16 * 4));
+    R.sink = sink;
+    void (*fn)(ReadProbeParams) = nullptr;
+    switch (m.pm.packet_bytes / 64u) {
+        case 24: fn = read_probe_kernel<24>; break;
+        case 48: fn = read_probe_kernel<48>; break;
+        case 16: fn = read_probe_kernel<16>; break;
+        case 12: fn = read_probe_kernel<12>; break;
+        default: break;
+    }
+    if (const char *f = getenv("TKSPMV_READ_PROBE")) {  // "depth,work" (tuning runs; fp32 packets only)
+        int depth = 8, work = 0;
+        sscanf(f, "%d,%d", &depth, &work);
+        if (m.pm.packet_bytes == 1536u) {
+#define RP(D, W) if (depth == D && work == W) fn = read_probe_kernel<24, D, W>;
+            RP(3, -1) RP(3, -2) RP(4, -2) RP(2, 0) RP(3, 0) RP(4, 0) RP(6, 0) RP(12, 0) RP(16, 0)
+            RP(3, 1) RP(3, 32) RP(3, 64) RP(3, 96) RP(3, 128) RP(4, 64) RP(4, 96) RP(6, 64) RP(6, 96) RP(8, 64) RP(8, 96) RP(8, 1)
+#undef RP
+        }
+    }
+    if (!fn) {
+        (void)hipFree(sink);
+        err = "no read probe for this packet size";
+        return TKSPMV_ERR_UNSUPPORTED;
+    }
+    HIP_TRY(hipStreamSynchronize(m.stream));
+    R.n_pass = 2;  // (warm-up: code object, clocks)
+    hipLaunchKernelGGL(fn, dim3(m.grid), dim3(stream_block), 0, m.stream, R);
+    R.n_pass = (uint32_t)passes;
+    HIP_TRY(hipEventRecord(m.ev0, m.stream));
+    hipLaunchKernelGGL(fn, dim3(m.grid), dim3(stream_block), 0, m.stream, R);
+    HIP_TRY(hipEventRecord(m.ev1, m.stream));
+    HIP_TRY(hipEventSynchronize(m.ev1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, m.ev0, m.ev1));
+    HIP_TRY(hipGetLastError());
+    (void)hipFree(sink);
+    *ns_per_pass = (double)ms * 1e6 / passes;
+    return TKSPMV_OK;
+}
+
 int Engine::profile(const float *dev_xs, int32_t n_x, int32_t iters, tkspmv_timing *out, std::string &err) {
     EngineImpl &m = *impl_;
     if (!dev_xs || n_x < 1 || iters < 1 || !out) {
@@ -1679,8 +1742,10 @@ int Engine::profile(const float *dev_xs, int32_t n_x, int32_t iters, tkspmv_timi
     if (m.collect_stats) {
         unsigned long long sx[12];
         HIP_TRY(hipMemcpy(sx, m.d_stats, sizeof(sx), hipMemcpyDeviceToHost));
-        fprintf(stderr, "[tkspmv stats] selections %llu, general-path selections %llu, max candidates %llu, overflow entries per selection %.1f\n",
-                sx[1], sx[3], sx[2], (double)sx[8] / (double)std::max<unsigned long long>(1, sx[1]));
+        const double nsel = (double)std::max<unsigned long long>(1, sx[1]);
+        fprintf(stderr, "[tkspmv stats] selections %llu, general-path selections %llu, max candidates %llu, overflow entries per selection %.1f; "
+                        "per selection: waves that waited for a threshold at the end of their partition %.1f (%.1f us in all)\n",
+                sx[1], sx[3], sx[2], (double)sx[8] / nsel, (double)sx[10] / nsel, (double)sx[9] / 100.0 / nsel);
     }
     if (m.collect_stamps) {
         unsigned long long st[16];

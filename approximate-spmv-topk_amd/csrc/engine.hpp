@@ -46,6 +46,7 @@ class Engine {
     int scores(float *host_y, std::string &err);
     int read_trace(unsigned long long *host, size_t max_words, size_t *words, std::string &err);
     int time_queries(const float *dev_xs, int32_t n_x, int32_t iters, double *ns_per_query, std::string &err);
+    int time_stream_read(int32_t passes, double *ns_per_pass, std::string &err);
     int profile(const float *dev_xs, int32_t n_x, int32_t iters, tkspmv_timing *out, std::string &err);
     void info(tkspmv_info *out) const;
 

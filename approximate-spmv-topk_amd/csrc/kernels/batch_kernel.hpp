@@ -31,6 +31,7 @@ constexpr uint32_t STG_N = 8;  // survivors a wave can stage per query (64 lanes
 #define TKSPMV_TAU_WAIT 3000
 #endif
 constexpr unsigned long long BATCH_TAU_WAIT = TKSPMV_TAU_WAIT;  // x 10 ns (s_memrealtime runs at 100 MHz)
+constexpr int MISC_DBG_WAITS = 26, MISC_DBG_WAIT_TICKS = 27;  // TKSPMV_STATS=1 only
 constexpr int MISC_XREADY = 2, MISC_MINU = 3;  // batch kernel only: x staged for query (value - 1); min score in units
 
 // Per query only what differs from query to query travels in the kernel arguments (32 bytes); the exchange-state set of
@@ -94,6 +95,9 @@ struct BatchLds {
     // Deferred packets (threshold exchange cold start) wait here, not in registers: row sums and packed row flags per
     // lane. No register cost, so more packets can be deferred (5 while x is small) and fewer rows are appended before
     // the threshold has arrived.
+#ifndef TKSPMV_ALTERNATE_PRIO
+#define TKSPMV_ALTERNATE_PRIO 1
+#endif
 #ifndef TKSPMV_DEFER_B
 #define TKSPMV_DEFER_B 2
 #endif
@@ -213,15 +217,21 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
                 S.wt_reset = 1u;                   // the sets are reused within this launch: resets must be written through
                 S.t_seen = t_seen;                 // (wave 0 holds it; thread 0 reports the query's device time)
             }
+            // (timing aid, TKSPMV_DBG_FLAGS & 16: the set keeps its final threshold, and the next query that uses the set
+            //  starts from it -- exact when the same vector comes back, tools/ablate_probe.py: what a threshold that is
+            //  there from a query's first packet would be worth: 0.7 us of 20.5 on BASELINE configs[1])
+            const uint32_t keep_tau = (DBG && (P0.dbg_flags & 16u)) ? __hip_atomic_load(S.tau_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
             select_body(S, tid, blockDim.x, L.u.sel);
             __syncthreads();
+            if (DBG && (P0.dbg_flags & 16u) && tid == 0) *S.tau_g = keep_tau;
             if (P0.trace && tid == 0 && q < 8u) P0.trace[q] = __builtin_amdgcn_s_memrealtime();
         }
         return;
     }
     const uint32_t bid = blockIdx.x - 1u, n_wg = gridDim.x - 1u;
     // traced queries: the first, the middle and the last of the batch
-#define TRSLOT(q) ((q) == 0u ? 0u : ((q) == nq / 2u ? 1u : ((q) + 1u == nq ? 2u : 9u)))
+// traced queries: the first, the middle one and (batches of 8 or more) the one after it, else the last
+#define TRSLOT(q) ((q) == 0u ? 0u : ((q) == nq / 2u ? 1u : ((q) == (nq >= 8u ? nq / 2u + 1u : nq - 1u) ? 2u : 9u)))
     unsigned long long *trw = P0.trace ? P0.trace + ((size_t)blockIdx.x * 9u + wave) * 8u : nullptr;
     if (trw && lane == 0) trw[0] = __builtin_amdgcn_s_memrealtime();
     if (tid < 2u * MISC_WORDS) (&L.misc[0][0])[tid] = 0u;
@@ -338,8 +348,13 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
                 if (lane < (uint32_t)MISC_WORDS && lane != (uint32_t)MISC_XREADY) mp[lane] = 0u;
                 if (lane < 8u) L.stg_cnt[par][lane] = 0u;
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                float tau_init = min_units_q[par];
+                if (DBG && (P0.dbg_flags & 16u)) {
+                    const uint32_t kx = __hip_atomic_load(B.tau_g(set_of(staged)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (kx && key_to_float(kx) > tau_init) tau_init = key_to_float(kx);
+                }
                 if (lane == 0) {
-                    mp[MISC_TAU] = __float_as_uint(min_units_q[par]);
+                    mp[MISC_TAU] = __float_as_uint(tau_init);
                     mp[MISC_MINU] = __float_as_uint(min_units_q[par]);
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -397,6 +412,8 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
                     if (P0.dbg && lane == 0) {  // TKSPMV_STATS=1
                         atomicAdd(&P0.dbg[0], (unsigned long long)mp[MISC_SLOW_CNT]);
                         atomicAdd(&P0.dbg[1], (unsigned long long)mp[MISC_CAND_CNT]);
+                        atomicAdd(&P0.dbg[5], (unsigned long long)mp[MISC_DBG_WAIT_TICKS]);
+                        atomicAdd(&P0.dbg[6], (unsigned long long)mp[MISC_DBG_WAITS]);
                     }
                     // lane l copies entry (l % 8) of wave (l / 8): the first goes to the wave's slot, others to the
                     // query's overflow list
@@ -517,6 +534,14 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
                 carry = 0.0f;
                 wcnt = 0u;
                 waited = false;
+#if TKSPMV_ALTERNATE_PRIO
+                // The two workgroups of a CU do not share it evenly at equal priority: the older one wins the arbitration
+                // (traced over a 32-query launch: 17.2 against 21.5 us per query), runs ahead, finishes early and leaves
+                // the CU half empty while the launch waits for the slower half. They take turns instead, query by query:
+                // 18.7 against 19.8-20.3 us per query on one box (tools/ab_variants.sh; turns of 2 or 4 packets gain less).
+                if (((qc ^ (bid >= n_wg / 2u ? 1u : 0u)) & 1u) != 0u) __builtin_amdgcn_s_setprio(TKSPMV_STREAM_PRIO);
+                else __builtin_amdgcn_s_setprio(TKSPMV_STREAM_PRIO - 1);
+#endif
             }
             const float tau = __uint_as_float(lds_load(&mp[MISC_TAU]));
             const RowSums<C> R = reduce_packet<C, QM>(cur, carry, xq, P0.fixed_mask);
@@ -561,6 +586,13 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
                     while (P0.tau_possible && lds_load(&mp[MISC_TAU]) == __float_as_uint(min_units) && !(P0.dbg_flags & 4u) &&
                            __builtin_amdgcn_s_memrealtime() - t0 < BATCH_TAU_WAIT)
                         __builtin_amdgcn_s_sleep(4);
+                    if (DBG && P0.dbg && lane == 0) {  // TKSPMV_STATS=1
+                        const unsigned long long dt = __builtin_amdgcn_s_memrealtime() - t0;
+                        if (dt > 50ull) {
+                            atomicAdd(&mp[MISC_DBG_WAIT_TICKS], (uint32_t)dt);
+                            atomicAdd(&mp[MISC_DBG_WAITS], 1u);
+                        }
+                    }
                     const float tau2 = __uint_as_float(lds_load(&mp[MISC_TAU]));
                     const uint32_t nd = np < DEFER_B ? np : DEFER_B;
                     for (uint32_t d = 0; d < nd; ++d) {

@@ -1,0 +1,112 @@
+// kernels/read_probe.hpp -- measurement aid: the packet stream read and nothing else (read_probe_kernel).
+// Part of engine.hip (one translation unit; device code only).
+#pragma once
+#include "common.hpp"
+#include "packet_math.hpp"
+
+namespace tkspmv {
+
+// What does it cost on THIS GPU to move the matrix stream from HBM into registers, with the engine's own geometry (same
+// grid, same waves, same partition of the stream among them, the same wide non-temporal loads) and no arithmetic, no
+// x, no selection? bench.py reports the streaming kernels against this figure beside the 8 TB/s specification: boxes of
+// one pool differ by several per cent, and the best plain copy the microarchitecture guide measured is 6.29 TB/s.
+// One launch makes n_pass passes (rotating the stream copies like the batch kernel), so that no launch boundary falls
+// into the timed region. Every loaded word is folded into a value that is stored once per wave (the loads cannot be
+// dropped by the compiler).
+struct ReadProbeParams {
+    const uint8_t *replicas[8];
+    uint32_t n_replicas;
+    const uint32_t *part_first, *part_count;
+    uint32_t n_parts, n_pass;
+    uint32_t *sink;  // [grid * waves]
+};
+
+template <int BPL>  // bytes per lane and packet: 24 (fp32, C = 4), 48 (fp32, C = 8), 16 (FIXED20), 12 (byte / half values)
+__device__ __forceinline__ uint32_t read_probe_packet(const uint8_t *__restrict__ pk, uint32_t lane) {
+    uint32_t acc = 0u;
+    if (BPL == 24 || BPL == 48) {
+#pragma unroll
+        for (int q = 0; q < BPL / 24; ++q) {
+            const f32x4 f = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(pk + q * 1024 + lane * 16));
+            const u32x2 c = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(pk + (BPL / 24) * 1024 + q * 512 + lane * 8));
+            acc ^= __float_as_uint(f.x) ^ __float_as_uint(f.y) ^ __float_as_uint(f.z) ^ __float_as_uint(f.w) ^ c.x ^ c.y;
+        }
+    } else if (BPL == 16) {
+        const f32x4 f = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(pk + lane * 16));
+        acc ^= __float_as_uint(f.x) ^ __float_as_uint(f.y) ^ __float_as_uint(f.z) ^ __float_as_uint(f.w);
+    } else {
+        const uint32_t v = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(pk + lane * 4));
+        const u32x2 c = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(pk + 256 + lane * 8));
+        acc ^= v ^ c.x ^ c.y;
+    }
+    return acc;
+}
+
+// DEPTH: packets in flight per wave; WORK: dependent vector instructions spent per packet on what was loaded (tuning
+// runs, TKSPMV_READ_PROBE=depth,work: how the floor moves with the prefetch depth and with arithmetic in the loop)
+template <int BPL, int DEPTH = 8, int WORK = 0>
+__global__ void __launch_bounds__(1024) read_probe_kernel(const ReadProbeParams R) {
+    constexpr uint32_t PB = BPL * 64u;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    uint32_t acc = 0u;
+    __shared__ float xl[WORK < 0 ? 1024 : 1];
+    if (WORK < 0) {
+        for (uint32_t i = threadIdx.x; i < 1024u; i += blockDim.x) xl[i] = 1.0f + (float)(i & 7u);
+        __syncthreads();
+    }
+    for (uint32_t pass = 0; pass < R.n_pass; ++pass) {
+        const uint8_t *base = R.replicas[pass % R.n_replicas];
+        for (uint32_t p = wave * gridDim.x + blockIdx.x; p < R.n_parts; p += n_waves * gridDim.x) {
+            const uint32_t first = R.part_first[p], count = R.part_count[p];
+            const uint8_t *pk = base + (size_t)first * PB;
+            if (WORK < 0) {  // the engine's own per-packet arithmetic (x gathers from LDS, products, segmented scan) on a ring of DEPTH
+                if constexpr (BPL == 24) {
+                    Pkt<4, 0> buf[DEPTH];
+#pragma unroll
+                    for (int j = 0; j < DEPTH - 1; ++j) load_packet<4, 0>(pk + (size_t)((uint32_t)j < count ? j : count - 1u) * PB, lane, buf[j]);
+                    float carry = 0.0f, best = 0.0f;
+                    for (uint32_t i = 0; i < count; i += DEPTH) {
+#pragma unroll
+                        for (int j = 0; j < DEPTH; ++j) {
+                            const uint32_t nxt = i + j + DEPTH - 1;
+                            load_packet<4, 0>(pk + (size_t)(nxt < count ? nxt : count - 1u) * PB, lane, buf[(j + DEPTH - 1) % DEPTH]);
+                            if (i + j < count) {
+                                const RowSums<4> S = reduce_packet<4, 0>(buf[j], carry, xl, 0u);
+                                if (WORK == -1) best = fmaxf(best, S.best_any);
+                                else if (__any(S.best_any >= 1e30f)) best += S.rs[0];  // WORK == -2: the hot-path trigger as the engine has it
+                            }
+                        }
+                    }
+                    acc ^= __float_as_uint(best) ^ __float_as_uint(carry);
+                }
+            } else if (WORK == 0) {
+                uint32_t i = 0;
+                for (; i + DEPTH <= count; i += DEPTH) {
+#pragma unroll
+                    for (int j = 0; j < DEPTH; ++j) acc ^= read_probe_packet<BPL>(pk + (size_t)(i + j) * PB, lane);
+                }
+                for (; i < count; ++i) acc ^= read_probe_packet<BPL>(pk + (size_t)i * PB, lane);
+            } else {  // a rotating window of DEPTH requests, WORK dependent multiply-adds on every packet as it arrives
+                uint32_t buf[DEPTH];
+#pragma unroll
+                for (int j = 0; j < DEPTH; ++j) buf[j] = (uint32_t)j < count ? read_probe_packet<BPL>(pk + (size_t)j * PB, lane) : 0u;
+                for (uint32_t i = 0; i < count; i += DEPTH) {
+#pragma unroll
+                    for (int j = 0; j < DEPTH; ++j) {
+                        uint32_t w = buf[j];
+                        const uint32_t nxt = i + j + DEPTH;
+                        buf[j] = nxt < count ? read_probe_packet<BPL>(pk + (size_t)nxt * PB, lane) : 0u;
+#pragma unroll
+                        for (int t = 0; t < WORK; ++t) w = (w ^ 0x9E3779B1u) + acc;  // v_xad_u32: full-rate, dependent
+                        acc ^= (i + j < count) ? w : 0u;
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) acc ^= (uint32_t)__shfl_xor((int)acc, d);
+    if (lane == 0) R.sink[blockIdx.x * n_waves + wave] = acc;
+}
+
+}  // namespace tkspmv

@@ -112,6 +112,13 @@ class SpMV:
         _lib.check(_lib.lib().tkspmv_time_queries(self._h, C.c_void_p(int(dev_xs)), int(n_x), int(iters), C.byref(ns)))
         return ns.value
 
+    def time_stream_read(self, passes):
+        """ns per pass of a kernel that only loads the engine's packet stream (engine geometry, one launch, rotating
+        stream copies): the floor this GPU sets for any kernel that streams the matrix (measurement aid)."""
+        ns = C.c_double()
+        _lib.check(_lib.lib().tkspmv_time_stream_read(self._h, int(passes), C.byref(ns)))
+        return ns.value
+
     def enqueue_batch(self, dev_xs, count, dev_idx=0, dev_val=0, stream=0):
         """A batch of `count` queries (rows of a device array, stride cols floats); query i's k results go to
         dev_idx + i*k / dev_val + i*k (device pointers; 0 => engine buffers, last query wins). No host sync."""

@@ -401,6 +401,16 @@ def bench_single(a, mod, torch, np, dev, local_rank):
               "kernel_us_median": pct(reps, 50), "kernel_us_p95": pct(reps, 95), "kernel_us_mean": float(np.mean(reps)),
               "frac_at_median": alg_bytes / (pct(reps, 50) * 1e3) / HBM_PEAK_GBS}
     extra = {"parity_checked": parity_ok, "parity": parity, "timing": timing}
+    # ---- what this GPU charges for only LOADING the same stream (engine geometry, no arithmetic): boxes differ by several %
+    read_us = sorted(eng.time_stream_read(64) / 1e3 for _ in range(7))[3]
+    stream_bytes = int(info["n_packets"]) * int(info["packet_entries"]) * 6
+    read_only = {"us_per_pass": read_us, "stream_bytes": stream_bytes, "GBps": stream_bytes / (read_us * 1e3),
+                 "frac_of_peak": stream_bytes / (read_us * 1e3) / HBM_PEAK_GBS,
+                 "kernel": "tkspmv::read_probe_kernel<24>: the engine's grid, waves, partitions and non-temporal dwordx4/x2 "
+                           "loads, 8 packets in flight per wave, 64 passes in one launch over the rotating stream copies; "
+                           "median of 7",
+                 "headline_kernel_vs_read_only": read_us / (kernel_ns / 1e3),
+                 "median_kernel_vs_read_only": read_us / pct(reps, 50)}
     if not a.skip_warm:
         extra["single_query"] = single_query_leg(mod, m, xs, dxs, a, local_rank, eng, alg_bytes)
         prof = eng.profile(dxs.data_ptr(), a.queries, 100)
@@ -447,7 +457,7 @@ def bench_single(a, mod, torch, np, dev, local_rank):
                      "frac": alg_bytes / kernel_ns / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": source,
                      "traffic_detail": detail,
                      "kernel": "tkspmv::batch_kernel<4,1024,0> (up to 32 queries per launch; figures are per query)",
-                     "algorithmic_bytes": int(alg_bytes), "kernel_us": kernel_ns / 1e3,
+                     "algorithmic_bytes": int(alg_bytes), "kernel_us": kernel_ns / 1e3, "read_only": read_only,
                      "method": "one hipEvent pair on the engine stream around the timed region's back-to-back launches, "
                                "duration = event time / steps. A launch of the batch kernel streams the matrix once per "
                                "query for up to 32 queries (one continuous prefetch pipeline per wave) and selects each "

@@ -221,6 +221,11 @@ int tkspmv_debug_trace(tkspmv_t *e, uint64_t *host, uint64_t max_words, uint64_t
 /* `iters` queries back to back on the engine stream (cycling over n_x device-resident vectors), ONE hipEvent pair
  * around the batch: *ns_per_query = batch time / iters. Nothing else is launched (for profiler runs). */
 int tkspmv_time_queries(tkspmv_t *e, const float *dev_xs, int32_t n_x, int32_t iters, double *ns_per_query);
+/* Measurement aid: `passes` passes over the engine's packet stream (rotating its stream copies) by a kernel with the
+ * engine's launch geometry that only LOADS the packets -- no x, no arithmetic, no selection -- in ONE launch, inside one
+ * hipEvent pair: *ns_per_pass = what moving the stream from HBM into registers costs on this GPU. bench.py prints the
+ * streaming kernels' time against it next to the fraction of the 8 TB/s specification. */
+int tkspmv_time_stream_read(tkspmv_t *e, int32_t passes, double *ns_per_pass);
 
 /* Benchmark helper: run `iters` queries cycling over `n_x` device-resident vectors (stride cols floats)
  * back-to-back on the engine stream, timed with hipEvents on that stream. */

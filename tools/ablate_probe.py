@@ -1,0 +1,42 @@
+"""Batch kernel, DBG instantiation, under the ablation switches of TKSPMV_DBG_FLAGS (2: candidate path off -- wrong
+results, timing only; 4: no wait for a threshold at the end of a query; 8: packets without a threshold are judged at
+once instead of being noted): us per query, one engine per setting; `None` = the production instantiation.
+  python tools/ablate_probe.py ROWS COLS NNZ [flags ...]"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import _pkg  # noqa: E402
+
+torch.cuda.init()
+mod = _pkg.load()
+rows, cols, nnz = (int(v) for v in sys.argv[1:4]) if len(sys.argv) >= 4 else (1000000, 1024, 20)
+m = mod.generate_matrix(rows, cols, nnz, "gamma", 2)
+xs = np.stack([mod.create_sample_vector(cols, True, False, True, 1000 + i) for i in range(64)])
+dxs = torch.from_numpy(xs).cuda()
+settings = [None] if sys.argv[4:5] == ["none"] else [None] + [int(f) for f in (sys.argv[4:] or ["0", "2", "8"])] + [None]
+for flags in settings:
+    if flags is None:
+        os.environ.pop("TKSPMV_DBG_FLAGS", None)
+        os.environ.pop("TKSPMV_STATS", None)
+    else:
+        os.environ["TKSPMV_DBG_FLAGS"] = str(flags)
+        if os.environ.get("STATS"):
+            os.environ["TKSPMV_STATS"] = "1"
+    eng = mod.SpMV(m.row, m.col, m.val, m.rows, m.cols, vec=xs[0], k=100, device=0, stream_replicas=4)
+    eng.enqueue_many(dxs.data_ptr(), 64, 256)
+    eng.synchronize()
+    nx = 32 if (flags is not None and flags & 16) else 64  # (flag 16: the same vector must come back to the same state set)
+    eng.enqueue_many(dxs.data_ptr(), nx, 64)
+    t = sorted(eng.time_queries(dxs.data_ptr(), nx, 512) / 1e3 for _ in range(7))[3]
+    r = sorted(eng.time_stream_read(64) / 1e3 for _ in range(5))[2] if hasattr(eng, "time_stream_read") else float("nan")
+    extra = ""
+    if flags is not None and os.environ.get("STATS"):
+        p = eng.profile(dxs.data_ptr(), 64, 128)
+        extra = f"; slow-path packets {p['slow_paths_avg']:.0f}, rows offered {p['appended_avg']:.0f}, candidates {p['candidates_avg']:.0f} per query"
+    print(f"{rows}x{cols}x{nnz} flags {flags}: {t:.2f} us per query (read-only floor {r:.2f}){extra}")
+    eng.close()

@@ -43,6 +43,17 @@ for j, nm in ((4, "q0 end"), (5, "q1 end"), (6, "q2 end")):
     a = (a[a > 0] - base) * 0.01; b = (b[b > 0] - base) * 0.01
     print(f"{nm}: first-round workgroups p50 {np.percentile(a,50):7.1f}, second-round p50 {np.percentile(b,50):7.1f}")
 
+# the middle query and its successor, wave by wave: how long each takes and what lies between them
+ok = (st[..., 2] > 0) & (st[..., 5] > 0) & (st[..., 3] > 0) & (st[..., 6] > 0)
+d1 = (st[..., 5] - st[..., 2])[ok] * 0.01
+gap = (st[..., 3] - st[..., 5])[ok] * 0.01
+d2 = (st[..., 6] - st[..., 3])[ok] * 0.01
+per = (st[..., 3] - st[..., 2])[ok] * 0.01
+for nm, v in (("qM duration (x ready -> counted out)", d1), ("gap qM counted out -> qM+1 x ready", gap), ("qM+1 duration", d2), ("qM start -> qM+1 start", per)):
+    print(f"{nm:40s} mean {v.mean():6.2f} p10 {np.percentile(v,10):6.2f} p50 {np.percentile(v,50):6.2f} p90 {np.percentile(v,90):6.2f} p99 {np.percentile(v,99):6.2f} max {v.max():6.2f}")
+s0 = (st[..., 2][ok] - base) * 0.01
+print(f"spread of qM starts over the waves: p1 {np.percentile(s0,1):.1f} p50 {np.percentile(s0,50):.1f} p99 {np.percentile(s0,99):.1f}")
+
 sv7 = st[..., 7]
 for slot_i, nm in enumerate(("qF", "qM", "qL")):
     surv = (sv7 >> (16 * slot_i + 8)) & 0xFF

@@ -1,0 +1,28 @@
+"""us per query of back-to-back queries (batch kernel) over matrix sizes and k: for A/B runs of two builds on one box."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import _pkg  # noqa: E402
+
+torch.cuda.init()
+mod = _pkg.load()
+out = []
+for rows, cols, nnz, k, prec in [(50000, 1024, 20, 100, "F32"), (200000, 1024, 20, 100, "F32"), (1000000, 1024, 20, 100, "F32"),
+                                 (1000000, 1024, 20, 10, "F32"), (1000000, 1024, 20, 200, "F32"), (1000000, 512, 40, 100, "F32"),
+                                 (1000000, 512, 40, 100, "Q1_7"), (1000000, 1024, 20, 100, "F16"), (2000000, 1024, 20, 100, "F32"),
+                                 (3000000, 1024, 20, 100, "F32"), (1000000, 4096, 20, 100, "F32")]:
+    m = mod.generate_matrix(rows, cols, nnz, "gamma", 2)
+    xs = np.stack([mod.create_sample_vector(cols, True, False, True, 1000 + i) for i in range(16)])
+    dxs = torch.from_numpy(xs).cuda()
+    eng = mod.SpMV(m.row, m.col, m.val, m.rows, m.cols, vec=xs[0], k=k, device=0, stream_replicas=4, precision=getattr(mod, prec))
+    eng.enqueue_many(dxs.data_ptr(), 16, 128)
+    eng.synchronize()
+    t = sorted(eng.time_queries(dxs.data_ptr(), 16, 256) / 1e3 for _ in range(5))[2]
+    out.append(f"{rows}x{cols} nnz/row {nnz} k={k} {prec}: {t:.2f}")
+    eng.close()
+print("\n".join(out))
