@@ -538,7 +538,8 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
                 // The two workgroups of a CU do not share it evenly at equal priority: the older one wins the arbitration
                 // (traced over a 32-query launch: 17.2 against 21.5 us per query), runs ahead, finishes early and leaves
                 // the CU half empty while the launch waits for the slower half. They take turns instead, query by query:
-                // 18.7 against 19.8-20.3 us per query on one box (tools/ab_variants.sh; turns of 2 or 4 packets gain less).
+                // 18.7 against 19.8-20.3 us per query on one box (tools/ab_variants.sh; turns of 8, 12 or 32 packets: the same; of 2
+                // or 4: less). Partitions twice as long (2M rows, 512 x 40) neither gain nor lose.
                 if (((qc ^ (bid >= n_wg / 2u ? 1u : 0u)) & 1u) != 0u) __builtin_amdgcn_s_setprio(TKSPMV_STREAM_PRIO);
                 else __builtin_amdgcn_s_setprio(TKSPMV_STREAM_PRIO - 1);
 #endif

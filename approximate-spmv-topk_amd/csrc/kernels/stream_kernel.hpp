@@ -5,6 +5,9 @@
 
 namespace tkspmv {
 
+#ifndef TKSPMV_STREAM_TURNS
+#define TKSPMV_STREAM_TURNS 2
+#endif
 #ifndef TKSPMV_STREAM_PRIO
 #define TKSPMV_STREAM_PRIO 2
 #endif
@@ -232,6 +235,16 @@ __global__ void __launch_bounds__(576, (C == 8 && !SCORES) ? 6 : 5) stream_kerne
         if (dbg_repeat > 1u) np *= dbg_repeat;  // experiment: what a persistent multi-query kernel would stream
         uint32_t ia_cur = NBUF - 1 < np_one ? NBUF - 1 : 0u, ia_rep = 0u;
         for (uint32_t i0 = 0; i0 < np; i0 += NBUF) {
+#if TKSPMV_STREAM_TURNS
+            // The two workgroups of a CU take turns at the higher priority (see batch_kernel.hpp): at equal priority the
+            // older one wins the arbitration, finishes ~3 us early and leaves the CU to the other for the rest of the launch.
+            // SpMV-only variant: 22.9 against 23.75 us. The top-k variant loses by it (35.4-36.0 against 34.5 us per single
+            // launch, whatever the turn length): it keeps equal priorities.
+            if (SCORES && !is_server) {
+                if ((((i0 / (uint32_t)(NBUF * TKSPMV_STREAM_TURNS)) ^ (bid >= n_wg / 2u ? 1u : 0u)) & 1u) != 0u) __builtin_amdgcn_s_setprio(TKSPMV_STREAM_PRIO);
+                else __builtin_amdgcn_s_setprio(TKSPMV_STREAM_PRIO - 1);
+            }
+#endif
 #pragma unroll
             for (int u = 0; u < NBUF; ++u) {
                 const uint32_t i = i0 + (uint32_t)u;

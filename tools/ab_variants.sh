@@ -17,7 +17,7 @@ else
     for r in $(seq 1 $rounds); do
         for v in "$@"; do
             d=_ab/$v; [ "$v" = . ] && d=.
-            echo -n "$v: "; (cd $d && timeout -k 10 120 python tools/ablate_probe.py $rows $cols $nnz none 2>&1 | grep flags | head -1)
+            echo -n "$v: "; (cd $d && timeout -k 10 200 python tools/ablate_probe.py $rows $cols $nnz none 2>&1 | grep flags | head -1)
         done
     done
 fi

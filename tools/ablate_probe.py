@@ -38,5 +38,16 @@ for flags in settings:
     if flags is not None and os.environ.get("STATS"):
         p = eng.profile(dxs.data_ptr(), 64, 128)
         extra = f"; slow-path packets {p['slow_paths_avg']:.0f}, rows offered {p['appended_avg']:.0f}, candidates {p['candidates_avg']:.0f} per query"
+    if flags is None:
+        p = eng.profile(dxs.data_ptr(), 64, 200)
+        extra = (f"; single launches: {p['stream_kernel_ns'] / 1e3:.2f} us (event bracket, empty kernel {p['event_bracket_ns'] / 1e3:.2f}), "
+                 f"SpMV-only {p['scores_kernel_ns'] / 1e3:.2f}")
+    if flags is None and os.environ.get("MULTI"):
+        for mq in (int(v) for v in os.environ["MULTI"].split(",")):
+            me = mod.SpMV(m.row, m.col, m.val, m.rows, m.cols, vec=xs[0], k=100, device=0, stream_replicas=4, multi_q=mq)
+            me.time_multi(dxs.data_ptr(), 64, 256)
+            tm = sorted(me.time_multi(dxs.data_ptr(), 64, 1024) / 1e3 for _ in range(5))[2]
+            extra += f"; multi_q={mq}: {tm:.2f} us per query"
+            me.close()
     print(f"{rows}x{cols}x{nnz} flags {flags}: {t:.2f} us per query (read-only floor {r:.2f}){extra}")
     eng.close()
