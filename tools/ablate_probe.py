@@ -1,7 +1,8 @@
-"""Batch kernel, DBG instantiation, under the ablation switches of TKSPMV_DBG_FLAGS (2: candidate path off -- wrong
-results, timing only; 4: no wait for a threshold at the end of a query; 8: packets without a threshold are judged at
-once instead of being noted): us per query, one engine per setting; `None` = the production instantiation.
-  python tools/ablate_probe.py ROWS COLS NNZ [flags ...]"""
+"""Batch kernel under the ablation switches of TKSPMV_DBG_FLAGS (DBG instantiation: 2: candidate path off -- wrong
+results, timing only; 4: no threshold duty; 16: every state set keeps its final threshold and the same vector comes back
+to it: an exact threshold from a query's first packet), one engine per setting; `None` = the production instantiation,
+with single launches and the SpMV-only kernel beside it (MULTI=1,4,8 adds the multi-query path; STATS=1 the counters).
+  python tools/ablate_probe.py ROWS COLS NNZ [flags ... | none]"""
 import os
 import sys
 
@@ -18,7 +19,7 @@ rows, cols, nnz = (int(v) for v in sys.argv[1:4]) if len(sys.argv) >= 4 else (10
 m = mod.generate_matrix(rows, cols, nnz, "gamma", 2)
 xs = np.stack([mod.create_sample_vector(cols, True, False, True, 1000 + i) for i in range(64)])
 dxs = torch.from_numpy(xs).cuda()
-settings = [None] if sys.argv[4:5] == ["none"] else [None] + [int(f) for f in (sys.argv[4:] or ["0", "2", "8"])] + [None]
+settings = [None] if sys.argv[4:5] == ["none"] else [None] + [int(f) for f in (sys.argv[4:] or ["0", "2", "16"])] + [None]
 for flags in settings:
     if flags is None:
         os.environ.pop("TKSPMV_DBG_FLAGS", None)

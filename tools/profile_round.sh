@@ -13,6 +13,8 @@ OUT=$REPO/gpurun_out/prof_$TAG
 rm -rf "$OUT"  # (a summary must never mix two runs)
 mkdir -p "$OUT"
 python3 bench.py --steps 3000 --warmup 300 > "$OUT/bench_plain.json" 2> "$OUT/bench_plain.err"
+# (the driver's own command line: ONE launch of 20 queries, start-up and tail included)
+python3 bench.py --gpus 1 --steps 20 --warmup 5 --skip-warm --cpu-seconds 0 --traffic off > "$OUT/bench_steps20.json" 2> "$OUT/bench_steps20.err"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/ktrace" -- python3 "$REPO/bench.py" --steps 2048 --warmup 256 --cpu-seconds 0 --skip-warm > "$OUT/bench_under_rocprofv3.json" 2> "$OUT/ktrace.err"
 i=0

@@ -28,6 +28,7 @@ for src, name in ((find("ktrace/**/*kernel_stats.csv"), f"{tag}_kernel_stats.csv
     if src:
         shutil.copy(src, os.path.join(dst, name))
 for src, name in (("bench_plain.json", f"{tag}_bench_plain.json"),
+                  ("bench_steps20.json", f"{tag}_bench_steps20.json"),
                   ("bench_under_rocprofv3.json", f"{tag}_bench_under_rocprofv3.json")):
     p = os.path.join(out, src)
     if os.path.exists(p):
