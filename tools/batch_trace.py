@@ -7,7 +7,7 @@ import torch
 from importlib import import_module
 mod = _pkg.load()
 _lib = import_module("approximate_spmv_topk_amd._lib")
-m = mod.generate_matrix(1000000, 1024, 20, "gamma", 2)
+m = mod.generate_matrix(int(os.environ.get("ROWS", "1000000")), 1024, 20, "gamma", 2)
 xs = np.stack([mod.create_sample_vector(1024, True, False, True, 1000 + i) for i in range(8)])
 dxs = torch.from_numpy(xs).cuda()
 eng = mod.SpMV(m.row, m.col, m.val, m.rows, m.cols, k=100, device=0, stream_replicas=4)
