@@ -58,12 +58,13 @@ summary = {}
 for d in sorted(glob.glob(os.path.join(out, "pmc*"))):
     if not os.path.isdir(d):
         continue
-    # queries the profiled run executed: warm-up + timed steps + the kernel-timing batch (bench.py --skip-warm)
+    # queries the profiled run executed: warm-up + timed steps + the repetitions of `timing` (bench.py --skip-warm)
     n_queries = None
     try:
         line = [l for l in open(d + ".json").read().splitlines() if l.startswith("{")][-1]
         j = json.loads(line)
-        n_queries = j["warmup"] + j["steps"] + min(max(j["steps"], 50), 500)
+        tm = j.get("timing", {})
+        n_queries = j["warmup"] + j["steps"] + (tm.get("repetitions", 0) + tm.get("dropped", 0)) * tm.get("queries_per_repetition", 0)
     except Exception:
         pass
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
