@@ -51,6 +51,10 @@ d2 = (st[..., 6] - st[..., 3])[ok] * 0.01
 per = (st[..., 3] - st[..., 2])[ok] * 0.01
 for nm, v in (("qM duration (x ready -> counted out)", d1), ("gap qM counted out -> qM+1 x ready", gap), ("qM+1 duration", d2), ("qM start -> qM+1 start", per)):
     print(f"{nm:40s} mean {v.mean():6.2f} p10 {np.percentile(v,10):6.2f} p50 {np.percentile(v,50):6.2f} p90 {np.percentile(v,90):6.2f} p99 {np.percentile(v,99):6.2f} max {v.max():6.2f}")
+dur = np.where(ok, (st[..., 5] - st[..., 2]) * 0.01, np.nan)
+print("qM duration by wave index (mean over workgroups):", np.nanmean(dur, axis=0).round(2).tolist())
+per_w = np.where(ok, (st[..., 3] - st[..., 2]) * 0.01, np.nan)
+print("qM start -> qM+1 start by wave index:", np.nanmean(per_w, axis=0).round(2).tolist())
 s0 = (st[..., 2][ok] - base) * 0.01
 print(f"spread of qM starts over the waves: p1 {np.percentile(s0,1):.1f} p50 {np.percentile(s0,50):.1f} p99 {np.percentile(s0,99):.1f}")
 
