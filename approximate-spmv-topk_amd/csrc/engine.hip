@@ -1601,6 +1601,7 @@ int Engine::time_stream_read(int32_t passes, double *ns_per_pass, std::string &e
     R.part_count = m.d_part_count;
     R.n_parts = (uint32_t)m.pm.part_first.size();
     R.n_pass = (uint32_t)passes;
+    if (const char *f = getenv("TKSPMV_READ_PROBE_MAP")) R.map = (uint32_t)atoi(f);
     uint32_t *sink = nullptr;
     HIP_TRY(hipMalloc((void **)&sink, (size_t)m.grid * 16 * 4));
     R.sink = sink;

@@ -18,6 +18,7 @@ struct ReadProbeParams {
     uint32_t n_replicas;
     const uint32_t *part_first, *part_count;
     uint32_t n_parts, n_pass;
+    uint32_t map;  // 0: the engine's partition of wave w of workgroup b (w * grid + b); 1, 2: XCD-contiguous variants (tuning runs)
     uint32_t *sink;  // [grid * waves]
 };
 
@@ -56,7 +57,12 @@ __global__ void __launch_bounds__(1024) read_probe_kernel(const ReadProbeParams 
     }
     for (uint32_t pass = 0; pass < R.n_pass; ++pass) {
         const uint8_t *base = R.replicas[pass % R.n_replicas];
-        for (uint32_t p = wave * gridDim.x + blockIdx.x; p < R.n_parts; p += n_waves * gridDim.x) {
+        uint32_t p_first = wave * gridDim.x + blockIdx.x;
+        if (R.map != 0u) {  // workgroups are dealt to the 8 XCDs round-robin: give every XCD one contiguous eighth of the stream
+            const uint32_t xcd = blockIdx.x & 7u, li = blockIdx.x >> 3, per_xcd = (gridDim.x >> 3) * n_waves;
+            p_first = xcd * per_xcd + (R.map == 1u ? li * n_waves + wave : wave * (gridDim.x >> 3) + li);
+        }
+        for (uint32_t p = p_first; p < R.n_parts; p += n_waves * gridDim.x) {
             const uint32_t first = R.part_first[p], count = R.part_count[p];
             const uint8_t *pk = base + (size_t)first * PB;
             if (WORK < 0) {  // the engine's own per-packet arithmetic (x gathers from LDS, products, segmented scan) on a ring of DEPTH

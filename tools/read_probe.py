@@ -21,6 +21,11 @@ eng.synchronize()
 t = sorted(eng.time_queries(dxs.data_ptr(), 64, 512) / 1e3 for _ in range(7))[3]
 print(f"batch kernel: {t:.2f} us per query")
 cases = ["8,0", "2,0", "3,0", "4,0", "6,0", "12,0", "16,0", "3,1", "3,32", "3,64", "3,96", "3,128", "4,64", "4,96", "6,64", "6,96", "8,1", "8,64", "8,96"]
+for mp in ("1", "2", "0"):
+    os.environ["TKSPMV_READ_PROBE_MAP"] = mp
+    os.environ["TKSPMV_READ_PROBE"] = "8,0"
+    r = sorted(eng.time_stream_read(64) / 1e3 for _ in range(5))[2]
+    print(f"read probe, partition map {mp}: {r:6.2f} us per pass")
 for c in (sys.argv[1:] or cases):
     os.environ["TKSPMV_READ_PROBE"] = c
     r = sorted(eng.time_stream_read(64) / 1e3 for _ in range(5))[2]
