@@ -267,6 +267,15 @@ __device__ __forceinline__ void place(const ScatterParams &P, uint32_t r, unsign
         *reinterpret_cast<uint32_t *>(pkt + (size_t)slot * 4) = fixed20_word(to_fixed(v, P.fixed_width), (uint32_t)(cw >> COLW_COL_SHIFT), cw & 3u);
         return;
     }
+    if ((Precision)P.precision == Precision::F32C12) {
+        *reinterpret_cast<float *>(pkt + (size_t)slot * 4) = v;
+        // 12 bits at bit 12 t of the entry's plane: OR-ed into the zeroed stream (a word is shared by up to three entries)
+        const uint32_t t = slot & 255u, bit = t * 12u;
+        uint32_t *plane = reinterpret_cast<uint32_t *>(pkt + (size_t)P.PE * 4 + (size_t)(slot >> 8) * 384u);
+        atomicOr(&plane[bit >> 5], (uint32_t)cw << (bit & 31u));
+        if ((bit & 31u) > 20u) atomicOr(&plane[(bit >> 5) + 1u], (uint32_t)cw >> (32u - (bit & 31u)));
+        return;
+    }
     switch ((Precision)P.precision) {
         case Precision::F32: *reinterpret_cast<float *>(pkt + (size_t)slot * 4) = v; break;
         case Precision::F16: *reinterpret_cast<uint16_t *>(pkt + (size_t)slot * 2) = to_half(v); break;
@@ -339,6 +348,7 @@ std::string pack_wbscsr_device(uint32_t rows, uint32_t cols, uint64_t nnz, const
                                         : (precision == Precision::FIXED ? (fixed_width < 8 || fixed_width > 32) : fixed_width != 0))
         return "fixed_width must be in [8, 32] for fixed-point values (bit-packed: at most 20 bits and 1024 columns) and 0 otherwise";
     if (cols == 0 || cols > MAX_COLS) return "cols must be in [1, 16384]";
+    if (precision == Precision::F32C12 && (cols > F32C12_MAX_COLS || C != 4)) return "12-bit column words need at most 1024 columns and 4 entries per lane";
     if (nnz > 0 && (!row || !col)) return "row/col arrays are NULL";
     if (n_partitions_hint == 0) n_partitions_hint = 1;
     if (min_packets_per_partition == 0) min_packets_per_partition = 1;
@@ -353,7 +363,7 @@ std::string pack_wbscsr_device(uint32_t rows, uint32_t cols, uint64_t nnz, const
     pm.fixed_width = fixed_width;
     pm.C = C;
     pm.packet_entries = WAVE * C;
-    pm.packet_bytes = pm.packet_entries * (value_bytes(precision) + 2);
+    pm.packet_bytes = packet_bytes_for(precision, pm.packet_entries);
     out.d_packets = nullptr;
     out.d_pkt_row = nullptr;
     if (nnz == 0) {  // empty matrix: no packets, no partitions

@@ -375,6 +375,7 @@ struct EngineImpl {
         if (desc.precision == TKSPMV_FIXED) return pm.precision == Precision::FIXED20 ? &batch_kernel<4, 1024, 6> : &batch_kernel<4, 1024, 4>;
         if (desc.precision == TKSPMV_Q1_7_F32) return &batch_kernel<4, 1024, 5>;
         if (info.packet_entries == 512) return &batch_kernel<8, 1024, 0>;
+        if (pm.precision == Precision::F32C12) return dbg_kernels ? &batch_kernel<4, 1024, 7, true> : &batch_kernel<4, 1024, 7>;
         return dbg_kernels ? &batch_kernel<4, 1024, 0, true> : &batch_kernel<4, 1024, 0>;
     }
     // n <= BATCH_MAX queries in one launch of the batch kernel; results complete in stream order after the launch.
@@ -460,6 +461,10 @@ struct EngineImpl {
             return scores ? &stream_kernel<4, true, 16384, 2> : &stream_kernel<4, false, 16384, 2>;
         }
         if (c8) return scores ? &stream_kernel<8, true, 1024, 0, 2> : &stream_kernel<8, false, 1024, 0, 2>;  // (two packet buffers: 3 KB packets)
+        if (pm.precision == Precision::F32C12) {  // 12-bit column words: at most 1024 columns, 4 entries per lane
+            if (dbg_kernels && !scores) return &stream_kernel<4, false, 1024, 7, TKSPMV_NBUF, true>;
+            return scores ? &stream_kernel<4, true, 1024, 7> : &stream_kernel<4, false, 1024, 7>;
+        }
         if (xcols <= 1024 && dbg_kernels && !scores) return &stream_kernel<4, false, 1024, 0, TKSPMV_NBUF, true>;
         if (xcols <= 1024) return scores ? &stream_kernel<4, true, 1024> : &stream_kernel<4, false, 1024>;
         if (xcols <= 4096) return scores ? &stream_kernel<4, true, 4096> : &stream_kernel<4, false, 4096>;
@@ -550,7 +555,10 @@ struct EngineImpl {
         B.idle_ticks = resident_idle_ticks;
         B.n_replicas = d_replicas.empty() ? 1u : (uint32_t)std::min<size_t>(d_replicas.size(), 8);
         for (uint32_t r = 0; r < 8u; ++r) B.replicas[r] = d_replicas.empty() ? d_packets : d_replicas[r % d_replicas.size()];
-        hipLaunchKernelGGL((batch_kernel<4, 1024, 0, false, true>), dim3(grid), dim3(block + 64), 0, rstream, P, S, B);
+        if (pm.precision == Precision::F32C12)
+            hipLaunchKernelGGL((batch_kernel<4, 1024, 7, false, true>), dim3(grid), dim3(block + 64), 0, rstream, P, S, B);
+        else
+            hipLaunchKernelGGL((batch_kernel<4, 1024, 0, false, true>), dim3(grid), dim3(block + 64), 0, rstream, P, S, B);
         e = hipGetLastError();
         resident_running = e == hipSuccess;
         return e;
@@ -600,7 +608,8 @@ void fill_info(const PackedMatrix &pm, int k, tkspmv_info *out) {
     out->packets_per_partition = pm.packets_per_partition;
     out->k = k;
     // (the bit-packed narrow fixed-point stream is a layout of TKSPMV_FIXED, not a precision of the API)
-    out->precision = pm.precision == Precision::FIXED20 ? (int32_t)Precision::FIXED : (int32_t)pm.precision;
+    out->precision = pm.precision == Precision::FIXED20 ? (int32_t)Precision::FIXED
+                                                       : (pm.precision == Precision::F32C12 ? (int32_t)Precision::F32 : (int32_t)pm.precision);
     out->fixed_width = pm.fixed_width;
 }
 
@@ -757,7 +766,8 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
         // more partitions than this launch geometry has streaming waves (the batch kernel gives every wave one).
         const PackedMatrix &q = *prepacked;
         const bool fixed_either = d.precision == TKSPMV_FIXED && (q.precision == Precision::FIXED || q.precision == Precision::FIXED20);
-        if (q.rows != d.rows || q.cols != d.cols || (!fixed_either && q.precision != stream_precision(d.precision)) ||
+        const bool f32_either = d.precision == TKSPMV_F32 && (q.precision == Precision::F32 || q.precision == Precision::F32C12);
+        if (q.rows != d.rows || q.cols != d.cols || (!fixed_either && !f32_either && q.precision != stream_precision(d.precision)) ||
             q.C != C || q.fixed_width != fixed_width_of(d)) {
             err = "the packed matrix does not match the descriptor (rows, cols, precision or entries per lane)";
             return TKSPMV_ERR_INVALID;
@@ -1607,6 +1617,7 @@ int Engine::time_stream_read(int32_t passes, double *ns_per_pass, std::string &e
     R.sink = sink;
     void (*fn)(ReadProbeParams) = nullptr;
     switch (m.pm.packet_bytes / 64u) {
+        case 22: fn = read_probe_kernel<22>; break;
         case 24: fn = read_probe_kernel<24>; break;
         case 48: fn = read_probe_kernel<48>; break;
         case 16: fn = read_probe_kernel<16>; break;
@@ -1618,6 +1629,7 @@ int Engine::time_stream_read(int32_t passes, double *ns_per_pass, std::string &e
         sscanf(f, "%d,%d", &depth, &work);
         if (m.pm.packet_bytes == 1536u) {
 #define RP(D, W) if (depth == D && work == W) fn = read_probe_kernel<24, D, W>;
+            if (depth == 22) fn = read_probe_kernel<22, 8, 1>;  // what 1408-byte packets would cost, read out of this 1536-byte stream
             RP(3, -1) RP(3, -2) RP(4, -2) RP(2, 0) RP(3, 0) RP(4, 0) RP(6, 0) RP(12, 0) RP(16, 0)
             RP(3, 1) RP(3, 32) RP(3, 64) RP(3, 96) RP(3, 128) RP(4, 64) RP(4, 96) RP(6, 64) RP(6, 96) RP(8, 64) RP(8, 96) RP(8, 1)
 #undef RP

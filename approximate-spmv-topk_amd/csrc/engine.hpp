@@ -72,8 +72,11 @@ inline uint32_t fixed_width_of(const tkspmv_desc &d) {
     if (d.precision != TKSPMV_FIXED) return (uint32_t)d.fixed_width;
     return d.fixed_width == 0 ? 32u : (uint32_t)d.fixed_width;
 }
-// Value type of the packet stream a descriptor asks for (narrow fixed point with at most 1024 columns: bit-packed FIXED20).
-inline Precision stream_precision_of(const tkspmv_desc &d) { return stream_precision(d.precision, fixed_width_of(d), d.cols); }
+// Value type of the packet stream a descriptor asks for (at most 1024 columns: narrow fixed point travels bit-packed, FIXED20,
+// and fp32 values with 12-bit column words, F32C12).
+inline Precision stream_precision_of(const tkspmv_desc &d) {
+    return stream_precision(d.precision, fixed_width_of(d), d.cols, entries_per_lane_of(d));
+}
 // Wave partitions tkspmv_create would cut the matrix into on desc.device (= streaming waves of its launch geometry).
 int wave_partitions_for(const tkspmv_desc &desc, uint32_t *out, std::string &err);
 

@@ -74,12 +74,14 @@ constexpr uint32_t SLOT_INVALID = 0xFFFFFFFFu;  // row id of an unused slot
 // FPGA's real_type for any FIXED_WIDTH): values and x as left-aligned Q1.31 words, integer products and sums.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));  // a dwordx2 at a 4-byte boundary
 // QM 5 = Q1.7 values (rounded to nearest) dequantised to fp32 (v_cvt_f32_ubyteN: one VALU per entry), fp32 x held in LDS
 // pre-scaled by 2^-7 (exact), fp32 products and sums: the byte stream of the Q1.7 modes with the arithmetic of the fp32
 // path (TKSPMV_Q1_7_F32, BASELINE configs[4]).
 // QM 6 = fixed point of at most 20 bits, bit-packed (wbscsr.hpp FIXED20): one dword per entry carrying value, column and
 // flags; the arithmetic is QM 4's with both factors as 20-bit integers.
-constexpr int value_type_of(int QM) { return QM == 6 ? 3 : (QM == 3 ? 2 : ((QM == 1 || QM == 2 || QM == 5) ? 1 : 0)); }  // QM 4: one u32 per value, loaded like fp32
+// QM 7 = fp32 exactly like QM 0, the column words travelling as 12 bits each (wbscsr.hpp F32C12): value type 4.
+constexpr int value_type_of(int QM) { return QM == 7 ? 4 : (QM == 6 ? 3 : (QM == 3 ? 2 : ((QM == 1 || QM == 2 || QM == 5) ? 1 : 0))); }  // QM 4: one u32 per value, loaded like fp32
 // Byte b (0..3) of a dword as a float: v_cvt_f32_ubyte0..3.
 template <int B>
 __device__ __forceinline__ float ubyte_to_float(uint32_t w) {
@@ -99,9 +101,9 @@ constexpr float Q17_UNIT = 0.0078125f;  // 2^-7
 // from them when the stream comes from HBM, tools/stream_probe.hip).
 template <int C, int VT>
 struct Pkt {
-    float v[(VT == 0 || VT == 3) ? C : 1];  // VT 3: the packed dwords (value | column | flags); cw stays unused
+    float v[(VT == 0 || VT == 3 || VT == 4) ? C : 1];  // VT 3: the packed dwords (value | column | flags); cw stays unused
     uint32_t vq[VT == 1 ? C / 4 : (VT == 2 ? C / 2 : 1)];
-    uint32_t cw[C / 2];
+    uint32_t cw[C / 2];  // VT 4: the two dwords that hold the lane's four 12-bit words (from bit 0, or bit 16 on odd lanes)
 };
 
 template <int C, int VT>
@@ -114,6 +116,16 @@ __device__ __forceinline__ void load_packet(const uint8_t *__restrict__ pk, uint
             o.v[VT == 3 ? 4 * q + 1 : 0] = f.y;
             o.v[VT == 3 ? 4 * q + 2 : 0] = f.z;
             o.v[VT == 3 ? 4 * q + 3 : 0] = f.w;
+        } else if (VT == 4) {
+            const f32x4 f = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(pk + q * 1024 + lane * 16));
+            o.v[VT == 4 ? 4 * q + 0 : 0] = f.x;
+            o.v[VT == 4 ? 4 * q + 1 : 0] = f.y;
+            o.v[VT == 4 ? 4 * q + 2 : 0] = f.z;
+            o.v[VT == 4 ? 4 * q + 3 : 0] = f.w;
+            // two lanes share three dwords: the even lane takes dwords 0-1, the odd one dwords 1-2 (4-byte aligned dwordx2)
+            const u32x2_a4 c = __builtin_nontemporal_load(reinterpret_cast<const u32x2_a4 *>(pk + C * 256 + q * 384 + (lane >> 1) * 12 + (lane & 1u) * 4));
+            o.cw[2 * q + 0] = c.x;
+            o.cw[2 * q + 1] = c.y;
         } else if (VT == 1) {
             o.vq[VT == 1 ? q : 0] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(pk + q * 256 + lane * 4));
             const u32x2 c = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(pk + C * 64 + q * 512 + lane * 8));

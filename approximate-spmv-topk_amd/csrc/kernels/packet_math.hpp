@@ -248,6 +248,29 @@ __device__ __forceinline__ RowSums<C> reduce_packet(const Pkt<C, value_type_of(Q
         }
         return reduce_core<C, true>(p, cwv, carry);
     }
+    if (QM == 7) {
+        // fp32 values, 12-bit column words: the lane's four words are 48 bits of the two dwords it loaded, from bit 0 on even
+        // lanes and from bit 16 on odd ones; word j = column << 2 | flags, so (word & 0xFFC) is the LDS byte offset of x[col]
+        // as ever. The reduction wants the flags where 16-bit column words have them (bits 0-1 and 16-17 of a dword).
+        uint32_t cwv[C / 2];
+        const uint32_t odd16 = (threadIdx.x & 1u) << 4;  // (lane parity: a wave is 64 consecutive threads)
+#pragma unroll
+        for (int q = 0; q < C / 4; ++q) {
+            // bits 0..31 and 32..47 of the lane's 48 bits (32-bit funnel shifts: no 64-bit register pairs)
+            const uint32_t lo = __builtin_amdgcn_alignbit(cur.cw[2 * q + 1], cur.cw[2 * q], odd16), hi = cur.cw[2 * q + 1] >> odd16;
+            const uint32_t mid = __builtin_amdgcn_alignbit(hi, lo, 24);  // word 2 from bit 0
+            const unsigned char *xb = reinterpret_cast<const unsigned char *>(x_lds);
+            p[4 * q + 0] = __fmul_rn(cur.v[VT == 4 ? 4 * q + 0 : 0], *reinterpret_cast<const float *>(xb + (lo & 0xFFCu)));
+            p[4 * q + 1] = __fmul_rn(cur.v[VT == 4 ? 4 * q + 1 : 0], *reinterpret_cast<const float *>(xb + ((lo >> 12) & 0xFFCu)));
+            p[4 * q + 2] = __fmul_rn(cur.v[VT == 4 ? 4 * q + 2 : 0], *reinterpret_cast<const float *>(xb + (mid & 0xFFCu)));
+            p[4 * q + 3] = __fmul_rn(cur.v[VT == 4 ? 4 * q + 3 : 0], *reinterpret_cast<const float *>(xb + ((hi >> 4) & 0xFFCu)));
+            // flags of words 0, 1 (bits 0-1 and 12-13 of lo) to bits 0-1 and 16-17; of words 2, 3 (bits 0-1 of mid, 4-5 of hi)
+            const uint32_t f01 = lo & 0x3003u, f23 = (mid & 3u) | ((hi & 0x30u) << 12);
+            cwv[2 * q] = (f01 | (f01 << 4)) & 0x30003u;
+            cwv[2 * q + 1] = f23;
+        }
+        return reduce_core<C, false>(p, cwv, carry);
+    }
 #pragma unroll
     for (int j = 0; j < C; ++j) {
         const uint32_t word = cur.cw[j >> 1];

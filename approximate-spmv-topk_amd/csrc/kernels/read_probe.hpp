@@ -22,10 +22,14 @@ struct ReadProbeParams {
     uint32_t *sink;  // [grid * waves]
 };
 
-template <int BPL>  // bytes per lane and packet: 24 (fp32, C = 4), 48 (fp32, C = 8), 16 (FIXED20), 12 (byte / half values)
+template <int BPL>  // bytes per lane and packet: 22 (fp32 + 12-bit column words), 24 (fp32, C = 4), 48 (fp32, C = 8), 16 (FIXED20), 12 (byte / half values)
 __device__ __forceinline__ uint32_t read_probe_packet(const uint8_t *__restrict__ pk, uint32_t lane) {
     uint32_t acc = 0u;
-    if (BPL == 24 || BPL == 48) {
+    if (BPL == 22) {  // values as they are, 12-bit column words: two lanes share three dwords (overlapping dwordx2 loads)
+        const f32x4 f = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(pk + lane * 16));
+        const u32x2 c = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(pk + 1024 + (lane >> 1) * 12 + (lane & 1u) * 4));
+        acc ^= __float_as_uint(f.x) ^ __float_as_uint(f.y) ^ __float_as_uint(f.z) ^ __float_as_uint(f.w) ^ c.x ^ c.y;
+    } else if (BPL == 24 || BPL == 48) {
 #pragma unroll
         for (int q = 0; q < BPL / 24; ++q) {
             const f32x4 f = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(pk + q * 1024 + lane * 16));
@@ -47,7 +51,7 @@ __device__ __forceinline__ uint32_t read_probe_packet(const uint8_t *__restrict_
 // runs, TKSPMV_READ_PROBE=depth,work: how the floor moves with the prefetch depth and with arithmetic in the loop)
 template <int BPL, int DEPTH = 8, int WORK = 0>
 __global__ void __launch_bounds__(1024) read_probe_kernel(const ReadProbeParams R) {
-    constexpr uint32_t PB = BPL * 64u;
+    constexpr uint32_t PB = (BPL == 22 && WORK == 1 ? 24 : BPL) * 64u;  // (22 with WORK 1: 1408-byte packets read out of a 1536-byte stream)
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
     uint32_t acc = 0u;
     __shared__ float xl[WORK < 0 ? 1024 : 1];

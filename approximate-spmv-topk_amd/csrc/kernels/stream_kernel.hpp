@@ -41,7 +41,7 @@ struct StreamLds {
 #endif
 // DBG = false (production): tracing / statistics / ablation hooks compiled out (see batch_kernel).
 template <int C, bool SCORES, int XCOLS, int QM = 0, int NBUF = TKSPMV_NBUF, bool DBG = false>
-__global__ void __launch_bounds__(576, (C == 8 && !SCORES) ? 6 : 5) stream_kernel(const StreamParams P, const SelectParams SP) {
+__global__ void __launch_bounds__(576, ((C == 8 && !SCORES) || QM == 7) ? 6 : 5) stream_kernel(const StreamParams P, const SelectParams SP) {
     // (constants, not a modified copy of P: a copy that is passed on by reference ends up in scratch memory)
     const uint32_t dbg_flags = DBG ? P.dbg_flags : 0u;
     const uint32_t dbg_repeat = DBG ? P.dbg_repeat : 0u;

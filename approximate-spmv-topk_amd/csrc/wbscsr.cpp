@@ -43,6 +43,7 @@ std::string pack_wbscsr(uint32_t rows, uint32_t cols, uint64_t nnz, const uint32
                                         : (precision == Precision::FIXED ? (fixed_width < 8 || fixed_width > 32) : fixed_width != 0))
         return "fixed_width must be in [8, 32] for fixed-point values (bit-packed: at most 20 bits and 1024 columns) and 0 otherwise";
     if (cols == 0 || cols > MAX_COLS) return "cols must be in [1, 16384]";
+    if (precision == Precision::F32C12 && (cols > F32C12_MAX_COLS || C != 4)) return "12-bit column words need at most 1024 columns and 4 entries per lane";
     if (nnz > 0 && (!row || !col)) return "row/col arrays are NULL";
     if (n_partitions_hint == 0) n_partitions_hint = 1;
     if (min_packets_per_partition == 0) min_packets_per_partition = 1;
@@ -55,7 +56,7 @@ std::string pack_wbscsr(uint32_t rows, uint32_t cols, uint64_t nnz, const uint32
     out.fixed_width = fixed_width;
     out.C = C;
     out.packet_entries = WAVE * C;
-    out.packet_bytes = out.packet_entries * (value_bytes(precision) + 2);
+    out.packet_bytes = packet_bytes_for(precision, out.packet_entries);
 
     // Row lengths over [0, last_row]; validates ordering and ranges.
     for (uint64_t i = 1; i < nnz; ++i) {
@@ -160,6 +161,11 @@ std::string pack_wbscsr(uint32_t rows, uint32_t cols, uint64_t nnz, const uint32
                     std::memcpy(pkt + (size_t)slot * 4, &w, 4);
                     continue;
                 }
+                if (precision == Precision::F32C12) {
+                    std::memcpy(pkt + (size_t)slot * 4, &v, 4);
+                    colw12_store(pkt + (size_t)PE * 4, slot, cw);
+                    continue;
+                }
                 if (precision == Precision::F32) {
                     std::memcpy(pkt + (size_t)slot * 4, &v, 4);
                 } else if (precision == Precision::F16) {
@@ -202,11 +208,13 @@ void decode_wbscsr(const PackedMatrix &pm, std::vector<uint32_t> &row, std::vect
                     std::memcpy(&w, pkt + (size_t)s * 4, 4);
                     cw = (uint16_t)(w & 0xFFFu);
                     v = from_fixed(w & 0xFFFFF000u);
+                } else if (pm.precision == Precision::F32C12) {
+                    cw = colw12_load(pkt + (size_t)PE * 4, s);
                 } else {
                     std::memcpy(&cw, pkt + (size_t)PE * vb + (size_t)s * 2, 2);
                 }
                 if (pm.precision == Precision::FIXED20) {
-                } else if (pm.precision == Precision::F32) {
+                } else if (pm.precision == Precision::F32 || pm.precision == Precision::F32C12) {
                     std::memcpy(&v, pkt + (size_t)s * 4, 4);
                 } else if (pm.precision == Precision::F16) {
                     uint16_t hv;
@@ -327,13 +335,15 @@ std::string load_packed(const char *path, PackedMatrix &pm) {
     if (hd.version != 1) return fail("unsupported .tkspmv version");
     if ((hd.precision != (uint32_t)Precision::F32 && hd.precision != (uint32_t)Precision::Q1_7 &&
          hd.precision != (uint32_t)Precision::F16 && hd.precision != (uint32_t)Precision::FIXED &&
-         hd.precision != (uint32_t)Precision::Q1_7_RND && hd.precision != (uint32_t)Precision::FIXED20) ||
+         hd.precision != (uint32_t)Precision::Q1_7_RND && hd.precision != (uint32_t)Precision::FIXED20 &&
+         hd.precision != (uint32_t)Precision::F32C12) ||
+        (hd.precision == (uint32_t)Precision::F32C12 && (hd.cols > F32C12_MAX_COLS || hd.C != 4)) ||
         (hd.precision == (uint32_t)Precision::FIXED20
              ? (hd.fixed_width < 8 || hd.fixed_width > FIXED20_MAX_WIDTH || hd.cols > FIXED20_MAX_COLS)
              : (hd.precision == (uint32_t)Precision::FIXED ? (hd.fixed_width < 8 || hd.fixed_width > 32) : hd.fixed_width != 0)) ||
         (hd.C != 4 && hd.C != 8) ||
         hd.packet_entries != 64 * hd.C ||
-        hd.packet_bytes != hd.packet_entries * (value_bytes((Precision)hd.precision) + 2) ||
+        hd.packet_bytes != packet_bytes_for((Precision)hd.precision, hd.packet_entries) ||
         hd.packed_entries != (uint64_t)hd.n_packets * hd.packet_entries)
         return fail("inconsistent header");
     const uint64_t expect = (uint64_t)hd.n_packets * hd.packet_bytes + (uint64_t)hd.n_packets * 4 + (uint64_t)hd.n_parts * 16;
@@ -394,6 +404,8 @@ std::string load_packed(const char *path, PackedMatrix &pm) {
                     uint32_t w;
                     std::memcpy(&w, out.packets.data() + (size_t)p * hd.packet_bytes + (size_t)s * 4, 4);
                     cw = (uint16_t)(w & 0xFFFu);
+                } else if (hd.precision == (uint32_t)Precision::F32C12) {
+                    cw = colw12_load(cwp, s);
                 } else {
                     std::memcpy(&cw, cwp + (size_t)s * 2, 2);
                 }

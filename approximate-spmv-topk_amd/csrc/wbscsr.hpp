@@ -57,19 +57,55 @@ TKSPMV_HD inline uint32_t slot_to_index(uint32_t s, uint32_t C) {
 // value (the top 20 bits of the left-aligned Q1.31 word of wbscsr's fixed-point type), bits 11..2 = the column -- so
 // (word & 0xFFC) is the LDS byte offset of x[col] -- and bits 1..0 = the ROW_END / SKIP flags of a column word. A packet
 // is [64 * C dwords] = 4 B per entry; there is no separate column-word region.
-enum class Precision : int32_t { F32 = 0, Q1_7 = 1, F16 = 3, FIXED = 4, Q1_7_RND = 5, FIXED20 = 6 };
-constexpr uint32_t FIXED20_MAX_WIDTH = 20, FIXED20_MAX_COLS = 1024;
+// F32C12 = fp32 values with 12-BIT column words (round 2): with at most 1024 columns a column word -- 10 bits of
+// column, 2 flags -- needs 12 bits, not 16; a packet is [64 * C floats][64 * C x 12 bits] = 5.5 B per entry instead of 6,
+// 8.3 % fewer bytes from HBM for the same arithmetic on the same fp32 values (the reference packs its BSCSR packets to
+// the bit for the same reason: types.hpp:57-79). The 12-bit words of a plane of 256 entries lie back to back (entry t at
+// bit 12 t): a lane's 4 words are 6 bytes, two lanes share three dwords, and a lane fetches its words with ONE dwordx2
+// load at a 4-byte boundary (load_packet in kernels/common.hpp). Opt-in for TKSPMV_F32 with cols <= 1024 and 4 entries per
+// lane: TKSPMV_F32_C12=1 (see stream_precision below for why it is not the default); results are bit-identical either way.
+enum class Precision : int32_t { F32 = 0, Q1_7 = 1, F16 = 3, FIXED = 4, Q1_7_RND = 5, FIXED20 = 6, F32C12 = 7 };
+constexpr uint32_t FIXED20_MAX_WIDTH = 20, FIXED20_MAX_COLS = 1024, F32C12_MAX_COLS = 1024;
 
 // bytes of a packet per entry, minus the 2 of a column word (FIXED20: 20-bit value + 10-bit column + 2 flags in 4 bytes)
 TKSPMV_HD inline uint32_t value_bytes(Precision p) {
-    return (p == Precision::F32 || p == Precision::FIXED) ? 4u : ((p == Precision::F16 || p == Precision::FIXED20) ? 2u : 1u);
+    return (p == Precision::F32 || p == Precision::FIXED || p == Precision::F32C12) ? 4u : ((p == Precision::F16 || p == Precision::FIXED20) ? 2u : 1u);
+}
+// bytes of a packet of PE entries
+TKSPMV_HD inline uint32_t packet_bytes_for(Precision p, uint32_t PE) {
+    return p == Precision::F32C12 ? PE * 4u + PE * 3u / 2u : PE * (value_bytes(p) + 2u);
+}
+// 12-bit column words (F32C12): `planes` = start of the packet's column region, `slot` = slot_to_index() of the entry
+// (plane = slot / 256, entry t = slot % 256 of the plane at bit 12 t of the plane's 384 bytes).
+TKSPMV_HD inline void colw12_store(uint8_t *planes, uint32_t slot, uint16_t cw) {
+    const uint32_t t = slot & 255u;
+    uint8_t *b = planes + (size_t)(slot >> 8) * 384u + (t * 3u) / 2u;
+    if (t & 1u) {
+        b[0] = (uint8_t)((b[0] & 0x0Fu) | ((cw & 0xFu) << 4));
+        b[1] = (uint8_t)(cw >> 4);
+    } else {
+        b[0] = (uint8_t)(cw & 0xFFu);
+        b[1] = (uint8_t)((b[1] & 0xF0u) | ((cw >> 8) & 0xFu));
+    }
+}
+TKSPMV_HD inline uint16_t colw12_load(const uint8_t *planes, uint32_t slot) {
+    const uint32_t t = slot & 255u;
+    const uint8_t *b = planes + (size_t)(slot >> 8) * 384u + (t * 3u) / 2u;
+    return (t & 1u) ? (uint16_t)((b[0] >> 4) | ((uint16_t)b[1] << 4)) : (uint16_t)(b[0] | ((uint16_t)(b[1] & 0x0Fu) << 8));
 }
 TKSPMV_HD inline uint32_t fixed20_word(uint32_t q_left_aligned, uint32_t col, uint32_t flags) {
     return (q_left_aligned & 0xFFFFF000u) | (col << 2) | flags;
 }
 // Value type of the stream for a tkspmv_precision (TKSPMV_Q1_7 and TKSPMV_Q1_7_WIDE share the truncated Q1.7 stream;
 // TKSPMV_Q1_7_F32 streams Q1.7 values rounded to nearest).
-inline Precision stream_precision(int32_t api_precision, uint32_t fixed_width = 0, uint32_t cols = 0) {
+inline Precision stream_precision(int32_t api_precision, uint32_t fixed_width = 0, uint32_t cols = 0, uint32_t C = 0) {
+    // fp32 values over few columns travel with 12-bit column words (C = entries per lane; 0: not known, keep 16 bits)
+    // -- opt-in (TKSPMV_F32_C12=1): 8.3 % fewer bytes bought 2 % (the batch kernel is no longer bound by bytes) and cost the
+    // single-query kernel 10 % (register pressure of the unpacking), DESIGN.md section 3
+    if (api_precision == 0 && C == 4 && cols >= 1 && cols <= F32C12_MAX_COLS) {
+        const char *f = getenv("TKSPMV_F32_C12");
+        if (f && atoi(f) != 0) return Precision::F32C12;
+    }
     // narrow fixed point with few columns travels bit-packed (TKSPMV_FIXED_UNPACKED=1 keeps one u32 per value + a column word)
     if (api_precision == 4 && fixed_width >= 8 && fixed_width <= FIXED20_MAX_WIDTH && cols >= 1 && cols <= FIXED20_MAX_COLS &&
         getenv("TKSPMV_FIXED_UNPACKED") == nullptr)
@@ -170,7 +206,7 @@ struct PackedMatrix {
     uint32_t fixed_width = 0;     // Precision::FIXED: bits per value (8..32); 0 otherwise
     uint32_t C = 4;               // entries per lane
     uint32_t packet_entries = 0;  // 64*C
-    uint32_t packet_bytes = 0;    // packet_entries*(value_bytes+2)
+    uint32_t packet_bytes = 0;    // packet_bytes_for(precision, packet_entries)
     uint32_t n_packets = 0;
     uint32_t packets_per_partition = 0;  // m: fill capacity (partitions holding one giant row may exceed it)
     uint64_t packed_entries = 0;         // n_packets * packet_entries

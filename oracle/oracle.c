@@ -396,10 +396,14 @@ void oracle_packed_scores(const uint8_t *packets, uint64_t packet_bytes, const u
             const uint8_t *pk = packets + (size_t)pidx * packet_bytes;
             /* value type from the packet size: 4 bytes = fp32, 2 bytes = fp16 (TKSPMV_F16; converted exactly to fp32
              * before the multiply, as the kernel does) */
-            const uint32_t vb = (uint32_t)(packet_bytes / PE) - 2u;
+            /* 5.5 bytes per entry: fp32 values with 12-BIT column words (the engine's F32C12 layout, csrc/wbscsr.hpp): entry t of
+             * a plane of 256 entries at bit 12 t of the plane's 384 bytes, little-endian; same arithmetic as 16-bit words */
+            const int c12 = packet_bytes * 2u == (uint64_t)PE * 11u;
+            const uint32_t vb = c12 ? 4u : (uint32_t)(packet_bytes / PE) - 2u;
             const float *vals = (const float *)pk;
             const uint16_t *hvals = (const uint16_t *)pk;
             const uint16_t *cws = (const uint16_t *)(pk + (size_t)PE * vb);
+            const uint8_t *c12p = pk + (size_t)PE * 4u;
             float s[64][8], rs[64][8], head[64], tail[64], vv[64], nv[64];
             uint32_t e[64][8], skip[64][8];
             int first[64], any_e[64], dist[64];
@@ -407,7 +411,14 @@ void oracle_packed_scores(const uint8_t *packets, uint64_t packet_bytes, const u
                 float p[8] = {0};
                 for (uint32_t j = 0; j < C; j++) {
                     uint32_t at = (j >> 2) * 256 + l * 4 + (j & 3);
-                    uint16_t w = cws[at];
+                    uint16_t w;
+                    if (c12) {
+                        const uint32_t t = at & 255u;
+                        const uint8_t *b = c12p + (size_t)(at >> 8) * 384u + (t * 3u) / 2u;
+                        w = (t & 1u) ? (uint16_t)((b[0] >> 4) | ((uint16_t)b[1] << 4)) : (uint16_t)(b[0] | ((uint16_t)(b[1] & 0x0Fu) << 8));
+                    } else {
+                        w = cws[at];
+                    }
                     float xv = x[w >> 2];
                     if (vb == 1u) /* Q1.7 bytes, fp32 arithmetic (TKSPMV_Q1_7_F32): byte * (x * 2^-7), as the kernel does */
                         p[j] = (float)pk[at] * (xv * 0.0078125f);

@@ -146,6 +146,38 @@ def test_pack_decode_round_trip(pkg, C, parts):
     assert p.info()["packed_entries"] - g.nnz <= p.info()["n_wave_partitions"] * 64 * C
 
 
+def test_fp32_column_words_travel_as_12_bits(pkg, oracle, monkeypatch):
+    """TKSPMV_F32_C12=1: TKSPMV_F32 over at most 1024 columns packs its column words (10 bits of column, 2 flags) into 12
+    bits: 1408-byte packets instead of 1536. Same entries, same order; the bits are where csrc/wbscsr.hpp says (entry t of a plane of 256
+    at bit 12 t, little-endian); the order-matched oracle computes the same scores, bit for bit, from either layout."""
+    g = pkg.generate_matrix(5000, 1024, 20, "gamma", 9)
+    p16 = pkg.Packed(g, nnz_per_lane=4, n_wave_partitions=64)
+    monkeypatch.setenv("TKSPMV_F32_C12", "1")
+    p12 = pkg.Packed(g, nnz_per_lane=4, n_wave_partitions=64)
+    r12, r16 = p12.raw(), p16.raw()
+    assert r12[1] == 1408 and r16[1] == 1536
+    for a, b in zip(r12[2:], r16[2:]):
+        assert np.array_equal(np.asarray(a), np.asarray(b))  # packet rows and partitions do not depend on the word size
+    for p in (p12, p16):
+        dr, dc, dv = p.decode()
+        assert np.array_equal(dr, g.row) and np.array_equal(dc, g.col) and np.array_equal(dv, g.val)
+    a12 = np.asarray(r12[0]).reshape(-1, 1408)
+    a16 = np.asarray(r16[0]).reshape(-1, 1536)
+    assert np.array_equal(a12[:, :1024], a16[:, :1024])  # the values
+    cw16 = a16[:, 1024:].copy().view(np.uint16).astype(np.uint64)  # [packets][256]
+    bits = np.zeros((a12.shape[0], 384 * 8), np.uint8)
+    for k in range(12):
+        bits[:, k::12] = ((cw16 >> np.uint64(k)) & np.uint64(1)).astype(np.uint8)
+    assert np.array_equal(np.packbits(bits, axis=1, bitorder="little"), a12[:, 1024:])
+    x = pkg.create_sample_vector(1024, True, False, True, 5)
+    y12, pr12 = oracle.packed_scores(r12, x, g.rows, 4)
+    y16, pr16 = oracle.packed_scores(r16, x, g.rows, 4)
+    assert np.array_equal(y12.view(np.uint32), y16.view(np.uint32)) and np.array_equal(pr12, pr16)
+    # more than 1024 columns, or 8 entries per lane: 16-bit words as before
+    assert pkg.Packed(pkg.generate_matrix(2000, 2048, 10, "uniform", 1), nnz_per_lane=4).raw()[1] == 1536
+    assert pkg.Packed(g, nnz_per_lane=8).raw()[1] == 3072
+
+
 def test_pack_rejects_bad_input(pkg):
     rows, cols, r, c, v = _special_matrix(10, 16, [2] * 10)
     bad = r.copy()
