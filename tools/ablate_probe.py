@@ -30,7 +30,8 @@ for flags in settings:
         os.environ["TKSPMV_DBG_FLAGS"] = str(flags)
         if os.environ.get("STATS"):
             os.environ["TKSPMV_STATS"] = "1"
-    eng = mod.SpMV(m.row, m.col, m.val, m.rows, m.cols, vec=xs[0], k=100, device=0, stream_replicas=4)
+    eng = mod.SpMV(m.row, m.col, m.val, m.rows, m.cols, vec=xs[0], k=100, device=0, stream_replicas=4,
+                   nnz_per_lane=int(os.environ.get("NNZ_PER_LANE", "0")))
     eng.enqueue_many(dxs.data_ptr(), 64, 256)
     eng.synchronize()
     nx = 32 if (flags is not None and flags & 16) else 64  # (flag 16: the same vector must come back to the same state set)
