@@ -543,6 +543,43 @@ def bench_sharded(a, mod, torch, np, dev, local_rank, rank, world):
             print(f"[rank {rank}] the native RCCL exchange is unavailable: {e}\n"
                   f"          (set TKSPMV_DIST=torch to measure the torch.distributed exchange instead)", file=sys.stderr)
             sys.exit(3)
+    cross = None
+    if native is not None and (multi or os.environ.get("TKSPMV_BENCH_CROSS")):  # (the variable: rehearsal on one GPU)
+        # The native exchange has to prove itself before it is timed (it cannot be rehearsed on a one-GPU box: RCCL refuses two
+        # ranks on one device): a few queries through it, the last one's merged list against the same query through the
+        # torch.distributed exchange. A mismatch, an error or no answer within 3 minutes ends the run with a message and a
+        # non-zero exit code -- never a silent switch to the other exchange.
+        import signal
+
+        def stuck(signum, frame):  # noqa: ARG001
+            print(f"[rank {rank}] the native RCCL exchange did not answer within 180 s (TKSPMV_DIST=torch measures the "
+                  "torch.distributed exchange instead)", file=sys.stderr, flush=True)
+            os._exit(4)
+
+        signal.signal(signal.SIGALRM, stuck)
+        signal.alarm(180)
+        n_chk = min(5, a.queries)
+        native.run_many(dxs.data_ptr(), a.queries, n_chk)
+        native.synchronize()
+        nv, ni = native.read()
+        sh = dmod.ShardedTopK(a.k, dev)
+        idx_v, val_v = sh.local_views()
+        torch.cuda.synchronize()
+        ts = torch.cuda.Stream(device=dev)  # (a stream of its own: handle 0, torch's default stream, means "the engine's stream")
+        with torch.cuda.stream(ts):
+            eng.enqueue(dxs[n_chk - 1].data_ptr(), idx_v.data_ptr(), val_v.data_ptr(), ts.cuda_stream)
+            ti, tv = sh.step()
+        torch.cuda.synchronize()
+        signal.alarm(0)
+        ti, tv = ti.cpu().numpy().astype(np.uint32), tv.cpu().numpy()
+        same = bool(np.array_equal(ni, ti) and np.array_equal(nv.view(np.uint32), tv.view(np.uint32)))
+        cross = {"native_vs_torch_exchange_same_list": same, "queries": n_chk}
+        if not same and os.environ.get("TKSPMV_BENCH_CROSS"):
+            print("native", ni[:6], nv[:6], "torch", ti[:6], tv[:6], file=sys.stderr)
+        if not same:
+            print(f"[rank {rank}] the native exchange and the torch.distributed exchange disagree on query {n_chk - 1}: "
+                  f"{int((ni != ti).sum())} of {a.k} row ids differ", file=sys.stderr, flush=True)
+            sys.exit(5)
     if native is not None:
         native.run_many(dxs.data_ptr(), a.queries, a.warmup)
         native.synchronize()
@@ -557,23 +594,27 @@ def bench_sharded(a, mod, torch, np, dev, local_rank, rank, world):
         exchange = {"kind": "native: RCCL ncclAllGather of 2*K int32 per rank and query + merge kernel, 32 queries per exchange, on a "
                             "side stream overlapping the next batch's local kernels (csrc/dist.hip)",
                     "us_per_exchange_batch": exchange_ns / 1e3, "queries_per_exchange": 32,
-                    "note": "the exchange alone, back to back (all-gather + merge launch); inside the step it overlaps the local kernels"}
+                    "note": "the exchange alone, back to back (all-gather + merge launch); inside the step it overlaps the local kernels",
+                    "cross_check": cross}
         native.close()
     else:
         sh = dmod.ShardedTopK(a.k, dev)
         idx_v, val_v = sh.local_views()
-        stream = torch.cuda.current_stream().cuda_stream
+        torch.cuda.synchronize()
+        ts = torch.cuda.Stream(device=dev)  # (handle 0 -- torch's default stream -- would mean "the engine's own stream")
 
         def step(i):
-            eng.enqueue(dxs[i % a.queries].data_ptr(), idx_v.data_ptr(), val_v.data_ptr(), stream)
+            eng.enqueue(dxs[i % a.queries].data_ptr(), idx_v.data_ptr(), val_v.data_ptr(), ts.cuda_stream)
             return sh.step()
 
-        for i in range(a.warmup):
-            step(i)
+        with torch.cuda.stream(ts):
+            for i in range(a.warmup):
+                step(i)
         sync_all()
         t0 = time.perf_counter()
-        for i in range(a.steps):
-            ei, ev = step(i)
+        with torch.cuda.stream(ts):
+            for i in range(a.steps):
+                ei, ev = step(i)
         sync_all()
         elapsed = time.perf_counter() - t0
         idx, val = ei.cpu().numpy().astype(np.uint32), ev.cpu().numpy()
