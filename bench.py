@@ -411,9 +411,13 @@ def bench_single(a, mod, torch, np, dev, local_rank):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     kernel_ns = eng.time_queries(dxs.data_ptr(), a.queries, a.steps)  # enqueue + event pair + wait for the end event
+    t1 = time.perf_counter()
     eng.synchronize()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    host_side = {"timed_call_us": 1e6 * (t1 - t0), "device_us_by_events": kernel_ns * a.steps / 1e3,
+                 "synchronisations_after_us": 1e6 * (elapsed - (t1 - t0)),
+                 "note": "value uses the host clock over call + synchronisations; roofline the event pair inside the call"}
     # ---- parity of the last timed query against the oracle
     val, idx = eng.read_result()
     parity_ok, parity = check_parity(mod, m, xs[(a.steps - 1) % a.queries], a.k, idx, val, eng)
@@ -423,7 +427,7 @@ def bench_single(a, mod, torch, np, dev, local_rank):
     timing = {"repetitions": len(reps), "dropped": 2, "queries_per_repetition": n_rep,
               "kernel_us_median": pct(reps, 50), "kernel_us_p95": pct(reps, 95), "kernel_us_mean": float(np.mean(reps)),
               "frac_at_median": alg_bytes / (pct(reps, 50) * 1e3) / HBM_PEAK_GBS}
-    extra = {"parity_checked": parity_ok, "parity": parity, "timing": timing}
+    extra = {"parity_checked": parity_ok, "parity": parity, "timing": timing, "host_side": host_side}
     # ---- what this GPU charges for only LOADING the same stream (engine geometry, no arithmetic): boxes differ by several %
     read_us = sorted(eng.time_stream_read(64) / 1e3 for _ in range(7))[3]
     stream_bytes = int(info["n_packets"]) * int(info["packet_entries"]) * 6
