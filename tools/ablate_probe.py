@@ -31,7 +31,8 @@ for flags in settings:
         if os.environ.get("STATS"):
             os.environ["TKSPMV_STATS"] = "1"
     eng = mod.SpMV(m.row, m.col, m.val, m.rows, m.cols, vec=xs[0], k=100, device=0, stream_replicas=4,
-                   nnz_per_lane=int(os.environ.get("NNZ_PER_LANE", "0")))
+                   nnz_per_lane=int(os.environ.get("NNZ_PER_LANE", "0")), threads_per_wg=int(os.environ.get("THREADS_PER_WG", "0")),
+                   waves_per_cu=int(os.environ.get("WAVES_PER_CU", "0")))
     eng.enqueue_many(dxs.data_ptr(), 64, 256)
     eng.synchronize()
     nx = 32 if (flags is not None and flags & 16) else 64  # (flag 16: the same vector must come back to the same state set)
