@@ -61,7 +61,9 @@ def test_load_only_probe_brackets_the_kernel(pkg):
     eng.time_queries(dxs.data_ptr(), 8, 64)
     t_kernel = min(eng.time_queries(dxs.data_ptr(), 8, 256) for _ in range(3))
     t_read = sorted(eng.time_stream_read(32) for _ in range(5))[2]
-    assert stream_bytes / 8000.0 < t_read < t_kernel  # above the 8 TB/s specification, below the kernel that also computes
+    # not faster than twice the 8 TB/s specification (part of a 47 MB stream copy may still sit in the Infinity Cache), and
+    # below the kernel that also computes
+    assert 0.5 * stream_bytes / 8000.0 < t_read < t_kernel
     with pytest.raises(pkg.TkspmvError):
         eng.time_stream_read(0)
     eng.close()
