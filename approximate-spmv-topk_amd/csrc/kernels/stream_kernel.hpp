@@ -53,7 +53,7 @@ __global__ void __launch_bounds__(576, ((C == 8 && !SCORES) || QM == 7) ? 6 : 5)
     // Deferred packets live in registers (C row sums + C / 2 flag words each): with 8 entries per lane one packet is held,
     // not three -- the same number of rows as two 4-entry packets, and the kernel stays at 80 registers (two workgroups
     // per CU; with three it needed 96 and a single query took 57 us instead of 36).
-    constexpr int DEFER_C = C == 8 ? 1 : DEFER;
+    constexpr int DEFER_C = (C == 8 || QM == 7) ? 1 : DEFER;  // (12-bit column words: the unpacking needs the registers)
     __shared__ StreamLds<XCOLS> L;
     float *x_lds = L.u.w.x;
     uint2 *cand = L.u.w.cand;

@@ -62,8 +62,8 @@ TKSPMV_HD inline uint32_t slot_to_index(uint32_t s, uint32_t C) {
 // 8.3 % fewer bytes from HBM for the same arithmetic on the same fp32 values (the reference packs its BSCSR packets to
 // the bit for the same reason: types.hpp:57-79). The 12-bit words of a plane of 256 entries lie back to back (entry t at
 // bit 12 t): a lane's 4 words are 6 bytes, two lanes share three dwords, and a lane fetches its words with ONE dwordx2
-// load at a 4-byte boundary (load_packet in kernels/common.hpp). Opt-in for TKSPMV_F32 with cols <= 1024 and 4 entries per
-// lane: TKSPMV_F32_C12=1 (see stream_precision below for why it is not the default); results are bit-identical either way.
+// load at a 4-byte boundary (load_packet in kernels/common.hpp). The default for TKSPMV_F32 with cols <= 1024 and 4 entries
+// per lane (TKSPMV_F32_C12=0 keeps 16-bit column words); results are bit-identical either way.
 enum class Precision : int32_t { F32 = 0, Q1_7 = 1, F16 = 3, FIXED = 4, Q1_7_RND = 5, FIXED20 = 6, F32C12 = 7 };
 constexpr uint32_t FIXED20_MAX_WIDTH = 20, FIXED20_MAX_COLS = 1024, F32C12_MAX_COLS = 1024;
 
@@ -100,11 +100,10 @@ TKSPMV_HD inline uint32_t fixed20_word(uint32_t q_left_aligned, uint32_t col, ui
 // TKSPMV_Q1_7_F32 streams Q1.7 values rounded to nearest).
 inline Precision stream_precision(int32_t api_precision, uint32_t fixed_width = 0, uint32_t cols = 0, uint32_t C = 0) {
     // fp32 values over few columns travel with 12-bit column words (C = entries per lane; 0: not known, keep 16 bits)
-    // -- opt-in (TKSPMV_F32_C12=1): 8.3 % fewer bytes bought 2 % (the batch kernel is no longer bound by bytes) and cost the
-    // single-query kernel 10 % (register pressure of the unpacking), DESIGN.md section 3
+    // (TKSPMV_F32_C12=0 keeps 16-bit column words: 8.3 % more bytes, 2.7 % slower back-to-back queries)
     if (api_precision == 0 && C == 4 && cols >= 1 && cols <= F32C12_MAX_COLS) {
         const char *f = getenv("TKSPMV_F32_C12");
-        if (f && atoi(f) != 0) return Precision::F32C12;
+        if (!f || atoi(f) != 0) return Precision::F32C12;
     }
     // narrow fixed point with few columns travels bit-packed (TKSPMV_FIXED_UNPACKED=1 keeps one u32 per value + a column word)
     if (api_precision == 4 && fixed_width >= 8 && fixed_width <= FIXED20_MAX_WIDTH && cols >= 1 && cols <= FIXED20_MAX_COLS &&

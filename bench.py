@@ -283,7 +283,7 @@ def single_query_leg(mod, m, xs, dxs, a, device, eng, alg_bytes):
         rok, _ = check_parity(mod, m, xs[(n - 1) % xs.shape[0]], a.k, ridx, rval, reng)
         reng.close()
         rk, re2e = rk[2:], re2e[2:]
-        resident = {"kernel": "tkspmv::batch_kernel<4,1024,0,false,true> (resident: one launch serves the loop)",
+        resident = {"kernel": "tkspmv::batch_kernel<4,1024,7,false,true> (resident: one launch serves the loop)",
                     "device_us": float(np.median(rk)), "device_us_p95": pct(rk, 95),
                     "frac": alg_bytes / (float(np.median(rk)) * 1e3) / HBM_PEAK_GBS,
                     "end_to_end_us": float(np.median(re2e)), "end_to_end_us_p95": pct(re2e, 95), "parity_checked": rok,
@@ -291,7 +291,7 @@ def single_query_leg(mod, m, xs, dxs, a, device, eng, alg_bytes):
                             "(its own 100 MHz clock); end_to_end_us = host clock around set_query + run + read"}
     except Exception as e:  # noqa: BLE001 -- a side leg must not cost the bench line
         resident = {"error": f"{type(e).__name__}: {e}"}
-    return {"kernel": "tkspmv::stream_kernel<4,false,1024,0,3> (one fused launch per query: stream, flush, in-launch selection)",
+    return {"kernel": "tkspmv::stream_kernel<4,false,1024,7,3> (one fused launch per query: stream, flush, in-launch selection)",
             "resident": resident,
             "runs": len(kern), "dropped": 2, "kernel_us": med, "kernel_us_p95": pct(kern, 95), "frac": alg_bytes / (med * 1e3) / HBM_PEAK_GBS,
             "end_to_end_us": float(np.median(e2e)), "end_to_end_us_p95": pct(e2e, 95), "parity_checked": ok,
@@ -430,10 +430,11 @@ def bench_single(a, mod, torch, np, dev, local_rank):
     extra = {"parity_checked": parity_ok, "parity": parity, "timing": timing, "host_side": host_side}
     # ---- what this GPU charges for only LOADING the same stream (engine geometry, no arithmetic): boxes differ by several %
     read_us = sorted(eng.time_stream_read(64) / 1e3 for _ in range(7))[3]
-    stream_bytes = int(info["n_packets"]) * int(info["packet_entries"]) * 6
+    c12 = os.environ.get("TKSPMV_F32_C12", "1") != "0" and a.cols <= 1024 and int(info["packet_entries"]) == 256
+    stream_bytes = int(info["n_packets"]) * (1408 if c12 else int(info["packet_entries"]) * 6)  # 12-bit column words: 5.5 B per entry
     read_only = {"us_per_pass": read_us, "stream_bytes": stream_bytes, "GBps": stream_bytes / (read_us * 1e3),
                  "frac_of_peak": stream_bytes / (read_us * 1e3) / HBM_PEAK_GBS,
-                 "kernel": "tkspmv::read_probe_kernel<24>: the engine's grid, waves, partitions and non-temporal dwordx4/x2 "
+                 "kernel": "tkspmv::read_probe_kernel<22>: the engine's grid, waves, partitions and non-temporal dwordx4/x2 "
                            "loads, 8 packets in flight per wave, 64 passes in one launch over the rotating stream copies; "
                            "median of 7",
                  "headline_kernel_vs_read_only": read_us / (kernel_ns / 1e3),
@@ -461,22 +462,21 @@ def bench_single(a, mod, torch, np, dev, local_rank):
             extra["multi_query"] = multi_query_leg(mod, m, dxs, a, local_rank, alg_bytes)
     eng.close()
     if not a.skip_warm:
-        # the same workload with 12-bit column words (opt-in layout, TKSPMV_F32_C12=1: 5.5 instead of 6 bytes per nnz, same bits)
-        os.environ["TKSPMV_F32_C12"] = "1"
+        # the same workload with 16-bit column words (TKSPMV_F32_C12=0: 6 instead of 5.5 bytes per nnz, same bits)
+        os.environ["TKSPMV_F32_C12"] = "0"
         try:
-            e12 = mod.SpMV(m.row, m.col, m.val, m.rows, m.cols, k=a.k, device=local_rank, stream_replicas=a.replicas)
-            e12.time_queries(dxs.data_ptr(), a.queries, 64)
-            k12 = sorted(e12.time_queries(dxs.data_ptr(), a.queries, 512) for _ in range(5))[2]
-            r12 = sorted(e12.time_stream_read(64) for _ in range(5))[2]
-            v12, i12 = e12.read_result()
-            extra["f32_c12"] = {"layout": "fp32 values + 12-bit column words (1408-byte packets instead of 1536), opt-in",
-                                "stream_bytes": int(e12.info()["n_packets"]) * 1408, "kernel_us": k12 / 1e3,
-                                "read_only_us_per_pass": r12 / 1e3, "frac_of_algorithmic_peak": alg_bytes / k12 / HBM_PEAK_GBS,
-                                "note": "8.3 % fewer bytes, a load-only floor 8 % lower, and a kernel 2 % faster: the batch "
-                                        "kernel is bound by its per-packet work, not by bytes (DESIGN.md section 3)"}
-            e12.close()
+            e16 = mod.SpMV(m.row, m.col, m.val, m.rows, m.cols, k=a.k, device=local_rank, stream_replicas=a.replicas)
+            e16.time_queries(dxs.data_ptr(), a.queries, 64)
+            k16 = sorted(e16.time_queries(dxs.data_ptr(), a.queries, 512) for _ in range(5))[2]
+            r16 = sorted(e16.time_stream_read(64) for _ in range(5))[2]
+            extra["f32_c16"] = {"layout": "fp32 values + 16-bit column words (1536-byte packets instead of 1408), TKSPMV_F32_C12=0",
+                                "stream_bytes": int(e16.info()["n_packets"]) * 1536, "kernel_us": k16 / 1e3,
+                                "read_only_us_per_pass": r16 / 1e3, "frac_of_algorithmic_peak": alg_bytes / k16 / HBM_PEAK_GBS,
+                                "note": "8.3 % fewer bytes move the load-only floor by 8 % and the kernel by 2-3 %: the batch kernel "
+                                        "is bound by bytes and by entries per second at once (DESIGN.md section 3)"}
+            e16.close()
         except Exception as e:  # noqa: BLE001
-            extra["f32_c12"] = {"error": str(e)}
+            extra["f32_c16"] = {"error": str(e)}
         del os.environ["TKSPMV_F32_C12"]
         extra["configs"] = config_legs(mod, a, local_rank)
     # ---- HBM traffic of the headline kernel
@@ -500,7 +500,7 @@ def bench_single(a, mod, torch, np, dev, local_rank):
         "roofline": {"bound": "hbm", "achieved": alg_bytes / kernel_ns, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": alg_bytes / kernel_ns / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": source,
                      "traffic_detail": detail,
-                     "kernel": "tkspmv::batch_kernel<4,1024,0> (up to 32 queries per launch; figures are per query)",
+                     "kernel": "tkspmv::batch_kernel<4,1024,7> (fp32, 12-bit column words; up to 32 queries per launch; figures are per query)",
                      "algorithmic_bytes": int(alg_bytes), "kernel_us": kernel_ns / 1e3, "read_only": read_only,
                      "method": "one hipEvent pair on the engine stream around the timed region's back-to-back launches, "
                                "duration = event time / steps. A launch of the batch kernel streams the matrix once per "
@@ -655,7 +655,7 @@ def bench_sharded(a, mod, torch, np, dev, local_rank, rank, world):
                        "parallelism": f"row-shard x{world}"},
             "roofline": {"bound": "hbm", "achieved": slowest["algorithmic_bytes"] / (slowest["kernel_us"] * 1e3), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": slowest["frac"], "traffic": None,
-                         "kernel": "tkspmv::batch_kernel<4,1024,0> on the slowest rank's shard (per query)",
+                         "kernel": "tkspmv::batch_kernel<4,1024,7> on the slowest rank's shard (per query)",
                          "algorithmic_bytes": slowest["algorithmic_bytes"], "kernel_us": slowest["kernel_us"],
                          "method": "per rank: one hipEvent pair around a batch of back-to-back local launches, no exchange"},
             "per_rank": per_rank, "exchange": exchange, "parity_checked": parity_ok, "parity": parity,

@@ -57,7 +57,7 @@ def test_load_only_probe_brackets_the_kernel(pkg):
     dxs = torch.from_numpy(xs).cuda()
     eng = pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, vec=xs[0], k=100, device=0, stream_replicas=8)  # 8 x 47 MB: no cache holds them
     info = eng.info()
-    stream_bytes = info["n_packets"] * info["packet_entries"] * 6
+    stream_bytes = info["n_packets"] * 1408  # fp32 values + 12-bit column words
     eng.time_queries(dxs.data_ptr(), 8, 64)
     t_kernel = min(eng.time_queries(dxs.data_ptr(), 8, 256) for _ in range(3))
     t_read = sorted(eng.time_stream_read(32) for _ in range(5))[2]

@@ -1,4 +1,4 @@
-"""fp32 values with 12-BIT column words (csrc/wbscsr.hpp F32C12; opt-in: TKSPMV_F32_C12=1): 8.3 % fewer bytes in the
+"""fp32 values with 12-BIT column words (csrc/wbscsr.hpp F32C12; the default up to 1024 columns, TKSPMV_F32_C12=0 keeps 16 bits): 8.3 % fewer bytes in the
 stream, the same fp32 arithmetic in the same order. Every path that streams the packets must return the same bits as with
 16-bit column words; the device packer must produce the host packer's bytes; a packed file must round-trip."""
 import numpy as np
@@ -8,11 +8,10 @@ pytestmark = pytest.mark.gpu
 
 
 def _engines(pkg, monkeypatch, m, x, **kw):
-    monkeypatch.delenv("TKSPMV_F32_C12", raising=False)
+    monkeypatch.setenv("TKSPMV_F32_C12", "0")
     e16 = pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, vec=x, device=0, **kw)
-    monkeypatch.setenv("TKSPMV_F32_C12", "1")
-    e12 = pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, vec=x, device=0, **kw)
     monkeypatch.delenv("TKSPMV_F32_C12")
+    e12 = pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, vec=x, device=0, **kw)
     return e16, e12
 
 
@@ -57,7 +56,6 @@ def test_same_bits_as_16_bit_column_words(pkg, oracle, monkeypatch, rows, cols, 
 
 def test_device_packer_and_file_round_trip(pkg, monkeypatch, tmp_path):
     m = pkg.generate_matrix(150000, 1000, 25, "gamma", 3)
-    monkeypatch.setenv("TKSPMV_F32_C12", "1")
     host = pkg.Packed(m, k=100, nnz_per_lane=4, n_wave_partitions=512)
     dev = pkg.Packed(m, k=100, nnz_per_lane=4, n_wave_partitions=512, on_device=True)
     rh, rd = host.raw(), dev.raw()
@@ -84,9 +82,8 @@ def test_device_packer_and_file_round_trip(pkg, monkeypatch, tmp_path):
 def test_resident_kernel_with_12_bit_column_words(pkg, oracle, monkeypatch):
     m = pkg.generate_matrix(300000, 1024, 20, "gamma", 12)
     xs = [pkg.create_sample_vector(1024, True, False, True, 40 + i) for i in range(5)]
-    monkeypatch.setenv("TKSPMV_F32_C12", "1")
     eng = pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, vec=xs[0], k=100, device=0, impl=pkg._lib.IMPL_RESIDENT)
-    monkeypatch.delenv("TKSPMV_F32_C12")
+    assert eng.info()["packed_bytes"] < 0.93 * 6.3 * m.nnz
     for x in xs:
         eng.reset(x)
         eng()

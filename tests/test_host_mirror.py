@@ -136,7 +136,8 @@ def test_pack_decode_round_trip(pkg, C, parts):
     assert info["packet_entries"] == 64 * C and info["n_wave_partitions"] <= parts
     assert info["packed_entries"] == info["n_packets"] * 64 * C
     packets, packet_bytes, pkt_row, part_first, part_count = p.raw()
-    assert packet_bytes == 64 * C * 6 and len(packets) == info["n_packets"] * packet_bytes
+    # (fp32 over at most 1024 columns, 4 entries per lane: 12-bit column words, 5.5 bytes per entry)
+    assert packet_bytes == (64 * C * 11 // 2 if C == 4 else 64 * C * 6) and len(packets) == info["n_packets"] * packet_bytes
     assert part_count.sum() == info["n_packets"] and np.all(part_first[1:] == np.cumsum(part_count)[:-1])
     g = pkg.generate_matrix(3000, 512, 20, "gamma", 3)
     p = pkg.Packed(g, nnz_per_lane=C, n_wave_partitions=parts)
@@ -147,13 +148,14 @@ def test_pack_decode_round_trip(pkg, C, parts):
 
 
 def test_fp32_column_words_travel_as_12_bits(pkg, oracle, monkeypatch):
-    """TKSPMV_F32_C12=1: TKSPMV_F32 over at most 1024 columns packs its column words (10 bits of column, 2 flags) into 12
-    bits: 1408-byte packets instead of 1536. Same entries, same order; the bits are where csrc/wbscsr.hpp says (entry t of a plane of 256
+    """TKSPMV_F32 over at most 1024 columns packs its column words (10 bits of column, 2 flags) into 12 bits (the default;
+    TKSPMV_F32_C12=0 keeps 16): 1408-byte packets instead of 1536. Same entries, same order; the bits are where csrc/wbscsr.hpp says (entry t of a plane of 256
     at bit 12 t, little-endian); the order-matched oracle computes the same scores, bit for bit, from either layout."""
     g = pkg.generate_matrix(5000, 1024, 20, "gamma", 9)
-    p16 = pkg.Packed(g, nnz_per_lane=4, n_wave_partitions=64)
-    monkeypatch.setenv("TKSPMV_F32_C12", "1")
     p12 = pkg.Packed(g, nnz_per_lane=4, n_wave_partitions=64)
+    monkeypatch.setenv("TKSPMV_F32_C12", "0")
+    p16 = pkg.Packed(g, nnz_per_lane=4, n_wave_partitions=64)
+    monkeypatch.delenv("TKSPMV_F32_C12")
     r12, r16 = p12.raw(), p16.raw()
     assert r12[1] == 1408 and r16[1] == 1536
     for a, b in zip(r12[2:], r16[2:]):

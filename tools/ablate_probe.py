@@ -19,8 +19,8 @@ rows, cols, nnz = (int(v) for v in sys.argv[1:4]) if len(sys.argv) >= 4 else (10
 m = mod.generate_matrix(rows, cols, nnz, "gamma", 2)
 xs = np.stack([mod.create_sample_vector(cols, True, False, True, 1000 + i) for i in range(64)])
 dxs = torch.from_numpy(xs).cuda()
-if os.environ.get("C12"):
-    os.environ["TKSPMV_F32_C12"] = "1"  # 12-bit column words (A/B against the 16-bit default)
+if os.environ.get("C16"):
+    os.environ["TKSPMV_F32_C12"] = "0"  # 16-bit column words (A/B against the 12-bit default)
 settings = [None] if sys.argv[4:5] == ["none"] else [None] + [int(f) for f in (sys.argv[4:] or ["0", "2", "16"])] + [None]
 for flags in settings:
     if flags is None:
