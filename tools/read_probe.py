@@ -10,6 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import _pkg  # noqa: E402
 
+os.environ.setdefault("TKSPMV_F32_C12", "0")  # the depth / work variants of the probe are built for the 1536-byte (16-bit column word) packets
 torch.cuda.init()
 mod = _pkg.load()
 m = mod.generate_matrix(1000000, 1024, 20, "gamma", 2)
