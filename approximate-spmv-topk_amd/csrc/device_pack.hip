@@ -531,6 +531,7 @@ struct SellScatterParams {
     const uint32_t *chunk0, *n_chunks_of;
     uint8_t *packets;
     uint32_t n_slices, vb, packet_bytes;
+    uint32_t cw_bits, pad_neutral, pad_one;  // 12-bit column words: the padding slots sit at columns 1022 / 1023
 };
 
 __global__ void __launch_bounds__(64) sell_scatter_kernel(const SellScatterParams P) {
@@ -554,11 +555,11 @@ __global__ void __launch_bounds__(64) sell_scatter_kernel(const SellScatterParam
             } else if (!have && e == 0) {
                 v[j] = -__builtin_huge_valf();
                 qv[j] = 1;
-                cw[j] = (uint16_t)(SELL_PAD_ONE << 2);
+                cw[j] = (uint16_t)(P.pad_one << 2);
             } else {
                 v[j] = 0.0f;
                 qv[j] = 0;
-                cw[j] = (uint16_t)(SELL_PAD_NEUTRAL << 2);
+                cw[j] = (uint16_t)(P.pad_neutral << 2);
             }
             if (c + 1 == nc) {
                 if (j == 0) cw[j] |= SELL_LAST_CHUNK;
@@ -567,8 +568,23 @@ __global__ void __launch_bounds__(64) sell_scatter_kernel(const SellScatterParam
         }
         if (P.vb == 4u) *reinterpret_cast<float4 *>(pkt + (size_t)l * 16) = make_float4(v[0], v[1], v[2], v[3]);
         else *reinterpret_cast<uint32_t *>(pkt + (size_t)l * 4) = (uint32_t)qv[0] | ((uint32_t)qv[1] << 8) | ((uint32_t)qv[2] << 16) | ((uint32_t)qv[3] << 24);
-        *reinterpret_cast<uint2 *>(pkt + 256u * P.vb + (size_t)l * 8) =
-            make_uint2((uint32_t)cw[0] | ((uint32_t)cw[1] << 16), (uint32_t)cw[2] | ((uint32_t)cw[3] << 16));
+        if (P.cw_bits == 12u) {
+            // the lane's four 12-bit words are 48 bits; two lanes share three dwords: the even lane writes the first two (the
+            // second one completed with the odd lane's low 16 bits), the odd lane the third
+            const uint32_t lo = (uint32_t)cw[0] | ((uint32_t)cw[1] << 12) | ((uint32_t)cw[2] << 24);
+            const uint32_t hi = ((uint32_t)cw[2] >> 8) | ((uint32_t)cw[3] << 4);  // bits 32..47
+            const uint32_t other_lo = (uint32_t)__shfl_xor((int)lo, 1);
+            uint32_t *d = reinterpret_cast<uint32_t *>(pkt + 256u * P.vb + (size_t)(l >> 1) * 12);
+            if ((l & 1u) == 0u) {
+                d[0] = lo;
+                d[1] = hi | (other_lo << 16);
+            } else {
+                d[2] = (lo >> 16) | (hi << 16);
+            }
+        } else {
+            *reinterpret_cast<uint2 *>(pkt + 256u * P.vb + (size_t)l * 8) =
+                make_uint2((uint32_t)cw[0] | ((uint32_t)cw[1] << 16), (uint32_t)cw[2] | ((uint32_t)cw[3] << 16));
+        }
     }
 }
 
@@ -626,6 +642,9 @@ std::string pack_wsell_device(uint32_t rows, uint32_t cols, uint64_t nnz, const 
     S.n_slices = sm.n_slices;
     S.vb = (uint32_t)sm.values;
     S.packet_bytes = sm.packet_bytes;
+    S.cw_bits = sm.cw_bits;
+    S.pad_neutral = sm.pad_neutral;
+    S.pad_one = sm.pad_one;
     hipLaunchKernelGGL(sell_scatter_kernel, dim3(sm.n_slices), dim3(64), 0, 0, S);
     DP_TRY(hipGetLastError());
     DP_TRY(hipDeviceSynchronize());

@@ -146,6 +146,7 @@ struct EngineImpl {
     uint32_t *d_sell_rows = nullptr, *d_sell_part_first = nullptr, *d_sell_part_count = nullptr, *d_sell_part_slice0 = nullptr;
     uint32_t sell_parts = 0, multi_stream_waves = 8, sell_packet_bytes = 1536;
     bool sell_byte_values = false;  // TKSPMV_Q1_7_F32: 768-byte chunks of Q1.7 bytes
+    bool sell_c12 = false;          // ... with 12-bit column words: 640-byte chunks (at most 1022 columns)
     uint64_t sell_bytes = 0;
     uint32_t *d_multi_out_idx = nullptr;  // [2 * MULTI_Q_MAX][k] results of tkspmv_time_multi
     float *d_multi_out_val = nullptr;
@@ -325,9 +326,10 @@ struct EngineImpl {
         const dim3 mblock(multi_stream_waves * 64u + 64u);
         typedef void (*multi_fn)(const StreamParams, const SelectParams, const MultiParams);
         const int qi = multi_q <= 1 ? 0 : (multi_q <= 2 ? 1 : (multi_q <= 4 ? 2 : 3));
-        static const multi_fn fns[2][4] = {{&multi_kernel<1, 0>, &multi_kernel<2, 0>, &multi_kernel<4, 0>, &multi_kernel<8, 0>},
-                                           {&multi_kernel<1, 1>, &multi_kernel<2, 1>, &multi_kernel<4, 1>, &multi_kernel<8, 1>}};
-        hipLaunchKernelGGL(fns[sell_byte_values ? 1 : 0][qi], dim3(grid), mblock, 0, s, P, S, M);
+        static const multi_fn fns[3][4] = {{&multi_kernel<1, 0>, &multi_kernel<2, 0>, &multi_kernel<4, 0>, &multi_kernel<8, 0>},
+                                           {&multi_kernel<1, 1>, &multi_kernel<2, 1>, &multi_kernel<4, 1>, &multi_kernel<8, 1>},
+                                           {&multi_kernel<1, 5>, &multi_kernel<2, 5>, &multi_kernel<4, 5>, &multi_kernel<8, 5>}};
+        hipLaunchKernelGGL(fns[sell_byte_values ? (sell_c12 ? 2 : 1) : 0][qi], dim3(grid), mblock, 0, s, P, S, M);
         pending_group[chain] = M.cur;
         multi_parity[chain] ^= 1;
     }
@@ -984,6 +986,7 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
         m.sell_pack_us = (uint32_t)std::min<long long>(std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_sell).count(), 0xFFFFFFFFll);
         m.sell_packet_bytes = sm.packet_bytes;
         m.sell_byte_values = sv == SellValues::Q1_7_RND;
+        m.sell_c12 = sm.cw_bits == 12;
         if (!perr.empty()) {
             err = perr;
             return perr.find("failed:") != std::string::npos ? TKSPMV_ERR_DEVICE : TKSPMV_ERR_INVALID;

@@ -102,7 +102,7 @@ constexpr float Q17_UNIT = 0.0078125f;  // 2^-7
 template <int C, int VT>
 struct Pkt {
     float v[(VT == 0 || VT == 3 || VT == 4) ? C : 1];  // VT 3: the packed dwords (value | column | flags); cw stays unused
-    uint32_t vq[VT == 1 ? C / 4 : (VT == 2 ? C / 2 : 1)];
+    uint32_t vq[(VT == 1 || VT == 5) ? C / 4 : (VT == 2 ? C / 2 : 1)];  // VT 5: byte values with 12-bit column words (row-per-lane chunks)
     uint32_t cw[C / 2];  // VT 4: the two dwords that hold the lane's four 12-bit words (from bit 0, or bit 16 on odd lanes)
 };
 
@@ -124,6 +124,11 @@ __device__ __forceinline__ void load_packet(const uint8_t *__restrict__ pk, uint
             o.v[VT == 4 ? 4 * q + 3 : 0] = f.w;
             // two lanes share three dwords: the even lane takes dwords 0-1, the odd one dwords 1-2 (4-byte aligned dwordx2)
             const u32x2_a4 c = __builtin_nontemporal_load(reinterpret_cast<const u32x2_a4 *>(pk + C * 256 + q * 384 + (lane >> 1) * 12 + (lane & 1u) * 4));
+            o.cw[2 * q + 0] = c.x;
+            o.cw[2 * q + 1] = c.y;
+        } else if (VT == 5) {
+            o.vq[VT == 5 ? q : 0] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(pk + q * 256 + lane * 4));
+            const u32x2_a4 c = __builtin_nontemporal_load(reinterpret_cast<const u32x2_a4 *>(pk + C * 64 + q * 384 + (lane >> 1) * 12 + (lane & 1u) * 4));
             o.cw[2 * q + 0] = c.x;
             o.cw[2 * q + 1] = c.y;
         } else if (VT == 1) {

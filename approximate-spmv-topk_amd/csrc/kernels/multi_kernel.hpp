@@ -142,14 +142,16 @@ __device__ __forceinline__ void offer_rows(const SetAddr &A, uint32_t set, uint3
 // fp32 number as (byte / 128) * x.
 template <int VT>
 __device__ __forceinline__ float chunk_value(const Pkt<4, VT> &p, int j) {
-    if (VT == 1) return ubyte_to_float(p.vq[0], j);
+    if (VT == 1 || VT == 5) return ubyte_to_float(p.vq[0], j);
     return p.v[VT == 0 ? j : 0];
 }
 
 // VT: 0 = fp32 chunks (1536 B), 1 = byte chunks (768 B; four of them in flight behind the one being reduced instead of two).
 template <int Q, int VT = 0>
 __global__ void __launch_bounds__(576, Q >= 8 ? 4 : 6) multi_kernel(const StreamParams P0, const SelectParams SP0, const MultiParams M) {
-    constexpr int C = 4, NBUF = VT == 1 ? TKSPMV_SELL_BYTE_NBUF : 3, DEFER_S = MultiGeom<Q>::HOLD;
+    constexpr int C = 4, NBUF = (VT == 1 || VT == 5) ? TKSPMV_SELL_BYTE_NBUF : 3, DEFER_S = MultiGeom<Q>::HOLD;
+    constexpr bool BYTES = VT == 1 || VT == 5;  // VT 5: byte values with 12-bit column words (640-byte chunks, padding slots 1022 / 1023)
+    constexpr uint32_t PAD_NEUTRAL = VT == 5 ? 1022u : SELL_PAD_NEUTRAL, PAD_ONE = VT == 5 ? 1023u : SELL_PAD_ONE;
     constexpr uint32_t MULTI_WAVE_CAP = MultiGeom<Q>::WAVE_CAP;
     __shared__ MultiLds<Q> L;
     const uint32_t tid = threadIdx.x;
@@ -209,10 +211,10 @@ __global__ void __launch_bounds__(576, Q >= 8 ? 4 : 6) multi_kernel(const Stream
     for (uint32_t q = 0; q < (uint32_t)Q; ++q) {  // queries beyond nq (a partial group): zeros, their sums are never looked at
         const float *xg = M.cur.io[q < nq ? q : 0u].x;
         for (uint32_t i = tid; i < SELL_XCOLS; i += blockDim.x)
-            x_slot(q, i) = (i < P0.cols && q < nq) ? (VT == 1 ? xg[i] * Q17_UNIT : xg[i]) : 0.0f;
+            x_slot(q, i) = (i < P0.cols && q < nq) ? (BYTES ? xg[i] * Q17_UNIT : xg[i]) : 0.0f;
         if (tid == 0) {
-            x_slot(q, SELL_PAD_NEUTRAL) = -0.0f;
-            x_slot(q, SELL_PAD_ONE) = VT == 1 ? -__builtin_huge_valf() : 1.0f;  // byte chunks: a lane without a row starts with byte 1
+            x_slot(q, PAD_NEUTRAL) = -0.0f;
+            x_slot(q, PAD_ONE) = BYTES ? -__builtin_huge_valf() : 1.0f;  // byte chunks: a lane without a row starts with byte 1
         }
     }
     __syncthreads();
@@ -298,10 +300,21 @@ __global__ void __launch_bounds__(576, Q >= 8 ? 4 : 6) multi_kernel(const Stream
                 if (i + (NBUF - 1) < np) pk_ahead += P0.packet_bytes;
                 load_packet<C, VT>(pk_ahead, lane, buf[(u + NBUF - 1) % NBUF]);
             }
+            uint32_t cwv[2];  // the chunk's column words as two dwords of two 16-bit words
+            if (VT == 5) {    // 12-bit words: 48 bits of the two dwords loaded, from bit 0 on even lanes and from bit 16 on odd ones
+                const uint32_t odd16 = (threadIdx.x & 1u) << 4;
+                const uint32_t lo = __builtin_amdgcn_alignbit(cur.cw[1], cur.cw[0], odd16), hi = cur.cw[1] >> odd16;
+                const uint32_t mid = __builtin_amdgcn_alignbit(hi, lo, 24);
+                cwv[0] = (lo & 0xFFFu) | ((lo << 4) & 0x0FFF0000u);
+                cwv[1] = (mid & 0xFFFu) | ((hi << 12) & 0x0FFF0000u);
+            } else {
+                cwv[0] = cur.cw[0];
+                cwv[1] = cur.cw[1];
+            }
             uint32_t off[C];
 #pragma unroll
             for (int j = 0; j < C; ++j) {
-                const uint32_t word = cur.cw[j >> 1];
+                const uint32_t word = cwv[j >> 1];
                 off[j] = (j & 1) ? ((word >> 16) & 0xFFFCu) : (word & 0xFFFCu);  // byte offset of x[col]
             }
             if (IL) {
@@ -340,10 +353,10 @@ __global__ void __launch_bounds__(576, Q >= 8 ? 4 : 6) multi_kernel(const Stream
                     }
                 }
             }
-            if (__builtin_amdgcn_readfirstlane(cur.cw[0]) & 1u) {  // last chunk of the slice: 64 rows are complete
+            if (__builtin_amdgcn_readfirstlane(cwv[0]) & 1u) {  // last chunk of the slice: 64 rows are complete
                 // A row of more than 64 entries spans adjacent lanes (segment index in the flag bits of this chunk, wsell.hpp):
                 // its segment sums are added left to right and the score ends up on its last lane; rare.
-                const uint32_t depth = ((cur.cw[0] >> 16) & 3u) | ((cur.cw[1] & 3u) << 2) | (((cur.cw[1] >> 16) & 3u) << 4);
+                const uint32_t depth = ((cwv[0] >> 16) & 3u) | ((cwv[1] & 3u) << 2) | (((cwv[1] >> 16) & 3u) << 4);
                 if (__ballot(depth != 0u) != 0ull) {
                     for (uint32_t d = 1; d < 64u; ++d) {
                         if (__ballot(depth == d) == 0ull) break;

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 
@@ -22,7 +23,12 @@ std::string plan_wsell(uint32_t rows, uint32_t cols, uint64_t nnz, const uint32_
     out.nnz = nnz;
     out.values = values;
     const uint32_t vb = (uint32_t)values;
-    const uint32_t PB = 256u * (vb + 2u);
+    if (values == SellValues::Q1_7_RND && cols <= SELL_C12_MAX_COLS && sell_c12_wanted()) {
+        out.cw_bits = 12;
+        out.pad_neutral = 1022;
+        out.pad_one = 1023;
+    }
+    const uint32_t PB = 256u * vb + 256u * out.cw_bits / 8u;
     out.packet_bytes = PB;
     if (nnz == 0) return "";
     for (uint64_t i = 1; i < nnz; ++i)
@@ -154,11 +160,11 @@ void fill_wsell_host(const SellPlan &plan, const uint32_t *col, const float *val
                     } else if (!have && e == 0) {
                         v = neg_inf;  // a lane without a row: its sum is -inf
                         qv = 1;       // (byte values: the PAD_ONE slot holds -inf)
-                        cw = (uint16_t)(SELL_PAD_ONE << 2);
+                        cw = (uint16_t)(out.pad_one << 2);
                     } else {
                         v = 0.0f;  // (+0.0) * (-0.0) = -0.0: leaves every sum as it is
                         qv = 0;
-                        cw = (uint16_t)(SELL_PAD_NEUTRAL << 2);
+                        cw = (uint16_t)(out.pad_neutral << 2);
                     }
                     if (c + 1 == nc) {  // flags of the slice's last chunk
                         if (j == 0) cw |= SELL_LAST_CHUNK;
@@ -166,7 +172,8 @@ void fill_wsell_host(const SellPlan &plan, const uint32_t *col, const float *val
                     }
                     if (vb == 4u) std::memcpy(pkt + ((size_t)l * 4 + j) * 4, &v, 4);
                     else pkt[(size_t)l * 4 + j] = qv;
-                    std::memcpy(pkt + 256u * vb + ((size_t)l * 4 + j) * 2, &cw, 2);
+                    if (out.cw_bits == 12) colw12_store(pkt + 256u * vb, l * 4 + j, cw);
+                    else std::memcpy(pkt + 256u * vb + ((size_t)l * 4 + j) * 2, &cw, 2);
                 }
             }
         }
@@ -182,6 +189,11 @@ std::string pack_wsell(uint32_t rows, uint32_t cols, uint64_t nnz, const uint32_
     return "";
 }
 
+bool sell_c12_wanted() {
+    const char *f = getenv("TKSPMV_SELL_C12");
+    return !f || atoi(f) != 0;
+}
+
 void decode_wsell(const SellMatrix &sm, std::vector<uint32_t> &row, std::vector<uint32_t> &col, std::vector<float> &val) {
     row.clear();
     col.clear();
@@ -193,18 +205,21 @@ void decode_wsell(const SellMatrix &sm, std::vector<uint32_t> &row, std::vector<
         const uint32_t c_end = c0 + sm.part_count[p];
         while (c0 < c_end) {
             uint32_t nc = 1;  // chunks of this slice: up to the one flagged as last
-            for (;; ++nc) {
+            auto cw_at = [&](const uint8_t *pkt, uint32_t t) -> uint16_t {  // column word of entry t (lane * 4 + j) of a chunk
+                if (sm.cw_bits == 12) return colw12_load(pkt + CW0, t);
                 uint16_t cw;
-                std::memcpy(&cw, sm.packets.data() + (size_t)(c0 + nc - 1) * PB + CW0, 2);
-                if (cw & SELL_LAST_CHUNK) break;
+                std::memcpy(&cw, pkt + CW0 + (size_t)t * 2, 2);
+                return cw;
+            };
+            for (;; ++nc) {
+                if (cw_at(sm.packets.data() + (size_t)(c0 + nc - 1) * PB, 0) & SELL_LAST_CHUNK) break;
             }
             // segment index of every lane (flags of the last chunk); a lane with segment index d > 0 continues the row of
             // the lane to its left, the row id sits on the row's last lane
             uint32_t depth[64], owner[64];
             const uint8_t *last = sm.packets.data() + (size_t)(c0 + nc - 1) * PB;
             for (uint32_t l = 0; l < 64; ++l) {
-                uint16_t w[4];
-                std::memcpy(w, last + CW0 + (size_t)l * 8, 8);
+                const uint16_t w[4] = {cw_at(last, l * 4), cw_at(last, l * 4 + 1), cw_at(last, l * 4 + 2), cw_at(last, l * 4 + 3)};
                 depth[l] = (w[1] & 3u) | ((w[2] & 3u) << 2) | ((w[3] & 3u) << 4);
             }
             for (int l = 63; l >= 0; --l) {
@@ -217,13 +232,12 @@ void decode_wsell(const SellMatrix &sm, std::vector<uint32_t> &row, std::vector<
                 for (uint32_t c = 0; c < nc; ++c) {
                     const uint8_t *pkt = sm.packets.data() + (size_t)(c0 + c) * PB;
                     for (uint32_t j = 0; j < 4; ++j) {
-                        uint16_t cw;
+                        const uint16_t cw = cw_at(pkt, l * 4 + j);
                         float v;
-                        std::memcpy(&cw, pkt + CW0 + ((size_t)l * 4 + j) * 2, 2);
                         if (vb == 4u) std::memcpy(&v, pkt + ((size_t)l * 4 + j) * 4, 4);
                         else v = from_q1_7(pkt[(size_t)l * 4 + j]);
                         const uint32_t cc = cw >> 2;
-                        if (cc >= SELL_XCOLS) continue;  // padding
+                        if (cc >= sm.pad_neutral) continue;  // padding
                         row.push_back(r);
                         col.push_back(cc);
                         val.push_back(v);

@@ -56,12 +56,21 @@ inline uint32_t sell_segment_length(uint32_t len) {
 // a lane without a row starts with (byte 1, column PAD_ONE) where that slot holds -inf instead of (value -inf, slot 1.0f).
 enum class SellValues : uint32_t { F32 = 4, Q1_7_RND = 1 };  // = bytes per value
 
+// Column words of 12 bits (round 2, byte chunks only -- BASELINE configs[4]): with at most 1022 columns a column word
+// (10 bits of column or padding slot, 2 flags) needs 12 bits: the two padding slots move to columns 1022 and 1023, the 256
+// words of a chunk lie back to back (entry t at bit 12 t, as in wbscsr.hpp's F32C12) and a byte chunk is 256 + 384 = 640
+// bytes instead of 768: 2.5 bytes per entry. TKSPMV_SELL_C12=0 keeps 16-bit words.
+constexpr uint32_t SELL_C12_MAX_COLS = 1022;
+bool sell_c12_wanted();  // (the environment switch)
+
 struct SellMatrix {
     uint32_t rows = 0, cols = 0;
     uint64_t nnz = 0;
     uint32_t n_slices = 0, n_chunks = 0;
     SellValues values = SellValues::F32;
-    uint32_t packet_bytes = 1536;           // 256 * (bytes per value + 2)
+    uint32_t cw_bits = 16;                   // bits per column word: 16, or 12 (byte chunks of at most 1022 columns)
+    uint32_t pad_neutral = SELL_PAD_NEUTRAL, pad_one = SELL_PAD_ONE;  // padding slots (1022 / 1023 with 12-bit words)
+    uint32_t packet_bytes = 1536;           // 256 * bytes per value + 256 * cw_bits / 8
     uint64_t padded_entries = 0;            // n_chunks * 256
     std::vector<uint8_t> packets;           // n_chunks * packet_bytes
     std::vector<uint32_t> slice_rows;       // [n_slices][64], stream order

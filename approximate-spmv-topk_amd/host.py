@@ -123,7 +123,7 @@ class Options:
                        bool(o.use_half_precision_gpu), o.block_size_1d, o.block_size_2d, o.num_blocks)
 
 
-def sell_roundtrip(m, n_wave_partitions=4088):
+def sell_roundtrip(m, n_wave_partitions=4088, precision=_lib.F32):
     """Packs m into the wave-sliced ELL layout of the multi-query kernel and decodes it again (layout tests):
     (row, col, val, info) with the entries grouped by row, rows in stream order; info = dict of the layout's sizes."""
     row = np.ascontiguousarray(m.row, dtype=np.uint32)
@@ -131,6 +131,7 @@ def sell_roundtrip(m, n_wave_partitions=4088):
     val = np.ascontiguousarray(m.val, dtype=np.float32)
     d = _lib.Desc()
     d.rows, d.cols, d.nnz = m.rows, m.cols, row.shape[0]
+    d.precision = int(precision)  # Q1_7_F32: byte chunks (Q1.7 rounded to nearest; decoded values are the rounded ones)
     d.row = row.ctypes.data_as(C.POINTER(C.c_uint32))
     d.col = col.ctypes.data_as(C.POINTER(C.c_uint32))
     d.val = val.ctypes.data_as(C.POINTER(C.c_float))

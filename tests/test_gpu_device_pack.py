@@ -115,7 +115,8 @@ def test_full_size_identical_and_engine_uses_the_device_packer(pkg, oracle, monk
 def test_sell_layout_packs_identically(pkg, precision, rows, cols, nnz, dist, seed, hint):
     m = pkg.generate_matrix(rows, cols, nnz, dist, seed)
     r = pkg.sell_pack_device_check(m, hint, precision=getattr(pkg, precision))
-    assert r["identical"] and r["chunks"] > 0 and r["stream_bytes"] == r["chunks"] * (1536 if precision == "F32" else 768)
+    # (byte chunks of at most 1022 columns carry 12-bit column words: 640 bytes instead of 768)
+    assert r["identical"] and r["chunks"] > 0 and r["stream_bytes"] == r["chunks"] * (1536 if precision == "F32" else (640 if cols <= 1022 else 768))
 
 
 @pytest.mark.parametrize("precision", ["F32", "Q1_7_F32"])

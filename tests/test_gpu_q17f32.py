@@ -100,7 +100,8 @@ def test_row_per_lane_passes_are_bit_identical_to_the_gold_order(pkg, oracle, mq
     xs[2] *= np.float32(0.01)
     dxs = torch.from_numpy(xs).cuda()
     eng = pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, k=k, device=0, stream_replicas=2, multi_q=mq, precision=pkg.Q1_7_F32)
-    assert eng.info()["multi_q"] == mq and 3.0 * m.nnz < eng.info()["multi_bytes"] < 3.6 * m.nnz + 8 * rows
+    # (512 columns: byte values with 12-bit column words, 2.5 bytes per padded entry)
+    assert eng.info()["multi_q"] == mq and 2.5 * m.nnz < eng.info()["multi_bytes"] < 3.0 * m.nnz + 8 * rows
     want = []
     for q in range(nq):
         y, present = oracle.scores_f32_segmented(m.row, m.col, vq, xs[q], m.rows)

@@ -311,6 +311,24 @@ def test_sliced_ell_round_trip(pkg, rows, cols, nnz, dist, parts):
         assert info["most_chunks_per_partition"] <= info["chunks"] / info["partitions"] + 16  # within one slice of the mean
 
 
+@pytest.mark.parametrize("cols,chunk_bytes", [(512, 640), (1022, 640), (1023, 768), (1024, 768)])
+def test_sliced_ell_byte_chunks_and_12_bit_column_words(pkg, oracle, monkeypatch, cols, chunk_bytes):
+    """Byte chunks (TKSPMV_Q1_7_F32: Q1.7 values rounded to nearest): with at most 1022 columns the column words take 12 bits
+    (640-byte chunks, padding slots at columns 1022 / 1023), else 16 (768 bytes); TKSPMV_SELL_C12=0 keeps 16 bits. Either way
+    decode(pack(A)) returns every entry with its rounded value."""
+    m = pkg.generate_matrix(6000, cols, 30, "gamma", 8)
+    want = oracle.round_to_q17(m.val)
+    for env, nbytes in ((None, chunk_bytes), ("0", 768)):
+        if env is not None:
+            monkeypatch.setenv("TKSPMV_SELL_C12", env)
+        r, c, v, info = pkg.sell_roundtrip(m, 64, precision=pkg.Q1_7_F32)
+        monkeypatch.delenv("TKSPMV_SELL_C12", raising=False)
+        assert info["stream_bytes"] == info["chunks"] * nbytes
+        order = np.argsort(r, kind="stable")
+        assert np.array_equal(r[order], m.row) and np.array_equal(c[order], m.col)
+        assert np.array_equal(v[order].view(np.uint32), want.view(np.uint32))
+
+
 def test_sliced_ell_edge_cases(pkg):
     """Empty rows vanish (they can never be candidates), a single row, a row longer than any chunk, one column."""
     rng = np.random.RandomState(1)
