@@ -31,8 +31,11 @@ namespace {
 constexpr uint32_t SCAN_BLOCK = 256, SCAN_ITEMS = 4, SCAN_TILE = SCAN_BLOCK * SCAN_ITEMS;
 
 // flags[0]: 1 = rows not sorted, 2 = row id out of range, 4 = column id out of range
+// len[] has n_rows = row[nnz - 1] + 1 entries: a row id beyond it can only occur in an unsorted COO (it exceeds the last
+// entry's row) and must not be counted -- the atomic would land outside the allocation.
 __global__ void __launch_bounds__(256) count_kernel(const uint32_t *__restrict__ row, const uint32_t *__restrict__ col, uint64_t nnz,
-                                                    uint32_t rows, uint32_t cols, uint32_t *__restrict__ len, uint32_t *__restrict__ flags) {
+                                                    uint32_t rows, uint32_t n_rows, uint32_t cols, uint32_t *__restrict__ len,
+                                                    uint32_t *__restrict__ flags) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     uint32_t bad = 0u;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += stride) {
@@ -43,6 +46,10 @@ __global__ void __launch_bounds__(256) count_kernel(const uint32_t *__restrict__
             continue;
         }
         if (col[i] >= cols) bad |= 4u;
+        if (r >= n_rows) {
+            bad |= 1u;
+            continue;
+        }
         atomicAdd(&len[r], 1u);
     }
     if (bad) atomicOr(flags, bad);
@@ -390,8 +397,8 @@ std::string pack_wbscsr_device(uint32_t rows, uint32_t cols, uint64_t nnz, const
     DP_TRY(hipMalloc(&d_flags.p, 64));
     DP_TRY(hipMemset(d_flags.p, 0, 64));
     const uint32_t grid_nnz = (uint32_t)std::min<uint64_t>((nnz + 255) / 256, 8192);
-    hipLaunchKernelGGL(count_kernel, dim3(grid_nnz), dim3(256), 0, 0, d_row.as<uint32_t>(), d_col.as<uint32_t>(), nnz, rows, cols,
-                       d_len.as<uint32_t>(), d_flags.as<uint32_t>());
+    hipLaunchKernelGGL(count_kernel, dim3(grid_nnz), dim3(256), 0, 0, d_row.as<uint32_t>(), d_col.as<uint32_t>(), nnz, rows, n_rows,
+                       cols, d_len.as<uint32_t>(), d_flags.as<uint32_t>());
     uint32_t flags = 0;
     DP_TRY(hipMemcpy(&flags, d_flags.p, 4, hipMemcpyDeviceToHost));
     if (flags & 1u) {

@@ -580,7 +580,15 @@ struct EngineImpl {
         if (!x_on_host_only) return hipSuccess;
         x_on_host_only = false;
         x_pending = true;
-        return hipMemcpyAsync(d_x, h_x, (size_t)desc.cols * 4, hipMemcpyHostToDevice, stream);
+        const hipError_t e = hipMemcpyAsync(d_x, h_x, (size_t)desc.cols * 4, hipMemcpyHostToDevice, stream);
+        return e != hipSuccess ? e : hipEventRecord(ev2, stream);
+    }
+    // tkspmv_set_query enqueues the upload of x on the engine's stream and does not wait for it. A launch that reads d_x from
+    // ANOTHER stream (tkspmv_enqueue with a caller's stream and dev_x = NULL) has no ordering against that copy -- the
+    // engine's stream is non-blocking -- so it waits for the event recorded behind the copy.
+    hipError_t order_x(const float *x, hipStream_t s) const {
+        if (x != d_x || !x_pending || s == stream) return hipSuccess;
+        return hipStreamWaitEvent(s, ev2, 0);
     }
     // Every entry point other than set_query / run / read: the resident kernel must have left (it shares the exchange
     // state and would compete for the whole GPU), and x must be where the launch schemes expect it.
@@ -1159,8 +1167,10 @@ int Engine::set_query(const float *host_x, double *elapsed_ns, std::string &err)
         // resident engines: the kernel fetches x from the pinned copy itself; the upload happens only if another entry
         // point needs x in device memory (ensure_x)
         m.x_on_host_only = m.resident_capable;
-        if (!m.host_x_direct && !m.x_on_host_only)
+        if (!m.host_x_direct && !m.x_on_host_only) {
             HIP_TRY(hipMemcpyAsync(m.d_x, m.h_x, (size_t)m.desc.cols * 4, hipMemcpyHostToDevice, m.stream));
+            HIP_TRY(hipEventRecord(m.ev2, m.stream));  // a launch on another stream waits for this upload (order_x)
+        }
         m.x_pending = !m.x_on_host_only;
         m.d_x_cur = m.host_x_direct ? m.h_x_dev : m.d_x;
         m.have_query = true;
@@ -1201,6 +1211,7 @@ int Engine::enqueue(const float *dev_x, uint32_t *dev_idx, float *dev_val, void 
     hipStream_t s = stream ? (hipStream_t)stream : m.stream;
     HIP_TRY(hipSetDevice(m.device));
     HIP_TRY(m.leave_resident_mode());
+    HIP_TRY(m.order_x(x, s));
     m.launch_query(x, dev_idx ? dev_idx : m.d_out_idx, dev_val ? dev_val : m.d_out_val, s);
     HIP_TRY(hipGetLastError());
     m.ran = true;
@@ -1624,9 +1635,14 @@ int Engine::time_stream_read(int32_t passes, double *ns_per_pass, std::string &e
     R.n_parts = (uint32_t)m.pm.part_first.size();
     R.n_pass = (uint32_t)passes;
     if (const char *f = getenv("TKSPMV_READ_PROBE_MAP")) R.map = (uint32_t)atoi(f);
-    uint32_t *sink = nullptr;
-    HIP_TRY(hipMalloc((void **)&sink, (size_t)m.grid * 16 * 4));
-    R.sink = sink;
+    struct SinkGuard {  // freed on every return path
+        uint32_t *p = nullptr;
+        ~SinkGuard() {
+            if (p) (void)hipFree(p);
+        }
+    } sink;
+    HIP_TRY(hipMalloc((void **)&sink.p, (size_t)m.grid * 16 * 4));
+    R.sink = sink.p;
     void (*fn)(ReadProbeParams) = nullptr;
     switch (m.pm.packet_bytes / 64u) {
         case 22: fn = read_probe_kernel<22>; break;
@@ -1648,7 +1664,6 @@ int Engine::time_stream_read(int32_t passes, double *ns_per_pass, std::string &e
         }
     }
     if (!fn) {
-        (void)hipFree(sink);
         err = "no read probe for this packet size";
         return TKSPMV_ERR_UNSUPPORTED;
     }
@@ -1663,7 +1678,6 @@ int Engine::time_stream_read(int32_t passes, double *ns_per_pass, std::string &e
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, m.ev0, m.ev1));
     HIP_TRY(hipGetLastError());
-    (void)hipFree(sink);
     *ns_per_pass = (double)ms * 1e6 / passes;
     return TKSPMV_OK;
 }

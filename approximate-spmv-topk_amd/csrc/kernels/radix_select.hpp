@@ -127,9 +127,13 @@ __global__ void __launch_bounds__(RADIX_THREADS) radix_filter_kernel(const Radix
 // into SPMV_PARTITIONS ranges (p = row / ceil(N / P), host_spmv_bscsr.cpp:133-141), every core keeps only K candidates
 // (types.hpp:49) and the host merges the P x K of them (host_spmv_bscsr.cpp:399-448); a row of the true top-k that is
 // not among the K best of its partition is lost (topk_errors.py:29-42 models the loss). Engines created with
-// partitions = P and k > k_per_partition reproduce exactly that: the SpMV-only kernel writes every score, one workgroup
-// per partition selects the k_per_partition best rows of its range EXACTLY (score desc, row desc) and appends them to the
-// candidate list, and the ordinary selection kernel ranks the union.
+// partitions = P and k > k_per_partition run the STRICT form of that scheme -- the one topk_errors.py models: the SpMV-only
+// kernel writes every score, one workgroup per partition selects the k_per_partition best rows of its range exactly (score
+// desc, row desc) and appends them to the candidate list, and the ordinary selection kernel ranks the union. The HLS core
+// itself is looser: it keeps LIMITED_FINISHED_ROWS independent K-lists per partition (res_local[4][K],
+// spmv_bscsr_top_k_multicore.hpp:466) and its host merges K x packet-size entries per partition
+// (host_spmv_bscsr.cpp:410-417), so its candidate set is a superset of this one; oracle/hls_model.c restates that
+// dataflow and experiments.py reports both.
 // ------------------------------------------------------------------------------------------------------------
 struct PartitionParams {
     const float *scores;  // [rows]; -inf where a row has no entry

@@ -81,6 +81,30 @@ def test_errors_match_the_host_packer(pkg):
     assert e.value.status == pkg._lib.ERR_INVALID and "row id" in e.value.message
 
 
+def test_large_unsorted_coo_is_refused_without_touching_memory_beyond_the_row_table(pkg):
+    """A reversed COO of 200k rows: the row-length table is sized by the LAST entry's row (0 here), so every other row id
+    lies beyond it; the count kernel must flag the input as unsorted instead of counting into memory it does not own
+    (an engine created before and used after proves that neighbouring allocations are intact)."""
+    m = pkg.generate_matrix(20000, 1024, 20, "gamma", 5)
+    x = pkg.create_sample_vector(1024, True, False, True, 5)
+    eng = pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, vec=x, k=100, device=0)
+    eng()
+    before = eng.read_result()
+    big = pkg.generate_matrix(200000, 1024, 20, "gamma", 9)
+    bad = pkg.CooMatrix(big.rows, big.cols, big.row[::-1].copy(), big.col[::-1].copy(), big.val[::-1].copy())
+    for _ in range(3):
+        with pytest.raises(pkg.TkspmvError) as e:
+            pkg.Packed(bad, on_device=True)
+        assert e.value.status == pkg._lib.ERR_NOT_SORTED
+    with pytest.raises(pkg.TkspmvError) as e:  # tkspmv_create's default packer is this one
+        pkg.SpMV(bad.row, bad.col, bad.val, bad.rows, bad.cols, vec=x, k=100, device=0)
+    assert e.value.status == pkg._lib.ERR_NOT_SORTED
+    eng()
+    after = eng.read_result()
+    assert np.array_equal(before[1], after[1]) and np.array_equal(before[0].view(np.uint32), after[0].view(np.uint32))
+    eng.close()
+
+
 def test_full_size_identical_and_engine_uses_the_device_packer(pkg, oracle, monkeypatch):
     """BASELINE configs[1]'s matrix: identical bytes, the times of both packers, and an engine built either way returns
     the same bits."""
