@@ -276,11 +276,14 @@ __device__ __forceinline__ void place(const ScatterParams &P, uint32_t r, unsign
     }
     if ((Precision)P.precision == Precision::F32C12) {
         *reinterpret_cast<float *>(pkt + (size_t)slot * 4) = v;
-        // 12 bits at bit 12 t of the entry's plane: OR-ed into the zeroed stream (a word is shared by up to three entries)
-        const uint32_t t = slot & 255u, bit = t * 12u;
+        // split 12-bit plane (wbscsr.hpp colw12s_*): the entry's bits are OR-ed into the lane's dword A and halfword B of the
+        // zeroed stream (four entries share them; B through the aligned dword that holds it)
+        const uint32_t t = slot & 255u, lane = t >> 2;
         uint32_t *plane = reinterpret_cast<uint32_t *>(pkt + (size_t)P.PE * 4 + (size_t)(slot >> 8) * 384u);
-        atomicOr(&plane[bit >> 5], (uint32_t)cw << (bit & 31u));
-        if ((bit & 31u) > 20u) atomicOr(&plane[(bit >> 5) + 1u], (uint32_t)cw >> (32u - (bit & 31u)));
+        uint32_t a, b;
+        colw12s_bits(t & 3u, cw, a, b);
+        if (a) atomicOr(&plane[lane], a);
+        if (b) atomicOr(&plane[64u + (lane >> 1)], b << ((lane & 1u) * 16u));
         return;
     }
     switch ((Precision)P.precision) {

@@ -1779,12 +1779,14 @@ int Engine::profile(const float *dev_xs, int32_t n_x, int32_t iters, tkspmv_timi
     out->select_kernel_ns = t_select * 1e6 / iters;
     out->n_queries = (uint32_t)iters;
     if (m.collect_stats) {
-        unsigned long long sx[12];
+        unsigned long long sx[14];
         HIP_TRY(hipMemcpy(sx, m.d_stats, sizeof(sx), hipMemcpyDeviceToHost));
         const double nsel = (double)std::max<unsigned long long>(1, sx[1]);
         fprintf(stderr, "[tkspmv stats] selections %llu, general-path selections %llu, max candidates %llu, overflow entries per selection %.1f; "
                         "per selection: waves that waited for a threshold at the end of their partition %.1f (%.1f us in all)\n",
                 sx[1], sx[3], sx[2], (double)sx[8] / nsel, (double)sx[10] / nsel, (double)sx[9] / 100.0 / nsel);
+        fprintf(stderr, "[tkspmv stats] per selection: waves that redid their cold packets %.1f (%.1f packets in all)\n",
+                (double)sx[12] / nsel, (double)sx[11] / nsel);
     }
     if (m.collect_stamps) {
         unsigned long long st[16];

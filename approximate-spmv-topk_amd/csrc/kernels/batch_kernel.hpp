@@ -31,7 +31,7 @@ constexpr uint32_t STG_N = 8;  // survivors a wave can stage per query (64 lanes
 #define TKSPMV_TAU_WAIT 3000
 #endif
 constexpr unsigned long long BATCH_TAU_WAIT = TKSPMV_TAU_WAIT;  // x 10 ns (s_memrealtime runs at 100 MHz)
-constexpr int MISC_DBG_WAITS = 26, MISC_DBG_WAIT_TICKS = 27;  // TKSPMV_STATS=1 only
+constexpr int MISC_DBG_WAITS = 26, MISC_DBG_WAIT_TICKS = 27, MISC_DBG_REDO_PK = 28, MISC_DBG_REDO_WV = 29;  // TKSPMV_STATS=1 only
 constexpr int MISC_XREADY = 2, MISC_MINU = 3;  // batch kernel only: x staged for query (value - 1); min score in units
 
 // Per query only what differs from query to query travels in the kernel arguments (32 bytes); the exchange-state set of
@@ -92,19 +92,9 @@ struct BatchLds {
     uint32_t misc[2][MISC_WORDS];                        // per query parity
     unsigned long long stg[2][8][STG_N];                 // survivors staged by the streaming waves
     uint32_t stg_cnt[2][8];
-    // Deferred packets (threshold exchange cold start) wait here, not in registers: row sums and packed row flags per
-    // lane. No register cost, so more packets can be deferred (5 while x is small) and fewer rows are appended before
-    // the threshold has arrived.
 #ifndef TKSPMV_ALTERNATE_PRIO
 #define TKSPMV_ALTERNATE_PRIO 1
 #endif
-#ifndef TKSPMV_DEFER_B
-#define TKSPMV_DEFER_B 2
-#endif
-    static constexpr int DEFER_B = C == 8 ? 1 : (XCOLS <= 1024 ? TKSPMV_DEFER_B : 2);
-    float4 drs[8][DEFER_B][C / 4][64];
-    uint32_t dfl[8][DEFER_B][64];
-    uint32_t drb[8][DEFER_B];
 };
 
 __device__ __forceinline__ uint32_t lds_load(const uint32_t *p) {
@@ -414,6 +404,8 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
                         atomicAdd(&P0.dbg[1], (unsigned long long)mp[MISC_CAND_CNT]);
                         atomicAdd(&P0.dbg[5], (unsigned long long)mp[MISC_DBG_WAIT_TICKS]);
                         atomicAdd(&P0.dbg[6], (unsigned long long)mp[MISC_DBG_WAITS]);
+                        atomicAdd(&P0.dbg[7], (unsigned long long)mp[MISC_DBG_REDO_PK]);
+                        atomicAdd(&P0.dbg[8], (unsigned long long)mp[MISC_DBG_REDO_WV]);
                     }
                     // lane l copies entry (l % 8) of wave (l / 8): the first goes to the wave's slot, others to the
                     // query's overflow list
@@ -457,6 +449,19 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
     }
 
     // ---- streaming waves ---------------------------------------------------------------------------------------
+    // Cold start of a query (round 3). The threshold of a query arrives ~8 us after its first packets have been reduced --
+    // a third of a 19-packet partition -- and until then every finished row used to be appended to the wave's list (35 % of all
+    // packets took the candidate path, ~100 vector instructions each, and 295 k rows per query were appended and thrown
+    // away again). Now a wave that has no threshold yet only keeps, per lane, the largest trigger value it has seen (one
+    // v_max per packet: the lane's CHAMPION, an upper bound of every row it has finished in this query so far) and feeds the
+    // exchange with the exact maxima of its first EXACT_PK packets. Three packets before the end of its partition -- the
+    // next request will be the first one past it -- the wave compares its champions with the threshold as it then stands
+    // (waiting for one, bounded, if there is none yet): only if some champion reaches it (1-2 % of the waves) can a row of
+    // the cold packets belong to the result, and the wave REDOES those packets after its last one -- requested through the
+    // same prefetch ring, reduced again from a zero carry (a partition starts on a row boundary) and judged against the
+    // threshold like any other packet. Rows are never lost: a champion bounds every row its lane finished in the cold
+    // packets, so "no champion reaches tau" proves that none of those rows does. Nothing is stored per packet (the deferred
+    // packets' 26 KB of LDS are gone) and nothing is appended before a threshold exists.
     __builtin_amdgcn_s_setprio(TKSPMV_STREAM_PRIO);
     const uint32_t part = wave * n_wg + bid;
     uint32_t p0 = 0, np = 0;
@@ -466,185 +471,213 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
     }
     uint2 *wcand = L.u.w.cand + wave * WAVE_CAP;
     if (np == 0u) return;  // no partition (n_active does not count this wave)
+    static_assert(C == 4 || C == 8, "the batch kernel is built for 4 or 8 entries per lane");
+    constexpr bool INT = int_sums<QM>();
+    constexpr uint32_t EXACT_PK = 2u;  // packets per wave and query whose exact row maxima start the threshold exchange
+    // champions need a threshold that can form and a decision point inside the partition (shorter partitions -- the odd
+    // trailing one: the packer fills at least 4 packets -- put every row through the candidate path)
+#ifndef TKSPMV_CHAMPIONS
+#define TKSPMV_CHAMPIONS 0
+#endif
+    const bool champ_ok = TKSPMV_CHAMPIONS && P0.n_sets != 0u && P0.tau_possible != 0u && np >= 3u && !(DBG && (P0.dbg_flags & 64u));
 
     Pkt<C, VT> buf[NBUF];
     uint32_t rbs[NBUF];
-    // Next packet to request: a running pointer into the stream copy of its query, a running pointer into pkt_row, and two
-    // down-counters (requests left in the query, requests left in the launch): per request two pointer increments and a
-    // compare; no multiply, nothing re-read from the kernel arguments (measured with rocprofv3 --pmc: the kernel issued
-    // as many scalar as vector instructions, ~100 per packet, a third of them in this bookkeeping).
-    uint32_t qa = 0u;
+    // Requests run NBUF - 1 packets ahead of the reduction, through the segments of the launch in order: the np packets of
+    // query 0, its redo packets if the reduction side has asked for them by then (redo_len, set while packet np - 3 is being
+    // reduced: the request side has just asked for packet np - 1 and turns to the next segment with its NEXT request), query
+    // 1, ... Two running pointers and a down-counter per request; past the end of the launch the last packet is requested
+    // again (a fixed number of younger loads lets the compiler wait with a counted vmcnt).
+    auto stream_of = [&](uint32_t q) __attribute__((always_inline)) -> const uint8_t * {
+        return RESIDENT ? B.replicas[q % B.n_replicas] : B.io[q].packets;
+    };
     const size_t part_off = (size_t)p0 * P0.packet_bytes;
-    const uint8_t *pk_a = (RESIDENT ? B.replicas[0] : B.io[0].packets) + part_off;
+    const uint8_t *pk_a = stream_of(0u) + part_off;
     const uint32_t *row_a = P0.pkt_row + p0;
-    uint32_t left_q = np, left_all = RESIDENT ? 0xFFFFFFFFu : np * nq;
+    uint32_t qa = 0u, req_left = np, redo_len = 0u;
+    bool req_done = false;
 #define TKSPMV_REQUEST(dst, rb_dst)                                                                                   \
     do {                                                                                                              \
-        load_packet<C, VT>(pk_a, lane, dst);                                                                          \
-        rb_dst = *row_a;                                                                                              \
-        if (left_all > 1u) { /* past the end: the last packet is requested again (counted vmcnt) */                    \
-            --left_all;                                                                                               \
-            pk_a += P0.packet_bytes;                                                                                  \
-            ++row_a;                                                                                                  \
-            if (--left_q == 0u) {                                                                                     \
-                left_q = np;                                                                                          \
+        if (req_left == 0u && !req_done) { /* the previous request was the last of its segment */                      \
+            if (redo_len != 0u) {                                                                                     \
+                req_left = redo_len;                                                                                  \
+                redo_len = 0u;                                                                                        \
+            } else {                                                                                                  \
                 ++qa;                                                                                                 \
-                pk_a = (RESIDENT ? B.replicas[qa % B.n_replicas] : B.io[qa].packets) + part_off;                     \
+                if (!RESIDENT && qa == nq) req_done = true;                                                           \
+                else req_left = np;                                                                                   \
+            }                                                                                                         \
+            if (!req_done) {                                                                                          \
+                pk_a = stream_of(qa) + part_off;                                                                      \
                 row_a = P0.pkt_row + p0;                                                                              \
             }                                                                                                         \
+        }                                                                                                             \
+        load_packet<C, VT>(pk_a, lane, dst);                                                                          \
+        rb_dst = *row_a;                                                                                              \
+        if (!req_done && --req_left != 0u) {                                                                          \
+            pk_a += P0.packet_bytes;                                                                                  \
+            ++row_a;                                                                                                  \
         }                                                                                                             \
     } while (0)
 #pragma unroll
     for (int u = 0; u < NBUF - 1; ++u) TKSPMV_REQUEST(buf[u], rbs[u]);
     rbs[NBUF - 1] = 0u;
 
-    uint32_t qc = 0u, jc = 0u;  // packet being reduced
+    uint32_t qc = 0u, jc = 0u, seg_n = np;  // query / packet of the segment being reduced / its length
+    bool in_redo = false;                   // the segment is the redo of the query's cold packets
+    bool cold = false, decided = false;     // no threshold has been seen in this query yet / the redo decision has been taken
+    bool redo_owed = false;                 // ... and it was "redo": the query's segment is followed by its cold packets again
+    uint32_t ncold = 0u;                    // packets of this query reduced without a threshold
+    float champ = -__builtin_huge_valf();   // per lane: upper bound of the rows finished in those packets
     float carry = 0.0f, min_units = 0.0f;
     uint32_t wcnt = 0u;
-    bool waited = false;  // this wave has used its bounded wait for a threshold in the current query
-    const bool long_partition = np * (uint32_t)(C / 4) >= 28u;  // ~14 rows finish per 256 entries: > 1.5 lists per query
     uint32_t *mp = L.misc[0];
-    const float *xq = L.u.w.x[0];
+    uint32_t xbase = 0u;
     StreamParams P = P0;
-    constexpr uint32_t DEFER_B = (uint32_t)BatchLds<XCOLS, C>::DEFER_B;
-    static_assert(C == 4 || C == 8, "the batch kernel is built for 4 or 8 entries per lane");
 
-    const uint32_t total = RESIDENT ? 0xFFFFFFFFu : np * nq;
-    for (uint32_t i0 = 0; RESIDENT || i0 < total; i0 += NBUF) {  // (resident: left through the quit signal below)
+    for (;;) {
 #pragma unroll
         for (int u = 0; u < NBUF; ++u) {
-            if (!RESIDENT && i0 + (uint32_t)u >= total) break;
             const Pkt<C, VT> &cur = buf[u];
             const uint32_t rb_cur = rbs[u];
             TKSPMV_REQUEST(buf[(u + NBUF - 1) % NBUF], rbs[(u + NBUF - 1) % NBUF]);
-            if (jc == 0u) {  // a new query starts: its x must have been staged
-                mp = L.misc[qc & 1u];
-                xq = L.u.w.x[qc & 1u];
-                for (;;) {
-                    const uint32_t xr_ = lds_load(&mp[MISC_XREADY]);
-                    if (xr_ == qc + 1u) break;
-                    if (RESIDENT && xr_ == RESIDENT_QUIT) return;  // the kernel is leaving (host request or idle timeout)
-                    __builtin_amdgcn_s_sleep(2);
-                }
-                asm volatile("" ::: "memory");
-                min_units = __uint_as_float(lds_load(&mp[MISC_MINU]));
-                if (trw && lane == 0 && TRSLOT(qc) < 3u) trw[1 + TRSLOT(qc)] = __builtin_amdgcn_s_memrealtime();
-                P.ovf_cand = B.ovf_cand(set_of(qc));
-                P.ovf_count = B.ovf_count(set_of(qc));
-                carry = 0.0f;
-                wcnt = 0u;
-                waited = false;
+            if (jc == 0u) {
+                carry = 0.0f;  // (a partition starts on a row boundary; so does its redo)
+                if (!in_redo) {  // a new query starts: its x must have been staged
+                    mp = L.misc[qc & 1u];
+                    xbase = lds_addr_of(L.u.w.x[qc & 1u]);
+                    for (;;) {
+                        const uint32_t xr_ = lds_load(&mp[MISC_XREADY]);
+                        if (xr_ == qc + 1u) break;
+                        if (RESIDENT && xr_ == RESIDENT_QUIT) return;  // the kernel is leaving (host request or idle timeout)
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                    asm volatile("" ::: "memory");
+                    min_units = __uint_as_float(lds_load(&mp[MISC_MINU]));
+                    if (trw && lane == 0 && TRSLOT(qc) < 3u) trw[1 + TRSLOT(qc)] = __builtin_amdgcn_s_memrealtime();
+                    P.ovf_cand = B.ovf_cand(set_of(qc));
+                    P.ovf_count = B.ovf_count(set_of(qc));
+                    wcnt = 0u;
+                    cold = champ_ok;
+                    decided = false;
+                    redo_owed = false;
+                    ncold = 0u;
+                    champ = -__builtin_huge_valf();
 #if TKSPMV_ALTERNATE_PRIO
-                // The two workgroups of a CU do not share it evenly at equal priority: the older one wins the arbitration
-                // (traced over a 32-query launch: 17.2 against 21.5 us per query), runs ahead, finishes early and leaves
-                // the CU half empty while the launch waits for the slower half. They take turns instead, query by query:
-                // 18.7 against 19.8-20.3 us per query on one box (tools/ab_variants.sh; turns of 8, 12 or 32 packets: the same; of 2
-                // or 4: less). Partitions twice as long (2M rows, 512 x 40) neither gain nor lose.
-                if (((qc ^ (bid >= n_wg / 2u ? 1u : 0u)) & 1u) != 0u) __builtin_amdgcn_s_setprio(TKSPMV_STREAM_PRIO);
-                else __builtin_amdgcn_s_setprio(TKSPMV_STREAM_PRIO - 1);
+                    // The two workgroups of a CU do not share it evenly at equal priority: the older one wins the arbitration
+                    // (traced over a 32-query launch: 17.2 against 21.5 us per query), runs ahead, finishes early and leaves
+                    // the CU half empty while the launch waits for the slower half. They take turns instead, query by query:
+                    // 18.7 against 19.8-20.3 us per query on one box (tools/ab_variants.sh; turns of 8, 12 or 32 packets: the same; of 2
+                    // or 4: less). Partitions twice as long (2M rows, 512 x 40) neither gain nor lose.
+                    if (((qc ^ (bid >= n_wg / 2u ? 1u : 0u)) & 1u) != 0u) __builtin_amdgcn_s_setprio(TKSPMV_STREAM_PRIO);
+                    else __builtin_amdgcn_s_setprio(TKSPMV_STREAM_PRIO - 1);
 #endif
-            }
-            const float tau = __uint_as_float(lds_load(&mp[MISC_TAU]));
-            const RowSums<C> R = reduce_packet<C, QM>(cur, carry, xq, P0.fixed_mask);
-            if (jc < DEFER_B && P0.n_sets != 0u) {
-                uint32_t fl = 0u;
-#pragma unroll
-                for (int h = 0; h < C / 4; ++h) {
-                    L.drs[wave][jc][h][lane] = make_float4(R.rs[4 * h], R.rs[4 * h + 1], R.rs[4 * h + 2], R.rs[4 * h + 3]);
-                    fl |= ((R.cw[2 * h] & 0x00030003u) << (4 * h)) | ((R.cw[2 * h + 1] & 0x00030003u) << (4 * h + 2));
                 }
-                L.dfl[wave][jc][lane] = fl;
-                if (lane == 0) L.drb[wave][jc] = rb_cur;
-                const float wmax = wave_max(lane_best<C, QM>(R));
-                if (lane == 0 && publishes && wmax >= min_units)
-                    (void)__hip_atomic_fetch_max(&mp[MISC_GRPMAX + grp_local], order_key(wmax), __ATOMIC_RELAXED,
-                                                 __HIP_MEMORY_SCOPE_WORKGROUP);
-            } else if (__any(R.best_any >= tau) && !(P0.dbg_flags & 2u)) {
-                float tau_now = tau;
-                // Long partitions only (more rows per wave and query than its list holds: from ~1.5M rows on 256 CUs). A
-                // wave that runs ahead of its workgroup's exchange has no threshold yet: every row passes, and once the
-                // list is nearly full the rest would pour into the query's overflow list. It is ahead of the others anyway:
-                // it waits for the threshold instead, bounded, once per query (2M rows: 40.4 against 42.1 us per query, 3M:
-                // 58.5 against 60.7). On shorter partitions the list holds a whole query's rows and the wait only costs
-                // the overlap of consecutive queries (1M rows, bench.py's conditions: 3-10 % slower), hence the condition.
-                if (long_partition && wcnt + 2u * 64u > WAVE_CAP && tau <= min_units && P0.tau_possible && !waited) {
-                    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-                    while (lds_load(&mp[MISC_TAU]) == __float_as_uint(min_units) && __builtin_amdgcn_s_memrealtime() - t0 < BATCH_TAU_WAIT)
-                        __builtin_amdgcn_s_sleep(4);
-                    waited = true;
-                    tau_now = __uint_as_float(lds_load(&mp[MISC_TAU]));
-                }
-                if (tau_now == tau || __any(R.best_any >= tau_now))
-                    offer_candidates<C, QM, WAVE_CAP>(P, R, rb_cur, tau_now, lane, grp_local, publishes, wcand, wcnt, mp);
             }
-            if (jc + 1u == np) {  // the query ends for this wave
-                if (P0.n_sets != 0u) {
-                    // A workgroup that runs ahead of the others can get here before any threshold exists for this
-                    // query; judging now would keep (and dump to global memory) every row it has seen. Give the
-                    // exchange a moment -- bounded: after BATCH_TAU_WAIT the wave goes on without a threshold, so
-                    // progress never depends on other workgroups being resident.
-                    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-                    while (P0.tau_possible && lds_load(&mp[MISC_TAU]) == __float_as_uint(min_units) && !(P0.dbg_flags & 4u) &&
-                           __builtin_amdgcn_s_memrealtime() - t0 < BATCH_TAU_WAIT)
-                        __builtin_amdgcn_s_sleep(4);
-                    if (DBG && P0.dbg && lane == 0) {  // TKSPMV_STATS=1
-                        const unsigned long long dt = __builtin_amdgcn_s_memrealtime() - t0;
-                        if (dt > 50ull) {
-                            atomicAdd(&mp[MISC_DBG_WAIT_TICKS], (uint32_t)dt);
-                            atomicAdd(&mp[MISC_DBG_WAITS], 1u);
+            const uint32_t tau_bits = lds_load(&mp[MISC_TAU]);
+            const float tau = __uint_as_float(tau_bits);
+            const Reduced<C> Rd = reduce_packet<C, QM>(cur, carry, xbase, P0.fixed_mask);
+            const float trig = trigger_of<C, INT>(Rd);
+            if (cold && tau_bits != __float_as_uint(min_units)) cold = false;  // the threshold has arrived: this packet is judged
+            if (cold) {
+                champ = max2(champ, trig);
+                ++ncold;
+                if (jc < EXACT_PK) {  // exact maxima (scores of distinct rows) start the exchange
+                    const RowSums<C> R = expand<C, INT>(Rd, packet_flags<C, QM>(cur));
+                    const float wmax = wave_max(lane_best<C, QM>(R));
+                    if (lane == 0 && publishes && wmax >= min_units)
+                        (void)__hip_atomic_fetch_max(&mp[MISC_GRPMAX + grp_local], order_key(wmax), __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            } else if (__any(trig >= tau) && !(P0.dbg_flags & 2u)) {
+                const RowSums<C> R = expand<C, INT>(Rd, packet_flags<C, QM>(cur));
+                offer_candidates<C, QM, WAVE_CAP>(P, R, rb_cur, tau, lane, grp_local, publishes, wcand, wcnt, mp);
+            }
+            if (champ_ok && !decided && jc + 3u >= np) {  // (jc == np - 3 in the query's own segment: in a redo, decided is set)
+                decided = true;
+                if (ncold != 0u) {
+                    if (cold) {
+                        // No threshold yet (a short partition, or a workgroup running ahead of the others): give the exchange
+                        // a moment -- bounded, so that progress never depends on other workgroups being resident.
+                        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                        while (lds_load(&mp[MISC_TAU]) == __float_as_uint(min_units) && !(P0.dbg_flags & 4u) &&
+                               __builtin_amdgcn_s_memrealtime() - t0 < BATCH_TAU_WAIT)
+                            __builtin_amdgcn_s_sleep(4);
+                        if (DBG && P0.dbg && lane == 0) {  // TKSPMV_STATS=1
+                            const unsigned long long dt = __builtin_amdgcn_s_memrealtime() - t0;
+                            if (dt > 50ull) {
+                                atomicAdd(&mp[MISC_DBG_WAIT_TICKS], (uint32_t)dt);
+                                atomicAdd(&mp[MISC_DBG_WAITS], 1u);
+                            }
                         }
                     }
-                    const float tau2 = __uint_as_float(lds_load(&mp[MISC_TAU]));
-                    const uint32_t nd = np < DEFER_B ? np : DEFER_B;
-                    for (uint32_t d = 0; d < nd; ++d) {
-                        const uint32_t c = L.dfl[wave][d][lane];
-                        RowSums<C> S;
-#pragma unroll
-                        for (int h = 0; h < C / 4; ++h) {
-                            const float4 v = L.drs[wave][d][h][lane];
-                            S.rs[4 * h] = v.x;
-                            S.rs[4 * h + 1] = v.y;
-                            S.rs[4 * h + 2] = v.z;
-                            S.rs[4 * h + 3] = v.w;
-                            S.cw[2 * h] = (c >> (4 * h)) & 0x00030003u;
-                            S.cw[2 * h + 1] = (c >> (4 * h + 2)) & 0x00030003u;
+                    const uint32_t tb = lds_load(&mp[MISC_TAU]);
+                    // still none: the cold packets go through the candidate path in the redo (every row is kept, as it
+                    // must be); else only if a champion reaches the threshold
+                    if (tb == __float_as_uint(min_units) || __any(champ >= __uint_as_float(tb))) {
+                        redo_len = ncold;  // (consumed by the request side when it turns to the next segment)
+                        redo_owed = true;
+                        if (DBG && P0.dbg && lane == 0) {
+                            atomicAdd(&mp[MISC_DBG_REDO_PK], ncold);
+                            atomicAdd(&mp[MISC_DBG_REDO_WV], 1u);
                         }
-                        float best = -__builtin_huge_valf();
-#pragma unroll
-                        for (int j = 0; j < C; ++j) best = (S.end(j) && S.rs[j] > best) ? S.rs[j] : best;
-                        S.best_any = best;
-                        const uint32_t rb_d = __builtin_amdgcn_readfirstlane(L.drb[wave][d]);
-                        if (__any(best >= tau2))
-                            offer_candidates<C, QM, WAVE_CAP>(P, S, rb_d, tau2, lane, grp_local, publishes, wcand, wcnt, mp);
                     }
                 }
-                const float tau3 = __uint_as_float(lds_load(&mp[MISC_TAU]));
-                ListScan<WAVE_CAP / 64u> LS;
-                const uint32_t surv = scan_list<WAVE_CAP / 64u>(wcand, wcnt, tau3, lane, LS);
-                uint32_t gbase = 0u;
-                if (surv > STG_N) {  // rare: more survivors than the staging area holds go to global memory directly
-                    if (lane == 0) gbase = atomicAdd(P.ovf_count, surv - STG_N);
-                    gbase = __builtin_amdgcn_readfirstlane(gbase);
-                }
-#pragma unroll
-                for (uint32_t e = 0; e < WAVE_CAP / 64u; ++e) {
-                    if (LS.keep[e]) {
-                        const unsigned long long v = pack_cand(LS.e[e].x, LS.e[e].y);
-                        if (LS.pos[e] < STG_N) L.stg[qc & 1u][wave][LS.pos[e]] = v;
-                        else if (gbase + LS.pos[e] - STG_N < P0.ovf_cap) st_agent(&P.ovf_cand[gbase + LS.pos[e] - STG_N], v);
+                cold = false;  // from here on every packet is judged (without a threshold: every row is kept)
+            }
+            if (jc + 1u == seg_n) {
+                if (redo_owed) {
+                    redo_owed = false;
+                    in_redo = true;  // the request side has turned (or is about to turn) to the same packets
+                    seg_n = ncold;
+                    jc = 0u;
+                } else {  // the query ends for this wave
+                    if (!champ_ok && P0.n_sets != 0u && P0.tau_possible && wcnt != 0u) {
+                        // A wave that runs ahead of the others gets here before any threshold exists for this query; flushing
+                        // now would dump every row it has seen to global memory. Give the exchange a moment -- bounded: after
+                        // BATCH_TAU_WAIT the wave goes on without one, so progress never depends on other workgroups being
+                        // resident. (On a small matrix every wave is in that position: 100+ us per query without this wait.)
+                        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                        while (lds_load(&mp[MISC_TAU]) == __float_as_uint(min_units) && !(P0.dbg_flags & 4u) &&
+                               __builtin_amdgcn_s_memrealtime() - t0 < BATCH_TAU_WAIT)
+                            __builtin_amdgcn_s_sleep(4);
+                        if (DBG && P0.dbg && lane == 0) {  // TKSPMV_STATS=1
+                            const unsigned long long dt = __builtin_amdgcn_s_memrealtime() - t0;
+                            if (dt > 50ull) {
+                                atomicAdd(&mp[MISC_DBG_WAIT_TICKS], (uint32_t)dt);
+                                atomicAdd(&mp[MISC_DBG_WAITS], 1u);
+                            }
+                        }
                     }
+                    if (wcnt != 0u) {
+                        const float tau3 = __uint_as_float(lds_load(&mp[MISC_TAU]));
+                        ListScan<WAVE_CAP / 64u> LS;
+                        const uint32_t surv = scan_list<WAVE_CAP / 64u>(wcand, wcnt, tau3, lane, LS);
+                        uint32_t gbase = 0u;
+                        if (surv > STG_N) {  // rare: more survivors than the staging area holds go to global memory directly
+                            if (lane == 0) gbase = atomicAdd(P.ovf_count, surv - STG_N);
+                            gbase = __builtin_amdgcn_readfirstlane(gbase);
+                        }
+#pragma unroll
+                        for (uint32_t e = 0; e < WAVE_CAP / 64u; ++e) {
+                            if (LS.keep[e]) {
+                                const unsigned long long v = pack_cand(LS.e[e].x, LS.e[e].y);
+                                if (LS.pos[e] < STG_N) L.stg[qc & 1u][wave][LS.pos[e]] = v;
+                                else if (gbase + LS.pos[e] - STG_N < P0.ovf_cap) st_agent(&P.ovf_cand[gbase + LS.pos[e] - STG_N], v);
+                            }
+                        }
+                        if (surv > STG_N) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // those stores precede the ticket
+                        if (lane == 0) L.stg_cnt[qc & 1u][wave] = surv < STG_N ? surv : STG_N;
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (lane == 0) atomicAdd(&mp[MISC_DONE], 1u);
+                    if (trw && lane == 0 && TRSLOT(qc) < 3u) trw[4 + TRSLOT(qc)] = __builtin_amdgcn_s_memrealtime();
+                    ++qc;
+                    if (!RESIDENT && qc == nq) return;
+                    in_redo = false;
+                    seg_n = np;
+                    jc = 0u;
                 }
-                if (surv > STG_N) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // those stores precede the ticket
-                if (lane == 0) L.stg_cnt[qc & 1u][wave] = surv < STG_N ? surv : STG_N;
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (lane == 0) atomicAdd(&mp[MISC_DONE], 1u);
-                if (trw && lane == 0 && TRSLOT(qc) < 3u) {
-                    trw[4 + TRSLOT(qc)] = __builtin_amdgcn_s_memrealtime();
-                    trw[7] = (TRSLOT(qc) == 0u ? 0ull : trw[7]) | ((unsigned long long)(((surv > 0xFFu ? 0xFFu : surv) << 8) | 0xFFu) << (16u * TRSLOT(qc))) |
-                             ((unsigned long long)(tau3 <= min_units ? 1u : 0u) << (48u + TRSLOT(qc)));
-                }
-                ++qc;
-                jc = 0u;
             } else {
                 ++jc;
             }

@@ -80,7 +80,7 @@ typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));  // a
 // path (TKSPMV_Q1_7_F32, BASELINE configs[4]).
 // QM 6 = fixed point of at most 20 bits, bit-packed (wbscsr.hpp FIXED20): one dword per entry carrying value, column and
 // flags; the arithmetic is QM 4's with both factors as 20-bit integers.
-// QM 7 = fp32 exactly like QM 0, the column words travelling as 12 bits each (wbscsr.hpp F32C12): value type 4.
+// QM 7 = fp32 exactly like QM 0, the column words travelling as 12 bits each in a split plane (wbscsr.hpp F32C12): value type 4.
 constexpr int value_type_of(int QM) { return QM == 7 ? 4 : (QM == 6 ? 3 : (QM == 3 ? 2 : ((QM == 1 || QM == 2 || QM == 5) ? 1 : 0))); }  // QM 4: one u32 per value, loaded like fp32
 // Byte b (0..3) of a dword as a float: v_cvt_f32_ubyte0..3.
 template <int B>
@@ -103,7 +103,7 @@ template <int C, int VT>
 struct Pkt {
     float v[(VT == 0 || VT == 3 || VT == 4) ? C : 1];  // VT 3: the packed dwords (value | column | flags); cw stays unused
     uint32_t vq[(VT == 1 || VT == 5) ? C / 4 : (VT == 2 ? C / 2 : 1)];  // VT 5: byte values with 12-bit column words (row-per-lane chunks)
-    uint32_t cw[C / 2];  // VT 4: the two dwords that hold the lane's four 12-bit words (from bit 0, or bit 16 on odd lanes)
+    uint32_t cw[C / 2];  // VT 4: [0] = columns 0-2 (bits 2-11, 12-21, 22-31) + SKIP 0, 1 (bits 0, 1); [1] = column 3 (bits 2-11) + SKIP 2, 3 (bits 0, 1) + ROW_END 0-3 (bits 12-15)
 };
 
 template <int C, int VT>
@@ -122,10 +122,10 @@ __device__ __forceinline__ void load_packet(const uint8_t *__restrict__ pk, uint
             o.v[VT == 4 ? 4 * q + 1 : 0] = f.y;
             o.v[VT == 4 ? 4 * q + 2 : 0] = f.z;
             o.v[VT == 4 ? 4 * q + 3 : 0] = f.w;
-            // two lanes share three dwords: the even lane takes dwords 0-1, the odd one dwords 1-2 (4-byte aligned dwordx2)
-            const u32x2_a4 c = __builtin_nontemporal_load(reinterpret_cast<const u32x2_a4 *>(pk + C * 256 + q * 384 + (lane >> 1) * 12 + (lane & 1u) * 4));
-            o.cw[2 * q + 0] = c.x;
-            o.cw[2 * q + 1] = c.y;
+            // split 12-bit plane (wbscsr.hpp colw12s_*): one dword per lane (columns 0-2 + two SKIP flags) and one halfword per
+            // lane (column 3, two SKIP flags, the four ROW_END flags): 256 + 128 contiguous bytes per wave instruction
+            o.cw[2 * q + 0] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(pk + C * 256 + q * 384 + lane * 4));
+            o.cw[2 * q + 1] = __builtin_nontemporal_load(reinterpret_cast<const uint16_t *>(pk + C * 256 + q * 384 + 256 + lane * 2));
         } else if (VT == 5) {
             o.vq[VT == 5 ? q : 0] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(pk + q * 256 + lane * 4));
             const u32x2_a4 c = __builtin_nontemporal_load(reinterpret_cast<const u32x2_a4 *>(pk + C * 64 + q * 384 + (lane >> 1) * 12 + (lane & 1u) * 4));

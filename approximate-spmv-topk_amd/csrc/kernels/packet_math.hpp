@@ -14,6 +14,11 @@ __device__ __forceinline__ float dpp_zero(float src) {
 constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114, DPP_ROW_SHR8 = 0x118;
 constexpr int DPP_WAVE_SHL1 = 0x130, DPP_WAVE_SHR1 = 0x138, DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143;
 
+__device__ __forceinline__ float max2(float a, float b) {  // one v_max_f32 (fmaxf puts a canonicalising v_max in front of each operand)
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 // Wave-wide maximum with DPP (result uniform, returned through an SGPR).
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_keep(float v) {  // lanes without a valid source keep their own value
@@ -21,12 +26,13 @@ __device__ __forceinline__ float dpp_keep(float v) {  // lanes without a valid s
                                                                  CTRL, ROW_MASK, 0xF, false));
 }
 __device__ __forceinline__ float wave_max(float v) {
-    v = fmaxf(v, dpp_keep<DPP_ROW_SHR1, 0xF>(v));
-    v = fmaxf(v, dpp_keep<DPP_ROW_SHR2, 0xF>(v));
-    v = fmaxf(v, dpp_keep<DPP_ROW_SHR4, 0xF>(v));
-    v = fmaxf(v, dpp_keep<DPP_ROW_SHR8, 0xF>(v));
-    v = fmaxf(v, dpp_keep<DPP_ROW_BCAST15, 0xA>(v));
-    v = fmaxf(v, dpp_keep<DPP_ROW_BCAST31, 0xC>(v));
+    v = fmaxf(v, v);  // (one canonicalisation; the steps below are plain v_max)
+    v = max2(v, dpp_keep<DPP_ROW_SHR1, 0xF>(v));
+    v = max2(v, dpp_keep<DPP_ROW_SHR2, 0xF>(v));
+    v = max2(v, dpp_keep<DPP_ROW_SHR4, 0xF>(v));
+    v = max2(v, dpp_keep<DPP_ROW_SHR8, 0xF>(v));
+    v = max2(v, dpp_keep<DPP_ROW_BCAST15, 0xA>(v));
+    v = max2(v, dpp_keep<DPP_ROW_BCAST31, 0xC>(v));
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
@@ -114,67 +120,85 @@ __device__ __forceinline__ float max3(float a, float b, float c) {
     return r;
 }
 
-// Finished-row sums of one packet as seen by one lane. The flags stay where they are, in the packet's column
-// words: entry j -> word j/2, bits 16*(j&1) (ROW_END) and 16*(j&1)+1 (SKIP).
+// LDS reads at an integer byte address (address space 3): the gathers of x[col] compute their addresses with integer
+// instructions (field extraction fused with the base of the x copy in use), so the pointer is an integer.
+typedef __attribute__((address_space(3))) const float lds_cfloat;
+typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
+__device__ __forceinline__ float lds_f32(uint32_t byte_addr) { return *reinterpret_cast<lds_cfloat *>((uintptr_t)byte_addr); }
+__device__ __forceinline__ uint32_t lds_u32(uint32_t byte_addr) { return *reinterpret_cast<lds_cu32 *>((uintptr_t)byte_addr); }
+__device__ __forceinline__ uint32_t lds_addr_of(const void *p) {  // LDS byte address of a pointer into a __shared__ object
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)p;
+}
+// (w & mask) | base in one instruction; mask lives in a VGPR (VOP3 takes no literal on gfx9 and only one scalar operand)
+__device__ __forceinline__ uint32_t and_or(uint32_t w, uint32_t mask_vgpr, uint32_t base_sgpr) {
+    uint32_t r;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(w), "v"(mask_vgpr), "s"(base_sgpr));
+    return r;
+}
+
+// Finished-row sums of one packet as seen by one lane, in full: what the candidate path, the SpMV-only variant and the
+// per-partition lists need. fl: bit j = ROW_END of the lane's entry j, bit 8 + j = its SKIP flag (placeholder of an empty row).
 template <int C>
 struct RowSums {
     float rs[C];
-    uint32_t cw[C / 2];
-    float best_any;  // max over the lane's row ends, placeholders included: only the hot-path trigger uses it
-    __device__ __forceinline__ bool end(int j) const { return (cw[j >> 1] >> (16 * (j & 1))) & 1u; }
-    __device__ __forceinline__ bool valid(int j) const { return ((cw[j >> 1] >> (16 * (j & 1))) & 3u) == 1u; }
+    uint32_t fl;
+    float best_any;  // max over the lane's row ends, placeholders included
+    __device__ __forceinline__ bool end(int j) const { return (fl >> j) & 1u; }
+    __device__ __forceinline__ bool valid(int j) const { return ((fl >> j) & 0x101u) == 1u; }
 };
 
-// Products, in-lane segmented sums, cross-lane segmented scan. Updates the packet carry.
+// What the reduction leaves behind on the hot path: nothing is selected or compared per entry until some lane's trigger
+// reaches the threshold (expand() then produces the RowSums).
+//   s[j] : in-lane running sum of entry j's row segment (restarted behind every row end inside the lane; lane 0's entry 0
+//          includes the carry of the previous packet)
+//   S    : the row sum at the lane's FIRST row end = inclusive scan value of the lane below + the lane's head
+//   m[j] : all ones where entry j ends a row
+// Every finished row of the lane has its sum in {S, s[1], ..., s[C-1]} (the first row end yields S, later ones their own
+// s[j]); the other members of that set are partial sums of rows still running.
+template <int C>
+struct Reduced {
+    float s[C];
+    float S;
+    uint32_t m[C];
+};
+
+// Products are in p; in-lane segmented sums, cross-lane segmented scan; updates the packet carry.
 // Arithmetic (mirrored statement for statement by oracle_packed_scores in oracle/oracle.c):
-//   p_j = v_j * x[col_j];  p_0 += carry on lane 0;  s_0 = p_0,  s_j = (end_{j-1} ? +0 : s_{j-1}) + p_j
+//   p_0 += carry on lane 0;  s_0 = p_0,  s_j = (end_{j-1} ? +0 : s_{j-1}) + p_j
 //   tail = end_{C-1} ? +0 : s_{C-1};   head = s at the lane's first row end
 //   vv = clipped Kogge-Stone scan of tail over the 64 lanes (never across a lane that holds a row end)
 //   row sum at the lane's first row end = vv[lane-1] + head, at its later row ends = s_j; carry' = vv[63]
-// The reduction proper, from the C products of a lane (p) and its column words (cwv).
 // INT: the C "floats" (and the carry) hold u32 fixed-point words; every sum is an integer add (wrapping at 2^32 = 2.0 in
-// Q1.31: the reference's real_type sums wrap the same way), lane movement and masking are bitwise either way. At the end
-// the row sums are converted to fp32 (round to nearest even, what C's (float)u32 does) so that thresholds, candidate
-// lists and the selection see ordinary floats: "score units" of 2^-31.
+// Q1.31: the reference's real_type sums wrap the same way), lane movement and masking are bitwise either way.
 template <bool INT>
 __device__ __forceinline__ float add_rn(float a, float b) {
     if (INT) return __uint_as_float(__float_as_uint(a) + __float_as_uint(b));
     return __fadd_rn(a, b);
 }
 template <int C, bool INT = false>
-__device__ __forceinline__ RowSums<C> reduce_core(float (&p)[C], const uint32_t (&cwv)[C / 2], float &carry) {
-    uint32_t m[C];  // all-ones where entry j ends a row
-#pragma unroll
-    for (int j = 0; j < C; ++j) m[j] = (j & 1) ? bit_mask<16>(cwv[j >> 1]) : bit_mask<0>(cwv[j >> 1]);
+__device__ __forceinline__ Reduced<C> reduce_core(float (&p)[C], const uint32_t (&m)[C], const bool has_end, float &carry) {
+    Reduced<C> R;
     p[0] = __builtin_amdgcn_inverse_ballot_w64(1ull) ? add_rn<INT>(p[0], carry) : p[0];  // lane 0 only
-
-    float s[C];
-    uint32_t o[C];  // o_j = m_0 | ... | m_j
-    s[0] = p[0];
-    o[0] = m[0];
+    R.s[0] = p[0];
 #pragma unroll
-    for (int j = 1; j < C; ++j) {
-        s[j] = add_rn<INT>(mask_clear(m[j - 1], s[j - 1]), p[j]);
-        o[j] = o[j - 1] | m[j];
-    }
-    float head = s[C - 1];
+    for (int j = 1; j < C; ++j) R.s[j] = add_rn<INT>(mask_clear(m[j - 1], R.s[j - 1]), p[j]);
+    float head = R.s[C - 1];
 #pragma unroll
-    for (int j = C - 2; j >= 0; --j) head = mask_select(m[j], s[j], head);
+    for (int j = C - 2; j >= 0; --j) head = mask_select(m[j], R.s[j], head);
     float tail;
     // (the DPP instruction that reads `tail` next needs two wait states after a VALU write; the compiler does
     //  not look inside asm, hence the explicit s_nop)
-    asm("v_bfi_b32 %0, %1, 0, %2\n\ts_nop 1" : "=v"(tail) : "v"(m[C - 1]), "v"(s[C - 1]));
+    asm("v_bfi_b32 %0, %1, 0, %2\n\ts_nop 1" : "=v"(tail) : "v"(m[C - 1]), "v"(R.s[C - 1]));
 
     // Lane masks of the clipped scan, computed once on the scalar unit from H = lanes holding a row end:
     //   M_d  : no row end in lanes (l-d, l]                     (steps row_shr:1,2,4,8)
     //   P16  : no row end in [first lane of l's 16-lane row, l]  (step row_bcast:15)
     //   P32  : no row end in [first lane of l's 32-lane half, l] (step row_bcast:31)
-    const uint64_t H = __ballot(o[C - 1] != 0u);
+    const uint64_t H = __ballot(has_end);
     const uint64_t M1 = ~H;
     // One doubling chain serves all steps: its links are clipped at the start of every 16-lane row (the constants fill the
     // bits shifted in there), which is what P16 needs; for the row_shr steps the clipping is immaterial, because the
-    // lanes it concerns (lane % 16 < d) receive 0 from the DPP shift whatever their mask says. (A separate unclipped
-    // chain for M2, M4, M8 cost nine more scalar instructions per packet.)
+    // lanes it concerns (lane % 16 < d) receive 0 from the DPP shift whatever their mask says.
     const uint64_t M2 = M1 & ((M1 << 1) | 0x0001000100010001ull);
     const uint64_t M4 = M2 & ((M2 << 2) | 0x0003000300030003ull);
     const uint64_t M8 = M4 & ((M4 << 4) | 0x000F000F000F000Full);
@@ -194,107 +218,160 @@ __device__ __forceinline__ RowSums<C> reduce_core(float (&p)[C], const uint32_t 
         vv = __builtin_amdgcn_inverse_ballot_w64(M4) ? t : vv;
         t = add_rn<INT>(vv, dpp_zero<DPP_ROW_SHR8, 0xF>(vv));
         vv = __builtin_amdgcn_inverse_ballot_w64(M8) ? t : vv;
-        t = add_rn<INT>(vv, dpp_zero<DPP_ROW_BCAST15, 0xA>(vv));  // lane 15 -> row 1, lane 47 -> row 3
-        vv = __builtin_amdgcn_inverse_ballot_w64(P16) ? t : vv;
-        t = add_rn<INT>(vv, dpp_zero<DPP_ROW_BCAST31, 0xC>(vv));  // lane 31 -> rows 2 and 3
-        vv = __builtin_amdgcn_inverse_ballot_w64(P32) ? t : vv;
+        // The two broadcast steps write only the rows that have a source (row_mask); the add is fused into the DPP instruction
+        // (the compiler's own form moves a zero, moves the lane, then adds: two more instructions per step) and the lanes of the
+        // other rows keep a stale t that the step's mask, cleared for those rows, never selects. (s_nop 1: a DPP read of a
+        // register written by the previous vector instruction needs two wait states; the compiler does not look inside asm.)
+        if (INT) asm("s_nop 1\n\tv_add_u32_dpp %0, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(t) : "v"(vv));
+        else asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(t) : "v"(vv));  // lane 15 -> row 1, lane 47 -> row 3
+        vv = __builtin_amdgcn_inverse_ballot_w64(P16 & 0xFFFF0000FFFF0000ull) ? t : vv;
+        if (INT) asm("s_nop 1\n\tv_add_u32_dpp %0, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(t) : "v"(vv));
+        else asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(t) : "v"(vv));  // lane 31 -> rows 2 and 3
+        vv = __builtin_amdgcn_inverse_ballot_w64(P32 & 0xFFFFFFFF00000000ull) ? t : vv;
     }
     const float cin = dpp_zero<DPP_WAVE_SHR1, 0xF>(vv);  // lane l-1's inclusive sum; 0 for lane 0
-    const float S = add_rn<INT>(cin, head);
+    R.S = add_rn<INT>(cin, head);
     carry = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, vv), 63));
-
-    RowSums<C> out;
-    out.rs[0] = S;  // if entry 0 ends a row it is the lane's first row end
 #pragma unroll
-    for (int j = 1; j < C; ++j) out.rs[j] = mask_select(o[j - 1], s[j], S);  // an earlier end in the lane => s_j
+    for (int j = 0; j < C; ++j) R.m[j] = m[j];
+    return R;
+}
+
+// The hot-path trigger: an upper bound of every finished row's score in this lane, three instructions. It is the maximum of
+// the set {S, s[1], ..., s[C-1]}, which contains every finished row's sum; its other members are partial sums of rows that
+// are still running, so it may fire for a packet without a passing row (the candidate path then finds none) but can never
+// miss one. With non-negative products a partial sum reaches the threshold only if its row will.
+// INT: the words are converted to fp32 score units first (round to nearest even, what C's (float)u32 does), like the row
+// sums themselves.
+template <int C, bool INT>
+__device__ __forceinline__ float trigger_of(const Reduced<C> &R) {
+    float c[C];
+    c[0] = R.S;
+#pragma unroll
+    for (int j = 1; j < C; ++j) c[j] = R.s[j];
+    if (INT) {
+#pragma unroll
+        for (int j = 0; j < C; ++j) c[j] = (float)__float_as_uint(c[j]);
+    }
+    const float NEG_INF = -__builtin_huge_valf();
+    float best = max3(c[0], C > 1 ? c[1] : NEG_INF, C > 2 ? c[2] : NEG_INF);
+#pragma unroll
+    for (int j = 3; j < C; j += 2) best = max3(best, c[j], c[j + 1 < C ? j + 1 : j]);  // (v_max3: no canonicalising v_max in front)
+    return best;
+}
+
+// The full row sums of a packet (candidate path, SpMV-only variant, exact group maxima): fl as in RowSums.
+template <int C, bool INT>
+__device__ __forceinline__ RowSums<C> expand(const Reduced<C> &R, const uint32_t fl) {
+    RowSums<C> out;
+    out.rs[0] = R.S;  // if entry 0 ends a row it is the lane's first row end
+    uint32_t o = R.m[0];
+#pragma unroll
+    for (int j = 1; j < C; ++j) {
+        out.rs[j] = mask_select(o, R.s[j], R.S);  // an earlier end in the lane => s_j
+        o |= R.m[j];
+    }
     if (INT) {
 #pragma unroll
         for (int j = 0; j < C; ++j) out.rs[j] = (float)__float_as_uint(out.rs[j]);  // fixed-point word -> score units
     }
-#pragma unroll
-    for (int j = 0; j < C / 2; ++j) out.cw[j] = cwv[j];
+    out.fl = fl;
     const float NEG_INF = -__builtin_huge_valf();
-    float e[C];
+    float best = NEG_INF;
 #pragma unroll
-    for (int j = 0; j < C; ++j) e[j] = mask_select(m[j], out.rs[j], NEG_INF);
-    float best = max3(e[0], e[1], e[2]);
-#pragma unroll
-    for (int j = 3; j < C; j += 2) best = max3(best, e[j], (j + 1 < C) ? e[j + 1] : NEG_INF);
+    for (int j = 0; j < C; ++j) best = fmaxf(best, mask_select(R.m[j], out.rs[j], NEG_INF));
     out.best_any = best;
     return out;
 }
 
-// Products from a packet and the x vector staged in LDS, then the reduction.
+// Flag word (RowSums::fl) of the lane's entries of a packet.
 template <int C, int QM>
-__device__ __forceinline__ RowSums<C> reduce_packet(const Pkt<C, value_type_of(QM)> &cur, float &carry, const float *x_lds,
+__device__ __forceinline__ uint32_t packet_flags(const Pkt<C, value_type_of(QM)> &cur) {
+    constexpr int VT = value_type_of(QM);
+    if (VT == 4) {  // split 12-bit plane: ROW_END 0-3 at bits 12-15 of the halfword, SKIP 0, 1 in the dword, 2, 3 in the halfword
+        const uint32_t A = cur.cw[0], B = cur.cw[1];
+        return (B >> 12) | ((A & 3u) << 8) | ((B & 3u) << 10);
+    }
+    uint32_t fl = 0u;
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+        const uint32_t w = VT == 3 ? __float_as_uint(cur.v[VT == 3 ? j : 0]) : (cur.cw[j >> 1] >> (16 * (j & 1)));
+        fl |= ((w & 1u) << j) | (((w >> 1) & 1u) << (8 + j));
+    }
+    return fl;
+}
+
+// Products from a packet and the x vector staged in LDS (at LDS byte address xbase), then the reduction.
+template <int C, int QM>
+__device__ __forceinline__ Reduced<C> reduce_packet(const Pkt<C, value_type_of(QM)> &cur, float &carry, const uint32_t xbase,
                                                     const uint32_t fixed_mask = 0u) {
     constexpr int VT = value_type_of(QM);
     float p[C];
+    uint32_t m[C];
     if (QM == 6) {
         // Bit-packed fixed point: word = value (bits 31..12, the top 20 bits of its Q1.31 word) | column << 2 | flags. x is
         // staged as a 20-bit integer (Q1.19); both factors fit the full-rate 24-bit multipliers; the 40-bit product is
         // Q2.38, of which bits 38..7 are the product in Q1.31 (integer part wrapped to one bit), masked to the width.
-        uint32_t cwv[C / 2];
+        uint32_t any = 0u;
 #pragma unroll
         for (int j = 0; j < C; ++j) {
             const uint32_t w = __float_as_uint(cur.v[VT == 3 ? j : 0]);
-            const uint32_t xq = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const unsigned char *>(x_lds) + (w & 0xFFCu));
+            const uint32_t xq = lds_u32(xbase + (w & 0xFFCu));
             uint32_t v20, hi;
             asm("v_bfe_u32 %0, %1, 12, 20" : "=v"(v20) : "v"(w));
             asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(hi) : "v"(v20), "v"(xq));
             p[j] = __uint_as_float(__builtin_amdgcn_alignbit(hi, __umul24(v20, xq), 7) & fixed_mask);
-            if (j & 1) cwv[j >> 1] |= (w & 3u) << 16;
-            else cwv[j >> 1] = w & 3u;
+            m[j] = bit_mask<0>(w);
+            any |= w;
         }
-        return reduce_core<C, true>(p, cwv, carry);
+        return reduce_core<C, true>(p, m, (any & 1u) != 0u, carry);
     }
     if (QM == 7) {
-        // fp32 values, 12-bit column words: the lane's four words are 48 bits of the two dwords it loaded, from bit 0 on even
-        // lanes and from bit 16 on odd ones; word j = column << 2 | flags, so (word & 0xFFC) is the LDS byte offset of x[col]
-        // as ever. The reduction wants the flags where 16-bit column words have them (bits 0-1 and 16-17 of a dword).
-        uint32_t cwv[C / 2];
-        const uint32_t odd16 = (threadIdx.x & 1u) << 4;  // (lane parity: a wave is 64 consecutive threads)
-#pragma unroll
-        for (int q = 0; q < C / 4; ++q) {
-            // bits 0..31 and 32..47 of the lane's 48 bits (32-bit funnel shifts: no 64-bit register pairs)
-            const uint32_t lo = __builtin_amdgcn_alignbit(cur.cw[2 * q + 1], cur.cw[2 * q], odd16), hi = cur.cw[2 * q + 1] >> odd16;
-            const uint32_t mid = __builtin_amdgcn_alignbit(hi, lo, 24);  // word 2 from bit 0
-            const unsigned char *xb = reinterpret_cast<const unsigned char *>(x_lds);
-            p[4 * q + 0] = __fmul_rn(cur.v[VT == 4 ? 4 * q + 0 : 0], *reinterpret_cast<const float *>(xb + (lo & 0xFFCu)));
-            p[4 * q + 1] = __fmul_rn(cur.v[VT == 4 ? 4 * q + 1 : 0], *reinterpret_cast<const float *>(xb + ((lo >> 12) & 0xFFCu)));
-            p[4 * q + 2] = __fmul_rn(cur.v[VT == 4 ? 4 * q + 2 : 0], *reinterpret_cast<const float *>(xb + (mid & 0xFFCu)));
-            p[4 * q + 3] = __fmul_rn(cur.v[VT == 4 ? 4 * q + 3 : 0], *reinterpret_cast<const float *>(xb + ((hi >> 4) & 0xFFCu)));
-            // flags of words 0, 1 (bits 0-1 and 12-13 of lo) to bits 0-1 and 16-17; of words 2, 3 (bits 0-1 of mid, 4-5 of hi)
-            const uint32_t f01 = lo & 0x3003u, f23 = (mid & 3u) | ((hi & 0x30u) << 12);
-            cwv[2 * q] = (f01 | (f01 << 4)) & 0x30003u;
-            cwv[2 * q + 1] = f23;
-        }
-        return reduce_core<C, false>(p, cwv, carry);
+        // fp32 values, split 12-bit plane: A = col0 << 2 | col1 << 12 | col2 << 22 | SKIP0 | SKIP1 << 1,
+        // B = col3 << 2 | SKIP2 | SKIP3 << 1 | ROW_END0..3 << 12. One instruction per LDS address where the field sits at
+        // bit 2 (mask + base of the x copy), two where it has to be shifted down first; the row-end masks are single bit
+        // extractions of B, and "this lane holds a row end" is one compare.
+        static_assert(QM != 7 || C == 4, "the split 12-bit plane is built for 4 entries per lane");
+        uint32_t mask = 0xFFCu;
+        asm("" : "+v"(mask));  // (kept in a register: v_and_or_b32 takes no literal)
+        const uint32_t A = cur.cw[0], B = cur.cw[VT == 4 ? 1 : 0];
+        const uint32_t a0 = and_or(A, mask, xbase), a1 = and_or(A >> 10, mask, xbase), a2 = and_or(A >> 20, mask, xbase),
+                       a3 = and_or(B, mask, xbase);
+        p[0] = __fmul_rn(cur.v[VT == 4 ? 0 : 0], lds_f32(a0));
+        p[C > 1 ? 1 : 0] = __fmul_rn(cur.v[VT == 4 ? 1 : 0], lds_f32(a1));
+        p[C > 2 ? 2 : 0] = __fmul_rn(cur.v[VT == 4 ? 2 : 0], lds_f32(a2));
+        p[C > 3 ? 3 : 0] = __fmul_rn(cur.v[VT == 4 ? 3 : 0], lds_f32(a3));
+        m[0] = bit_mask<12>(B);
+        m[C > 1 ? 1 : 0] = bit_mask<13>(B);
+        m[C > 2 ? 2 : 0] = bit_mask<14>(B);
+        m[C > 3 ? 3 : 0] = bit_mask<15>(B);
+        return reduce_core<C, false>(p, m, B > 0xFFFu, carry);
     }
+    uint32_t any = 0u;
 #pragma unroll
     for (int j = 0; j < C; ++j) {
         const uint32_t word = cur.cw[j >> 1];
-        const uint32_t off = (j & 1) ? ((word >> 16) & 0xFFFCu) : (word & 0xFFFCu);  // byte offset of x[col]
+        const uint32_t off = xbase + ((j & 1) ? ((word >> 16) & 0xFFFCu) : (word & 0xFFFCu));  // LDS byte address of x[col]
+        m[j] = (j & 1) ? bit_mask<16>(word) : bit_mask<0>(word);
+        if ((j & 1) == 0) any |= word;
         if (QM == 5) {
             // x is staged as fp32 scaled by 2^-7: byte * (x / 128), one conversion and one multiply per entry
-            const float xv = *reinterpret_cast<const float *>(reinterpret_cast<const unsigned char *>(x_lds) + off);
-            p[j] = __fmul_rn(ubyte_to_float(cur.vq[VT == 1 ? (j >> 2) : 0], j & 3), xv);
+            p[j] = __fmul_rn(ubyte_to_float(cur.vq[VT == 1 ? (j >> 2) : 0], j & 3), lds_f32(off));
         } else if (VT == 1) {
             // x is staged as Q1.7 integers; product truncated to Q1.7 and wrapped to 8 bits, exact in fp32
-            const uint32_t xq = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const unsigned char *>(x_lds) + off);
+            const uint32_t xq = lds_u32(off);
             const uint32_t vq = (cur.vq[VT == 1 ? (j >> 2) : 0] >> (8 * (j & 3))) & 255u;
             // both factors are below 2^8: the 24-bit multiply is exact (and full rate; v_mul_lo_u32 is quarter rate)
             const uint32_t t = __umul24(vq, xq);
             p[j] = (float)(QM == 2 ? (t >> 7) : ((t >> 7) & 255u));  // wide mode: no wrap
         } else if (VT == 2) {
-            const float xv = *reinterpret_cast<const float *>(reinterpret_cast<const unsigned char *>(x_lds) + off);
             const uint32_t hw = cur.vq[VT == 2 ? (j >> 1) : 0];
             const _Float16 hv = __builtin_bit_cast(_Float16, (uint16_t)((j & 1) ? (hw >> 16) : (hw & 0xFFFFu)));
-            p[j] = __fmul_rn((float)hv, xv);  // the conversion is exact
+            p[j] = __fmul_rn((float)hv, lds_f32(off));  // the conversion is exact
         } else if (QM == 4) {
             // both factors are Q1.31 words: the 64-bit product is Q2.62; bits 31..62 are the product in Q1.31 (its integer
             // part wrapped to one bit, like an assignment to real_type), masked down to the W-1 fraction bits kept
-            const uint32_t xq = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const unsigned char *>(x_lds) + off);
+            const uint32_t xq = lds_u32(off);
             const uint32_t vq = __float_as_uint(cur.v[VT == 0 ? j : 0]);
             if (fixed_mask & 0xFFu) {
                 p[j] = __uint_as_float(__builtin_amdgcn_alignbit(__umulhi(vq, xq), vq * xq, 31) & fixed_mask);
@@ -308,12 +385,14 @@ __device__ __forceinline__ RowSums<C> reduce_packet(const Pkt<C, value_type_of(Q
                 p[j] = __uint_as_float(__builtin_amdgcn_alignbit(hi, __umul24(v24, xq), 15) & fixed_mask);
             }
         } else {
-            const float xv = *reinterpret_cast<const float *>(reinterpret_cast<const unsigned char *>(x_lds) + off);
-            p[j] = __fmul_rn(cur.v[VT == 0 ? j : 0], xv);
+            p[j] = __fmul_rn(cur.v[VT == 0 ? j : 0], lds_f32(off));
         }
     }
-    return reduce_core<C, QM == 4>(p, cur.cw, carry);  // (QM 6 returned above)
+    // (`any` holds every column word of the lane: the odd entries' flags sit at bit 16 of the same words)
+    return reduce_core<C, QM == 4>(p, m, (any & 0x00010001u) != 0u, carry);  // (QM 6 returned above)
 }
+template <int QM>
+constexpr bool int_sums() { return QM == 4 || QM == 6; }
 
 template <int C, int QM>
 __device__ __forceinline__ float row_score(const RowSums<C> &R, int j) {  // strict Q1.7: the 8-bit wrap of the row sum

@@ -81,9 +81,10 @@ __global__ void __launch_bounds__(1024) read_probe_kernel(const ReadProbeParams 
                             const uint32_t nxt = i + j + DEPTH - 1;
                             load_packet<4, 0>(pk + (size_t)(nxt < count ? nxt : count - 1u) * PB, lane, buf[(j + DEPTH - 1) % DEPTH]);
                             if (i + j < count) {
-                                const RowSums<4> S = reduce_packet<4, 0>(buf[j], carry, xl, 0u);
-                                if (WORK == -1) best = fmaxf(best, S.best_any);
-                                else if (__any(S.best_any >= 1e30f)) best += S.rs[0];  // WORK == -2: the hot-path trigger as the engine has it
+                                const Reduced<4> S = reduce_packet<4, 0>(buf[j], carry, lds_addr_of(xl), 0u);
+                                const float trig = trigger_of<4, false>(S);
+                                if (WORK == -1) best = fmaxf(best, trig);
+                                else if (__any(trig >= 1e30f)) best += S.S;  // WORK == -2: the hot-path trigger as the engine has it
                             }
                         }
                     }

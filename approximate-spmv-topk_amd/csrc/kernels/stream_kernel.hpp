@@ -16,7 +16,7 @@ namespace tkspmv {
 #endif
 constexpr unsigned long long FLUSH_TAU_WAIT = 2000;  // x 10 ns: longest wait of a wave for a first threshold
 #ifndef TKSPMV_DEFER_PACKETS
-#define TKSPMV_DEFER_PACKETS 3
+#define TKSPMV_DEFER_PACKETS 2
 #endif
 constexpr int DEFER = TKSPMV_DEFER_PACKETS;  // packets per wave whose rows are judged at the end (threshold exchange cold start)
 
@@ -50,12 +50,15 @@ __global__ void __launch_bounds__(576, ((C == 8 && !SCORES) || QM == 7) ? 6 : 5)
     unsigned long long *const dbg_counters = DBG ? P.dbg : nullptr;
     constexpr bool Q8 = QM == 1 || QM == 2;  // x staged as Q1.7 integers
     constexpr int VT = value_type_of(QM);
+    constexpr bool INT = int_sums<QM>();
     // Deferred packets live in registers (C row sums + C / 2 flag words each): with 8 entries per lane one packet is held,
     // not three -- the same number of rows as two 4-entry packets, and the kernel stays at 80 registers (two workgroups
     // per CU; with three it needed 96 and a single query took 57 us instead of 36).
-    constexpr int DEFER_C = (C == 8 || QM == 7) ? 1 : DEFER;  // (12-bit column words: the unpacking needs the registers)
+    // (at most 1024 columns: two -- the third would push the 16-bit layouts past 80 registers; the 12-bit layout keeps one)
+    constexpr int DEFER_C = (C == 8 || QM == 7) ? 1 : (XCOLS <= 1024 ? DEFER : DEFER + 1);
     __shared__ StreamLds<XCOLS> L;
     float *x_lds = L.u.w.x;
+    const uint32_t xbase = lds_addr_of(L.u.w.x);  // (0: the object is the kernel's only LDS block and x its first member)
     uint2 *cand = L.u.w.cand;
     uint32_t *misc = L.misc;
     SelectShared &sel_sh = L.u.sel;
@@ -224,8 +227,7 @@ __global__ void __launch_bounds__(576, ((C == 8 && !SCORES) || QM == 7) ? 6 : 5)
             st_rb[d] = 0u;
 #pragma unroll
             for (int j = 0; j < C; ++j) st[d].rs[j] = 0.0f;
-#pragma unroll
-            for (int j = 0; j < C / 2; ++j) st[d].cw[j] = 0u;
+            st[d].fl = 0u;
         }
 
         // Two packets in flight behind the one being reduced. The buffers rotate by NAME (the loop is unrolled by
@@ -277,10 +279,11 @@ __global__ void __launch_bounds__(576, ((C == 8 && !SCORES) || QM == 7) ? 6 : 5)
                 tau = __uint_as_float(
                     __hip_atomic_load(&misc[MISC_TAU], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
 
-            const RowSums<C> R = reduce_packet<C, QM>(cur, carry, x_lds, P.fixed_mask);
-            if (tr && i == 0u) tr2 = __builtin_amdgcn_s_memrealtime() + (__float_as_uint(R.best_any) & 0u);
+            const Reduced<C> Rd = reduce_packet<C, QM>(cur, carry, xbase, P.fixed_mask);
+            if (tr && i == 0u) tr2 = __builtin_amdgcn_s_memrealtime() + (__float_as_uint(Rd.S) & 0u);
 
             if (SCORES) {
+                const RowSums<C> R = expand<C, INT>(Rd, packet_flags<C, QM>(cur));
                 uint32_t r = rb_cur + ends_below<C>(R);
 #pragma unroll
                 for (int j = 0; j < C; ++j) {
@@ -292,6 +295,7 @@ __global__ void __launch_bounds__(576, ((C == 8 && !SCORES) || QM == 7) ? 6 : 5)
             } else {
                 if (i < (uint32_t)DEFER_C && P.n_sets != 0u) {
                     // Cold start of the threshold exchange: keep the sums in registers, only feed the maxima.
+                    const RowSums<C> R = expand<C, INT>(Rd, packet_flags<C, QM>(cur));
 #pragma unroll
                     for (int d = 0; d < DEFER_C; ++d) {
                         if (i == (uint32_t)d) {
@@ -303,7 +307,9 @@ __global__ void __launch_bounds__(576, ((C == 8 && !SCORES) || QM == 7) ? 6 : 5)
                     if (lane == 0 && publishes && wmax >= min_units)
                         (void)__hip_atomic_fetch_max(&misc[MISC_GRPMAX + grp_local], order_key(wmax), __ATOMIC_RELAXED,
                                                      __HIP_MEMORY_SCOPE_WORKGROUP);
-                } else if (__any(R.best_any >= tau) && !(dbg_flags & 2u)) {
+                } else if (__any(trigger_of<C, INT>(Rd) >= tau) && !(dbg_flags & 2u)) {
+                    // (the trigger bounds every finished row of its lane from above: packet_math.hpp)
+                    const RowSums<C> R = expand<C, INT>(Rd, packet_flags<C, QM>(cur));
                     offer_candidates<C, QM, ListGeom<XCOLS>::WAVE_CAP, DBG>(P, R, rb_cur, tau, lane, grp_local, publishes, wcand, wcnt, misc);
                 }
             }

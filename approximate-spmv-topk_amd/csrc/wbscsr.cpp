@@ -163,7 +163,7 @@ std::string pack_wbscsr(uint32_t rows, uint32_t cols, uint64_t nnz, const uint32
                 }
                 if (precision == Precision::F32C12) {
                     std::memcpy(pkt + (size_t)slot * 4, &v, 4);
-                    colw12_store(pkt + (size_t)PE * 4, slot, cw);
+                    colw12s_store(pkt + (size_t)PE * 4, slot, cw);
                     continue;
                 }
                 if (precision == Precision::F32) {
@@ -209,7 +209,7 @@ void decode_wbscsr(const PackedMatrix &pm, std::vector<uint32_t> &row, std::vect
                     cw = (uint16_t)(w & 0xFFFu);
                     v = from_fixed(w & 0xFFFFF000u);
                 } else if (pm.precision == Precision::F32C12) {
-                    cw = colw12_load(pkt + (size_t)PE * 4, s);
+                    cw = colw12s_load(pkt + (size_t)PE * 4, s);
                 } else {
                     std::memcpy(&cw, pkt + (size_t)PE * vb + (size_t)s * 2, 2);
                 }
@@ -286,7 +286,7 @@ std::string save_packed(const PackedMatrix &pm, const char *path) {
     FileHeader hd;
     std::memset(&hd, 0, sizeof(hd));
     std::memcpy(hd.magic, MAGIC, 8);
-    hd.version = 1;
+    hd.version = 2;  // (2: F32C12 streams carry the split 12-bit plane)
     hd.precision = (uint32_t)pm.precision;
     hd.fixed_width = pm.fixed_width;
     hd.C = pm.C;
@@ -332,7 +332,7 @@ std::string load_packed(const char *path, PackedMatrix &pm) {
     };
     if (std::fread(&hd, sizeof(hd), 1, f) != 1) return fail("file too short for a header");
     if (std::memcmp(hd.magic, MAGIC, 8) != 0) return fail("not a .tkspmv file (bad magic)");
-    if (hd.version != 1) return fail("unsupported .tkspmv version");
+    if (hd.version != 2) return fail("unsupported .tkspmv version");
     if ((hd.precision != (uint32_t)Precision::F32 && hd.precision != (uint32_t)Precision::Q1_7 &&
          hd.precision != (uint32_t)Precision::F16 && hd.precision != (uint32_t)Precision::FIXED &&
          hd.precision != (uint32_t)Precision::Q1_7_RND && hd.precision != (uint32_t)Precision::FIXED20 &&
@@ -405,7 +405,7 @@ std::string load_packed(const char *path, PackedMatrix &pm) {
                     std::memcpy(&w, out.packets.data() + (size_t)p * hd.packet_bytes + (size_t)s * 4, 4);
                     cw = (uint16_t)(w & 0xFFFu);
                 } else if (hd.precision == (uint32_t)Precision::F32C12) {
-                    cw = colw12_load(cwp, s);
+                    cw = colw12s_load(cwp, s);
                 } else {
                     std::memcpy(&cw, cwp + (size_t)s * 2, 2);
                 }

@@ -60,10 +60,10 @@ TKSPMV_HD inline uint32_t slot_to_index(uint32_t s, uint32_t C) {
 // F32C12 = fp32 values with 12-BIT column words (round 2): with at most 1024 columns a column word -- 10 bits of
 // column, 2 flags -- needs 12 bits, not 16; a packet is [64 * C floats][64 * C x 12 bits] = 5.5 B per entry instead of 6,
 // 8.3 % fewer bytes from HBM for the same arithmetic on the same fp32 values (the reference packs its BSCSR packets to
-// the bit for the same reason: types.hpp:57-79). The 12-bit words of a plane of 256 entries lie back to back (entry t at
-// bit 12 t): a lane's 4 words are 6 bytes, two lanes share three dwords, and a lane fetches its words with ONE dwordx2
-// load at a 4-byte boundary (load_packet in kernels/common.hpp). The default for TKSPMV_F32 with cols <= 1024 and 4 entries
-// per lane (TKSPMV_F32_C12=0 keeps 16-bit column words); results are bit-identical either way.
+// the bit for the same reason: types.hpp:57-79). The 12 bits of a lane's 4 entries are split over one dword and one
+// halfword per lane (colw12s_* below; round 2 had the words back to back, which the row-per-lane layout of wsell.hpp
+// still uses: colw12_*). The default for TKSPMV_F32 with cols <= 1024 and 4 entries per lane (TKSPMV_F32_C12=0 keeps
+// 16-bit column words); results are bit-identical either way.
 enum class Precision : int32_t { F32 = 0, Q1_7 = 1, F16 = 3, FIXED = 4, Q1_7_RND = 5, FIXED20 = 6, F32C12 = 7 };
 constexpr uint32_t FIXED20_MAX_WIDTH = 20, FIXED20_MAX_COLS = 1024, F32C12_MAX_COLS = 1024;
 
@@ -92,6 +92,44 @@ TKSPMV_HD inline uint16_t colw12_load(const uint8_t *planes, uint32_t slot) {
     const uint32_t t = slot & 255u;
     const uint8_t *b = planes + (size_t)(slot >> 8) * 384u + (t * 3u) / 2u;
     return (t & 1u) ? (uint16_t)((b[0] >> 4) | ((uint16_t)b[1] << 4)) : (uint16_t)(b[0] | ((uint16_t)(b[1] & 0x0Fu) << 8));
+}
+// F32C12's plane is SPLIT (round 3): the 384 bytes of a plane of 256 entries are [64 x u32 A][64 x u16 B], lane l (entries
+// 4l .. 4l+3) owning A[l] and B[l]:
+//   A = col0 << 2 | col1 << 12 | col2 << 22 | SKIP0 | SKIP1 << 1
+//   B = col3 << 2 | SKIP2 | SKIP3 << 1 | ROW_END0..3 << 12
+// The same 12 bits per entry, arranged for the kernel: every lane loads one aligned dword and one halfword (no funnel
+// shifts between neighbouring lanes), a column's LDS offset is one or two instructions (mask, or shift + mask), the four
+// row-end masks are single-bit extractions of B and "this lane holds a row end" is B > 0xFFF -- 24 vector instructions
+// fewer per packet than with the back-to-back words.
+TKSPMV_HD inline void colw12s_bits(uint32_t j, uint16_t cw, uint32_t &a, uint32_t &b) {  // what entry j ORs into A and B
+    const uint32_t col = (uint32_t)(cw >> COLW_COL_SHIFT), end = cw & COLW_ROW_END, skip = (cw & COLW_SKIP) ? 1u : 0u;
+    a = j == 0u ? ((col << 2) | skip) : (j == 1u ? ((col << 12) | (skip << 1)) : (j == 2u ? (col << 22) : 0u));
+    b = (j == 2u ? skip : (j == 3u ? ((col << 2) | (skip << 1)) : 0u)) | (end << (12u + j));
+}
+inline void colw12s_store(uint8_t *planes, uint32_t slot, uint16_t cw) {  // into a zeroed plane
+    const uint32_t t = slot & 255u, lane = t >> 2;
+    uint8_t *pl = planes + (size_t)(slot >> 8) * 384u;
+    uint32_t a, b, A;
+    uint16_t Bv;
+    colw12s_bits(t & 3u, cw, a, b);
+    std::memcpy(&A, pl + lane * 4u, 4);
+    std::memcpy(&Bv, pl + 256u + lane * 2u, 2);
+    A |= a;
+    Bv = (uint16_t)(Bv | b);
+    std::memcpy(pl + lane * 4u, &A, 4);
+    std::memcpy(pl + 256u + lane * 2u, &Bv, 2);
+}
+inline uint16_t colw12s_load(const uint8_t *planes, uint32_t slot) {
+    const uint32_t t = slot & 255u, lane = t >> 2, j = t & 3u;
+    const uint8_t *pl = planes + (size_t)(slot >> 8) * 384u;
+    uint32_t A;
+    uint16_t Bv;
+    std::memcpy(&A, pl + lane * 4u, 4);
+    std::memcpy(&Bv, pl + 256u + lane * 2u, 2);
+    const uint32_t col = j == 0u ? (A >> 2) & 1023u : (j == 1u ? (A >> 12) & 1023u : (j == 2u ? (A >> 22) & 1023u : ((uint32_t)Bv >> 2) & 1023u));
+    const uint32_t skip = j == 0u ? (A & 1u) : (j == 1u ? ((A >> 1) & 1u) : (j == 2u ? (Bv & 1u) : ((Bv >> 1) & 1u)));
+    const uint32_t end = ((uint32_t)Bv >> (12u + j)) & 1u;
+    return (uint16_t)((col << COLW_COL_SHIFT) | (skip ? COLW_SKIP : 0u) | (end ? COLW_ROW_END : 0u));
 }
 TKSPMV_HD inline uint32_t fixed20_word(uint32_t q_left_aligned, uint32_t col, uint32_t flags) {
     return (q_left_aligned & 0xFFFFF000u) | (col << 2) | flags;

@@ -396,8 +396,8 @@ void oracle_packed_scores(const uint8_t *packets, uint64_t packet_bytes, const u
             const uint8_t *pk = packets + (size_t)pidx * packet_bytes;
             /* value type from the packet size: 4 bytes = fp32, 2 bytes = fp16 (TKSPMV_F16; converted exactly to fp32
              * before the multiply, as the kernel does) */
-            /* 5.5 bytes per entry: fp32 values with 12-BIT column words (the engine's F32C12 layout, csrc/wbscsr.hpp): entry t of
-             * a plane of 256 entries at bit 12 t of the plane's 384 bytes, little-endian; same arithmetic as 16-bit words */
+            /* 5.5 bytes per entry: fp32 values with 12-BIT column words (the engine's F32C12 layout, csrc/wbscsr.hpp: a split
+             * plane of one dword and one halfword per lane); same arithmetic as 16-bit words */
             const int c12 = packet_bytes * 2u == (uint64_t)PE * 11u;
             const uint32_t vb = c12 ? 4u : (uint32_t)(packet_bytes / PE) - 2u;
             const float *vals = (const float *)pk;
@@ -413,9 +413,16 @@ void oracle_packed_scores(const uint8_t *packets, uint64_t packet_bytes, const u
                     uint32_t at = (j >> 2) * 256 + l * 4 + (j & 3);
                     uint16_t w;
                     if (c12) {
-                        const uint32_t t = at & 255u;
-                        const uint8_t *b = c12p + (size_t)(at >> 8) * 384u + (t * 3u) / 2u;
-                        w = (t & 1u) ? (uint16_t)((b[0] >> 4) | ((uint16_t)b[1] << 4)) : (uint16_t)(b[0] | ((uint16_t)(b[1] & 0x0Fu) << 8));
+                        /* split plane: [64 x u32 A][64 x u16 B] per 256 entries; A = col0 << 2 | col1 << 12 | col2 << 22 | SKIP0 |
+                         * SKIP1 << 1, B = col3 << 2 | SKIP2 | SKIP3 << 1 | ROW_END0..3 << 12 (little-endian) */
+                        const uint32_t t = at & 255u, ln = t >> 2, jj = t & 3u;
+                        const uint8_t *pl = c12p + (size_t)(at >> 8) * 384u;
+                        const uint8_t *ab = pl + ln * 4u, *bb = pl + 256u + ln * 2u;
+                        const uint32_t A = (uint32_t)ab[0] | ((uint32_t)ab[1] << 8) | ((uint32_t)ab[2] << 16) | ((uint32_t)ab[3] << 24);
+                        const uint32_t Bw = (uint32_t)bb[0] | ((uint32_t)bb[1] << 8);
+                        const uint32_t col = jj == 0u ? (A >> 2) & 1023u : (jj == 1u ? (A >> 12) & 1023u : (jj == 2u ? (A >> 22) & 1023u : (Bw >> 2) & 1023u));
+                        const uint32_t sk = jj == 0u ? (A & 1u) : (jj == 1u ? ((A >> 1) & 1u) : (jj == 2u ? (Bw & 1u) : ((Bw >> 1) & 1u)));
+                        w = (uint16_t)((col << 2) | (sk << 1) | ((Bw >> (12u + jj)) & 1u));
                     } else {
                         w = cws[at];
                     }

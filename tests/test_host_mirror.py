@@ -149,8 +149,8 @@ def test_pack_decode_round_trip(pkg, C, parts):
 
 def test_fp32_column_words_travel_as_12_bits(pkg, oracle, monkeypatch):
     """TKSPMV_F32 over at most 1024 columns packs its column words (10 bits of column, 2 flags) into 12 bits (the default;
-    TKSPMV_F32_C12=0 keeps 16): 1408-byte packets instead of 1536. Same entries, same order; the bits are where csrc/wbscsr.hpp says (entry t of a plane of 256
-    at bit 12 t, little-endian); the order-matched oracle computes the same scores, bit for bit, from either layout."""
+    TKSPMV_F32_C12=0 keeps 16): 1408-byte packets instead of 1536. Same entries, same order; the bits are where csrc/wbscsr.hpp says (a split plane: one
+    dword and one halfword per lane); the order-matched oracle computes the same scores, bit for bit, from either layout."""
     g = pkg.generate_matrix(5000, 1024, 20, "gamma", 9)
     p12 = pkg.Packed(g, nnz_per_lane=4, n_wave_partitions=64)
     monkeypatch.setenv("TKSPMV_F32_C12", "0")
@@ -166,11 +166,15 @@ def test_fp32_column_words_travel_as_12_bits(pkg, oracle, monkeypatch):
     a12 = np.asarray(r12[0]).reshape(-1, 1408)
     a16 = np.asarray(r16[0]).reshape(-1, 1536)
     assert np.array_equal(a12[:, :1024], a16[:, :1024])  # the values
-    cw16 = a16[:, 1024:].copy().view(np.uint16).astype(np.uint64)  # [packets][256]
-    bits = np.zeros((a12.shape[0], 384 * 8), np.uint8)
-    for k in range(12):
-        bits[:, k::12] = ((cw16 >> np.uint64(k)) & np.uint64(1)).astype(np.uint8)
-    assert np.array_equal(np.packbits(bits, axis=1, bitorder="little"), a12[:, 1024:])
+    # the split plane, rebuilt here from the 16-bit words (column << 2 | SKIP << 1 | ROW_END), lane l owning entries 4l..4l+3:
+    #   A[l] = col0 << 2 | col1 << 12 | col2 << 22 | SKIP0 | SKIP1 << 1      (64 dwords)
+    #   B[l] = col3 << 2 | SKIP2 | SKIP3 << 1 | ROW_END0..3 << 12            (64 halfwords)
+    cw16 = a16[:, 1024:].copy().view(np.uint16).astype(np.uint32).reshape(-1, 64, 4)  # [packets][lane][j]
+    col, skip, end = cw16 >> 2, (cw16 >> 1) & 1, cw16 & 1
+    A = (col[:, :, 0] << 2) | (col[:, :, 1] << 12) | (col[:, :, 2] << 22) | skip[:, :, 0] | (skip[:, :, 1] << 1)
+    B = (col[:, :, 3] << 2) | skip[:, :, 2] | (skip[:, :, 3] << 1) | (end[:, :, 0] << 12) | (end[:, :, 1] << 13) | (end[:, :, 2] << 14) | (end[:, :, 3] << 15)
+    plane = np.concatenate([A.astype("<u4").view(np.uint8).reshape(-1, 256), B.astype("<u2").view(np.uint8).reshape(-1, 128)], axis=1)
+    assert np.array_equal(plane, a12[:, 1024:])
     x = pkg.create_sample_vector(1024, True, False, True, 5)
     y12, pr12 = oracle.packed_scores(r12, x, g.rows, 4)
     y16, pr16 = oracle.packed_scores(r16, x, g.rows, 4)
