@@ -38,6 +38,7 @@
 #include "kernels/packet_math.hpp"
 #include "kernels/stream_kernel.hpp"
 #include "kernels/batch_kernel.hpp"
+#include "kernels/claim_kernel.hpp"
 #include "kernels/multi_kernel.hpp"
 #include "kernels/radix_select.hpp"
 #include "kernels/read_probe.hpp"
@@ -161,6 +162,12 @@ struct EngineImpl {
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     uint32_t *d_tickets = nullptr;  // [BATCH_MAX] x 32 words
+    // claim_kernel (kernels/claim_kernel.hpp): the matrix is packed into sets of 8 wave partitions that workgroups claim
+    bool can_claim = false;
+    uint32_t n_claim_sets = 0;
+    uint32_t *d_claim = nullptr;        // [2 launch parities][CLAIM_SHARDS] x 32 words
+    uint32_t *d_claim_done = nullptr;   // [BATCH_MAX][CLAIM_SHARDS] x 32 words
+    mutable int claim_parity = 0;
     uint32_t groups_with_rows = 0;  // publishing groups that own at least one wave partition
     uint32_t n_reducers = 0;  // TKSPMV_REDUCERS (tuning): workgroups whose server derives tau from all maxima itself
     float *d_out_val = nullptr, *d_scores = nullptr;
@@ -400,6 +407,34 @@ struct EngineImpl {
         launch_counter += (uint64_t)n;
         hipLaunchKernelGGL(batch_kernel_for(), dim3(grid), dim3(block + 64), 0, s, P, S, B);
     }
+    // n <= batch_max queries in one launch of the claim kernel (the matrix dealt out dynamically); results complete in stream
+    // order after the launch.
+    void launch_claim(const float *const *xs, uint32_t *const *out_idx, float *const *out_val, int n, hipStream_t s) const {
+        drain(s);
+        StreamParams P = stream_params(xs[0], 0);
+        P.fused = 0u;
+        // a threshold needs k publishing groups: every workgroup that gets a set of a query publishes for it
+        P.tau_possible = (uint64_t)std::min<uint32_t>(n_claim_sets, grid - 1u) * gpw >= (uint64_t)desc.k ? 1u : 0u;
+        SelectParams S = select_params(out_idx[0], out_val[0], 0);
+        ClaimParams B{};
+        B.n_q = (uint32_t)n;
+        B.n_sets = n_claim_sets;
+        B.claim = d_claim + (size_t)claim_parity * CLAIM_SHARDS * 32u;
+        B.claim_other = d_claim + (size_t)(claim_parity ^ 1) * CLAIM_SHARDS * 32u;
+        B.done = d_claim_done;
+        claim_parity ^= 1;
+        static_cast<SetAddr &>(B) = set_addr(0);
+        for (int q = 0; q < n; ++q) {
+            BatchIO &Q = B.io[q];
+            Q.x = xs[q];
+            Q.packets = d_replicas.empty() ? d_packets : d_replicas[(launch_counter + q) % d_replicas.size()];
+            Q.out_idx = out_idx[q];
+            Q.out_val = out_val[q];
+        }
+        launch_counter += (uint64_t)n;
+        if (pm.precision == Precision::F32C12) hipLaunchKernelGGL((claim_kernel<1024, 7>), dim3(grid), dim3(block + 64), 0, s, P, S, B);
+        else hipLaunchKernelGGL((claim_kernel<1024, 0>), dim3(grid), dim3(block + 64), 0, s, P, S, B);
+    }
     // A back-to-back sequence of queries given as pointer lists: batch kernel launches of up to BATCH_MAX queries
     // when it is available, else deferred selection.
     void launch_sequence(const float *const *xs, uint32_t *const *out_idx, float *const *out_val, int n, hipStream_t s) const {
@@ -408,7 +443,10 @@ struct EngineImpl {
             drain(s);
             return;
         }
-        for (int i = 0; i < n; i += batch_max) launch_batch(xs + i, out_idx + i, out_val + i, std::min(batch_max, n - i), s);
+        for (int i = 0; i < n; i += batch_max) {
+            if (can_claim) launch_claim(xs + i, out_idx + i, out_val + i, std::min(batch_max, n - i), s);
+            else launch_batch(xs + i, out_idx + i, out_val + i, std::min(batch_max, n - i), s);
+        }
     }
     // One query of a back-to-back sequence: its selection runs inside the NEXT deferred launch (or in drain()).
     void launch_deferred(const float *x, uint32_t *out_idx, float *out_val, hipStream_t s) const {
@@ -645,7 +683,8 @@ Engine::~Engine() {
                 m.rs_n, m.rs_host / m.rs_n / 1e3, m.rs_pub / m.rs_n / 1e3, m.rs_tick / m.rs_n / 1e3, m.rs_dev / m.rs_n / 1e3);
     if (m.stream) (void)hipStreamSynchronize(m.stream);
     void *bufs[] = {m.d_packets, m.d_pkt_row, m.d_part_first, m.d_part_count, m.d_x,
-                    m.d_out_idx, m.d_out_val, m.d_scores,     m.d_stats,      m.d_done, m.d_trace, m.d_tickets};
+                    m.d_out_idx, m.d_out_val, m.d_scores,     m.d_stats,      m.d_done, m.d_trace, m.d_tickets,
+                    m.d_claim,   m.d_claim_done};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     {
@@ -771,6 +810,27 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
     // partition per streaming wave of the remaining grid - 1 workgroups.
     const bool defer_capable = m.grid >= 2 && (uint64_t)m.grid * WG_SLOTS <= (uint64_t)SEL_PER_THREAD * (m.block + 64);
     const uint32_t n_stream_waves = (m.grid - (defer_capable ? 1u : 0u)) * waves_per_wg;
+    // (measurement aid, tools/claim_probe.py: more partitions than waves -- only the read probe may run on such an engine)
+    // claim_kernel: fp32 values, 4 entries per lane, x of at most 1024 columns, 8 streaming waves per workgroup, no tracing
+    // hooks. The matrix is cut into sets of 8 partitions of ~10 packets (at least 2 sets per workgroup, at most 32) instead of
+    // one partition per wave. (TKSPMV_CLAIM=0: one partition per wave and batch_kernel.)
+    bool want_claim = d.precision == TKSPMV_F32 && C == 4u && d.cols <= 1024u && d.impl == TKSPMV_IMPL_STREAM && waves_per_wg == 8u &&
+                      defer_capable && d.partitions <= 1 && !getenv("TKSPMV_TRACE") && !getenv("TKSPMV_STATS") && !getenv("TKSPMV_STAMPS") &&
+                      !getenv("TKSPMV_DBG_FLAGS") && !getenv("TKSPMV_DBG_REPEAT");
+    // Opt-in (TKSPMV_CLAIM=1): measured on one box against the static partitions of batch_kernel -- 18.35 us per query --
+    // 19.1 / 19.6 / 28.6 us at 1 / 2 / 4 sets per workgroup: the server wave's staging chain (claim, side tables and x, the
+    // exchange duty, the drain before the DONE add: ~6 us per assignment) does not keep up with assignments of 5-10 packets.
+    want_claim = want_claim && getenv("TKSPMV_CLAIM") != nullptr && atoi(getenv("TKSPMV_CLAIM")) != 0;
+    uint32_t claim_parts = 0;
+    if (want_claim) {
+        const uint64_t n_wg = m.grid - 1u;
+        uint32_t spw = 2;
+        if (const char *f = getenv("TKSPMV_CLAIM_SETS_PER_WG")) spw = (uint32_t)std::max(1, std::min(32, atoi(f)));
+        const uint64_t by_size = (d.nnz / 256u / 10u + 7u) / 8u;  // sets of 8 partitions of ~10 packets
+        claim_parts = (uint32_t)(std::max<uint64_t>(n_wg * spw, std::min<uint64_t>(by_size, n_wg * 32u)) * 8u);
+    }
+    const uint32_t n_parts_hint = getenv("TKSPMV_PARTITIONS_HINT") ? (uint32_t)atoi(getenv("TKSPMV_PARTITIONS_HINT"))
+                                                                   : (want_claim ? claim_parts : n_stream_waves);
     if (prepacked) {
         // A matrix packed earlier (tkspmv_pack / a .tkspmv file): it must describe the same problem and must not have
         // more partitions than this launch geometry has streaming waves (the batch kernel gives every wave one).
@@ -782,7 +842,7 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
             err = "the packed matrix does not match the descriptor (rows, cols, precision or entries per lane)";
             return TKSPMV_ERR_INVALID;
         }
-        if (q.part_first.size() > n_stream_waves) {
+        if (q.part_first.size() > n_stream_waves && !want_claim) {
             err = "the packed matrix has more wave partitions than this GPU's launch geometry has streaming waves: pack it "
                   "again with tkspmv_pack(desc, " + std::to_string(n_stream_waves) + ", ...)";
             return TKSPMV_ERR_UNSUPPORTED;
@@ -805,7 +865,7 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
             // (a multi-query engine packs the same COO a second time below: leave its columns and values in HBM until then)
             dp.keep_coo = d.cols <= SELL_XCOLS && (d.multi_q != 0 || d.impl == TKSPMV_IMPL_ROW_PER_LANE || getenv("TKSPMV_MULTI_Q"));
             perr = pack_wbscsr_device(d.rows, d.cols, d.nnz, d.row, d.col, d.val, stream_precision_of(d), C,
-                                      n_stream_waves, 4, fixed_width_of(d), dp, kind);
+                                      n_parts_hint, 4, fixed_width_of(d), dp, kind);
             if (perr.empty()) {
                 m.pm = std::move(dp.meta);
                 m.d_packets = dp.d_packets;
@@ -815,7 +875,7 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
                 m.packed_on_device = true;
             }
         } else {
-            perr = pack_wbscsr(d.rows, d.cols, d.nnz, d.row, d.col, d.val, stream_precision_of(d), C, n_stream_waves, 4,
+            perr = pack_wbscsr(d.rows, d.cols, d.nnz, d.row, d.col, d.val, stream_precision_of(d), C, n_parts_hint, 4,
                                m.pm, kind, fixed_width_of(d));
         }
         if (!perr.empty()) {
@@ -942,6 +1002,15 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
         std::vector<float> ninf(n, -std::numeric_limits<float>::infinity());
         HIP_TRY(hipMemcpy(m.d_rscores, ninf.data(), n * 4, hipMemcpyHostToDevice));
         HIP_TRY(hipMalloc((void **)&m.d_rhist, 4 * 256 * 4));
+    }
+    m.can_claim = want_claim && m.can_batch && !m.use_radix;
+    if (want_claim && !m.can_claim && m.pm.part_first.size() > n_stream_waves && m.can_batch) m.can_batch = false;  // (batch_kernel needs one partition per wave)
+    if (m.can_claim) {
+        m.n_claim_sets = (uint32_t)((m.pm.part_first.size() + 7u) / 8u);
+        HIP_TRY(malloc_exchange((void **)&m.d_claim, 2 * CLAIM_SHARDS * 32 * 4));
+        HIP_TRY(hipMemset(m.d_claim, 0, 2 * CLAIM_SHARDS * 32 * 4));
+        HIP_TRY(malloc_exchange((void **)&m.d_claim_done, (size_t)BATCH_MAX * CLAIM_SHARDS * 32 * 4));
+        HIP_TRY(hipMemset(m.d_claim_done, 0, (size_t)BATCH_MAX * CLAIM_SHARDS * 32 * 4));
     }
     // Multi-query passes (desc.multi_q; TKSPMV_MULTI_Q overrides): a second copy of the matrix in the wave-sliced ELL layout.
     {
@@ -1121,6 +1190,7 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
     m.info.pack_us = m.pack_us;
     m.info.multi_pack_us = m.sell_pack_us;
     m.info.pack_on_device = m.packed_on_device ? 1u : 0u;
+    m.info.claim_sets = m.can_claim ? m.n_claim_sets : 0u;
     HIP_TRY(hipDeviceSynchronize());
     return TKSPMV_OK;
 }
@@ -1641,8 +1711,12 @@ int Engine::time_stream_read(int32_t passes, double *ns_per_pass, std::string &e
             if (p) (void)hipFree(p);
         }
     } sink;
-    HIP_TRY(hipMalloc((void **)&sink.p, (size_t)m.grid * 16 * 4));
+    const size_t n_end = (size_t)m.grid * 16;
+    HIP_TRY(hipMalloc((void **)&sink.p, (size_t)m.grid * 16 * 4 + (size_t)(passes + 2) * 128 + n_end * 8));
     R.sink = sink.p;
+    R.claim = sink.p + (size_t)m.grid * 16;
+    const bool want_ends = getenv("TKSPMV_READ_PROBE_ENDS") != nullptr;  // (tuning runs: when did the waves of each XCD finish?)
+    R.t_end = want_ends ? reinterpret_cast<unsigned long long *>(R.claim + (size_t)(passes + 2) * 32) : nullptr;
     void (*fn)(ReadProbeParams) = nullptr;
     switch (m.pm.packet_bytes / 64u) {
         case 22: fn = read_probe_kernel<22>; break;
@@ -1669,8 +1743,10 @@ int Engine::time_stream_read(int32_t passes, double *ns_per_pass, std::string &e
     }
     HIP_TRY(hipStreamSynchronize(m.stream));
     R.n_pass = 2;  // (warm-up: code object, clocks)
+    HIP_TRY(hipMemsetAsync(R.claim, 0, (size_t)(passes + 2) * 128, m.stream));
     hipLaunchKernelGGL(fn, dim3(m.grid), dim3(stream_block), 0, m.stream, R);
     R.n_pass = (uint32_t)passes;
+    HIP_TRY(hipMemsetAsync(R.claim, 0, (size_t)(passes + 2) * 128, m.stream));
     HIP_TRY(hipEventRecord(m.ev0, m.stream));
     hipLaunchKernelGGL(fn, dim3(m.grid), dim3(stream_block), 0, m.stream, R);
     HIP_TRY(hipEventRecord(m.ev1, m.stream));
@@ -1678,6 +1754,40 @@ int Engine::time_stream_read(int32_t passes, double *ns_per_pass, std::string &e
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, m.ev0, m.ev1));
     HIP_TRY(hipGetLastError());
+    if (want_ends) {
+        std::vector<unsigned long long> te(n_end);
+        HIP_TRY(hipMemcpy(te.data(), R.t_end, n_end * 8, hipMemcpyDeviceToHost));
+        const uint32_t nw = stream_block / 64u;
+        unsigned long long t0 = ~0ull, t1 = 0ull;
+        for (uint32_t b = 0; b < m.grid; ++b)
+            for (uint32_t w = 0; w < nw; ++w) {
+                t0 = std::min(t0, te[(size_t)b * nw + w]);
+                t1 = std::max(t1, te[(size_t)b * nw + w]);
+            }
+        fprintf(stderr, "[read probe] wave end times relative to the last one, by blockIdx %% 8 (mean / earliest, us):");
+        for (uint32_t x = 0; x < 8u; ++x) {
+            double sum = 0, mn = 1e30;
+            uint32_t n = 0;
+            for (uint32_t b = x; b < m.grid; b += 8u)
+                for (uint32_t w = 0; w < nw; ++w, ++n) {
+                    const double d = (double)(t1 - te[(size_t)b * nw + w]) * 0.01;
+                    sum += d;
+                    mn = std::min(mn, -d);
+                }
+            fprintf(stderr, " %.1f / %.1f", -sum / std::max(1u, n), mn);
+        }
+        fprintf(stderr, "  (launch %.1f us)\n", (double)ms * 1e3);
+        std::vector<double> lead;
+        for (size_t i = 0; i < n_end; ++i)
+            if (te[i] != 0ull && (double)(t1 - te[i]) * 0.01 < (double)ms * 1e3 * 0.9) lead.push_back((double)(t1 - te[i]) * 0.01);
+        std::sort(lead.begin(), lead.end());
+        if (!lead.empty()) {
+            fprintf(stderr, "[read probe] waves still running x us before the end of the launch:");
+            for (double x : {1.0, 5.0, 10.0, 20.0, 40.0, 80.0, 160.0, 320.0})
+                fprintf(stderr, " %g us: %zu", x, (size_t)(std::lower_bound(lead.begin(), lead.end(), x) - lead.begin()));
+            fprintf(stderr, " (of %zu)\n", lead.size());
+        }
+    }
     *ns_per_pass = (double)ms * 1e6 / passes;
     return TKSPMV_OK;
 }

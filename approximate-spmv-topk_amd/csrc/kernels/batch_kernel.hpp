@@ -92,8 +92,15 @@ struct BatchLds {
     uint32_t misc[2][MISC_WORDS];                        // per query parity
     unsigned long long stg[2][8][STG_N];                 // survivors staged by the streaming waves
     uint32_t stg_cnt[2][8];
+    uint32_t pace;  // issue priority the workgroup's streaming waves take at their next query start (0..2), set by the server
 #ifndef TKSPMV_ALTERNATE_PRIO
 #define TKSPMV_ALTERNATE_PRIO 1
+#endif
+#ifndef TKSPMV_RANK_PRIO
+#define TKSPMV_RANK_PRIO 1
+#endif
+#ifndef TKSPMV_PACE_SLEEP
+#define TKSPMV_PACE_SLEEP 4
 #endif
 };
 
@@ -226,6 +233,7 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
     if (trw && lane == 0) trw[0] = __builtin_amdgcn_s_memrealtime();
     if (tid < 2u * MISC_WORDS) (&L.misc[0][0])[tid] = 0u;
     if (tid < 16u) (&L.stg_cnt[0][0])[tid] = 0u;
+    if (tid == 0u) L.pace = 4u;
     __syncthreads();
     const uint32_t grp_local = is_server ? 0u : wave * P0.gpw / nwaves;
     const bool publishes = (bid * P0.gpw + grp_local) < P0.n_groups_pub;
@@ -431,6 +439,24 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
                     // write-through (sc1) store; drain them, then a RELAXED agent-scope add. A release-ordered atomic
                     // would write back the whole L2 (buffer_wbl2) once per workgroup and query: measured 4 ms/query.
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if TKSPMV_RANK_PRIO
+                    // The ticket's value tells this workgroup where it stands in the field: among the first to deliver a
+                    // query, it is ahead of the others; among the last, behind. Workgroups are not equally fast -- the two on a
+                    // CU do not share it evenly (the older one wins the arbitration), and the less a wave does per packet the
+                    // more that shows: with the candidate path switched off the median wave streams a query in 11.5 us while a
+                    // tenth of the workgroups take 26-28 us, and the launch waits for them (tools/batch_trace.py). The rank is
+                    // the feedback: an early workgroup lowers the issue priority of its streaming waves, a late one raises it.
+                    if (!RESIDENT) {
+                        uint32_t rank = 0u;
+                        if (lane == 0) rank = __hip_atomic_fetch_add(B.tickets + 32u * set_of(tail), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        rank = __builtin_amdgcn_readfirstlane(rank);
+                        // pace: 0..3 = sleep per packet (x TKSPMV_PACE_SLEEP x 64 cycles) for the first eighths of the field, 4 = none,
+                        // 5 = none and the higher issue priority (last third)
+                        const uint32_t e8 = 8u * rank / n_wg;  // 0..7
+                        const uint32_t lvl = e8 < 3u ? e8 : (3u * rank >= 2u * n_wg ? 5u : 4u);
+                        if (lane == 0) __hip_atomic_store(&L.pace, lvl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    } else
+#endif
                     if (lane == 0)
                         (void)__hip_atomic_fetch_add(B.tickets + 32u * set_of(tail), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (trw && lane == 0 && TRSLOT(tail) < 3u) trw[4 + TRSLOT(tail)] = __builtin_amdgcn_s_memrealtime();
@@ -531,6 +557,9 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
     float champ = -__builtin_huge_valf();   // per lane: upper bound of the rows finished in those packets
     float carry = 0.0f, min_units = 0.0f;
     uint32_t wcnt = 0u;
+    uint32_t pace = 4u;  // this query's pacing level (server: from the workgroup's rank in the previous query's tickets)
+    bool waited = false;  // this wave has used its bounded wait for a threshold in the current query (long partitions)
+    const bool long_partition = np * (uint32_t)(C / 4) >= 28u;  // ~14 rows finish per 256 entries: > 1.5 lists per query
     uint32_t *mp = L.misc[0];
     uint32_t xbase = 0u;
     StreamParams P = P0;
@@ -558,12 +587,19 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
                     P.ovf_cand = B.ovf_cand(set_of(qc));
                     P.ovf_count = B.ovf_count(set_of(qc));
                     wcnt = 0u;
+                    waited = false;
                     cold = champ_ok;
                     decided = false;
                     redo_owed = false;
                     ncold = 0u;
                     champ = -__builtin_huge_valf();
-#if TKSPMV_ALTERNATE_PRIO
+#if TKSPMV_RANK_PRIO
+                    if (!RESIDENT) {
+                        pace = __builtin_amdgcn_readfirstlane(lds_load(&L.pace));
+                        if (pace == 5u) __builtin_amdgcn_s_setprio(2);
+                        else __builtin_amdgcn_s_setprio(1);
+                    }
+#elif TKSPMV_ALTERNATE_PRIO
                     // The two workgroups of a CU do not share it evenly at equal priority: the older one wins the arbitration
                     // (traced over a 32-query launch: 17.2 against 21.5 us per query), runs ahead, finishes early and leaves
                     // the CU half empty while the launch waits for the slower half. They take turns instead, query by query:
@@ -574,6 +610,14 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
 #endif
                 }
             }
+#if TKSPMV_RANK_PRIO
+            // a workgroup ahead of the field yields: fewer requests from it, more bandwidth for the XCDs that lag
+            if (pace < 3u) {
+                if (pace == 0u) __builtin_amdgcn_s_sleep(3 * TKSPMV_PACE_SLEEP);
+                else if (pace == 1u) __builtin_amdgcn_s_sleep(2 * TKSPMV_PACE_SLEEP);
+                else __builtin_amdgcn_s_sleep(TKSPMV_PACE_SLEEP);
+            }
+#endif
             const uint32_t tau_bits = lds_load(&mp[MISC_TAU]);
             const float tau = __uint_as_float(tau_bits);
             const Reduced<C> Rd = reduce_packet<C, QM>(cur, carry, xbase, P0.fixed_mask);
@@ -590,8 +634,24 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
                                                      __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             } else if (__any(trig >= tau) && !(P0.dbg_flags & 2u)) {
-                const RowSums<C> R = expand<C, INT>(Rd, packet_flags<C, QM>(cur));
-                offer_candidates<C, QM, WAVE_CAP>(P, R, rb_cur, tau, lane, grp_local, publishes, wcand, wcnt, mp);
+                float tau_now = tau;
+                // Long partitions only (more rows per wave and query than its list holds: from ~1.5M rows on 256 CUs). A
+                // wave that runs ahead of its workgroup's exchange has no threshold yet: every row passes, and once the
+                // list is nearly full the rest would pour into the query's overflow list. It is ahead of the others anyway:
+                // it waits for the threshold instead, bounded, once per query (2M rows: 40.4 against 42.1 us per query, 3M:
+                // 58.5 against 60.7; 10M rows: 191 against 206). On shorter partitions the list holds a whole query's rows
+                // and the wait only costs the overlap of consecutive queries, hence the condition.
+                if (long_partition && wcnt + 2u * 64u > WAVE_CAP && tau_bits == __float_as_uint(min_units) && P0.tau_possible && !waited) {
+                    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                    while (lds_load(&mp[MISC_TAU]) == __float_as_uint(min_units) && __builtin_amdgcn_s_memrealtime() - t0 < BATCH_TAU_WAIT)
+                        __builtin_amdgcn_s_sleep(4);
+                    waited = true;
+                    tau_now = __uint_as_float(lds_load(&mp[MISC_TAU]));
+                }
+                if (tau_now == tau || __any(trig >= tau_now)) {
+                    const RowSums<C> R = expand<C, INT>(Rd, packet_flags<C, QM>(cur));
+                    offer_candidates<C, QM, WAVE_CAP>(P, R, rb_cur, tau_now, lane, grp_local, publishes, wcand, wcnt, mp);
+                }
             }
             if (champ_ok && !decided && jc + 3u >= np) {  // (jc == np - 3 in the query's own segment: in a redo, decided is set)
                 decided = true;

@@ -20,6 +20,8 @@ struct ReadProbeParams {
     uint32_t n_parts, n_pass;
     uint32_t map;  // 0: the engine's partition of wave w of workgroup b (w * grid + b); 1, 2: XCD-contiguous variants (tuning runs)
     uint32_t *sink;  // [grid * waves]
+    uint32_t *claim;  // map 3: [n_pass] counters, 32 words apart, zeroed: waves claim their partitions instead of owning them
+    unsigned long long *t_end;  // [grid * waves] (optional) s_memrealtime when the wave has finished its last pass
 };
 
 template <int BPL>  // bytes per lane and packet: 22 (fp32 + 12-bit column words), 24 (fp32, C = 4), 48 (fp32, C = 8), 16 (FIXED20), 12 (byte / half values)
@@ -59,6 +61,37 @@ __global__ void __launch_bounds__(1024) read_probe_kernel(const ReadProbeParams 
         for (uint32_t i = threadIdx.x; i < 1024u; i += blockDim.x) xl[i] = 1.0f + (float)(i & 7u);
         __syncthreads();
     }
+    if (R.map == 4u) {
+        // map 4: the WORKGROUP claims sets of n_waves partitions (one atomic per set, prefetched: the next set is claimed
+        // before the current one is streamed, so the counter's round trip is off the path)
+        __shared__ uint32_t set_lds[2];
+        const uint32_t n_sets = (R.n_parts + n_waves - 1u) / n_waves;
+        for (uint32_t pass = 0; pass < R.n_pass; ++pass) {
+            const uint8_t *base = R.replicas[pass % R.n_replicas];
+            if (threadIdx.x == 0) set_lds[0] = atomicAdd(&R.claim[32u * pass], 1u);
+            __syncthreads();
+            for (uint32_t it = 0;; ++it) {
+                const uint32_t sset = set_lds[it & 1u];
+                if (sset >= n_sets) break;
+                uint32_t nxt = 0u;
+                if (threadIdx.x == 0) nxt = atomicAdd(&R.claim[32u * pass], 1u);
+                const uint32_t p = sset * n_waves + wave;
+                if (p < R.n_parts) {
+                    const uint32_t first = R.part_first[p], count = R.part_count[p];
+                    const uint8_t *pk = base + (size_t)first * PB;
+                    uint32_t i = 0;
+                    for (; i + DEPTH <= count; i += DEPTH) {
+#pragma unroll
+                        for (int j = 0; j < DEPTH; ++j) acc ^= read_probe_packet<BPL>(pk + (size_t)(i + j) * PB, lane);
+                    }
+                    for (; i < count; ++i) acc ^= read_probe_packet<BPL>(pk + (size_t)i * PB, lane);
+                }
+                if (threadIdx.x == 0) set_lds[(it + 1u) & 1u] = nxt;
+                __syncthreads();
+            }
+            __syncthreads();
+        }
+    } else
     for (uint32_t pass = 0; pass < R.n_pass; ++pass) {
         const uint8_t *base = R.replicas[pass % R.n_replicas];
         uint32_t p_first = wave * gridDim.x + blockIdx.x;
@@ -66,7 +99,16 @@ __global__ void __launch_bounds__(1024) read_probe_kernel(const ReadProbeParams 
             const uint32_t xcd = blockIdx.x & 7u, li = blockIdx.x >> 3, per_xcd = (gridDim.x >> 3) * n_waves;
             p_first = xcd * per_xcd + (R.map == 1u ? li * n_waves + wave : wave * (gridDim.x >> 3) + li);
         }
-        for (uint32_t p = p_first; p < R.n_parts; p += n_waves * gridDim.x) {
+        // map 3: every wave CLAIMS its next partition of the pass from one counter (what would dynamic balancing buy? XCDs do
+        // not stream equally fast when all of them ask for all they can take: tools/batch_trace.py)
+        const bool dyn = R.map == 3u;
+        auto claim_next = [&]() -> uint32_t {
+            uint32_t v = 0u;
+            if (lane == 0) v = atomicAdd(&R.claim[32u * pass], 1u);
+            return __builtin_amdgcn_readfirstlane(v);
+        };
+        if (dyn) p_first = claim_next();
+        for (uint32_t p = p_first; p < R.n_parts; p = dyn ? claim_next() : p + n_waves * gridDim.x) {
             const uint32_t first = R.part_first[p], count = R.part_count[p];
             const uint8_t *pk = base + (size_t)first * PB;
             if (WORK < 0) {  // the engine's own per-packet arithmetic (x gathers from LDS, products, segmented scan) on a ring of DEPTH
@@ -118,6 +160,7 @@ __global__ void __launch_bounds__(1024) read_probe_kernel(const ReadProbeParams 
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) acc ^= (uint32_t)__shfl_xor((int)acc, d);
     if (lane == 0) R.sink[blockIdx.x * n_waves + wave] = acc;
+    if (lane == 0 && R.t_end) R.t_end[blockIdx.x * n_waves + wave] = __builtin_amdgcn_s_memrealtime();
 }
 
 }  // namespace tkspmv

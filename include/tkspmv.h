@@ -137,7 +137,7 @@ typedef struct {
     uint64_t algorithmic_bytes;   /* nnz*(sizeof(val)+2) + rows*4 + cols*sizeof(val) + k*8 */
     uint32_t n_packets;
     uint32_t packet_entries;      /* entries per packet = 64 lanes * nnz_per_lane */
-    uint32_t n_wave_partitions;   /* physical row ranges, one per wave */
+    uint32_t n_wave_partitions;   /* physical row ranges: one per wave, or (claim_sets != 0) 8 per claimable set */
     uint32_t packets_per_partition;
     uint32_t grid, block;         /* launch geometry of the streaming kernel */
     uint32_t n_groups;            /* threshold groups publishing maxima */
@@ -150,6 +150,9 @@ typedef struct {
     uint64_t multi_bytes;         /* bytes of the wave-sliced ELL copy the multi-query kernel streams (0 without it) */
     uint32_t pack_us;             /* tkspmv_create: microseconds spent packing (on the device: upload of the COO included) */
     uint32_t pack_on_device;      /* 1: the stream was packed by the device packer (default), 0: by the host packer */
+    uint32_t claim_sets;          /* back-to-back queries run through the claim kernel: the wave partitions form this many sets of 8
+                                     that workgroups claim dynamically (0: one partition per wave, batch kernel) */
+    uint32_t reserved0;
 } tkspmv_info;
 
 typedef struct {
@@ -335,9 +338,10 @@ int tkspmv_sell_pack_device_check(const tkspmv_desc *desc, uint32_t n_wave_parti
  * The reference parses the MatrixMarket text (utils.hpp:380-388, minutes at 10^7 rows) and packs
  * (host_spmv_bscsr.cpp:133-248, `hw_setup_time_ms`) on every run. Here the packed matrix can be written once
  * (".tkspmv": 128-byte header, packet stream, side tables, checksum) and an engine created straight from it.
- * tkspmv_wave_partitions: how many wave partitions tkspmv_create would use on desc->device (pass it to tkspmv_pack
- * as the hint so that the file suits that GPU; a file with MORE partitions than the GPU has streaming waves is
- * rejected with TKSPMV_ERR_UNSUPPORTED, fewer is fine). tkspmv_packed_load: TKSPMV_ERR_IO for a missing, truncated,
+ * tkspmv_wave_partitions: how many streaming waves a launch on desc->device has (pass it to tkspmv_pack as the hint
+ * so that the file suits that GPU; a file with MORE partitions is rejected with TKSPMV_ERR_UNSUPPORTED unless the engine
+ * deals the partitions out dynamically -- fp32 values, at most 1024 columns: tkspmv_info.claim_sets -- where any count
+ * works and tkspmv_create itself cuts ~2 sets of 8 per workgroup; fewer is fine everywhere). tkspmv_packed_load: TKSPMV_ERR_IO for a missing, truncated,
  * inconsistent or corrupted file. tkspmv_create_packed: rows/cols/nnz and the value type come from the packed matrix,
  * everything else (k, device, min_score, first_row, stream_replicas, TKSPMV_Q1_7 vs TKSPMV_Q1_7_WIDE) from desc. */
 int tkspmv_wave_partitions(const tkspmv_desc *desc, uint32_t *n);

@@ -20,7 +20,7 @@ RTOL = 1e-4
 def _expected(pkg, oracle, m, x, k, eng, min_score=0.0, first_row=0):
     info = eng.info()
     C = info["packet_entries"] // 64
-    packed = pkg.Packed(m, k=k, nnz_per_lane=C, n_wave_partitions=info["grid"] * info["block"] // 64)
+    packed = pkg.Packed(m, k=k, nnz_per_lane=C, n_wave_partitions=info["n_wave_partitions"])
     assert packed.info()["n_wave_partitions"] == info["n_wave_partitions"]
     yp, present = oracle.packed_scores(packed.raw(), x, m.rows, C)
     return oracle.select_topk(yp, present, k, min_score, first_row)
@@ -928,15 +928,25 @@ def test_engine_from_packed_file_equals_engine_from_coo(pkg, oracle, tmp_path, p
     t_file = time.perf_counter() - t0
     b()
     vb, ib = b.read_result()
-    assert np.array_equal(ia, ib) and np.array_equal(va, vb)
-    assert a.info()["n_packets"] == b.info()["n_packets"] and a.info()["n_wave_partitions"] == b.info()["n_wave_partitions"]
+    claim = a.info()["claim_sets"] != 0  # fp32: tkspmv_create cuts sets of 8 partitions that workgroups claim (other packet cuts)
+    assert np.array_equal(ia, ib) and (np.allclose(va, vb, rtol=1e-5, atol=0) if claim else np.array_equal(va, vb))
+    if not claim:
+        assert a.info()["n_packets"] == b.info()["n_packets"] and a.info()["n_wave_partitions"] == b.info()["n_wave_partitions"]
     print(f"setup from COO {t_coo * 1e3:.1f} ms, from the packed file {t_file * 1e3:.1f} ms")
-    # a file packed for a bigger launch geometry is refused, a smaller one works (idle waves)
+    # a file packed for a bigger launch geometry is refused -- unless the engine deals partitions out dynamically --, a smaller
+    # one works (idle waves)
     big = pkg.Packed(m, k=100, n_wave_partitions=2 * n_parts, precision=pkg.F32 if precision == "F32" else pkg.Q1_7)
     if big.info()["n_wave_partitions"] > n_parts:
-        with pytest.raises(pkg.TkspmvError) as ei:
-            pkg.SpMV.from_packed(big, k=100, device=0, precision=prec)
-        assert ei.value.status == pkg._lib.ERR_UNSUPPORTED
+        if claim:
+            e2 = pkg.SpMV.from_packed(big, k=100, vec=x, device=0, precision=prec)
+            e2()
+            v2, i2 = e2.read_result()
+            assert np.array_equal(ia, i2) and np.allclose(va, v2, rtol=1e-5, atol=0)
+            e2.close()
+        else:
+            with pytest.raises(pkg.TkspmvError) as ei:
+                pkg.SpMV.from_packed(big, k=100, device=0, precision=prec)
+            assert ei.value.status == pkg._lib.ERR_UNSUPPORTED
     small = pkg.Packed(m, k=100, n_wave_partitions=n_parts // 3, precision=pkg.F32 if precision == "F32" else pkg.Q1_7)
     c = pkg.SpMV.from_packed(small, k=100, vec=x, device=0, precision=prec)
     c()

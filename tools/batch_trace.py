@@ -19,6 +19,8 @@ buf = np.zeros(words, dtype=np.uint64)
 got = C.c_uint64()
 _lib.check(_lib.lib().tkspmv_debug_trace(eng._h, buf.ctypes.data_as(C.POINTER(C.c_uint64)), words, C.byref(got)))
 t = buf.reshape(4, grid + 1, 9, 8).astype(np.int64)
+if os.environ.get("TRACE_NPZ"):
+    np.savez_compressed(os.environ["TRACE_NPZ"], t=t)
 slot = int(np.argmax(t[:, 1:, 0, 0].max(axis=1)))
 w = t[slot]
 base = w[1:, :, 0][w[1:, :, 0] > 0].min()
