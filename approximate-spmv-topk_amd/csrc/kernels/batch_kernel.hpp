@@ -96,8 +96,12 @@ struct BatchLds {
 #ifndef TKSPMV_ALTERNATE_PRIO
 #define TKSPMV_ALTERNATE_PRIO 1
 #endif
+// Pacing by rank (experiment, off): a workgroup among the first to deliver a query sleeps a little per packet, one among the
+// last gets the higher priority. With the candidate path switched off it takes the launch from 18.3-19.6 to 17.2 us per
+// query (the XCDs no longer drift apart); with it on -- the cold phase of every query already acts as a governor -- it costs
+// 0.2-0.5 us (tools/ab_variants.sh, one box).
 #ifndef TKSPMV_RANK_PRIO
-#define TKSPMV_RANK_PRIO 1
+#define TKSPMV_RANK_PRIO 0
 #endif
 #ifndef TKSPMV_PACE_SLEEP
 #define TKSPMV_PACE_SLEEP 4
@@ -193,7 +197,11 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
                 // Polled with a compare-and-swap (which also resets the counter for the next launch): atomics execute
                 // at the device-wide coherence point, whereas a load -- even agent-scope -- can keep hitting a stale
                 // copy of the line in this XCD's L2 (seen: 33 ms on an otherwise idle L2).
-                while (atomicCAS(t, n_stream, 0u) != n_stream) __builtin_amdgcn_s_sleep(RESIDENT ? 4 : 32);
+                // (the last query's selection is the launch's tail: poll it faster)
+                while (atomicCAS(t, n_stream, 0u) != n_stream) {
+                    if (RESIDENT || q + 1u == nq) __builtin_amdgcn_s_sleep(4);
+                    else __builtin_amdgcn_s_sleep(32);
+                }
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 if (RESIDENT && SP0.host_out)  // diagnostics: ticks from "request seen" to "every workgroup has delivered"
                     __hip_atomic_store(&SP0.host_out[2u * SP0.k + 3u], (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_seen), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -241,10 +249,13 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
     // Streaming waves that own a partition (wave w streams partition w * n_wg + bid): only they take part in the
     // per-query protocol. Waves without one leave at once -- spinning at stream priority on every query's x flag, six of
     // them per workgroup on a small matrix, they starved the server wave (585 us per query at 50k rows).
+    // (the server counts them with ONE load instruction -- lane w looks at wave w's partition; a loop of eight dependent
+    //  scalar loads here cost every launch 4-5 us before its first x was staged)
     uint32_t n_active = 0;
-    for (uint32_t w = 0; w < nwaves; ++w) {  // the very test the waves apply to themselves below
-        const uint32_t pw = w * n_wg + bid;
-        if (pw < P0.n_parts && P0.part_count[pw] != 0u) ++n_active;
+    if (is_server) {
+        const uint32_t pw = lane * n_wg + bid;
+        const bool has = lane < nwaves && pw < P0.n_parts && P0.part_count[pw] != 0u;
+        n_active = (uint32_t)__popcll(__ballot(has));
     }
 
     if (is_server) {

@@ -49,9 +49,11 @@ def parse():
     ap.add_argument("--cols", type=int, default=1024)
     ap.add_argument("--nnz", type=int, default=20)
     ap.add_argument("--k", type=int, default=100)
+    ap.add_argument("--config3-rows", type=int, default=10000000,
+                    help="--gpus N > 1: rows of the BASELINE configs[3] matrix sharded over the same GPUs beside the headline (0 = skip)")
     ap.add_argument("--total-rows", type=int, default=0,
-                    help="row-sharded workload (BASELINE configs[3]): rows of the ONE matrix cut across the ranks; "
-                         "default 10000000 when --gpus > 1, off (configs[1]) at --gpus 1")
+                    help="rows of the ONE matrix cut across the ranks (default: --rows, the matrix of the --gpus 1 line); given at "
+                         "--gpus 1 it runs the sharded code path with one shard")
     ap.add_argument("--replicas", type=int, default=4, help="packet-stream copies rotated per query (cache defeat)")
     ap.add_argument("--reps", type=int, default=32, help="repetitions of the timed batch for median / p95 (first 2 dropped)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
@@ -70,6 +72,13 @@ def parse():
                          "or the figure committed under profiles/ (labelled static)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # the child of the live traffic pass
     return ap.parse_args()
+
+
+def workload_name(rows, cols, nnz_per_row, nnz, k, replicas):
+    """config.workload: the same text for the --gpus 1 line and the --gpus N lines of one matrix (how it is spread over GPUs is
+    config.parallelism)."""
+    return (f"{rows}x{cols} gamma nnz/row={nnz_per_row} (nnz={nnz}) K={k} fp32, queries back to back, cache-defeated "
+            f"({replicas} rotating stream copies)")
 
 
 def pct(v, p):
@@ -491,9 +500,9 @@ def bench_single(a, mod, torch, np, dev, local_rank):
     line = {
         "metric": "queries_per_sec", "value": a.steps / elapsed, "unit": "queries/s", "n_gpus": 1,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{a.rows}x{a.cols} gamma nnz/row={a.nnz} (nnz={info['nnz']}) K={a.k} fp32, "
-                               f"queries back to back on one stream, cache-defeated ({a.replicas} rotating stream copies)",
+        # (strong: --gpus N cuts THIS matrix into N row shards -- bench_sharded -- so the total work is fixed as N grows)
+        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": workload_name(a.rows, a.cols, a.nnz, int(info["nnz"]), a.k, a.replicas),
                    "rows": a.rows, "cols": a.cols, "nnz": int(info["nnz"]), "k": a.k, "parallelism": "single GPU",
                    "launch": {"grid": info["grid"], "block": info["block"] + 64,
                               "wave_partitions": info["n_wave_partitions"], "packet_entries": info["packet_entries"]}},
@@ -516,11 +525,22 @@ def bench_single(a, mod, torch, np, dev, local_rank):
 
 # ---- row-sharded: BASELINE configs[3] ---------------------------------------------------------------------------------------
 def bench_sharded(a, mod, torch, np, dev, local_rank, rank, world):
+    """--gpus N strong-scales THE workload of the --gpus 1 line: the same 1M x 1024 matrix (seed 2; every row has its own PRNG
+    streams, so a rank generates exactly its rows of it), cut into N contiguous row shards balanced by nnz. BASELINE configs[3]
+    -- the 10M-row matrix over the same N GPUs -- rides along as the line's `config3` key (--config3-rows 0 skips it)."""
+    line = sharded_leg(a, mod, torch, np, dev, local_rank, rank, world, a.total_rows or a.rows, 2, a.steps, a.warmup)
+    if a.config3_rows > 0 and (world > 1 or a.total_rows == 0):
+        c3 = sharded_leg(a, mod, torch, np, dev, local_rank, rank, world, a.config3_rows, 4, min(a.steps, 256), min(a.warmup, 32))
+        if rank == 0:
+            line["config3"] = {k: c3[k] for k in ("value", "unit", "ms_per_step", "steps", "config", "roofline", "per_rank", "parity_checked")}
+    if rank == 0:
+        print(json.dumps(line))
+
+
+def sharded_leg(a, mod, torch, np, dev, local_rank, rank, world, total_rows, seed, steps, warmup):
     from importlib import import_module
     dist = import_module("torch.distributed")
     dmod = import_module("approximate_spmv_topk_amd.distributed")
-    total_rows = a.total_rows or 10000000
-    seed = 4  # SURVEY 8(d), cfg 4
     shard, (r0, r1), total_nnz = dmod.generate_shard(total_rows, a.cols, a.nnz, "gamma", seed, rank, world)
     xs = np.stack([mod.create_sample_vector(a.cols, True, False, True, 1000 + i) for i in range(a.queries)])
     dxs = torch.from_numpy(xs).to(dev)
@@ -585,11 +605,11 @@ def bench_sharded(a, mod, torch, np, dev, local_rank, rank, world):
                   f"{int((ni != ti).sum())} of {a.k} row ids differ", file=sys.stderr, flush=True)
             sys.exit(5)
     if native is not None:
-        native.run_many(dxs.data_ptr(), a.queries, a.warmup)
+        native.run_many(dxs.data_ptr(), a.queries, warmup)
         native.synchronize()
         sync_all()
         t0 = time.perf_counter()
-        native.run_many(dxs.data_ptr(), a.queries, a.steps)
+        native.run_many(dxs.data_ptr(), a.queries, steps)
         native.synchronize()
         sync_all()
         elapsed = time.perf_counter() - t0
@@ -612,19 +632,19 @@ def bench_sharded(a, mod, torch, np, dev, local_rank, rank, world):
             return sh.step()
 
         with torch.cuda.stream(ts):
-            for i in range(a.warmup):
+            for i in range(warmup):
                 step(i)
         sync_all()
         t0 = time.perf_counter()
         with torch.cuda.stream(ts):
-            for i in range(a.steps):
+            for i in range(steps):
                 ei, ev = step(i)
         sync_all()
         elapsed = time.perf_counter() - t0
         idx, val = ei.cpu().numpy().astype(np.uint32), ev.cpu().numpy()
         exchange = {"kind": "torch.distributed all_gather_into_tensor of 2*K int32 per rank + on-device merge, every step "
                             "(TKSPMV_DIST=torch)"}
-    kernel_ns = eng.time_queries(dxs.data_ptr(), a.queries, min(max(a.steps, 64), 512))  # this rank's local kernel alone
+    kernel_ns = eng.time_queries(dxs.data_ptr(), a.queries, min(max(steps, 64), 512))  # this rank's local kernel alone
     per_rank = [{"rank": rank, "rows": r1 - r0, "first_row": r0, "nnz": int(info["nnz"]), "kernel_us": kernel_ns / 1e3,
                  "algorithmic_bytes": int(info["algorithmic_bytes"]),
                  "frac": info["algorithmic_bytes"] / kernel_ns / HBM_PEAK_GBS}]
@@ -635,24 +655,23 @@ def bench_sharded(a, mod, torch, np, dev, local_rank, rank, world):
         gathered = [None] * world
         dist.all_gather_object(gathered, per_rank[0])
         per_rank = gathered
-    parity_ok, parity = None, None
+    parity_ok, parity, line = None, None, None
     if rank == 0:
         # the merged result of the last timed query against the gold over the WHOLE matrix (built here, outside the timed
         # region, on rank 0 only)
         whole = mod.generate_matrix(total_rows, a.cols, a.nnz, "gamma", seed)
         assert whole.nnz == total_nnz
-        parity_ok, parity = check_parity(mod, whole, xs[(a.steps - 1) % a.queries], a.k, idx, val, None, bit_exact=False)
+        parity_ok, parity = check_parity(mod, whole, xs[(steps - 1) % a.queries], a.k, idx, val, None, bit_exact=False)
         del whole
         slowest = max(per_rank, key=lambda r: r["kernel_us"])
         line = {
-            "metric": "queries_per_sec", "value": a.steps / elapsed, "unit": "queries/s", "n_gpus": world,
-            "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True,
+            "metric": "queries_per_sec", "value": steps / elapsed, "unit": "queries/s", "n_gpus": world,
+            "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[3]: ONE {total_rows}x{a.cols} gamma nnz/row={a.nnz} matrix (nnz={total_nnz}) "
-                                   f"K={a.k} fp32, row-sharded by nnz over {world} GPU(s), per query one RCCL all-gather of K pairs "
-                                   f"per rank + merge; queries back to back, cache-defeated ({a.replicas} rotating stream copies)",
+            "config": {"workload": workload_name(total_rows, a.cols, a.nnz, total_nnz, a.k, a.replicas),
                        "rows": total_rows, "cols": a.cols, "nnz": total_nnz, "k": a.k, "n_shards": world,
-                       "parallelism": f"row-shard x{world}"},
+                       "parallelism": f"row-shard x{world}: ONE matrix cut into {world} contiguous row shards balanced by nnz; per "
+                                      f"query one RCCL all-gather of K (row, score) pairs per rank + merge"},
             "roofline": {"bound": "hbm", "achieved": slowest["algorithmic_bytes"] / (slowest["kernel_us"] * 1e3), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": slowest["frac"], "traffic": None,
                          "kernel": "tkspmv::batch_kernel<4,1024,7> on the slowest rank's shard (per query)",
@@ -660,8 +679,8 @@ def bench_sharded(a, mod, torch, np, dev, local_rank, rank, world):
                          "method": "per rank: one hipEvent pair around a batch of back-to-back local launches, no exchange"},
             "per_rank": per_rank, "exchange": exchange, "parity_checked": parity_ok, "parity": parity,
         }
-        print(json.dumps(line))
     eng.close()
+    return line if rank == 0 else None
 
 
 def main():
