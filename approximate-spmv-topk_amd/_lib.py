@@ -86,10 +86,14 @@ EXPORTED_SYMBOLS = [
     "tkspmv_create_packed",
     "tkspmv_dist_unique_id", "tkspmv_dist_create", "tkspmv_dist_set_batch", "tkspmv_dist_enqueue", "tkspmv_dist_run_many",
     "tkspmv_dist_synchronize", "tkspmv_dist_time_exchange", "tkspmv_dist_read", "tkspmv_dist_destroy", "tkspmv_dist_last_error",
-    "tkspmv_merge_topk",
+    "tkspmv_merge_topk", "tkspmv_merge_topk_batch", "tkspmv_dist_set_host_exchange", "tkspmv_dist_read_batch",
 ]
 
 _lib = None
+
+
+# int (*)(const void *send, void *recv, uint64_t bytes_per_rank, void *user): the host all-gather of the rehearsal exchange
+HOST_ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)
 
 
 def lib():
@@ -158,6 +162,9 @@ def lib():
     L.tkspmv_dist_destroy.argtypes = [vp]
     L.tkspmv_dist_destroy.restype = None
     L.tkspmv_merge_topk.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, vp]
+    L.tkspmv_merge_topk_batch.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp]
+    L.tkspmv_dist_set_host_exchange.argtypes = [vp, HOST_ALLGATHER_FN, vp]
+    L.tkspmv_dist_read_batch.argtypes = [vp, u32p, f32p, C.POINTER(C.c_int32)]
     _lib = L
     return L
 

@@ -126,6 +126,10 @@ struct Dist {
     uint32_t *pend_idx[MAX_BATCH] = {};
     float *pend_val[MAX_BATCH] = {};
     int last_set = -1, last_slot = -1;  // where the most recent query's merged result lands
+    int last_batch_set = -1, last_batch_n = 0;  // the most recently exchanged batch (tkspmv_dist_read_batch)
+    tkspmv_host_allgather_fn host_fn = nullptr;  // rehearsal: the all-gather through host buffers (tkspmv_dist_set_host_exchange)
+    void *host_user = nullptr;
+    std::vector<uint32_t> host_send, host_recv;
 };
 
 }  // namespace tkspmv
@@ -174,6 +178,30 @@ int tkspmv_merge_topk(const uint32_t *dev_gathered, int32_t world, int32_t k, ui
     return TKSPMV_OK;
 }
 
+// The merge of a whole exchange batch as the pipelined step launches it: dev_gathered is [world][n_q][2][k] (what the
+// all-gather of n_q * 2k words per rank leaves behind), one block per query, results to dev_idx / dev_val [n_q][k].
+int tkspmv_merge_topk_batch(const uint32_t *dev_gathered, int32_t world, int32_t n_q, int32_t k, uint32_t *dev_idx, float *dev_val,
+                            void *stream) {
+    if (!dev_gathered || !dev_idx || !dev_val || world < 1 || k < 1 || n_q < 1 || n_q > MAX_BATCH || (uint64_t)world * k > MERGE_MAX)
+        return dfail(TKSPMV_ERR_INVALID, "bad arguments to tkspmv_merge_topk_batch (world * k must be <= 8192, n_q in [1, 32])");
+    hipLaunchKernelGGL(merge_kernel, dim3((uint32_t)n_q), dim3(MERGE_THREADS), 0, (hipStream_t)stream, dev_gathered, (uint32_t)world,
+                       (uint32_t)k, dev_idx, dev_val);
+    DHIP(hipGetLastError());
+    return TKSPMV_OK;
+}
+
+// Rehearsal of the pipelined step without RCCL (which refuses two ranks on one device): the all-gather of dist_flush is replaced
+// by a device-to-host copy of this rank's block, a callback that exchanges host buffers between the ranks (e.g. torch.distributed
+// over gloo), and a host-to-device copy of the gathered blocks -- buffer rotation, events, partial batches and the merge launch
+// are the real ones. send: this rank's n_q * 2k words; recv: room for world such blocks, rank-major.
+int tkspmv_dist_set_host_exchange(tkspmv_dist_t *h, tkspmv_host_allgather_fn fn, void *user) {
+    if (!h) return dfail(TKSPMV_ERR_INVALID, "NULL argument");
+    if (h->d.fill != 0) return dfail(TKSPMV_ERR_STATE, "a batch is open: synchronize first");
+    h->d.host_fn = fn;
+    h->d.host_user = user;
+    return TKSPMV_OK;
+}
+
 int tkspmv_dist_create(tkspmv_dist_t **out, tkspmv_t *engine, const uint8_t *id128, int32_t rank, int32_t world) {
     if (!out || !engine || world < 1 || rank < 0 || rank >= world) return dfail(TKSPMV_ERR_INVALID, "bad arguments");
     *out = nullptr;
@@ -198,7 +226,8 @@ int tkspmv_dist_create(tkspmv_dist_t **out, tkspmv_t *engine, const uint8_t *id1
         if (_e != hipSuccess) return bail(TKSPMV_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e)); \
     } while (0)
     DHIP_OR_BAIL(hipSetDevice(d.device));
-    d.use_nccl = world > 1 || getenv("TKSPMV_DIST_FORCE_NCCL") != nullptr;
+    // (TKSPMV_DIST_NO_NCCL=1: no communicator -- the exchange goes through tkspmv_dist_set_host_exchange's callback)
+    d.use_nccl = (world > 1 && getenv("TKSPMV_DIST_NO_NCCL") == nullptr) || getenv("TKSPMV_DIST_FORCE_NCCL") != nullptr;
     if (d.use_nccl) {
         if (!id128) return bail(TKSPMV_ERR_INVALID, "world > 1 needs the unique id of rank 0");
         std::string err;
@@ -290,7 +319,17 @@ static int dist_flush(Dist &d) {
     }
     DHIP(hipEventRecord(d.ev_comp[b], d.compute));
     DHIP(hipStreamWaitEvent(d.comm_stream, d.ev_comp[b], 0));
-    if (d.use_nccl) {
+    if (d.host_fn) {
+        const size_t words = (size_t)n_q * 2 * d.k;
+        d.host_send.resize(words);
+        d.host_recv.assign(words * d.world, 0u);
+        DHIP(hipMemcpyAsync(d.host_send.data(), d.local[b], words * 4, hipMemcpyDeviceToHost, d.comm_stream));
+        DHIP(hipStreamSynchronize(d.comm_stream));
+        if (d.host_fn(d.host_send.data(), d.host_recv.data(), (uint64_t)words * 4, d.host_user) != 0)
+            return dfail(TKSPMV_ERR_DEVICE, "the host exchange callback failed");
+        DHIP(hipMemcpyAsync(d.gathered[b], d.host_recv.data(), words * 4 * d.world, hipMemcpyHostToDevice, d.comm_stream));
+        DHIP(hipStreamSynchronize(d.comm_stream));  // (host_recv is reused by the next flush)
+    } else if (d.use_nccl) {
         const ncclResult_t rc = g_rccl.AllGather(d.local[b], d.gathered[b], (size_t)n_q * 2 * d.k, ncclInt32, d.comm, d.comm_stream);
         if (rc != ncclSuccess)
             return dfail(TKSPMV_ERR_DEVICE, std::string("ncclAllGather failed: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?"));
@@ -301,6 +340,8 @@ static int dist_flush(Dist &d) {
                        (uint32_t)d.k, d.out_idx[b], d.out_val[b]);
     DHIP(hipGetLastError());
     DHIP(hipEventRecord(d.ev_merge[b], d.comm_stream));
+    d.last_batch_set = b;
+    d.last_batch_n = n_q;
     d.fill = 0;
     ++d.flushes;
     return TKSPMV_OK;
@@ -358,6 +399,20 @@ int tkspmv_dist_read(tkspmv_dist_t *h, uint32_t *idx, float *val, int32_t *n) {
     if (idx) DHIP(hipMemcpy(idx, d.out_idx[b] + off, (size_t)d.k * 4, hipMemcpyDeviceToHost));
     if (val) DHIP(hipMemcpy(val, d.out_val[b] + off, (size_t)d.k * 4, hipMemcpyDeviceToHost));
     if (n) *n = d.k;
+    return TKSPMV_OK;
+}
+
+// Every merged list of the most recently exchanged batch (the open batch is flushed first): idx / val [n_q][k], *n_q queries.
+int tkspmv_dist_read_batch(tkspmv_dist_t *h, uint32_t *idx, float *val, int32_t *n_q) {
+    if (!h || !n_q) return dfail(TKSPMV_ERR_INVALID, "NULL argument");
+    Dist &d = h->d;
+    if (d.steps == 0) return dfail(TKSPMV_ERR_STATE, "no query has been enqueued");
+    int st = tkspmv_dist_synchronize(h);
+    if (st != TKSPMV_OK) return st;
+    const int b = d.last_batch_set;
+    if (idx) DHIP(hipMemcpy(idx, d.out_idx[b], (size_t)d.last_batch_n * d.k * 4, hipMemcpyDeviceToHost));
+    if (val) DHIP(hipMemcpy(val, d.out_val[b], (size_t)d.last_batch_n * d.k * 4, hipMemcpyDeviceToHost));
+    *n_q = d.last_batch_n;
     return TKSPMV_OK;
 }
 

@@ -129,8 +129,8 @@ struct EngineImpl {
     bool can_batch = false;         // batch kernel usable (exchange on, x double-buffered in LDS, 4 entries per lane)
     // Queries per launch of the batch kernel = exchange-state sets allocated. Every set carries an overflow list that must be
     // able to hold EVERY row (a degenerate query -- x = 0, all scores equal -- makes every row a candidate, and the result
-    // must still be exact), 8 B per row: 32 sets up to 4M rows (256 MB at 1M rows); larger matrices get fewer sets so that
-    // the lists stay within 1 GiB -- their queries are long, the launch overhead per query matters proportionally less.
+    // must still be exact), 8 B per row: 256 MB at 1M rows, 2.6 GB at 10M rows -- under 1 % of this GPU's 288 GB either way;
+    // 32 sets up to 64M rows, fewer beyond (the lists stay within 16 GiB).
     int batch_max = BATCH_MAX;
     // Multi-query passes (multi_kernel, desc.multi_q): fp32 values, <= 1024 columns, exchange on. multi_q queries share one
     // pass over the wave-sliced ELL copy of the matrix (wsell.hpp); a group's selection is owed to the next launch (or to
@@ -1123,7 +1123,9 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
         // Exchange-state sets: one block per field, set s at s strides (the batch kernel addresses them that way).
         if (m.can_batch && !m.can_multi && !m.resident_capable) {
             const uint64_t per_set = (uint64_t)m.ovf_cap * 8u;
-            m.batch_max = (int)std::max<uint64_t>(4, std::min<uint64_t>(BATCH_MAX, (1ull << 30) / std::max<uint64_t>(per_set, 1)));
+            // (16 GiB of 288: 32 queries per launch up to 64M rows. Round 2 capped the lists at 1 GiB, which left a 10M-row matrix
+            //  13 queries per launch -- for memory, not for speed.)
+            m.batch_max = (int)std::max<uint64_t>(4, std::min<uint64_t>(BATCH_MAX, (16ull << 30) / std::max<uint64_t>(per_set, 1)));
         }
         if (const char *f = getenv("TKSPMV_BATCH_MAX")) m.batch_max = std::max(1, std::min(BATCH_MAX, atoi(f)));
         const int n_sets_alloc = (m.can_multi || m.resident_capable) ? EngineImpl::N_STATE : (m.can_batch ? m.batch_max : (m.can_defer ? 2 : 1));

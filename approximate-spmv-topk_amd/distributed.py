@@ -142,7 +142,10 @@ class NativeShardedSpMV:
     rank 0's RCCL unique id. Raises TkspmvError (e.g. ERR_UNSUPPORTED when RCCL cannot be loaded): callers fall back
     to ShardedTopK."""
 
-    def __init__(self, engine, device, group=None):
+    def __init__(self, engine, device, group=None, host_exchange=False):
+        """host_exchange=True: rehearsal without RCCL (which refuses two ranks on one device): the all-gather of every exchange
+        batch goes through host buffers and torch.distributed (any backend, e.g. gloo); batches, buffer rotation, events and the
+        merge launch are the real step's (tkspmv_dist_set_host_exchange)."""
         import ctypes as C
         from . import _lib
         self._lib, self._C = _lib, C
@@ -152,7 +155,9 @@ class NativeShardedSpMV:
         rank = dist.get_rank(group) if dist.is_initialized() else 0
         idbuf = (C.c_uint8 * 128)()
         import os
-        if world > 1 or os.environ.get("TKSPMV_DIST_FORCE_NCCL"):
+        if host_exchange:
+            os.environ["TKSPMV_DIST_NO_NCCL"] = "1"
+        if (world > 1 and not host_exchange) or os.environ.get("TKSPMV_DIST_FORCE_NCCL"):
             t = torch.zeros(128, dtype=torch.uint8, device=device)
             if rank == 0:
                 _lib.check_dist(_lib.lib().tkspmv_dist_unique_id(idbuf))
@@ -164,6 +169,26 @@ class NativeShardedSpMV:
         self._h = C.c_void_p()
         _lib.check_dist(_lib.lib().tkspmv_dist_create(C.byref(self._h), engine._h, idbuf, rank, world))
         self.world, self.rank = world, rank
+        self._cb = None
+        if host_exchange:
+            os.environ.pop("TKSPMV_DIST_NO_NCCL", None)
+
+            def _allgather(send, recv, nbytes, user):  # noqa: ARG001
+                try:
+                    n = int(nbytes) // 4
+                    mine = torch.from_numpy(np.ctypeslib.as_array((C.c_int32 * n).from_address(send)).copy())
+                    outs = [torch.empty(n, dtype=torch.int32) for _ in range(world)]
+                    if world > 1:
+                        dist.all_gather(outs, mine, group=group)
+                    else:
+                        outs[0] = mine
+                    np.ctypeslib.as_array((C.c_int32 * (n * world)).from_address(recv))[:] = torch.cat(outs).numpy()
+                    return 0
+                except Exception:  # noqa: BLE001
+                    return 1
+
+            self._cb = _lib.HOST_ALLGATHER_FN(_allgather)
+            _lib.check_dist(_lib.lib().tkspmv_dist_set_host_exchange(self._h, self._cb, None))
 
     def set_batch(self, batch):
         """Queries per exchange (1..32, default 32): one local sequence, one all-gather, one merge launch per batch."""
@@ -193,6 +218,16 @@ class NativeShardedSpMV:
                                                              val.ctypes.data_as(C.POINTER(C.c_float)), C.byref(n)))
         return val, idx
 
+    def read_batch(self):
+        """(val [n_q][k], idx [n_q][k]) of the most recently exchanged batch (flushes the open one first)."""
+        C = self._C
+        idx = np.empty((32, self.k), dtype=np.uint32)
+        val = np.empty((32, self.k), dtype=np.float32)
+        n = C.c_int32()
+        self._lib.check_dist(self._lib.lib().tkspmv_dist_read_batch(self._h, idx.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                                                   val.ctypes.data_as(C.POINTER(C.c_float)), C.byref(n)))
+        return val[:n.value], idx[:n.value]
+
     def close(self):
         if getattr(self, "_h", None):
             self._lib.lib().tkspmv_dist_destroy(self._h)
@@ -203,6 +238,19 @@ class NativeShardedSpMV:
             self.close()
         except Exception:
             pass
+
+
+def merge_topk_batch_device(gathered_i32, world, n_q, k, stream=0):
+    """The native merge kernel as the pipelined step launches it: gathered_i32 is a [world][n_q][2][k] int32 CUDA tensor (what
+    the all-gather of an exchange batch leaves behind); returns (idx int32[n_q][k], val float32[n_q][k])."""
+    import ctypes as C
+    from . import _lib
+    out_idx = torch.zeros((n_q, k), dtype=torch.int32, device=gathered_i32.device)
+    out_val = torch.zeros((n_q, k), dtype=torch.float32, device=gathered_i32.device)
+    _lib.check_dist(_lib.lib().tkspmv_merge_topk_batch(C.c_void_p(gathered_i32.data_ptr()), world, n_q, k,
+                                                       C.c_void_p(out_idx.data_ptr()), C.c_void_p(out_val.data_ptr()),
+                                                       C.c_void_p(int(stream))))
+    return out_idx, out_val
 
 
 def merge_topk_device(gathered_i32, world, k, stream=0):

@@ -261,10 +261,21 @@ int tkspmv_dist_read(tkspmv_dist_t *d, uint32_t *idx, float *val, int32_t *n);
 /* The exchange step alone, for measurement (collective: every rank calls it with the same arguments): `iters` times the
  * all-gather of one full batch (batch x 2k words per rank) + the merge launch, back to back on the communication stream,
  * one hipEvent pair around them. */
+int tkspmv_dist_read_batch(tkspmv_dist_t *d, uint32_t *idx, float *val, int32_t *n_q);  /* every list of the last exchanged batch: [n_q][k] */
 int tkspmv_dist_time_exchange(tkspmv_dist_t *d, int32_t iters, double *ns_per_exchange);
 void tkspmv_dist_destroy(tkspmv_dist_t *d);
 const char *tkspmv_dist_last_error(void);
 /* The merge step alone: dev_gathered = [world][2][k] u32 (row ids, then score bits) -> k best, sort_tuples order. */
+/* The merge of an exchange batch as the pipelined step launches it: dev_gathered [world][n_q][2][k], one block per query,
+ * results [n_q][k] (n_q <= 32). Lifts the host-side merge of host_spmv_bscsr.cpp:399-448 for a batch of queries. */
+int tkspmv_merge_topk_batch(const uint32_t *dev_gathered, int32_t world, int32_t n_q, int32_t k, uint32_t *dev_idx,
+                            float *dev_val, void *stream);
+/* Rehearsal without RCCL (which refuses two ranks on one device): the all-gather of the pipelined step goes through host
+ * buffers and this callback (send: this rank's bytes_per_rank bytes; recv: world such blocks, rank-major; 0 = success);
+ * everything else -- batches, buffer rotation, events, merge launch -- is the real step. With TKSPMV_DIST_NO_NCCL=1
+ * tkspmv_dist_create builds no communicator for world > 1 and the callback is mandatory. */
+typedef int (*tkspmv_host_allgather_fn)(const void *send, void *recv, uint64_t bytes_per_rank, void *user);
+int tkspmv_dist_set_host_exchange(tkspmv_dist_t *d, tkspmv_host_allgather_fn fn, void *user);
 int tkspmv_merge_topk(const uint32_t *dev_gathered, int32_t world, int32_t k, uint32_t *dev_idx, float *dev_val,
                       void *stream);
 

@@ -1112,3 +1112,48 @@ def test_large_k_radix_select_ties_and_batches(pkg, oracle):
         ei, ev = _expected(pkg, oracle, mm, xs[q], 800, eng)
         assert np.array_equal(out_i[q].cpu().numpy().view(np.uint32), ei) and np.array_equal(out_v[q].cpu().numpy(), ev)
     eng.close()
+
+
+def test_degenerate_queries_every_row_a_candidate(pkg, oracle):
+    """x = 0 (every score 0.0 = min_score: every row is a candidate and ties with every other) and all-equal positive scores
+    (identical rows): the exact list by (score desc, row desc) -- the k LARGEST row ids -- through the fused single launch and
+    through the batch kernel, alone and between ordinary queries (the reference's gold keeps whichever tied rows its
+    insertion order favours, gold_algorithms.hpp:219-230; this engine's contract is the total order of sort_tuples)."""
+    import torch
+    k, rows = 100, 200000
+    m = pkg.generate_matrix(rows, 1024, 20, "gamma", 6)
+    x0 = np.zeros(1024, np.float32)
+    xr = pkg.create_sample_vector(1024, True, False, True, 61)
+    eng = pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, vec=x0, k=k, device=0)
+    eng()
+    val, idx = eng.read_result()
+    present = np.zeros(rows, bool)
+    present[m.row] = True
+    want = np.flatnonzero(present)[::-1][:k].astype(np.uint32)  # rows that own an entry, largest ids first
+    assert np.array_equal(idx, want) and np.all(val == 0.0)
+    # the same through the batch kernel: zero vectors between ordinary queries (their lists must be untouched by the flood)
+    xs = np.stack([xr, x0, x0, xr, x0])
+    dxs = torch.from_numpy(xs).cuda()
+    out_i = torch.zeros(5, k, dtype=torch.int32, device="cuda")
+    out_v = torch.zeros(5, k, dtype=torch.float32, device="cuda")
+    eng.enqueue_batch(dxs.data_ptr(), 5, out_i.data_ptr(), out_v.data_ptr())
+    eng.synchronize()
+    oi, ov = out_i.cpu().numpy().astype(np.uint32), out_v.cpu().numpy()
+    gi, gv = oracle.gold_topk(m.row, m.col, m.val, xr, k)
+    for q in (1, 2, 4):
+        assert np.array_equal(oi[q], want) and np.all(ov[q] == 0.0)
+    for q in (0, 3):
+        assert set(oi[q].tolist()) == set(gi.tolist()) and np.allclose(ov[q], gv, rtol=1e-4, atol=0)
+    eng.close()
+    # identical rows: one entry of value 0.5 in column 3 per row, x[3] = 2 -> every score is exactly 1.0
+    rows2 = 150000
+    r = np.arange(rows2, dtype=np.uint32)
+    c = np.full(rows2, 3, np.uint32)
+    v = np.full(rows2, 0.5, np.float32)
+    x1 = np.zeros(1024, np.float32)
+    x1[3] = 2.0
+    eng = pkg.SpMV(r, c, v, rows2, 1024, vec=x1, k=k, device=0)
+    eng()
+    val, idx = eng.read_result()
+    assert np.array_equal(idx, np.arange(rows2 - 1, rows2 - 1 - k, -1, dtype=np.uint32)) and np.all(val == 1.0)
+    eng.close()
