@@ -277,13 +277,13 @@ __device__ __forceinline__ void place(const ScatterParams &P, uint32_t r, unsign
     if ((Precision)P.precision == Precision::F32C12) {
         *reinterpret_cast<float *>(pkt + (size_t)slot * 4) = v;
         // split 12-bit plane (wbscsr.hpp colw12s_*): the entry's bits are OR-ed into the lane's dword A and halfword B of the
-        // zeroed stream (four entries share them; B through the aligned dword that holds it)
+        // zeroed stream (four entries share them; B through the dword it shares with the pair's other lane)
         const uint32_t t = slot & 255u, lane = t >> 2;
         uint32_t *plane = reinterpret_cast<uint32_t *>(pkt + (size_t)P.PE * 4 + (size_t)(slot >> 8) * 384u);
         uint32_t a, b;
         colw12s_bits(t & 3u, cw, a, b);
-        if (a) atomicOr(&plane[lane], a);
-        if (b) atomicOr(&plane[64u + (lane >> 1)], b << ((lane & 1u) * 16u));
+        if (a) atomicOr(&plane[colw12s_a_offset(lane) >> 2], a);
+        if (b) atomicOr(&plane[(lane >> 1) * 3u + 1u], b << ((lane & 1u) * 16u));
         return;
     }
     switch ((Precision)P.precision) {

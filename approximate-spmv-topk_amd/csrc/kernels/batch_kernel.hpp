@@ -550,7 +550,7 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
             }                                                                                                         \
         }                                                                                                             \
         load_packet<C, VT>(pk_a, lane, dst);                                                                          \
-        rb_dst = *row_a;                                                                                              \
+        rb_dst = scalar_load(row_a);                                                                                              \
         if (!req_done && --req_left != 0u) {                                                                          \
             pk_a += P0.packet_bytes;                                                                                  \
             ++row_a;                                                                                                  \

@@ -321,7 +321,7 @@ __global__ void __launch_bounds__(576, 6) claim_kernel(const StreamParams P0, co
             }                                                                                                         \
         }                                                                                                             \
         load_packet<C, VT>(pk_a, lane, dst);                                                                          \
-        rb_dst = *row_a;                                                                                              \
+        rb_dst = scalar_load(row_a);                                                                                              \
         if (req_left != 0u) {                                                                                         \
             info_dst = seg_first;                                                                                     \
             seg_first = 0u;                                                                                           \

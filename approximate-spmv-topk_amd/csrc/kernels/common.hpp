@@ -97,13 +97,23 @@ __device__ __forceinline__ float ubyte_to_float(uint32_t w, int b) {
 }
 constexpr float Q17_UNIT = 0.0078125f;  // 2^-7
 
+// A wave-uniform word of read-only memory through the SCALAR cache (s_load_dword): the row base of a packet is the same for
+// all 64 lanes and only the candidate path looks at it. As a vector load it was one of four vector-memory instructions per
+// packet -- and the streaming kernels turned out to be bound by exactly that: a CU gets through ~70 vector-memory
+// instructions per microsecond whatever their width (the row-per-lane byte kernel ran at 67 and 71 per us and CU with two
+// and with three loads per chunk, 19.6 and 27.8 us per query; the wave-BSCSR batch kernel at 68 with four per packet).
+typedef __attribute__((address_space(4))) const uint32_t scalar_cu32;
+__device__ __forceinline__ uint32_t scalar_load(const uint32_t *uniform_ptr) {
+    return *(scalar_cu32 *)(uintptr_t)uniform_ptr;
+}
+
 // The packet stream is read once per query: nontemporal loads (a plain read kernel over the same bytes gains 12 %
 // from them when the stream comes from HBM, tools/stream_probe.hip).
 template <int C, int VT>
 struct Pkt {
     float v[(VT == 0 || VT == 3 || VT == 4) ? C : 1];  // VT 3: the packed dwords (value | column | flags); cw stays unused
     uint32_t vq[(VT == 1 || VT == 5) ? C / 4 : (VT == 2 ? C / 2 : 1)];  // VT 5: byte values with 12-bit column words (row-per-lane chunks)
-    uint32_t cw[C / 2];  // VT 4: [0] = columns 0-2 (bits 2-11, 12-21, 22-31) + SKIP 0, 1 (bits 0, 1); [1] = column 3 (bits 2-11) + SKIP 2, 3 (bits 0, 1) + ROW_END 0-3 (bits 12-15)
+    uint32_t cw[C / 2];  // VT 4: the two dwords of the pair's 12-byte block that hold the lane's A and the pair's B (split_ab below)
 };
 
 template <int C, int VT>
@@ -122,12 +132,20 @@ __device__ __forceinline__ void load_packet(const uint8_t *__restrict__ pk, uint
             o.v[VT == 4 ? 4 * q + 1 : 0] = f.y;
             o.v[VT == 4 ? 4 * q + 2 : 0] = f.z;
             o.v[VT == 4 ? 4 * q + 3 : 0] = f.w;
-            // split 12-bit plane (wbscsr.hpp colw12s_*): one dword per lane (columns 0-2 + two SKIP flags) and one halfword per
-            // lane (column 3, two SKIP flags, the four ROW_END flags): 256 + 128 contiguous bytes per wave instruction
-            o.cw[2 * q + 0] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(pk + C * 256 + q * 384 + lane * 4));
-            o.cw[2 * q + 1] = __builtin_nontemporal_load(reinterpret_cast<const uint16_t *>(pk + C * 256 + q * 384 + 256 + lane * 2));
+            // split 12-bit plane (wbscsr.hpp colw12s_*), 12 bytes per pair of lanes [A_even][B_even | B_odd << 16][A_odd]: ONE
+            // dwordx2 at a 4-byte boundary per lane -- dwords 0-1 on the even lane, 1-2 on the odd one. cw[0] / cw[1] hold the
+            // two dwords as loaded: reduce_packet picks A and B out of them by the lane's parity.
+            const u32x2_a4 c = __builtin_nontemporal_load(reinterpret_cast<const u32x2_a4 *>(pk + C * 256 + q * 384 + (lane >> 1) * 12 + (lane & 1u) * 4));
+            o.cw[2 * q + 0] = c.x;
+            o.cw[2 * q + 1] = c.y;
         } else if (VT == 5) {
             o.vq[VT == 5 ? q : 0] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(pk + q * 256 + lane * 4));
+            // Back-to-back 12-bit words, two lanes sharing three dwords: one dwordx2 at a 4-byte boundary per lane. Two other
+            // arrangements were measured on BASELINE configs[4] (19.6 us per query as it stands): the split plane of the
+            // wave-BSCSR packets (one dword + one halfword per lane: three loads per chunk, 9 of 29 vector instructions fewer)
+            // took 27.8 us, and a pair-interleaved chunk read with ONE dwordx4 at a 4-byte boundary per lane 37.0 us -- the
+            // kernel is bound by what the vector-memory pipeline does per load (an unaligned wide load counts several
+            // times), not by its vector instructions.
             const u32x2_a4 c = __builtin_nontemporal_load(reinterpret_cast<const u32x2_a4 *>(pk + C * 64 + q * 384 + (lane >> 1) * 12 + (lane & 1u) * 4));
             o.cw[2 * q + 0] = c.x;
             o.cw[2 * q + 1] = c.y;

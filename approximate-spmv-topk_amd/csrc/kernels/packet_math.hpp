@@ -284,12 +284,22 @@ __device__ __forceinline__ RowSums<C> expand(const Reduced<C> &R, const uint32_t
     return out;
 }
 
+// A and B of the split 12-bit plane out of the two dwords a lane loaded (even lane: [A][B_even | B_odd << 16], odd lane:
+// [B_even | B_odd << 16][A]): two selects and one field extraction.
+__device__ __forceinline__ void split_ab(const uint32_t d0, const uint32_t d1, uint32_t &A, uint32_t &B) {
+    const bool odd = (threadIdx.x & 1u) != 0u;  // (lane parity: a wave is 64 consecutive threads)
+    A = odd ? d1 : d0;
+    const uint32_t bw = odd ? d0 : d1;
+    B = odd ? bw >> 16 : bw & 0xFFFFu;
+}
+
 // Flag word (RowSums::fl) of the lane's entries of a packet.
 template <int C, int QM>
 __device__ __forceinline__ uint32_t packet_flags(const Pkt<C, value_type_of(QM)> &cur) {
     constexpr int VT = value_type_of(QM);
     if (VT == 4) {  // split 12-bit plane: ROW_END 0-3 at bits 12-15 of the halfword, SKIP 0, 1 in the dword, 2, 3 in the halfword
-        const uint32_t A = cur.cw[0], B = cur.cw[1];
+        uint32_t A, B;
+        split_ab(cur.cw[0], cur.cw[1], A, B);
         return (B >> 12) | ((A & 3u) << 8) | ((B & 3u) << 10);
     }
     uint32_t fl = 0u;
@@ -334,7 +344,8 @@ __device__ __forceinline__ Reduced<C> reduce_packet(const Pkt<C, value_type_of(Q
         static_assert(QM != 7 || C == 4, "the split 12-bit plane is built for 4 entries per lane");
         uint32_t mask = 0xFFCu;
         asm("" : "+v"(mask));  // (kept in a register: v_and_or_b32 takes no literal)
-        const uint32_t A = cur.cw[0], B = cur.cw[VT == 4 ? 1 : 0];
+        uint32_t A, B;
+        split_ab(cur.cw[0], cur.cw[VT == 4 ? 1 : 0], A, B);
         const uint32_t a0 = and_or(A, mask, xbase), a1 = and_or(A >> 10, mask, xbase), a2 = and_or(A >> 20, mask, xbase),
                        a3 = and_or(B, mask, xbase);
         p[0] = __fmul_rn(cur.v[VT == 4 ? 0 : 0], lds_f32(a0));

@@ -118,7 +118,7 @@ __global__ void __launch_bounds__(576, ((C == 8 && !SCORES) || QM == 7) ? 6 : 5)
             if (np > 0) {
                 const uint32_t iu = ((uint32_t)u < np) ? (uint32_t)u : (np - 1);
                 load_packet<C, VT>(P.packets + (size_t)(p0 + iu) * P.packet_bytes, lane, buf[u]);
-                rbs[u] = P.pkt_row[p0 + iu];
+                rbs[u] = SCORES ? P.pkt_row[p0 + iu] : scalar_load(P.pkt_row + p0 + iu);  // (the SpMV-only variant needs it for every packet)
             }
         }
         rbs[NBUF - 1] = 0u;
@@ -272,7 +272,7 @@ __global__ void __launch_bounds__(576, ((C == 8 && !SCORES) || QM == 7) ? 6 : 5)
                     }
                 }
                 load_packet<C, VT>(pk_a + (size_t)ia * P.packet_bytes, lane, ahead);
-                rb_ahead = P.pkt_row[p0 + ia];
+                rb_ahead = SCORES ? P.pkt_row[p0 + ia] : scalar_load(P.pkt_row + p0 + ia);
             }
             float tau = 0.0f;
             if (!SCORES)

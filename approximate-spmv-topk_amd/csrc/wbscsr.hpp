@@ -93,14 +93,18 @@ TKSPMV_HD inline uint16_t colw12_load(const uint8_t *planes, uint32_t slot) {
     const uint8_t *b = planes + (size_t)(slot >> 8) * 384u + (t * 3u) / 2u;
     return (t & 1u) ? (uint16_t)((b[0] >> 4) | ((uint16_t)b[1] << 4)) : (uint16_t)(b[0] | ((uint16_t)(b[1] & 0x0Fu) << 8));
 }
-// F32C12's plane is SPLIT (round 3): the 384 bytes of a plane of 256 entries are [64 x u32 A][64 x u16 B], lane l (entries
-// 4l .. 4l+3) owning A[l] and B[l]:
+// F32C12's plane is SPLIT (round 3): the 12 bits of a lane's 4 entries (entries 4l .. 4l+3) are one dword A and one halfword B,
 //   A = col0 << 2 | col1 << 12 | col2 << 22 | SKIP0 | SKIP1 << 1
 //   B = col3 << 2 | SKIP2 | SKIP3 << 1 | ROW_END0..3 << 12
-// The same 12 bits per entry, arranged for the kernel: every lane loads one aligned dword and one halfword (no funnel
-// shifts between neighbouring lanes), a column's LDS offset is one or two instructions (mask, or shift + mask), the four
-// row-end masks are single-bit extractions of B and "this lane holds a row end" is B > 0xFFF -- 24 vector instructions
-// fewer per packet than with the back-to-back words.
+// and the 384 bytes of a plane of 256 entries are 32 blocks of 12 bytes, one per PAIR of lanes: [A_even][B_even | B_odd << 16]
+// [A_odd]. A lane loads ONE dwordx2 at a 4-byte boundary -- the even lane the block's dwords 0-1, the odd lane dwords 1-2 -- and
+// has its A and the pair's B word in it. The same 12 bits per entry as the back-to-back words of round 2, arranged for the
+// kernel: no funnel shifts, a column's LDS offset is one or two instructions, the four row-end masks are single-bit
+// extractions of B and "this lane holds a row end" is B > 0xFFF -- 22 vector instructions fewer per packet (DESIGN.md
+// section 3) with the same two vector-memory instructions per packet (a dword plane + a halfword plane, three loads, was
+// measured slower: the kernels are bound by what the vector-memory pipeline does per load).
+TKSPMV_HD inline uint32_t colw12s_a_offset(uint32_t lane) { return (lane >> 1) * 12u + (lane & 1u) * 8u; }        // byte offset of A
+TKSPMV_HD inline uint32_t colw12s_b_offset(uint32_t lane) { return (lane >> 1) * 12u + 4u + (lane & 1u) * 2u; }   // ... of B
 TKSPMV_HD inline void colw12s_bits(uint32_t j, uint16_t cw, uint32_t &a, uint32_t &b) {  // what entry j ORs into A and B
     const uint32_t col = (uint32_t)(cw >> COLW_COL_SHIFT), end = cw & COLW_ROW_END, skip = (cw & COLW_SKIP) ? 1u : 0u;
     a = j == 0u ? ((col << 2) | skip) : (j == 1u ? ((col << 12) | (skip << 1)) : (j == 2u ? (col << 22) : 0u));
@@ -112,20 +116,20 @@ inline void colw12s_store(uint8_t *planes, uint32_t slot, uint16_t cw) {  // int
     uint32_t a, b, A;
     uint16_t Bv;
     colw12s_bits(t & 3u, cw, a, b);
-    std::memcpy(&A, pl + lane * 4u, 4);
-    std::memcpy(&Bv, pl + 256u + lane * 2u, 2);
+    std::memcpy(&A, pl + colw12s_a_offset(lane), 4);
+    std::memcpy(&Bv, pl + colw12s_b_offset(lane), 2);
     A |= a;
     Bv = (uint16_t)(Bv | b);
-    std::memcpy(pl + lane * 4u, &A, 4);
-    std::memcpy(pl + 256u + lane * 2u, &Bv, 2);
+    std::memcpy(pl + colw12s_a_offset(lane), &A, 4);
+    std::memcpy(pl + colw12s_b_offset(lane), &Bv, 2);
 }
 inline uint16_t colw12s_load(const uint8_t *planes, uint32_t slot) {
     const uint32_t t = slot & 255u, lane = t >> 2, j = t & 3u;
     const uint8_t *pl = planes + (size_t)(slot >> 8) * 384u;
     uint32_t A;
     uint16_t Bv;
-    std::memcpy(&A, pl + lane * 4u, 4);
-    std::memcpy(&Bv, pl + 256u + lane * 2u, 2);
+    std::memcpy(&A, pl + colw12s_a_offset(lane), 4);
+    std::memcpy(&Bv, pl + colw12s_b_offset(lane), 2);
     const uint32_t col = j == 0u ? (A >> 2) & 1023u : (j == 1u ? (A >> 12) & 1023u : (j == 2u ? (A >> 22) & 1023u : ((uint32_t)Bv >> 2) & 1023u));
     const uint32_t skip = j == 0u ? (A & 1u) : (j == 1u ? ((A >> 1) & 1u) : (j == 2u ? (Bv & 1u) : ((Bv >> 1) & 1u)));
     const uint32_t end = ((uint32_t)Bv >> (12u + j)) & 1u;

@@ -413,11 +413,11 @@ void oracle_packed_scores(const uint8_t *packets, uint64_t packet_bytes, const u
                     uint32_t at = (j >> 2) * 256 + l * 4 + (j & 3);
                     uint16_t w;
                     if (c12) {
-                        /* split plane: [64 x u32 A][64 x u16 B] per 256 entries; A = col0 << 2 | col1 << 12 | col2 << 22 | SKIP0 |
-                         * SKIP1 << 1, B = col3 << 2 | SKIP2 | SKIP3 << 1 | ROW_END0..3 << 12 (little-endian) */
+                        /* split plane: per PAIR of lanes 12 bytes [A_even][B_even | B_odd << 16][A_odd]; A = col0 << 2 | col1 << 12 |
+                         * col2 << 22 | SKIP0 | SKIP1 << 1, B = col3 << 2 | SKIP2 | SKIP3 << 1 | ROW_END0..3 << 12 (little-endian) */
                         const uint32_t t = at & 255u, ln = t >> 2, jj = t & 3u;
                         const uint8_t *pl = c12p + (size_t)(at >> 8) * 384u;
-                        const uint8_t *ab = pl + ln * 4u, *bb = pl + 256u + ln * 2u;
+                        const uint8_t *ab = pl + (ln >> 1) * 12u + (ln & 1u) * 8u, *bb = pl + (ln >> 1) * 12u + 4u + (ln & 1u) * 2u;
                         const uint32_t A = (uint32_t)ab[0] | ((uint32_t)ab[1] << 8) | ((uint32_t)ab[2] << 16) | ((uint32_t)ab[3] << 24);
                         const uint32_t Bw = (uint32_t)bb[0] | ((uint32_t)bb[1] << 8);
                         const uint32_t col = jj == 0u ? (A >> 2) & 1023u : (jj == 1u ? (A >> 12) & 1023u : (jj == 2u ? (A >> 22) & 1023u : (Bw >> 2) & 1023u));

@@ -167,13 +167,15 @@ def test_fp32_column_words_travel_as_12_bits(pkg, oracle, monkeypatch):
     a16 = np.asarray(r16[0]).reshape(-1, 1536)
     assert np.array_equal(a12[:, :1024], a16[:, :1024])  # the values
     # the split plane, rebuilt here from the 16-bit words (column << 2 | SKIP << 1 | ROW_END), lane l owning entries 4l..4l+3:
-    #   A[l] = col0 << 2 | col1 << 12 | col2 << 22 | SKIP0 | SKIP1 << 1      (64 dwords)
-    #   B[l] = col3 << 2 | SKIP2 | SKIP3 << 1 | ROW_END0..3 << 12            (64 halfwords)
+    #   A[l] = col0 << 2 | col1 << 12 | col2 << 22 | SKIP0 | SKIP1 << 1
+    #   B[l] = col3 << 2 | SKIP2 | SKIP3 << 1 | ROW_END0..3 << 12
     cw16 = a16[:, 1024:].copy().view(np.uint16).astype(np.uint32).reshape(-1, 64, 4)  # [packets][lane][j]
     col, skip, end = cw16 >> 2, (cw16 >> 1) & 1, cw16 & 1
     A = (col[:, :, 0] << 2) | (col[:, :, 1] << 12) | (col[:, :, 2] << 22) | skip[:, :, 0] | (skip[:, :, 1] << 1)
     B = (col[:, :, 3] << 2) | skip[:, :, 2] | (skip[:, :, 3] << 1) | (end[:, :, 0] << 12) | (end[:, :, 1] << 13) | (end[:, :, 2] << 14) | (end[:, :, 3] << 15)
-    plane = np.concatenate([A.astype("<u4").view(np.uint8).reshape(-1, 256), B.astype("<u2").view(np.uint8).reshape(-1, 128)], axis=1)
+    # ... laid out per PAIR of lanes as 12 bytes [A_even][B_even | B_odd << 16][A_odd] (one dwordx2 per lane at a 4-byte boundary)
+    blocks = np.stack([A[:, 0::2], B[:, 0::2] | (B[:, 1::2] << 16), A[:, 1::2]], axis=2)  # [packets][pair][3 dwords]
+    plane = blocks.astype("<u4").view(np.uint8).reshape(-1, 384)
     assert np.array_equal(plane, a12[:, 1024:])
     x = pkg.create_sample_vector(1024, True, False, True, 5)
     y12, pr12 = oracle.packed_scores(r12, x, g.rows, 4)
