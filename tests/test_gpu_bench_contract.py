@@ -30,7 +30,7 @@ def test_headline_line_on_the_drivers_command_line():
                 "dtype", "data", "config", "roofline", "parity_checked", "timing"):
         assert key in d, key
     assert d["metric"] == "queries_per_sec" and d["unit"] == "queries/s" and d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5
-    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32"
+    assert d["higher_is_better"] is True and d["scaling"] == "strong" and d["vs_baseline"] is None and d["dtype"] == "f32"
     assert d["config"]["rows"] == 1000000 and d["config"]["cols"] == 1024 and d["config"]["k"] == 100 and "workload" in d["config"]
     assert d["parity_checked"] is True and d["parity"]["bit_exact_vs_order_matched_oracle"] is True
     r = d["roofline"]
