@@ -105,7 +105,8 @@ struct EngineImpl {
     double rs_n = 0, rs_host = 0, rs_dev = 0, rs_pub = 0, rs_tick = 0;
     float *h_x_dev = nullptr;           // h_x as the device sees it (TKSPMV_HOST_X=direct: kernels read x from host memory)
     bool host_x_direct = false;
-    bool run_events = true;             // TKSPMV_RUN_EVENTS=0 (experiment): tkspmv_run reports host-clock time, no events
+    bool run_events = false;            // TKSPMV_RUN_EVENTS=1: tkspmv_run brackets the fused launch with a hipEvent pair instead of taking the kernel's own duration
+    unsigned long long *d_tstart = nullptr;  // the fused launch's start stamp (SelectParams::t_start)
     // Exchange state of one query in flight (published maxima, threshold word, survivor slots, overflow list).
     // Two sets: with deferred selection, launch q+1 streams into one set while its workgroup 0 selects query q from
     // the other. Everything else uses set 0.
@@ -516,6 +517,7 @@ struct EngineImpl {
         if (to_host) {
             S.host_out = h_res_dev;
             S.host_epoch = ++host_epoch;
+            S.t_start = d_tstart;
         }
         ++launch_counter;
         hipLaunchKernelGGL(kernel_for(false), dim3(grid), dim3(block + 64), 0, s, P, S);
@@ -684,7 +686,7 @@ Engine::~Engine() {
     if (m.stream) (void)hipStreamSynchronize(m.stream);
     void *bufs[] = {m.d_packets, m.d_pkt_row, m.d_part_first, m.d_part_count, m.d_x,
                     m.d_out_idx, m.d_out_val, m.d_scores,     m.d_stats,      m.d_done, m.d_trace, m.d_tickets,
-                    m.d_claim,   m.d_claim_done};
+                    m.d_claim,   m.d_claim_done, m.d_tstart};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     {
@@ -978,6 +980,8 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
     m.collect_stats = getenv("TKSPMV_STATS") != nullptr;
     if (const char *f = getenv("TKSPMV_DBG_FLAGS")) m.dbg_flags = (uint32_t)atoi(f);
     if (const char *f = getenv("TKSPMV_DBG_REPEAT")) m.dbg_repeat = (uint32_t)atoi(f);
+    HIP_TRY(malloc_exchange((void **)&m.d_tstart, 128));
+    HIP_TRY(hipMemset(m.d_tstart, 0, 128));
     HIP_TRY(malloc_exchange((void **)&m.d_done, 9 * 128));
     HIP_TRY(hipMemset(m.d_done, 0, 9 * 128));
     // Fused tail / deferred selection: one workgroup (block + 64 threads) must hold every slot in SEL_PER_THREAD
@@ -1564,7 +1568,11 @@ int Engine::run(double *kernel_ns, std::string &err) {
     }
     if (!seen) HIP_TRY(hipStreamSynchronize(m.stream));
     m.x_pending = false;  // the kernel has read x: the staging copy is free again
-    if (kernel_ns && !events) *kernel_ns = (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_host0).count();
+    if (kernel_ns && !events) {
+        // the kernel's own duration (100 MHz ticks: first workgroup's entry -> result flag), or the host clock if the flag never came
+        if (seen) *kernel_ns = (double)m.h_res[2 * (size_t)m.desc.k + 1] * 10.0;
+        else *kernel_ns = (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_host0).count();
+    }
     if (events) {
         if (seen) {  // the kernel is in its last instructions: the end event follows within a microsecond or two
             hipError_t q;

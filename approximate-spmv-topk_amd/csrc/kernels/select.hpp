@@ -41,6 +41,10 @@ struct SelectParams {
     // host_out[2k + 1] receives the device time of the query in 10 ns ticks.
     uint32_t wt_reset;
     unsigned long long t_seen;
+    // Fused single launch with the host-visible result (tkspmv_run): workgroup 0 stamps the launch's start here (s_memrealtime,
+    // 100 MHz) and the selecting workgroup reports end - start in host_out[2k + 1] -- the kernel's own duration, so that
+    // tkspmv_run needs no hipEvent pair around the launch (two records and a query: ~6 us of the 67 us a query took end to end).
+    unsigned long long *t_start;
 };
 
 constexpr int MAX_GM = 16;  // n_groups_pub <= 1024 => at most 16 published maxima per lane
@@ -255,6 +259,10 @@ __device__ __forceinline__ void select_body(const SelectParams &P, const uint32_
         if (tid == 0) {
             if (P.wt_reset)
                 __hip_atomic_store(&P.host_out[2u * P.k + 1u], (uint32_t)(__builtin_amdgcn_s_memrealtime() - P.t_seen), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            else if (P.t_start)
+                __hip_atomic_store(&P.host_out[2u * P.k + 1u],
+                                   (uint32_t)(__builtin_amdgcn_s_memrealtime() - __hip_atomic_load(P.t_start, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(&P.host_out[2u * P.k], P.host_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     };

@@ -71,6 +71,8 @@ __global__ void __launch_bounds__(576, ((C == 8 && !SCORES) || QM == 7) ? 6 : 5)
     unsigned long long *tr = (!SCORES && dbg_trace) ? dbg_trace + ((size_t)blockIdx.x * 9u + wave) * 8u : nullptr;
     unsigned long long tr0 = 0, tr1 = 0, tr2 = 0, tr3 = 0, tr4 = 0;
     if (tr) tr0 = __builtin_amdgcn_s_memrealtime();
+    if (!SCORES && SP.t_start && blockIdx.x == 0u && tid == 0u)  // (workgroup 0 is dispatched first: the launch's start within a microsecond)
+        __hip_atomic_store(SP.t_start, (unsigned long long)__builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (!SCORES && P.deferred) {
         // The selection of the previous query rides along in workgroup 0 (SP.n_wg = 0: there is none); the others
         // stream. The launch has as many workgroups as fit the GPU at once (two per CU) and the matrix is cut into
