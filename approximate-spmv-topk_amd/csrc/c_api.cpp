@@ -400,14 +400,14 @@ int tkspmv_create_packed(tkspmv_t **out, const tkspmv_packed *p, const tkspmv_de
     d.cols = p->pm.cols;
     d.nnz = p->pm.nnz;
     // desc.precision chooses among the arithmetic modes of the packed value type (only Q1.7 has two)
-    const bool fixed_either = desc->precision == TKSPMV_FIXED && (p->pm.precision == Precision::FIXED || p->pm.precision == Precision::FIXED20);
+    const bool fixed_either = desc->precision == TKSPMV_FIXED && (p->pm.precision == Precision::FIXED || p->pm.precision == Precision::FIXED20 || p->pm.precision == Precision::FIXED26);
     const bool f32_either = desc->precision == TKSPMV_F32 && (p->pm.precision == Precision::F32 || p->pm.precision == Precision::F32C12);
     if (!fixed_either && !f32_either && stream_precision(desc->precision) != p->pm.precision)
         d.precision = (p->pm.precision == Precision::F32 || p->pm.precision == Precision::F32C12)
                           ? TKSPMV_F32
                           : (p->pm.precision == Precision::F16
                                  ? TKSPMV_F16
-                                 : ((p->pm.precision == Precision::FIXED || p->pm.precision == Precision::FIXED20)
+                                 : ((p->pm.precision == Precision::FIXED || p->pm.precision == Precision::FIXED20 || p->pm.precision == Precision::FIXED26)
                                         ? TKSPMV_FIXED
                                         : (p->pm.precision == Precision::Q1_7_RND ? TKSPMV_Q1_7_F32 : TKSPMV_Q1_7)));
     d.fixed_width = (int32_t)p->pm.fixed_width;  // a property of the packed values

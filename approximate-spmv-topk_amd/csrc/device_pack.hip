@@ -274,6 +274,13 @@ __device__ __forceinline__ void place(const ScatterParams &P, uint32_t r, unsign
         *reinterpret_cast<uint32_t *>(pkt + (size_t)slot * 4) = fixed20_word(to_fixed(v, P.fixed_width), (uint32_t)(cw >> COLW_COL_SHIFT), cw & 3u);
         return;
     }
+    if ((Precision)P.precision == Precision::FIXED26) {  // (zeroed stream: the lane's E collects 6 bits from each of its 4 entries)
+        const uint32_t colv = (uint32_t)(cw >> COLW_COL_SHIFT);
+        *reinterpret_cast<uint32_t *>(pkt + (size_t)slot * 4) = fixed26_d(to_fixed(v, P.fixed_width), colv, cw & 3u);
+        const uint32_t e = fixed26_e(slot & 3u, colv);
+        if (e) atomicOr(reinterpret_cast<uint32_t *>(pkt + (size_t)P.PE * 4) + (slot >> 2), e);
+        return;
+    }
     if ((Precision)P.precision == Precision::F32C12) {
         *reinterpret_cast<float *>(pkt + (size_t)slot * 4) = v;
         // split 12-bit plane (wbscsr.hpp colw12s_*): the entry's bits are OR-ed into the lane's dword A and halfword B of the
@@ -354,7 +361,8 @@ std::string pack_wbscsr_device(uint32_t rows, uint32_t cols, uint64_t nnz, const
                                uint32_t min_packets_per_partition, uint32_t fixed_width, DevicePacked &out, int &kind) {
     kind = 1;
     if (C != 4 && C != 8) return "nnz_per_lane must be 4 or 8";
-    if (precision == Precision::FIXED20 ? (fixed_width < 8 || fixed_width > FIXED20_MAX_WIDTH || cols > FIXED20_MAX_COLS)
+    if (precision == Precision::FIXED26 ? (fixed_width < 8 || fixed_width > FIXED26_MAX_WIDTH || cols > FIXED26_MAX_COLS || C != 4)
+        : precision == Precision::FIXED20 ? (fixed_width < 8 || fixed_width > FIXED20_MAX_WIDTH || cols > FIXED20_MAX_COLS)
                                         : (precision == Precision::FIXED ? (fixed_width < 8 || fixed_width > 32) : fixed_width != 0))
         return "fixed_width must be in [8, 32] for fixed-point values (bit-packed: at most 20 bits and 1024 columns) and 0 otherwise";
     if (cols == 0 || cols > MAX_COLS) return "cols must be in [1, 16384]";

@@ -382,7 +382,8 @@ struct EngineImpl {
         if (desc.precision == TKSPMV_Q1_7) return &batch_kernel<4, 1024, 1>;
         if (desc.precision == TKSPMV_Q1_7_WIDE) return &batch_kernel<4, 1024, 2>;
         if (desc.precision == TKSPMV_F16) return &batch_kernel<4, 1024, 3>;
-        if (desc.precision == TKSPMV_FIXED) return pm.precision == Precision::FIXED20 ? &batch_kernel<4, 1024, 6> : &batch_kernel<4, 1024, 4>;
+        if (desc.precision == TKSPMV_FIXED)
+            return pm.precision == Precision::FIXED20 ? &batch_kernel<4, 1024, 6> : (pm.precision == Precision::FIXED26 ? &batch_kernel<4, 1024, 8> : &batch_kernel<4, 1024, 4>);
         if (desc.precision == TKSPMV_Q1_7_F32) return &batch_kernel<4, 1024, 5>;
         if (info.packet_entries == 512) return &batch_kernel<8, 1024, 0>;
         if (pm.precision == Precision::F32C12) return dbg_kernels ? &batch_kernel<4, 1024, 7, true> : &batch_kernel<4, 1024, 7>;
@@ -486,6 +487,8 @@ struct EngineImpl {
         }
         if (desc.precision == TKSPMV_FIXED && pm.precision == Precision::FIXED20)  // bit-packed: at most 1024 columns
             return scores ? &stream_kernel<4, true, 1024, 6> : &stream_kernel<4, false, 1024, 6>;
+        if (desc.precision == TKSPMV_FIXED && pm.precision == Precision::FIXED26)  // five bytes per entry: at most 1024 columns
+            return scores ? &stream_kernel<4, true, 1024, 8> : &stream_kernel<4, false, 1024, 8>;
         if (desc.precision == TKSPMV_FIXED) {
             if (xcols <= 1024) return scores ? &stream_kernel<4, true, 1024, 4> : &stream_kernel<4, false, 1024, 4>;
             if (xcols <= 4096) return scores ? &stream_kernel<4, true, 4096, 4> : &stream_kernel<4, false, 4096, 4>;
@@ -658,7 +661,7 @@ void fill_info(const PackedMatrix &pm, int k, tkspmv_info *out) {
     out->packets_per_partition = pm.packets_per_partition;
     out->k = k;
     // (the bit-packed narrow fixed-point stream is a layout of TKSPMV_FIXED, not a precision of the API)
-    out->precision = pm.precision == Precision::FIXED20 ? (int32_t)Precision::FIXED
+    out->precision = (pm.precision == Precision::FIXED20 || pm.precision == Precision::FIXED26) ? (int32_t)Precision::FIXED
                                                        : (pm.precision == Precision::F32C12 ? (int32_t)Precision::F32 : (int32_t)pm.precision);
     out->fixed_width = pm.fixed_width;
 }
@@ -837,7 +840,7 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
         // A matrix packed earlier (tkspmv_pack / a .tkspmv file): it must describe the same problem and must not have
         // more partitions than this launch geometry has streaming waves (the batch kernel gives every wave one).
         const PackedMatrix &q = *prepacked;
-        const bool fixed_either = d.precision == TKSPMV_FIXED && (q.precision == Precision::FIXED || q.precision == Precision::FIXED20);
+        const bool fixed_either = d.precision == TKSPMV_FIXED && (q.precision == Precision::FIXED || q.precision == Precision::FIXED20 || q.precision == Precision::FIXED26);
         const bool f32_either = d.precision == TKSPMV_F32 && (q.precision == Precision::F32 || q.precision == Precision::F32C12);
         if (q.rows != d.rows || q.cols != d.cols || (!fixed_either && !f32_either && q.precision != stream_precision(d.precision)) ||
             q.C != C || q.fixed_width != fixed_width_of(d)) {
@@ -1733,6 +1736,7 @@ int Engine::time_stream_read(int32_t passes, double *ns_per_pass, std::string &e
         case 24: fn = read_probe_kernel<24>; break;
         case 48: fn = read_probe_kernel<48>; break;
         case 16: fn = read_probe_kernel<16>; break;
+        case 20: fn = read_probe_kernel<20>; break;
         case 12: fn = read_probe_kernel<12>; break;
         default: break;
     }

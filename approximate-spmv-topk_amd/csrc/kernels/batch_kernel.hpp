@@ -326,7 +326,7 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
                     unit_scale = 128.0f * x_scale;
                 } else if (QM == 1) {
                     unit_scale = 128.0f;
-                } else if (QM == 4 || QM == 6) {
+                } else if (QM == 4 || QM == 6 || QM == 8) {
                     unit_scale = 2147483648.0f;
                 }
                 inv_unit_q[par] = 1.0f / unit_scale;
@@ -347,7 +347,7 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
                             reinterpret_cast<uint32_t *>(xl)[i] = to_q1_7_dev(r[u] * x_scale);
                         else if (QM == 6)
                             reinterpret_cast<uint32_t *>(xl)[i] = to_fixed_dev(r[u], P0.fixed_width) >> 12;
-                        else if (QM == 4)
+                        else if (QM == 4 || QM == 8)
                             reinterpret_cast<uint32_t *>(xl)[i] = to_fixed_dev(r[u], P0.fixed_width) >> (P0.fixed_width <= 24u ? 8 : 0);
                         else
                             xl[i] = QM == 5 ? r[u] * Q17_UNIT : r[u];

@@ -81,7 +81,8 @@ typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));  // a
 // QM 6 = fixed point of at most 20 bits, bit-packed (wbscsr.hpp FIXED20): one dword per entry carrying value, column and
 // flags; the arithmetic is QM 4's with both factors as 20-bit integers.
 // QM 7 = fp32 exactly like QM 0, the column words travelling as 12 bits each in a split plane (wbscsr.hpp F32C12): value type 4.
-constexpr int value_type_of(int QM) { return QM == 7 ? 4 : (QM == 6 ? 3 : (QM == 3 ? 2 : ((QM == 1 || QM == 2 || QM == 5) ? 1 : 0))); }  // QM 4: one u32 per value, loaded like fp32
+// QM 8 = fixed point of 21..26 bits in five bytes per entry (wbscsr.hpp FIXED26): value type 6; the arithmetic is QM 4's.
+constexpr int value_type_of(int QM) { return QM == 8 ? 6 : (QM == 7 ? 4 : (QM == 6 ? 3 : (QM == 3 ? 2 : ((QM == 1 || QM == 2 || QM == 5) ? 1 : 0)))); }  // QM 4: one u32 per value, loaded like fp32
 // Byte b (0..3) of a dword as a float: v_cvt_f32_ubyte0..3.
 template <int B>
 __device__ __forceinline__ float ubyte_to_float(uint32_t w) {
@@ -111,7 +112,7 @@ __device__ __forceinline__ uint32_t scalar_load(const uint32_t *uniform_ptr) {
 // from them when the stream comes from HBM, tools/stream_probe.hip).
 template <int C, int VT>
 struct Pkt {
-    float v[(VT == 0 || VT == 3 || VT == 4) ? C : 1];  // VT 3: the packed dwords (value | column | flags); cw stays unused
+    float v[(VT == 0 || VT == 3 || VT == 4 || VT == 6) ? C : 1];  // VT 3, 6: the packed dwords (value | column bits | flags); VT 6: cw[0] = E (column bits 9..4)
     uint32_t vq[(VT == 1 || VT == 5) ? C / 4 : (VT == 2 ? C / 2 : 1)];  // VT 5: byte values with 12-bit column words (row-per-lane chunks)
     uint32_t cw[C / 2];  // VT 4: the two dwords of the pair's 12-byte block that hold the lane's A and the pair's B (split_ab below)
 };
@@ -126,6 +127,13 @@ __device__ __forceinline__ void load_packet(const uint8_t *__restrict__ pk, uint
             o.v[VT == 3 ? 4 * q + 1 : 0] = f.y;
             o.v[VT == 3 ? 4 * q + 2 : 0] = f.z;
             o.v[VT == 3 ? 4 * q + 3 : 0] = f.w;
+        } else if (VT == 6) {  // FIXED26: the lane's four dwords D_j and its dword E
+            const f32x4 f = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(pk + lane * 16));
+            o.v[VT == 6 ? 0 : 0] = f.x;
+            o.v[VT == 6 ? 1 : 0] = f.y;
+            o.v[VT == 6 ? 2 : 0] = f.z;
+            o.v[VT == 6 ? 3 : 0] = f.w;
+            o.cw[0] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(pk + 1024 + lane * 4));
         } else if (VT == 4) {
             const f32x4 f = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(pk + q * 1024 + lane * 16));
             o.v[VT == 4 ? 4 * q + 0 : 0] = f.x;

@@ -305,7 +305,7 @@ __device__ __forceinline__ uint32_t packet_flags(const Pkt<C, value_type_of(QM)>
     uint32_t fl = 0u;
 #pragma unroll
     for (int j = 0; j < C; ++j) {
-        const uint32_t w = VT == 3 ? __float_as_uint(cur.v[VT == 3 ? j : 0]) : (cur.cw[j >> 1] >> (16 * (j & 1)));
+        const uint32_t w = (VT == 3 || VT == 6) ? __float_as_uint(cur.v[(VT == 3 || VT == 6) ? j : 0]) : (cur.cw[j >> 1] >> (16 * (j & 1)));
         fl |= ((w & 1u) << j) | (((w >> 1) & 1u) << (8 + j));
     }
     return fl;
@@ -331,6 +331,33 @@ __device__ __forceinline__ Reduced<C> reduce_packet(const Pkt<C, value_type_of(Q
             asm("v_bfe_u32 %0, %1, 12, 20" : "=v"(v20) : "v"(w));
             asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(hi) : "v"(v20), "v"(xq));
             p[j] = __uint_as_float(__builtin_amdgcn_alignbit(hi, __umul24(v20, xq), 7) & fixed_mask);
+            m[j] = bit_mask<0>(w);
+            any |= w;
+        }
+        return reduce_core<C, true>(p, m, (any & 1u) != 0u, carry);
+    }
+    if (QM == 8) {
+        // Five bytes per entry (wbscsr.hpp FIXED26): D_j = value (bits 31..6) | column bits 3..0 << 2 | flags, E = column bits 9..4
+        // of entry j at bits 6 j. The arithmetic is QM 4's: Q1.31 words, 24-bit multipliers up to 24 bits (x staged shifted down
+        // by 8), quarter-rate 32-bit multiplies for 25 and 26.
+        static_assert(QM != 8 || C == 4, "FIXED26 is built for 4 entries per lane");
+        uint32_t any = 0u;
+        const uint32_t E = cur.cw[0];
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            const uint32_t w = __float_as_uint(cur.v[VT == 6 ? j : 0]);
+            uint32_t hi6;
+            asm("v_bfe_u32 %0, %1, %2, 6" : "=v"(hi6) : "v"(E), "n"(6 * j));
+            const uint32_t xq = lds_u32(xbase + ((w & 0x3Cu) | (hi6 << 6)));
+            const uint32_t vq = w & 0xFFFFFFC0u;
+            if (fixed_mask & 0xFFu) {
+                p[j] = __uint_as_float(__builtin_amdgcn_alignbit(__umulhi(vq, xq), vq * xq, 31) & fixed_mask);
+            } else {
+                uint32_t hi;
+                const uint32_t v24 = vq >> 8;
+                asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(hi) : "v"(v24), "v"(xq));
+                p[j] = __uint_as_float(__builtin_amdgcn_alignbit(hi, __umul24(v24, xq), 15) & fixed_mask);
+            }
             m[j] = bit_mask<0>(w);
             any |= w;
         }
@@ -403,7 +430,7 @@ __device__ __forceinline__ Reduced<C> reduce_packet(const Pkt<C, value_type_of(Q
     return reduce_core<C, QM == 4>(p, m, (any & 0x00010001u) != 0u, carry);  // (QM 6 returned above)
 }
 template <int QM>
-constexpr bool int_sums() { return QM == 4 || QM == 6; }
+constexpr bool int_sums() { return QM == 4 || QM == 6 || QM == 8; }
 
 template <int C, int QM>
 __device__ __forceinline__ float row_score(const RowSums<C> &R, int j) {  // strict Q1.7: the 8-bit wrap of the row sum

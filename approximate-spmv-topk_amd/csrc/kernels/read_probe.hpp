@@ -38,6 +38,10 @@ __device__ __forceinline__ uint32_t read_probe_packet(const uint8_t *__restrict_
             const u32x2 c = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(pk + (BPL / 24) * 1024 + q * 512 + lane * 8));
             acc ^= __float_as_uint(f.x) ^ __float_as_uint(f.y) ^ __float_as_uint(f.z) ^ __float_as_uint(f.w) ^ c.x ^ c.y;
         }
+    } else if (BPL == 20) {  // FIXED26: 16 + 4 bytes per lane
+        const f32x4 f = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(pk + lane * 16));
+        const uint32_t e = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(pk + 1024 + lane * 4));
+        acc ^= __float_as_uint(f.x) ^ __float_as_uint(f.y) ^ __float_as_uint(f.z) ^ __float_as_uint(f.w) ^ e;
     } else if (BPL == 16) {
         const f32x4 f = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(pk + lane * 16));
         acc ^= __float_as_uint(f.x) ^ __float_as_uint(f.y) ^ __float_as_uint(f.z) ^ __float_as_uint(f.w);

@@ -152,7 +152,7 @@ __global__ void __launch_bounds__(576, ((C == 8 && !SCORES) || QM == 7) ? 6 : 5)
         unit_scale = 128.0f * x_scale;
     } else if (QM == 1) {
         unit_scale = 128.0f;
-    } else if (QM == 4 || QM == 6) {
+    } else if (QM == 4 || QM == 6 || QM == 8) {
         unit_scale = 2147483648.0f;  // scores are Q1.31 words converted to fp32
     }
     const float inv_unit = 1.0f / unit_scale;             // exact: unit_scale is a power of two
@@ -163,7 +163,7 @@ __global__ void __launch_bounds__(576, ((C == 8 && !SCORES) || QM == 7) ? 6 : 5)
             reinterpret_cast<uint32_t *>(x_lds)[i] = to_q1_7_dev(xv * x_scale);  // x quantised like the matrix values
         else if (QM == 6)  // bit-packed narrow fixed point: x as a 20-bit integer
             reinterpret_cast<uint32_t *>(x_lds)[i] = to_fixed_dev(xv, P.fixed_width) >> 12;
-        else if (QM == 4)  // W <= 24: as a 24-bit integer (see reduce_packet)
+        else if (QM == 4 || QM == 8)  // W <= 24: as a 24-bit integer (see reduce_packet)
             reinterpret_cast<uint32_t *>(x_lds)[i] = to_fixed_dev(xv, P.fixed_width) >> (P.fixed_width <= 24u ? 8 : 0);
         else
             x_lds[i] = QM == 5 ? xv * Q17_UNIT : xv;

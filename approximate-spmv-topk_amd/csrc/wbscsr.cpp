@@ -39,9 +39,10 @@ std::string pack_wbscsr(uint32_t rows, uint32_t cols, uint64_t nnz, const uint32
                         uint32_t min_packets_per_partition, PackedMatrix &out, int &kind, uint32_t fixed_width) {
     kind = 1;
     if (C != 4 && C != 8) return "nnz_per_lane must be 4 or 8";
-    if (precision == Precision::FIXED20 ? (fixed_width < 8 || fixed_width > FIXED20_MAX_WIDTH || cols > FIXED20_MAX_COLS)
-                                        : (precision == Precision::FIXED ? (fixed_width < 8 || fixed_width > 32) : fixed_width != 0))
-        return "fixed_width must be in [8, 32] for fixed-point values (bit-packed: at most 20 bits and 1024 columns) and 0 otherwise";
+    if (precision == Precision::FIXED26 ? (fixed_width < 8 || fixed_width > FIXED26_MAX_WIDTH || cols > FIXED26_MAX_COLS || C != 4)
+        : precision == Precision::FIXED20 ? (fixed_width < 8 || fixed_width > FIXED20_MAX_WIDTH || cols > FIXED20_MAX_COLS)
+                                          : (precision == Precision::FIXED ? (fixed_width < 8 || fixed_width > 32) : fixed_width != 0))
+        return "fixed_width must be in [8, 32] for fixed-point values (bit-packed: at most 20 / 26 bits, 1024 columns; 26: 4 entries per lane) and 0 otherwise";
     if (cols == 0 || cols > MAX_COLS) return "cols must be in [1, 16384]";
     if (precision == Precision::F32C12 && (cols > F32C12_MAX_COLS || C != 4)) return "12-bit column words need at most 1024 columns and 4 entries per lane";
     if (nnz > 0 && (!row || !col)) return "row/col arrays are NULL";
@@ -166,6 +167,16 @@ std::string pack_wbscsr(uint32_t rows, uint32_t cols, uint64_t nnz, const uint32
                     colw12s_store(pkt + (size_t)PE * 4, slot, cw);
                     continue;
                 }
+                if (precision == Precision::FIXED26) {  // 5 bytes per entry: a dword of the 16-byte plane + 6 bits of the lane's E
+                    const uint32_t colv = (uint32_t)(cw >> COLW_COL_SHIFT);
+                    const uint32_t w = fixed26_d(to_fixed(v, fixed_width), colv, cw & 3u);
+                    std::memcpy(pkt + (size_t)slot * 4, &w, 4);
+                    uint32_t e;
+                    std::memcpy(&e, pkt + (size_t)PE * 4 + (size_t)(slot >> 2) * 4, 4);
+                    e |= fixed26_e(slot & 3u, colv);
+                    std::memcpy(pkt + (size_t)PE * 4 + (size_t)(slot >> 2) * 4, &e, 4);
+                    continue;
+                }
                 if (precision == Precision::F32) {
                     std::memcpy(pkt + (size_t)slot * 4, &v, 4);
                 } else if (precision == Precision::F16) {
@@ -208,12 +219,19 @@ void decode_wbscsr(const PackedMatrix &pm, std::vector<uint32_t> &row, std::vect
                     std::memcpy(&w, pkt + (size_t)s * 4, 4);
                     cw = (uint16_t)(w & 0xFFFu);
                     v = from_fixed(w & 0xFFFFF000u);
+                } else if (pm.precision == Precision::FIXED26) {
+                    uint32_t w, e;
+                    std::memcpy(&w, pkt + (size_t)s * 4, 4);
+                    std::memcpy(&e, pkt + (size_t)PE * 4 + (size_t)(s >> 2) * 4, 4);
+                    const uint32_t colv = ((w >> 2) & 15u) | (((e >> (6u * (s & 3u))) & 63u) << 4);
+                    cw = (uint16_t)((colv << COLW_COL_SHIFT) | (w & 3u));
+                    v = from_fixed(w & 0xFFFFFFC0u);
                 } else if (pm.precision == Precision::F32C12) {
                     cw = colw12s_load(pkt + (size_t)PE * 4, s);
                 } else {
                     std::memcpy(&cw, pkt + (size_t)PE * vb + (size_t)s * 2, 2);
                 }
-                if (pm.precision == Precision::FIXED20) {
+                if (pm.precision == Precision::FIXED20 || pm.precision == Precision::FIXED26) {
                 } else if (pm.precision == Precision::F32 || pm.precision == Precision::F32C12) {
                     std::memcpy(&v, pkt + (size_t)s * 4, 4);
                 } else if (pm.precision == Precision::F16) {
@@ -336,9 +354,11 @@ std::string load_packed(const char *path, PackedMatrix &pm) {
     if ((hd.precision != (uint32_t)Precision::F32 && hd.precision != (uint32_t)Precision::Q1_7 &&
          hd.precision != (uint32_t)Precision::F16 && hd.precision != (uint32_t)Precision::FIXED &&
          hd.precision != (uint32_t)Precision::Q1_7_RND && hd.precision != (uint32_t)Precision::FIXED20 &&
-         hd.precision != (uint32_t)Precision::F32C12) ||
+         hd.precision != (uint32_t)Precision::F32C12 && hd.precision != (uint32_t)Precision::FIXED26) ||
         (hd.precision == (uint32_t)Precision::F32C12 && (hd.cols > F32C12_MAX_COLS || hd.C != 4)) ||
-        (hd.precision == (uint32_t)Precision::FIXED20
+        (hd.precision == (uint32_t)Precision::FIXED26
+             ? (hd.fixed_width < 8 || hd.fixed_width > FIXED26_MAX_WIDTH || hd.cols > FIXED26_MAX_COLS || hd.C != 4)
+         : hd.precision == (uint32_t)Precision::FIXED20
              ? (hd.fixed_width < 8 || hd.fixed_width > FIXED20_MAX_WIDTH || hd.cols > FIXED20_MAX_COLS)
              : (hd.precision == (uint32_t)Precision::FIXED ? (hd.fixed_width < 8 || hd.fixed_width > 32) : hd.fixed_width != 0)) ||
         (hd.C != 4 && hd.C != 8) ||
@@ -404,6 +424,12 @@ std::string load_packed(const char *path, PackedMatrix &pm) {
                     uint32_t w;
                     std::memcpy(&w, out.packets.data() + (size_t)p * hd.packet_bytes + (size_t)s * 4, 4);
                     cw = (uint16_t)(w & 0xFFFu);
+                } else if (hd.precision == (uint32_t)Precision::FIXED26) {
+                    uint32_t w, e;
+                    const uint8_t *pk = out.packets.data() + (size_t)p * hd.packet_bytes;
+                    std::memcpy(&w, pk + (size_t)s * 4, 4);
+                    std::memcpy(&e, pk + (size_t)hd.packet_entries * 4 + (size_t)(s >> 2) * 4, 4);
+                    cw = (uint16_t)(((((w >> 2) & 15u) | (((e >> (6u * (s & 3u))) & 63u) << 4)) << COLW_COL_SHIFT) | (w & 3u));
                 } else if (hd.precision == (uint32_t)Precision::F32C12) {
                     cw = colw12s_load(cwp, s);
                 } else {

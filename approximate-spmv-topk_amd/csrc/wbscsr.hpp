@@ -64,12 +64,20 @@ TKSPMV_HD inline uint32_t slot_to_index(uint32_t s, uint32_t C) {
 // halfword per lane (colw12s_* below; round 2 had the words back to back, which the row-per-lane layout of wsell.hpp
 // still uses: colw12_*). The default for TKSPMV_F32 with cols <= 1024 and 4 entries per lane (TKSPMV_F32_C12=0 keeps
 // 16-bit column words); results are bit-identical either way.
-enum class Precision : int32_t { F32 = 0, Q1_7 = 1, F16 = 3, FIXED = 4, Q1_7_RND = 5, FIXED20 = 6, F32C12 = 7 };
-constexpr uint32_t FIXED20_MAX_WIDTH = 20, FIXED20_MAX_COLS = 1024, F32C12_MAX_COLS = 1024;
+// FIXED26 = fixed point of 21..26 bits with at most 1024 columns in 5 BYTES PER ENTRY (round 3; the reference's 21-, 25- and
+// 26-bit builds, test_spmv_topk.py:42-47: B = 13 entries per 512 bits at 25 bits against 11 at 32, types.hpp:57-79): 26 bits
+// of value + 10 of column + 2 flags = 38 bits. A lane's 4 entries are 5 dwords -- 4 in a plane of 16 bytes per lane, 1 in a
+// plane of 4 bytes per lane (a packet is 1024 + 256 = 1280 bytes):
+//   D_j = value (bits 31..6: the top 26 bits of its left-aligned Q1.31 word) | column bits 3..0 << 2 | SKIP << 1 | ROW_END
+//   E   = column bits 9..4 of entry j at bits 6 j .. 6 j + 5
+// so the value is one mask, the flags sit where FIXED20 has them and the LDS offset of x[col] is (D_j & 0x3C) | field(E) << 6.
+enum class Precision : int32_t { F32 = 0, Q1_7 = 1, F16 = 3, FIXED = 4, Q1_7_RND = 5, FIXED20 = 6, F32C12 = 7, FIXED26 = 8 };
+constexpr uint32_t FIXED20_MAX_WIDTH = 20, FIXED20_MAX_COLS = 1024, F32C12_MAX_COLS = 1024, FIXED26_MAX_WIDTH = 26, FIXED26_MAX_COLS = 1024;
 
 // bytes of a packet per entry, minus the 2 of a column word (FIXED20: 20-bit value + 10-bit column + 2 flags in 4 bytes)
 TKSPMV_HD inline uint32_t value_bytes(Precision p) {
-    return (p == Precision::F32 || p == Precision::FIXED || p == Precision::F32C12) ? 4u : ((p == Precision::F16 || p == Precision::FIXED20) ? 2u : 1u);
+    return (p == Precision::F32 || p == Precision::FIXED || p == Precision::F32C12) ? 4u
+                                                                                      : (p == Precision::FIXED26 ? 3u : ((p == Precision::F16 || p == Precision::FIXED20) ? 2u : 1u));
 }
 // bytes of a packet of PE entries
 TKSPMV_HD inline uint32_t packet_bytes_for(Precision p, uint32_t PE) {
@@ -138,6 +146,10 @@ inline uint16_t colw12s_load(const uint8_t *planes, uint32_t slot) {
 TKSPMV_HD inline uint32_t fixed20_word(uint32_t q_left_aligned, uint32_t col, uint32_t flags) {
     return (q_left_aligned & 0xFFFFF000u) | (col << 2) | flags;
 }
+TKSPMV_HD inline uint32_t fixed26_d(uint32_t q_left_aligned, uint32_t col, uint32_t flags) {  // the entry's dword of the 16-byte plane
+    return (q_left_aligned & 0xFFFFFFC0u) | ((col & 15u) << 2) | flags;
+}
+TKSPMV_HD inline uint32_t fixed26_e(uint32_t j, uint32_t col) { return (col >> 4) << (6u * j); }  // what entry j ORs into the lane's E
 // Value type of the stream for a tkspmv_precision (TKSPMV_Q1_7 and TKSPMV_Q1_7_WIDE share the truncated Q1.7 stream;
 // TKSPMV_Q1_7_F32 streams Q1.7 values rounded to nearest).
 inline Precision stream_precision(int32_t api_precision, uint32_t fixed_width = 0, uint32_t cols = 0, uint32_t C = 0) {
@@ -151,6 +163,10 @@ inline Precision stream_precision(int32_t api_precision, uint32_t fixed_width = 
     if (api_precision == 4 && fixed_width >= 8 && fixed_width <= FIXED20_MAX_WIDTH && cols >= 1 && cols <= FIXED20_MAX_COLS &&
         getenv("TKSPMV_FIXED_UNPACKED") == nullptr)
         return Precision::FIXED20;
+    // 21..26 bits: five bytes per entry (4 entries per lane; C = 0: not known, the one-u32-per-value stream)
+    if (api_precision == 4 && C == 4 && fixed_width > FIXED20_MAX_WIDTH && fixed_width <= FIXED26_MAX_WIDTH && cols >= 1 && cols <= FIXED26_MAX_COLS &&
+        getenv("TKSPMV_FIXED_UNPACKED") == nullptr)
+        return Precision::FIXED26;
     switch (api_precision) {
         case 0: return Precision::F32;
         case 3: return Precision::F16;
