@@ -40,8 +40,8 @@ $(EXE): $(CSRC)/main_topk.cpp $(LIB) $(HDRS)
 	@mkdir -p bin
 	$(HIPCC) -O2 -std=c++17 -ffp-contract=off -o $@ $(CSRC)/main_topk.cpp -L$(PKG) -ltkspmv -Wl,-rpath,'$$ORIGIN/../$(PKG)'
 
-$(ORACLE): oracle/oracle.c oracle/oracle.h
-	$(CC) $(CFLAGS) -shared -o $@ oracle/oracle.c -lm
+$(ORACLE): oracle/oracle.c oracle/hls_model.c oracle/oracle.h
+	$(CC) $(CFLAGS) -shared -o $@ oracle/oracle.c oracle/hls_model.c -lm
 
 ref: $(REF) $(REFHOST)
 $(REF): oracle/ref_shim.cpp

@@ -57,6 +57,84 @@ def ndcg(sw_idx, sw_val, hw_idx, hw_val):
     return dcg / idcg, dcg, idcg
 
 
+def bscsr_packet_size(fixed_width):
+    """BSCSR_PACKET_SIZE of the reference for a value width (types.hpp:57-79): (512 - 1) // (W + 10 + 4) -- 15 entries per 512-bit
+    packet at 20 bits, 13 at 25, 11 at 32."""
+    return (512 - 1) // (int(fixed_width) + 10 + 4)
+
+
+def hls_dataflow_topk(row, scores, rows, k, partitions=32, k_per_list=8, packet_entries=15, limited=4):
+    """The candidate set the reference's HLS cores deliver, from EXACT per-row scores (this engine's SpMV-only kernel in the same
+    arithmetic: `SpMV(..., precision=FIXED, fixed_width=W).scores()`): a host-side transform of the matrix's row structure.
+
+    The design keeps, per partition of ceil(rows / partitions) rows (host_spmv_bscsr.cpp:133-141), `limited` independent lists
+    of k_per_list entries -- one per packet SLOT (spmv_bscsr_top_k_multicore.hpp:331-409): a row that finishes inside a packet
+    of packet_entries entries is offered to list 1 + (row ends before it in that packet); a row whose last entry is the
+    packet's last is offered to list 0 by the next packet; lists `limited` and beyond do not exist, so the 4th and later rows
+    that finish inside one packet are lost, and so is the last row of every partition (its flush is commented out, :396-403).
+    The host keeps every list entry with a positive value, one per row id, and sorts (host_spmv_bscsr.cpp:399-448).
+
+    Not modelled here: a packet with MORE than `limited` row segments also drops the products of the segments beyond and
+    shifts the row ids the core reports for the rest of its partition (:104-149,246-326); `overfull_packets` counts them (0 on
+    the BASELINE matrices at 15 entries per packet) and oracle/hls_model.c restates that part too.
+
+    row: row ids of the row-sorted COO; scores[r]: exact score of row r. Returns (idx, val, info): the merged top-k in
+    sort_tuples order and info = {candidates, lost_rows, overfull_packets}."""
+    row = np.asarray(row, dtype=np.int64)
+    scores = np.asarray(scores, dtype=np.float32)
+    per = (int(rows) + partitions - 1) // partitions
+    part = row // per
+    # position of every entry inside its partition's packet stream
+    first_of_part = np.searchsorted(part, np.arange(partitions + 1))
+    local = np.arange(row.shape[0], dtype=np.int64) - first_of_part[part]
+    pkt = local // packet_entries
+    off = local % packet_entries
+    is_end = np.ones(row.shape[0], bool)
+    is_end[:-1] = row[1:] != row[:-1]
+    part_len = (first_of_part[1:] - first_of_part[:-1])[part]
+    last_of_packet = (off == packet_entries - 1) | (local == part_len - 1)
+    ends = np.flatnonzero(is_end)
+    # row ends before this one inside the same packet of the same partition
+    gkey = part[ends] * (1 << 40) + pkt[ends]
+    first_in_group = np.ones(ends.shape[0], bool)
+    first_in_group[1:] = gkey[1:] != gkey[:-1]
+    rank_in_packet = np.arange(ends.shape[0]) - np.maximum.accumulate(np.where(first_in_group, np.arange(ends.shape[0]), 0))
+    n_packets = (part_len[ends] + packet_entries - 1) // packet_entries
+    at_packet_end = last_of_packet[ends]
+    slot = np.where(at_packet_end, 0, 1 + rank_in_packet)
+    offered = np.where(at_packet_end, pkt[ends] + 1 < n_packets, slot < limited)
+    # segments of a packet = the rows that end in it + the unfinished one behind them (unless its last entry ends a row)
+    all_key = part * (1 << 40) + pkt
+    pk_ids, pk_inv = np.unique(all_key, return_inverse=True)
+    ends_per_packet = np.bincount(pk_inv[ends], minlength=pk_ids.shape[0]) if ends.size else np.zeros(pk_ids.shape[0], np.int64)
+    trailing = np.ones(pk_ids.shape[0], np.int64)
+    trailing[pk_inv[ends[at_packet_end]]] = 0
+    overfull = int((ends_per_packet + trailing > limited).sum())
+    r_ids = row[ends]
+    val = scores[r_ids]
+    keep = offered & (val > 0)
+    lists = part[ends] * limited + slot
+    cand_idx, cand_val = [], []
+    if keep.any():
+        li, ri, vi = lists[keep], r_ids[keep], val[keep]
+        order = np.lexsort((ri, vi, li))  # by list, then value, then row id (ascending)
+        li, ri, vi = li[order], ri[order], vi[order]
+        # rank from the top inside each list
+        idx_in = np.arange(li.shape[0])
+        start = np.ones(li.shape[0], bool)
+        start[1:] = li[1:] != li[:-1]
+        gstart = np.maximum.accumulate(np.where(start, idx_in, 0))
+        size = np.bincount(np.cumsum(start) - 1)[np.cumsum(start) - 1]
+        from_top = size - 1 - (idx_in - gstart)
+        top = from_top < k_per_list
+        cand_idx, cand_val = ri[top], vi[top]
+    cand_idx = np.asarray(cand_idx, dtype=np.uint32)
+    cand_val = np.asarray(cand_val, dtype=np.float32)
+    order = np.lexsort((cand_idx, cand_val))[::-1][:k]  # (value desc, row id desc) = sort_tuples
+    info = {"candidates": int(cand_idx.shape[0]), "lost_rows": int((~offered).sum()), "overfull_packets": overfull}
+    return cand_idx[order], cand_val[order], info
+
+
 def read_result_csv(path):
     """Rows of a result CSV in the GPU-host schema (the one bin/approximate-spmv-mi355x-topk prints), lists decoded."""
     out = []

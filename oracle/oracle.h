@@ -112,4 +112,13 @@ int oracle_cpu_bench(const uint64_t *ptr, const uint32_t *idx, const double *v64
 #ifdef __cplusplus
 }
 #endif
+/* oracle/hls_model.c: the reference's HLS dataflow restated (at most LIMITED_FINISHED_ROWS row segments per packet of B entries,
+ * one K-list per packet slot and partition, last row of a partition never flushed, host merge): spmv_bscsr_top_k_multicore.hpp
+ * :104-149,246-326,331-409 and host_spmv_bscsr.cpp:133-248,399-448. W = FIXED_WIDTH (0: fp32). Returns the number of merged
+ * candidates (at most max_out written), -1 on bad parameters. row_slot [rows] (optional): slot each finished row was offered to,
+ * 0xFF = never offered; row_local [rows] (optional): the partition-local id the kernel gave it. PARITY UNPINNED (see the file). */
+int hls_model_topk(const uint32_t *row, const uint32_t *col, const float *val, uint64_t nnz, uint32_t rows, const float *vec,
+                   uint32_t P, uint32_t B, uint32_t K, uint32_t limited, uint32_t W, uint32_t *out_idx, float *out_val,
+                   uint32_t max_out, uint8_t *row_slot, uint32_t *row_local);
+
 #endif

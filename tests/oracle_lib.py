@@ -269,3 +269,22 @@ def ref_spmv_gold_csr(row, col, val, rows, cols, vec):
     ref().ref_spmv_gold_csr(_p(row, u32p), _p(col, u32p), _p(val, f32p), C.c_ulonglong(row.shape[0]), C.c_uint(rows),
                             C.c_uint(cols), _p(vec, f32p), _p(y, f32p))
     return y[:rows]
+
+
+def hls_model_topk(row, col, val, vec, rows, P, B, K, limited, W, max_out=4096):
+    """The reference's HLS dataflow restated (oracle/hls_model.c): (idx, val) of the merged candidates in sort_tuples order,
+    row_slot [rows] (0xFF = never offered to a list), row_local [rows]."""
+    nnz = row.shape[0]
+    out_idx = np.zeros(max_out, np.uint32)
+    out_val = np.zeros(max_out, np.float32)
+    slot = np.zeros(rows, np.uint8)
+    local = np.zeros(rows, np.uint32)
+    f = oracle().hls_model_topk
+    f.restype = C.c_int
+    n = f(_p(row, u32p), _p(col, u32p), _p(val, f32p), C.c_uint64(nnz), C.c_uint32(rows), _p(vec, f32p), C.c_uint32(P), C.c_uint32(B),
+          C.c_uint32(K), C.c_uint32(limited), C.c_uint32(W), _p(out_idx, u32p), _p(out_val, f32p), C.c_uint32(max_out),
+          slot.ctypes.data_as(C.POINTER(C.c_uint8)), _p(local, u32p))
+    if n < 0:
+        raise ValueError("hls_model_topk: bad parameters")
+    n = min(n, max_out)
+    return out_idx[:n], out_val[:n], slot, local

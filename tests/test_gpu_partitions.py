@@ -114,3 +114,43 @@ def test_partitions_with_ties_batches_and_first_row(pkg, oracle):
         assert out_i[q].cpu().numpy().view(np.uint32).tolist() == want
         assert np.all(out_v[q].cpu().numpy() == np.float32(0.75 * (q + 1)))
     eng.close()
+
+
+@pytest.mark.parametrize("width", [20, 25])
+def test_hls_dataflow_from_the_engines_scores_at_full_size(pkg, oracle, width):
+    """The reference's own operating point -- 32 partitions, 4 slot lists of K = 8 each, packets of (512 - 1) // (W + 14)
+    entries, fixed point of W bits -- on BASELINE configs[2]'s matrix: exact scores from the engine's SpMV-only kernel in that
+    arithmetic, the host-side transform of the row structure (experiments.hls_dataflow_topk), against the plain-C restatement
+    of the HLS dataflow (oracle/hls_model.c: same list, same bits) and, for the record, against the fp32 gold (the paper's
+    96.7-98.4 % precision at 20 bits is the figure of merit, plot_errors / host_spmv_bscsr.cpp:646-650)."""
+    from importlib import import_module
+    ex = import_module("approximate_spmv_topk_amd.experiments")
+    m = pkg.generate_matrix(1000000, 1024, 20, "gamma", 2)
+    B = ex.bscsr_packet_size(width)
+    precisions = []
+    for seed in (11, 12, 13):
+        x = pkg.create_sample_vector(1024, True, False, True, seed)
+        eng = pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, vec=x, k=100, device=0, precision=pkg.FIXED, fixed_width=width)
+        y = eng.scores()
+        eng.close()
+        ei, ev, info = ex.hls_dataflow_topk(m.row, y, m.rows, 100, partitions=32, k_per_list=8, packet_entries=B, limited=4)
+        # (gamma row lengths: a few dozen of the 1.3 million packets hold more than 4 row segments -- there the cores also drop
+        #  products and shift row ids, which the structural transform reports instead of modelling)
+        assert info["overfull_packets"] < 200 and 32 <= info["lost_rows"] < 32 + 4 * 200
+        if seed == 11:
+            ci, cv, slot, local = oracle.hls_model_topk(m.row, m.col, m.val, x, m.rows, 32, B, 8, 4, width)
+            if info["overfull_packets"] == 0:
+                assert np.array_equal(ci[:100], ei) and np.array_equal(cv[:100].view(np.uint32), ev.view(np.uint32))
+            # With overfull packets the restated cores report SHIFTED row ids for the rest of the partition (their row counter
+            # misses a row per such packet, spmv_bscsr_top_k_multicore.hpp:286-289), so the two lists differ by design; the
+            # SCORES the restated cores deliver are still the top scores (within a partition the lost rows aside).
+            gold_i = set(oracle.gold_topk(m.row, m.col, m.val, x, 100)[0].tolist())
+            hls_precision = len(set(ci[:100].tolist()) & gold_i) / 100.0
+            hls_recall_all = len(set(ci.tolist()) & gold_i) / 100.0  # the reference's own figure counts ALL merged candidates (:646-648)
+            assert np.allclose(np.sort(cv[:100])[::-1][:50], np.sort(ev)[::-1][:50], rtol=2e-2)
+        gi, gv = oracle.gold_topk(m.row, m.col, m.val, x, 100)
+        precisions.append(len(set(ei.tolist()) & set(gi.tolist())) / 100.0)
+    print(f"\n[HLS dataflow emulation, {width} bits, 32 partitions x 4 lists x K = 8, {B} entries per packet] precision@100 against "
+          f"the fp32 gold: {precisions} ({info['candidates']} candidates, {info['overfull_packets']} overfull packets); the restated "
+          f"dataflow itself on the first query (row ids shifted behind overfull packets): top-100 {hls_precision}, all candidates {hls_recall_all}")
+    assert min(precisions) >= 0.9
