@@ -103,6 +103,9 @@ struct BatchLds {
 #ifndef TKSPMV_RANK_PRIO
 #define TKSPMV_RANK_PRIO 0
 #endif
+#ifndef TKSPMV_DUAL_EXCHANGE
+#define TKSPMV_DUAL_EXCHANGE 0
+#endif
 #ifndef TKSPMV_PACE_SLEEP
 #define TKSPMV_PACE_SLEEP 4
 #endif
@@ -378,8 +381,16 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
                 if (tail + 1u < staged &&
                     2u * __builtin_amdgcn_readfirstlane(lds_load(&L.misc[tail & 1u][MISC_DONE])) >= n_active)
                     hq = tail + 1u;
+#if TKSPMV_DUAL_EXCHANGE
+                // (experiment: both queries in flight are served in every round -- a wave that runs ahead of its workgroup gets its
+                //  query's threshold as soon as the other workgroups have produced one)
+                const uint32_t sq_first = tail, sq_last = tail + 1u < staged ? tail + 1u : tail;
+                (void)hq;
+                for (uint32_t sq = sq_first; sq <= sq_last; ++sq) {
+#else
                 {
                     const uint32_t sq = hq;
+#endif
                     StreamParams P = P0;
                     P.gmax = B.gmax(set_of(sq));
                     P.tau_g = B.tau_g(set_of(sq));

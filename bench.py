@@ -511,6 +511,12 @@ def bench_single(a, mod, torch, np, dev, local_rank):
                      "traffic_detail": detail,
                      "kernel": "tkspmv::batch_kernel<4,1024,7> (fp32, 12-bit column words; up to 32 queries per launch; figures are per query)",
                      "algorithmic_bytes": int(alg_bytes), "kernel_us": kernel_ns / 1e3, "read_only": read_only,
+                     # what the memory system physically moves (the stream is 5.5 B/nnz, the algorithmic figure counts 6): the
+                     # measured traffic, or the stream's size, over the same kernel time -- `frac` above is the SURVEY 8(d) figure
+                     "physical": {"bytes": float(traffic) if traffic else float(stream_bytes),
+                                  "source": "measured traffic" if traffic else "stream bytes",
+                                  "GBps": (float(traffic) if traffic else float(stream_bytes)) / kernel_ns,
+                                  "frac_of_peak": (float(traffic) if traffic else float(stream_bytes)) / kernel_ns / HBM_PEAK_GBS},
                      "method": "one hipEvent pair on the engine stream around the timed region's back-to-back launches, "
                                "duration = event time / steps. A launch of the batch kernel streams the matrix once per "
                                "query for up to 32 queries (one continuous prefetch pipeline per wave) and selects each "
