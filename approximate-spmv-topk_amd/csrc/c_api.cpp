@@ -230,7 +230,7 @@ int tkspmv_pack(const tkspmv_desc *d, uint32_t n_wave_partitions_hint, tkspmv_pa
     uint32_t C = entries_per_lane_of(*d);
     const Precision sp = stream_precision_of(*d);
     std::string err = pack_wbscsr(d->rows, d->cols, d->nnz, d->row, d->col, d->val, sp, C,
-                                  n_wave_partitions_hint ? n_wave_partitions_hint : 4096u, 4, p->pm, kind,
+                                  n_wave_partitions_hint ? n_wave_partitions_hint : 4096u, min_packets_per_partition_for(d->nnz, C, d->cols), p->pm, kind,
                                   fixed_width_of(*d));
     if (!err.empty()) {
         delete p;
@@ -250,7 +250,8 @@ int tkspmv_pack_device(const tkspmv_desc *d, uint32_t n_wave_partitions_hint, tk
     DevicePacked dp;
     int kind = 0;
     std::string err = pack_wbscsr_device(d->rows, d->cols, d->nnz, d->row, d->col, d->val, stream_precision_of(*d),
-                                         entries_per_lane_of(*d), n_wave_partitions_hint ? n_wave_partitions_hint : 4096u, 4,
+                                         entries_per_lane_of(*d), n_wave_partitions_hint ? n_wave_partitions_hint : 4096u,
+                                         min_packets_per_partition_for(d->nnz, entries_per_lane_of(*d), d->cols),
                                          fixed_width_of(*d), dp, kind);
     if (err.empty()) err = download_device_packed(dp);
     free_device_packed(dp);

@@ -163,6 +163,12 @@ struct EngineImpl {
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     uint32_t *d_tickets = nullptr;  // [BATCH_MAX] x 32 words
+    // prior thresholds of the batch kernel (BatchParams::prior_word): word 0 = the prior, words 32.. = the repair flags
+    uint32_t *d_prior = nullptr;
+    bool use_prior = false;
+    uint32_t use_local = 0;  // workgroup-local thresholds (BatchParams::local: 0 off, 1 / 2: a wave's best / second best packet maximum)
+    uint32_t n_sel_wg = 1;   // selector workgroups of a batch launch (BatchParams::n_selectors): 4 on small matrices
+    float prior_beta = 0.9f, prior_rise = 1.02f;
     // claim_kernel (kernels/claim_kernel.hpp): the matrix is packed into sets of 8 wave partitions that workgroups claim
     bool can_claim = false;
     uint32_t n_claim_sets = 0;
@@ -407,7 +413,20 @@ struct EngineImpl {
             Q.out_val = out_val[q];
         }
         launch_counter += (uint64_t)n;
+        if (use_prior) {
+            B.prior_word = d_prior;
+            B.prior_beta = prior_beta;
+            B.prior_rise = prior_rise;
+        }
+        if (use_prior || use_local) B.repair_flags = d_prior + 32;
+        B.n_selectors = n_sel_wg;
+        B.scratch_stride = (uint64_t)grid * WG_SLOTS + ovf_cap;
+        B.local = use_local;
         hipLaunchKernelGGL(batch_kernel_for(), dim3(grid), dim3(block + 64), 0, s, P, S, B);
+        if (use_prior || use_local) {  // the queries whose guess did not hold, again and without one (nobody flagged: the launch is empty)
+            B.repair = 1u;
+            hipLaunchKernelGGL(batch_kernel_for(), dim3(grid), dim3(block + 64), 0, s, P, S, B);
+        }
     }
     // n <= batch_max queries in one launch of the claim kernel (the matrix dealt out dynamically); results complete in stream
     // order after the launch.
@@ -588,6 +607,8 @@ struct EngineImpl {
         BatchParams B{};
         static_cast<SetAddr &>(B) = set_addr(0);
         B.n_q = 0u;
+        B.n_selectors = n_sel_wg;  // (only the first one works in this mode; the others leave -- the partitions were dealt for grid - n_sel_wg)
+        B.scratch_stride = (uint64_t)grid * WG_SLOTS + ovf_cap;
         B.tickets = d_tickets;
         B.io[0].out_idx = d_out_idx;
         B.io[0].out_val = d_out_val;
@@ -689,7 +710,7 @@ Engine::~Engine() {
     if (m.stream) (void)hipStreamSynchronize(m.stream);
     void *bufs[] = {m.d_packets, m.d_pkt_row, m.d_part_first, m.d_part_count, m.d_x,
                     m.d_out_idx, m.d_out_val, m.d_scores,     m.d_stats,      m.d_done, m.d_trace, m.d_tickets,
-                    m.d_claim,   m.d_claim_done, m.d_tstart};
+                    m.d_claim,   m.d_claim_done, m.d_tstart, m.d_prior};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     {
@@ -814,7 +835,19 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
     // Deferred selection gives workgroup 0 of a back-to-back launch to the previous query's selection: one
     // partition per streaming wave of the remaining grid - 1 workgroups.
     const bool defer_capable = m.grid >= 2 && (uint64_t)m.grid * WG_SLOTS <= (uint64_t)SEL_PER_THREAD * (m.block + 64);
-    const uint32_t n_stream_waves = (m.grid - (defer_capable ? 1u : 0u)) * waves_per_wg;
+    // Small matrices (the shards of a strong-scaled run): a query streams in less time than one selection takes and than a
+    // device-wide threshold needs to form. They get 4 selector workgroups, partitions from 2 packets up (every wave streams:
+    // twice the loads in flight) and -- decided below, once the partitions are known -- workgroup-local thresholds.
+    // TKSPMV_SELECTORS / TKSPMV_MIN_PACKETS / TKSPMV_LOCAL override.
+    const uint64_t packets_lb = d.nnz / (64u * C);
+    const uint64_t small_packets = small_matrix_packets();  // ~500k rows of 20 non-zeros
+    const bool small_matrix = defer_capable && m.grid >= 64u && d.cols <= 1024u && d.impl == TKSPMV_IMPL_STREAM && d.multi_q == 0 &&
+                              d.partitions <= 1 && packets_lb <= small_packets && !getenv("TKSPMV_MULTI_Q") && !getenv("TKSPMV_CLAIM");
+    m.n_sel_wg = small_matrix ? 4u : 1u;
+    if (const char *f = getenv("TKSPMV_SELECTORS")) m.n_sel_wg = (uint32_t)std::max(1, std::min(8, atoi(f)));
+    if (!defer_capable || m.grid < 2u * m.n_sel_wg) m.n_sel_wg = 1u;
+    if (prepacked && prepacked->part_first.size() > (size_t)(m.grid - m.n_sel_wg) * waves_per_wg) m.n_sel_wg = 1u;
+    const uint32_t n_stream_waves = (m.grid - (defer_capable ? m.n_sel_wg : 0u)) * waves_per_wg;
     // (measurement aid, tools/claim_probe.py: more partitions than waves -- only the read probe may run on such an engine)
     // claim_kernel: fp32 values, 4 entries per lane, x of at most 1024 columns, 8 streaming waves per workgroup, no tracing
     // hooks. The matrix is cut into sets of 8 partitions of ~10 packets (at least 2 sets per workgroup, at most 32) instead of
@@ -863,6 +896,7 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
         // with TKSPMV_DEVICE_PACK=0 and serves tkspmv_pack / the .tkspmv files).
         bool on_device = d.nnz > 0;
         if (const char *f = getenv("TKSPMV_DEVICE_PACK")) on_device = on_device && atoi(f) != 0;
+        const uint32_t min_packets = min_packets_per_partition_for(d.nnz, C, d.cols);
         const auto t_pack = std::chrono::steady_clock::now();
         std::string perr;
         if (on_device) {
@@ -870,7 +904,7 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
             // (a multi-query engine packs the same COO a second time below: leave its columns and values in HBM until then)
             dp.keep_coo = d.cols <= SELL_XCOLS && (d.multi_q != 0 || d.impl == TKSPMV_IMPL_ROW_PER_LANE || getenv("TKSPMV_MULTI_Q"));
             perr = pack_wbscsr_device(d.rows, d.cols, d.nnz, d.row, d.col, d.val, stream_precision_of(d), C,
-                                      n_parts_hint, 4, fixed_width_of(d), dp, kind);
+                                      n_parts_hint, min_packets, fixed_width_of(d), dp, kind);
             if (perr.empty()) {
                 m.pm = std::move(dp.meta);
                 m.d_packets = dp.d_packets;
@@ -880,7 +914,7 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
                 m.packed_on_device = true;
             }
         } else {
-            perr = pack_wbscsr(d.rows, d.cols, d.nnz, d.row, d.col, d.val, stream_precision_of(d), C, n_parts_hint, 4,
+            perr = pack_wbscsr(d.rows, d.cols, d.nnz, d.row, d.col, d.val, stream_precision_of(d), C, n_parts_hint, min_packets,
                                m.pm, kind, fixed_width_of(d));
         }
         if (!perr.empty()) {
@@ -896,7 +930,7 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
     // Counted on the workgroups that stream in a sequence launch (grid - 1: workgroup 0 selects). Aim for 4k groups
     // where the 1024-word limit of the exchange allows: with k close to the number of groups the k-th largest maximum
     // is a weak bound (k = 256 on 511 groups ran 2x slower than k = 100).
-    const uint32_t n_pub_wg = m.grid - (defer_capable ? 1u : 0u);
+    const uint32_t n_pub_wg = m.grid - (defer_capable ? m.n_sel_wg : 0u);
     m.gpw = 1;
     while (n_pub_wg * m.gpw < 4u * (uint32_t)d.k && m.gpw < 8 && m.gpw < waves_per_wg && (waves_per_wg % (m.gpw * 2) == 0) &&
            m.grid * m.gpw * 2 <= (uint32_t)MAX_GM * 64)
@@ -910,7 +944,7 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
     {
         // groups (workgroup, local group) whose first wave owns a partition: wave w of streaming workgroup b streams
         // partition w * n_wg + b, where n_wg is the number of streaming workgroups of a sequence launch
-        const uint32_t n_wg = m.grid - (defer_capable ? 1u : 0u), n_parts = (uint32_t)m.pm.part_first.size();
+        const uint32_t n_wg = m.grid - (defer_capable ? m.n_sel_wg : 0u), n_parts = (uint32_t)m.pm.part_first.size();
         m.groups_with_rows = 0;
         for (uint32_t b = 0; b < n_wg; ++b)
             for (uint32_t g = 0; g < m.gpw; ++g) {
@@ -1126,6 +1160,37 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
     }
     HIP_TRY(malloc_exchange((void **)&m.d_tickets, BATCH_MAX * 32 * 4));
     HIP_TRY(hipMemset(m.d_tickets, 0, BATCH_MAX * 32 * 4));
+    HIP_TRY(malloc_exchange((void **)&m.d_prior, (32 + BATCH_MAX) * 4));
+    HIP_TRY(hipMemset(m.d_prior, 0, (32 + BATCH_MAX) * 4));
+    // TKSPMV_PRIOR=1 (opt-in): queries of a batch start from a guessed threshold, verified by the selection
+    if (const char *f = getenv("TKSPMV_PRIOR")) m.use_prior = atoi(f) != 0;
+    if (const char *f = getenv("TKSPMV_PRIOR_BETA")) m.prior_beta = (float)atof(f);
+    if (const char *f = getenv("TKSPMV_PRIOR_RISE")) m.prior_rise = (float)atof(f);
+    m.use_prior = m.use_prior && !m.collect_stats && !getenv("TKSPMV_TRACE") && !getenv("TKSPMV_STAMPS");
+    {
+        // Workgroup-local thresholds pay when they practically never fail the selection's check (a failure costs the query a
+        // second pass). The workgroup's threshold is the smallest of its waves' words; it exceeds the k-th best score when EVERY
+        // streaming wave's word does (a = waves with a partition per workgroup, at least). A wave's word is its best packet
+        // maximum (mode 1: lambda = k / partitions of the k best rows sit in a wave: ~lambda) or its second best (mode 2: two of
+        // them in different packets, ~lambda^2 / 2; a single-packet partition has no second one). Mode 1 forms the threshold a
+        // packet earlier: preferred where it is safe. And a workgroup keeps its 8 best rows: 9 of the k best in one workgroup
+        // fail too (Poisson tail at k / workgroups).
+        const double n_parts = (double)std::max<size_t>(m.pm.part_first.size(), 1), n_wg = (double)(m.grid - m.n_sel_wg);
+        const double lam = std::min(1.0, (double)d.k / n_parts);
+        const double per_part = (double)m.pm.n_packets / n_parts;
+        const double a = std::max(1.0, std::floor(n_parts / n_wg));
+        const double lw = (double)d.k / n_wg;
+        double tail9 = 1.0, term = std::exp(-lw);
+        for (int i = 0; i < 9; ++i) { tail9 -= term; term *= lw / (i + 1); }
+        tail9 = std::max(tail9, 0.0);
+        const double p1 = n_wg * (std::pow(lam, a) + tail9);
+        const double p2 = n_wg * (std::pow(per_part < 1.5 ? lam : std::min(1.0, 0.5 * lam * lam), a) + tail9);
+        m.use_local = !small_matrix ? 0u : (p1 <= 1e-4 ? 1u : (p2 <= 1e-3 ? 2u : 0u));
+        if (getenv("TKSPMV_DEBUG_OCC"))
+            fprintf(stderr, "[tkspmv] small matrix %d: %u selector workgroups, %.0f partitions of %.1f packets, %.0f per workgroup; local thresholds fail with p = %.2e (mode 1) / %.2e (mode 2): mode %u\n",
+                    (int)small_matrix, m.n_sel_wg, n_parts, per_part, a, p1, p2, m.use_local);
+    }
+    if (const char *f = getenv("TKSPMV_LOCAL")) m.use_local = (uint32_t)std::max(0, std::min(2, atoi(f)));
     {
         // Exchange-state sets: one block per field, set s at s strides (the batch kernel addresses them that way).
         if (m.can_batch && !m.can_multi && !m.resident_capable) {
@@ -1148,7 +1213,7 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
         HIP_TRY(hipMemset(E0.wg_cand, 0xFF, ns * m.grid * WG_SLOTS * 8));
         HIP_TRY(hipMalloc((void **)&E0.ovf, ns * m.ovf_cap * 8));
         // the scratch of the selection's general path is used by one selection at a time: shared by all sets
-        HIP_TRY(hipMalloc((void **)&E0.scratch, ((size_t)m.grid * WG_SLOTS + m.ovf_cap) * 8));
+        HIP_TRY(hipMalloc((void **)&E0.scratch, (size_t)m.n_sel_wg * ((size_t)m.grid * WG_SLOTS + m.ovf_cap) * 8));
         HIP_TRY(hipMalloc((void **)&E0.unit_inv, ns * EngineImpl::STATE_WORD_STRIDE * 4));
         std::vector<float> ones(ns * EngineImpl::STATE_WORD_STRIDE, 1.0f);
         HIP_TRY(hipMemcpy(E0.unit_inv, ones.data(), ones.size() * 4, hipMemcpyHostToDevice));
@@ -1200,6 +1265,7 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
     m.info.multi_pack_us = m.sell_pack_us;
     m.info.pack_on_device = m.packed_on_device ? 1u : 0u;
     m.info.claim_sets = m.can_claim ? m.n_claim_sets : 0u;
+    m.info.batch_mode = m.can_batch ? (m.n_sel_wg | (m.use_local << 8)) : 0u;
     HIP_TRY(hipDeviceSynchronize());
     return TKSPMV_OK;
 }

@@ -33,6 +33,7 @@ constexpr uint32_t STG_N = 8;  // survivors a wave can stage per query (64 lanes
 constexpr unsigned long long BATCH_TAU_WAIT = TKSPMV_TAU_WAIT;  // x 10 ns (s_memrealtime runs at 100 MHz)
 constexpr int MISC_DBG_WAITS = 26, MISC_DBG_WAIT_TICKS = 27, MISC_DBG_REDO_PK = 28, MISC_DBG_REDO_WV = 29;  // TKSPMV_STATS=1 only
 constexpr int MISC_XREADY = 2, MISC_MINU = 3;  // batch kernel only: x staged for query (value - 1); min score in units
+constexpr int MISC_TAUKEY = 4;  // local thresholds: order key of the largest threshold formed in this workgroup (what goes on record)
 
 // Per query only what differs from query to query travels in the kernel arguments (32 bytes); the exchange-state set of
 // query q is set 0 plus q strides (the sets are allocated as one block per field), so the argument block stays small (64 queries would fit the 4 KiB limit; 32 are used: longer batches measured no faster).
@@ -60,6 +61,34 @@ struct BatchParams : SetAddr {
     uint32_t n_q;
     uint32_t *tickets;  // [BATCH_MAX] counters, 32 words apart
     BatchIO io[BATCH_MAX];
+    // ---- prior thresholds (round 3; prior_word = NULL: off) ------------------------------------------------------------------
+    // A query starts with a GUESSED threshold -- prior_beta x the k-th best score of the query selected most recently -- instead
+    // of none: no cold phase, nothing appended before the exchange has produced a threshold (a quarter of all packets took the
+    // candidate path for that). Exactness does not rest on the guess: the selection checks that at least k candidates reach
+    // the largest guess any workgroup used (SelectParams::tau0_g; then so does the k-th best score, and nothing that belongs
+    // to the result was dropped below it) and raises the query's repair flag otherwise; every batch launch is followed by a
+    // REPAIR launch of the same kernel (repair = 1) that runs the flagged queries again without a guess -- its workgroups
+    // leave at once when no flag is set.
+    uint32_t *prior_word;     // order key of the lower envelope of the k-th best scores selected so far (0: none yet)
+    uint32_t *repair_flags;   // [BATCH_MAX] written by the selector of the launch (0 / 1), read by the repair launch
+    uint32_t repair;          // 1: this IS the repair launch
+    float prior_beta, prior_rise;
+    // ---- workgroup-local thresholds (round 3; small matrices: shards of a strong-scaled run) -----------------------------------
+    // On a short partition (4-6 packets per wave and query) the device-wide exchange is slower than the query: a threshold takes
+    // three trips through global memory (~8 us) and the waves wait for it before they flush -- 10-11 us per query from 50k to
+    // 250k rows, whatever the size. local = 1: the threshold of a workgroup comes from its OWN waves, through LDS: every
+    // streaming wave publishes the largest (local = 1) or the second largest (local = 2) of the packet maxima it has seen (scores
+    // of distinct rows), and the smallest of the waves' words is the threshold -- as many rows of this workgroup reach it (local =
+    // 2: twice as many; for workgroups with few streaming waves). That is no proof that k
+    // rows of the MATRIX do, so it is checked like a guess: the servers record the largest local threshold in tau0_g, the
+    // selection verifies that k candidates reach it and flags the query for the repair launch otherwise (the host switches the
+    // mode on only where that is a once-in-thousands event: engine.hip).
+    uint32_t local;
+    // Selector workgroups (round 3): blocks 0 .. n_selectors-1 select, selector s the queries s, s + n_selectors, ... One selection
+    // is a chain of four or five trips through global memory (7-10 us): a single selector is the slowest stage of the launch
+    // as soon as a query streams faster than that (below ~500k rows). Each has its own scratch for the general path.
+    uint32_t n_selectors;
+    uint64_t scratch_stride;
     // ---- resident mode (RESIDENT = true; tkspmv_run with desc.impl = TKSPMV_IMPL_RESIDENT) -------------------------------
     // ONE launch serves queries as the host submits them: no launch, no copy engine, no stream synchronisation per query.
     // The host writes x into pinned memory and raises `request` (an epoch counter); the doorman -- wave 0 of the selector
@@ -139,14 +168,35 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t nwaves = (blockDim.x >> 6) - 1u;  // streaming waves
     const bool is_server = (wave == nwaves);
-    const uint32_t nq = RESIDENT ? 0xFFFFFFF0u : B.n_q;
+    // Repair launch: the flagged queries of the launch before, in order (every workgroup derives the same list from the same
+    // flags); none flagged: everybody leaves.
+    __shared__ uint32_t rq_lds[BATCH_MAX + 1];
+    const bool repair = !RESIDENT && B.repair != 0u;
+    if (repair) {
+        if (tid < 64u) {
+            const bool f = tid < B.n_q && __hip_atomic_load(&B.repair_flags[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+            const uint64_t bm = __ballot(f);
+            if (f) rq_lds[__builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u))] = tid;
+            if (tid == 0) rq_lds[BATCH_MAX] = (uint32_t)__popcll(bm);
+        }
+        __syncthreads();
+        if (rq_lds[BATCH_MAX] == 0u) return;
+    }
+    const uint32_t nq = RESIDENT ? 0xFFFFFFF0u : (repair ? rq_lds[BATCH_MAX] : B.n_q);
+    // query q of THIS launch in the launch's argument block (repair: the q-th flagged query of the launch before)
+    auto qx = [&](uint32_t q) __attribute__((always_inline)) -> uint32_t { return repair ? rq_lds[q] : q; };
     // exchange-state set / ticket counter of query q (resident: the sets are reused round robin -- one query is in flight)
-    auto set_of = [](uint32_t q) -> uint32_t { return RESIDENT ? q % (uint32_t)BATCH_MAX : q; };
+    auto set_of = [&](uint32_t q) __attribute__((always_inline)) -> uint32_t { return RESIDENT ? q % (uint32_t)BATCH_MAX : qx(q); };
+    const bool use_prior = !RESIDENT && !repair && B.prior_word != nullptr;
+    const bool local = !RESIDENT && !repair && B.local != 0u;
+    const bool local_top1 = B.local == 1u;  // a wave's word is its best packet maximum (1) or its second best (2)
 
-    if (blockIdx.x == 0u) {
-        // ---- selector workgroup ------------------------------------------------------------------------------
-        const uint32_t n_stream = gridDim.x - 1u;
-        for (uint32_t q = 0; q < nq; ++q) {
+    const uint32_t nsel = B.n_selectors;  // (>= 1)
+    if (blockIdx.x < nsel) {
+        // ---- selector workgroups -----------------------------------------------------------------------------
+        if (RESIDENT && blockIdx.x != 0u) return;  // (one query in flight: one selector, who is also the doorman)
+        const uint32_t n_stream = gridDim.x - nsel;
+        for (uint32_t q = RESIDENT ? 0u : blockIdx.x; q < nq; q += RESIDENT ? 1u : nsel) {
             unsigned long long t_seen = 0ull;
             if (RESIDENT) {
                 // doorman: wait for the host to submit query q (bounded), fetch its x, publish it to the server waves
@@ -195,6 +245,11 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
                 }
                 __syncthreads();
             }
+            const bool tr_sel = P0.trace && q == 4u;  // (tools/batch_trace.py, NQ=8: the phases of one selection)
+            if (tr_sel && tid == 0) {
+                P0.trace[8] = __builtin_amdgcn_s_memrealtime();
+                P0.trace[9] = __builtin_amdgcn_s_memtime();
+            }
             if (tid == 0) {
                 uint32_t *t = B.tickets + 32u * set_of(q);
                 // Polled with a compare-and-swap (which also resets the counter for the next launch): atomics execute
@@ -202,7 +257,7 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
                 // copy of the line in this XCD's L2 (seen: 33 ms on an otherwise idle L2).
                 // (the last query's selection is the launch's tail: poll it faster)
                 while (atomicCAS(t, n_stream, 0u) != n_stream) {
-                    if (RESIDENT || q + 1u == nq) __builtin_amdgcn_s_sleep(4);
+                    if (RESIDENT || local || q + nsel >= nq) __builtin_amdgcn_s_sleep(4);
                     else __builtin_amdgcn_s_sleep(32);
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -216,10 +271,17 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
             S.ovf_count = B.ovf_count(set_of(q));
             S.gmax = B.gmax(set_of(q));
             S.tau_g = B.tau_g(set_of(q));
-            S.scratch = B.scratch;
+            S.scratch = B.scratch + (size_t)blockIdx.x * B.scratch_stride;
             S.unit_inv_in = B.unit_inv(set_of(q));
-            S.out_idx = B.io[RESIDENT ? 0u : q].out_idx;
-            S.out_val = B.io[RESIDENT ? 0u : q].out_val;
+            S.out_idx = B.io[RESIDENT ? 0u : qx(q)].out_idx;
+            S.out_val = B.io[RESIDENT ? 0u : qx(q)].out_val;
+            if (!RESIDENT && B.repair_flags) {
+                S.tau0_g = B.tau_g(set_of(q)) + 32;  // (the set's second 128-byte line)
+                S.repair_flag = repair ? nullptr : &B.repair_flags[q];
+                S.prior_word = B.prior_word;
+                S.prior_rise = B.prior_rise;
+                S.local_thr = local ? 1u : 0u;
+            }
             if (RESIDENT) {
                 S.host_epoch = B.epoch0 + q + 1u;  // (host_out comes with SP0)
                 S.wt_reset = 1u;                   // the sets are reused within this launch: resets must be written through
@@ -229,14 +291,16 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
             //  starts from it -- exact when the same vector comes back, tools/ablate_probe.py: what a threshold that is
             //  there from a query's first packet would be worth: 0.7 us of 20.5 on BASELINE configs[1])
             const uint32_t keep_tau = (DBG && (P0.dbg_flags & 16u)) ? __hip_atomic_load(S.tau_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-            select_body(S, tid, blockDim.x, L.u.sel);
+            if (tr_sel && tid == 0) P0.trace[10] = __builtin_amdgcn_s_memrealtime();
+            select_body(S, tid, blockDim.x, L.u.sel, 0u, tr_sel ? P0.trace + 8 : nullptr);
             __syncthreads();
+            if (tr_sel && tid == 0) P0.trace[15] = __builtin_amdgcn_s_memrealtime();
             if (DBG && (P0.dbg_flags & 16u) && tid == 0) *S.tau_g = keep_tau;
             if (P0.trace && tid == 0 && q < 8u) P0.trace[q] = __builtin_amdgcn_s_memrealtime();
         }
         return;
     }
-    const uint32_t bid = blockIdx.x - 1u, n_wg = gridDim.x - 1u;
+    const uint32_t bid = blockIdx.x - nsel, n_wg = gridDim.x - nsel;
     // traced queries: the first, the middle and the last of the batch
 // traced queries: the first, the middle one and (batches of 8 or more) the one after it, else the last
 #define TRSLOT(q) ((q) == 0u ? 0u : ((q) == nq / 2u ? 1u : ((q) == (nq >= 8u ? nq / 2u + 1u : nq - 1u) ? 2u : 9u)))
@@ -247,7 +311,7 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
     if (tid == 0u) L.pace = 4u;
     __syncthreads();
     const uint32_t grp_local = is_server ? 0u : wave * P0.gpw / nwaves;
-    const bool publishes = (bid * P0.gpw + grp_local) < P0.n_groups_pub;
+    const bool publishes = !local && (bid * P0.gpw + grp_local) < P0.n_groups_pub;  // (local: the waves publish by themselves)
     const bool reducer = bid < P0.n_reducers;
     // Streaming waves that own a partition (wave w streams partition w * n_wg + bid): only they take part in the
     // per-query protocol. Waves without one leave at once -- spinning at stream priority on every query's x flag, six of
@@ -255,10 +319,11 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
     // (the server counts them with ONE load instruction -- lane w looks at wave w's partition; a loop of eight dependent
     //  scalar loads here cost every launch 4-5 us before its first x was staged)
     uint32_t n_active = 0;
-    if (is_server) {
+    bool wave_has = false;  // (lane w: wave w streams a partition -- the server counts them, local thresholds need to know who takes part)
+    if (is_server || local) {
         const uint32_t pw = lane * n_wg + bid;
-        const bool has = lane < nwaves && pw < P0.n_parts && P0.part_count[pw] != 0u;
-        n_active = (uint32_t)__popcll(__ballot(has));
+        wave_has = lane < nwaves && pw < P0.n_parts && P0.part_count[pw] != 0u;
+        n_active = (uint32_t)__popcll(__ballot(wave_has));
     }
 
     if (is_server) {
@@ -268,7 +333,8 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
 #if TKSPMV_ALL_SERVERS_PRIO
         __builtin_amdgcn_s_setprio(3);
 #else
-        if (reducer) __builtin_amdgcn_s_setprio(3);
+        // (local thresholds: the query is short and the workgroup's waves wait for this wave's next x: it must not queue behind them)
+        if (reducer || local) __builtin_amdgcn_s_setprio(3);
 #endif
         uint32_t staged = 0u, tail = 0u;
         uint32_t published = RESIDENT ? 0u : nq;  // queries whose x is available (resident: as the doorman publishes them)
@@ -296,7 +362,9 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
             }
             if (staged < nq && staged < published && staged - tail < 2u) {
                 const uint32_t par = staged & 1u;
-                const float *xg = RESIDENT ? reinterpret_cast<const float *>(B.xr + (size_t)par * XCOLS) : B.io[staged].x;
+                const float *xg = RESIDENT ? reinterpret_cast<const float *>(B.xr + (size_t)par * XCOLS) : B.io[qx(staged)].x;
+                // the guess for this query (issued here, used below: its round trip overlaps the loads of x)
+                const uint32_t prior_key = use_prior ? __hip_atomic_load(B.prior_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
                 // (resident: the two device-side copies of x are rewritten in place query after query; they live in fine-
                 //  grained memory and are read with agent-scope loads, so no cache can serve a previous query's x)
                 auto x_at = [&](uint32_t i) __attribute__((always_inline)) -> float {
@@ -361,6 +429,14 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
                 if (lane < 8u) L.stg_cnt[par][lane] = 0u;
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                 float tau_init = min_units_q[par];
+                if (prior_key != 0u) {
+                    const float t0 = key_to_float(prior_key) * unit_scale * B.prior_beta;  // (reported score -> this query's units)
+                    if (t0 > 0.0f && t0 > tau_init) {
+                        tau_init = t0;
+                        if (lane == 0)
+                            (void)__hip_atomic_fetch_max(B.tau_g(set_of(staged)) + 32, order_key(t0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
                 if (DBG && (P0.dbg_flags & 16u)) {
                     const uint32_t kx = __hip_atomic_load(B.tau_g(set_of(staged)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (kx && key_to_float(kx) > tau_init) tau_init = key_to_float(kx);
@@ -376,7 +452,9 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
             }
             // Threshold exchange of the query this workgroup's waves are streaming: the oldest unfinished one until
             // half of the waves have left it, then the next (whose waves need a threshold most).
-            if (P0.n_sets != 0u && !(P0.dbg_flags & 4u)) {
+            if (local) {
+                // (workgroup-local thresholds are formed by the streaming waves themselves, in LDS: nothing to do here)
+            } else if (P0.n_sets != 0u && !(P0.dbg_flags & 4u)) {
                 uint32_t hq = tail;
                 if (tail + 1u < staged &&
                     2u * __builtin_amdgcn_readfirstlane(lds_load(&L.misc[tail & 1u][MISC_DONE])) >= n_active)
@@ -428,7 +506,12 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
                     asm volatile("" ::: "memory");
                     StreamParams P = P0;
                     P.gmax = B.gmax(set_of(tail));
-                    if (P0.n_sets != 0u) publish_group_max(P, bid, lane, mp);  // complete maxima (fire and forget)
+                    if (local) {
+                        // the largest threshold this workgroup's waves can have used goes on record (what they dropped lies below it)
+                        const uint32_t k_used = lds_load(&mp[MISC_TAUKEY]);
+                        if (lane == 0 && k_used != 0u)
+                            (void)__hip_atomic_fetch_max(B.tau_g(set_of(tail)) + 32, k_used, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } else if (P0.n_sets != 0u) publish_group_max(P, bid, lane, mp);  // complete maxima (fire and forget)
                     if (P0.dbg && lane == 0) {  // TKSPMV_STATS=1
                         atomicAdd(&P0.dbg[0], (unsigned long long)mp[MISC_SLOW_CNT]);
                         atomicAdd(&P0.dbg[1], (unsigned long long)mp[MISC_CAND_CNT]);
@@ -441,8 +524,30 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
                     // query's overflow list
                     const uint32_t w = lane >> 3, e = lane & 7u;
                     const uint32_t cnt = L.stg_cnt[tp][w];
-                    const bool have = e < cnt;
+                    bool have = e < cnt;
                     const unsigned long long v = have ? L.stg[tp][w][e] : 0ull;
+                    if (local) {
+                        // Local thresholds leave 10-30 rows per workgroup: its eight best go to its slots IN ORDER (slot 0 = the
+                        // workgroup's best row: the selection's first cut builds on those), the rest is dropped -- and the best of
+                        // the dropped goes on record as a threshold used, one step up (a dropped row may TIE with it).
+                        const float f = have ? __uint_as_float((uint32_t)v) : -__builtin_huge_valf();
+                        bool taken = !have;
+#pragma unroll 1
+                        for (uint32_t r = 0; r <= WG_SLOTS; ++r) {
+                            const float mx = wave_max(taken ? -__builtin_huge_valf() : f);
+                            const uint64_t bm = __ballot(!taken && f == mx);
+                            if (bm == 0ull) break;  // fewer entries than slots
+                            const uint32_t first = (uint32_t)__builtin_ctzll(bm);
+                            if (r == WG_SLOTS) {
+                                if (lane == 0)
+                                    (void)__hip_atomic_fetch_max(B.tau_g(set_of(tail)) + 32, order_key(mx) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            } else if (lane == first) {
+                                st_agent(B.wg_cand(set_of(tail)) + (size_t)bid * WG_SLOTS + r, v);
+                                taken = true;
+                            }
+                        }
+                        have = false;  // (nothing is left for the copy below)
+                    }
                     const bool extra = have && e > 0u;
                     const uint64_t bm = __ballot(extra);
                     uint32_t gbase = 0u;
@@ -490,7 +595,8 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
                 }
             }
             if (tail == nq) break;
-            if (reducer) __builtin_amdgcn_s_sleep(TKSPMV_REDUCER_SLEEP);
+            if (local) __builtin_amdgcn_s_sleep(2);
+            else if (reducer) __builtin_amdgcn_s_sleep(TKSPMV_REDUCER_SLEEP);
             else __builtin_amdgcn_s_sleep(8);
         }
         return;
@@ -537,7 +643,7 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
     // 1, ... Two running pointers and a down-counter per request; past the end of the launch the last packet is requested
     // again (a fixed number of younger loads lets the compiler wait with a counted vmcnt).
     auto stream_of = [&](uint32_t q) __attribute__((always_inline)) -> const uint8_t * {
-        return RESIDENT ? B.replicas[q % B.n_replicas] : B.io[q].packets;
+        return RESIDENT ? B.replicas[q % B.n_replicas] : B.io[qx(q)].packets;
     };
     const size_t part_off = (size_t)p0 * P0.packet_bytes;
     const uint8_t *pk_a = stream_of(0u) + part_off;
@@ -578,6 +684,7 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
     uint32_t ncold = 0u;                    // packets of this query reduced without a threshold
     float champ = -__builtin_huge_valf();   // per lane: upper bound of the rows finished in those packets
     float carry = 0.0f, min_units = 0.0f;
+    float top1 = 0.0f, top2 = 0.0f;  // local thresholds: the two largest packet maxima of this wave in the current query
     uint32_t wcnt = 0u;
     uint32_t pace = 4u;  // this query's pacing level (server: from the workgroup's rank in the previous query's tickets)
     bool waited = false;  // this wave has used its bounded wait for a threshold in the current query (long partitions)
@@ -609,6 +716,7 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
                     P.ovf_cand = B.ovf_cand(set_of(qc));
                     P.ovf_count = B.ovf_count(set_of(qc));
                     wcnt = 0u;
+                    top1 = top2 = -__builtin_huge_valf();
                     waited = false;
                     cold = champ_ok;
                     decided = false;
@@ -672,7 +780,30 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
                 }
                 if (tau_now == tau || __any(trig >= tau_now)) {
                     const RowSums<C> R = expand<C, INT>(Rd, packet_flags<C, QM>(cur));
-                    offer_candidates<C, QM, WAVE_CAP>(P, R, rb_cur, tau_now, lane, grp_local, publishes, wcand, wcnt, mp);
+                    const float wm = offer_candidates<C, QM, WAVE_CAP>(P, R, rb_cur, tau_now, lane, grp_local, publishes, wcand, wcnt, mp);
+                    if (local && wm > top2 && wm >= min_units) {
+                        // (a wave with a single packet has no second maximum: it stands for one row)
+                        top2 = wm > top1 ? top1 : wm;
+                        top1 = wm > top1 ? wm : top1;
+                        const float pub = (np >= 2u && !local_top1) ? top2 : top1;
+                        if (pub >= min_units) {
+                            if (lane == 0)  // single writer: this wave's word
+                                __hip_atomic_store(&mp[MISC_GRPMAX + wave], order_key(pub), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            // The workgroup's threshold: the smallest word, once every streaming wave has one (lane w looks at wave
+                            // w's; this wave's LDS operations execute in order). Whoever raises it records it (MISC_TAUKEY, an
+                            // atomic max: the largest threshold ever formed) and passes it on; a smaller value landing last in
+                            // MISC_TAU is still a threshold.
+                            const uint32_t key = wave_has ? lds_load(&mp[MISC_GRPMAX + (lane & 7u)]) : 0xFFFFFFFFu;
+                            if (__ballot(key == 0u) == 0ull) {
+                                const uint32_t kmin = wave_min_u32(key);
+                                if (lane == 0) {
+                                    const uint32_t old = __hip_atomic_fetch_max(&mp[MISC_TAUKEY], kmin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                    if (kmin > old)
+                                        __hip_atomic_store(&mp[MISC_TAU], __float_as_uint(key_to_float(kmin)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                }
+                            }
+                        }
+                    }
                 }
             }
             if (champ_ok && !decided && jc + 3u >= np) {  // (jc == np - 3 in the query's own segment: in a redo, decided is set)
@@ -714,7 +845,7 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
                     seg_n = ncold;
                     jc = 0u;
                 } else {  // the query ends for this wave
-                    if (!champ_ok && P0.n_sets != 0u && P0.tau_possible && wcnt != 0u) {
+                    if (!champ_ok && (local || (P0.n_sets != 0u && P0.tau_possible)) && wcnt != 0u) {
                         // A wave that runs ahead of the others gets here before any threshold exists for this query; flushing
                         // now would dump every row it has seen to global memory. Give the exchange a moment -- bounded: after
                         // BATCH_TAU_WAIT the wave goes on without one, so progress never depends on other workgroups being

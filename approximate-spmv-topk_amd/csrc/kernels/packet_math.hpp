@@ -499,7 +499,7 @@ __device__ __forceinline__ uint32_t compact_list(uint2 *wcand, uint32_t n, float
 // current threshold; only what still does not fit goes to the shared overflow list in global memory, with ONE
 // atomic per wave and packet. One LDS atomic raises the group maximum (the server wave pushes it to global memory).
 template <int C, int QM, uint32_t WAVE_CAP, bool STATS = true>
-__device__ __forceinline__ void offer_candidates(const StreamParams &P, const RowSums<C> &R, uint32_t rb, float tau,
+__device__ __forceinline__ float offer_candidates(const StreamParams &P, const RowSums<C> &R, uint32_t rb, float tau,
                                                  uint32_t lane, uint32_t grp_local, bool publishes, uint2 *wcand,
                                                  uint32_t &wcnt, uint32_t *misc) {
     bool pass[C];
@@ -515,7 +515,7 @@ __device__ __forceinline__ void offer_candidates(const StreamParams &P, const Ro
     }
     const float best = lane_best<C, QM>(R);
     const float wmax = wave_max(best >= tau ? best : -__builtin_huge_valf());
-    if (total == 0u) return;  // only placeholders of empty rows tripped the trigger
+    if (total == 0u) return -__builtin_huge_valf();  // only placeholders of empty rows tripped the trigger
     if (lane == 0) {
         if (publishes)
             (void)__hip_atomic_fetch_max(&misc[MISC_GRPMAX + grp_local], order_key(wmax), __ATOMIC_RELAXED,
@@ -548,6 +548,7 @@ __device__ __forceinline__ void offer_candidates(const StreamParams &P, const Ro
         r += R.end(j) ? 1u : 0u;
     }
     wcnt = base + total < WAVE_CAP ? base + total : WAVE_CAP;
+    return wmax;  // the best of the rows appended (wave-uniform): the batch kernel's workgroup-local thresholds build on it
 }
 
 }  // namespace tkspmv

@@ -45,6 +45,19 @@ struct SelectParams {
     // 100 MHz) and the selecting workgroup reports end - start in host_out[2k + 1] -- the kernel's own duration, so that
     // tkspmv_run needs no hipEvent pair around the launch (two records and a query: ~6 us of the 67 us a query took end to end).
     unsigned long long *t_start;
+    // Prior thresholds (batch kernel, round 3): a query may START with a guessed threshold -- a fraction of the k-th best score of
+    // a query selected shortly before. tau0_g: order key of the largest guess any workgroup used for THIS query (atomic max by
+    // the servers; 0 = none). The guess was harmless iff at least k candidates reach it (then the k-th best score does too, and
+    // no row of the result was dropped below it); otherwise the selection raises *repair_flag and the query is run again
+    // without a guess by the repair launch that follows every batch launch. prior_word receives the order key of this
+    // query's k-th best score as it is reported, folded into a lower envelope (the next guesses derive from it).
+    uint32_t *tau0_g;
+    uint32_t *repair_flag;
+    uint32_t *prior_word;
+    float prior_rise;
+    // Workgroup-local thresholds (batch kernel): nobody has computed a device-wide threshold, but slot 0 of every workgroup
+    // holds its best row -- the k-th largest of those (distinct rows) is a lower bound of the k-th best score: the first cut.
+    uint32_t local_thr;
 };
 
 constexpr int MAX_GM = 16;  // n_groups_pub <= 1024 => at most 16 published maxima per lane
@@ -113,7 +126,27 @@ __device__ __forceinline__ void select_body(const SelectParams &P, const uint32_
     }
     // The reducer servers keep the k-th largest published maximum in tau_g: a valid lower bound of the k-th best
     // score (slightly stale, never too high). It prunes what was appended while the threshold was converging.
-    const uint32_t thr = P.use_gmax ? __hip_atomic_load(P.tau_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    // (the recorded guess of this query, for the check further down: its round trip rides with the loads above)
+    const uint32_t t0 = (P.repair_flag && P.tau0_g) ? __hip_atomic_load(P.tau0_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    uint32_t thr = P.use_gmax ? __hip_atomic_load(P.tau_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    if (P.local_thr) {  // (wave-uniform)
+        if (tid < 64u) {
+            uint32_t gk[MAX_GM];
+#pragma unroll
+            for (int i = 0; i < MAX_GM; ++i) {
+                const uint32_t w = lane + 64u * (uint32_t)i;
+                gk[i] = 0u;
+                if (w < P.n_wg) {
+                    const unsigned long long v = ld_agent(&P.wg_cand[(size_t)w * WG_SLOTS]);
+                    if ((uint32_t)(v >> 32) != SLOT_INVALID) gk[i] = order_key(__uint_as_float((uint32_t)v));
+                }
+            }
+            const uint32_t t = P.n_wg <= 512u ? kth_largest_prefix<8, 17>(gk, P.k) : kth_largest_prefix<MAX_GM, 17>(gk, P.k);
+            if (tid == 0) S.thr = t;
+        }
+        __syncthreads();
+        thr = S.thr;
+    }
     uint32_t novf = __hip_atomic_load(P.ovf_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     novf = novf < P.ovf_cap ? novf : P.ovf_cap;
     if (stamps && tid == 0) stamps[4] = __builtin_amdgcn_s_memtime() + (mine[0] & 1ull) * 0ull;  // after the loads returned
@@ -215,6 +248,25 @@ __device__ __forceinline__ void select_body(const SelectParams &P, const uint32_
     }
     if (stamps && tid == 0) stamps[5] = __builtin_amdgcn_s_memtime();  // keys in LDS
 
+    // Prior threshold of this query, if any: did at least k candidates reach it?
+    if (P.repair_flag) {
+        if (tid == 0) S.cnt = 0;
+        __syncthreads();
+        uint32_t c = 0;
+        for (uint32_t i = tid; i < n_sel; i += nthreads) c += ((uint32_t)(S.keys[i] >> 32) >= t0) ? 1u : 0u;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) c += (uint32_t)__shfl_xor((int)c, d);
+        if (lane == 0 && c) atomicAdd(&S.cnt, c);
+        __syncthreads();
+        if (tid == 0) {
+            // (n_sel is capped at SEL_CAP >= k: a cap hit still proves k candidates when they all reach the guess)
+            const uint32_t bad = (t0 != 0u && S.cnt < P.k) ? 1u : 0u;
+            __hip_atomic_store(P.repair_flag, bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (P.tau0_g) __hip_atomic_store(P.tau0_g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+    }
+
     // Rank by counting: keys are unique (distinct rows), rank r = number of larger keys. G threads share one key
     // (each counts a slice of the list, partial counts meet through quad/oct shuffles) so the whole workgroup works.
     uint32_t G = 1;
@@ -231,6 +283,14 @@ __device__ __forceinline__ void select_body(const SelectParams &P, const uint32_
             for (uint32_t u = 0; u < 8; ++u) r += (S.keys[blk * 8u + u] > kx);
         }
         for (uint32_t d = 1; d < G; d <<= 1) r += (uint32_t)__shfl_xor((int)r, (int)d);
+        if (active && part == 0u && r + 1u == P.k && P.prior_word) {
+            // The next guesses derive from a LOWER ENVELOPE of the k-th best scores seen so far: it drops to this query's at once
+            // and rises by prior_rise per query otherwise -- a repair costs a whole query, a low guess a few candidates.
+            const float kth = key_to_float((uint32_t)(kx >> 32)) * out_scale;
+            const uint32_t old = __hip_atomic_load(P.prior_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float env = old ? fminf(kth, key_to_float(old) * P.prior_rise) : kth;
+            __hip_atomic_store(P.prior_word, env > 0.0f ? order_key(env) : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         if (active && part == 0u && r < P.k) {
             const uint32_t oi = (uint32_t)(kx & 0xFFFFFFFFull) + P.first_row;
             const float ov = key_to_float((uint32_t)(kx >> 32)) * out_scale;

@@ -1,6 +1,7 @@
 // wbscsr.cpp -- host packer / decoder for the wave block-streaming CSR layout (see wbscsr.hpp).
 // Role of the reference's SpMV::packet_coo / packet_coo_partition (src/fpga/src/host_spmv_bscsr.cpp:133-248).
 #include "wbscsr.hpp"
+#include <cstdlib>
 
 #include <cstdio>
 #include <cstring>
@@ -33,6 +34,17 @@ uint32_t fill_partitions(const std::vector<uint32_t> &len, uint64_t cap, std::ve
 }
 
 }  // namespace
+
+uint64_t small_matrix_packets() {
+    if (const char *f = getenv("TKSPMV_SMALL_PACKETS")) return (uint64_t)atoll(f);
+    return SMALL_MATRIX_PACKETS;
+}
+uint32_t min_packets_per_partition_for(uint64_t nnz, uint32_t C, uint32_t cols) {
+    if (const char *f = getenv("TKSPMV_MIN_PACKETS")) return (uint32_t)std::max(1, atoi(f));
+    const uint64_t packets = nnz / (64u * (uint64_t)std::max(C, 1u));
+    if (cols > 1024u || packets > small_matrix_packets()) return 4u;
+    return packets <= small_matrix_packets() / 5u ? 1u : 2u;  // (up to ~2 packets per streaming wave: one each)
+}
 
 std::string pack_wbscsr(uint32_t rows, uint32_t cols, uint64_t nnz, const uint32_t *row, const uint32_t *col,
                         const float *val, Precision precision, uint32_t C, uint32_t n_partitions_hint,

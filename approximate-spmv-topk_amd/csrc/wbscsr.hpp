@@ -279,6 +279,15 @@ struct PackedMatrix {
     uint64_t side_bytes() const { return (uint64_t)pkt_row.size() * 4 + (uint64_t)part_first.size() * 8; }
 };
 
+// Shortest partition the packers cut, a property of the matrix alone so that every packer (host, device, tkspmv_pack, the engine)
+// cuts the same partitions: 4 packets; 2 on small matrices (up to SMALL_MATRIX_PACKETS packets: ~320k rows of 20 non-zeros),
+// where there are fewer packets than 4 per streaming wave of a 256-CU launch and half of the waves would have nothing to stream;
+// 1 up to a fifth of that.
+// (TKSPMV_MIN_PACKETS / TKSPMV_SMALL_PACKETS: tuning runs.)
+constexpr uint64_t SMALL_MATRIX_PACKETS = 25000;
+uint64_t small_matrix_packets();
+uint32_t min_packets_per_partition_for(uint64_t nnz, uint32_t C, uint32_t cols);
+
 // Packs a row-sorted COO. Returns empty string on success, else an error message.
 // kind: 0 ok, 1 invalid, 2 not sorted.
 std::string pack_wbscsr(uint32_t rows, uint32_t cols, uint64_t nnz, const uint32_t *row, const uint32_t *col,

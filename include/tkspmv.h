@@ -152,7 +152,8 @@ typedef struct {
     uint32_t pack_on_device;      /* 1: the stream was packed by the device packer (default), 0: by the host packer */
     uint32_t claim_sets;          /* back-to-back queries run through the claim kernel: the wave partitions form this many sets of 8
                                      that workgroups claim dynamically (0: one partition per wave, batch kernel) */
-    uint32_t reserved0;
+    uint32_t batch_mode;          /* back-to-back queries: bits 0-7 = selector workgroups of a launch (4 on small matrices), bits 8-15 =
+                                     workgroup-local thresholds (0: the device-wide exchange; 1 / 2: see DESIGN.md 3.0b) */
 } tkspmv_info;
 
 typedef struct {

@@ -25,6 +25,11 @@ slot = int(np.argmax(t[:, 1:, 0, 0].max(axis=1)))
 w = t[slot]
 base = w[1:, :, 0][w[1:, :, 0] > 0].min()
 print("slot", slot, "selector stamps (us):", ((w[0, 0, :8] - base) * 0.01).round(1).tolist())
+sel = w[0].reshape(-1)[8:16]
+if sel[0] > 0 and sel[7] > 0:  # the phases of the selection of query 4 (s_memtime stamps rebased on the pair taken at its start)
+    mt = lambda v: (sel[0] + (v - sel[1]) - base) * 0.01
+    print(f"selection of query 4: poll from {(sel[0] - base) * 0.01:.1f}, ticket seen {(sel[2] - base) * 0.01:.1f}, loads returned {mt(sel[4]):.1f}, "
+          f"keys in LDS {mt(sel[5]):.1f}, ranked {mt(sel[6]):.1f}, done {(sel[7] - base) * 0.01:.1f}")
 names = ["entry", "qF start", "qM start", "qL start", "qF end", "qM end", "qL end"]
 st = w[1:, :8, :]
 for j, nm in enumerate(names):
