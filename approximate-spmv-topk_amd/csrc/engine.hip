@@ -167,6 +167,9 @@ struct EngineImpl {
     uint32_t *d_prior = nullptr;
     bool use_prior = false;
     uint32_t use_local = 0;  // workgroup-local thresholds (BatchParams::local: 0 off, 1 / 2: a wave's best / second best packet maximum)
+    float *d_wg_prior = nullptr;  // [grid] + the countdown word (BatchParams::wg_prior / prior_block)
+    bool carry_local = true;
+    float local_beta = 1.0f;
     uint32_t n_sel_wg = 1;   // selector workgroups of a batch launch (BatchParams::n_selectors): 4 on small matrices
     float prior_beta = 0.9f, prior_rise = 1.02f;
     // claim_kernel (kernels/claim_kernel.hpp): the matrix is packed into sets of 8 wave partitions that workgroups claim
@@ -422,6 +425,11 @@ struct EngineImpl {
         B.n_selectors = n_sel_wg;
         B.scratch_stride = (uint64_t)grid * WG_SLOTS + ovf_cap;
         B.local = use_local;
+        if (use_local && carry_local) {
+            B.wg_prior = d_wg_prior;
+            B.prior_block = reinterpret_cast<uint32_t *>(d_wg_prior + grid);
+            B.local_beta = local_beta;
+        }
         hipLaunchKernelGGL(batch_kernel_for(), dim3(grid), dim3(block + 64), 0, s, P, S, B);
         if (use_prior || use_local) {  // the queries whose guess did not hold, again and without one (nobody flagged: the launch is empty)
             B.repair = 1u;
@@ -710,7 +718,7 @@ Engine::~Engine() {
     if (m.stream) (void)hipStreamSynchronize(m.stream);
     void *bufs[] = {m.d_packets, m.d_pkt_row, m.d_part_first, m.d_part_count, m.d_x,
                     m.d_out_idx, m.d_out_val, m.d_scores,     m.d_stats,      m.d_done, m.d_trace, m.d_tickets,
-                    m.d_claim,   m.d_claim_done, m.d_tstart, m.d_prior};
+                    m.d_claim,   m.d_claim_done, m.d_tstart, m.d_prior, m.d_wg_prior};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     {
@@ -755,6 +763,21 @@ static hipError_t malloc_exchange(void **p, size_t bytes) {
     if (getenv("TKSPMV_DEBUG_OCC")) fprintf(stderr, "[tkspmv] fine-grained allocation unavailable, using hipMalloc\n");
     (void)hipGetLastError();
     return hipMalloc(p, bytes);
+}
+
+// Small matrices (the shards of a strong-scaled run): a query streams in less time than one selection takes and than a
+// device-wide threshold needs to form. They get 4 selector workgroups, partitions from 1-2 packets up (every wave streams:
+// twice the loads in flight; wbscsr.hpp: min_packets_per_partition_for) and workgroup-local thresholds. Returns the selector
+// workgroups of a batch launch for this matrix and geometry (TKSPMV_SELECTORS overrides; the matrix unknown -- nnz = 0 --: 1).
+static uint32_t small_matrix_settings(const tkspmv_desc &d, uint32_t grid, bool defer_capable, uint32_t C, bool *small_out) {
+    const uint64_t packets_lb = d.nnz / (64u * (uint64_t)std::max(C, 1u));
+    const bool small = defer_capable && grid >= 64u && d.nnz != 0 && d.cols <= 1024u && d.impl == TKSPMV_IMPL_STREAM && d.multi_q == 0 &&
+                       d.partitions <= 1 && packets_lb <= small_matrix_packets() && !getenv("TKSPMV_MULTI_Q") && !getenv("TKSPMV_CLAIM");
+    if (small_out) *small_out = small;
+    uint32_t n = small ? 4u : 1u;
+    if (const char *f = getenv("TKSPMV_SELECTORS")) n = (uint32_t)std::max(1, std::min(8, atoi(f)));
+    if (!defer_capable || grid < 2u * n) n = 1u;
+    return n;
 }
 
 static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, const PackedMatrix *prepacked = nullptr) {
@@ -835,17 +858,10 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
     // Deferred selection gives workgroup 0 of a back-to-back launch to the previous query's selection: one
     // partition per streaming wave of the remaining grid - 1 workgroups.
     const bool defer_capable = m.grid >= 2 && (uint64_t)m.grid * WG_SLOTS <= (uint64_t)SEL_PER_THREAD * (m.block + 64);
-    // Small matrices (the shards of a strong-scaled run): a query streams in less time than one selection takes and than a
-    // device-wide threshold needs to form. They get 4 selector workgroups, partitions from 2 packets up (every wave streams:
-    // twice the loads in flight) and -- decided below, once the partitions are known -- workgroup-local thresholds.
-    // TKSPMV_SELECTORS / TKSPMV_MIN_PACKETS / TKSPMV_LOCAL override.
-    const uint64_t packets_lb = d.nnz / (64u * C);
-    const uint64_t small_packets = small_matrix_packets();  // ~500k rows of 20 non-zeros
-    const bool small_matrix = defer_capable && m.grid >= 64u && d.cols <= 1024u && d.impl == TKSPMV_IMPL_STREAM && d.multi_q == 0 &&
-                              d.partitions <= 1 && packets_lb <= small_packets && !getenv("TKSPMV_MULTI_Q") && !getenv("TKSPMV_CLAIM");
-    m.n_sel_wg = small_matrix ? 4u : 1u;
-    if (const char *f = getenv("TKSPMV_SELECTORS")) m.n_sel_wg = (uint32_t)std::max(1, std::min(8, atoi(f)));
-    if (!defer_capable || m.grid < 2u * m.n_sel_wg) m.n_sel_wg = 1u;
+    // Small matrices (the shards of a strong-scaled run) get 4 selector workgroups, shorter partitions and -- decided below, once
+    // the partitions are known -- workgroup-local thresholds: small_matrix_settings().
+    bool small_matrix = false;
+    m.n_sel_wg = small_matrix_settings(d, m.grid, defer_capable, C, &small_matrix);
     if (prepacked && prepacked->part_first.size() > (size_t)(m.grid - m.n_sel_wg) * waves_per_wg) m.n_sel_wg = 1u;
     const uint32_t n_stream_waves = (m.grid - (defer_capable ? m.n_sel_wg : 0u)) * waves_per_wg;
     // (measurement aid, tools/claim_probe.py: more partitions than waves -- only the read probe may run on such an engine)
@@ -1185,12 +1201,16 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
         tail9 = std::max(tail9, 0.0);
         const double p1 = n_wg * (std::pow(lam, a) + tail9);
         const double p2 = n_wg * (std::pow(per_part < 1.5 ? lam : std::min(1.0, 0.5 * lam * lam), a) + tail9);
-        m.use_local = !small_matrix ? 0u : (p1 <= 1e-4 ? 1u : (p2 <= 1e-3 ? 2u : 0u));
+        m.use_local = (!small_matrix || m.grid > 512u) ? 0u : (p1 <= 1e-4 ? 1u : (p2 <= 1e-3 ? 2u : 0u));  // (512: select_body's first cut)
         if (getenv("TKSPMV_DEBUG_OCC"))
             fprintf(stderr, "[tkspmv] small matrix %d: %u selector workgroups, %.0f partitions of %.1f packets, %.0f per workgroup; local thresholds fail with p = %.2e (mode 1) / %.2e (mode 2): mode %u\n",
                     (int)small_matrix, m.n_sel_wg, n_parts, per_part, a, p1, p2, m.use_local);
     }
-    if (const char *f = getenv("TKSPMV_LOCAL")) m.use_local = (uint32_t)std::max(0, std::min(2, atoi(f)));
+    HIP_TRY(malloc_exchange((void **)&m.d_wg_prior, ((size_t)m.grid + 32) * 4));
+    HIP_TRY(hipMemset(m.d_wg_prior, 0, ((size_t)m.grid + 32) * 4));
+    if (const char *f = getenv("TKSPMV_LOCAL_CARRY")) m.carry_local = atoi(f) != 0;
+    if (const char *f = getenv("TKSPMV_LOCAL_BETA")) m.local_beta = (float)atof(f);
+    if (const char *f = getenv("TKSPMV_LOCAL")) m.use_local = m.grid > 512u ? 0u : (uint32_t)std::max(0, std::min(2, atoi(f)));
     {
         // Exchange-state sets: one block per field, set s at s strides (the batch kernel addresses them that way).
         if (m.can_batch && !m.can_multi && !m.resident_capable) {
@@ -1265,7 +1285,7 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
     m.info.multi_pack_us = m.sell_pack_us;
     m.info.pack_on_device = m.packed_on_device ? 1u : 0u;
     m.info.claim_sets = m.can_claim ? m.n_claim_sets : 0u;
-    m.info.batch_mode = m.can_batch ? (m.n_sel_wg | (m.use_local << 8)) : 0u;
+    m.info.batch_mode = (m.can_batch ? (m.n_sel_wg | (m.use_local << 8)) : 0u) | (std::min<uint32_t>(n_parts_hint, 0xFFFFu) << 16);
     HIP_TRY(hipDeviceSynchronize());
     return TKSPMV_OK;
 }
@@ -1293,7 +1313,9 @@ int wave_partitions_for(const tkspmv_desc &d, uint32_t *out, std::string &err) {
     const uint32_t waves_per_wg = block / 64;
     const uint32_t grid = std::max(1u, (uint32_t)prop.multiProcessorCount * waves_per_cu / waves_per_wg);
     const bool defer_capable = grid >= 2 && (uint64_t)grid * WG_SLOTS <= (uint64_t)SEL_PER_THREAD * (block + 64);
-    *out = (grid - (defer_capable ? 1u : 0u)) * waves_per_wg;
+    // (with the matrix described -- rows, cols, nnz, precision --: the hint tkspmv_create itself would pack this matrix with;
+    //  without: the largest count any engine of this geometry accepts)
+    *out = (grid - (defer_capable ? small_matrix_settings(d, grid, defer_capable, entries_per_lane_of(d), nullptr) : 0u)) * waves_per_wg;
     return TKSPMV_OK;
 }
 

@@ -89,6 +89,15 @@ struct BatchParams : SetAddr {
     // as soon as a query streams faster than that (below ~500k rows). Each has its own scratch for the general path.
     uint32_t n_selectors;
     uint64_t scratch_stride;
+    // Local thresholds, carried over (wg_prior != NULL): a workgroup STARTS a query at local_beta x the score of the 8th best row it
+    // delivered for its previous one -- the ~98th percentile of its rows, far below the k-th best score of the matrix unless
+    // the queries change scale (checked like every local threshold). Without it every packet of a small matrix takes the
+    // candidate path (no threshold is tight before the query is over); with it one packet in five. wg_prior[b]: workgroup
+    // b's value between launches; prior_block: countdown set by a selection whose check failed -- no carried thresholds
+    // while it runs (a query that fails goes through the repair launch: that must stay an exception).
+    float *wg_prior;
+    uint32_t *prior_block;
+    float local_beta;
     // ---- resident mode (RESIDENT = true; tkspmv_run with desc.impl = TKSPMV_IMPL_RESIDENT) -------------------------------
     // ONE launch serves queries as the host submits them: no launch, no copy engine, no stream synchronisation per query.
     // The host writes x into pinned memory and raises `request` (an epoch counter); the doorman -- wave 0 of the selector
@@ -281,6 +290,7 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
                 S.prior_word = B.prior_word;
                 S.prior_rise = B.prior_rise;
                 S.local_thr = local ? 1u : 0u;
+                S.prior_block = (local && B.wg_prior) ? B.prior_block : nullptr;
             }
             if (RESIDENT) {
                 S.host_epoch = B.epoch0 + q + 1u;  // (host_out comes with SP0)
@@ -292,7 +302,7 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
             //  there from a query's first packet would be worth: 0.7 us of 20.5 on BASELINE configs[1])
             const uint32_t keep_tau = (DBG && (P0.dbg_flags & 16u)) ? __hip_atomic_load(S.tau_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
             if (tr_sel && tid == 0) P0.trace[10] = __builtin_amdgcn_s_memrealtime();
-            select_body(S, tid, blockDim.x, L.u.sel, 0u, tr_sel ? P0.trace + 8 : nullptr);
+            select_body<!RESIDENT>(S, tid, blockDim.x, L.u.sel, 0u, tr_sel ? P0.trace + 8 : nullptr);
             __syncthreads();
             if (tr_sel && tid == 0) P0.trace[15] = __builtin_amdgcn_s_memrealtime();
             if (DBG && (P0.dbg_flags & 16u) && tid == 0) *S.tau_g = keep_tau;
@@ -337,6 +347,8 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
         if (reducer || local) __builtin_amdgcn_s_setprio(3);
 #endif
         uint32_t staged = 0u, tail = 0u;
+        const bool carry_local = local && B.wg_prior != nullptr;
+        float wg_prior = carry_local ? B.wg_prior[bid] : 0.0f;  // (reported-score units; 0: none)
         uint32_t published = RESIDENT ? 0u : nq;  // queries whose x is available (resident: as the doorman publishes them)
         float inv_unit_q[2] = {1.0f, 1.0f}, min_units_q[2] = {0.0f, 0.0f};
         unsigned long long dbg_first_duty = 0ull;
@@ -365,6 +377,7 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
                 const float *xg = RESIDENT ? reinterpret_cast<const float *>(B.xr + (size_t)par * XCOLS) : B.io[qx(staged)].x;
                 // the guess for this query (issued here, used below: its round trip overlaps the loads of x)
                 const uint32_t prior_key = use_prior ? __hip_atomic_load(B.prior_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                const uint32_t prior_blocked = carry_local ? __hip_atomic_load(B.prior_block, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1u;
                 // (resident: the two device-side copies of x are rewritten in place query after query; they live in fine-
                 //  grained memory and are read with agent-scope loads, so no cache can serve a previous query's x)
                 auto x_at = [&](uint32_t i) __attribute__((always_inline)) -> float {
@@ -437,6 +450,14 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
                             (void)__hip_atomic_fetch_max(B.tau_g(set_of(staged)) + 32, order_key(t0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                 }
+                uint32_t carried_key = 0u;
+                if (prior_blocked == 0u && wg_prior > 0.0f) {
+                    const float t0 = wg_prior * unit_scale * B.local_beta;
+                    if (t0 > tau_init) {
+                        tau_init = t0;
+                        carried_key = order_key(t0);  // (on record with the thresholds the waves form: MISC_TAUKEY)
+                    }
+                }
                 if (DBG && (P0.dbg_flags & 16u)) {
                     const uint32_t kx = __hip_atomic_load(B.tau_g(set_of(staged)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (kx && key_to_float(kx) > tau_init) tau_init = key_to_float(kx);
@@ -444,6 +465,7 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
                 if (lane == 0) {
                     mp[MISC_TAU] = __float_as_uint(tau_init);
                     mp[MISC_MINU] = __float_as_uint(min_units_q[par]);
+                    if (carry_local) mp[MISC_TAUKEY] = carried_key;
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 if (lane == 0) __hip_atomic_store(&mp[MISC_XREADY], staged + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -532,6 +554,8 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
                         // the dropped goes on record as a threshold used, one step up (a dropped row may TIE with it).
                         const float f = have ? __uint_as_float((uint32_t)v) : -__builtin_huge_valf();
                         bool taken = !have;
+                        float kept_last = 0.0f;
+                        uint32_t n_kept = 0u;
 #pragma unroll 1
                         for (uint32_t r = 0; r <= WG_SLOTS; ++r) {
                             const float mx = wave_max(taken ? -__builtin_huge_valf() : f);
@@ -541,10 +565,21 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
                             if (r == WG_SLOTS) {
                                 if (lane == 0)
                                     (void)__hip_atomic_fetch_max(B.tau_g(set_of(tail)) + 32, order_key(mx) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            } else if (lane == first) {
-                                st_agent(B.wg_cand(set_of(tail)) + (size_t)bid * WG_SLOTS + r, v);
-                                taken = true;
+                            } else {
+                                if (lane == first) {
+                                    st_agent(B.wg_cand(set_of(tail)) + (size_t)bid * WG_SLOTS + r, v);
+                                    taken = true;
+                                }
+                                kept_last = mx;
+                                ++n_kept;
                             }
+                        }
+                        // what the next queries of this workgroup start from: the score of the last row kept when the slots filled
+                        // up; else the threshold in force (it let fewer than 8 rows through: high enough), a little lower
+                        if (carry_local) {
+                            const float t_end = __uint_as_float(lds_load(&mp[MISC_TAU]));
+                            if (n_kept == WG_SLOTS) wg_prior = kept_last * inv_unit_q[tp];
+                            else if (t_end > min_units_q[tp]) wg_prior = t_end * inv_unit_q[tp] * 0.95f;
                         }
                         have = false;  // (nothing is left for the copy below)
                     }
@@ -594,7 +629,10 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
                     ++tail;
                 }
             }
-            if (tail == nq) break;
+            if (tail == nq) {
+                if (carry_local && lane == 0) B.wg_prior[bid] = wg_prior;
+                break;
+            }
             if (local) __builtin_amdgcn_s_sleep(2);
             else if (reducer) __builtin_amdgcn_s_sleep(TKSPMV_REDUCER_SLEEP);
             else __builtin_amdgcn_s_sleep(8);

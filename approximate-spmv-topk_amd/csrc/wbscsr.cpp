@@ -43,7 +43,7 @@ uint32_t min_packets_per_partition_for(uint64_t nnz, uint32_t C, uint32_t cols) 
     if (const char *f = getenv("TKSPMV_MIN_PACKETS")) return (uint32_t)std::max(1, atoi(f));
     const uint64_t packets = nnz / (64u * (uint64_t)std::max(C, 1u));
     if (cols > 1024u || packets > small_matrix_packets()) return 4u;
-    return packets <= small_matrix_packets() / 5u ? 1u : 2u;  // (up to ~2 packets per streaming wave: one each)
+    return packets <= small_matrix_packets() / 10u ? 1u : 2u;  // (up to ~2 packets per streaming wave: one each)
 }
 
 std::string pack_wbscsr(uint32_t rows, uint32_t cols, uint64_t nnz, const uint32_t *row, const uint32_t *col,

@@ -280,11 +280,12 @@ struct PackedMatrix {
 };
 
 // Shortest partition the packers cut, a property of the matrix alone so that every packer (host, device, tkspmv_pack, the engine)
-// cuts the same partitions: 4 packets; 2 on small matrices (up to SMALL_MATRIX_PACKETS packets: ~320k rows of 20 non-zeros),
+// cuts the same partitions: 4 packets; 2 on small matrices (up to SMALL_MATRIX_PACKETS packets: ~700k rows of 20 non-zeros -- where the batch kernel's small-matrix
+// settings pay, engine.hip),
 // where there are fewer packets than 4 per streaming wave of a 256-CU launch and half of the waves would have nothing to stream;
-// 1 up to a fifth of that.
+// 1 up to a tenth of that.
 // (TKSPMV_MIN_PACKETS / TKSPMV_SMALL_PACKETS: tuning runs.)
-constexpr uint64_t SMALL_MATRIX_PACKETS = 25000;
+constexpr uint64_t SMALL_MATRIX_PACKETS = 55000;
 uint64_t small_matrix_packets();
 uint32_t min_packets_per_partition_for(uint64_t nnz, uint32_t C, uint32_t cols);
 

@@ -206,10 +206,14 @@ class Packed:
         _lib.check(_lib.lib().tkspmv_packed_save(self._h, str(path).encode()))
 
     @staticmethod
-    def wave_partitions(device=-1, waves_per_cu=0, threads_per_wg=0):
-        """Wave partitions an engine on `device` cuts a matrix into (the n_wave_partitions to pack for). Needs a GPU."""
+    def wave_partitions(device=-1, waves_per_cu=0, threads_per_wg=0, m=None, precision=_lib.F32, nnz_per_lane=0):
+        """Wave partitions an engine on `device` cuts a matrix into (the n_wave_partitions to pack for). Needs a GPU. With the
+        matrix `m` given: the hint tkspmv_create itself would use for it (small matrices keep 4 workgroups for selections);
+        without: the largest count an engine of this geometry accepts."""
         d = _lib.Desc()
         d.device, d.waves_per_cu, d.threads_per_wg = int(device), int(waves_per_cu), int(threads_per_wg)
+        if m is not None:
+            d.rows, d.cols, d.nnz, d.precision, d.nnz_per_lane = int(m.rows), int(m.cols), int(m.row.shape[0]), int(precision), int(nnz_per_lane)
         n = C.c_uint32()
         _lib.check(_lib.lib().tkspmv_wave_partitions(C.byref(d), C.byref(n)))
         return int(n.value)

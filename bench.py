@@ -150,7 +150,7 @@ def check_parity(mod, m, x, k, idx, val, eng=None, bit_exact=True):
     if eng is not None and bit_exact:
         info = eng.info()
         C = info["packet_entries"] // 64
-        packed = mod.Packed(m, k=k, nnz_per_lane=C, n_wave_partitions=info["n_wave_partitions"])
+        packed = mod.Packed(m, k=k, nnz_per_lane=C, n_wave_partitions=(info.get("batch_mode", 0) >> 16) or info["n_wave_partitions"])
         yp, present = O.packed_scores(packed.raw(), x, m.rows, C)
         ei, ev = O.select_topk(yp, present, k, 0.0, info.get("first_row", 0))
         out["bit_exact_vs_order_matched_oracle"] = bool(np.array_equal(idx, ei) and np.array_equal(val.view(np.uint32), ev.view(np.uint32)))

@@ -153,7 +153,8 @@ typedef struct {
     uint32_t claim_sets;          /* back-to-back queries run through the claim kernel: the wave partitions form this many sets of 8
                                      that workgroups claim dynamically (0: one partition per wave, batch kernel) */
     uint32_t batch_mode;          /* back-to-back queries: bits 0-7 = selector workgroups of a launch (4 on small matrices), bits 8-15 =
-                                     workgroup-local thresholds (0: the device-wide exchange; 1 / 2: see DESIGN.md 3.0b) */
+                                     workgroup-local thresholds (0: the device-wide exchange; 1 / 2: see DESIGN.md 3.0b); bits 16-31 = the
+                                     n_wave_partitions_hint this engine packed with (tkspmv_pack with the same hint cuts the same partitions) */
 } tkspmv_info;
 
 typedef struct {

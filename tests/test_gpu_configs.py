@@ -54,7 +54,7 @@ def test_config1_the_measured_path_against_the_gold_at_full_size(pkg, oracle):
     gi_all = out_i.cpu().numpy().astype(np.uint32)
     gv_all = out_v.cpu().numpy()
     C = info["packet_entries"] // 64
-    packed = pkg.Packed(m, k=k, nnz_per_lane=C, n_wave_partitions=info["n_wave_partitions"])
+    packed = pkg.Packed(m, k=k, nnz_per_lane=C, n_wave_partitions=(info["batch_mode"] >> 16) or info["n_wave_partitions"])
     assert packed.info()["n_wave_partitions"] == info["n_wave_partitions"]
     raw = packed.raw()
     swaps = 0
@@ -104,7 +104,7 @@ def test_config3_ten_million_rows_in_eight_shards_on_one_gpu(pkg, oracle):
         # order-matched scores of this shard (the shard's own packing), for the bit-exact comparison below
         C = info["packet_entries"] // 64
         sm = pkg.CooMatrix(r1 - r0, 1024, lr, lc, lv)
-        packed = pkg.Packed(sm, k=k, nnz_per_lane=C, n_wave_partitions=info["n_wave_partitions"])
+        packed = pkg.Packed(sm, k=k, nnz_per_lane=C, n_wave_partitions=(info["batch_mode"] >> 16) or info["n_wave_partitions"])
         assert packed.info()["n_wave_partitions"] == info["n_wave_partitions"]
         yp, present = oracle.packed_scores(packed.raw(), xs[0], r1 - r0, C)
         assert present.all()

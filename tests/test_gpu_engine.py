@@ -20,7 +20,7 @@ RTOL = 1e-4
 def _expected(pkg, oracle, m, x, k, eng, min_score=0.0, first_row=0):
     info = eng.info()
     C = info["packet_entries"] // 64
-    packed = pkg.Packed(m, k=k, nnz_per_lane=C, n_wave_partitions=info["n_wave_partitions"])
+    packed = pkg.Packed(m, k=k, nnz_per_lane=C, n_wave_partitions=(info["batch_mode"] >> 16) or info["n_wave_partitions"])
     assert packed.info()["n_wave_partitions"] == info["n_wave_partitions"]
     yp, present = oracle.packed_scores(packed.raw(), x, m.rows, C)
     return oracle.select_topk(yp, present, k, min_score, first_row)
@@ -1010,8 +1010,10 @@ def test_engine_from_packed_file_equals_engine_from_coo(pkg, oracle, tmp_path, p
     t_coo = time.perf_counter() - t0
     a()
     va, ia = a.read_result()
-    n_parts = pkg.Packed.wave_partitions(device=0)
-    assert n_parts == a.info()["grid"] * 8 - 8  # one partition per streaming wave, workgroup 0 left to the selection
+    n_parts = pkg.Packed.wave_partitions(device=0, m=m, precision=prec)
+    # one partition per streaming wave; workgroup 0 -- on small matrices workgroups 0..3 -- left to the selection
+    assert n_parts == (a.info()["grid"] - max(a.info()["batch_mode"] & 0xFF, 1)) * 8 == a.info()["batch_mode"] >> 16
+    assert pkg.Packed.wave_partitions(device=0) == a.info()["grid"] * 8 - 8  # (matrix unknown: the most any engine accepts)
     packed = pkg.Packed(m, k=100, n_wave_partitions=n_parts, precision=pkg.F32 if precision == "F32" else pkg.Q1_7)
     path = tmp_path / "m.tkspmv"
     packed.save(path)
@@ -1088,7 +1090,7 @@ def test_f16_values_bit_exact_against_the_half_model(pkg, oracle, rows, cols, nn
     eng = pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, k=k, device=0, precision=pkg.F16)
     info = eng.info()
     assert info["packet_entries"] == 256 and info["packed_bytes"] < 4.1 * m.row.shape[0] + 8 * rows + 70000
-    packed = pkg.Packed(m, k=k, n_wave_partitions=pkg.Packed.wave_partitions(0), precision=pkg.F16)
+    packed = pkg.Packed(m, k=k, n_wave_partitions=pkg.Packed.wave_partitions(0, m=m, precision=pkg.F16), precision=pkg.F16)
     assert packed.info()["n_wave_partitions"] == info["n_wave_partitions"]
     for q in range(2):
         x = pkg.create_sample_vector(cols, True, False, True, 50 * seed + q)

@@ -51,7 +51,7 @@ def test_topk_matches_oracle(pkg, oracle, rows, cols, nnz, dist, k, seed):
         # bit-exact against the order-matched model of the kernel arithmetic
         info = eng.info()
         packed = pkg.Packed(m, k=k, nnz_per_lane=info["packet_entries"] // 64,
-                            n_wave_partitions=info["n_wave_partitions"])
+                            n_wave_partitions=(info["batch_mode"] >> 16) or info["n_wave_partitions"])
         assert packed.info()["n_wave_partitions"] == info["n_wave_partitions"]
         yp, present = oracle.packed_scores(packed.raw(), x, m.rows, info["packet_entries"] // 64)
         ei, ev = oracle.select_topk(yp, present, k)
@@ -68,7 +68,7 @@ def test_full_scores_bit_exact(pkg, oracle):
     y = eng.scores()
     info = eng.info()
     C = info["packet_entries"] // 64
-    packed = pkg.Packed(m, k=100, nnz_per_lane=C, n_wave_partitions=info["n_wave_partitions"])
+    packed = pkg.Packed(m, k=100, nnz_per_lane=C, n_wave_partitions=(info["batch_mode"] >> 16) or info["n_wave_partitions"])
     yp, present = oracle.packed_scores(packed.raw(), x, m.rows, C)
     assert present.all()
     assert np.array_equal(y.view(np.uint32), yp.view(np.uint32))

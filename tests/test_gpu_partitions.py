@@ -61,7 +61,7 @@ def test_lossy_partitions_match_the_model_and_the_closed_form(pkg, oracle, rows,
     info = eng.info()
     assert info["partitions"] == P and info["k_per_partition"] == k_part
     C = info["packet_entries"] // 64
-    packed = pkg.Packed(m, k=k, nnz_per_lane=C, n_wave_partitions=info["n_wave_partitions"])
+    packed = pkg.Packed(m, k=k, nnz_per_lane=C, n_wave_partitions=(info["batch_mode"] >> 16) or info["n_wave_partitions"])
     assert packed.info()["n_wave_partitions"] == info["n_wave_partitions"]
     raw = packed.raw()
     n_q = 12 if rows >= 1000000 else 6

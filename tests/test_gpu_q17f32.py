@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 def _packed_expect(pkg, oracle, m, x, k, eng, min_score=0.0):
     info = eng.info()
     C = info["packet_entries"] // 64
-    packed = pkg.Packed(m, k=k, nnz_per_lane=C, n_wave_partitions=info["n_wave_partitions"], precision=pkg.Q1_7_F32)
+    packed = pkg.Packed(m, k=k, nnz_per_lane=C, n_wave_partitions=(info["batch_mode"] >> 16) or info["n_wave_partitions"], precision=pkg.Q1_7_F32)
     assert packed.info()["n_wave_partitions"] == info["n_wave_partitions"]
     raw = packed.raw()
     assert raw[1] == 64 * C * 3  # 3 bytes per entry: one value byte + the column word
