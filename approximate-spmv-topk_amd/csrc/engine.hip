@@ -425,9 +425,9 @@ struct EngineImpl {
         B.n_selectors = n_sel_wg;
         B.scratch_stride = (uint64_t)grid * WG_SLOTS + ovf_cap;
         B.local = use_local;
+        B.prior_block = reinterpret_cast<uint32_t *>(d_wg_prior + grid);
         if (use_local && carry_local) {
             B.wg_prior = d_wg_prior;
-            B.prior_block = reinterpret_cast<uint32_t *>(d_wg_prior + grid);
             B.local_beta = local_beta;
         }
         hipLaunchKernelGGL(batch_kernel_for(), dim3(grid), dim3(block + 64), 0, s, P, S, B);

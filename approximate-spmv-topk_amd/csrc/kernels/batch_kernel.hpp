@@ -290,7 +290,7 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
                 S.prior_word = B.prior_word;
                 S.prior_rise = B.prior_rise;
                 S.local_thr = local ? 1u : 0u;
-                S.prior_block = (local && B.wg_prior) ? B.prior_block : nullptr;
+                S.prior_block = ((local && B.wg_prior) || use_prior) ? B.prior_block : nullptr;
             }
             if (RESIDENT) {
                 S.host_epoch = B.epoch0 + q + 1u;  // (host_out comes with SP0)
@@ -377,7 +377,7 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
                 const float *xg = RESIDENT ? reinterpret_cast<const float *>(B.xr + (size_t)par * XCOLS) : B.io[qx(staged)].x;
                 // the guess for this query (issued here, used below: its round trip overlaps the loads of x)
                 const uint32_t prior_key = use_prior ? __hip_atomic_load(B.prior_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-                const uint32_t prior_blocked = carry_local ? __hip_atomic_load(B.prior_block, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1u;
+                const uint32_t prior_blocked = (carry_local || use_prior) ? __hip_atomic_load(B.prior_block, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1u;
                 // (resident: the two device-side copies of x are rewritten in place query after query; they live in fine-
                 //  grained memory and are read with agent-scope loads, so no cache can serve a previous query's x)
                 auto x_at = [&](uint32_t i) __attribute__((always_inline)) -> float {
@@ -442,7 +442,7 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
                 if (lane < 8u) L.stg_cnt[par][lane] = 0u;
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                 float tau_init = min_units_q[par];
-                if (prior_key != 0u) {
+                if (prior_key != 0u && prior_blocked == 0u) {
                     const float t0 = key_to_float(prior_key) * unit_scale * B.prior_beta;  // (reported score -> this query's units)
                     if (t0 > 0.0f && t0 > tau_init) {
                         tau_init = t0;
