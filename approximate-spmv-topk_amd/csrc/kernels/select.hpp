@@ -104,7 +104,11 @@ __device__ __forceinline__ uint32_t kth_largest_prefix(const uint32_t (&gk)[MAX_
 
 // VERIFY: the batch kernel's checked thresholds (tau0_g / repair_flag / prior_word / local_thr) are compiled in; the other kernels
 // never set those fields and do without the code (and its registers).
-template <bool VERIFY = false>
+// OVF_SPEC: the first OVF_SPEC x nthreads entries of the overflow list are loaded BLINDLY with the slots (before the list's length
+// is known): the single-query launches, whose tail this selection is, save the two trips through memory that counting and
+// placing a short overflow list cost otherwise (it holds ~100 entries at 1M rows). 0: the batch kernel (its selections run
+// beside the stream, and it has no registers to spare).
+template <bool VERIFY = false, int OVF_SPEC = 0>
 __device__ __forceinline__ void select_body(const SelectParams &P, const uint32_t tid, const uint32_t nthreads,
                                             SelectShared &S, const uint32_t dbg_flags = 0u,
                                             unsigned long long *stamps = nullptr, const float out_scale_override = 0.0f) {
@@ -148,6 +152,14 @@ __device__ __forceinline__ void select_body(const SelectParams &P, const uint32_
         const uint32_t f = tid + u * nthreads;
         mine[u] = ~0ull;
         if (f < n_slots) mine[u] = ld_agent(&P.wg_cand[f]);
+    }
+    unsigned long long ospec[OVF_SPEC > 0 ? OVF_SPEC : 1];
+    if (OVF_SPEC > 0) {
+#pragma unroll
+        for (int u = 0; u < OVF_SPEC; ++u) {
+            const uint32_t i = tid + (uint32_t)u * nthreads;
+            ospec[u] = i < P.ovf_cap ? ld_agent(&P.ovf_cand[i]) : 0ull;
+        }
     }
     if (P.pos_to_row) {
 #pragma unroll
@@ -193,7 +205,12 @@ __device__ __forceinline__ void select_body(const SelectParams &P, const uint32_
     // that is not final yet, and a late threshold floods the list): count first, then place.
     {
         uint32_t c = 0;
-        for (uint32_t i = tid; i < novf; i += nthreads)
+        if (OVF_SPEC > 0) {
+#pragma unroll
+            for (int u = 0; u < OVF_SPEC; ++u)
+                c += (tid + (uint32_t)u * nthreads < novf && order_key(__uint_as_float((uint32_t)ospec[u])) >= thr) ? 1u : 0u;
+        }
+        for (uint32_t i = tid + (uint32_t)OVF_SPEC * nthreads; i < novf; i += nthreads)
             c += (order_key(__uint_as_float((uint32_t)ld_agent(&P.ovf_cand[i]))) >= thr) ? 1u : 0u;
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) c += (uint32_t)__shfl_xor((int)c, d);
@@ -210,7 +227,14 @@ __device__ __forceinline__ void select_body(const SelectParams &P, const uint32_
     }
     for (uint32_t i0 = 0; i0 < novf; i0 += nthreads) {  // wave-uniform trip count
         const uint32_t i = i0 + tid;
-        unsigned long long v = i < novf ? ld_agent(&P.ovf_cand[i]) : 0ull;
+        unsigned long long v = 0ull;
+        if (OVF_SPEC > 0 && i0 < (uint32_t)OVF_SPEC * nthreads) {
+#pragma unroll
+            for (int u = 0; u < OVF_SPEC; ++u)
+                if (i0 == (uint32_t)u * nthreads) v = ospec[u];
+        } else if (i < novf) {
+            v = ld_agent(&P.ovf_cand[i]);
+        }
         const bool keep = i < novf && order_key(__uint_as_float((uint32_t)v)) >= thr;
         if (keep && P.pos_to_row) v = pack_cand((uint32_t)v, P.pos_to_row[(uint32_t)(v >> 32)]);
         const uint64_t bm = __ballot(keep);

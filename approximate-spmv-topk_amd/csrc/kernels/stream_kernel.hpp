@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(576, ((C == 8 && !SCORES) || QM == 7) ? 6 : 5)
         // one partition per streaming wave of grid - 1 workgroups, so nothing waits for a free slot: the selection
         // runs during the launch's start-up, when the memory system is still idle.
         if (bid == 0u) {
-            if (SP.n_wg != 0u) select_body(SP, tid, blockDim.x, sel_sh);
+            if (SP.n_wg != 0u) select_body<false, 1>(SP, tid, blockDim.x, sel_sh);
             if (tr && lane == 0) {
                 tr[0] = tr0;
                 tr[5] = __builtin_amdgcn_s_memrealtime();
@@ -212,6 +212,37 @@ __global__ void __launch_bounds__(576, ((C == 8 && !SCORES) || QM == 7) ? 6 : 5)
     constexpr uint32_t WAVE_CAP = ListGeom<XCOLS>::WAVE_CAP;
     uint2 *wcand = cand + (is_server ? 0u : wave) * WAVE_CAP;  // this wave's private candidate list
     uint32_t wcnt = 0u;                                         // its length (wave-uniform)
+    // Flush of the wave's list: what clears the threshold goes to global memory -- the first survivor of the launch to this
+    // wave's fixed slot, further ones to the shared overflow list (write-through stores: in fused mode another workgroup of
+    // this launch reads them) -- and the list is empty again. Slots without a survivor are NOT written: the selection resets
+    // every slot it consumed, so an untouched slot is invalid by construction.
+    bool slot_used = false;
+    auto flush_list = [&](float tau_f) __attribute__((always_inline)) {
+        ListScan<WAVE_CAP / 64u> LS;
+        const uint32_t surv = scan_list<WAVE_CAP / 64u>(wcand, wcnt, tau_f, lane, LS);
+        wcnt = 0u;
+        if (surv == 0u) return;
+        const uint32_t to_slot = slot_used ? 0u : 1u;
+        uint32_t gbase = 0u;
+        if (surv > to_slot) {
+            if (lane == 0) gbase = atomicAdd(P.ovf_count, surv - to_slot);
+            gbase = __builtin_amdgcn_readfirstlane(gbase);
+        }
+        unsigned long long *slot = P.wg_cand + (size_t)bid * WG_SLOTS + wave;
+#pragma unroll
+        for (uint32_t u = 0; u < WAVE_CAP / 64u; ++u) {
+            if (LS.keep[u]) {
+                const unsigned long long v = pack_cand(LS.e[u].x, LS.e[u].y);
+                if (LS.pos[u] < to_slot) st_agent(slot, v);
+                else if (gbase + LS.pos[u] - to_slot < P.ovf_cap) st_agent(&P.ovf_cand[gbase + LS.pos[u] - to_slot], v);
+            }
+        }
+        slot_used = true;
+    };
+    // (Flushing EARLY -- four packets before the end of the partition, so that the stores' ~3 us trip to memory rides under the
+    //  remaining packets instead of sitting between the last workgroup's last packet and its ticket -- was measured and is not
+    //  done: the threshold of that moment lets thousands of rows through that the final one stops (the final flush delivers
+    //  ~110 candidates per query at 1M rows), the overflow list and the selection grow: 32-35 us per launch against 30.9.)
     for (bool first_part = true; q < P.n_parts; q += total_waves, first_part = false) {
         if (!first_part) {  // more partitions than waves (not the case for engines built by tkspmv_create)
             p0 = P.part_first[q];
@@ -356,24 +387,7 @@ __global__ void __launch_bounds__(576, ((C == 8 && !SCORES) || QM == 7) ? 6 : 5)
     if (!is_server) {
         const float tau = __uint_as_float(
             __hip_atomic_load(&misc[MISC_TAU], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-        ListScan<WAVE_CAP / 64u> LS;
-        const uint32_t surv = scan_list<WAVE_CAP / 64u>(wcand, wcnt, tau, lane, LS);
-        if (surv != 0u) {
-            uint32_t gbase = 0u;
-            if (surv > 1u) {
-                if (lane == 0) gbase = atomicAdd(P.ovf_count, surv - 1u);
-                gbase = __builtin_amdgcn_readfirstlane(gbase);
-            }
-            unsigned long long *slot = P.wg_cand + (size_t)bid * WG_SLOTS + wave;
-#pragma unroll
-            for (uint32_t u = 0; u < WAVE_CAP / 64u; ++u) {
-                if (LS.keep[u]) {
-                    const unsigned long long v = pack_cand(LS.e[u].x, LS.e[u].y);
-                    if (LS.pos[u] == 0u) st_agent(slot, v);
-                    else if (gbase + LS.pos[u] - 1u < P.ovf_cap) st_agent(&P.ovf_cand[gbase + LS.pos[u] - 1u], v);
-                }
-            }
-        }
+        if (wcnt != 0u) flush_list(tau);
         if (dbg_counters && lane == 0 && wave == 0u) {  // TKSPMV_STATS=1 (approximate: waves still running are not counted)
             atomicAdd(&dbg_counters[0], (unsigned long long)misc[MISC_SLOW_CNT]);
             atomicAdd(&dbg_counters[1], (unsigned long long)misc[MISC_CAND_CNT]);
@@ -424,7 +438,7 @@ __global__ void __launch_bounds__(576, ((C == 8 && !SCORES) || QM == 7) ? 6 : 5)
     }
     __syncthreads();
     const unsigned long long ts_ticket = dbg_stamps ? __builtin_amdgcn_s_memtime() : 0ull;
-    if (sel_sh.last && !(dbg_flags & 16u)) select_body(SP, tid, blockDim.x, sel_sh, dbg_flags, dbg_stamps, inv_unit);
+    if (sel_sh.last && !(dbg_flags & 16u)) select_body<false, 1>(SP, tid, blockDim.x, sel_sh, dbg_flags, dbg_stamps, inv_unit);
     if (dbg_stamps && sel_sh.last && tid == 0) {
         dbg_stamps[0] = ts_stream_end;
         dbg_stamps[1] = ts_flush_issued;

@@ -308,6 +308,14 @@ def single_query_leg(mod, m, xs, dxs, a, device, eng, alg_bytes):
                     "--kernel-trace durations of the same launches are committed under profiles/"}
 
 
+def read_only_floor(eng, info, passes=64):
+    """The load-only probe on THIS engine's wave-BSCSR stream (tkspmv_time_stream_read: same launch geometry, rotating copies,
+    loads only): what moving that stream costs on this box -- the floor the leg's kernel_us stands against."""
+    ns = sorted(eng.time_stream_read(passes) for _ in range(3))[1]
+    return {"us": ns / 1e3, "stream_bytes": int(info["packed_bytes"]), "GB_per_s": info["packed_bytes"] / ns if ns else None,
+            "method": "tkspmv_time_stream_read on this engine, median of 3 x %d passes" % passes}
+
+
 def config_legs(mod, a, device):
     """BASELINE.json configs[2] and configs[4] at their own sizes, each with its roofline fraction (and, for the reduced
     precision, the reference's acceptance metric: precision@K against the fp32 gold)."""
@@ -326,10 +334,12 @@ def config_legs(mod, a, device):
     ns = min(eng.time_queries(dxs.data_ptr(), 16, 512) for _ in range(3))
     val, idx = eng.read_result()
     ok, _ = check_parity(mod, m, xs[511 % 16], 8, idx, val, eng)
+    ro = read_only_floor(eng, info)
     out.append({"workload": "configs[2]: 1000000x1024 gamma nnz/row=20, K=8, 32 row partitions x K=8 lists (exact: k <= K per partition)",
                 "kernel_us": ns / 1e3, "algorithmic_bytes": int(info["algorithmic_bytes"]),
                 "roofline": {"bound": "hbm", "achieved": info["algorithmic_bytes"] / ns, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": info["algorithmic_bytes"] / ns / HBM_PEAK_GBS},
+                             "frac": info["algorithmic_bytes"] / ns / HBM_PEAK_GBS, "read_only": ro,
+                             "kernel_vs_read_only": ro["us"] * 1e3 / ns if ns else None},
                 "parity_checked": ok})
     eng.close()
     del eng, m
@@ -347,6 +357,11 @@ def config_legs(mod, a, device):
     torch.cuda.synchronize()
     eng.enqueue_multi(dxs.data_ptr(), 4, out_i.data_ptr(), out_v.data_ptr())
     eng.synchronize()
+    ro4 = read_only_floor(eng, info)
+    # (the probe reads the engine's wave-BSCSR byte stream -- 3 B/nnz + row words; the kernel of this leg streams the SELL copy,
+    #  2.5 B/nnz: at the probe's rate that stream would take sell_stream_at_that_rate_us)
+    ro4["sell_stream_bytes"] = int(info["multi_bytes"])
+    ro4["sell_stream_at_that_rate_us"] = info["multi_bytes"] / ro4["GB_per_s"] / 1e3 if ro4["GB_per_s"] else None
     vq = O.round_to_q17(m.val)
     prec, exact = [], True
     for q in range(4):
@@ -361,7 +376,9 @@ def config_legs(mod, a, device):
                 "dtype": "u8 values / f32 arithmetic", "kernel": "tkspmv::multi_kernel<1,1>",
                 "kernel_us": ns / 1e3, "algorithmic_bytes": int(info["algorithmic_bytes"]), "stream_bytes": int(info["multi_bytes"]),
                 "roofline": {"bound": "hbm", "achieved": info["algorithmic_bytes"] / ns, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": info["algorithmic_bytes"] / ns / HBM_PEAK_GBS},
+                             "frac": info["algorithmic_bytes"] / ns / HBM_PEAK_GBS, "read_only": ro4,
+                             "physical": {"bytes": int(info["multi_bytes"]), "achieved": info["multi_bytes"] / ns,
+                                          "frac": info["multi_bytes"] / ns / HBM_PEAK_GBS}},
                 "precision_at_100": float(np.mean(prec)), "precision_at_100_min": float(min(prec)),
                 "parity_checked": exact,
                 "parity_note": "bit-exact against the order-matched oracle on the de-quantised values (parity unpinned against "
@@ -381,11 +398,13 @@ def config_legs(mod, a, device):
         ns = min(eng.time_queries(dxs.data_ptr(), 16, 64) for _ in range(3))
         val, idx = eng.read_result()
         ok, _ = check_parity(mod, m, xs[63 % 16], a.k, idx, val, None, bit_exact=False)
+        ro3 = read_only_floor(eng, info, 16)
         out.append({"workload": f"configs[3] on ONE GPU: {rows3}x1024 gamma nnz/row=20 (nnz={info['nnz']}), K={a.k}, fp32, two rotating "
                                 "stream copies (1.17 GB each: no cache holds one) -- what `--gpus N` strong-scales",
                     "value": 1e9 / ns, "unit": "queries/s", "kernel_us": ns / 1e3, "algorithmic_bytes": int(info["algorithmic_bytes"]),
                     "roofline": {"bound": "hbm", "achieved": info["algorithmic_bytes"] / ns, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                 "frac": info["algorithmic_bytes"] / ns / HBM_PEAK_GBS},
+                                 "frac": info["algorithmic_bytes"] / ns / HBM_PEAK_GBS, "read_only": ro3,
+                                 "kernel_vs_read_only": ro3["us"] * 1e3 / ns if ns else None},
                     "parity_checked": ok})
         eng.close()
     except Exception as e:  # noqa: BLE001  (a box short of host memory: the leg is reported as missing, the line survives)

@@ -147,6 +147,25 @@ def test_pack_decode_round_trip(pkg, C, parts):
     assert p.info()["packed_entries"] - g.nnz <= p.info()["n_wave_partitions"] * 64 * C
 
 
+def test_shortest_partition_depends_on_the_matrix_size_alone(pkg, monkeypatch):
+    """wbscsr.hpp: min_packets_per_partition_for -- every packer (host, device, tkspmv_pack, the engine) must cut the same
+    partitions from the same hint. Small matrices (the shards of a strong-scaled run) get partitions from one or two packets
+    up, so that every streaming wave of a 256-CU launch has something to stream; large ones at least four packets each."""
+    tiny = pkg.generate_matrix(40000, 1024, 20, "gamma", 3)      # ~3100 packets of 256 entries: up to 1 per partition
+    small = pkg.generate_matrix(150000, 1024, 20, "gamma", 3)    # ~11700 packets: 2+
+    large = pkg.generate_matrix(800000, 1024, 20, "gamma", 3)    # ~62500 packets: 4+
+    for m, lo, hi in ((tiny, 1, 2), (small, 2, 3), (large, 4, 1000)):
+        i = pkg.Packed(m, nnz_per_lane=4, n_wave_partitions=16384).info()
+        assert lo <= i["packets_per_partition"] <= hi, (m.rows, i["packets_per_partition"])
+        assert i["n_wave_partitions"] * i["packets_per_partition"] >= i["n_packets"]
+    # the same hint on the same matrix gives the same cut (what the parity tests rely on when they re-pack on the host)
+    a = pkg.Packed(small, nnz_per_lane=4, n_wave_partitions=4064).raw()
+    b = pkg.Packed(small, nnz_per_lane=4, n_wave_partitions=4064).raw()
+    assert np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
+    monkeypatch.setenv("TKSPMV_SMALL_PACKETS", "0")  # round 2's rule: four packets at least, whatever the size
+    assert pkg.Packed(tiny, nnz_per_lane=4, n_wave_partitions=16384).info()["packets_per_partition"] >= 4
+
+
 def test_fp32_column_words_travel_as_12_bits(pkg, oracle, monkeypatch):
     """TKSPMV_F32 over at most 1024 columns packs its column words (10 bits of column, 2 flags) into 12 bits (the default;
     TKSPMV_F32_C12=0 keeps 16): 1408-byte packets instead of 1536. Same entries, same order; the bits are where csrc/wbscsr.hpp says (a split plane: one

@@ -4,7 +4,8 @@
 # 1. plain bench line; 2. the same command under rocprofv3 --kernel-trace --stats; 3. separate --pmc passes for the
 # memory-side counters (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE do not fit one pass; no trace domains with --pmc);
 # 4. the multi-query path alone (8 and 4 queries per pass) under --kernel-trace --stats; 5. single fused launches
-# (tkspmv_run) under --kernel-trace --stats; 6. configs[4] (Q1.7 bytes, fp32 arithmetic) under --kernel-trace --stats.
+# (tkspmv_run) under --kernel-trace --stats; 6. configs[4] (Q1.7 bytes, fp32 arithmetic) under --kernel-trace --stats;
+# 7. one 125k-row shard through the sharded step; 8. configs[3] (10M rows) on one GPU, both under --kernel-trace --stats.
 # Everything lands in gpurun_out/prof_<tag>/; tools/summarize_profile.py turns it into the files kept under profiles/.
 set -u
 TAG=${1:-r01}
@@ -34,5 +35,10 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/single" -- python3
 export TKSPMV_MULTI_CHAINS=1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/q17f" -- python3 "$REPO/tools/q17f_probe.py" --only > "$OUT/q17f.log" 2> "$OUT/q17f.err"
 unset TKSPMV_MULTI_CHAINS
+# 7. one shard of a strong-scaled run (1/8 of the 1M-row matrix) through bench.py's sharded code path: the batch kernel with its
+#    small-matrix settings (4 selector workgroups, workgroup-local thresholds, the repair launch behind every batch launch)
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/shard125k" -- python3 "$REPO/bench.py" --total-rows 125000 --config3-rows 0 --steps 2048 --warmup 256 > "$OUT/shard125k.json" 2> "$OUT/shard125k.err"
+# 8. BASELINE configs[3] on ONE GPU (10M rows) in the mode the bench reports it: back-to-back batch launches, two stream copies
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/config3" -- python3 "$REPO/bench.py" --rows 10000000 --replicas 2 --steps 128 --warmup 32 --cpu-seconds 0 --skip-warm --traffic off --reps 4 --multi-q > "$OUT/config3.json" 2> "$OUT/config3.err"
 cd "$REPO"
 python3 tools/summarize_profile.py "$OUT" "$TAG"

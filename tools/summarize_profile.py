@@ -54,6 +54,16 @@ for sub, name in (("single", f"{tag}_single_query_kernel_stats.csv"), ("q17f", f
     if os.path.exists(log):
         shutil.copy(log, os.path.join(dst, name.replace("_kernel_stats.csv", ".log")))
 
+for sub, stem in (("shard125k", f"{tag}_shard125k"), ("config3", f"{tag}_config3_10M")):
+    src = find(f"{sub}/**/*kernel_stats.csv")
+    if src:
+        shutil.copy(src, os.path.join(dst, stem + "_kernel_stats.csv"))
+    p = os.path.join(out, sub + ".json")
+    if os.path.exists(p):
+        lines = [l for l in open(p).read().splitlines() if l.startswith("{")]
+        if lines:
+            open(os.path.join(dst, stem + "_under_rocprofv3.json"), "w").write(lines[-1] + "\n")
+
 summary = {}
 for d in sorted(glob.glob(os.path.join(out, "pmc*"))):
     if not os.path.isdir(d):
