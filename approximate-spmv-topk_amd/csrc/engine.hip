@@ -170,6 +170,7 @@ struct EngineImpl {
     float *d_wg_prior = nullptr;  // [grid] + the countdown word (BatchParams::wg_prior / prior_block)
     bool carry_local = true;
     float local_beta = 1.0f;
+    uint32_t pace_quads = 0; // pacing by rank (BatchParams::pace_quads)
     uint32_t n_sel_wg = 1;   // selector workgroups of a batch launch (BatchParams::n_selectors): 4 on small matrices
     float prior_beta = 0.9f, prior_rise = 1.02f;
     // claim_kernel (kernels/claim_kernel.hpp): the matrix is packed into sets of 8 wave partitions that workgroups claim
@@ -425,6 +426,7 @@ struct EngineImpl {
         B.n_selectors = n_sel_wg;
         B.scratch_stride = (uint64_t)grid * WG_SLOTS + ovf_cap;
         B.local = use_local;
+        B.pace_quads = pace_quads;
         B.prior_block = reinterpret_cast<uint32_t *>(d_wg_prior + grid);
         if (use_local && carry_local) {
             B.wg_prior = d_wg_prior;
@@ -767,12 +769,18 @@ static hipError_t malloc_exchange(void **p, size_t bytes) {
 
 // Small matrices (the shards of a strong-scaled run): a query streams in less time than one selection takes and than a
 // device-wide threshold needs to form. They get 4 selector workgroups, partitions from 1-2 packets up (every wave streams:
-// twice the loads in flight; wbscsr.hpp: min_packets_per_partition_for) and workgroup-local thresholds. Returns the selector
-// workgroups of a batch launch for this matrix and geometry (TKSPMV_SELECTORS overrides; the matrix unknown -- nnz = 0 --: 1).
+// twice the loads in flight; wbscsr.hpp: min_packets_per_partition_for) and workgroup-local thresholds. With pacing by rank
+// (create_impl) the same settings win up to LOCAL_MATRIX_PACKETS -- the headline's 1M rows included; beyond, the device-wide
+// exchange is as fast and checks nothing. Returns the selector workgroups of a batch launch for this matrix and geometry
+// (TKSPMV_SELECTORS overrides; the matrix unknown -- nnz = 0 --: 1). TKSPMV_SMALL_PACKETS: both limits (0: round 2's behaviour).
+static uint64_t local_matrix_packets() {
+    if (const char *f = getenv("TKSPMV_SMALL_PACKETS")) return (uint64_t)atoll(f);
+    return LOCAL_MATRIX_PACKETS;
+}
 static uint32_t small_matrix_settings(const tkspmv_desc &d, uint32_t grid, bool defer_capable, uint32_t C, bool *small_out) {
     const uint64_t packets_lb = d.nnz / (64u * (uint64_t)std::max(C, 1u));
     const bool small = defer_capable && grid >= 64u && d.nnz != 0 && d.cols <= 1024u && d.impl == TKSPMV_IMPL_STREAM && d.multi_q == 0 &&
-                       d.partitions <= 1 && packets_lb <= small_matrix_packets() && !getenv("TKSPMV_MULTI_Q") && !getenv("TKSPMV_CLAIM");
+                       d.partitions <= 1 && packets_lb <= local_matrix_packets() && !getenv("TKSPMV_MULTI_Q") && !getenv("TKSPMV_CLAIM");
     if (small_out) *small_out = small;
     uint32_t n = small ? 4u : 1u;
     if (const char *f = getenv("TKSPMV_SELECTORS")) n = (uint32_t)std::max(1, std::min(8, atoi(f)));
@@ -1206,11 +1214,16 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
             fprintf(stderr, "[tkspmv] small matrix %d: %u selector workgroups, %.0f partitions of %.1f packets, %.0f per workgroup; local thresholds fail with p = %.2e (mode 1) / %.2e (mode 2): mode %u\n",
                     (int)small_matrix, m.n_sel_wg, n_parts, per_part, a, p1, p2, m.use_local);
     }
-    HIP_TRY(malloc_exchange((void **)&m.d_wg_prior, ((size_t)m.grid + 32) * 4));
+    HIP_TRY(malloc_exchange((void **)&m.d_wg_prior, ((size_t)m.grid + 32) * 4));  // priors | countdown words
     HIP_TRY(hipMemset(m.d_wg_prior, 0, ((size_t)m.grid + 32) * 4));
     if (const char *f = getenv("TKSPMV_LOCAL_CARRY")) m.carry_local = atoi(f) != 0;
     if (const char *f = getenv("TKSPMV_LOCAL_BETA")) m.local_beta = (float)atof(f);
     if (const char *f = getenv("TKSPMV_LOCAL")) m.use_local = m.grid > 512u ? 0u : (uint32_t)std::max(0, std::min(2, atoi(f)));
+    // Pacing by rank, with local thresholds only (with the device-wide exchange the cold phase of every query is governor enough, §3.0):
+    // the longer the partitions, the longer the pause (size sweeps on two boxes, tools/ab_rank.sh: best at 0 / 1 / 2 units
+    // up to 575k / 830k / 1.3M rows of 20 non-zeros).
+    if (m.use_local) m.pace_quads = m.pm.n_packets <= 45000u ? 0u : (m.pm.n_packets <= 65000u ? 1u : 2u);
+    if (const char *f = getenv("TKSPMV_PACE")) m.pace_quads = (uint32_t)std::max(0, std::min(16, atoi(f)));
     {
         // Exchange-state sets: one block per field, set s at s strides (the batch kernel addresses them that way).
         if (m.can_batch && !m.can_multi && !m.resident_capable) {

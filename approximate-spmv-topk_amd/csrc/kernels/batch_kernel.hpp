@@ -98,6 +98,12 @@ struct BatchParams : SetAddr {
     float *wg_prior;
     uint32_t *prior_block;
     float local_beta;
+    // Pacing by rank (pace_quads != 0; see the note at the ticket add): the per-packet pause of the workgroups that led the field
+    // in the previous query, in units of s_sleep(4) = 256 cycles (first, second, third eighth of the field: 3, 2, 1 units).
+    // (An integrating variant -- every workgroup carries its own pause, one unit up after a query delivered in the first third,
+    //  one down after one in the second half, kept between launches -- was measured and is worse than no pacing, 19-20 us per
+    //  query at 1M rows: what helps is not equal finishing times but fewer requests in flight from whoever happens to lead.)
+    uint32_t pace_quads;
     // ---- resident mode (RESIDENT = true; tkspmv_run with desc.impl = TKSPMV_IMPL_RESIDENT) -------------------------------
     // ONE launch serves queries as the host submits them: no launch, no copy engine, no stream synchronisation per query.
     // The host writes x into pinned memory and raises `request` (an epoch counter); the doorman -- wave 0 of the selector
@@ -130,22 +136,17 @@ struct BatchLds {
     uint32_t misc[2][MISC_WORDS];                        // per query parity
     unsigned long long stg[2][8][STG_N];                 // survivors staged by the streaming waves
     uint32_t stg_cnt[2][8];
-    uint32_t pace;  // issue priority the workgroup's streaming waves take at their next query start (0..2), set by the server
+    uint32_t pace;  // pause per packet (bits 0-7: 0..3 units) and issue priority (bit 8) of the streaming waves in their next query, set by the server
 #ifndef TKSPMV_ALTERNATE_PRIO
 #define TKSPMV_ALTERNATE_PRIO 1
 #endif
-// Pacing by rank (experiment, off): a workgroup among the first to deliver a query sleeps a little per packet, one among the
-// last gets the higher priority. With the candidate path switched off it takes the launch from 18.3-19.6 to 17.2 us per
-// query (the XCDs no longer drift apart); with it on -- the cold phase of every query already acts as a governor -- it costs
-// 0.2-0.5 us (tools/ab_variants.sh, one box).
-#ifndef TKSPMV_RANK_PRIO
-#define TKSPMV_RANK_PRIO 0
-#endif
+// Pacing by rank (BatchParams::pace_quads, decided by the host): a workgroup among the first to deliver a query sleeps a little per
+// packet, one among the last gets the higher priority. With the device-wide exchange -- the cold phase of every query already
+// acts as a governor -- it costs 0.2-0.7 us per query; with workgroup-local thresholds carried from query to query (no cold
+// phase: every wave asks for all it can get, and the XCDs drift apart) it is what makes that mode the faster one at 1M rows:
+// 16.8 us per query against 19.1-19.9 unpaced and 18.0 with the device-wide exchange (tools/ab_rank.sh, one box).
 #ifndef TKSPMV_DUAL_EXCHANGE
 #define TKSPMV_DUAL_EXCHANGE 0
-#endif
-#ifndef TKSPMV_PACE_SLEEP
-#define TKSPMV_PACE_SLEEP 4
 #endif
 };
 
@@ -198,7 +199,8 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
     auto set_of = [&](uint32_t q) __attribute__((always_inline)) -> uint32_t { return RESIDENT ? q % (uint32_t)BATCH_MAX : qx(q); };
     const bool use_prior = !RESIDENT && !repair && B.prior_word != nullptr;
     const bool local = !RESIDENT && !repair && B.local != 0u;
-    const bool local_top1 = B.local == 1u;  // a wave's word is its best packet maximum (1) or its second best (2)
+    const bool local_top1 = B.local == 1u;
+    const uint32_t pace_q = (RESIDENT || repair) ? 0u : B.pace_quads;  // a wave's word is its best packet maximum (1) or its second best (2)
 
     const uint32_t nsel = B.n_selectors;  // (>= 1)
     if (blockIdx.x < nsel) {
@@ -318,7 +320,7 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
     if (trw && lane == 0) trw[0] = __builtin_amdgcn_s_memrealtime();
     if (tid < 2u * MISC_WORDS) (&L.misc[0][0])[tid] = 0u;
     if (tid < 16u) (&L.stg_cnt[0][0])[tid] = 0u;
-    if (tid == 0u) L.pace = 4u;
+    if (tid == 0u) L.pace = 0u;
     __syncthreads();
     const uint32_t grp_local = is_server ? 0u : wave * P0.gpw / nwaves;
     const bool publishes = !local && (bid * P0.gpw + grp_local) < P0.n_groups_pub;  // (local: the waves publish by themselves)
@@ -349,6 +351,7 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
         uint32_t staged = 0u, tail = 0u;
         const bool carry_local = local && B.wg_prior != nullptr;
         float wg_prior = carry_local ? B.wg_prior[bid] : 0.0f;  // (reported-score units; 0: none)
+
         uint32_t published = RESIDENT ? 0u : nq;  // queries whose x is available (resident: as the doorman publishes them)
         float inv_unit_q[2] = {1.0f, 1.0f}, min_units_q[2] = {0.0f, 0.0f};
         unsigned long long dbg_first_duty = 0ull;
@@ -601,25 +604,22 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
                     // write-through (sc1) store; drain them, then a RELAXED agent-scope add. A release-ordered atomic
                     // would write back the whole L2 (buffer_wbl2) once per workgroup and query: measured 4 ms/query.
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#if TKSPMV_RANK_PRIO
                     // The ticket's value tells this workgroup where it stands in the field: among the first to deliver a
                     // query, it is ahead of the others; among the last, behind. Workgroups are not equally fast -- the two on a
                     // CU do not share it evenly (the older one wins the arbitration), and the less a wave does per packet the
                     // more that shows: with the candidate path switched off the median wave streams a query in 11.5 us while a
                     // tenth of the workgroups take 26-28 us, and the launch waits for them (tools/batch_trace.py). The rank is
                     // the feedback: an early workgroup lowers the issue priority of its streaming waves, a late one raises it.
-                    if (!RESIDENT) {
+                    if (pace_q != 0u) {
                         uint32_t rank = 0u;
                         if (lane == 0) rank = __hip_atomic_fetch_add(B.tickets + 32u * set_of(tail), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         rank = __builtin_amdgcn_readfirstlane(rank);
-                        // pace: 0..3 = sleep per packet (x TKSPMV_PACE_SLEEP x 64 cycles) for the first eighths of the field, 4 = none,
-                        // 5 = none and the higher issue priority (last third)
+                        // the pause per packet of the next query (bits 0-7, units of pace_quads x 256 cycles): 3, 2, 1 for the first
+                        // three eighths of the field; bit 8: the last third gets the higher issue priority
                         const uint32_t e8 = 8u * rank / n_wg;  // 0..7
-                        const uint32_t lvl = e8 < 3u ? e8 : (3u * rank >= 2u * n_wg ? 5u : 4u);
+                        const uint32_t lvl = (e8 < 3u ? 3u - e8 : 0u) | (3u * rank >= 2u * n_wg ? 256u : 0u);
                         if (lane == 0) __hip_atomic_store(&L.pace, lvl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    } else
-#endif
-                    if (lane == 0)
+                    } else if (lane == 0)
                         (void)__hip_atomic_fetch_add(B.tickets + 32u * set_of(tail), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (trw && lane == 0 && TRSLOT(tail) < 3u) trw[4 + TRSLOT(tail)] = __builtin_amdgcn_s_memrealtime();
                     if (trw && lane == 0 && TRSLOT(tail) == 1u) {
@@ -724,7 +724,7 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
     float carry = 0.0f, min_units = 0.0f;
     float top1 = 0.0f, top2 = 0.0f;  // local thresholds: the two largest packet maxima of this wave in the current query
     uint32_t wcnt = 0u;
-    uint32_t pace = 4u;  // this query's pacing level (server: from the workgroup's rank in the previous query's tickets)
+    uint32_t pace = 0u;  // this query's pause per packet, units of pace_quads x 256 cycles (the server: from the workgroup's rank in the previous query)
     bool waited = false;  // this wave has used its bounded wait for a threshold in the current query (long partitions)
     const bool long_partition = np * (uint32_t)(C / 4) >= 28u;  // ~14 rows finish per 256 entries: > 1.5 lists per query
     uint32_t *mp = L.misc[0];
@@ -761,13 +761,13 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
                     redo_owed = false;
                     ncold = 0u;
                     champ = -__builtin_huge_valf();
-#if TKSPMV_RANK_PRIO
-                    if (!RESIDENT) {
-                        pace = __builtin_amdgcn_readfirstlane(lds_load(&L.pace));
-                        if (pace == 5u) __builtin_amdgcn_s_setprio(2);
+                    if (pace_q != 0u) {
+                        const uint32_t pw = __builtin_amdgcn_readfirstlane(lds_load(&L.pace));
+                        pace = pw & 255u;
+                        if (pw & 256u) __builtin_amdgcn_s_setprio(2);
                         else __builtin_amdgcn_s_setprio(1);
-                    }
-#elif TKSPMV_ALTERNATE_PRIO
+                    } else {
+#if TKSPMV_ALTERNATE_PRIO
                     // The two workgroups of a CU do not share it evenly at equal priority: the older one wins the arbitration
                     // (traced over a 32-query launch: 17.2 against 21.5 us per query), runs ahead, finishes early and leaves
                     // the CU half empty while the launch waits for the slower half. They take turns instead, query by query:
@@ -776,16 +776,12 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
                     if (((qc ^ (bid >= n_wg / 2u ? 1u : 0u)) & 1u) != 0u) __builtin_amdgcn_s_setprio(TKSPMV_STREAM_PRIO);
                     else __builtin_amdgcn_s_setprio(TKSPMV_STREAM_PRIO - 1);
 #endif
+                    }
                 }
             }
-#if TKSPMV_RANK_PRIO
             // a workgroup ahead of the field yields: fewer requests from it, more bandwidth for the XCDs that lag
-            if (pace < 3u) {
-                if (pace == 0u) __builtin_amdgcn_s_sleep(3 * TKSPMV_PACE_SLEEP);
-                else if (pace == 1u) __builtin_amdgcn_s_sleep(2 * TKSPMV_PACE_SLEEP);
-                else __builtin_amdgcn_s_sleep(TKSPMV_PACE_SLEEP);
-            }
-#endif
+#pragma unroll 1
+            for (uint32_t z = pace * pace_q; z != 0u; --z) __builtin_amdgcn_s_sleep(4);
             const uint32_t tau_bits = lds_load(&mp[MISC_TAU]);
             const float tau = __uint_as_float(tau_bits);
             const Reduced<C> Rd = reduce_packet<C, QM>(cur, carry, xbase, P0.fixed_mask);

@@ -286,6 +286,8 @@ struct PackedMatrix {
 // 1 up to a tenth of that.
 // (TKSPMV_MIN_PACKETS / TKSPMV_SMALL_PACKETS: tuning runs.)
 constexpr uint64_t SMALL_MATRIX_PACKETS = 55000;
+// (up to this many packets -- ~1.3M rows of 20 non-zeros -- the batch kernel runs with workgroup-local thresholds: engine.hip)
+constexpr uint64_t LOCAL_MATRIX_PACKETS = 100000;
 uint64_t small_matrix_packets();
 uint32_t min_packets_per_partition_for(uint64_t nnz, uint32_t C, uint32_t cols);
 
