@@ -1222,7 +1222,9 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
     // Pacing by rank, with local thresholds only (with the device-wide exchange the cold phase of every query is governor enough, §3.0):
     // the longer the partitions, the longer the pause (size sweeps on two boxes, tools/ab_rank.sh: best at 0 / 1 / 2 units
     // up to 575k / 830k / 1.3M rows of 20 non-zeros).
-    if (m.use_local) m.pace_quads = m.pm.n_packets <= 45000u ? 0u : (m.pm.n_packets <= 65000u ? 1u : 2u);
+    // The pause follows the packet's size (fp32 values with 12-bit columns, 1408 bytes: 2 units; fp16, 896 bytes: 1 -- 15.4 us per query
+    // at 1M rows against 16.3 at 2 units and 16.7 with the device-wide exchange).
+    if (m.use_local) m.pace_quads = m.pm.n_packets <= 45000u ? 0u : (m.pm.n_packets <= 65000u ? 1u : std::max(1u, (m.pm.packet_bytes + 352u) / 704u));
     if (const char *f = getenv("TKSPMV_PACE")) m.pace_quads = (uint32_t)std::max(0, std::min(16, atoi(f)));
     {
         // Exchange-state sets: one block per field, set s at s strides (the batch kernel addresses them that way).

@@ -1,9 +1,11 @@
-# A/B at 1M rows on one box (run on the GPU box): round 3's defaults (workgroup-local thresholds, carried, pacing by rank at 2 units)
-# against other pauses (TKSPMV_PACE, units of 256 cycles per level) and against round 2's behaviour (TKSPMV_SMALL_PACKETS=0)
+# One box (run on the GPU box): other value types and shapes under workgroup-local thresholds + pacing
 cd $GRAFT_REPO_ROOT
-run() { echo -n "$*: "; env "$@" timeout -k 10 200 python tools/ablate_probe.py ${ROWS:-1000000} 1024 20 none 2>&1 | grep flags | head -1 | cut -c1-75; }
-for r in 1 2 3; do
-  run TKSPMV_SMALL_PACKETS=0
-  run TKSPMV_DEFAULTS=1
-  run TKSPMV_PACE=3
+run() { echo -n "$*: "; env SWEEP=wide "$@" timeout -k 10 300 python tools/size_sweep.py 2>&1 | grep -E "F32|F16|Q1_7" | tr '\n' ' '; echo; }
+for p in off 1 2 3; do
+  if [ $p = off ]; then E="TKSPMV_SMALL_PACKETS=0"; else E="TKSPMV_SMALL_PACKETS=400000 TKSPMV_PACE=$p"; fi
+  run $E SWEEP_ROWS=1000000 SWEEP_PREC=F16
+  run $E SWEEP_ROWS=1000000 SWEEP_COLS=512 SWEEP_NNZ=40 SWEEP_PREC=Q1_7
+  run $E SWEEP_ROWS=1000000 SWEEP_COLS=512 SWEEP_NNZ=40 SWEEP_PREC=F32
+  run $E SWEEP_ROWS=1000000 SWEEP_PREC=FIXED
+  run $E SWEEP_ROWS=1000000 SWEEP_K=8
 done

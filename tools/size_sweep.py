@@ -16,7 +16,8 @@ SMALL = [(r, 1024, 20, 100, "F32") for r in (50000, 125000, 250000, 500000)]  # 
 MID = [(r, 1024, 20, 100, "F32") for r in (400000, 600000, 800000, 1000000)]  # SWEEP=mid: where the small-matrix settings stop paying
 WIDE = [(r, 1024, 20, 100, "F32") for r in (250000, 500000, 750000, 1000000, 1500000, 2000000, 3000000)]  # SWEEP=wide: pacing by size
 if os.environ.get("SWEEP_ROWS"):
-    WIDE = [(int(r), 1024, 20, 100, os.environ.get("SWEEP_PREC", "F32")) for r in os.environ["SWEEP_ROWS"].split(",")]
+    WIDE = [(int(r), int(os.environ.get("SWEEP_COLS", "1024")), int(os.environ.get("SWEEP_NNZ", "20")), int(os.environ.get("SWEEP_K", "100")),
+             os.environ.get("SWEEP_PREC", "F32")) for r in os.environ["SWEEP_ROWS"].split(",")]
 for rows, cols, nnz, k, prec in SMALL if os.environ.get("SWEEP") == "small" else MID if os.environ.get("SWEEP") == "mid" else WIDE if os.environ.get("SWEEP") == "wide" else [(50000, 1024, 20, 100, "F32"), (200000, 1024, 20, 100, "F32"), (1000000, 1024, 20, 100, "F32"),
                                  (1000000, 1024, 20, 10, "F32"), (1000000, 1024, 20, 200, "F32"), (1000000, 512, 40, 100, "F32"),
                                  (1000000, 512, 40, 100, "Q1_7"), (1000000, 1024, 20, 100, "F16"), (2000000, 1024, 20, 100, "F32"),
