@@ -170,7 +170,7 @@ struct EngineImpl {
     float *d_wg_prior = nullptr;  // [grid] + the countdown word (BatchParams::wg_prior / prior_block)
     bool carry_local = true;
     float local_beta = 1.0f;
-    uint32_t pace_quads = 0; // pacing by rank (BatchParams::pace_quads)
+    uint32_t pace_quads = 0, pace_levels = 3; // pacing by rank (BatchParams::pace_quads, pace_levels)
     uint32_t n_sel_wg = 1;   // selector workgroups of a batch launch (BatchParams::n_selectors): 4 on small matrices
     float prior_beta = 0.9f, prior_rise = 1.02f;
     // claim_kernel (kernels/claim_kernel.hpp): the matrix is packed into sets of 8 wave partitions that workgroups claim
@@ -427,6 +427,7 @@ struct EngineImpl {
         B.scratch_stride = (uint64_t)grid * WG_SLOTS + ovf_cap;
         B.local = use_local;
         B.pace_quads = pace_quads;
+        B.pace_levels = pace_levels;
         B.prior_block = reinterpret_cast<uint32_t *>(d_wg_prior + grid);
         if (use_local && carry_local) {
             B.wg_prior = d_wg_prior;
@@ -1220,12 +1221,14 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
     if (const char *f = getenv("TKSPMV_LOCAL_BETA")) m.local_beta = (float)atof(f);
     if (const char *f = getenv("TKSPMV_LOCAL")) m.use_local = m.grid > 512u ? 0u : (uint32_t)std::max(0, std::min(2, atoi(f)));
     // Pacing by rank, with local thresholds only (with the device-wide exchange the cold phase of every query is governor enough, §3.0):
-    // the longer the partitions, the longer the pause (size sweeps on two boxes, tools/ab_rank.sh: best at 0 / 1 / 2 units
+    // the longer the partitions, the longer the pause (size sweeps on two boxes, tools/ab_rank.sh: best at 0 / 1 / 2 units of 256 cycles
     // up to 575k / 830k / 1.3M rows of 20 non-zeros).
     // The pause follows the packet's size (fp32 values with 12-bit columns, 1408 bytes: 2 units; fp16, 896 bytes: 1 -- 15.4 us per query
     // at 1M rows against 16.3 at 2 units and 16.7 with the device-wide exchange).
-    if (m.use_local) m.pace_quads = m.pm.n_packets <= 45000u ? 0u : (m.pm.n_packets <= 65000u ? 1u : std::max(1u, (m.pm.packet_bytes + 352u) / 704u));
-    if (const char *f = getenv("TKSPMV_PACE")) m.pace_quads = (uint32_t)std::max(0, std::min(16, atoi(f)));
+    // (units of 128 cycles per level)
+    if (m.use_local) m.pace_quads = m.pm.n_packets <= 45000u ? 0u : (m.pm.n_packets <= 65000u ? 2u : 2u * std::max(1u, (m.pm.packet_bytes + 352u) / 704u));
+    if (const char *f = getenv("TKSPMV_PACE_LEVELS")) m.pace_levels = (uint32_t)std::max(1, std::min(8, atoi(f)));
+    if (const char *f = getenv("TKSPMV_PACE")) m.pace_quads = (uint32_t)std::max(0, std::min(32, atoi(f)));
     {
         // Exchange-state sets: one block per field, set s at s strides (the batch kernel addresses them that way).
         if (m.can_batch && !m.can_multi && !m.resident_capable) {

@@ -99,11 +99,12 @@ struct BatchParams : SetAddr {
     uint32_t *prior_block;
     float local_beta;
     // Pacing by rank (pace_quads != 0; see the note at the ticket add): the per-packet pause of the workgroups that led the field
-    // in the previous query, in units of s_sleep(4) = 256 cycles (first, second, third eighth of the field: 3, 2, 1 units).
+    // in the previous query: pace_quads units of s_sleep(2) = 128 cycles, times pace_levels, pace_levels - 1, ..., 1 for the first,
+    // second, ... eighth of the field (pace_levels = 3: three eighths pause).
     // (An integrating variant -- every workgroup carries its own pause, one unit up after a query delivered in the first third,
     //  one down after one in the second half, kept between launches -- was measured and is worse than no pacing, 19-20 us per
     //  query at 1M rows: what helps is not equal finishing times but fewer requests in flight from whoever happens to lead.)
-    uint32_t pace_quads;
+    uint32_t pace_quads, pace_levels;
     // ---- resident mode (RESIDENT = true; tkspmv_run with desc.impl = TKSPMV_IMPL_RESIDENT) -------------------------------
     // ONE launch serves queries as the host submits them: no launch, no copy engine, no stream synchronisation per query.
     // The host writes x into pinned memory and raises `request` (an epoch counter); the doorman -- wave 0 of the selector
@@ -614,10 +615,10 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
                         uint32_t rank = 0u;
                         if (lane == 0) rank = __hip_atomic_fetch_add(B.tickets + 32u * set_of(tail), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         rank = __builtin_amdgcn_readfirstlane(rank);
-                        // the pause per packet of the next query (bits 0-7, units of pace_quads x 256 cycles): 3, 2, 1 for the first
+                        // the pause per packet of the next query (bits 0-7, units of pace_quads x 128 cycles): 3, 2, 1 for the first
                         // three eighths of the field; bit 8: the last third gets the higher issue priority
                         const uint32_t e8 = 8u * rank / n_wg;  // 0..7
-                        const uint32_t lvl = (e8 < 3u ? 3u - e8 : 0u) | (3u * rank >= 2u * n_wg ? 256u : 0u);
+                        const uint32_t lvl = (e8 < B.pace_levels ? B.pace_levels - e8 : 0u) | (3u * rank >= 2u * n_wg ? 256u : 0u);
                         if (lane == 0) __hip_atomic_store(&L.pace, lvl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     } else if (lane == 0)
                         (void)__hip_atomic_fetch_add(B.tickets + 32u * set_of(tail), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -724,7 +725,7 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
     float carry = 0.0f, min_units = 0.0f;
     float top1 = 0.0f, top2 = 0.0f;  // local thresholds: the two largest packet maxima of this wave in the current query
     uint32_t wcnt = 0u;
-    uint32_t pace = 0u;  // this query's pause per packet, units of pace_quads x 256 cycles (the server: from the workgroup's rank in the previous query)
+    uint32_t pace = 0u;  // this query's pause per packet, units of pace_quads x 128 cycles (the server: from the workgroup's rank in the previous query)
     bool waited = false;  // this wave has used its bounded wait for a threshold in the current query (long partitions)
     const bool long_partition = np * (uint32_t)(C / 4) >= 28u;  // ~14 rows finish per 256 entries: > 1.5 lists per query
     uint32_t *mp = L.misc[0];
@@ -781,7 +782,7 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
             }
             // a workgroup ahead of the field yields: fewer requests from it, more bandwidth for the XCDs that lag
 #pragma unroll 1
-            for (uint32_t z = pace * pace_q; z != 0u; --z) __builtin_amdgcn_s_sleep(4);
+            for (uint32_t z = pace * pace_q; z != 0u; --z) __builtin_amdgcn_s_sleep(2);
             const uint32_t tau_bits = lds_load(&mp[MISC_TAU]);
             const float tau = __uint_as_float(tau_bits);
             const Reduced<C> Rd = reduce_packet<C, QM>(cur, carry, xbase, P0.fixed_mask);
