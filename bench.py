@@ -524,7 +524,11 @@ def bench_single(a, mod, torch, np, dev, local_rank):
         "config": {"workload": workload_name(a.rows, a.cols, a.nnz, int(info["nnz"]), a.k, a.replicas),
                    "rows": a.rows, "cols": a.cols, "nnz": int(info["nnz"]), "k": a.k, "parallelism": "single GPU",
                    "launch": {"grid": info["grid"], "block": info["block"] + 64,
-                              "wave_partitions": info["n_wave_partitions"], "packet_entries": info["packet_entries"]}},
+                              "wave_partitions": info["n_wave_partitions"], "packet_entries": info["packet_entries"],
+                              # (tkspmv_info.batch_mode: how the engine runs back-to-back queries on this matrix)
+                              "selector_workgroups": info.get("batch_mode", 0) & 0xFF,
+                              "thresholds": {0: "device-wide exchange", 1: "workgroup-local (best packet maximum per wave), checked by the selection, repair launch",
+                                             2: "workgroup-local (second best packet maximum per wave), checked by the selection, repair launch"}[(info.get("batch_mode", 0) >> 8) & 0xFF]}},
         "roofline": {"bound": "hbm", "achieved": alg_bytes / kernel_ns, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": alg_bytes / kernel_ns / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": source,
                      "traffic_detail": detail,
