@@ -62,8 +62,11 @@ __device__ __forceinline__ uint32_t order_key_d(float f) {
     const uint32_t u = __float_as_uint(f);
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
-constexpr uint32_t MERGE_THREADS = 1024;
-constexpr uint32_t MERGE_MAX = 8192;  // world * k
+// 256 threads and as much LDS as the batch needs (8 bytes per gathered pair): a merge block must fit on a CU BESIDE two workgroups of
+// the persistent batch kernel (18 of its 32 wave slots) -- with 1024 threads and a fixed 64 KB it could not, the merge of batch b
+// waited for the local kernel of batch b+1 to end, and that kernel's successor for the merge (rocprofv3: 113 us per merge launch).
+constexpr uint32_t MERGE_THREADS = 256;
+constexpr uint32_t MERGE_MAX = 8184;  // world * k (+ 8 padding keys: 64 KB of dynamic LDS)
 
 // gathered: [world][n_q][2][k] u32 (row ids, then score bits); block q merges query q of the batch. Output: the k best
 // by (score desc, row desc); equal keys (the (0, 0.0) fillers several shards may contribute) are ordered by position,
@@ -71,7 +74,7 @@ constexpr uint32_t MERGE_MAX = 8192;  // world * k
 __global__ void __launch_bounds__(MERGE_THREADS) merge_kernel(const uint32_t *__restrict__ gathered, uint32_t world,
                                                               uint32_t k, uint32_t *__restrict__ out_idx,
                                                               float *__restrict__ out_val) {
-    __shared__ unsigned long long keys[MERGE_MAX + 8];
+    extern __shared__ unsigned long long keys[];  // [world * k + 8]
     const uint32_t n = world * k, tid = threadIdx.x, q = blockIdx.x, n_q = gridDim.x;
     out_idx += (size_t)q * k;
     out_val += (size_t)q * k;
@@ -101,6 +104,8 @@ __global__ void __launch_bounds__(MERGE_THREADS) merge_kernel(const uint32_t *__
         }
     }
 }
+
+static inline size_t merge_lds(uint32_t world, uint32_t k) { return ((size_t)world * k + 8u) * sizeof(unsigned long long); }
 
 constexpr int MAX_BATCH = 32;
 
@@ -172,7 +177,7 @@ int tkspmv_merge_topk(const uint32_t *dev_gathered, int32_t world, int32_t k, ui
                       void *stream) {
     if (!dev_gathered || !dev_idx || !dev_val || world < 1 || k < 1 || (uint64_t)world * k > MERGE_MAX)
         return dfail(TKSPMV_ERR_INVALID, "bad arguments to tkspmv_merge_topk (world * k must be <= 8192)");
-    hipLaunchKernelGGL(merge_kernel, dim3(1), dim3(MERGE_THREADS), 0, (hipStream_t)stream, dev_gathered, (uint32_t)world,
+    hipLaunchKernelGGL(merge_kernel, dim3(1), dim3(MERGE_THREADS), merge_lds((uint32_t)world, (uint32_t)k), (hipStream_t)stream, dev_gathered, (uint32_t)world,
                        (uint32_t)k, dev_idx, dev_val);
     DHIP(hipGetLastError());
     return TKSPMV_OK;
@@ -184,7 +189,7 @@ int tkspmv_merge_topk_batch(const uint32_t *dev_gathered, int32_t world, int32_t
                             void *stream) {
     if (!dev_gathered || !dev_idx || !dev_val || world < 1 || k < 1 || n_q < 1 || n_q > MAX_BATCH || (uint64_t)world * k > MERGE_MAX)
         return dfail(TKSPMV_ERR_INVALID, "bad arguments to tkspmv_merge_topk_batch (world * k must be <= 8192, n_q in [1, 32])");
-    hipLaunchKernelGGL(merge_kernel, dim3((uint32_t)n_q), dim3(MERGE_THREADS), 0, (hipStream_t)stream, dev_gathered, (uint32_t)world,
+    hipLaunchKernelGGL(merge_kernel, dim3((uint32_t)n_q), dim3(MERGE_THREADS), merge_lds((uint32_t)world, (uint32_t)k), (hipStream_t)stream, dev_gathered, (uint32_t)world,
                        (uint32_t)k, dev_idx, dev_val);
     DHIP(hipGetLastError());
     return TKSPMV_OK;
@@ -207,7 +212,7 @@ int tkspmv_dist_create(tkspmv_dist_t **out, tkspmv_t *engine, const uint8_t *id1
     *out = nullptr;
     tkspmv_info info;
     engine->e->info(&info);
-    if ((uint64_t)world * info.k > MERGE_MAX) return dfail(TKSPMV_ERR_INVALID, "world * k must be <= 8192");
+    if ((uint64_t)world * info.k > MERGE_MAX) return dfail(TKSPMV_ERR_INVALID, "world * k must be <= 8184");
     tkspmv_dist *h = new tkspmv_dist();
     Dist &d = h->d;
     d.engine = engine->e;
@@ -284,7 +289,7 @@ int tkspmv_dist_time_exchange(tkspmv_dist_t *h, int32_t iters, double *ns_per_ex
         } else {
             DHIP(hipMemcpyAsync(d.gathered[0], d.local[0], (size_t)n_q * 2 * d.k * 4, hipMemcpyDeviceToDevice, d.comm_stream));
         }
-        hipLaunchKernelGGL(merge_kernel, dim3(n_q), dim3(MERGE_THREADS), 0, d.comm_stream, d.gathered[0], (uint32_t)d.world,
+        hipLaunchKernelGGL(merge_kernel, dim3(n_q), dim3(MERGE_THREADS), merge_lds((uint32_t)d.world, (uint32_t)d.k), d.comm_stream, d.gathered[0], (uint32_t)d.world,
                            (uint32_t)d.k, d.out_idx[0], d.out_val[0]);
     }
     DHIP(hipGetLastError());
@@ -336,7 +341,7 @@ static int dist_flush(Dist &d) {
     } else {
         DHIP(hipMemcpyAsync(d.gathered[b], d.local[b], (size_t)n_q * 2 * d.k * 4, hipMemcpyDeviceToDevice, d.comm_stream));
     }
-    hipLaunchKernelGGL(merge_kernel, dim3(n_q), dim3(MERGE_THREADS), 0, d.comm_stream, d.gathered[b], (uint32_t)d.world,
+    hipLaunchKernelGGL(merge_kernel, dim3(n_q), dim3(MERGE_THREADS), merge_lds((uint32_t)d.world, (uint32_t)d.k), d.comm_stream, d.gathered[b], (uint32_t)d.world,
                        (uint32_t)d.k, d.out_idx[b], d.out_val[b]);
     DHIP(hipGetLastError());
     DHIP(hipEventRecord(d.ev_merge[b], d.comm_stream));
