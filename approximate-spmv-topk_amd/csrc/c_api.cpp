@@ -94,6 +94,7 @@ int tkspmv_debug_trace(tkspmv_t *h, uint64_t *host, uint64_t max_words, uint64_t
     if (words) *words = w;
     return st;
 }
+int tkspmv_debug_counters(tkspmv_t *h, uint64_t *out, int32_t n) { ENGINE_CALL(debug_counters(reinterpret_cast<unsigned long long *>(out), n, err)) }
 int tkspmv_enqueue_multi(tkspmv_t *h, const float *dev_xs, int32_t count, uint32_t *dev_idx, float *dev_val, void *stream) {
     ENGINE_CALL(enqueue_multi(dev_xs, count, dev_idx, dev_val, stream, err))
 }

@@ -171,6 +171,7 @@ struct EngineImpl {
     bool carry_local = true;
     float local_beta = 1.0f;
     uint32_t pace_quads = 0, pace_levels = 3; // pacing by rank (BatchParams::pace_quads, pace_levels)
+    mutable uint64_t batch_launches = 0;
     uint32_t n_sel_wg = 1;   // selector workgroups of a batch launch (BatchParams::n_selectors): 4 on small matrices
     float prior_beta = 0.9f, prior_rise = 1.02f;
     // claim_kernel (kernels/claim_kernel.hpp): the matrix is packed into sets of 8 wave partitions that workgroups claim
@@ -428,6 +429,7 @@ struct EngineImpl {
         B.local = use_local;
         B.pace_quads = pace_quads;
         B.pace_levels = pace_levels;
+        ++batch_launches;
         B.prior_block = reinterpret_cast<uint32_t *>(d_wg_prior + grid);
         if (use_local && carry_local) {
             B.wg_prior = d_wg_prior;
@@ -1726,6 +1728,25 @@ int Engine::read(uint32_t *idx, float *val, int32_t *n, std::string &err) {
     if (idx) HIP_TRY(hipMemcpy(idx, m.d_out_idx, (size_t)m.desc.k * 4, hipMemcpyDeviceToHost));
     if (val) HIP_TRY(hipMemcpy(val, m.d_out_val, (size_t)m.desc.k * 4, hipMemcpyDeviceToHost));
     if (n) *n = m.desc.k;
+    return TKSPMV_OK;
+}
+
+// out[0] = selections whose threshold check failed so far (each sent its query through the repair launch), out[1] = the current
+// suspension length of carried thresholds, out[2] = selections to go until they are used again, out[3] = batch launches so far.
+int Engine::debug_counters(unsigned long long *out, int n, std::string &err) {
+    EngineImpl &m = *impl_;
+    if (!out || n < 4) {
+        err = "debug_counters needs room for 4 values";
+        return TKSPMV_ERR_INVALID;
+    }
+    HIP_TRY(hipSetDevice(m.device));
+    if (m.stream) HIP_TRY(hipStreamSynchronize(m.stream));
+    uint32_t w[4] = {0, 0, 0, 0};
+    if (m.d_wg_prior) HIP_TRY(hipMemcpy(w, m.d_wg_prior + m.grid, sizeof(w), hipMemcpyDeviceToHost));
+    out[0] = w[3];
+    out[1] = w[1];
+    out[2] = w[0];
+    out[3] = m.batch_launches;
     return TKSPMV_OK;
 }
 

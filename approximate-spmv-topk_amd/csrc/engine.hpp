@@ -45,6 +45,7 @@ class Engine {
     int result_device(const uint32_t **dev_idx, const float **dev_val);
     int scores(float *host_y, std::string &err);
     int read_trace(unsigned long long *host, size_t max_words, size_t *words, std::string &err);
+    int debug_counters(unsigned long long *out, int n, std::string &err);
     int time_queries(const float *dev_xs, int32_t n_x, int32_t iters, double *ns_per_query, std::string &err);
     int time_stream_read(int32_t passes, double *ns_per_pass, std::string &err);
     int profile(const float *dev_xs, int32_t n_x, int32_t iters, tkspmv_timing *out, std::string &err);

@@ -306,6 +306,7 @@ __device__ __forceinline__ void select_body(const SelectParams &P, const uint32_
                 // failure (16 .. 4096: data on which carried thresholds keep failing ends up paying a repair per 4096 queries),
                 // halved by every 64 checks passed in a row with them (word 2).
                 if (bad) {
+                    (void)__hip_atomic_fetch_add(P.prior_block + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (word 3: checks failed so far -- tkspmv_debug_counters)
                     const uint32_t len = __hip_atomic_load(P.prior_block + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     const uint32_t nl = len < 16u ? 16u : (len >= 2048u ? 4096u : 2u * len);
                     __hip_atomic_store(P.prior_block + 1, nl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

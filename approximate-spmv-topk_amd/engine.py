@@ -142,6 +142,13 @@ class SpMV:
         _lib.check(_lib.lib().tkspmv_time_multi(self._h, C.c_void_p(int(dev_xs)), int(n_x), int(iters), C.byref(ns)))
         return ns.value
 
+    def debug_counters(self):
+        """Checked thresholds of back-to-back queries (info()["batch_mode"]): how many selections failed their check so far (and
+        sent their query through the repair launch), the suspension state of carried thresholds, batch launches so far."""
+        out = (C.c_uint64 * 4)()
+        _lib.check(_lib.lib().tkspmv_debug_counters(self._h, out, 4))
+        return {"checks_failed": int(out[0]), "suspension_length": int(out[1]), "suspended_for": int(out[2]), "batch_launches": int(out[3])}
+
     def synchronize(self):
         _lib.check(_lib.lib().tkspmv_synchronize(self._h))
 

@@ -222,6 +222,11 @@ int tkspmv_scores(tkspmv_t *e, float *host_y);
  * [4][grid+1][9 waves][8] words: entry, x staged, first packet reduced, stream loop done, deferred packets judged,
  * flush done. tools/timeline.py turns them into a timeline. TKSPMV_ERR_STATE when tracing is off. */
 int tkspmv_debug_trace(tkspmv_t *e, uint64_t *host, uint64_t max_words, uint64_t *words);
+/* Diagnostics of the checked thresholds of back-to-back queries (tkspmv_info.batch_mode; no reference counterpart): out[0] =
+ * selections whose check failed so far (each sent its query through the repair launch), out[1] = current suspension length of
+ * carried thresholds (selections), out[2] = selections to go until they are used again, out[3] = batch launches so far. n >= 4.
+ * Synchronises the engine's stream. */
+int tkspmv_debug_counters(tkspmv_t *e, uint64_t *out, int32_t n);
 
 /* `iters` queries back to back on the engine stream (cycling over n_x device-resident vectors), ONE hipEvent pair
  * around the batch: *ns_per_query = batch time / iters. Nothing else is launched (for profiler runs). */
