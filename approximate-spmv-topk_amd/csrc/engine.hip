@@ -1732,21 +1732,24 @@ int Engine::read(uint32_t *idx, float *val, int32_t *n, std::string &err) {
 }
 
 // out[0] = selections whose threshold check failed so far (each sent its query through the repair launch), out[1] = the current
-// suspension length of carried thresholds, out[2] = selections to go until they are used again, out[3] = batch launches so far.
+// suspension length of carried thresholds, out[2] = selections to go until they are used again, out[3] = batch launches so far,
+// out[4] = launches the local thresholds as a whole stay switched off for, out[5] = the length of that closure.
 int Engine::debug_counters(unsigned long long *out, int n, std::string &err) {
     EngineImpl &m = *impl_;
-    if (!out || n < 4) {
-        err = "debug_counters needs room for 4 values";
+    if (!out || n < 6) {
+        err = "debug_counters needs room for 6 values";
         return TKSPMV_ERR_INVALID;
     }
     HIP_TRY(hipSetDevice(m.device));
     if (m.stream) HIP_TRY(hipStreamSynchronize(m.stream));
-    uint32_t w[4] = {0, 0, 0, 0};
+    uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (m.d_wg_prior) HIP_TRY(hipMemcpy(w, m.d_wg_prior + m.grid, sizeof(w), hipMemcpyDeviceToHost));
     out[0] = w[3];
     out[1] = w[1];
     out[2] = w[0];
     out[3] = m.batch_launches;
+    out[4] = w[4];  // launches the gate of the local thresholds stays closed for
+    out[5] = w[5];  // length of its latest closure
     return TKSPMV_OK;
 }
 

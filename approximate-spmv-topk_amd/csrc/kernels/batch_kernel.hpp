@@ -191,17 +191,38 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
             if (tid == 0) rq_lds[BATCH_MAX] = (uint32_t)__popcll(bm);
         }
         __syncthreads();
+        // The gate of the local thresholds (words 4, 5 behind prior_block; written HERE only -- between two batch launches, so
+        // every workgroup of the next one reads the same value): a launch of which a quarter or more failed its checks closes it
+        // for 8, 16, ... 1024 launches (the matrix keeps its best rows together: a workgroup's 8 slots cannot hold them, whatever
+        // the thresholds do); it counts down by one per launch, and 16 clean launches in a row halve the next closure.
+        if (blockIdx.x == 0u && tid == 0u && B.local != 0u && B.prior_block) {
+            uint32_t *gate = B.prior_block + 4;
+            const uint32_t failed = rq_lds[BATCH_MAX];
+            if (B.n_q >= 4u && 4u * failed >= B.n_q) {
+                const uint32_t len = gate[1] < 8u ? 8u : (gate[1] >= 512u ? 1024u : 2u * gate[1]);
+                gate[1] = len;
+                gate[0] = len;
+                gate[2] = 0u;
+            } else if (gate[0] != 0u) {
+                gate[0] -= 1u;
+            } else if (failed == 0u && ++gate[2] >= 16u) {
+                gate[2] = 0u;
+                if (gate[1] > 8u) gate[1] /= 2u;
+            }
+        }
         if (rq_lds[BATCH_MAX] == 0u) return;
     }
+    // (closed gate: this launch runs with the device-wide exchange, like a repair launch does)
+    const bool local_open = B.local != 0u && !(B.prior_block && B.prior_block[4] != 0u);
     const uint32_t nq = RESIDENT ? 0xFFFFFFF0u : (repair ? rq_lds[BATCH_MAX] : B.n_q);
     // query q of THIS launch in the launch's argument block (repair: the q-th flagged query of the launch before)
     auto qx = [&](uint32_t q) __attribute__((always_inline)) -> uint32_t { return repair ? rq_lds[q] : q; };
     // exchange-state set / ticket counter of query q (resident: the sets are reused round robin -- one query is in flight)
     auto set_of = [&](uint32_t q) __attribute__((always_inline)) -> uint32_t { return RESIDENT ? q % (uint32_t)BATCH_MAX : qx(q); };
     const bool use_prior = !RESIDENT && !repair && B.prior_word != nullptr;
-    const bool local = !RESIDENT && !repair && B.local != 0u;
+    const bool local = !RESIDENT && !repair && local_open;
     const bool local_top1 = B.local == 1u;
-    const uint32_t pace_q = (RESIDENT || repair) ? 0u : B.pace_quads;  // a wave's word is its best packet maximum (1) or its second best (2)
+    const uint32_t pace_q = (RESIDENT || repair || !local_open) ? 0u : B.pace_quads;  // a wave's word is its best packet maximum (1) or its second best (2)
 
     const uint32_t nsel = B.n_selectors;  // (>= 1)
     if (blockIdx.x < nsel) {

@@ -145,9 +145,10 @@ class SpMV:
     def debug_counters(self):
         """Checked thresholds of back-to-back queries (info()["batch_mode"]): how many selections failed their check so far (and
         sent their query through the repair launch), the suspension state of carried thresholds, batch launches so far."""
-        out = (C.c_uint64 * 4)()
-        _lib.check(_lib.lib().tkspmv_debug_counters(self._h, out, 4))
-        return {"checks_failed": int(out[0]), "suspension_length": int(out[1]), "suspended_for": int(out[2]), "batch_launches": int(out[3])}
+        out = (C.c_uint64 * 6)()
+        _lib.check(_lib.lib().tkspmv_debug_counters(self._h, out, 6))
+        return {"checks_failed": int(out[0]), "suspension_length": int(out[1]), "suspended_for": int(out[2]), "batch_launches": int(out[3]),
+                "local_off_for_launches": int(out[4]), "local_off_length": int(out[5])}
 
     def synchronize(self):
         _lib.check(_lib.lib().tkspmv_synchronize(self._h))

@@ -224,7 +224,9 @@ int tkspmv_scores(tkspmv_t *e, float *host_y);
 int tkspmv_debug_trace(tkspmv_t *e, uint64_t *host, uint64_t max_words, uint64_t *words);
 /* Diagnostics of the checked thresholds of back-to-back queries (tkspmv_info.batch_mode; no reference counterpart): out[0] =
  * selections whose check failed so far (each sent its query through the repair launch), out[1] = current suspension length of
- * carried thresholds (selections), out[2] = selections to go until they are used again, out[3] = batch launches so far. n >= 4.
+ * carried thresholds (selections), out[2] = selections to go until they are used again, out[3] = batch launches so far, out[4] =
+ * launches for which the workgroup-local thresholds as a whole stay switched off (a launch of which a quarter failed closes them
+ * for 8 .. 1024 launches: data that keeps its best rows together), out[5] = the length of the latest such closure. n >= 6.
  * Synchronises the engine's stream. */
 int tkspmv_debug_counters(tkspmv_t *e, uint64_t *out, int32_t n);
 

@@ -974,6 +974,52 @@ def test_workgroup_local_thresholds_are_verified_and_repaired(pkg, oracle, monke
     eng.close()
 
 
+def test_local_thresholds_switch_themselves_off_on_adversarial_data(pkg, monkeypatch):
+    """What defeats the 8 slots of a workgroup is a matrix whose best rows sit, a few each, in ALL the partitions of the same
+    workgroups (many in ONE partition are harmless: that wave hands them over itself). Built here from the engine's own cut:
+    five heavy rows at the head of each of the 8 partitions of three workgroups -- 120 rows that hold every top-100, 40 per
+    workgroup. Every check fails, whatever the thresholds do. Results stay exact (the repair launch), and the mode must not
+    keep paying for it: a launch of which a quarter failed closes the gate for 8, 16, ... launches (tkspmv_debug_counters)."""
+    import torch
+    m = pkg.generate_matrix(200000, 1024, 20, "gamma", 13)
+    probe = pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, k=100, device=0)
+    info = probe.info()
+    probe.close()
+    n_wg = info["grid"] - (info["batch_mode"] & 0xFF)
+    assert (info["batch_mode"] >> 8) & 0xFF != 0  # local thresholds are this size's default
+    packed = pkg.Packed(m, k=100, nnz_per_lane=4, n_wave_partitions=info["batch_mode"] >> 16)
+    _, _, pkt_row, part_first, _ = packed.raw()
+    assert len(part_first) == info["n_wave_partitions"] and len(part_first) > 7 * n_wg + 200
+    heavy = np.concatenate([pkt_row[part_first[b + w * n_wg]] + np.arange(5) for b in (3, 77, 200) for w in range(8)])
+    val = m.val.copy()
+    val[np.isin(m.row, heavy)] *= np.float32(50.0)
+    nq, launches = 64, 12
+    xs = np.stack([pkg.create_sample_vector(1024, True, False, True, 7700 + i) for i in range(nq)])
+    dxs = torch.from_numpy(np.tile(xs, (launches * 32 // nq, 1))).cuda()
+    total = dxs.shape[0]
+    monkeypatch.setenv("TKSPMV_LOCAL", "0")
+    plain = pkg.SpMV(m.row, m.col, val, m.rows, m.cols, k=100, device=0)
+    ref_i = torch.full((total, 100), -1, dtype=torch.int32, device="cuda")
+    ref_v = torch.full((total, 100), -1.0, dtype=torch.float32, device="cuda")
+    plain.enqueue_batch(dxs.data_ptr(), total, ref_i.data_ptr(), ref_v.data_ptr())
+    plain.synchronize()
+    assert plain.debug_counters()["checks_failed"] == 0
+    plain.close()
+    assert bool(np.isin(ref_i.cpu().numpy().view(np.uint32), heavy).all())  # (the premise: every result row is a heavy row)
+    monkeypatch.delenv("TKSPMV_LOCAL")
+    eng = pkg.SpMV(m.row, m.col, val, m.rows, m.cols, k=100, device=0)
+    out_i = torch.full((total, 100), -1, dtype=torch.int32, device="cuda")
+    out_v = torch.full((total, 100), -1.0, dtype=torch.float32, device="cuda")
+    eng.enqueue_batch(dxs.data_ptr(), total, out_i.data_ptr(), out_v.data_ptr())
+    eng.synchronize()
+    assert torch.equal(out_i, ref_i) and torch.equal(out_v, ref_v)
+    c = eng.debug_counters()
+    assert c["batch_launches"] == launches
+    # launch 1 fails throughout and closes the gate for 8 launches; launch 10 tries again, fails, closes it for 16
+    assert c["checks_failed"] == 64 and c["local_off_length"] == 16 and c["local_off_for_launches"] == 14, c
+    eng.close()
+
+
 @pytest.mark.parametrize("cols,k", [(4096, 100), (1024, 600), (16384, 10)])
 def test_batches_on_geometries_without_the_batch_kernel(pkg, oracle, cols, k):
     """x too large to sit twice in LDS, or K above the number of publishing workgroups (several groups per workgroup /
