@@ -221,8 +221,8 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
     auto set_of = [&](uint32_t q) __attribute__((always_inline)) -> uint32_t { return RESIDENT ? q % (uint32_t)BATCH_MAX : qx(q); };
     const bool use_prior = !RESIDENT && !repair && B.prior_word != nullptr;
     const bool local = !RESIDENT && !repair && local_open;
-    const bool local_top1 = B.local == 1u;
-    const uint32_t pace_q = (RESIDENT || repair || !local_open) ? 0u : B.pace_quads;  // a wave's word is its best packet maximum (1) or its second best (2)
+    const bool local_top1 = B.local == 1u;  // a wave's word is its best packet maximum (1) or its second best (2)
+    const uint32_t pace_q = (RESIDENT || repair || !local_open) ? 0u : B.pace_quads;
 
     const uint32_t nsel = B.n_selectors;  // (>= 1)
     if (blockIdx.x < nsel) {
