@@ -1,6 +1,8 @@
 """GPU tests of the engine boundary beyond plain parity: the reference's golden vectors through the HIP path, edge
 cases (empty rows, k > rows, single row, rows longer than a packet, k = 1024, wide x), size-independent properties at
-the full BASELINE size, the drop-in executable's CSV, and the asynchronous/device-pointer entry points."""
+the full BASELINE size, the drop-in executable's CSV, and the asynchronous/device-pointer entry points.
+(_expected() is the bit-exact leg: it re-packs with the product's own host packer and the engine's partition hint, so it shares
+the packer with the product; the gold comparisons in the same tests are the independent leg -- see test_gpu_parity.py.)"""
 import glob
 import json
 import os

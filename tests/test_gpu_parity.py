@@ -2,6 +2,13 @@
 
 Bars (BASELINE.json north_star): same top-K index set as the reference CPU gold, fp32 scores within 1e-4 relative.
 On top of that the fused kernel must match the order-matched oracle (oracle_packed_scores) BIT FOR BIT.
+
+Two legs, two kinds of evidence: the GOLD leg (oracle.gold_topk / scores_f64: the reference's own algorithm restated in C from the
+COO, pinned to the reference's golden vectors) shares nothing with the product -- it is the independent check. The BIT-EXACT leg
+re-packs the matrix with the product's own host packer (pkg.Packed: csrc/wbscsr.cpp, with the partition hint the engine reports)
+and lets the oracle walk that layout in the kernel's summation order: it proves the kernels' arithmetic, scan, thresholds and
+selection bit for bit, but a packer bug common to both would pass it -- which is what the gold leg, the pack/decode round trips
+(test_host_mirror.py) and the device-packer-against-host-packer byte comparisons (test_gpu_device_pack.py) are for.
 """
 import numpy as np
 import pytest
