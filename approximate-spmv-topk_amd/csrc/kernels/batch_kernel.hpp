@@ -31,6 +31,9 @@ constexpr uint32_t STG_N = 8;  // survivors a wave can stage per query (64 lanes
 #define TKSPMV_TAU_WAIT 3000
 #endif
 constexpr unsigned long long BATCH_TAU_WAIT = TKSPMV_TAU_WAIT;  // x 10 ns (s_memrealtime runs at 100 MHz)
+// (a workgroup-local threshold forms through LDS within the workgroup's own query -- or never, when some wave of it holds no row
+//  above min_score: 3 us are plenty, and a workload filtered by min_score must not wait 30 us per query in such workgroups)
+constexpr unsigned long long LOCAL_TAU_WAIT = 300;
 constexpr int MISC_DBG_WAITS = 26, MISC_DBG_WAIT_TICKS = 27, MISC_DBG_REDO_PK = 28, MISC_DBG_REDO_WV = 29;  // TKSPMV_STATS=1 only
 constexpr int MISC_XREADY = 2, MISC_MINU = 3;  // batch kernel only: x staged for query (value - 1); min score in units
 constexpr int MISC_TAUKEY = 4;  // local thresholds: order key of the largest threshold formed in this workgroup (what goes on record)
@@ -908,7 +911,7 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
                         // resident. (On a small matrix every wave is in that position: 100+ us per query without this wait.)
                         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
                         while (lds_load(&mp[MISC_TAU]) == __float_as_uint(min_units) && !(P0.dbg_flags & 4u) &&
-                               __builtin_amdgcn_s_memrealtime() - t0 < BATCH_TAU_WAIT)
+                               __builtin_amdgcn_s_memrealtime() - t0 < (local ? LOCAL_TAU_WAIT : BATCH_TAU_WAIT))
                             __builtin_amdgcn_s_sleep(4);
                         if (DBG && P0.dbg && lane == 0) {  // TKSPMV_STATS=1
                             const unsigned long long dt = __builtin_amdgcn_s_memrealtime() - t0;

@@ -976,6 +976,46 @@ def test_workgroup_local_thresholds_are_verified_and_repaired(pkg, oracle, monke
     eng.close()
 
 
+def test_local_thresholds_with_a_min_score_that_filters_most_rows(pkg, monkeypatch):
+    """min_score above all but a few hundred rows' scores: most waves of a workgroup never see a row that counts, so most
+    workgroups never form a local threshold (a wave's word needs a row above min_score). Results equal the device-wide
+    exchange's bit for bit, fewer than k rows qualifying included, and no query may wait long for a threshold that cannot come
+    (LOCAL_TAU_WAIT): the batch must not be slower than a few times the unfiltered one."""
+    import torch
+    m = pkg.generate_matrix(150000, 1024, 20, "gamma", 21)
+    nq = 64
+    xs = np.stack([pkg.create_sample_vector(1024, True, False, True, 8800 + i) for i in range(nq)])
+    dxs = torch.from_numpy(xs).cuda()
+    base = pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, k=100, device=0)
+    bi = torch.zeros((nq, 100), dtype=torch.int32, device="cuda")
+    bv = torch.zeros((nq, 100), dtype=torch.float32, device="cuda")
+    base.enqueue_batch(dxs.data_ptr(), nq, bi.data_ptr(), bv.data_ptr())
+    base.synchronize()
+    t_plain = base.time_queries(dxs.data_ptr(), nq, 256)
+    base.close()
+    kth = float(np.sort(bv[0].cpu().numpy())[::-1][99])  # the 100th best score of the first query
+    for frac_kept, factor in ((3.0, 0.93), (0.4, 1.12)):  # min_score a little below / above it: a few hundred / fewer than k rows qualify
+        min_score = kth * factor
+        res = {}
+        for mode in ("0", "auto"):
+            if mode == "0":
+                monkeypatch.setenv("TKSPMV_LOCAL", "0")
+            else:
+                monkeypatch.delenv("TKSPMV_LOCAL", raising=False)
+            eng = pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, k=100, device=0, min_score=min_score)
+            oi = torch.full((nq, 100), -1, dtype=torch.int32, device="cuda")
+            ov = torch.full((nq, 100), -1.0, dtype=torch.float32, device="cuda")
+            eng.enqueue_batch(dxs.data_ptr(), nq, oi.data_ptr(), ov.data_ptr())
+            eng.synchronize()
+            res[mode] = (oi.clone(), ov.clone(), eng.time_queries(dxs.data_ptr(), nq, 256), eng.info()["batch_mode"])
+            eng.close()
+        assert (res["auto"][3] >> 8) & 0xFF != 0 and (res["0"][3] >> 8) & 0xFF == 0
+        assert torch.equal(res["0"][0], res["auto"][0]) and torch.equal(res["0"][1], res["auto"][1]), frac_kept
+        assert res["auto"][2] < 3.0 * t_plain, (res["auto"][2], t_plain)
+        if frac_kept < 1:
+            assert int((res["auto"][1][0] == 0).sum()) > 0  # (fewer than k rows qualify: the lists are padded like the reference's)
+
+
 def test_local_thresholds_switch_themselves_off_on_adversarial_data(pkg, monkeypatch):
     """What defeats the 8 slots of a workgroup is a matrix whose best rows sit, a few each, in ALL the partitions of the same
     workgroups (many in ONE partition are harmless: that wave hands them over itself). Built here from the engine's own cut:
