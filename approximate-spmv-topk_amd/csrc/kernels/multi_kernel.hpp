@@ -149,7 +149,9 @@ __device__ __forceinline__ float chunk_value(const Pkt<4, VT> &p, int j) {
 // VT: 0 = fp32 chunks (1536 B), 1 = byte chunks (768 B; four of them in flight behind the one being reduced instead of two).
 template <int Q, int VT = 0>
 __global__ void __launch_bounds__(576, Q >= 8 ? 4 : 6) multi_kernel(const StreamParams P0, const SelectParams SP0, const MultiParams M) {
-    constexpr int C = 4, NBUF = (VT == 1 || VT == 5) ? TKSPMV_SELL_BYTE_NBUF : 3, DEFER_S = MultiGeom<Q>::HOLD;
+    // (byte chunks: four in flight behind the one being reduced; one query per pass -- BASELINE configs[4] -- seven: 19.0 against 19.6 us
+    //  per query, while 4 queries per pass lose 1 % by it and ten or more chunks spill: 89 us)
+    constexpr int C = 4, NBUF = (VT == 1 || VT == 5) ? (Q == 1 ? 8 : TKSPMV_SELL_BYTE_NBUF) : 3, DEFER_S = MultiGeom<Q>::HOLD;
     constexpr bool BYTES = VT == 1 || VT == 5;  // VT 5: byte values with 12-bit column words (640-byte chunks, padding slots 1022 / 1023)
     constexpr uint32_t PAD_NEUTRAL = VT == 5 ? 1022u : SELL_PAD_NEUTRAL, PAD_ONE = VT == 5 ? 1023u : SELL_PAD_ONE;
     constexpr uint32_t MULTI_WAVE_CAP = MultiGeom<Q>::WAVE_CAP;
