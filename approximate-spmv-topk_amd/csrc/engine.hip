@@ -326,6 +326,7 @@ struct EngineImpl {
         MultiParams M{};
         M.A = set_addr(0);
         M.part_slice0 = d_sell_part_slice0;
+        M.n_sel = (uint32_t)multi_q;
         M.scratch0 = d_multi_scratch + (size_t)chain * MULTI_Q_MAX * ((uint64_t)grid * WG_SLOTS + ovf_cap);
         M.scratch_stride = (uint64_t)grid * WG_SLOTS + ovf_cap;
         M.prev = pending_group[chain];
@@ -1109,8 +1110,8 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
                       (uint64_t)m.grid * WG_SLOTS <= (uint64_t)SEL_PER_THREAD * (m.multi_stream_waves * 64u + 64u);
     }
     if (m.can_multi) {
-        // the first MULTI_Q_MAX workgroups of a multi-query launch are its selectors, the others stream
-        const uint32_t n_multi_waves = (m.grid - (uint32_t)MULTI_Q_MAX) * m.multi_stream_waves;
+        // the first multi_q workgroups of a multi-query launch are its selectors (one per query of a pass), the others stream
+        const uint32_t n_multi_waves = (m.grid - (uint32_t)m.multi_q) * m.multi_stream_waves;
         SellMatrix sm;
         std::string perr;
         const auto t_sell = std::chrono::steady_clock::now();

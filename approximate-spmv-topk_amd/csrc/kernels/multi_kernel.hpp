@@ -46,6 +46,7 @@ struct MultiParams {
     unsigned long long *scratch0;  // general-path scratch of selector q: scratch0 + q * scratch_stride
     uint64_t scratch_stride;
     const uint32_t *part_slice0;  // [n_parts] first slice of every partition
+    uint32_t n_sel;               // selector workgroups at the head of the grid = the engine's queries per pass (1, 2, 4 or 8)
 };
 template <int Q>
 struct MultiLds {
@@ -159,7 +160,7 @@ __global__ void __launch_bounds__(576, Q >= 8 ? 4 : 6) multi_kernel(const Stream
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (blockIdx.x < (uint32_t)MULTI_Q_MAX) {
+    if (blockIdx.x < M.n_sel) {
         // selector workgroups: workgroup q selects query q of the previous group (all of them at once: one after the other
         // in ONE workgroup they took longer than the pass they ride in)
         if (blockIdx.x < M.prev.n_q) {
@@ -169,7 +170,7 @@ __global__ void __launch_bounds__(576, Q >= 8 ? 4 : 6) multi_kernel(const Stream
         }
         return;
     }
-    const uint32_t bid = blockIdx.x - (uint32_t)MULTI_Q_MAX, n_wg = gridDim.x - (uint32_t)MULTI_Q_MAX;
+    const uint32_t bid = blockIdx.x - M.n_sel, n_wg = gridDim.x - M.n_sel;
     const uint32_t nwaves = (blockDim.x >> 6) - 1u;  // streaming waves
     const bool is_server = (wave == nwaves);
     const uint32_t nq = M.cur.n_q < (uint32_t)Q ? M.cur.n_q : (uint32_t)Q;
