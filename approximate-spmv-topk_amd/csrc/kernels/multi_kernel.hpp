@@ -303,22 +303,26 @@ __global__ void __launch_bounds__(576, Q >= 8 ? 4 : 6) multi_kernel(const Stream
                 if (i + (NBUF - 1) < np) pk_ahead += P0.packet_bytes;
                 load_packet<C, VT>(pk_ahead, lane, buf[(u + NBUF - 1) % NBUF]);
             }
-            uint32_t cwv[2];  // the chunk's column words as two dwords of two 16-bit words
-            if (VT == 5) {    // 12-bit words: 48 bits of the two dwords loaded, from bit 0 on even lanes and from bit 16 on odd ones
+            // Byte offsets of x[col] for the lane's four entries, and (f0, f1, f2, f3) the words that carry the flag bits in their low two
+            // bits. 16-bit words: two dwords of two. 12-bit words: 48 bits of the two dwords loaded, from bit 0 on even lanes and from
+            // bit 16 on odd ones -- taken apart straight into offsets (9 instructions; via an intermediate pair of 16-bit words: 15).
+            uint32_t off[C], fw[C];
+            if (VT == 5) {
                 const uint32_t odd16 = (threadIdx.x & 1u) << 4;
                 const uint32_t lo = __builtin_amdgcn_alignbit(cur.cw[1], cur.cw[0], odd16), hi = cur.cw[1] >> odd16;
                 const uint32_t mid = __builtin_amdgcn_alignbit(hi, lo, 24);
-                cwv[0] = (lo & 0xFFFu) | ((lo << 4) & 0x0FFF0000u);
-                cwv[1] = (mid & 0xFFFu) | ((hi << 12) & 0x0FFF0000u);
-            } else {
-                cwv[0] = cur.cw[0];
-                cwv[1] = cur.cw[1];
-            }
-            uint32_t off[C];
+                fw[0] = lo;
+                fw[1] = lo >> 12;
+                fw[2] = mid;
+                fw[3] = mid >> 12;
 #pragma unroll
-            for (int j = 0; j < C; ++j) {
-                const uint32_t word = cwv[j >> 1];
-                off[j] = (j & 1) ? ((word >> 16) & 0xFFFCu) : (word & 0xFFFCu);  // byte offset of x[col]
+                for (int j = 0; j < C; ++j) off[j] = fw[j] & 0xFFCu;
+            } else {
+#pragma unroll
+                for (int j = 0; j < C; ++j) {
+                    fw[j] = (j & 1) ? (cur.cw[j >> 1] >> 16) : cur.cw[j >> 1];
+                    off[j] = fw[j] & 0xFFFCu;
+                }
             }
             if (IL) {
                 // Two queries per VALU instruction: v_pk_mul_f32 / v_pk_add_f32 work on a pair of fp32 lanes each, every
@@ -356,10 +360,10 @@ __global__ void __launch_bounds__(576, Q >= 8 ? 4 : 6) multi_kernel(const Stream
                     }
                 }
             }
-            if (__builtin_amdgcn_readfirstlane(cwv[0]) & 1u) {  // last chunk of the slice: 64 rows are complete
+            if (__builtin_amdgcn_readfirstlane(fw[0]) & 1u) {  // last chunk of the slice: 64 rows are complete
                 // A row of more than 64 entries spans adjacent lanes (segment index in the flag bits of this chunk, wsell.hpp):
                 // its segment sums are added left to right and the score ends up on its last lane; rare.
-                const uint32_t depth = ((cwv[0] >> 16) & 3u) | ((cwv[1] & 3u) << 2) | (((cwv[1] >> 16) & 3u) << 4);
+                const uint32_t depth = (fw[1] & 3u) | ((fw[2] & 3u) << 2) | ((fw[3] & 3u) << 4);
                 if (__ballot(depth != 0u) != 0ull) {
                     for (uint32_t d = 1; d < 64u; ++d) {
                         if (__ballot(depth == d) == 0ull) break;
