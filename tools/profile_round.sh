@@ -35,6 +35,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/single" -- python3
 export TKSPMV_MULTI_CHAINS=1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/q17f" -- python3 "$REPO/tools/q17f_probe.py" --only > "$OUT/q17f.log" 2> "$OUT/q17f.err"
 unset TKSPMV_MULTI_CHAINS
+# 6b. the same in the mode bench.py reports it: two overlapping chains of launches (a launch's duration is then longer than the
+#     time per query: two are in flight; the log carries the us per query of that very run)
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/q17f2" -- python3 "$REPO/tools/q17f_probe.py" --only > "$OUT/q17f2.log" 2> "$OUT/q17f2.err"
 # 7. one shard of a strong-scaled run (1/8 of the 1M-row matrix) through bench.py's sharded code path: the batch kernel with its
 #    small-matrix settings (4 selector workgroups, workgroup-local thresholds, the repair launch behind every batch launch)
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/shard125k" -- python3 "$REPO/bench.py" --total-rows 125000 --config3-rows 0 --steps 2048 --warmup 256 > "$OUT/shard125k.json" 2> "$OUT/shard125k.err"

@@ -46,7 +46,8 @@ for q in (8, 4):  # the multi-query path alone: per-kernel summary + the JSON li
         if lines:
             open(os.path.join(dst, f"{tag}_multi{q}_under_rocprofv3.json"), "w").write(lines[-1] + "\n")
 
-for sub, name in (("single", f"{tag}_single_query_kernel_stats.csv"), ("q17f", f"{tag}_config4_q17f32_kernel_stats.csv")):
+for sub, name in (("single", f"{tag}_single_query_kernel_stats.csv"), ("q17f", f"{tag}_config4_q17f32_kernel_stats.csv"),
+                  ("q17f2", f"{tag}_config4_q17f32_two_chains_kernel_stats.csv")):
     src = find(f"{sub}/**/*kernel_stats.csv")
     if src:
         shutil.copy(src, os.path.join(dst, name))
