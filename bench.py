@@ -674,9 +674,12 @@ def sharded_leg(a, mod, torch, np, dev, local_rank, rank, world, total_rows, see
         exchange = {"kind": "torch.distributed all_gather_into_tensor of 2*K int32 per rank + on-device merge, every step "
                             "(TKSPMV_DIST=torch)"}
     kernel_ns = eng.time_queries(dxs.data_ptr(), a.queries, min(max(steps, 64), 512))  # this rank's local kernel alone
+    read_ns = sorted(eng.time_stream_read(64) for _ in range(3))[1]  # this shard's load-only floor on this rank's GPU
     per_rank = [{"rank": rank, "rows": r1 - r0, "first_row": r0, "nnz": int(info["nnz"]), "kernel_us": kernel_ns / 1e3,
                  "algorithmic_bytes": int(info["algorithmic_bytes"]),
-                 "frac": info["algorithmic_bytes"] / kernel_ns / HBM_PEAK_GBS}]
+                 "frac": info["algorithmic_bytes"] / kernel_ns / HBM_PEAK_GBS,
+                 "read_only_us": read_ns / 1e3, "batch_mode": {"selector_workgroups": info.get("batch_mode", 0) & 0xFF,
+                                                              "local_thresholds": (info.get("batch_mode", 0) >> 8) & 0xFF}}]
     if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
