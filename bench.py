@@ -435,16 +435,15 @@ def bench_single(a, mod, torch, np, dev, local_rank):
     # ---- warm-up, then EXACTLY `steps` queries between two device synchronisations (+ a hipEvent pair on the engine stream)
     if a.warmup > 0:  # (through the very call the timed region uses: its host path -- ctypes, events -- is warm as well)
         eng.time_queries(dxs.data_ptr(), a.queries, a.warmup)
-    eng.synchronize()
+    # (torch.cuda.synchronize() waits for the whole device, the engine's own stream included: one synchronisation per side)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     kernel_ns = eng.time_queries(dxs.data_ptr(), a.queries, a.steps)  # enqueue + event pair + wait for the end event
     t1 = time.perf_counter()
-    eng.synchronize()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     host_side = {"timed_call_us": 1e6 * (t1 - t0), "device_us_by_events": kernel_ns * a.steps / 1e3,
-                 "synchronisations_after_us": 1e6 * (elapsed - (t1 - t0)),
+                 "synchronisation_after_us": 1e6 * (elapsed - (t1 - t0)),
                  "note": "value uses the host clock over call + synchronisations; roofline the event pair inside the call"}
     # ---- parity of the last timed query against the oracle
     val, idx = eng.read_result()
