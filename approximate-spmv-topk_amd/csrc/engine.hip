@@ -37,6 +37,7 @@
 #include "kernels/select.hpp"
 #include "kernels/packet_math.hpp"
 #include "kernels/stream_kernel.hpp"
+#include "kernels/local.hpp"
 #include "kernels/batch_kernel.hpp"
 #include "kernels/claim_kernel.hpp"
 #include "kernels/multi_kernel.hpp"
@@ -203,6 +204,15 @@ struct EngineImpl {
     uint32_t *d_coo_col = nullptr;  // the COO's columns and values, kept in HBM between the two device packers (create only)
     float *d_coo_val = nullptr;
     uint32_t pack_us = 0;           // time of the packing step of tkspmv_create (upload of the COO included when on the device)
+    // single_kernel (kernels/local.hpp): the launch of tkspmv_run on engines that stream with workgroup-local thresholds
+    bool can_single = false;
+    unsigned long long *d_lslots = nullptr;  // [grid][WG_SLOTS] the workgroups' records
+    uint32_t *d_lused = nullptr;             // [grid]
+    float *d_lprior = nullptr;               // [grid] carried thresholds | 32 words: the suspension counters (LocalParams::prior_block)
+    uint32_t *d_lstatus = nullptr;           // [0] 1: the last single launch failed its check
+    mutable uint64_t single_launches = 0, single_repairs = 0;
+    uint32_t single_tune = 0;
+    uint32_t uni_ppp = 0, uni_last = 0;  // uniform partition table (StreamParams::uni_ppp): partition q = packets [q * uni_ppp, ...)
 
     StreamParams stream_params(const float *x, int set = 0) const {
         StreamParams P{};
@@ -213,6 +223,8 @@ struct EngineImpl {
         P.part_count = d_part_count;
         P.x = x;
         P.n_parts = (uint32_t)info.n_wave_partitions;
+        P.uni_ppp = uni_ppp;
+        P.uni_last = uni_last;
         P.cols = desc.cols;
         P.packet_bytes = pm.packet_bytes;
         P.n_sets = n_sets;
@@ -321,6 +333,7 @@ struct EngineImpl {
         P.part_first = d_sell_part_first;
         P.part_count = d_sell_part_count;
         P.n_parts = sell_parts;
+        P.uni_ppp = 0u;  // (the row-per-lane stream has its own partition tables)
         P.packet_bytes = sell_packet_bytes;
         P.pkt_row = nullptr;
         MultiParams M{};
@@ -558,6 +571,31 @@ struct EngineImpl {
         ++launch_counter;
         hipLaunchKernelGGL(kernel_for(false), dim3(grid), dim3(block + 64), 0, s, P, S);
     }
+    // One query through single_kernel (local thresholds, checked): the result is exact iff the status word / host flag says the
+    // check passed; otherwise the caller runs launch_stream, whose result is exact on its own.
+    void launch_single(const float *x, uint32_t *out_idx, float *out_val, hipStream_t s, bool to_host) const {
+        StreamParams P = stream_params(x);
+        SelectParams S = select_params(out_idx, out_val);
+        if (to_host) {
+            S.host_out = h_res_dev;
+            S.host_epoch = ++host_epoch;
+            S.t_start = d_tstart;
+        }
+        LocalParams G{};
+        G.slots = d_lslots;
+        G.used = d_lused;
+        G.wg_prior = carry_local ? d_lprior : nullptr;
+        G.prior_block = reinterpret_cast<uint32_t *>(d_lprior + grid);
+        G.status = d_lstatus;
+        G.mode = use_local;
+        G.beta = local_beta;
+        G.trace = d_trace ? d_trace + (launch_counter % 4) * trace_words : nullptr;
+        G.tune = single_tune;
+        ++launch_counter;
+        ++single_launches;
+        if (pm.precision == Precision::F32C12) hipLaunchKernelGGL((single_kernel<7>), dim3(grid), dim3(512), 0, s, P, S, G);
+        else hipLaunchKernelGGL((single_kernel<0>), dim3(grid), dim3(512), 0, s, P, S, G);
+    }
     void launch_query_radix(const float *x, uint32_t *out_idx, float *out_val, hipStream_t s) const {
         launch_scores(x, s, d_rscores);
         RadixParams R{};
@@ -652,6 +690,15 @@ struct EngineImpl {
         resident_running = false;
         return e;
     }
+    // Does the host-visible result block add up to the checksum its writer left behind the flag (result_checksum_term)? The block
+    // is written with relaxed system-scope stores; the flag alone proves nothing by the memory model.
+    bool result_block_complete(uint32_t epoch) const {
+        const size_t k = (size_t)desc.k;
+        const volatile uint32_t *r = h_res;
+        uint32_t sum = epoch * 0x9E3779B1u;
+        for (size_t i = 0; i < k; ++i) sum += result_checksum_term(r[i], r[k + i], (uint32_t)i);
+        return r[2 * k + 4] == sum;
+    }
     uint32_t resident_idle_ticks = 10000000u;  // 100 ms without a query: the kernel leaves (relaunched on demand)
     // x of the last tkspmv_set_query into device memory, if a resident engine left it in pinned memory only
     hipError_t ensure_x() {
@@ -724,7 +771,8 @@ Engine::~Engine() {
     if (m.stream) (void)hipStreamSynchronize(m.stream);
     void *bufs[] = {m.d_packets, m.d_pkt_row, m.d_part_first, m.d_part_count, m.d_x,
                     m.d_out_idx, m.d_out_val, m.d_scores,     m.d_stats,      m.d_done, m.d_trace, m.d_tickets,
-                    m.d_claim,   m.d_claim_done, m.d_tstart, m.d_prior, m.d_wg_prior};
+                    m.d_claim,   m.d_claim_done, m.d_tstart, m.d_prior, m.d_wg_prior,
+                    m.d_lslots,  m.d_lused, m.d_lprior, m.d_lstatus};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     {
@@ -952,6 +1000,17 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
         m.pack_us = (uint32_t)std::min<long long>(std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_pack).count(), 0xFFFFFFFFll);
     }
     fill_info(m.pm, d.k, &m.info);
+    {
+        // The packer's usual outcome is a uniform table -- every partition but the last holds packets_per_partition packets, back
+        // to back --: the kernels then derive a wave's range from its partition number (no table loads at the head of a launch).
+        const size_t np = m.pm.part_first.size();
+        const uint32_t ppp = m.pm.packets_per_partition;
+        bool uniform = np > 0 && ppp > 0 && (uint64_t)np * ppp <= 0xFFFFFFFFull && m.pm.part_count[np - 1] >= 1u && m.pm.part_count[np - 1] <= ppp;
+        for (size_t p = 0; uniform && p < np; ++p)
+            uniform = m.pm.part_first[p] == (uint32_t)(p * ppp) && (p + 1 == np || m.pm.part_count[p] == ppp);
+        m.uni_ppp = uniform ? ppp : 0u;
+        m.uni_last = uniform ? m.pm.part_count[np - 1] : 0u;
+    }
 
     // Threshold-exchange geometry: at least k publishing groups are needed (tau = k-th largest published maximum);
     // if one group per workgroup is not enough, the waves of a workgroup are split into up to 8 groups.
@@ -1232,6 +1291,23 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
     if (m.use_local) m.pace_quads = m.pm.n_packets <= 45000u ? 0u : (m.pm.n_packets <= 65000u ? 2u : 2u * std::max(1u, (m.pm.packet_bytes + 352u) / 704u));
     if (const char *f = getenv("TKSPMV_PACE_LEVELS")) m.pace_levels = (uint32_t)std::max(1, std::min(8, atoi(f)));
     if (const char *f = getenv("TKSPMV_PACE")) m.pace_quads = (uint32_t)std::max(0, std::min(32, atoi(f)));
+    // single_kernel serves tkspmv_run where the engine streams with local thresholds: fp32 values, 4 entries per lane, x of at most
+    // 1024 columns, at most 512 workgroups (select_local's first cut), one partition per wave of ITS launch (8 waves x grid).
+    m.can_single = m.use_local != 0u && d.precision == TKSPMV_F32 && C == 4u && m.xcols <= 1024u && m.grid <= 512u && m.block == 512u &&
+                   d.impl == TKSPMV_IMPL_STREAM && !m.use_radix && m.fused && m.host_path && m.h_res != nullptr &&
+                   m.pm.part_first.size() <= (size_t)m.grid * 8u;
+    if (const char *f = getenv("TKSPMV_SINGLE")) m.can_single = m.can_single && atoi(f) != 0;
+    if (const char *f = getenv("TKSPMV_SINGLE_TUNE")) m.single_tune = (uint32_t)atoi(f);
+    if (m.can_single) {
+        HIP_TRY(hipMalloc((void **)&m.d_lslots, (size_t)m.grid * WG_SLOTS * 8));
+        HIP_TRY(hipMemset(m.d_lslots, 0xFF, (size_t)m.grid * WG_SLOTS * 8));
+        HIP_TRY(hipMalloc((void **)&m.d_lused, (size_t)m.grid * 4));
+        HIP_TRY(hipMemset(m.d_lused, 0, (size_t)m.grid * 4));
+        HIP_TRY(malloc_exchange((void **)&m.d_lprior, ((size_t)m.grid + 32) * 4));
+        HIP_TRY(hipMemset(m.d_lprior, 0, ((size_t)m.grid + 32) * 4));
+        HIP_TRY(malloc_exchange((void **)&m.d_lstatus, 128));
+        HIP_TRY(hipMemset(m.d_lstatus, 0, 128));
+    }
     {
         // Exchange-state sets: one block per field, set s at s strides (the batch kernel addresses them that way).
         if (m.can_batch && !m.can_multi && !m.resident_capable) {
@@ -1612,7 +1688,7 @@ int Engine::run(double *kernel_ns, std::string &err) {
         const auto t0 = std::chrono::steady_clock::now();
         bool seen = false;
         for (uint64_t spins = 0;; ++spins) {
-            if (*flag == epoch) {
+            if (*flag == epoch && m.result_block_complete(epoch)) {
                 seen = true;
                 break;
             }
@@ -1656,33 +1732,45 @@ int Engine::run(double *kernel_ns, std::string &err) {
     const bool events = kernel_ns && (m.run_events || !to_host);
     const auto t_host0 = std::chrono::steady_clock::now();
     if (events) HIP_TRY(hipEventRecord(m.ev0, m.stream));
+    // The result flag of the launch with the current epoch, polled (never longer than 2 s), and the block behind it verified.
+    auto wait_flag = [&]() -> bool {
+        volatile uint32_t *flag = m.h_res + 2 * (size_t)m.desc.k;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (uint64_t spins = 0;; ++spins) {
+            if (*flag == m.host_epoch && m.result_block_complete(m.host_epoch)) return true;
+            __builtin_ia32_pause();
+            if ((spins & 0xFFFFu) == 0xFFFFu && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) return false;
+        }
+    };
+    bool seen = false;
+    double own_ticks = 0.0;  // the launches' own durations (100 MHz ticks: first workgroup's entry -> result flag)
     if (to_host) {
         m.drain(m.stream);
-        m.launch_stream(m.d_x_cur, m.d_out_idx, m.d_out_val, m.stream, true);
+        if (m.can_single) {
+            // workgroup-local thresholds, checked by the selection (kernels/local.hpp); a failed check -- a query unlike the ones
+            // before it -- sends the query through the exact launch below
+            m.launch_single(m.d_x_cur, m.d_out_idx, m.d_out_val, m.stream, true);
+            HIP_TRY(hipGetLastError());
+            seen = wait_flag();
+            if (seen) own_ticks += (double)m.h_res[2 * (size_t)m.desc.k + 1];
+        }
+        if (!m.can_single || !seen || m.h_res[2 * (size_t)m.desc.k + 2] != 0u) {
+            if (m.can_single) ++m.single_repairs;
+            m.launch_stream(m.d_x_cur, m.d_out_idx, m.d_out_val, m.stream, true);
+            HIP_TRY(hipGetLastError());
+            seen = wait_flag();
+            if (seen) own_ticks += (double)m.h_res[2 * (size_t)m.desc.k + 1];
+        }
     } else {
         m.launch_query(m.d_x_cur, m.d_out_idx, m.d_out_val, m.stream);
     }
     HIP_TRY(hipGetLastError());
     if (events) HIP_TRY(hipEventRecord(m.ev1, m.stream));
-    bool seen = false;
-    if (to_host) {
-        volatile uint32_t *flag = m.h_res + 2 * (size_t)m.desc.k;
-        const auto t0 = std::chrono::steady_clock::now();
-        for (uint64_t spins = 0;; ++spins) {
-            if (*flag == m.host_epoch) {
-                seen = true;
-                break;
-            }
-            __builtin_ia32_pause();
-            if ((spins & 0xFFFFu) == 0xFFFFu && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) break;  // never hang on the flag
-        }
-        std::atomic_thread_fence(std::memory_order_acquire);
-    }
     if (!seen) HIP_TRY(hipStreamSynchronize(m.stream));
     m.x_pending = false;  // the kernel has read x: the staging copy is free again
     if (kernel_ns && !events) {
-        // the kernel's own duration (100 MHz ticks: first workgroup's entry -> result flag), or the host clock if the flag never came
-        if (seen) *kernel_ns = (double)m.h_res[2 * (size_t)m.desc.k + 1] * 10.0;
+        // the kernels' own durations, or the host clock if the flag never came
+        if (seen) *kernel_ns = own_ticks * 10.0;
         else *kernel_ns = (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_host0).count();
     }
     if (events) {
@@ -1751,6 +1839,14 @@ int Engine::debug_counters(unsigned long long *out, int n, std::string &err) {
     out[3] = m.batch_launches;
     out[4] = w[4];  // launches the gate of the local thresholds stays closed for
     out[5] = w[5];  // length of its latest closure
+    if (n >= 10) {  // tkspmv_run through single_kernel: launches, queries sent on through the exact launch, failed checks, suspension
+        uint32_t s[4] = {0, 0, 0, 0};
+        if (m.d_lprior) HIP_TRY(hipMemcpy(s, m.d_lprior + m.grid, sizeof(s), hipMemcpyDeviceToHost));
+        out[6] = m.single_launches;
+        out[7] = m.single_repairs;
+        out[8] = s[3];
+        out[9] = s[0];
+    }
     return TKSPMV_OK;
 }
 

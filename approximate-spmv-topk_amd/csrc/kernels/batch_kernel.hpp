@@ -2,6 +2,7 @@
 // Part of engine.hip (one translation unit: included there in this order; device code only).
 #pragma once
 #include "stream_kernel.hpp"
+#include "local.hpp"
 
 namespace tkspmv {
 
@@ -23,7 +24,6 @@ namespace tkspmv {
 // workgroup that never block on anything but memory.
 // ------------------------------------------------------------------------------------------------------------
 constexpr int BATCH_MAX = 32;
-constexpr uint32_t STG_N = 8;  // survivors a wave can stage per query (64 lanes = 8 waves x 8 when the server copies)
 #ifndef TKSPMV_ALL_SERVERS_PRIO
 #define TKSPMV_ALL_SERVERS_PRIO 0
 #endif
@@ -36,7 +36,6 @@ constexpr unsigned long long BATCH_TAU_WAIT = TKSPMV_TAU_WAIT;  // x 10 ns (s_me
 constexpr unsigned long long LOCAL_TAU_WAIT = 300;
 constexpr int MISC_DBG_WAITS = 26, MISC_DBG_WAIT_TICKS = 27, MISC_DBG_REDO_PK = 28, MISC_DBG_REDO_WV = 29;  // TKSPMV_STATS=1 only
 constexpr int MISC_XREADY = 2, MISC_MINU = 3;  // batch kernel only: x staged for query (value - 1); min score in units
-constexpr int MISC_TAUKEY = 4;  // local thresholds: order key of the largest threshold formed in this workgroup (what goes on record)
 
 // Per query only what differs from query to query travels in the kernel arguments (32 bytes); the exchange-state set of
 // query q is set 0 plus q strides (the sets are allocated as one block per field), so the argument block stays small (64 queries would fit the 4 KiB limit; 32 are used: longer batches measured no faster).
@@ -359,7 +358,7 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
     bool wave_has = false;  // (lane w: wave w streams a partition -- the server counts them, local thresholds need to know who takes part)
     if (is_server || local) {
         const uint32_t pw = lane * n_wg + bid;
-        wave_has = lane < nwaves && pw < P0.n_parts && P0.part_count[pw] != 0u;
+        wave_has = lane < nwaves && pw < P0.n_parts && (P0.uni_ppp != 0u || P0.part_count[pw] != 0u);
         n_active = (uint32_t)__popcll(__ballot(wave_has));
     }
 
@@ -682,10 +681,7 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
     __builtin_amdgcn_s_setprio(TKSPMV_STREAM_PRIO);
     const uint32_t part = wave * n_wg + bid;
     uint32_t p0 = 0, np = 0;
-    if (part < P0.n_parts) {
-        p0 = P0.part_first[part];
-        np = P0.part_count[part];
-    }
+    if (part < P0.n_parts) TKSPMV_PARTITION_RANGE(P0, part, p0, np);
     uint2 *wcand = L.u.w.cand + wave * WAVE_CAP;
     if (np == 0u) return;  // no partition (n_active does not count this wave)
     static_assert(C == 4 || C == 8, "the batch kernel is built for 4 or 8 entries per lane");

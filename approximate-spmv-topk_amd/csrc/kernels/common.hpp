@@ -25,6 +25,10 @@ struct StreamParams {
     const uint32_t *part_count;
     const float *x;
     uint32_t n_parts, cols, packet_bytes;
+    // Uniform partition table (the packer's usual outcome: every partition but the last holds uni_ppp packets, back to back):
+    // a wave derives its range from its partition number instead of two dependent loads at the head of the launch (a cold
+    // round trip through memory before the first packet can be requested). 0: read part_first / part_count.
+    uint32_t uni_ppp, uni_last;
     uint32_t n_sets;        // 0 => threshold exchange disabled (fewer publishing groups than k), else 1
     uint32_t k;
     uint32_t n_groups_pub;  // groups [0, n_groups_pub) publish maxima (<= 1024)
@@ -54,8 +58,22 @@ struct StreamParams {
     unsigned long long *dbg;  // optional counters (TKSPMV_STATS=1): [0] slow-path executions, [1] appended rows
 };
 
-constexpr int MISC_CAND_CNT = 0, MISC_TAU = 1, MISC_DONE = 5, MISC_XMAX = 6, MISC_SLOW_CNT = 7,
-              MISC_GRPMAX = 8 /* [8] */, MISC_PUBLISHED = 16 /* [8] */, MISC_WORDS = 32;  // <= 8 groups per workgroup
+// First packet and packet count of wave partition q (q < n_parts). (Scalars, not the parameter block by reference: a block whose
+// address is taken ends up in scratch memory.)
+__device__ __forceinline__ void partition_range(const uint32_t uni_ppp, const uint32_t uni_last, const uint32_t n_parts, const uint32_t *part_first,
+                                                const uint32_t *part_count, uint32_t q, uint32_t &p0, uint32_t &np) {
+    if (uni_ppp != 0u) {
+        p0 = q * uni_ppp;
+        np = q + 1u < n_parts ? uni_ppp : uni_last;
+    } else {
+        p0 = part_first[q];
+        np = part_count[q];
+    }
+}
+#define TKSPMV_PARTITION_RANGE(P, q, p0, np) partition_range((P).uni_ppp, (P).uni_last, (P).n_parts, (P).part_first, (P).part_count, q, p0, np)
+
+constexpr int MISC_CAND_CNT = 0, MISC_TAU = 1, MISC_TAUKEY = 4 /* local thresholds: order key of the largest threshold formed in this workgroup */, MISC_DONE = 5, MISC_XMAX = 6, MISC_SLOW_CNT = 7,
+              MISC_GRPMAX = 8 /* [8] */, MISC_PUBLISHED = 16 /* [8] */, MISC_BOUND = 24 /* local thresholds: what was dropped lies below */, MISC_WORDS = 32;  // <= 8 groups per workgroup
 // Private candidate list of a streaming wave (entries in LDS): 256 while x is small, 128 when x itself takes 64 KiB
 // (two workgroups must still fit the CU's 160 KiB).
 template <int XCOLS>

@@ -69,8 +69,15 @@ constexpr uint32_t SEL_PER_THREAD = 8;  // slot entries held in registers per th
 
 struct SelectShared {
     unsigned long long keys[SEL_CAP + 8];
-    uint32_t cnt, total, thr, last;
+    uint32_t cnt, total, thr, last, sum;
 };
+
+// Checksum of a result block as the host recomputes it before it trusts the block (tkspmv_run): the payload stores and the flag
+// are relaxed system-scope stores, ordered in practice by a drain (s_waitcnt) but not by the memory model -- so the word behind
+// the flag carries what the payload must add up to (plus the epoch), and the host reads until it does.
+__host__ __device__ inline uint32_t result_checksum_term(uint32_t idx, uint32_t val_bits, uint32_t r) {
+    return (idx ^ ((val_bits << 13) | (val_bits >> 19))) * (2u * r + 1u);
+}
 
 __device__ __forceinline__ unsigned long long pack_cand(uint32_t score_bits, uint32_t row) {
     return (unsigned long long)score_bits | ((unsigned long long)row << 32);
@@ -185,6 +192,7 @@ __device__ __forceinline__ void select_body(const SelectParams &P, const uint32_
     if (tid == 0) {
         S.cnt = 0;
         S.total = 0;
+        S.sum = 0;
     }
     __syncthreads();
     uint32_t spos[SEL_PER_THREAD];
@@ -333,6 +341,7 @@ __device__ __forceinline__ void select_body(const SelectParams &P, const uint32_
     while (G < 8u && n_sel * (G * 2u) <= nthreads) G *= 2u;
     const uint32_t n_pad = (n_sel + 7u) & ~7u;
     const uint32_t n_blocks = n_pad >> 3;  // blocks of 8 keys
+    uint32_t cs = 0u;  // (host-visible results: this thread's share of the block's checksum)
     for (uint32_t base = 0; base < n_sel; base += nthreads / G) {
         const uint32_t i = base + tid / G, part = tid & (G - 1u);
         const bool active = i < n_sel;
@@ -359,8 +368,14 @@ __device__ __forceinline__ void select_body(const SelectParams &P, const uint32_
             if (P.host_out) {  // system-scope stores: written through to host memory
                 __hip_atomic_store(&P.host_out[r], oi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 __hip_atomic_store(&P.host_out[P.k + r], __float_as_uint(ov), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                cs += result_checksum_term(oi, __float_as_uint(ov), r);
             }
         }
+    }
+    if (P.host_out) {  // (wave-uniform)
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) cs += (uint32_t)__shfl_xor((int)cs, d);
+        if (lane == 0 && cs) atomicAdd(&S.sum, cs);
     }
     if (stamps && tid == 0) stamps[6] = __builtin_amdgcn_s_memtime();  // ranked
     for (uint32_t r = n_sel + tid; r < P.k; r += nthreads) {
@@ -373,10 +388,12 @@ __device__ __forceinline__ void select_body(const SelectParams &P, const uint32_
     }
     auto raise_host_flag = [&]() __attribute__((always_inline)) {
         // every writer drains its stores, the workgroup meets, one thread raises the flag (relaxed: the stores before it are
-        // write-through stores already drained by their writers; a release would write back the whole L2 first)
+        // write-through stores already drained by their writers; a release would write back the whole L2 first). The memory
+        // model does not order them, so the flag comes with a checksum of the payload that the host verifies (result_checksum_term).
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) {
+            __hip_atomic_store(&P.host_out[2u * P.k + 4u], S.sum + P.host_epoch * 0x9E3779B1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             if (P.wt_reset)
                 __hip_atomic_store(&P.host_out[2u * P.k + 1u], (uint32_t)(__builtin_amdgcn_s_memrealtime() - P.t_seen), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             else if (P.t_start)

@@ -109,10 +109,7 @@ __global__ void __launch_bounds__(576, ((C == 8 && !SCORES) || QM == 7) ? 6 : 5)
     Pkt<C, VT> buf[NBUF];
     uint32_t rbs[NBUF];
     uint32_t p0 = 0, np = 0;
-    if (q < P.n_parts) {
-        p0 = P.part_first[q];
-        np = P.part_count[q];
-    }
+    if (q < P.n_parts) TKSPMV_PARTITION_RANGE(P, q, p0, np);
     auto prologue = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < NBUF - 1; ++u) {  // NBUF-1 packets in flight
@@ -245,8 +242,7 @@ __global__ void __launch_bounds__(576, ((C == 8 && !SCORES) || QM == 7) ? 6 : 5)
     //  ~110 candidates per query at 1M rows), the overflow list and the selection grow: 32-35 us per launch against 30.9.)
     for (bool first_part = true; q < P.n_parts; q += total_waves, first_part = false) {
         if (!first_part) {  // more partitions than waves (not the case for engines built by tkspmv_create)
-            p0 = P.part_first[q];
-            np = P.part_count[q];
+            TKSPMV_PARTITION_RANGE(P, q, p0, np);
             prologue();
         }
         const uint8_t *pk = P.packets + (size_t)p0 * P.packet_bytes;

@@ -145,10 +145,14 @@ class SpMV:
     def debug_counters(self):
         """Checked thresholds of back-to-back queries (info()["batch_mode"]): how many selections failed their check so far (and
         sent their query through the repair launch), the suspension state of carried thresholds, batch launches so far."""
-        out = (C.c_uint64 * 6)()
-        _lib.check(_lib.lib().tkspmv_debug_counters(self._h, out, 6))
+        out = (C.c_uint64 * 10)()
+        _lib.check(_lib.lib().tkspmv_debug_counters(self._h, out, 10))
         return {"checks_failed": int(out[0]), "suspension_length": int(out[1]), "suspended_for": int(out[2]), "batch_launches": int(out[3]),
-                "local_off_for_launches": int(out[4]), "local_off_length": int(out[5])}
+                "local_off_for_launches": int(out[4]), "local_off_length": int(out[5]),
+                # tkspmv_run through the single-query kernel (local thresholds, checked): launches, queries repeated through the
+                # exact launch because their check failed, and the suspension of carried thresholds that follows a failure
+                "single_launches": int(out[6]), "single_repairs": int(out[7]), "single_checks_failed": int(out[8]),
+                "single_suspended_for": int(out[9])}
 
     def synchronize(self):
         _lib.check(_lib.lib().tkspmv_synchronize(self._h))

@@ -227,7 +227,9 @@ int tkspmv_debug_trace(tkspmv_t *e, uint64_t *host, uint64_t max_words, uint64_t
  * carried thresholds (selections), out[2] = selections to go until they are used again, out[3] = batch launches so far, out[4] =
  * launches for which the workgroup-local thresholds as a whole stay switched off (a launch of which a quarter failed closes them
  * for 8 .. 1024 launches: data that keeps its best rows together), out[5] = the length of the latest such closure. n >= 6.
- * Synchronises the engine's stream. */
+ * With n >= 10 also tkspmv_run's single-query kernel (workgroup-local thresholds, checked by its selection): out[6] = its
+ * launches, out[7] = queries run again through the exact launch because the check failed, out[8] = failed checks as the device
+ * counted them, out[9] = selections to go until carried thresholds are used again. Synchronises the engine's stream. */
 int tkspmv_debug_counters(tkspmv_t *e, uint64_t *out, int32_t n);
 
 /* `iters` queries back to back on the engine stream (cycling over n_x device-resident vectors), ONE hipEvent pair

@@ -1,0 +1,133 @@
+"""tkspmv_set_query -> tkspmv_run -> tkspmv_read (the literal loop of the reference's hosts, host_spmv_bscsr.cpp:602-632) through
+the single-query kernel of round 4 (kernels/local.hpp: workgroup-local thresholds carried from query to query, checked by the
+selection; a failed check sends the query through the exact launch), and the batch kernel at the headline's own size under a query
+stream that BREAKS carried thresholds. Every list is compared with the CPU gold (gold_algorithms.hpp:188-246 restated and pinned)
+and bit for bit with the order-matched oracle on the engine's own packing.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4  # north_star tolerance for fp32 scores
+TIE = 2e-6
+
+
+def _exact(pkg, oracle, m, eng, x, k, idx, val, raw, C, min_score=0.0, gold=True):
+    yp, present = oracle.packed_scores(raw, x, m.rows, C)
+    ei, ev = oracle.select_topk(yp, present, k, min_score)
+    assert np.array_equal(idx, ei), "index list differs from the order-matched oracle"
+    assert np.array_equal(val.view(np.uint32), ev.view(np.uint32)), "scores are not bit-identical"
+    if gold and np.count_nonzero(val > 0) == k:  # (the gold's list is full of positive scores: the contract of the result)
+        gi, gv = oracle.gold_topk(m.row, m.col, m.val, x, k)
+        if set(idx.tolist()) != set(gi.tolist()):
+            y64, _ = oracle.scores_f64(m.row, m.col, m.val, x, m.rows)
+            kth = np.sort(y64)[-k]
+            for r in set(idx.tolist()) ^ set(gi.tolist()):
+                assert abs(y64[r] - kth) <= TIE * abs(kth), f"row {r} differs from the gold and is not a k-th boundary near-tie"
+        assert np.allclose(np.sort(val)[::-1], np.sort(gv)[::-1], rtol=RTOL, atol=0)
+
+
+def _packed_raw(pkg, m, eng, k):
+    info = eng.info()
+    C = info["packet_entries"] // 64
+    packed = pkg.Packed(m, k=k, nnz_per_lane=C, n_wave_partitions=(info["batch_mode"] >> 16) or info["n_wave_partitions"])
+    assert packed.info()["n_wave_partitions"] == info["n_wave_partitions"]
+    return packed, packed.raw(), C
+
+
+@pytest.mark.parametrize("rows", [1000000, 250000, 125000, 60000])
+def test_reference_loop_through_the_single_query_kernel(pkg, oracle, rows):
+    k = 100
+    m = pkg.generate_matrix(rows, 1024, 20, "gamma", 2)
+    eng = pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, k=k, device=0, stream_replicas=4 if rows >= 500000 else 0)
+    assert (eng.info()["batch_mode"] >> 8) & 0xFF, "this size is expected to stream with workgroup-local thresholds"
+    packed, raw, C = _packed_raw(pkg, m, eng, k)
+    n = 24 if rows >= 500000 else 40
+    for i in range(n):
+        x = pkg.create_sample_vector(1024, True, False, True, 1000 + i)
+        eng.reset(x)
+        ns = eng()
+        val, idx = eng.read_result()
+        assert ns > 0
+        _exact(pkg, oracle, m, eng, x, k, idx, val, raw, C)
+    c = eng.debug_counters()
+    assert c["single_launches"] == n, c
+    # a stationary stream: carried thresholds hold (one failure would already be unusual), and a failed check costs a second launch
+    assert c["single_repairs"] <= 1 and c["single_repairs"] == c["single_checks_failed"], c
+    print(f"\n[{rows} rows] {n} queries through tkspmv_run: {c}")
+    eng.close()
+
+
+def test_single_query_kernel_survives_queries_that_break_its_thresholds(pkg, oracle):
+    """Scales 1 / 0.01 / 3, x = 0, -x and a min_score in the way: carried thresholds are invalidated again and again; every list
+    must still be exact, failed checks must have happened, and each of them must have gone through the exact launch."""
+    k, rows = 100, 300000
+    m = pkg.generate_matrix(rows, 1024, 20, "gamma", 7)
+    eng = pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, k=k, device=0)
+    assert (eng.info()["batch_mode"] >> 8) & 0xFF
+    packed, raw, C = _packed_raw(pkg, m, eng, k)
+    scales = [1, 1, 1, 0.01, 0.01, 3, 3, 1, 0, 1, -1, 1, 1, 0.01, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1]
+    for i, sc in enumerate(scales):
+        x = (pkg.create_sample_vector(1024, True, False, True, 500 + i) * np.float32(sc)).astype(np.float32)
+        eng.reset(x)
+        eng()
+        val, idx = eng.read_result()
+        _exact(pkg, oracle, m, eng, x, k, idx, val, raw, C, gold=sc > 0)
+    c = eng.debug_counters()
+    assert c["single_checks_failed"] > 0 and c["single_repairs"] == c["single_checks_failed"], c
+    print(f"\n[thresholds broken on purpose] {len(scales)} queries: {c}")
+    eng.close()
+
+
+def test_single_query_kernel_where_nearly_every_check_fails(pkg, oracle, monkeypatch):
+    """20 000 rows with local thresholds FORCED (the host would not choose them here: a workgroup holds several of the k best
+    rows): nearly every check fails and the exact launch answers. Also k = 8 and a min_score that empties most of the list."""
+    monkeypatch.setenv("TKSPMV_LOCAL", "1")
+    for k, min_score in ((100, 0.0), (8, 0.0), (100, 0.45)):
+        m = pkg.generate_matrix(20000, 512, 12, "uniform", 11)
+        eng = pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, k=k, device=0, min_score=min_score)
+        packed, raw, C = _packed_raw(pkg, m, eng, k)
+        for i in range(12):
+            x = pkg.create_sample_vector(512, True, False, True, 40 + i)
+            eng.reset(x)
+            eng()
+            val, idx = eng.read_result()
+            _exact(pkg, oracle, m, eng, x, k, idx, val, raw, C, min_score, gold=min_score == 0.0)
+        c = eng.debug_counters()
+        assert c["single_launches"] == 12 and c["single_repairs"] == c["single_checks_failed"], c
+        print(f"\n[20000 rows, local thresholds forced, k={k}, min_score={min_score}] {c}")
+        eng.close()
+
+
+def test_headline_size_default_engine_under_a_stream_that_breaks_carried_thresholds(pkg, oracle):
+    """BASELINE configs[1] at full size, the engine and the mode bench.py reports (stream_replicas = 4, workgroup-local thresholds
+    carried from query to query, paced by rank), 96 queries through tkspmv_enqueue_batch whose scales jump between 1, 0.01 and 3, with
+    an x = 0 and a -x inside: every list against the gold and bit for bit against the order-matched oracle; checks must have failed
+    (the repairs are what is being tested) and the results must still be exact."""
+    import torch
+    n_q, k = 96, 100
+    m = pkg.generate_matrix(1000000, 1024, 20, "gamma", 2)
+    xs = np.stack([pkg.create_sample_vector(1024, True, False, True, 1000 + i) for i in range(n_q)])
+    rng = np.random.default_rng(4)
+    scale = rng.choice([1.0, 0.01, 3.0], size=n_q).astype(np.float32)
+    scale[:8] = 1.0  # (thresholds get carried first, then broken)
+    xs = (xs * scale[:, None]).astype(np.float32)
+    xs[40] = 0.0
+    xs[70] *= np.float32(-1.0)
+    dxs = torch.from_numpy(np.ascontiguousarray(xs)).cuda()
+    out_i = torch.zeros(n_q, k, dtype=torch.int32, device="cuda")
+    out_v = torch.zeros(n_q, k, dtype=torch.float32, device="cuda")
+    eng = pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, k=k, device=0, stream_replicas=4)
+    assert (eng.info()["batch_mode"] >> 8) & 0xFF, "the headline engine is expected to run with workgroup-local thresholds"
+    packed, raw, C = _packed_raw(pkg, m, eng, k)
+    torch.cuda.synchronize()
+    eng.enqueue_batch(dxs.data_ptr(), n_q, out_i.data_ptr(), out_v.data_ptr())
+    eng.synchronize()
+    gi_all = out_i.cpu().numpy().astype(np.uint32)
+    gv_all = out_v.cpu().numpy()
+    for q in range(n_q):
+        _exact(pkg, oracle, m, eng, xs[q], k, gi_all[q], gv_all[q], raw, C, gold=q not in (40, 70))
+    c = eng.debug_counters()
+    assert c["checks_failed"] > 0, c
+    print(f"\n[configs[1], default engine, scales 1 / 0.01 / 3, x = 0, -x] {n_q} queries exact; {c}")
+    eng.close()
