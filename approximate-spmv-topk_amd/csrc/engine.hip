@@ -87,6 +87,10 @@ struct EngineImpl {
     mutable uint32_t host_epoch = 0;
     mutable bool last_on_host = false;  // the most recent result is complete in h_res
     bool x_pending = false;             // an upload from h_x may still be in flight
+    // Large BAR (every MI355X server has it; checked at create): tkspmv_set_query writes x into device memory with plain CPU stores
+    // through the PCIe aperture -- 0.5 us for 4 KiB, no copy kernel ahead of the query's launch (that copy, 3-10 us of device time
+    // plus a dispatch, stood between set_query and every tkspmv_run). Posted writes stay ordered with the launch's doorbell.
+    bool bar_x = false;
     int host_path = 1;                  // TKSPMV_HOST_PATH=0: the plain path (stream synchronisation + copies)
     // Resident kernel (desc.impl = TKSPMV_IMPL_RESIDENT; batch_kernel<.., RESIDENT = true>): one launch that stays on the
     // GPU and serves tkspmv_run queries as the host submits them through pinned memory -- see BatchParams.
@@ -211,7 +215,6 @@ struct EngineImpl {
     float *d_lprior = nullptr;               // [grid] carried thresholds | 32 words: the suspension counters (LocalParams::prior_block)
     uint32_t *d_lstatus = nullptr;           // [0] 1: the last single launch failed its check
     mutable uint64_t single_launches = 0, single_repairs = 0;
-    uint32_t single_tune = 0;
     uint32_t uni_ppp = 0, uni_last = 0;  // uniform partition table (StreamParams::uni_ppp): partition q = packets [q * uni_ppp, ...)
 
     StreamParams stream_params(const float *x, int set = 0) const {
@@ -590,7 +593,6 @@ struct EngineImpl {
         G.mode = use_local;
         G.beta = local_beta;
         G.trace = d_trace ? d_trace + (launch_counter % 4) * trace_words : nullptr;
-        G.tune = single_tune;
         ++launch_counter;
         ++single_launches;
         if (pm.precision == Precision::F32C12) hipLaunchKernelGGL((single_kernel<7>), dim3(grid), dim3(512), 0, s, P, S, G);
@@ -695,7 +697,7 @@ struct EngineImpl {
     bool result_block_complete(uint32_t epoch) const {
         const size_t k = (size_t)desc.k;
         const volatile uint32_t *r = h_res;
-        uint32_t sum = epoch * 0x9E3779B1u;
+        uint32_t sum = epoch * 0x9E3779B1u + (r[2 * k + 5] != 0u ? 0xBADC0DE5u : 0u);  // (word 2k + 5: the status of single_kernel's check)
         for (size_t i = 0; i < k; ++i) sum += result_checksum_term(r[i], r[k + i], (uint32_t)i);
         return r[2 * k + 4] == sum;
     }
@@ -712,7 +714,7 @@ struct EngineImpl {
     // ANOTHER stream (tkspmv_enqueue with a caller's stream and dev_x = NULL) has no ordering against that copy -- the
     // engine's stream is non-blocking -- so it waits for the event recorded behind the copy.
     hipError_t order_x(const float *x, hipStream_t s) const {
-        if (x != d_x || !x_pending || s == stream) return hipSuccess;
+        if (x != d_x || !x_pending || s == stream || bar_x) return hipSuccess;  // (bar_x: the host wrote x itself, nothing is enqueued)
         return hipStreamWaitEvent(s, ev2, 0);
     }
     // Every entry point other than set_query / run / read: the resident kernel must have left (it shares the exchange
@@ -1081,6 +1083,29 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
 
     HIP_TRY(hipMalloc((void **)&m.d_x, (size_t)d.cols * 4));
     if (const char *f = getenv("TKSPMV_HOST_PATH")) m.host_path = atoi(f);
+    {
+        // Host stores into device memory: only where the runtime reports a large BAR, and only after a round trip has shown that a
+        // value stored by the CPU is the value a device-side copy reads back.
+        int large_bar = 0;
+        if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, dev) != hipSuccess) large_bar = 0;
+        (void)hipGetLastError();
+        bool want = large_bar != 0 && m.host_path != 0;
+        if (const char *f = getenv("TKSPMV_BAR_X")) want = want && atoi(f) != 0;
+        if (want) {
+            HIP_TRY(hipMemset(m.d_x, 0, (size_t)d.cols * 4));
+            HIP_TRY(hipDeviceSynchronize());
+            volatile uint32_t *px = reinterpret_cast<volatile uint32_t *>(m.d_x);
+            px[0] = 0x5A17C0DEu;
+            px[d.cols - 1] = 0xC0DE5A17u ^ d.cols;
+            __builtin_ia32_sfence();
+            uint32_t back[2] = {0, 0};
+            HIP_TRY(hipMemcpy(&back[0], m.d_x, 4, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(&back[1], m.d_x + (d.cols - 1), 4, hipMemcpyDeviceToHost));
+            m.bar_x = back[0] == 0x5A17C0DEu && (d.cols == 1 || back[1] == (0xC0DE5A17u ^ d.cols));
+            HIP_TRY(hipMemset(m.d_x, 0, (size_t)d.cols * 4));
+            HIP_TRY(hipDeviceSynchronize());
+        }
+    }
     if (m.host_path) {  // pinned staging copy of x and the host-visible result block (optional: the plain path needs neither)
         if (const char *f = getenv("TKSPMV_HOST_X")) m.host_x_direct = std::string(f) == "direct" || std::string(f) == "direct_nc";
         if (const char *f = getenv("TKSPMV_RUN_EVENTS")) m.run_events = atoi(f) != 0;
@@ -1297,7 +1322,6 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
                    d.impl == TKSPMV_IMPL_STREAM && !m.use_radix && m.fused && m.host_path && m.h_res != nullptr &&
                    m.pm.part_first.size() <= (size_t)m.grid * 8u;
     if (const char *f = getenv("TKSPMV_SINGLE")) m.can_single = m.can_single && atoi(f) != 0;
-    if (const char *f = getenv("TKSPMV_SINGLE_TUNE")) m.single_tune = (uint32_t)atoi(f);
     if (m.can_single) {
         HIP_TRY(hipMalloc((void **)&m.d_lslots, (size_t)m.grid * WG_SLOTS * 8));
         HIP_TRY(hipMemset(m.d_lslots, 0xFF, (size_t)m.grid * WG_SLOTS * 8));
@@ -1424,6 +1448,19 @@ int Engine::set_query(const float *host_x, double *elapsed_ns, std::string &err)
     }
     auto t0 = std::chrono::high_resolution_clock::now();
     HIP_TRY(hipSetDevice(m.device));
+    if (m.bar_x && !m.resident_capable) {
+        // (a launch enqueued earlier may still be reading d_x: tkspmv_run clears x_pending, the asynchronous entry points do not)
+        if (m.x_pending) HIP_TRY(hipStreamSynchronize(m.stream));
+        std::memcpy(m.d_x, host_x, (size_t)m.desc.cols * 4);
+        __builtin_ia32_sfence();
+        m.x_pending = true;
+        m.x_on_host_only = false;
+        m.d_x_cur = m.d_x;
+        m.have_query = true;
+        if (elapsed_ns)
+            *elapsed_ns = (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::high_resolution_clock::now() - t0).count();
+        return TKSPMV_OK;
+    }
     if (m.host_path && m.h_x) {
         // (an earlier upload from the staging copy must have been consumed before it is overwritten)
         if (m.x_pending) HIP_TRY(hipStreamSynchronize(m.stream));
@@ -1754,8 +1791,9 @@ int Engine::run(double *kernel_ns, std::string &err) {
             seen = wait_flag();
             if (seen) own_ticks += (double)m.h_res[2 * (size_t)m.desc.k + 1];
         }
-        if (!m.can_single || !seen || m.h_res[2 * (size_t)m.desc.k + 2] != 0u) {
+        if (!m.can_single || !seen || m.h_res[2 * (size_t)m.desc.k + 5] != 0u) {
             if (m.can_single) ++m.single_repairs;
+            m.h_res[2 * (size_t)m.desc.k + 5] = 0u;  // (only single_kernel writes the status word: the exact launch's block has none)
             m.launch_stream(m.d_x_cur, m.d_out_idx, m.d_out_val, m.stream, true);
             HIP_TRY(hipGetLastError());
             seen = wait_flag();
@@ -2075,6 +2113,7 @@ int Engine::profile(const float *dev_xs, int32_t n_x, int32_t iters, tkspmv_timi
             const float *x = dev_xs + (size_t)(i % n_x) * stride;
             HIP_TRY(hipEventRecord(evs[2 * i], m.stream));
             if (m.use_radix) m.launch_query(x, m.d_out_idx, m.d_out_val, m.stream);  // (scores + radix select + selection)
+            else if (m.can_single) m.launch_single(x, m.d_out_idx, m.d_out_val, m.stream, false);  // (what tkspmv_run launches)
             else m.launch_stream(x, m.d_out_idx, m.d_out_val, m.stream);
             HIP_TRY(hipEventRecord(evs[2 * i + 1], m.stream));
             if (!m.fused && !m.use_radix) m.launch_select(m.d_out_idx, m.d_out_val, m.stream);

@@ -26,7 +26,6 @@ struct LocalParams {
     uint32_t mode;              // 1: a wave's word is its best packet maximum, 2: its second best
     float beta;                 // carried thresholds start at beta x the recorded score
     unsigned long long *trace;  // optional (TKSPMV_TRACE=1): [grid][8 waves][8] s_memrealtime stamps
-    uint32_t tune;              // experiments: bits 0-1 = issue priorities of the streaming waves (see single_kernel)
 };
 
 constexpr uint32_t STG_N = 8;         // survivors a wave stages per query (64 lanes = 8 waves x 8 when one wave finalises)
@@ -60,6 +59,16 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
     v = mv(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_ROW_SHR8, 0xF, 0xF, false));
     v = mv(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_ROW_BCAST15, 0xA, 0xF, false));
     v = mv(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_ROW_BCAST31, 0xC, 0xF, false));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {  // (DPP prefix sum; the total is read from lane 63)
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, DPP_ROW_SHR1, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, DPP_ROW_SHR2, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, DPP_ROW_SHR4, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, DPP_ROW_SHR8, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, DPP_ROW_BCAST15, 0xA, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, DPP_ROW_BCAST31, 0xC, 0xF, true);
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
@@ -199,6 +208,8 @@ __device__ __forceinline__ bool select_local(const LocalParams &G, const SelectP
     }
     // (the bookkeeping thread reads the suspension counters with the records: single writer -- one selection at a time --, so
     //  what follows the check is stores only, no trip through memory behind it)
+    unsigned long long t_start = 0ull;  // (thread 0: the launch's start stamp, for the duration it reports with the flag)
+    if (tid == 0 && HOST && SP.t_start) t_start = __hip_atomic_load(SP.t_start, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     uint32_t pbv[4] = {0u, 0u, 0u, 0u};
     if (tid == nthreads - 1u && G.prior_block) {
 #pragma unroll
@@ -211,6 +222,8 @@ __device__ __forceinline__ bool select_local(const LocalParams &G, const SelectP
         S.sum = 0;
     }
     for (uint32_t i = tid; i < LSEL_BUCKETS; i += nthreads) S.hist[i] = 0u;
+    // (zeroed while the loads are in flight: the rank loop reads whole blocks of 8 keys, and 0 is below every real key)
+    for (uint32_t i = tid; i < LSEL_RANK + 8u; i += nthreads) S.keys[i] = 0ull;
     __syncthreads();
     {
         const uint32_t mu = wave_max_u32(my_used);  // (waits for the loads of `used`, issued behind the records')
@@ -219,6 +232,9 @@ __device__ __forceinline__ bool select_local(const LocalParams &G, const SelectP
     unsigned long long key[8];
 #pragma unroll
     for (uint32_t u = 0; u < 8; ++u) key[u] = (uint32_t)(mine[u] >> 32) != SLOT_INVALID ? make_ckey(mine[u]) : 0ull;
+    // (the loads of the bookkeeping words and of the start stamp are consumed HERE, where the records' loads have been waited for
+    //  anyway: a first use behind the result stores would wait for those stores -- the counter retires in order)
+    asm volatile("" ::"v"(pbv[0]), "v"(pbv[1]), "v"(pbv[2]), "v"(pbv[3]), "v"((uint32_t)t_start), "v"((uint32_t)(t_start >> 32)));
     __syncthreads();
     if (stamps && tid == 0) stamps[0] = __builtin_amdgcn_s_memrealtime();  // the loads have returned
     const uint32_t t0 = S.t0;
@@ -335,35 +351,37 @@ __device__ __forceinline__ bool select_local(const LocalParams &G, const SelectP
             if (kv[u] != 0ull && kv[u] >= prefix) S.keys[atomicAdd(&S.total, 1u)] = kv[u];
         __syncthreads();
         n_sel = S.total;
+        if (tid < 8) S.keys[n_sel + tid] = 0ull;  // padding for the unrolled rank loop
+        __syncthreads();
     }
     if (bad) n_sel = 0u;  // (nothing is ranked: the list of a failed check is never read)
-    if (tid < 8) S.keys[n_sel + tid] = 0ull;  // padding for the unrolled rank loop (0 is below every real key)
-    __syncthreads();
     if (stamps && tid == 0) stamps[2] = __builtin_amdgcn_s_memrealtime();  // keys in LDS
-    // rank by counting (keys are unique: rank r = number of larger keys); GT threads share one key
-    uint32_t GT = 1;
-    while (GT < 8u && n_sel * (GT * 2u) <= nthreads) GT *= 2u;
-    const uint32_t n_blocks = ((n_sel + 7u) & ~7u) >> 3;
+    // Rank by counting (keys are unique: rank r = number of larger keys); GT threads share one key and meet through shuffles.
     uint32_t cs = 0u;
-    for (uint32_t base = 0; base < n_sel; base += nthreads / GT) {
-        const uint32_t i = base + tid / GT, part = tid & (GT - 1u);
-        const bool active = i < n_sel;
-        const unsigned long long kx = active ? S.keys[i] : ~0ull;
-        uint32_t r = 0;
-        for (uint32_t blk = part; blk < n_blocks; blk += GT) {
+    {
+        uint32_t GT = 1;
+        while (GT < 8u && n_sel * (GT * 2u) <= nthreads) GT *= 2u;
+        const uint32_t n_blocks = ((n_sel + 7u) & ~7u) >> 3;
+        for (uint32_t base = 0; base < n_sel; base += nthreads / GT) {
+            const uint32_t i = base + tid / GT, part = tid & (GT - 1u);
+            const bool active = i < n_sel;
+            const unsigned long long kx = active ? S.keys[i] : ~0ull;
+            uint32_t r = 0;
+            for (uint32_t blk = part; blk < n_blocks; blk += GT) {
 #pragma unroll
-            for (uint32_t u = 0; u < 8; ++u) r += (S.keys[blk * 8u + u] > kx);
-        }
-        for (uint32_t d = 1; d < GT; d <<= 1) r += (uint32_t)__shfl_xor((int)r, (int)d);
-        if (active && part == 0u && r < SP.k) {
-            const uint32_t oi = (uint32_t)(kx & 0xFFFFFFFFull) + SP.first_row;
-            const float ov = key_to_float((uint32_t)(kx >> 32)) * out_scale;
-            SP.out_idx[r] = oi;
-            SP.out_val[r] = ov;
-            if (HOST) {
-                __hip_atomic_store(&SP.host_out[r], oi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                __hip_atomic_store(&SP.host_out[SP.k + r], __float_as_uint(ov), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                cs += result_checksum_term(oi, __float_as_uint(ov), r);
+                for (uint32_t u = 0; u < 8; ++u) r += (S.keys[blk * 8u + u] > kx);
+            }
+            for (uint32_t d = 1; d < GT; d <<= 1) r += (uint32_t)__shfl_xor((int)r, (int)d);
+            if (active && part == 0u && r < SP.k) {
+                const uint32_t oi = (uint32_t)(kx & 0xFFFFFFFFull) + SP.first_row;
+                const float ov = key_to_float((uint32_t)(kx >> 32)) * out_scale;
+                SP.out_idx[r] = oi;
+                SP.out_val[r] = ov;
+                if (HOST) {
+                    __hip_atomic_store(&SP.host_out[r], oi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(&SP.host_out[SP.k + r], __float_as_uint(ov), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    cs += result_checksum_term(oi, __float_as_uint(ov), r);
+                }
             }
         }
     }
@@ -395,20 +413,17 @@ __device__ __forceinline__ bool select_local(const LocalParams &G, const SelectP
         }
     }
     if (HOST) {
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) cs += (uint32_t)__shfl_xor((int)cs, d);
+        // The flag does not wait for the payload's stores to drain: the memory model would not order them anyway, and the host trusts
+        // the block only once it adds up to the checksum (which also covers the status of the check) -- result_block_complete.
+        cs = wave_sum_u32(cs);
         if (lane == 0 && cs) atomicAdd(&S.sum, cs);
-        // every writer drains its stores, the workgroup meets, one thread raises the flag
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (stamps && tid == 0) stamps[4] = __builtin_amdgcn_s_memrealtime();  // stores drained
+        if (stamps && tid == 0) stamps[4] = __builtin_amdgcn_s_memrealtime();
         if (tid == 0) {
             uint32_t *tail = SP.host_out + 2u * SP.k;
-            if (SP.t_start)
-                __hip_atomic_store(&tail[1], (uint32_t)(__builtin_amdgcn_s_memrealtime() - __hip_atomic_load(SP.t_start, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)),
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(&tail[2], bad ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(&tail[4], S.sum + SP.host_epoch * 0x9E3779B1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (SP.t_start) __hip_atomic_store(&tail[1], (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_start), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&tail[5], bad ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&tail[4], S.sum + SP.host_epoch * 0x9E3779B1u + (bad ? 0xBADC0DE5u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(&tail[0], SP.host_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
@@ -506,15 +521,7 @@ __global__ void __launch_bounds__(512, 4) single_kernel(const StreamParams P, co
     uint2 *wcand = L.u.w.cand + wave * WAVE_CAP;
 
     if (np != 0u) {
-        // The two workgroups of a CU do not share it evenly (the one dispatched first runs ~1.4 us ahead at the end of a 15 us stream,
-        // and a workgroup's waves 0-3 ~0.6 us ahead of its waves 4-7): issue priorities lean against it.
-        {
-            const uint32_t pm = G.tune & 3u, late_wg = bid >= n_wg / 2u ? 1u : 0u, late_wave = wave >= 4u ? 1u : 0u;
-            if (pm == 1u) { if (late_wg) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1); }
-            else if (pm == 2u) { if (late_wg) { if (late_wave) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(2); } else { if (late_wave) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); } }
-            else if (pm == 3u) { if (late_wave) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1); }
-            else __builtin_amdgcn_s_setprio(1);
-        }
+        __builtin_amdgcn_s_setprio(1);
         float carry = 0.0f;
         uint32_t wcnt = 0u;
         float top1 = -__builtin_huge_valf(), top2 = -__builtin_huge_valf();

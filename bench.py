@@ -258,9 +258,15 @@ def multi_query_leg(mod, m, dxs, a, device, alg_bytes):
 
 def single_query_leg(mod, m, xs, dxs, a, device, eng, alg_bytes):
     """The literal loop of the reference's hosts (host_spmv_bscsr.cpp:602-632): ONE query in flight -- reset(vec),
-    operator()(), read_result() -- through tkspmv_set_query / tkspmv_run / tkspmv_read on host buffers. kernel_us = the
-    hipEvent bracket tkspmv_run returns (the reference's hw_exec_time: device time of one fused launch, rotating stream
-    copies), end_to_end_us = host clock around the three calls (hw_full_exec_time + reset). >= 30 runs, first 2 dropped."""
+    operator()(), read_result() -- through tkspmv_set_query / tkspmv_run / tkspmv_read on host buffers.
+    Two clocks, named as what they are:
+      * device_us_self_stamped: what tkspmv_run returns -- the launch's own s_memrealtime span (100 MHz), first workgroup's
+        entry to the raising of the result flag. It excludes the dispatch latency before the first wave and the kernel's
+        last instructions behind the flag, and is NOT comparable with round 2's hipEvent figures.
+      * the figure of record for the kernel is rocprofv3's average duration of the same launches, committed under
+        profiles/ (r04_single_query_kernel_stats.csv); `kernels_us.single_query_launch_with_event_bracket` of this line
+        is the hipEvent bracket (the reference's hw_exec_time clock: ~6 us around an empty kernel).
+    end_to_end_us = host clock around the three calls (hw_full_exec_time + reset). >= 30 runs, first 2 dropped."""
     import numpy as np
     n = max(a.reps, 30) + 2
     kern, e2e = [], []
@@ -275,6 +281,8 @@ def single_query_leg(mod, m, xs, dxs, a, device, eng, alg_bytes):
     ok, par = check_parity(mod, m, xs[(n - 1) % xs.shape[0]], a.k, idx, val, eng)
     kern, e2e = kern[2:], e2e[2:]
     med = float(np.median(kern))
+    counters = eng.debug_counters()
+    single = counters.get("single_launches", 0) > 0
     # The same loop served by the resident kernel (desc.impl = TKSPMV_IMPL_RESIDENT): one launch stays on the GPU, queries
     # arrive and results leave through pinned memory -- no launch, copy engine or stream synchronisation per query.
     resident = None
@@ -300,12 +308,21 @@ def single_query_leg(mod, m, xs, dxs, a, device, eng, alg_bytes):
                             "(its own 100 MHz clock); end_to_end_us = host clock around set_query + run + read"}
     except Exception as e:  # noqa: BLE001 -- a side leg must not cost the bench line
         resident = {"error": f"{type(e).__name__}: {e}"}
-    return {"kernel": "tkspmv::stream_kernel<4,false,1024,7,3> (one fused launch per query: stream, flush, in-launch selection)",
+    return {"kernel": ("tkspmv::single_kernel<7> (one launch per query: workgroup-local thresholds carried from the previous query, "
+                       "one record per workgroup, selection in the workgroup that draws the last ticket; a failed check repeats "
+                       "the query through tkspmv::stream_kernel)") if single else
+                      "tkspmv::stream_kernel<4,false,1024,7,3> (one fused launch per query: stream, flush, in-launch selection)",
             "resident": resident,
-            "runs": len(kern), "dropped": 2, "kernel_us": med, "kernel_us_p95": pct(kern, 95), "frac": alg_bytes / (med * 1e3) / HBM_PEAK_GBS,
+            "runs": len(kern), "dropped": 2, "device_us_self_stamped": med, "device_us_self_stamped_p95": pct(kern, 95),
+            "kernel_us": med, "kernel_us_p95": pct(kern, 95), "frac": alg_bytes / (med * 1e3) / HBM_PEAK_GBS,
             "end_to_end_us": float(np.median(e2e)), "end_to_end_us_p95": pct(e2e, 95), "parity_checked": ok,
-            "note": "kernel_us includes the hipEvent bracket (~6 us around an empty kernel of the same geometry); rocprofv3 "
-                    "--kernel-trace durations of the same launches are committed under profiles/"}
+            "counters": {k_: counters[k_] for k_ in ("single_launches", "single_repairs", "single_checks_failed") if k_ in counters},
+            "clock": "kernel_us = device_us_self_stamped: the launch's own s_memrealtime span at 100 MHz (10 ns ticks), first "
+                     "workgroup's entry to the result flag; it excludes dispatch latency and the instructions behind the flag",
+            "note": "figure of record for the kernel: rocprofv3 --kernel-trace average of the same launches under profiles/ "
+                    "(r04_single_query_kernel_stats.csv); the hipEvent bracket (~6 us around an empty kernel) is "
+                    "kernels_us.single_query_launch_with_event_bracket; x travels by CPU stores through the PCIe aperture "
+                    "(large BAR), the result by device stores into pinned host memory, verified by a checksum"}
 
 
 def read_only_floor(eng, info, passes=64):
@@ -470,7 +487,7 @@ def bench_single(a, mod, torch, np, dev, local_rank):
         extra["single_query"] = single_query_leg(mod, m, xs, dxs, a, local_rank, eng, alg_bytes)
         prof = eng.profile(dxs.data_ptr(), a.queries, 100)
         extra["kernels_us"] = {"query_back_to_back": prof["query_ns"] / 1e3,
-                               "single_query_fused_launch_with_event_bracket": prof["stream_kernel_ns"] / 1e3,
+                               "single_query_launch_with_event_bracket": prof["stream_kernel_ns"] / 1e3,
                                "event_bracket_around_an_empty_kernel": prof["event_bracket_ns"] / 1e3,
                                "spmv_only_variant": prof["scores_kernel_ns"] / 1e3}
         # same matrix every query (fits the Infinity Cache): the steady state of a deployed single-matrix service

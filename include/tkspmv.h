@@ -180,7 +180,12 @@ int tkspmv_set_query(tkspmv_t *e, const float *host_x, double *elapsed_ns);
 /* Same, but x already lives in device memory (no copy; pointer must stay valid until the run completes). */
 int tkspmv_set_query_device(tkspmv_t *e, const float *dev_x);
 
-/* Run one query on the current vector and wait. *kernel_ns = device time of the kernels (hipEvents). */
+/* Run one query on the current vector and wait. *kernel_ns = device time of the launch(es): where the result travels through
+ * host-visible memory (the default) the launch's OWN span -- its s_memrealtime clock, 100 MHz: 10 ns per tick, from the first
+ * workgroup's entry to the raising of the result flag; dispatch latency and the instructions behind the flag are outside it --,
+ * a hipEvent bracket otherwise (TKSPMV_RUN_EVENTS=1 asks for the bracket; it costs ~6 us around an empty kernel). Engines that
+ * stream with workgroup-local thresholds (tkspmv_info.batch_mode bits 8-15) launch single_kernel here; if its selection's
+ * check fails -- a query unlike the ones before it -- the query runs again through the exact launch and both spans are added. */
 int tkspmv_run(tkspmv_t *e, double *kernel_ns);
 /* Enqueue one query on `stream` (hipStream_t cast to void*; NULL => engine stream), no host sync.
  * dev_idx/dev_val: optional device output buffers of k entries (NULL => engine-owned result buffers). */

@@ -1,7 +1,7 @@
 #!/bin/bash
 set -u
 REPO=$PWD
-OUT=$REPO/gpurun_out/r4f
+OUT=$REPO/gpurun_out/r4j
 rm -rf "$OUT"; mkdir -p "$OUT"
 timeout -k 10 900 python3 -m pytest tests/test_gpu_single.py -x -q -m gpu > "$OUT/tests.log" 2>&1
 rc=$?
