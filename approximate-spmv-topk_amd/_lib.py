@@ -41,7 +41,7 @@ class Info(C.Structure):
         ("grid", C.c_uint32), ("block", C.c_uint32), ("n_groups", C.c_uint32), ("lds_bytes", C.c_uint32),
         ("k", C.c_int32), ("partitions", C.c_int32), ("k_per_partition", C.c_int32), ("precision", C.c_int32),
         ("device", C.c_int32), ("num_cus", C.c_uint32), ("fixed_width", C.c_uint32), ("multi_q", C.c_uint32), ("multi_pack_us", C.c_uint32), ("multi_bytes", C.c_uint64),
-        ("pack_us", C.c_uint32), ("pack_on_device", C.c_uint32), ("claim_sets", C.c_uint32), ("batch_mode", C.c_uint32),
+        ("pack_us", C.c_uint32), ("pack_on_device", C.c_uint32), ("claim_sets", C.c_uint32), ("batch_mode", C.c_uint32), ("state_bytes", C.c_uint64),
     ]
 
     def as_dict(self):

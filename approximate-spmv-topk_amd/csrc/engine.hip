@@ -39,7 +39,6 @@
 #include "kernels/stream_kernel.hpp"
 #include "kernels/local.hpp"
 #include "kernels/batch_kernel.hpp"
-#include "kernels/claim_kernel.hpp"
 #include "kernels/multi_kernel.hpp"
 #include "kernels/radix_select.hpp"
 #include "kernels/read_probe.hpp"
@@ -117,7 +116,7 @@ struct EngineImpl {
     // the other. Everything else uses set 0.
     struct ExState {
         uint32_t *tau_g = nullptr, *gmax = nullptr, *ovf_count = nullptr;
-        unsigned long long *wg_cand = nullptr, *ovf = nullptr, *scratch = nullptr;
+        unsigned long long *wg_cand = nullptr, *ovf = nullptr;
         float *unit_inv = nullptr;
     };
     static constexpr int N_STATE = BATCH_MAX;  // deferred selection uses sets 0/1, the batch kernel one per query
@@ -129,6 +128,8 @@ struct EngineImpl {
     mutable uint32_t *pending_idx = nullptr;  // ... these result buffers
     mutable float *pending_val = nullptr;
     uint32_t *d_out_idx = nullptr;
+    uint32_t *d_alias_idx = nullptr;  // [BATCH_MAX][k] where the earlier queries of a launch write when they share the last one's buffer
+    float *d_alias_val = nullptr;
     uint32_t *d_done = nullptr;
     bool fused = true;
     bool can_defer = false;
@@ -157,7 +158,6 @@ struct EngineImpl {
     uint64_t sell_bytes = 0;
     uint32_t *d_multi_out_idx = nullptr;  // [2 * MULTI_Q_MAX][k] results of tkspmv_time_multi
     float *d_multi_out_val = nullptr;
-    unsigned long long *d_multi_scratch = nullptr;  // [MULTI_Q_MAX] general-path scratches (the selectors of a group run at once)
     // Two independent chains of multi-query launches (TKSPMV_MULTI_CHAINS=1 switches the second off): chain c runs on its own
     // stream with its own exchange-state sets [16c, 16c + 16), so the start-up of one chain's launch fills the tail of the
     // other's (a launch still selects the previous group of ITS chain). Measured: 6.26 against 7.84 us per query at 4
@@ -168,9 +168,14 @@ struct EngineImpl {
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     uint32_t *d_tickets = nullptr;  // [BATCH_MAX] x 32 words
-    // prior thresholds of the batch kernel (BatchParams::prior_word): word 0 = the prior, words 32.. = the repair flags
-    uint32_t *d_prior = nullptr;
-    bool use_prior = false;
+    // checked local thresholds of the batch kernel (BatchParams): the launches' verdict words (two, by launch parity), the workgroups'
+    // records per exchange-state set, the epoch words of the overflow lists' flow control
+    unsigned long long *d_verdict = nullptr;
+    unsigned long long *d_rec_slots = nullptr;  // [batch_max][grid][WG_SLOTS]
+    uint32_t *d_rec_used = nullptr;             // [batch_max][grid]
+    uint32_t *d_ovf_epoch = nullptr;            // [ovf_lists] x 32 words
+    uint32_t ovf_lists = 1;                     // overflow lists allocated (batch engines: 2, shared by the queries of a launch under flow control)
+    bool inline_repair = false;                 // the whole grid is resident at once: a launch repairs its failed checks itself
     uint32_t use_local = 0;  // workgroup-local thresholds (BatchParams::local: 0 off, 1 / 2: a wave's best / second best packet maximum)
     float *d_wg_prior = nullptr;  // [grid] + the countdown word (BatchParams::wg_prior / prior_block)
     bool carry_local = true;
@@ -178,13 +183,6 @@ struct EngineImpl {
     uint32_t pace_quads = 0, pace_levels = 3; // pacing by rank (BatchParams::pace_quads, pace_levels)
     mutable uint64_t batch_launches = 0;
     uint32_t n_sel_wg = 1;   // selector workgroups of a batch launch (BatchParams::n_selectors): 4 on small matrices
-    float prior_beta = 0.9f, prior_rise = 1.02f;
-    // claim_kernel (kernels/claim_kernel.hpp): the matrix is packed into sets of 8 wave partitions that workgroups claim
-    bool can_claim = false;
-    uint32_t n_claim_sets = 0;
-    uint32_t *d_claim = nullptr;        // [2 launch parities][CLAIM_SHARDS] x 32 words
-    uint32_t *d_claim_done = nullptr;   // [BATCH_MAX][CLAIM_SHARDS] x 32 words
-    mutable int claim_parity = 0;
     uint32_t groups_with_rows = 0;  // publishing groups that own at least one wave partition
     uint32_t n_reducers = 0;  // TKSPMV_REDUCERS (tuning): workgroups whose server derives tau from all maxima itself
     float *d_out_val = nullptr, *d_scores = nullptr;
@@ -279,7 +277,6 @@ struct EngineImpl {
         S.done_count = d_done;
         S.n_groups_pub = n_groups_pub;
         S.use_gmax = (n_sets != 0u && n_groups_pub >= (uint32_t)desc.k) ? 1u : 0u;
-        S.scratch = E.scratch;
         S.stats = collect_stats ? d_stats : nullptr;
         S.host_out = nullptr;
         S.host_epoch = 0u;
@@ -304,9 +301,7 @@ struct EngineImpl {
         S.pos_to_row = d_sell_rows;
         const MultiGroup &G = pending_group[c];
         const bool serial = G.n_q > 1u && G.io[0].out_idx == G.io[1].out_idx;
-        hipLaunchKernelGGL(select_group_kernel, dim3(serial ? 1u : G.n_q), dim3(SEL_THREADS), 0, s, S, set_addr(0), G,
-                           d_multi_scratch + (size_t)c * MULTI_Q_MAX * ((uint64_t)grid * WG_SLOTS + ovf_cap),
-                           (uint64_t)grid * WG_SLOTS + ovf_cap, serial ? 1u : 0u);
+        hipLaunchKernelGGL(select_group_kernel, dim3(serial ? 1u : G.n_q), dim3(SEL_THREADS), 0, s, S, set_addr(0), G, serial ? 1u : 0u);
         pending_group[c].n_q = 0u;
     }
     SetAddr set_addr(int s0) const {
@@ -316,7 +311,6 @@ struct EngineImpl {
         A.ovf_count0 = st[s0].ovf_count;
         A.wg_cand0 = st[s0].wg_cand;
         A.ovf_cand0 = st[s0].ovf;
-        A.scratch = st[s0].scratch;
         A.unit_inv0 = st[s0].unit_inv;
         A.gmax_stride = GMAX_WORDS;
         A.word_stride = STATE_WORD_STRIDE;
@@ -343,8 +337,6 @@ struct EngineImpl {
         M.A = set_addr(0);
         M.part_slice0 = d_sell_part_slice0;
         M.n_sel = (uint32_t)multi_q;
-        M.scratch0 = d_multi_scratch + (size_t)chain * MULTI_Q_MAX * ((uint64_t)grid * WG_SLOTS + ovf_cap);
-        M.scratch_stride = (uint64_t)grid * WG_SLOTS + ovf_cap;
         M.prev = pending_group[chain];
         M.cur.n_q = (uint32_t)n;
         M.cur.set0 = (uint32_t)((2 * chain + multi_parity[chain]) * MULTI_Q_MAX);
@@ -405,7 +397,7 @@ struct EngineImpl {
         launch_stream(x, out_idx, out_val, s);
         if (!fused) launch_select(out_idx, out_val, s);
     }
-    typedef void (*batch_fn)(const StreamParams, const SelectParams, const BatchParams);
+    typedef void (*batch_fn)(const BatchArgs);
     batch_fn batch_kernel_for() const {  // can_batch: x of at most 1024 columns (it is held twice in LDS)
         if (desc.precision == TKSPMV_Q1_7) return &batch_kernel<4, 1024, 1>;
         if (desc.precision == TKSPMV_Q1_7_WIDE) return &batch_kernel<4, 1024, 2>;
@@ -433,58 +425,41 @@ struct EngineImpl {
             Q.packets = d_replicas.empty() ? d_packets : d_replicas[(launch_counter + q) % d_replicas.size()];
             Q.out_idx = out_idx[q];
             Q.out_val = out_val[q];
+            // Result buffers shared by several queries of the launch (the engine-owned pair: "the last query wins"): selections run
+            // concurrently and a repair phase writes after the fact, so only the LAST query may keep such a buffer -- the earlier
+            // ones write to a scratch block nobody reads.
+            if (q + 1 < n && out_idx[q] == out_idx[n - 1]) {
+                Q.out_idx = d_alias_idx + (size_t)q * desc.k;
+                Q.out_val = d_alias_val + (size_t)q * desc.k;
+            }
         }
         launch_counter += (uint64_t)n;
-        if (use_prior) {
-            B.prior_word = d_prior;
-            B.prior_beta = prior_beta;
-            B.prior_rise = prior_rise;
-        }
-        if (use_prior || use_local) B.repair_flags = d_prior + 32;
         B.n_selectors = n_sel_wg;
-        B.scratch_stride = (uint64_t)grid * WG_SLOTS + ovf_cap;
         B.local = use_local;
         B.pace_quads = pace_quads;
         B.pace_levels = pace_levels;
-        ++batch_launches;
         B.prior_block = reinterpret_cast<uint32_t *>(d_wg_prior + grid);
+        B.gate_parity = (uint32_t)(batch_launches & 1u);
+        B.verdict = d_verdict + 16 * (batch_launches & 1u);
+        B.verdict_next = d_verdict + 16 * ((batch_launches + 1u) & 1u);
+        ++batch_launches;
         if (use_local && carry_local) {
             B.wg_prior = d_wg_prior;
             B.local_beta = local_beta;
         }
-        hipLaunchKernelGGL(batch_kernel_for(), dim3(grid), dim3(block + 64), 0, s, P, S, B);
-        if (use_prior || use_local) {  // the queries whose guess did not hold, again and without one (nobody flagged: the launch is empty)
-            B.repair = 1u;
-            hipLaunchKernelGGL(batch_kernel_for(), dim3(grid), dim3(block + 64), 0, s, P, S, B);
+        B.lslots = d_rec_slots;
+        B.lused = d_rec_used;
+        B.lslots_stride = grid * WG_SLOTS;
+        B.lused_stride = grid;
+        B.ovf_epoch = d_ovf_epoch;
+        B.ovf_lists = std::min(ovf_lists, 4u);  // (engines with one list per set -- the multi-query ones -- lend the batch kernel their first four)
+        B.inline_repair = inline_repair ? 1u : 0u;
+        BatchArgs A{P, S, B};
+        hipLaunchKernelGGL(batch_kernel_for(), dim3(grid), dim3(block + 64), 0, s, A);
+        if (use_local && !inline_repair) {  // (a GPU that cannot hold the whole grid at once: the repair phase as a launch of its own)
+            A.B.repair = 1u;
+            hipLaunchKernelGGL(batch_kernel_for(), dim3(grid), dim3(block + 64), 0, s, A);
         }
-    }
-    // n <= batch_max queries in one launch of the claim kernel (the matrix dealt out dynamically); results complete in stream
-    // order after the launch.
-    void launch_claim(const float *const *xs, uint32_t *const *out_idx, float *const *out_val, int n, hipStream_t s) const {
-        drain(s);
-        StreamParams P = stream_params(xs[0], 0);
-        P.fused = 0u;
-        // a threshold needs k publishing groups: every workgroup that gets a set of a query publishes for it
-        P.tau_possible = (uint64_t)std::min<uint32_t>(n_claim_sets, grid - 1u) * gpw >= (uint64_t)desc.k ? 1u : 0u;
-        SelectParams S = select_params(out_idx[0], out_val[0], 0);
-        ClaimParams B{};
-        B.n_q = (uint32_t)n;
-        B.n_sets = n_claim_sets;
-        B.claim = d_claim + (size_t)claim_parity * CLAIM_SHARDS * 32u;
-        B.claim_other = d_claim + (size_t)(claim_parity ^ 1) * CLAIM_SHARDS * 32u;
-        B.done = d_claim_done;
-        claim_parity ^= 1;
-        static_cast<SetAddr &>(B) = set_addr(0);
-        for (int q = 0; q < n; ++q) {
-            BatchIO &Q = B.io[q];
-            Q.x = xs[q];
-            Q.packets = d_replicas.empty() ? d_packets : d_replicas[(launch_counter + q) % d_replicas.size()];
-            Q.out_idx = out_idx[q];
-            Q.out_val = out_val[q];
-        }
-        launch_counter += (uint64_t)n;
-        if (pm.precision == Precision::F32C12) hipLaunchKernelGGL((claim_kernel<1024, 7>), dim3(grid), dim3(block + 64), 0, s, P, S, B);
-        else hipLaunchKernelGGL((claim_kernel<1024, 0>), dim3(grid), dim3(block + 64), 0, s, P, S, B);
     }
     // A back-to-back sequence of queries given as pointer lists: batch kernel launches of up to BATCH_MAX queries
     // when it is available, else deferred selection.
@@ -495,8 +470,7 @@ struct EngineImpl {
             return;
         }
         for (int i = 0; i < n; i += batch_max) {
-            if (can_claim) launch_claim(xs + i, out_idx + i, out_val + i, std::min(batch_max, n - i), s);
-            else launch_batch(xs + i, out_idx + i, out_val + i, std::min(batch_max, n - i), s);
+            launch_batch(xs + i, out_idx + i, out_val + i, std::min(batch_max, n - i), s);
         }
     }
     // One query of a back-to-back sequence: its selection runs inside the NEXT deferred launch (or in drain()).
@@ -662,7 +636,8 @@ struct EngineImpl {
         static_cast<SetAddr &>(B) = set_addr(0);
         B.n_q = 0u;
         B.n_selectors = n_sel_wg;  // (only the first one works in this mode; the others leave -- the partitions were dealt for grid - n_sel_wg)
-        B.scratch_stride = (uint64_t)grid * WG_SLOTS + ovf_cap;
+        B.ovf_epoch = d_ovf_epoch;
+        B.ovf_lists = std::min(ovf_lists, 4u);  // (engines with one list per set -- the multi-query ones -- lend the batch kernel their first four)
         B.tickets = d_tickets;
         B.io[0].out_idx = d_out_idx;
         B.io[0].out_val = d_out_val;
@@ -676,9 +651,9 @@ struct EngineImpl {
         B.n_replicas = d_replicas.empty() ? 1u : (uint32_t)std::min<size_t>(d_replicas.size(), 8);
         for (uint32_t r = 0; r < 8u; ++r) B.replicas[r] = d_replicas.empty() ? d_packets : d_replicas[r % d_replicas.size()];
         if (pm.precision == Precision::F32C12)
-            hipLaunchKernelGGL((batch_kernel<4, 1024, 7, false, true>), dim3(grid), dim3(block + 64), 0, rstream, P, S, B);
+            hipLaunchKernelGGL((batch_kernel<4, 1024, 7, false, true>), dim3(grid), dim3(block + 64), 0, rstream, BatchArgs{P, S, B});
         else
-            hipLaunchKernelGGL((batch_kernel<4, 1024, 0, false, true>), dim3(grid), dim3(block + 64), 0, rstream, P, S, B);
+            hipLaunchKernelGGL((batch_kernel<4, 1024, 0, false, true>), dim3(grid), dim3(block + 64), 0, rstream, BatchArgs{P, S, B});
         e = hipGetLastError();
         resident_running = e == hipSuccess;
         return e;
@@ -773,13 +748,13 @@ Engine::~Engine() {
     if (m.stream) (void)hipStreamSynchronize(m.stream);
     void *bufs[] = {m.d_packets, m.d_pkt_row, m.d_part_first, m.d_part_count, m.d_x,
                     m.d_out_idx, m.d_out_val, m.d_scores,     m.d_stats,      m.d_done, m.d_trace, m.d_tickets,
-                    m.d_claim,   m.d_claim_done, m.d_tstart, m.d_prior, m.d_wg_prior,
+                    m.d_tstart, m.d_verdict, m.d_wg_prior, m.d_rec_slots, m.d_rec_used, m.d_ovf_epoch, m.d_alias_idx, m.d_alias_val,
                     m.d_lslots,  m.d_lused, m.d_lprior, m.d_lstatus};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     {
         EngineImpl::ExState &E = m.st[0];  // the other sets point into these blocks
-        void *eb[] = {E.tau_g, E.gmax, E.ovf_count, E.wg_cand, E.ovf, E.scratch, E.unit_inv};
+        void *eb[] = {E.tau_g, E.gmax, E.ovf_count, E.wg_cand, E.ovf, E.unit_inv};
         for (void *b : eb)
             if (b) (void)hipFree(b);
     }
@@ -792,7 +767,7 @@ Engine::~Engine() {
     for (size_t r = 1; r < m.d_replicas.size(); ++r) (void)hipFree(m.d_replicas[r]);
     for (size_t r = 1; r < m.d_sell_replicas.size(); ++r) (void)hipFree(m.d_sell_replicas[r]);
     {
-        void *sb[] = {m.d_coo_col, m.d_coo_val, m.d_sell_packets, m.d_sell_rows, m.d_sell_part_first, m.d_sell_part_count, m.d_sell_part_slice0, m.d_multi_scratch, m.d_multi_out_idx, m.d_multi_out_val, m.d_rscores, m.d_rhist};
+        void *sb[] = {m.d_coo_col, m.d_coo_val, m.d_sell_packets, m.d_sell_rows, m.d_sell_part_first, m.d_sell_part_count, m.d_sell_part_slice0, m.d_multi_out_idx, m.d_multi_out_val, m.d_rscores, m.d_rhist};
         for (void *b : sb)
             if (b) (void)hipFree(b);
     }
@@ -834,7 +809,7 @@ static uint64_t local_matrix_packets() {
 static uint32_t small_matrix_settings(const tkspmv_desc &d, uint32_t grid, bool defer_capable, uint32_t C, bool *small_out) {
     const uint64_t packets_lb = d.nnz / (64u * (uint64_t)std::max(C, 1u));
     const bool small = defer_capable && grid >= 64u && d.nnz != 0 && d.cols <= 1024u && d.impl == TKSPMV_IMPL_STREAM && d.multi_q == 0 &&
-                       d.partitions <= 1 && packets_lb <= local_matrix_packets() && !getenv("TKSPMV_MULTI_Q") && !getenv("TKSPMV_CLAIM");
+                       d.partitions <= 1 && packets_lb <= local_matrix_packets() && !getenv("TKSPMV_MULTI_Q");
     if (small_out) *small_out = small;
     uint32_t n = small ? 4u : 1u;
     if (const char *f = getenv("TKSPMV_SELECTORS")) n = (uint32_t)std::max(1, std::min(8, atoi(f)));
@@ -926,27 +901,8 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
     m.n_sel_wg = small_matrix_settings(d, m.grid, defer_capable, C, &small_matrix);
     if (prepacked && prepacked->part_first.size() > (size_t)(m.grid - m.n_sel_wg) * waves_per_wg) m.n_sel_wg = 1u;
     const uint32_t n_stream_waves = (m.grid - (defer_capable ? m.n_sel_wg : 0u)) * waves_per_wg;
-    // (measurement aid, tools/claim_probe.py: more partitions than waves -- only the read probe may run on such an engine)
-    // claim_kernel: fp32 values, 4 entries per lane, x of at most 1024 columns, 8 streaming waves per workgroup, no tracing
-    // hooks. The matrix is cut into sets of 8 partitions of ~10 packets (at least 2 sets per workgroup, at most 32) instead of
-    // one partition per wave. (TKSPMV_CLAIM=0: one partition per wave and batch_kernel.)
-    bool want_claim = d.precision == TKSPMV_F32 && C == 4u && d.cols <= 1024u && d.impl == TKSPMV_IMPL_STREAM && waves_per_wg == 8u &&
-                      defer_capable && d.partitions <= 1 && !getenv("TKSPMV_TRACE") && !getenv("TKSPMV_STATS") && !getenv("TKSPMV_STAMPS") &&
-                      !getenv("TKSPMV_DBG_FLAGS") && !getenv("TKSPMV_DBG_REPEAT");
-    // Opt-in (TKSPMV_CLAIM=1): measured on one box against the static partitions of batch_kernel -- 18.35 us per query --
-    // 19.1 / 19.6 / 28.6 us at 1 / 2 / 4 sets per workgroup: the server wave's staging chain (claim, side tables and x, the
-    // exchange duty, the drain before the DONE add: ~6 us per assignment) does not keep up with assignments of 5-10 packets.
-    want_claim = want_claim && getenv("TKSPMV_CLAIM") != nullptr && atoi(getenv("TKSPMV_CLAIM")) != 0;
-    uint32_t claim_parts = 0;
-    if (want_claim) {
-        const uint64_t n_wg = m.grid - 1u;
-        uint32_t spw = 2;
-        if (const char *f = getenv("TKSPMV_CLAIM_SETS_PER_WG")) spw = (uint32_t)std::max(1, std::min(32, atoi(f)));
-        const uint64_t by_size = (d.nnz / 256u / 10u + 7u) / 8u;  // sets of 8 partitions of ~10 packets
-        claim_parts = (uint32_t)(std::max<uint64_t>(n_wg * spw, std::min<uint64_t>(by_size, n_wg * 32u)) * 8u);
-    }
-    const uint32_t n_parts_hint = getenv("TKSPMV_PARTITIONS_HINT") ? (uint32_t)atoi(getenv("TKSPMV_PARTITIONS_HINT"))
-                                                                   : (want_claim ? claim_parts : n_stream_waves);
+    // (TKSPMV_PARTITIONS_HINT: measurement aid of the load-only probe -- more partitions than waves; such an engine runs no queries)
+    const uint32_t n_parts_hint = getenv("TKSPMV_PARTITIONS_HINT") ? (uint32_t)atoi(getenv("TKSPMV_PARTITIONS_HINT")) : n_stream_waves;
     if (prepacked) {
         // A matrix packed earlier (tkspmv_pack / a .tkspmv file): it must describe the same problem and must not have
         // more partitions than this launch geometry has streaming waves (the batch kernel gives every wave one).
@@ -958,7 +914,7 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
             err = "the packed matrix does not match the descriptor (rows, cols, precision or entries per lane)";
             return TKSPMV_ERR_INVALID;
         }
-        if (q.part_first.size() > n_stream_waves && !want_claim) {
+        if (q.part_first.size() > n_stream_waves) {
             err = "the packed matrix has more wave partitions than this GPU's launch geometry has streaming waves: pack it "
                   "again with tkspmv_pack(desc, " + std::to_string(n_stream_waves) + ", ...)";
             return TKSPMV_ERR_UNSUPPORTED;
@@ -1156,15 +1112,10 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
         HIP_TRY(hipMemcpy(m.d_rscores, ninf.data(), n * 4, hipMemcpyHostToDevice));
         HIP_TRY(hipMalloc((void **)&m.d_rhist, 4 * 256 * 4));
     }
-    m.can_claim = want_claim && m.can_batch && !m.use_radix;
-    if (want_claim && !m.can_claim && m.pm.part_first.size() > n_stream_waves && m.can_batch) m.can_batch = false;  // (batch_kernel needs one partition per wave)
-    if (m.can_claim) {
-        m.n_claim_sets = (uint32_t)((m.pm.part_first.size() + 7u) / 8u);
-        HIP_TRY(malloc_exchange((void **)&m.d_claim, 2 * CLAIM_SHARDS * 32 * 4));
-        HIP_TRY(hipMemset(m.d_claim, 0, 2 * CLAIM_SHARDS * 32 * 4));
-        HIP_TRY(malloc_exchange((void **)&m.d_claim_done, (size_t)BATCH_MAX * CLAIM_SHARDS * 32 * 4));
-        HIP_TRY(hipMemset(m.d_claim_done, 0, (size_t)BATCH_MAX * CLAIM_SHARDS * 32 * 4));
-    }
+    // (every streaming wave of a sequence launch owns ONE partition: an engine packed with more -- the load-only probe's
+    //  TKSPMV_PARTITIONS_HINT -- would silently skip the rest)
+    const bool partitions_fit = m.pm.part_first.size() <= (size_t)n_stream_waves;
+    if (!partitions_fit) m.can_batch = m.can_defer = false;
     // Multi-query passes (desc.multi_q; TKSPMV_MULTI_Q overrides): a second copy of the matrix in the wave-sliced ELL layout.
     {
         int mq = d.multi_q;
@@ -1235,7 +1186,6 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
         HIP_TRY(hipMemcpy(m.d_sell_part_first, sm.part_first.data(), (size_t)m.sell_parts * 4, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(m.d_sell_part_count, sm.part_count.data(), (size_t)m.sell_parts * 4, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(m.d_sell_part_slice0, sm.part_slice0.data(), (size_t)m.sell_parts * 4, hipMemcpyHostToDevice));
-        HIP_TRY(hipMalloc((void **)&m.d_multi_scratch, 2 * (size_t)MULTI_Q_MAX * ((size_t)m.grid * WG_SLOTS + std::max<uint32_t>(d.rows, 1u)) * 8));
         HIP_TRY(hipMalloc((void **)&m.d_multi_out_idx, 2 * (size_t)MULTI_Q_MAX * d.k * 4));
         HIP_TRY(hipMalloc((void **)&m.d_multi_out_val, 2 * (size_t)MULTI_Q_MAX * d.k * 4));
         HIP_TRY(hipStreamCreateWithFlags(&m.side, hipStreamNonBlocking));
@@ -1272,13 +1222,8 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
     }
     HIP_TRY(malloc_exchange((void **)&m.d_tickets, BATCH_MAX * 32 * 4));
     HIP_TRY(hipMemset(m.d_tickets, 0, BATCH_MAX * 32 * 4));
-    HIP_TRY(malloc_exchange((void **)&m.d_prior, (32 + BATCH_MAX) * 4));
-    HIP_TRY(hipMemset(m.d_prior, 0, (32 + BATCH_MAX) * 4));
-    // TKSPMV_PRIOR=1 (opt-in): queries of a batch start from a guessed threshold, verified by the selection
-    if (const char *f = getenv("TKSPMV_PRIOR")) m.use_prior = atoi(f) != 0;
-    if (const char *f = getenv("TKSPMV_PRIOR_BETA")) m.prior_beta = (float)atof(f);
-    if (const char *f = getenv("TKSPMV_PRIOR_RISE")) m.prior_rise = (float)atof(f);
-    m.use_prior = m.use_prior && !m.collect_stats && !getenv("TKSPMV_TRACE") && !getenv("TKSPMV_STAMPS");
+    HIP_TRY(malloc_exchange((void **)&m.d_verdict, 256));
+    HIP_TRY(hipMemset(m.d_verdict, 0, 256));
     {
         // Workgroup-local thresholds pay when they practically never fail the selection's check (a failure costs the query a
         // second pass). The workgroup's threshold is the smallest of its waves' words; it exceeds the k-th best score when EVERY
@@ -1333,28 +1278,29 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
         HIP_TRY(hipMemset(m.d_lstatus, 0, 128));
     }
     {
-        // Exchange-state sets: one block per field, set s at s strides (the batch kernel addresses them that way).
-        if (m.can_batch && !m.can_multi && !m.resident_capable) {
-            const uint64_t per_set = (uint64_t)m.ovf_cap * 8u;
-            // (16 GiB of 288: 32 queries per launch up to 64M rows. Round 2 capped the lists at 1 GiB, which left a 10M-row matrix
-            //  13 queries per launch -- for memory, not for speed.)
-            m.batch_max = (int)std::max<uint64_t>(4, std::min<uint64_t>(BATCH_MAX, (16ull << 30) / std::max<uint64_t>(per_set, 1)));
-        }
+        // Exchange-state sets: one block per field, set s at s strides (the batch kernel addresses them that way). The batch kernel
+        // runs one set per query of a launch; every set is small -- published maxima, a threshold word, one slot per wave --
+        // except for the overflow list, which must be able to hold EVERY row (a degenerate query -- x = 0, all scores equal --
+        // makes every row a candidate and the result must still be exact): 8 bytes per row. Round 3 kept one list per set: 256 MB
+        // at 1M rows, 2.6 GB at 10M. Engines of the batch kernel now keep FOUR, which the queries of a launch share round robin
+        // under flow control (BatchParams::ovf_epoch), and the general path of the selection needs no scratch copy any more
+        // (select_body): 32 MB at 1M rows, 320 MB at 10M. Multi-query engines keep one list per set (their groups' selections are
+        // owed across launches).
         if (const char *f = getenv("TKSPMV_BATCH_MAX")) m.batch_max = std::max(1, std::min(BATCH_MAX, atoi(f)));
         const int n_sets_alloc = (m.can_multi || m.resident_capable) ? EngineImpl::N_STATE : (m.can_batch ? m.batch_max : (m.can_defer ? 2 : 1));
         const size_t ns = (size_t)n_sets_alloc;
+        m.ovf_lists = m.can_multi ? (uint32_t)n_sets_alloc : (uint32_t)std::min(4, n_sets_alloc);
+        const size_t nl = m.ovf_lists;
         EngineImpl::ExState &E0 = m.st[0];
         HIP_TRY(malloc_exchange((void **)&E0.gmax, ns * EngineImpl::GMAX_WORDS * 4));
         HIP_TRY(hipMemset(E0.gmax, 0, ns * EngineImpl::GMAX_WORDS * 4));
         HIP_TRY(malloc_exchange((void **)&E0.tau_g, ns * EngineImpl::STATE_WORD_STRIDE * 4));
         HIP_TRY(hipMemset(E0.tau_g, 0, ns * EngineImpl::STATE_WORD_STRIDE * 4));
-        HIP_TRY(hipMalloc((void **)&E0.ovf_count, ns * EngineImpl::STATE_WORD_STRIDE * 4));
-        HIP_TRY(hipMemset(E0.ovf_count, 0, ns * EngineImpl::STATE_WORD_STRIDE * 4));
+        HIP_TRY(hipMalloc((void **)&E0.ovf_count, nl * EngineImpl::STATE_WORD_STRIDE * 4));
+        HIP_TRY(hipMemset(E0.ovf_count, 0, nl * EngineImpl::STATE_WORD_STRIDE * 4));
         HIP_TRY(hipMalloc((void **)&E0.wg_cand, ns * m.grid * WG_SLOTS * 8));
         HIP_TRY(hipMemset(E0.wg_cand, 0xFF, ns * m.grid * WG_SLOTS * 8));
-        HIP_TRY(hipMalloc((void **)&E0.ovf, ns * m.ovf_cap * 8));
-        // the scratch of the selection's general path is used by one selection at a time: shared by all sets
-        HIP_TRY(hipMalloc((void **)&E0.scratch, (size_t)m.n_sel_wg * ((size_t)m.grid * WG_SLOTS + m.ovf_cap) * 8));
+        HIP_TRY(hipMalloc((void **)&E0.ovf, nl * m.ovf_cap * 8));
         HIP_TRY(hipMalloc((void **)&E0.unit_inv, ns * EngineImpl::STATE_WORD_STRIDE * 4));
         std::vector<float> ones(ns * EngineImpl::STATE_WORD_STRIDE, 1.0f);
         HIP_TRY(hipMemcpy(E0.unit_inv, ones.data(), ones.size() * 4, hipMemcpyHostToDevice));
@@ -1362,12 +1308,33 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
             EngineImpl::ExState &E = m.st[si];
             E.gmax = E0.gmax + (size_t)si * EngineImpl::GMAX_WORDS;
             E.tau_g = E0.tau_g + (size_t)si * EngineImpl::STATE_WORD_STRIDE;
-            E.ovf_count = E0.ovf_count + (size_t)si * EngineImpl::STATE_WORD_STRIDE;
+            E.ovf_count = E0.ovf_count + ((size_t)si % nl) * EngineImpl::STATE_WORD_STRIDE;
             E.wg_cand = E0.wg_cand + (size_t)si * m.grid * WG_SLOTS;
-            E.ovf = E0.ovf + (size_t)si * m.ovf_cap;
-            E.scratch = E0.scratch;
+            E.ovf = E0.ovf + ((size_t)si % nl) * m.ovf_cap;
             E.unit_inv = E0.unit_inv + (size_t)si * EngineImpl::STATE_WORD_STRIDE;
         }
+        HIP_TRY(malloc_exchange((void **)&m.d_ovf_epoch, 128));
+        HIP_TRY(hipMemset(m.d_ovf_epoch, 0, 128));
+        if (m.can_batch) {
+            // the workgroups' records of local mode, one block per set; the scratch results of queries that share the last one's buffer
+            HIP_TRY(hipMalloc((void **)&m.d_rec_slots, ns * m.grid * WG_SLOTS * 8));
+            HIP_TRY(hipMemset(m.d_rec_slots, 0xFF, ns * m.grid * WG_SLOTS * 8));
+            HIP_TRY(hipMalloc((void **)&m.d_rec_used, ns * m.grid * 4));
+            HIP_TRY(hipMemset(m.d_rec_used, 0, ns * m.grid * 4));
+            HIP_TRY(hipMalloc((void **)&m.d_alias_idx, (size_t)BATCH_MAX * d.k * 4));
+            HIP_TRY(hipMalloc((void **)&m.d_alias_val, (size_t)BATCH_MAX * d.k * 4));
+            // A launch repairs its failed checks itself (every workgroup waits for the launch's verdict) only where the whole grid
+            // is resident at once: otherwise a workgroup waiting for the verdict could keep one that has not started yet -- and
+            // whose tickets the verdict needs -- from ever getting a slot.
+            int per_cu = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(m.batch_kernel_for()), (int)m.block + 64, 0) != hipSuccess) per_cu = 0;
+            (void)hipGetLastError();
+            m.inline_repair = (uint64_t)per_cu * num_cus >= m.grid;
+            if (const char *f = getenv("TKSPMV_INLINE_REPAIR")) m.inline_repair = m.inline_repair && atoi(f) != 0;
+        }
+        m.info.state_bytes = ns * (EngineImpl::GMAX_WORDS * 4 + 2 * EngineImpl::STATE_WORD_STRIDE * 4 + (uint64_t)m.grid * WG_SLOTS * 8) +
+                             nl * ((uint64_t)m.ovf_cap * 8 + EngineImpl::STATE_WORD_STRIDE * 4) +
+                             (m.can_batch ? ns * ((uint64_t)m.grid * WG_SLOTS * 8 + (uint64_t)m.grid * 4) : 0);
     }
     HIP_TRY(hipMemset(m.d_stats, 0, 32 * 8));
     m.collect_stamps = getenv("TKSPMV_STAMPS") != nullptr;
@@ -1405,7 +1372,7 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
     m.info.pack_us = m.pack_us;
     m.info.multi_pack_us = m.sell_pack_us;
     m.info.pack_on_device = m.packed_on_device ? 1u : 0u;
-    m.info.claim_sets = m.can_claim ? m.n_claim_sets : 0u;
+    m.info.claim_sets = 0u;
     m.info.batch_mode = (m.can_batch ? (m.n_sel_wg | (m.use_local << 8)) : 0u) | (std::min<uint32_t>(n_parts_hint, 0xFFFFu) << 16);
     HIP_TRY(hipDeviceSynchronize());
     return TKSPMV_OK;
@@ -1875,7 +1842,7 @@ int Engine::debug_counters(unsigned long long *out, int n, std::string &err) {
     out[1] = w[1];
     out[2] = w[0];
     out[3] = m.batch_launches;
-    out[4] = w[4];  // launches the gate of the local thresholds stays closed for
+    out[4] = w[(m.batch_launches & 1u) ? 7 : 4];  // launches the gate of the local thresholds stays closed for (the next launch's copy)
     out[5] = w[5];  // length of its latest closure
     if (n >= 10) {  // tkspmv_run through single_kernel: launches, queries sent on through the exact launch, failed checks, suspension
         uint32_t s[4] = {0, 0, 0, 0};
@@ -2175,8 +2142,6 @@ int Engine::profile(const float *dev_xs, int32_t n_x, int32_t iters, tkspmv_timi
         fprintf(stderr, "[tkspmv stats] selections %llu, general-path selections %llu, max candidates %llu, overflow entries per selection %.1f; "
                         "per selection: waves that waited for a threshold at the end of their partition %.1f (%.1f us in all)\n",
                 sx[1], sx[3], sx[2], (double)sx[8] / nsel, (double)sx[10] / nsel, (double)sx[9] / 100.0 / nsel);
-        fprintf(stderr, "[tkspmv stats] per selection: waves that redid their cold packets %.1f (%.1f packets in all)\n",
-                (double)sx[12] / nsel, (double)sx[11] / nsel);
     }
     if (m.collect_stamps) {
         unsigned long long st[16];

@@ -24,9 +24,6 @@ namespace tkspmv {
 // workgroup that never block on anything but memory.
 // ------------------------------------------------------------------------------------------------------------
 constexpr int BATCH_MAX = 32;
-#ifndef TKSPMV_ALL_SERVERS_PRIO
-#define TKSPMV_ALL_SERVERS_PRIO 0
-#endif
 #ifndef TKSPMV_TAU_WAIT
 #define TKSPMV_TAU_WAIT 3000
 #endif
@@ -34,7 +31,7 @@ constexpr unsigned long long BATCH_TAU_WAIT = TKSPMV_TAU_WAIT;  // x 10 ns (s_me
 // (a workgroup-local threshold forms through LDS within the workgroup's own query -- or never, when some wave of it holds no row
 //  above min_score: 3 us are plenty, and a workload filtered by min_score must not wait 30 us per query in such workgroups)
 constexpr unsigned long long LOCAL_TAU_WAIT = 300;
-constexpr int MISC_DBG_WAITS = 26, MISC_DBG_WAIT_TICKS = 27, MISC_DBG_REDO_PK = 28, MISC_DBG_REDO_WV = 29;  // TKSPMV_STATS=1 only
+constexpr int MISC_DBG_WAITS = 26, MISC_DBG_WAIT_TICKS = 27;  // TKSPMV_STATS=1 only
 constexpr int MISC_XREADY = 2, MISC_MINU = 3;  // batch kernel only: x staged for query (value - 1); min score in units
 
 // Per query only what differs from query to query travels in the kernel arguments (32 bytes); the exchange-state set of
@@ -48,7 +45,7 @@ struct BatchIO {
 // Exchange-state sets are allocated as one block per field: set s = set 0 plus s strides.
 struct SetAddr {
     uint32_t *gmax0, *tau_g0, *ovf_count0;
-    unsigned long long *wg_cand0, *ovf_cand0, *scratch;
+    unsigned long long *wg_cand0, *ovf_cand0;
     float *unit_inv0;
     uint32_t gmax_stride, word_stride, cand_stride;
     uint64_t ovf_stride;
@@ -63,50 +60,57 @@ struct BatchParams : SetAddr {
     uint32_t n_q;
     uint32_t *tickets;  // [BATCH_MAX] counters, 32 words apart
     BatchIO io[BATCH_MAX];
-    // ---- prior thresholds (round 3; prior_word = NULL: off) ------------------------------------------------------------------
-    // A query starts with a GUESSED threshold -- prior_beta x the k-th best score of the query selected most recently -- instead
-    // of none: no cold phase, nothing appended before the exchange has produced a threshold (a quarter of all packets took the
-    // candidate path for that). Exactness does not rest on the guess: the selection checks that at least k candidates reach
-    // the largest guess any workgroup used (SelectParams::tau0_g; then so does the k-th best score, and nothing that belongs
-    // to the result was dropped below it) and raises the query's repair flag otherwise; every batch launch is followed by a
-    // REPAIR launch of the same kernel (repair = 1) that runs the flagged queries again without a guess -- its workgroups
-    // leave at once when no flag is set.
-    uint32_t *prior_word;     // order key of the lower envelope of the k-th best scores selected so far (0: none yet)
-    uint32_t *repair_flags;   // [BATCH_MAX] written by the selector of the launch (0 / 1), read by the repair launch
-    uint32_t repair;          // 1: this IS the repair launch
-    float prior_beta, prior_rise;
-    // ---- workgroup-local thresholds (round 3; small matrices: shards of a strong-scaled run) -----------------------------------
-    // On a short partition (4-6 packets per wave and query) the device-wide exchange is slower than the query: a threshold takes
-    // three trips through global memory (~8 us) and the waves wait for it before they flush -- 10-11 us per query from 50k to
-    // 250k rows, whatever the size. local = 1: the threshold of a workgroup comes from its OWN waves, through LDS: every
-    // streaming wave publishes the largest (local = 1) or the second largest (local = 2) of the packet maxima it has seen (scores
-    // of distinct rows), and the smallest of the waves' words is the threshold -- as many rows of this workgroup reach it (local =
-    // 2: twice as many; for workgroups with few streaming waves). That is no proof that k
-    // rows of the MATRIX do, so it is checked like a guess: the servers record the largest local threshold in tau0_g, the
-    // selection verifies that k candidates reach it and flags the query for the repair launch otherwise (the host switches the
-    // mode on only where that is a once-in-thousands event: engine.hip).
+    // ---- workgroup-local thresholds, checked by the selection (kernels/local.hpp; round 3, reworked in round 4) ---------------
+    // local = 1 / 2: the threshold of a workgroup comes from its OWN waves, through LDS (a wave's word: the best / the second
+    // best packet maximum it has seen), it may start at what the workgroup delivered for its previous query (wg_prior), nothing
+    // is appended to global memory -- what does not fit a list or the workgroup's 8 slots is dropped under a recorded bound --, and
+    // every workgroup delivers one record per query (lslots / lused: set s at s strides). The selection (select_local) checks
+    // the records and reports a failed check in the launch's VERDICT word; the host switches the mode on only where a failure
+    // is a once-in-thousands event (engine.hip). 0: the device-wide exchange (exact on its own; larger matrices, repair
+    // phases, launches behind a closed gate).
     uint32_t local;
-    // Selector workgroups (round 3): blocks 0 .. n_selectors-1 select, selector s the queries s, s + n_selectors, ... One selection
-    // is a chain of four or five trips through global memory (7-10 us): a single selector is the slowest stage of the launch
-    // as soon as a query streams faster than that (below ~500k rows). Each has its own scratch for the general path.
+    // Selector workgroups: blocks 0 .. n_selectors-1 select, selector s the queries s, s + n_selectors, ... One selection is a
+    // chain of several trips through global memory: a single selector is the slowest stage of the launch as soon as a query
+    // streams faster than that (below ~500k rows).
     uint32_t n_selectors;
-    uint64_t scratch_stride;
-    // Local thresholds, carried over (wg_prior != NULL): a workgroup STARTS a query at local_beta x the score of the 8th best row it
-    // delivered for its previous one -- the ~98th percentile of its rows, far below the k-th best score of the matrix unless
-    // the queries change scale (checked like every local threshold). Without it every packet of a small matrix takes the
-    // candidate path (no threshold is tight before the query is over); with it one packet in five. wg_prior[b]: workgroup
-    // b's value between launches; prior_block: countdown set by a selection whose check failed -- no carried thresholds
-    // while it runs (a query that fails goes through the repair launch: that must stay an exception).
-    float *wg_prior;
-    uint32_t *prior_block;
+    float *wg_prior;        // [n_wg] what a workgroup's next query starts from, kept between launches (NULL: no carrying)
+    uint32_t *prior_block;  // [0..3] suspension of carried thresholds after a failed check (prior_block_update), [4..7] the gate
+    // The gate of the local thresholds: a launch of which a quarter or more failed its checks closes it for 8, 16, ... 1024 launches
+    // (the matrix keeps its best rows together: a workgroup's 8 slots cannot hold them, whatever the thresholds do); it counts down
+    // by one per launch, and 16 clean launches in a row halve the next closure. "Launches to go" is kept twice, prior_block[4] and
+    // [7]: a launch READS the copy of its parity (every workgroup, whenever it starts) and its boundary thread WRITES the other
+    // one -- the next launch's --, so that no word is read and written within one launch. [5]: length of a closure, [6]: clean run.
+    uint32_t gate_parity;
     float local_beta;
+    unsigned long long *lslots;  // records of local mode: [BATCH_MAX][n_wg][WG_SLOTS]
+    uint32_t *lused;             //                       [BATCH_MAX][n_wg]
+    uint32_t lslots_stride, lused_stride;
     // Pacing by rank (pace_quads != 0; see the note at the ticket add): the per-packet pause of the workgroups that led the field
     // in the previous query: pace_quads units of s_sleep(2) = 128 cycles, times pace_levels, pace_levels - 1, ..., 1 for the first,
     // second, ... eighth of the field (pace_levels = 3: three eighths pause).
-    // (An integrating variant -- every workgroup carries its own pause, one unit up after a query delivered in the first third,
-    //  one down after one in the second half, kept between launches -- was measured and is worse than no pacing, 19-20 us per
-    //  query at 1M rows: what helps is not equal finishing times but fewer requests in flight from whoever happens to lead.)
     uint32_t pace_quads, pace_levels;
+    // ---- the verdict of a launch's checks and the repair phase ------------------------------------------------------------------
+    // Every checked selection of a launch adds 1 | failed << (32 + q) to the launch's verdict word (one 64-bit atomic: the count of
+    // finished selections and the set of failed queries travel together). When the count reaches n_q the launch knows which
+    // queries to run again with the device-wide exchange: inside the same launch (inline_repair = 1: every workgroup waits for
+    // the verdict when it has finished its queries -- nobody has anything else to do, the launch cannot end before its last
+    // selection anyway -- and almost always leaves at once), or, on a GPU that cannot hold the whole grid at once, in a second
+    // launch of the same kernel (repair = 1) that reads the completed word. Round 3 launched that second kernel behind EVERY
+    // batch launch: 4-5 us per 32 queries for nothing.
+    unsigned long long *verdict;       // this launch's word
+    unsigned long long *verdict_next;  // the next launch's word: zeroed by this one
+    uint32_t inline_repair, repair;
+    // ---- overflow lists of the exact mode: ovf_lists of them (2), used round robin by the queries of a phase under flow control --
+    // A list must be able to hold EVERY row (x = 0 makes every row a candidate and the result must still be exact): 8 bytes per
+    // row. Round 3 kept one per query of a launch (256 MB at 1M rows, 2.6 GB at 10M); now query j of a phase uses list
+    // j % 4 and may append to it once the selections of its earlier users have finished (ovf_epoch[l] counts them; a wave
+    // checks only when it actually has something to append: staged rows go to the workgroup's slots first, but a wave whose
+    // private list fills up before the query's threshold has arrived -- routine from ~1M rows on -- appends, so the pipeline is
+    // four deep: with two lists the waves of query q stood waiting for the selection of q - 2, measured 30-60 us per query).
+    uint32_t *ovf_epoch;  // [ovf_lists] adjacent words
+    uint32_t ovf_lists;
+    __device__ __forceinline__ unsigned long long *ovf_list(uint32_t l) const { return ovf_cand0 + (size_t)l * ovf_stride; }
+    __device__ __forceinline__ uint32_t *ovf_list_count(uint32_t l) const { return ovf_count0 + (size_t)l * word_stride; }
     // ---- resident mode (RESIDENT = true; tkspmv_run with desc.impl = TKSPMV_IMPL_RESIDENT) -------------------------------
     // ONE launch serves queries as the host submits them: no launch, no copy engine, no stream synchronisation per query.
     // The host writes x into pinned memory and raises `request` (an epoch counter); the doorman -- wave 0 of the selector
@@ -131,25 +135,22 @@ template <int XCOLS, int C = 4>
 struct BatchLds {
     union {
         struct {
-            float x[2][XCOLS];                           // query vector, double-buffered by query parity
+            float x[2][XCOLS];                           // query vector, double-buffered by query parity (at LDS offset 0: the gathers OR a column's byte offset into the copy's base)
             uint2 cand[ListGeom<XCOLS>::CAND_CAP];       // private candidate lists of the streaming waves
         } w;
-        SelectShared sel;  // selector workgroup only
+        SelectShared sel;        // selector workgroups only: the exact mode's selection
+        LocalSelectShared lsel;  //                           local mode's
     } u;
     uint32_t misc[2][MISC_WORDS];                        // per query parity
     unsigned long long stg[2][8][STG_N];                 // survivors staged by the streaming waves
     uint32_t stg_cnt[2][8];
+    uint32_t ck[64];  // score keys of the staged rows while the server ranks them (local mode)
     uint32_t pace;  // pause per packet (bits 0-7: 0..3 units) and issue priority (bit 8) of the streaming waves in their next query, set by the server
+    uint32_t rq[BATCH_MAX + 2];  // repair phase: the flagged queries in order, [BATCH_MAX] their number; [BATCH_MAX + 1]: verdict hand-over
+    uint32_t epoch0[4];     // ovf_epoch as it stood when the phase began
+    uint32_t epoch_now[4];  // ... and as the server wave saw it last (what the streaming waves look at)
 #ifndef TKSPMV_ALTERNATE_PRIO
 #define TKSPMV_ALTERNATE_PRIO 1
-#endif
-// Pacing by rank (BatchParams::pace_quads, decided by the host): a workgroup among the first to deliver a query sleeps a little per
-// packet, one among the last gets the higher priority. With the device-wide exchange -- the cold phase of every query already
-// acts as a governor -- it costs 0.2-0.7 us per query; with workgroup-local thresholds carried from query to query (no cold
-// phase: every wave asks for all it can get, and the XCDs drift apart) it is what makes that mode the faster one at 1M rows:
-// 16.8 us per query against 19.1-19.9 unpaced and 18.0 with the device-wide exchange (tools/ab_rank.sh, one box).
-#ifndef TKSPMV_DUAL_EXCHANGE
-#define TKSPMV_DUAL_EXCHANGE 0
 #endif
 };
 
@@ -157,74 +158,137 @@ __device__ __forceinline__ uint32_t lds_load(const uint32_t *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+// One wave finalises a query of its workgroup in local mode: of the up to 8 x STG_N staged rows (lane l looks at entry l % 8 of
+// wave l / 8) the 8 best go to the workgroup's record -- all 8 slots are written: row SLOT_INVALID where there are fewer --, the
+// rest is dropped. With 8 rows or fewer (about every second query under carried thresholds) nothing is ranked: the rows go to the
+// slots as the lanes hold them. More: rank by counting on the score keys, ties by lane (every lane against all 64, 16 keys per
+// round of LDS reads). `used`: the order key above everything this workgroup dropped -- the thresholds it filtered with
+// (MISC_TAUKEY), what its waves dropped (MISC_BOUND), what did not fit the slots. `next_prior`: what its next query may start from,
+// in this query's score units (negative: nothing new to go by): the score of its 8th best row, else the threshold in force (it
+// let fewer than 8 rows through: high enough), a little lower.
+__device__ __forceinline__ void finalize_local_wave(const unsigned long long *stg, const uint32_t *stg_cnt, uint32_t *ck,
+                                                    const uint32_t *misc, uint32_t lane, float min_units, unsigned long long *slots,
+                                                    uint32_t &used, float &next_prior) {
+    const bool valid = (lane & 7u) < stg_cnt[lane >> 3];
+    const unsigned long long v = valid ? stg[lane] : 0ull;
+    const uint64_t bv = __ballot(valid);
+    const uint32_t n_valid = (uint32_t)__popcll(bv);
+    used = 0u;
+    next_prior = -1.0f;
+    if (n_valid <= WG_SLOTS) {  // (wave-uniform)
+        const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(bv >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bv, 0u));
+        if (valid) st_agent(slots + pos, v);
+        if (lane < WG_SLOTS && lane >= n_valid) st_agent(slots + lane, pack_cand(0u, SLOT_INVALID));
+        if (n_valid == WG_SLOTS) next_prior = -wave_max(valid ? -__uint_as_float((uint32_t)v) : -__builtin_huge_valf());  // the smallest of the 8
+    } else {
+        const uint32_t mk = valid ? order_key(__uint_as_float((uint32_t)v)) : 0u;
+        ck[lane] = mk;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (one wave: its LDS operations execute in order)
+        // (16 keys per round, their LDS reads issued back to back before the first compare: left to itself the scheduler keeps two
+        //  reads in flight and pays the LDS latency for each -- the server wave's chain per query is what bounds small matrices)
+        uint32_t r = 0;
+#pragma unroll 1
+        for (uint32_t j0 = 0; j0 < 64; j0 += 16) {
+            uint32_t o[16];
+#pragma unroll
+            for (uint32_t j = 0; j < 16; ++j) o[j] = ck[j0 + j];
+#pragma unroll
+            for (uint32_t j = 0; j < 16; ++j) r += (o[j] > mk || (o[j] == mk && j0 + j < lane)) ? 1u : 0u;
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 96, 0);
+        }
+        if (valid && r < WG_SLOTS) st_agent(slots + r, v);
+        const uint64_t b8 = __ballot(valid && r == WG_SLOTS);  // the best row that did not fit, one step up (a dropped row may tie with it)
+        if (b8 != 0ull) used = order_key(__uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, (int)__builtin_ctzll(b8)))) + 1u;
+        const uint64_t b7 = __ballot(valid && r == WG_SLOTS - 1u);
+        if (b7 != 0ull) next_prior = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, (int)__builtin_ctzll(b7)));
+    }
+    {
+        const uint32_t k_thr = __hip_atomic_load(&misc[MISC_TAUKEY], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const uint32_t k_drop = __hip_atomic_load(&misc[MISC_BOUND], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const uint32_t km = __builtin_amdgcn_readfirstlane(k_thr > k_drop ? k_thr : k_drop);
+        used = used > km ? used : km;
+    }
+    if (next_prior < 0.0f) {
+        const float t_end = __uint_as_float(__hip_atomic_load(&misc[MISC_TAU], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        if (t_end > min_units) next_prior = t_end * 0.95f;
+    }
+}
+
+// The two selections of the batch kernel as functions of their own (NOT inlined): inlined, their scalar state -- two parameter
+// blocks, a dozen pointers -- is spilled into vector registers that the whole kernel then reserves, the streaming loop included,
+// and the streaming waves have none to spare (80: two 576-thread workgroups per CU). Only selector workgroups ever call them.
+#ifndef TKSPMV_SELECT_INLINE
+#define TKSPMV_SELECT_INLINE 0
+#endif
+#if TKSPMV_SELECT_INLINE
+#define TKSPMV_SELECT_CALL __forceinline__
+#else
+#define TKSPMV_SELECT_CALL __attribute__((noinline))
+#endif
+template <class LDS>
+__device__ TKSPMV_SELECT_CALL bool batch_select_local(const LocalParams *G, const SelectParams *S, uint32_t n_stream, LDS *L, float out_scale,
+                                                             unsigned long long *stamps) {
+    return select_local(*G, *S, n_stream, threadIdx.x, blockDim.x, L->u.lsel, out_scale, stamps);
+}
+template <class LDS>
+__device__ TKSPMV_SELECT_CALL void batch_select_exact(const SelectParams *S, LDS *L, unsigned long long *stamps) {
+    select_body<false>(*S, threadIdx.x, blockDim.x, L->u.sel, 0u, stamps);
+}
+
+// The gate's bookkeeping (BatchParams::gate_parity), by ONE thread per launch: `failed` checks among the launch's n_q.
+__device__ __forceinline__ void gate_update(const BatchParams &B, uint32_t failed) {
+    uint32_t *g = B.prior_block;
+    const uint32_t cur = g[B.gate_parity ? 7 : 4];
+    uint32_t next = cur;
+    if (B.n_q >= 4u && 4u * failed >= B.n_q) {
+        const uint32_t len = g[5] < 8u ? 8u : (g[5] >= 512u ? 1024u : 2u * g[5]);
+        g[5] = len;
+        g[6] = 0u;
+        next = len;
+    } else if (cur != 0u) {
+        next = cur - 1u;
+    } else if (failed == 0u && ++g[6] >= 16u) {
+        g[6] = 0u;
+        if (g[5] > 8u) g[5] /= 2u;
+    }
+    g[B.gate_parity ? 4 : 7] = next;
+}
+
 // DBG = false (production): the tracing / statistics / ablation hooks of StreamParams (trace, dbg, dbg_flags) are compiled
 // out -- no per-packet compare of a tracing word or an ablation flag, and the scalar registers they held are free. The
 // engine launches the DBG = true instantiation only when TKSPMV_TRACE / TKSPMV_STATS / TKSPMV_DBG_FLAGS ask for it.
-template <int C, int XCOLS, int QM, bool DBG = false, bool RESIDENT = false>
-__global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg, const SelectParams SP0, const BatchParams B) {
-    StreamParams P0 = P0_arg;
-    if (!DBG) {
-        P0.trace = nullptr;
-        P0.dbg = nullptr;
-        P0.stamps = nullptr;
-        P0.dbg_flags = 0u;
-        P0.dbg_repeat = 0u;
-    }
+//
+// One PHASE of a launch: phase 0 = the launch's n_q queries in the mode the host chose (B.local, the gate permitting); phase 1 =
+// the queries whose check failed in phase 0 (L.rq), with the device-wide exchange. Returning from here ends the phase for the
+// calling wave; the kernel below puts the phases together.
+template <int C, int XCOLS, int QM, bool DBG, bool RESIDENT>
+__device__ __forceinline__ void batch_phase(const StreamParams &P0, const SelectParams &SP0, const BatchParams &B, const bool repair,
+                                            BatchLds<XCOLS, C> &L) {
     constexpr bool Q8 = QM == 1 || QM == 2;  // x staged as Q1.7 integers
     constexpr int VT = value_type_of(QM);
     constexpr int NBUF = C == 8 ? 2 : 3;  // packets of 8 entries per lane are twice as large: one ahead is as many bytes
     constexpr uint32_t WAVE_CAP = ListGeom<XCOLS>::WAVE_CAP;
-    __shared__ BatchLds<XCOLS, C> L;
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t nwaves = (blockDim.x >> 6) - 1u;  // streaming waves
     const bool is_server = (wave == nwaves);
-    // Repair launch: the flagged queries of the launch before, in order (every workgroup derives the same list from the same
-    // flags); none flagged: everybody leaves.
-    __shared__ uint32_t rq_lds[BATCH_MAX + 1];
-    const bool repair = !RESIDENT && B.repair != 0u;
-    if (repair) {
-        if (tid < 64u) {
-            const bool f = tid < B.n_q && __hip_atomic_load(&B.repair_flags[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
-            const uint64_t bm = __ballot(f);
-            if (f) rq_lds[__builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u))] = tid;
-            if (tid == 0) rq_lds[BATCH_MAX] = (uint32_t)__popcll(bm);
-        }
-        __syncthreads();
-        // The gate of the local thresholds (words 4, 5 behind prior_block; written HERE only -- between two batch launches, so
-        // every workgroup of the next one reads the same value): a launch of which a quarter or more failed its checks closes it
-        // for 8, 16, ... 1024 launches (the matrix keeps its best rows together: a workgroup's 8 slots cannot hold them, whatever
-        // the thresholds do); it counts down by one per launch, and 16 clean launches in a row halve the next closure.
-        if (blockIdx.x == 0u && tid == 0u && B.local != 0u && B.prior_block) {
-            uint32_t *gate = B.prior_block + 4;
-            const uint32_t failed = rq_lds[BATCH_MAX];
-            if (B.n_q >= 4u && 4u * failed >= B.n_q) {
-                const uint32_t len = gate[1] < 8u ? 8u : (gate[1] >= 512u ? 1024u : 2u * gate[1]);
-                gate[1] = len;
-                gate[0] = len;
-                gate[2] = 0u;
-            } else if (gate[0] != 0u) {
-                gate[0] -= 1u;
-            } else if (failed == 0u && ++gate[2] >= 16u) {
-                gate[2] = 0u;
-                if (gate[1] > 8u) gate[1] /= 2u;
-            }
-        }
-        if (rq_lds[BATCH_MAX] == 0u) return;
-    }
-    // (closed gate: this launch runs with the device-wide exchange, like a repair launch does)
-    const bool local_open = B.local != 0u && !(B.prior_block && B.prior_block[4] != 0u);
-    const uint32_t nq = RESIDENT ? 0xFFFFFFF0u : (repair ? rq_lds[BATCH_MAX] : B.n_q);
-    // query q of THIS launch in the launch's argument block (repair: the q-th flagged query of the launch before)
-    auto qx = [&](uint32_t q) __attribute__((always_inline)) -> uint32_t { return repair ? rq_lds[q] : q; };
+    // (closed gate: the launch runs with the device-wide exchange, like a repair phase does)
+    const bool local_open = B.local != 0u && !(B.prior_block && B.prior_block[B.gate_parity ? 7 : 4] != 0u);
+    const uint32_t nq = RESIDENT ? 0xFFFFFFF0u : (repair ? L.rq[BATCH_MAX] : B.n_q);
+    // query q of THIS phase in the launch's argument block (repair: the q-th flagged query)
+    auto qx = [&](uint32_t q) __attribute__((always_inline)) -> uint32_t { return repair ? L.rq[q] : q; };
     // exchange-state set / ticket counter of query q (resident: the sets are reused round robin -- one query is in flight)
     auto set_of = [&](uint32_t q) __attribute__((always_inline)) -> uint32_t { return RESIDENT ? q % (uint32_t)BATCH_MAX : qx(q); };
-    const bool use_prior = !RESIDENT && !repair && B.prior_word != nullptr;
     const bool local = !RESIDENT && !repair && local_open;
     const bool local_top1 = B.local == 1u;  // a wave's word is its best packet maximum (1) or its second best (2)
     const uint32_t pace_q = (RESIDENT || repair || !local_open) ? 0u : B.pace_quads;
+    // Overflow list of query q of this phase and the value its epoch word must show before anything may be appended: the
+    // selections of the list's earlier users in this phase have finished (L.epoch0: the words as the phase found them).
+    constexpr uint32_t n_lists = 4u;  // (BatchParams::ovf_lists: the engine allocates four)
+    auto list_of = [&](uint32_t q) __attribute__((always_inline)) -> uint32_t { return q % n_lists; };
 
     const uint32_t nsel = B.n_selectors;  // (>= 1)
     if (blockIdx.x < nsel) {
@@ -287,9 +351,9 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
             }
             if (tid == 0) {
                 uint32_t *t = B.tickets + 32u * set_of(q);
-                // Polled with a compare-and-swap (which also resets the counter for the next launch): atomics execute
-                // at the device-wide coherence point, whereas a load -- even agent-scope -- can keep hitting a stale
-                // copy of the line in this XCD's L2 (seen: 33 ms on an otherwise idle L2).
+                // Polled with a compare-and-swap (which also resets the counter for the next use): atomics execute at the
+                // device-wide coherence point, whereas a load -- even agent-scope -- can keep hitting a stale copy of the line
+                // in this XCD's L2 (seen: 33 ms on an otherwise idle L2).
                 // (the last query's selection is the launch's tail: poll it faster)
                 while (atomicCAS(t, n_stream, 0u) != n_stream) {
                     if (RESIDENT || local || q + nsel >= nq) __builtin_amdgcn_s_sleep(4);
@@ -301,59 +365,78 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
             }
             __syncthreads();
             SelectParams S = SP0;
-            S.wg_cand = B.wg_cand(set_of(q));
-            S.ovf_cand = B.ovf_cand(set_of(q));
-            S.ovf_count = B.ovf_count(set_of(q));
-            S.gmax = B.gmax(set_of(q));
-            S.tau_g = B.tau_g(set_of(q));
-            S.scratch = B.scratch + (size_t)blockIdx.x * B.scratch_stride;
-            S.unit_inv_in = B.unit_inv(set_of(q));
             S.out_idx = B.io[RESIDENT ? 0u : qx(q)].out_idx;
             S.out_val = B.io[RESIDENT ? 0u : qx(q)].out_val;
-            if (!RESIDENT && B.repair_flags) {
-                S.tau0_g = B.tau_g(set_of(q)) + 32;  // (the set's second 128-byte line)
-                S.repair_flag = repair ? nullptr : &B.repair_flags[q];
-                S.prior_word = B.prior_word;
-                S.prior_rise = B.prior_rise;
-                S.local_thr = local ? 1u : 0u;
-                S.prior_block = ((local && B.wg_prior) || use_prior) ? B.prior_block : nullptr;
+            if (local) {
+                // the workgroups' records of this query, checked: a failed check goes into the launch's verdict
+                LocalParams G{};
+                G.slots = B.lslots + (size_t)set_of(q) * B.lslots_stride;
+                G.used = B.lused + (size_t)set_of(q) * B.lused_stride;
+                G.prior_block = B.wg_prior ? B.prior_block : nullptr;
+                G.shared_bookkeeping = 1u;  // (several selectors at once)
+                S.host_out = nullptr;
+                const float out_scale = __hip_atomic_load(B.unit_inv(set_of(q)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (tr_sel && tid == 0) P0.trace[10] = __builtin_amdgcn_s_memrealtime();
+                const bool bad = batch_select_local(&G, &S, n_stream, &L, out_scale, tr_sel ? P0.trace + 11 : nullptr);
+                __syncthreads();
+                if (tid == 0 && B.verdict)
+                    (void)__hip_atomic_fetch_add(B.verdict, 1ull | ((bad ? 1ull : 0ull) << (32u + q)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                const uint32_t l = list_of(q);
+                S.wg_cand = B.wg_cand(set_of(q));
+                S.ovf_cand = B.ovf_list(l);
+                S.ovf_count = B.ovf_list_count(l);
+                S.gmax = B.gmax(set_of(q));
+                S.tau_g = B.tau_g(set_of(q));
+                S.unit_inv_in = B.unit_inv(set_of(q));
+                // The sets and lists are reused INSIDE a launch (a repair phase behind phase 0, the lists round robin, the resident
+                // kernel): the resets at the end of a selection are written through and drained before anybody is told.
+                S.wt_reset = 1u;
+                if (RESIDENT) {
+                    S.host_epoch = B.epoch0 + q + 1u;  // (host_out comes with SP0)
+                    S.t_seen = t_seen;                 // (wave 0 holds it; thread 0 reports the query's device time)
+                }
+                // (timing aid, TKSPMV_DBG_FLAGS & 16: the set keeps its final threshold, and the next query that uses the set
+                //  starts from it -- exact when the same vector comes back, tools/ablate_probe.py)
+                const uint32_t keep_tau = (DBG && (P0.dbg_flags & 16u)) ? __hip_atomic_load(S.tau_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                if (tr_sel && tid == 0) P0.trace[10] = __builtin_amdgcn_s_memrealtime();
+                if (RESIDENT) select_body<false>(S, tid, blockDim.x, L.u.sel, 0u, nullptr);  // (the resident kernel has one selection and no repair phase: inlined as it always was)
+                else batch_select_exact(&S, &L, tr_sel ? P0.trace + 8 : nullptr);
+                // the list is free for its next user: its count was reset (written through) and drained above
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0) (void)__hip_atomic_fetch_add(B.ovf_epoch + l, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (DBG && (P0.dbg_flags & 16u) && tid == 0) *S.tau_g = keep_tau;
             }
-            if (RESIDENT) {
-                S.host_epoch = B.epoch0 + q + 1u;  // (host_out comes with SP0)
-                S.wt_reset = 1u;                   // the sets are reused within this launch: resets must be written through
-                S.t_seen = t_seen;                 // (wave 0 holds it; thread 0 reports the query's device time)
-            }
-            // (timing aid, TKSPMV_DBG_FLAGS & 16: the set keeps its final threshold, and the next query that uses the set
-            //  starts from it -- exact when the same vector comes back, tools/ablate_probe.py: what a threshold that is
-            //  there from a query's first packet would be worth: 0.7 us of 20.5 on BASELINE configs[1])
-            const uint32_t keep_tau = (DBG && (P0.dbg_flags & 16u)) ? __hip_atomic_load(S.tau_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-            if (tr_sel && tid == 0) P0.trace[10] = __builtin_amdgcn_s_memrealtime();
-            select_body<!RESIDENT>(S, tid, blockDim.x, L.u.sel, 0u, tr_sel ? P0.trace + 8 : nullptr);
-            __syncthreads();
             if (tr_sel && tid == 0) P0.trace[15] = __builtin_amdgcn_s_memrealtime();
-            if (DBG && (P0.dbg_flags & 16u) && tid == 0) *S.tau_g = keep_tau;
             if (P0.trace && tid == 0 && q < 8u) P0.trace[q] = __builtin_amdgcn_s_memrealtime();
         }
+        // (a launch behind a closed gate makes no checks and has no verdict: its last act is to count the closure down -- every
+        //  streaming workgroup has read the gate by now: this selector has seen all their tickets)
+        if (!RESIDENT && !repair && blockIdx.x == 0u && tid == 0u && B.local != 0u && !local_open && B.inline_repair != 0u) gate_update(B, 0u);
         return;
     }
     const uint32_t bid = blockIdx.x - nsel, n_wg = gridDim.x - nsel;
-    // traced queries: the first, the middle and the last of the batch
 // traced queries: the first, the middle one and (batches of 8 or more) the one after it, else the last
 #define TRSLOT(q) ((q) == 0u ? 0u : ((q) == nq / 2u ? 1u : ((q) == (nq >= 8u ? nq / 2u + 1u : nq - 1u) ? 2u : 9u)))
     unsigned long long *trw = P0.trace ? P0.trace + ((size_t)blockIdx.x * 9u + wave) * 8u : nullptr;
-    if (trw && lane == 0) trw[0] = __builtin_amdgcn_s_memrealtime();
+    if (trw && lane == 0 && !repair) trw[0] = __builtin_amdgcn_s_memrealtime();
     if (tid < 2u * MISC_WORDS) (&L.misc[0][0])[tid] = 0u;
     if (tid < 16u) (&L.stg_cnt[0][0])[tid] = 0u;
     if (tid == 0u) L.pace = 0u;
+    if (tid < 4u) {
+        const uint32_t e = tid < n_lists ? __hip_atomic_load(B.ovf_epoch + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        L.epoch0[tid] = e;
+        L.epoch_now[tid] = e;
+    }
     __syncthreads();
     const uint32_t grp_local = is_server ? 0u : wave * P0.gpw / nwaves;
     const bool publishes = !local && (bid * P0.gpw + grp_local) < P0.n_groups_pub;  // (local: the waves publish by themselves)
     const bool reducer = bid < P0.n_reducers;
     // Streaming waves that own a partition (wave w streams partition w * n_wg + bid): only they take part in the
-    // per-query protocol. Waves without one leave at once -- spinning at stream priority on every query's x flag, six of
-    // them per workgroup on a small matrix, they starved the server wave (585 us per query at 50k rows).
-    // (the server counts them with ONE load instruction -- lane w looks at wave w's partition; a loop of eight dependent
-    //  scalar loads here cost every launch 4-5 us before its first x was staged)
+    // per-query protocol. Waves without one leave the phase at once -- spinning at stream priority on every query's x flag, six
+    // of them per workgroup on a small matrix, they starved the server wave (585 us per query at 50k rows).
+    // (the server counts them with ONE load instruction -- lane w looks at wave w's partition)
     uint32_t n_active = 0;
     bool wave_has = false;  // (lane w: wave w streams a partition -- the server counts them, local thresholds need to know who takes part)
     if (is_server || local) {
@@ -361,17 +444,23 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
         wave_has = lane < nwaves && pw < P0.n_parts && (P0.uni_ppp != 0u || P0.part_count[pw] != 0u);
         n_active = (uint32_t)__popcll(__ballot(wave_has));
     }
+    // what the epoch word of query q's overflow list must show before anything is appended to the list
+    auto ovf_need = [&](uint32_t q) __attribute__((always_inline)) -> uint32_t { return L.epoch0[list_of(q)] + q / n_lists; };
+    // (the streaming waves look at the server wave's LDS copy of the epoch words, refreshed once per turn of its loop)
+    auto ovf_wait = [&](uint32_t q) __attribute__((always_inline)) {
+        const uint32_t need = ovf_need(q);
+        while (__builtin_amdgcn_readfirstlane(lds_load(&L.epoch_now[list_of(q)])) != need) {
+            if (is_server && lane < n_lists) L.epoch_now[lane] = __hip_atomic_load(B.ovf_epoch + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_s_sleep(8);
+        }
+    };
 
     if (is_server) {
         // ---- server wave: x staging, threshold exchange of the newest query, finalisation of the oldest -------
         // The reducers' search must not starve: in a batch the streaming waves (priority 2) never pause, and a reducer at
         // the default priority got ONE pass per query (traced), i.e. the threshold arrived when the query was over.
-#if TKSPMV_ALL_SERVERS_PRIO
-        __builtin_amdgcn_s_setprio(3);
-#else
         // (local thresholds: the query is short and the workgroup's waves wait for this wave's next x: it must not queue behind them)
         if (reducer || local) __builtin_amdgcn_s_setprio(3);
-#endif
         uint32_t staged = 0u, tail = 0u;
         const bool carry_local = local && B.wg_prior != nullptr;
         float wg_prior = carry_local ? B.wg_prior[bid] : 0.0f;  // (reported-score units; 0: none)
@@ -402,9 +491,7 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
             if (staged < nq && staged < published && staged - tail < 2u) {
                 const uint32_t par = staged & 1u;
                 const float *xg = RESIDENT ? reinterpret_cast<const float *>(B.xr + (size_t)par * XCOLS) : B.io[qx(staged)].x;
-                // the guess for this query (issued here, used below: its round trip overlaps the loads of x)
-                const uint32_t prior_key = use_prior ? __hip_atomic_load(B.prior_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-                const uint32_t prior_blocked = (carry_local || use_prior) ? __hip_atomic_load(B.prior_block, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1u;
+                const uint32_t prior_blocked = carry_local ? __hip_atomic_load(B.prior_block, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1u;
                 // (resident: the two device-side copies of x are rewritten in place query after query; they live in fine-
                 //  grained memory and are read with agent-scope loads, so no cache can serve a previous query's x)
                 auto x_at = [&](uint32_t i) __attribute__((always_inline)) -> float {
@@ -469,14 +556,6 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
                 if (lane < 8u) L.stg_cnt[par][lane] = 0u;
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                 float tau_init = min_units_q[par];
-                if (prior_key != 0u && prior_blocked == 0u) {
-                    const float t0 = key_to_float(prior_key) * unit_scale * B.prior_beta;  // (reported score -> this query's units)
-                    if (t0 > 0.0f && t0 > tau_init) {
-                        tau_init = t0;
-                        if (lane == 0)
-                            (void)__hip_atomic_fetch_max(B.tau_g(set_of(staged)) + 32, order_key(t0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                }
                 uint32_t carried_key = 0u;
                 if (prior_blocked == 0u && wg_prior > 0.0f) {
                     const float t0 = wg_prior * unit_scale * B.local_beta;
@@ -504,20 +583,14 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
             if (local) {
                 // (workgroup-local thresholds are formed by the streaming waves themselves, in LDS: nothing to do here)
             } else if (P0.n_sets != 0u && !(P0.dbg_flags & 4u)) {
+                // (the overflow lists' epoch words for the streaming waves: loaded with this turn's exchange traffic, stored below)
+                const uint32_t e_now = lane < n_lists ? __hip_atomic_load(B.ovf_epoch + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
                 uint32_t hq = tail;
                 if (tail + 1u < staged &&
                     2u * __builtin_amdgcn_readfirstlane(lds_load(&L.misc[tail & 1u][MISC_DONE])) >= n_active)
                     hq = tail + 1u;
-#if TKSPMV_DUAL_EXCHANGE
-                // (experiment: both queries in flight are served in every round -- a wave that runs ahead of its workgroup gets its
-                //  query's threshold as soon as the other workgroups have produced one)
-                const uint32_t sq_first = tail, sq_last = tail + 1u < staged ? tail + 1u : tail;
-                (void)hq;
-                for (uint32_t sq = sq_first; sq <= sq_last; ++sq) {
-#else
                 {
                     const uint32_t sq = hq;
-#endif
                     StreamParams P = P0;
                     P.gmax = B.gmax(set_of(sq));
                     P.tau_g = B.tau_g(set_of(sq));
@@ -535,6 +608,7 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
                         const uint32_t kx = __hip_atomic_load(P.tau_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         t = kx ? key_to_float(kx) : min_units;
                     }
+                    if (lane < n_lists) L.epoch_now[lane] = e_now;
                     if (lane == 0) {
                         const float cur_tau = __uint_as_float(lds_load(&mp[MISC_TAU]));
                         if (t > cur_tau)
@@ -555,72 +629,40 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
                     asm volatile("" ::: "memory");
                     StreamParams P = P0;
                     P.gmax = B.gmax(set_of(tail));
-                    if (local) {
-                        // the largest threshold this workgroup's waves can have used goes on record (what they dropped lies below it)
-                        const uint32_t k_used = lds_load(&mp[MISC_TAUKEY]);
-                        if (lane == 0 && k_used != 0u)
-                            (void)__hip_atomic_fetch_max(B.tau_g(set_of(tail)) + 32, k_used, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    } else if (P0.n_sets != 0u) publish_group_max(P, bid, lane, mp);  // complete maxima (fire and forget)
                     if (P0.dbg && lane == 0) {  // TKSPMV_STATS=1
                         atomicAdd(&P0.dbg[0], (unsigned long long)mp[MISC_SLOW_CNT]);
                         atomicAdd(&P0.dbg[1], (unsigned long long)mp[MISC_CAND_CNT]);
                         atomicAdd(&P0.dbg[5], (unsigned long long)mp[MISC_DBG_WAIT_TICKS]);
                         atomicAdd(&P0.dbg[6], (unsigned long long)mp[MISC_DBG_WAITS]);
-                        atomicAdd(&P0.dbg[7], (unsigned long long)mp[MISC_DBG_REDO_PK]);
-                        atomicAdd(&P0.dbg[8], (unsigned long long)mp[MISC_DBG_REDO_WV]);
                     }
-                    // lane l copies entry (l % 8) of wave (l / 8): the first goes to the wave's slot, others to the
-                    // query's overflow list
-                    const uint32_t w = lane >> 3, e = lane & 7u;
-                    const uint32_t cnt = L.stg_cnt[tp][w];
-                    bool have = e < cnt;
-                    const unsigned long long v = have ? L.stg[tp][w][e] : 0ull;
                     if (local) {
-                        // Local thresholds leave 10-30 rows per workgroup: its eight best go to its slots IN ORDER (slot 0 = the
-                        // workgroup's best row: the selection's first cut builds on those), the rest is dropped -- and the best of
-                        // the dropped goes on record as a threshold used, one step up (a dropped row may TIE with it).
-                        const float f = have ? __uint_as_float((uint32_t)v) : -__builtin_huge_valf();
-                        bool taken = !have;
-                        float kept_last = 0.0f;
-                        uint32_t n_kept = 0u;
-#pragma unroll 1
-                        for (uint32_t r = 0; r <= WG_SLOTS; ++r) {
-                            const float mx = wave_max(taken ? -__builtin_huge_valf() : f);
-                            const uint64_t bm = __ballot(!taken && f == mx);
-                            if (bm == 0ull) break;  // fewer entries than slots
-                            const uint32_t first = (uint32_t)__builtin_ctzll(bm);
-                            if (r == WG_SLOTS) {
-                                if (lane == 0)
-                                    (void)__hip_atomic_fetch_max(B.tau_g(set_of(tail)) + 32, order_key(mx) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            } else {
-                                if (lane == first) {
-                                    st_agent(B.wg_cand(set_of(tail)) + (size_t)bid * WG_SLOTS + r, v);
-                                    taken = true;
-                                }
-                                kept_last = mx;
-                                ++n_kept;
-                            }
+                        // the workgroup's record of this query: its 8 best staged rows in order + what everything dropped lay below
+                        uint32_t used = 0u;
+                        float next_prior = -1.0f;
+                        finalize_local_wave(&L.stg[tp][0][0], L.stg_cnt[tp], L.ck, mp, lane, min_units_q[tp],
+                                            B.lslots + (size_t)set_of(tail) * B.lslots_stride + (size_t)bid * WG_SLOTS, used, next_prior);
+                        if (lane == 8u)
+                            __hip_atomic_store(B.lused + (size_t)set_of(tail) * B.lused_stride + bid, used, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (carry_local && next_prior >= 0.0f) wg_prior = next_prior * inv_unit_q[tp];
+                    } else {
+                        if (P0.n_sets != 0u) publish_group_max(P, bid, lane, mp);  // complete maxima (fire and forget)
+                        // lane l looks at entry (l % 8) of wave (l / 8): the staged rows go to the workgroup's 8 slots, in any
+                        // order; only a ninth and later ones go to the query's overflow list (under its flow control)
+                        const uint32_t w = lane >> 3, e = lane & 7u;
+                        const bool have = e < L.stg_cnt[tp][w];
+                        const unsigned long long v = have ? L.stg[tp][w][e] : 0ull;
+                        const uint64_t bh = __ballot(have);
+                        const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(bh >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bh, 0u));
+                        const uint32_t n_have = (uint32_t)__popcll(bh);
+                        if (have && pos < WG_SLOTS) st_agent(B.wg_cand(set_of(tail)) + (size_t)bid * WG_SLOTS + pos, v);
+                        if (n_have > WG_SLOTS) {
+                            ovf_wait(tail);
+                            uint32_t gbase = 0u;
+                            if (lane == 0) gbase = atomicAdd(B.ovf_list_count(list_of(tail)), n_have - WG_SLOTS);
+                            gbase = __builtin_amdgcn_readfirstlane(gbase);
+                            const uint32_t gp = gbase + pos - WG_SLOTS;
+                            if (have && pos >= WG_SLOTS && gp < P0.ovf_cap) st_agent(&B.ovf_list(list_of(tail))[gp], v);
                         }
-                        // what the next queries of this workgroup start from: the score of the last row kept when the slots filled
-                        // up; else the threshold in force (it let fewer than 8 rows through: high enough), a little lower
-                        if (carry_local) {
-                            const float t_end = __uint_as_float(lds_load(&mp[MISC_TAU]));
-                            if (n_kept == WG_SLOTS) wg_prior = kept_last * inv_unit_q[tp];
-                            else if (t_end > min_units_q[tp]) wg_prior = t_end * inv_unit_q[tp] * 0.95f;
-                        }
-                        have = false;  // (nothing is left for the copy below)
-                    }
-                    const bool extra = have && e > 0u;
-                    const uint64_t bm = __ballot(extra);
-                    uint32_t gbase = 0u;
-                    if (bm) {
-                        if (lane == 0) gbase = atomicAdd(B.ovf_count(set_of(tail)), (uint32_t)__popcll(bm));
-                        gbase = __builtin_amdgcn_readfirstlane(gbase);
-                    }
-                    if (have && e == 0u) st_agent(B.wg_cand(set_of(tail)) + (size_t)bid * WG_SLOTS + w, v);
-                    if (extra) {
-                        const uint32_t gp = gbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
-                        if (gp < P0.ovf_cap) st_agent(&B.ovf_cand(set_of(tail))[gp], v);
                     }
                     if (bid == 0u && lane == 0)
                         __hip_atomic_store(B.unit_inv(set_of(tail)), inv_unit_q[tp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -633,7 +675,7 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
                     // CU do not share it evenly (the older one wins the arbitration), and the less a wave does per packet the
                     // more that shows: with the candidate path switched off the median wave streams a query in 11.5 us while a
                     // tenth of the workgroups take 26-28 us, and the launch waits for them (tools/batch_trace.py). The rank is
-                    // the feedback: an early workgroup lowers the issue priority of its streaming waves, a late one raises it.
+                    // the feedback: an early workgroup pauses a little per packet, a late one gets the higher issue priority.
                     if (pace_q != 0u) {
                         uint32_t rank = 0u;
                         if (lane == 0) rank = __hip_atomic_fetch_add(B.tickets + 32u * set_of(tail), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -665,19 +707,6 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
     }
 
     // ---- streaming waves ---------------------------------------------------------------------------------------
-    // Cold start of a query (round 3). The threshold of a query arrives ~8 us after its first packets have been reduced --
-    // a third of a 19-packet partition -- and until then every finished row used to be appended to the wave's list (35 % of all
-    // packets took the candidate path, ~100 vector instructions each, and 295 k rows per query were appended and thrown
-    // away again). Now a wave that has no threshold yet only keeps, per lane, the largest trigger value it has seen (one
-    // v_max per packet: the lane's CHAMPION, an upper bound of every row it has finished in this query so far) and feeds the
-    // exchange with the exact maxima of its first EXACT_PK packets. Three packets before the end of its partition -- the
-    // next request will be the first one past it -- the wave compares its champions with the threshold as it then stands
-    // (waiting for one, bounded, if there is none yet): only if some champion reaches it (1-2 % of the waves) can a row of
-    // the cold packets belong to the result, and the wave REDOES those packets after its last one -- requested through the
-    // same prefetch ring, reduced again from a zero carry (a partition starts on a row boundary) and judged against the
-    // threshold like any other packet. Rows are never lost: a champion bounds every row its lane finished in the cold
-    // packets, so "no champion reaches tau" proves that none of those rows does. Nothing is stored per packet (the deferred
-    // packets' 26 KB of LDS are gone) and nothing is appended before a threshold exists.
     __builtin_amdgcn_s_setprio(TKSPMV_STREAM_PRIO);
     const uint32_t part = wave * n_wg + bid;
     uint32_t p0 = 0, np = 0;
@@ -686,47 +715,33 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
     if (np == 0u) return;  // no partition (n_active does not count this wave)
     static_assert(C == 4 || C == 8, "the batch kernel is built for 4 or 8 entries per lane");
     constexpr bool INT = int_sums<QM>();
-    constexpr uint32_t EXACT_PK = 2u;  // packets per wave and query whose exact row maxima start the threshold exchange
-    // champions need a threshold that can form and a decision point inside the partition (shorter partitions -- the odd
-    // trailing one: the packer fills at least 4 packets -- put every row through the candidate path)
-#ifndef TKSPMV_CHAMPIONS
-#define TKSPMV_CHAMPIONS 0
-#endif
-    const bool champ_ok = TKSPMV_CHAMPIONS && P0.n_sets != 0u && P0.tau_possible != 0u && np >= 3u && !(DBG && (P0.dbg_flags & 64u));
 
     Pkt<C, VT> buf[NBUF];
     uint32_t rbs[NBUF];
-    // Requests run NBUF - 1 packets ahead of the reduction, through the segments of the launch in order: the np packets of
-    // query 0, its redo packets if the reduction side has asked for them by then (redo_len, set while packet np - 3 is being
-    // reduced: the request side has just asked for packet np - 1 and turns to the next segment with its NEXT request), query
-    // 1, ... Two running pointers and a down-counter per request; past the end of the launch the last packet is requested
-    // again (a fixed number of younger loads lets the compiler wait with a counted vmcnt).
+    // Requests run NBUF - 1 packets ahead of the reduction, through the queries of the phase in order. Two running pointers and a
+    // down-counter per request; past the end of the phase the last packet is requested again (a fixed number of younger loads
+    // lets the compiler wait with a counted vmcnt).
     auto stream_of = [&](uint32_t q) __attribute__((always_inline)) -> const uint8_t * {
         return RESIDENT ? B.replicas[q % B.n_replicas] : B.io[qx(q)].packets;
     };
     const size_t part_off = (size_t)p0 * P0.packet_bytes;
     const uint8_t *pk_a = stream_of(0u) + part_off;
     const uint32_t *row_a = P0.pkt_row + p0;
-    uint32_t qa = 0u, req_left = np, redo_len = 0u;
+    uint32_t qa = 0u, req_left = np;
     bool req_done = false;
 #define TKSPMV_REQUEST(dst, rb_dst)                                                                                   \
     do {                                                                                                              \
-        if (req_left == 0u && !req_done) { /* the previous request was the last of its segment */                      \
-            if (redo_len != 0u) {                                                                                     \
-                req_left = redo_len;                                                                                  \
-                redo_len = 0u;                                                                                        \
-            } else {                                                                                                  \
-                ++qa;                                                                                                 \
-                if (!RESIDENT && qa == nq) req_done = true;                                                           \
-                else req_left = np;                                                                                   \
-            }                                                                                                         \
-            if (!req_done) {                                                                                          \
+        if (req_left == 0u && !req_done) { /* the previous request was the last of its query */                        \
+            ++qa;                                                                                                     \
+            if (!RESIDENT && qa == nq) req_done = true;                                                               \
+            else {                                                                                                    \
+                req_left = np;                                                                                        \
                 pk_a = stream_of(qa) + part_off;                                                                      \
                 row_a = P0.pkt_row + p0;                                                                              \
             }                                                                                                         \
         }                                                                                                             \
         load_packet<C, VT>(pk_a, lane, dst);                                                                          \
-        rb_dst = scalar_load(row_a);                                                                                              \
+        rb_dst = scalar_load(row_a);                                                                                  \
         if (!req_done && --req_left != 0u) {                                                                          \
             pk_a += P0.packet_bytes;                                                                                  \
             ++row_a;                                                                                                  \
@@ -736,12 +751,7 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
     for (int u = 0; u < NBUF - 1; ++u) TKSPMV_REQUEST(buf[u], rbs[u]);
     rbs[NBUF - 1] = 0u;
 
-    uint32_t qc = 0u, jc = 0u, seg_n = np;  // query / packet of the segment being reduced / its length
-    bool in_redo = false;                   // the segment is the redo of the query's cold packets
-    bool cold = false, decided = false;     // no threshold has been seen in this query yet / the redo decision has been taken
-    bool redo_owed = false;                 // ... and it was "redo": the query's segment is followed by its cold packets again
-    uint32_t ncold = 0u;                    // packets of this query reduced without a threshold
-    float champ = -__builtin_huge_valf();   // per lane: upper bound of the rows finished in those packets
+    uint32_t qc = 0u, jc = 0u;  // query / packet being reduced
     float carry = 0.0f, min_units = 0.0f;
     float top1 = 0.0f, top2 = 0.0f;  // local thresholds: the two largest packet maxima of this wave in the current query
     uint32_t wcnt = 0u;
@@ -758,36 +768,34 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
             const Pkt<C, VT> &cur = buf[u];
             const uint32_t rb_cur = rbs[u];
             TKSPMV_REQUEST(buf[(u + NBUF - 1) % NBUF], rbs[(u + NBUF - 1) % NBUF]);
-            if (jc == 0u) {
-                carry = 0.0f;  // (a partition starts on a row boundary; so does its redo)
-                if (!in_redo) {  // a new query starts: its x must have been staged
-                    mp = L.misc[qc & 1u];
-                    xbase = lds_addr_of(L.u.w.x[qc & 1u]);
-                    for (;;) {
-                        const uint32_t xr_ = lds_load(&mp[MISC_XREADY]);
-                        if (xr_ == qc + 1u) break;
-                        if (RESIDENT && xr_ == RESIDENT_QUIT) return;  // the kernel is leaving (host request or idle timeout)
-                        __builtin_amdgcn_s_sleep(2);
-                    }
-                    asm volatile("" ::: "memory");
-                    min_units = __uint_as_float(lds_load(&mp[MISC_MINU]));
-                    if (trw && lane == 0 && TRSLOT(qc) < 3u) trw[1 + TRSLOT(qc)] = __builtin_amdgcn_s_memrealtime();
-                    P.ovf_cand = B.ovf_cand(set_of(qc));
-                    P.ovf_count = B.ovf_count(set_of(qc));
-                    wcnt = 0u;
-                    top1 = top2 = -__builtin_huge_valf();
-                    waited = false;
-                    cold = champ_ok;
-                    decided = false;
-                    redo_owed = false;
-                    ncold = 0u;
-                    champ = -__builtin_huge_valf();
-                    if (pace_q != 0u) {
-                        const uint32_t pw = __builtin_amdgcn_readfirstlane(lds_load(&L.pace));
-                        pace = pw & 255u;
-                        if (pw & 256u) __builtin_amdgcn_s_setprio(2);
-                        else __builtin_amdgcn_s_setprio(1);
-                    } else {
+            if (jc == 0u) {  // a new query starts: its x must have been staged
+                carry = 0.0f;  // (a partition starts on a row boundary)
+                mp = L.misc[qc & 1u];
+                xbase = lds_addr_of(L.u.w.x[qc & 1u]);
+                for (;;) {
+                    const uint32_t xr_ = lds_load(&mp[MISC_XREADY]);
+                    if (xr_ == qc + 1u) break;
+                    if (RESIDENT && xr_ == RESIDENT_QUIT) return;  // the kernel is leaving (host request or idle timeout)
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                asm volatile("" ::: "memory");
+                min_units = __uint_as_float(lds_load(&mp[MISC_MINU]));
+                if (trw && lane == 0 && TRSLOT(qc) < 3u) trw[1 + TRSLOT(qc)] = __builtin_amdgcn_s_memrealtime();
+                if (!local) {  // (local mode appends nothing to global memory)
+                    P.ovf_cand = B.ovf_list(list_of(qc));
+                    P.ovf_count = B.ovf_list_count(list_of(qc));
+                    P.ovf_gate_lds = lds_addr_of(&L.epoch_now[list_of(qc)]);
+                    P.ovf_need = ovf_need(qc);
+                }
+                wcnt = 0u;
+                top1 = top2 = -__builtin_huge_valf();
+                waited = false;
+                if (pace_q != 0u) {
+                    const uint32_t pw = __builtin_amdgcn_readfirstlane(lds_load(&L.pace));
+                    pace = pw & 255u;
+                    if (pw & 256u) __builtin_amdgcn_s_setprio(2);
+                    else __builtin_amdgcn_s_setprio(1);
+                } else {
 #if TKSPMV_ALTERNATE_PRIO
                     // The two workgroups of a CU do not share it evenly at equal priority: the older one wins the arbitration
                     // (traced over a 32-query launch: 17.2 against 21.5 us per query), runs ahead, finishes early and leaves
@@ -797,7 +805,6 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
                     if (((qc ^ (bid >= n_wg / 2u ? 1u : 0u)) & 1u) != 0u) __builtin_amdgcn_s_setprio(TKSPMV_STREAM_PRIO);
                     else __builtin_amdgcn_s_setprio(TKSPMV_STREAM_PRIO - 1);
 #endif
-                    }
                 }
             }
             // a workgroup ahead of the field yields: fewer requests from it, more bandwidth for the XCDs that lag
@@ -807,18 +814,7 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
             const float tau = __uint_as_float(tau_bits);
             const Reduced<C> Rd = reduce_packet<C, QM>(cur, carry, xbase, P0.fixed_mask);
             const float trig = trigger_of<C, INT>(Rd);
-            if (cold && tau_bits != __float_as_uint(min_units)) cold = false;  // the threshold has arrived: this packet is judged
-            if (cold) {
-                champ = max2(champ, trig);
-                ++ncold;
-                if (jc < EXACT_PK) {  // exact maxima (scores of distinct rows) start the exchange
-                    const RowSums<C> R = expand<C, INT>(Rd, packet_flags<C, QM>(cur));
-                    const float wmax = wave_max(lane_best<C, QM>(R));
-                    if (lane == 0 && publishes && wmax >= min_units)
-                        (void)__hip_atomic_fetch_max(&mp[MISC_GRPMAX + grp_local], order_key(wmax), __ATOMIC_RELAXED,
-                                                     __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-            } else if (__any(trig >= tau) && !(P0.dbg_flags & 2u)) {
+            if (__any(trig >= tau) && !(P0.dbg_flags & 2u)) {
                 float tau_now = tau;
                 // Long partitions only (more rows per wave and query than its list holds: from ~1.5M rows on 256 CUs). A
                 // wave that runs ahead of its workgroup's exchange has no threshold yet: every row passes, and once the
@@ -835,7 +831,8 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
                 }
                 if (tau_now == tau || __any(trig >= tau_now)) {
                     const RowSums<C> R = expand<C, INT>(Rd, packet_flags<C, QM>(cur));
-                    const float wm = offer_candidates<C, QM, WAVE_CAP>(P, R, rb_cur, tau_now, lane, grp_local, publishes, wcand, wcnt, mp);
+                    // (local: what does not fit the list is dropped under a recorded bound, not appended to global memory)
+                    const float wm = offer_candidates<C, QM, WAVE_CAP>(P, R, rb_cur, tau_now, lane, grp_local, publishes, wcand, wcnt, mp, local);
                     if (local && wm > top2 && wm >= min_units) {
                         // (a wave with a single packet has no second maximum: it stands for one row)
                         top2 = wm > top1 ? top1 : wm;
@@ -861,68 +858,35 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
                     }
                 }
             }
-            if (champ_ok && !decided && jc + 3u >= np) {  // (jc == np - 3 in the query's own segment: in a redo, decided is set)
-                decided = true;
-                if (ncold != 0u) {
-                    if (cold) {
-                        // No threshold yet (a short partition, or a workgroup running ahead of the others): give the exchange
-                        // a moment -- bounded, so that progress never depends on other workgroups being resident.
-                        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-                        while (lds_load(&mp[MISC_TAU]) == __float_as_uint(min_units) && !(P0.dbg_flags & 4u) &&
-                               __builtin_amdgcn_s_memrealtime() - t0 < BATCH_TAU_WAIT)
-                            __builtin_amdgcn_s_sleep(4);
-                        if (DBG && P0.dbg && lane == 0) {  // TKSPMV_STATS=1
-                            const unsigned long long dt = __builtin_amdgcn_s_memrealtime() - t0;
-                            if (dt > 50ull) {
-                                atomicAdd(&mp[MISC_DBG_WAIT_TICKS], (uint32_t)dt);
-                                atomicAdd(&mp[MISC_DBG_WAITS], 1u);
-                            }
-                        }
-                    }
-                    const uint32_t tb = lds_load(&mp[MISC_TAU]);
-                    // still none: the cold packets go through the candidate path in the redo (every row is kept, as it
-                    // must be); else only if a champion reaches the threshold
-                    if (tb == __float_as_uint(min_units) || __any(champ >= __uint_as_float(tb))) {
-                        redo_len = ncold;  // (consumed by the request side when it turns to the next segment)
-                        redo_owed = true;
-                        if (DBG && P0.dbg && lane == 0) {
-                            atomicAdd(&mp[MISC_DBG_REDO_PK], ncold);
-                            atomicAdd(&mp[MISC_DBG_REDO_WV], 1u);
+            if (jc + 1u == np) {  // the query ends for this wave
+                if ((local || (P0.n_sets != 0u && P0.tau_possible)) && wcnt != 0u) {
+                    // A wave that runs ahead of the others gets here before any threshold exists for this query; flushing
+                    // now would dump every row it has seen to global memory. Give the exchange a moment -- bounded: after
+                    // BATCH_TAU_WAIT the wave goes on without one, so progress never depends on other workgroups being
+                    // resident. (On a small matrix every wave is in that position: 100+ us per query without this wait.)
+                    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                    while (lds_load(&mp[MISC_TAU]) == __float_as_uint(min_units) && !(P0.dbg_flags & 4u) &&
+                           __builtin_amdgcn_s_memrealtime() - t0 < (local ? LOCAL_TAU_WAIT : BATCH_TAU_WAIT))
+                        __builtin_amdgcn_s_sleep(4);
+                    if (DBG && P0.dbg && lane == 0) {  // TKSPMV_STATS=1
+                        const unsigned long long dt = __builtin_amdgcn_s_memrealtime() - t0;
+                        if (dt > 50ull) {
+                            atomicAdd(&mp[MISC_DBG_WAIT_TICKS], (uint32_t)dt);
+                            atomicAdd(&mp[MISC_DBG_WAITS], 1u);
                         }
                     }
                 }
-                cold = false;  // from here on every packet is judged (without a threshold: every row is kept)
-            }
-            if (jc + 1u == seg_n) {
-                if (redo_owed) {
-                    redo_owed = false;
-                    in_redo = true;  // the request side has turned (or is about to turn) to the same packets
-                    seg_n = ncold;
-                    jc = 0u;
-                } else {  // the query ends for this wave
-                    if (!champ_ok && (local || (P0.n_sets != 0u && P0.tau_possible)) && wcnt != 0u) {
-                        // A wave that runs ahead of the others gets here before any threshold exists for this query; flushing
-                        // now would dump every row it has seen to global memory. Give the exchange a moment -- bounded: after
-                        // BATCH_TAU_WAIT the wave goes on without one, so progress never depends on other workgroups being
-                        // resident. (On a small matrix every wave is in that position: 100+ us per query without this wait.)
-                        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-                        while (lds_load(&mp[MISC_TAU]) == __float_as_uint(min_units) && !(P0.dbg_flags & 4u) &&
-                               __builtin_amdgcn_s_memrealtime() - t0 < (local ? LOCAL_TAU_WAIT : BATCH_TAU_WAIT))
-                            __builtin_amdgcn_s_sleep(4);
-                        if (DBG && P0.dbg && lane == 0) {  // TKSPMV_STATS=1
-                            const unsigned long long dt = __builtin_amdgcn_s_memrealtime() - t0;
-                            if (dt > 50ull) {
-                                atomicAdd(&mp[MISC_DBG_WAIT_TICKS], (uint32_t)dt);
-                                atomicAdd(&mp[MISC_DBG_WAITS], 1u);
-                            }
-                        }
-                    }
-                    if (wcnt != 0u) {
-                        const float tau3 = __uint_as_float(lds_load(&mp[MISC_TAU]));
+                if (wcnt != 0u) {
+                    const float tau3 = __uint_as_float(lds_load(&mp[MISC_TAU]));
+                    if (local) {
+                        // the wave's best STG_N survivors are staged; more are dropped under a recorded bound
+                        stage_wave_local<WAVE_CAP, true>(wcand, wcnt, tau3, lane, &L.stg[qc & 1u][wave][0], &L.stg_cnt[qc & 1u][wave], mp);
+                    } else {
                         ListScan<WAVE_CAP / 64u> LS;
                         const uint32_t surv = scan_list<WAVE_CAP / 64u>(wcand, wcnt, tau3, lane, LS);
                         uint32_t gbase = 0u;
-                        if (surv > STG_N) {  // rare: more survivors than the staging area holds go to global memory directly
+                        if (surv > STG_N) {  // rare: more survivors than the staging area holds go to the overflow list directly
+                            if (P.ovf_gate_lds != 0u) ovf_wait(qc);
                             if (lane == 0) gbase = atomicAdd(P.ovf_count, surv - STG_N);
                             gbase = __builtin_amdgcn_readfirstlane(gbase);
                         }
@@ -937,21 +901,98 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const StreamParams P0_arg
                         if (surv > STG_N) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // those stores precede the ticket
                         if (lane == 0) L.stg_cnt[qc & 1u][wave] = surv < STG_N ? surv : STG_N;
                     }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    if (lane == 0) atomicAdd(&mp[MISC_DONE], 1u);
-                    if (trw && lane == 0 && TRSLOT(qc) < 3u) trw[4 + TRSLOT(qc)] = __builtin_amdgcn_s_memrealtime();
-                    ++qc;
-                    if (!RESIDENT && qc == nq) return;
-                    in_redo = false;
-                    seg_n = np;
-                    jc = 0u;
                 }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) atomicAdd(&mp[MISC_DONE], 1u);
+                if (trw && lane == 0 && TRSLOT(qc) < 3u) trw[4 + TRSLOT(qc)] = __builtin_amdgcn_s_memrealtime();
+                ++qc;
+                if (!RESIDENT && qc == nq) return;
+                jc = 0u;
             } else {
                 ++jc;
             }
         }
     }
 #undef TKSPMV_REQUEST
+#undef TRSLOT
+}
+
+// The launch: phase 0, then -- if checks were made and some failed -- the repair phase (see BatchParams::verdict).
+// The kernel's arguments as ONE block: the repair phase is a function of its own (below) and reads them where the dispatch put
+// them (the kernarg segment) instead of having 1.5 KB of parameters copied for it.
+struct BatchArgs {
+    StreamParams P;
+    SelectParams S;
+    BatchParams B;
+};
+
+// The repair phase, NOT inlined. It runs in one launch of thousands; inlined -- as a second copy of the phase or as a loop around
+// the first -- it cost the streaming loop of EVERY launch three reloads from scratch memory per packet (the kernel has no register
+// to spare: 80, two 576-thread workgroups per CU; measured: twice the time per query). As a function it has its own
+// registers; the price is paid in the repair phase only -- its LDS object arrives as a generic pointer.
+template <int C, int XCOLS, int QM, bool DBG>
+__device__ __attribute__((noinline)) void batch_repair_phase(const BatchArgs *args, BatchLds<XCOLS, C> *L) {
+    const BatchArgs &A = *args;  // (the kernel's own argument block in the kernarg segment: the KERNEL takes its address)
+    StreamParams P0 = A.P;
+    if (!DBG) {
+        P0.trace = nullptr;
+        P0.dbg = nullptr;
+        P0.stamps = nullptr;
+        P0.dbg_flags = 0u;
+        P0.dbg_repeat = 0u;
+    }
+    batch_phase<C, XCOLS, QM, DBG, false>(P0, A.S, A.B, true, *L);
+}
+
+template <int C, int XCOLS, int QM, bool DBG = false, bool RESIDENT = false>
+__global__ void __launch_bounds__(576, 6) batch_kernel(const BatchArgs A) {
+    StreamParams P0 = A.P;
+    const SelectParams &SP0 = A.S;
+    const BatchParams &B = A.B;
+    if (!DBG) {
+        P0.trace = nullptr;
+        P0.dbg = nullptr;
+        P0.stamps = nullptr;
+        P0.dbg_flags = 0u;
+        P0.dbg_repeat = 0u;
+    }
+    __shared__ BatchLds<XCOLS, C> L;
+    if (RESIDENT) {
+        batch_phase<C, XCOLS, QM, DBG, RESIDENT>(P0, SP0, B, false, L);
+        return;
+    }
+    const uint32_t tid = threadIdx.x;
+    const bool checks = B.local != 0u && B.verdict != nullptr && !(B.prior_block && B.prior_block[B.gate_parity ? 7 : 4] != 0u);  // phase 0 of this launch makes checks
+    if (B.repair == 0u) {
+        if (blockIdx.x == 0u && tid == 0u && B.verdict_next) __hip_atomic_store(B.verdict_next, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        batch_phase<C, XCOLS, QM, DBG, RESIDENT>(P0, SP0, B, false, L);
+        if (!checks || B.inline_repair == 0u) return;
+    }
+    // ---- the verdict: which queries of phase 0 failed their check? (a launch of its own for the repair phase: the word is
+    // complete; the same launch: wait for the last selection) ----------------------------------------------------------------
+    __syncthreads();
+    if (tid == 0u) {
+        unsigned long long v;
+        for (;;) {
+            v = __hip_atomic_load(B.verdict, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((uint32_t)v >= B.n_q || B.repair != 0u) break;
+            __builtin_amdgcn_s_sleep(32);
+        }
+        L.rq[BATCH_MAX + 1] = (uint32_t)(v >> 32);
+    }
+    __syncthreads();
+    const uint32_t mask = L.rq[BATCH_MAX + 1];
+    __syncthreads();
+    if (tid < 64u) {
+        const bool f = tid < B.n_q && ((mask >> tid) & 1u) != 0u;
+        const uint64_t bm = __ballot(f);
+        if (f) L.rq[__builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u))] = tid;
+        if (tid == 0) L.rq[BATCH_MAX] = (uint32_t)__popcll(bm);
+    }
+    __syncthreads();
+    if (blockIdx.x == 0u && tid == 0u && B.prior_block && B.local != 0u) gate_update(B, L.rq[BATCH_MAX]);
+    if (L.rq[BATCH_MAX] == 0u) return;
+    batch_repair_phase<C, XCOLS, QM, DBG>(reinterpret_cast<const BatchArgs *>((uintptr_t)__builtin_amdgcn_kernarg_segment_ptr()), &L);
 }
 
 }  // namespace tkspmv

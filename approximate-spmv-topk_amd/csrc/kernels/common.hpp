@@ -43,6 +43,13 @@ struct StreamParams {
     unsigned long long *ovf_cand;
     uint32_t *ovf_count;
     uint32_t ovf_cap;
+    // Flow control of an overflow list that several queries of one launch share (batch kernel; 0 elsewhere): nothing is
+    // appended before the LDS word at byte address ovf_gate_lds shows ovf_need -- the selections of the list's earlier users have
+    // finished. The word is a copy the workgroup's server wave keeps of the list's epoch in global memory: a streaming wave that
+    // went to memory for it would wait for its packet loads as well (the counter retires in order) -- measured, 4 % of a query at
+    // 3M rows. (mutable: a wave that has seen the gate open clears its copy -- the word never goes back.)
+    mutable uint32_t ovf_gate_lds;
+    uint32_t ovf_need;
     uint32_t fused;  // 1: the last workgroup to finish runs the selection (no second launch)
     // 1: deferred selection. Workgroup 0 of this launch selects the PREVIOUS query's top-k (its survivors sit in
     // the other exchange-state set, complete and visible since that launch ended) and exits; workgroups 1..grid-1

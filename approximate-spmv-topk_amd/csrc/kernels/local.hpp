@@ -26,6 +26,7 @@ struct LocalParams {
     uint32_t mode;              // 1: a wave's word is its best packet maximum, 2: its second best
     float beta;                 // carried thresholds start at beta x the recorded score
     unsigned long long *trace;  // optional (TKSPMV_TRACE=1): [grid][8 waves][8] s_memrealtime stamps
+    uint32_t shared_bookkeeping;  // 1: several selections run at once (batch kernel): prior_block is updated with atomics
 };
 
 constexpr uint32_t STG_N = 8;         // survivors a wave stages per query (64 lanes = 8 waves x 8 when one wave finalises)
@@ -73,40 +74,56 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {  // (DPP prefix s
 }
 
 // End of a wave's partition: what still clears the threshold is staged in LDS for the workgroup's finalisation -- at most STG_N
-// rows, the wave's BEST ones; if more survive, the rest is dropped and goes on record (MISC_BOUND). Lane 0 writes the count.
-template <uint32_t WAVE_CAP>
+// rows; if more survive, the rest is dropped and goes on record (MISC_BOUND). BEST: the wave keeps its STG_N BEST rows (an exact
+// bisection over the survivors' keys; single_kernel has the registers for it); else the first STG_N in list order, and the largest
+// dropped score is what goes on record -- a recorded bound is a bound either way, a loose one just fails the check sooner.
+// Lane 0 writes the count.
+template <uint32_t WAVE_CAP, bool BEST = true>
 __device__ __forceinline__ void stage_wave_local(const uint2 *wcand, uint32_t wcnt, float tau, uint32_t lane, unsigned long long *stg,
                                                  uint32_t *stg_cnt, uint32_t *misc) {
     constexpr uint32_t EPL = WAVE_CAP / 64u;
     ListScan<EPL> LS;
     uint32_t surv = scan_list<EPL>(wcand, wcnt, tau, lane, LS);
-    if (surv > STG_N) {  // rare: keep the STG_N best (ties: the first in list order), drop the rest under a recorded bound
-        uint32_t kk[EPL];
+    if (surv > STG_N) {  // rare
+        if (BEST) {
+            // keep the STG_N best (ties: the first in list order), drop the rest under a recorded bound
+            uint32_t kk[EPL];
 #pragma unroll
-        for (uint32_t u = 0; u < EPL; ++u) kk[u] = LS.keep[u] ? order_key(__uint_as_float(LS.e[u].x)) : 0u;
-        const uint32_t t = nth_largest_key<(int)EPL>(kk, STG_N);
-        uint32_t n_gt = 0;
+            for (uint32_t u = 0; u < EPL; ++u) kk[u] = LS.keep[u] ? order_key(__uint_as_float(LS.e[u].x)) : 0u;
+            const uint32_t t = nth_largest_key<(int)EPL>(kk, STG_N);
+            uint32_t n_gt = 0;
 #pragma unroll
-        for (uint32_t u = 0; u < EPL; ++u) n_gt += (uint32_t)__popcll(__ballot(kk[u] > t));
-        uint32_t eq_seen = 0, total = 0;
-        bool dropped_eq = false;
+            for (uint32_t u = 0; u < EPL; ++u) n_gt += (uint32_t)__popcll(__ballot(kk[u] > t));
+            uint32_t eq_seen = 0, total = 0;
+            bool dropped_eq = false;
 #pragma unroll
-        for (uint32_t u = 0; u < EPL; ++u) {
-            const bool eq = LS.keep[u] && kk[u] == t;
-            const uint64_t be = __ballot(eq);
-            const uint32_t my_eq = eq_seen + __builtin_amdgcn_mbcnt_hi((uint32_t)(be >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)be, 0u));
-            eq_seen += (uint32_t)__popcll(be);
-            const bool sel = LS.keep[u] && (kk[u] > t || (eq && n_gt + my_eq < STG_N));
-            dropped_eq = dropped_eq || (eq && !sel);
-            LS.keep[u] = sel;
-            const uint64_t bs = __ballot(sel);
-            LS.pos[u] = total + __builtin_amdgcn_mbcnt_hi((uint32_t)(bs >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bs, 0u));
-            total += (uint32_t)__popcll(bs);
+            for (uint32_t u = 0; u < EPL; ++u) {
+                const bool eq = LS.keep[u] && kk[u] == t;
+                const uint64_t be = __ballot(eq);
+                const uint32_t my_eq = eq_seen + __builtin_amdgcn_mbcnt_hi((uint32_t)(be >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)be, 0u));
+                eq_seen += (uint32_t)__popcll(be);
+                const bool sel = LS.keep[u] && (kk[u] > t || (eq && n_gt + my_eq < STG_N));
+                dropped_eq = dropped_eq || (eq && !sel);
+                LS.keep[u] = sel;
+                const uint64_t bs = __ballot(sel);
+                LS.pos[u] = total + __builtin_amdgcn_mbcnt_hi((uint32_t)(bs >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bs, 0u));
+                total += (uint32_t)__popcll(bs);
+            }
+            // everything dropped has a key <= t (== t only where a tie was dropped): on record strictly above it
+            const uint32_t bound = __ballot(dropped_eq) != 0ull ? t + 1u : t;
+            if (lane == 0) (void)__hip_atomic_fetch_max(&misc[MISC_BOUND], bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+            float dmax = -__builtin_huge_valf();
+#pragma unroll
+            for (uint32_t u = 0; u < EPL; ++u) {
+                const bool dropped = LS.keep[u] && LS.pos[u] >= STG_N;
+                dmax = dropped ? fmaxf(dmax, __uint_as_float(LS.e[u].x)) : dmax;
+                LS.keep[u] = LS.keep[u] && !dropped;
+            }
+            dmax = wave_max(dmax);
+            if (lane == 0) (void)__hip_atomic_fetch_max(&misc[MISC_BOUND], order_key(dmax) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-        // everything dropped has a key <= t (== t only where a tie was dropped): on record strictly above it
-        const uint32_t bound = __ballot(dropped_eq) != 0ull ? t + 1u : t;
-        if (lane == 0) (void)__hip_atomic_fetch_max(&misc[MISC_BOUND], bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        surv = total;  // (= STG_N)
+        surv = STG_N;
     }
 #pragma unroll
     for (uint32_t u = 0; u < EPL; ++u)
@@ -211,7 +228,7 @@ __device__ __forceinline__ bool select_local(const LocalParams &G, const SelectP
     unsigned long long t_start = 0ull;  // (thread 0: the launch's start stamp, for the duration it reports with the flag)
     if (tid == 0 && HOST && SP.t_start) t_start = __hip_atomic_load(SP.t_start, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     uint32_t pbv[4] = {0u, 0u, 0u, 0u};
-    if (tid == nthreads - 1u && G.prior_block) {
+    if (tid == nthreads - 1u && G.prior_block && !G.shared_bookkeeping) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) pbv[i] = __hip_atomic_load(G.prior_block + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -385,7 +402,9 @@ __device__ __forceinline__ bool select_local(const LocalParams &G, const SelectP
             }
         }
     }
-    for (uint32_t r = n_sel + tid; r < SP.k; r += nthreads) {
+    // (a failed check writes NO list: the repair that follows writes the same buffers, possibly from another XCD, and plain stores
+    //  of two workgroups of one launch reach memory in no particular order -- zeros landing last is what a test caught)
+    for (uint32_t r = n_sel + tid; r < SP.k && !bad; r += nthreads) {
         SP.out_idx[r] = 0u;
         SP.out_val[r] = 0.0f;
         if (HOST) {
@@ -396,7 +415,9 @@ __device__ __forceinline__ bool select_local(const LocalParams &G, const SelectP
     if (stamps && tid == 0) stamps[3] = __builtin_amdgcn_s_memrealtime();  // ranked, stores issued
     if (tid == nthreads - 1u) {  // the bookkeeping of the check (prior_block_update's rules, as plain stores of this single writer)
         if (G.status) __hip_atomic_store(G.status, bad ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (G.prior_block) {
+        if (G.prior_block && G.shared_bookkeeping) {
+            prior_block_update(G.prior_block, bad, t0 != 0u);
+        } else if (G.prior_block) {
             uint32_t *pb = G.prior_block;
             if (bad) {
                 const uint32_t nl = pbv[1] < 16u ? 16u : (pbv[1] >= 2048u ? 4096u : 2u * pbv[1]);
@@ -545,7 +566,7 @@ __global__ void __launch_bounds__(512, 4) single_kernel(const StreamParams P, co
                 if (tr && i == 0u) tr2 = __builtin_amdgcn_s_memrealtime() + (__float_as_uint(Rd.S) & 0u);
                 if (__any(trigger_of<C, false>(Rd) >= tau)) {
                     const RowSums<C> R = expand<C, false>(Rd, packet_flags<C, QM>(cur));
-                    const float wm = offer_candidates<C, QM, WAVE_CAP, false, true>(P, R, rb_cur, tau, lane, 0u, false, wcand, wcnt, misc);
+                    const float wm = offer_candidates<C, QM, WAVE_CAP, false>(P, R, rb_cur, tau, lane, 0u, false, wcand, wcnt, misc, true);
                     if (wm > top2 && wm >= min_units) {
                         // (a wave with a single packet has no second maximum: it stands for one row)
                         top2 = wm > top1 ? top1 : wm;

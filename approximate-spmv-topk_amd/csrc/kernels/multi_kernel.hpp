@@ -43,8 +43,6 @@ struct MultiGroup {  // a group of queries sharing one pass; their exchange-stat
 struct MultiParams {
     SetAddr A;
     MultiGroup cur, prev;  // prev.n_q == 0: no selection owed
-    unsigned long long *scratch0;  // general-path scratch of selector q: scratch0 + q * scratch_stride
-    uint64_t scratch_stride;
     const uint32_t *part_slice0;  // [n_parts] first slice of every partition
     uint32_t n_sel;               // selector workgroups at the head of the grid = the engine's queries per pass (1, 2, 4 or 8)
 };
@@ -70,7 +68,6 @@ __device__ __forceinline__ SelectParams select_params_of_set(const SelectParams 
     S.ovf_count = A.ovf_count(set);
     S.gmax = A.gmax(set);
     S.tau_g = A.tau_g(set);
-    S.scratch = A.scratch;
     S.unit_inv_in = nullptr;
     S.out_idx = io.out_idx;
     S.out_val = io.out_val;
@@ -81,13 +78,11 @@ __device__ __forceinline__ SelectParams select_params_of_set(const SelectParams 
 // scratch. Queries that share a result buffer (the engine-owned pair: "the last query wins") are selected one after the
 // other by workgroup 0 instead.
 __global__ void __launch_bounds__(SEL_THREADS) select_group_kernel(const SelectParams SP0, const SetAddr A, const MultiGroup G,
-                                                                   unsigned long long *scratch0, uint64_t scratch_stride,
                                                                    uint32_t serial) {
     __shared__ SelectShared S;
     const uint32_t q0 = serial ? 0u : blockIdx.x, q1 = serial ? G.n_q : blockIdx.x + 1u;
     for (uint32_t q = q0; q < q1 && q < G.n_q; ++q) {
         SelectParams P = select_params_of_set(SP0, A, G.set0 + q, G.io[q]);
-        P.scratch = scratch0 + (size_t)q * scratch_stride;
         select_body(P, threadIdx.x, blockDim.x, S);
         __syncthreads();
     }
@@ -165,7 +160,6 @@ __global__ void __launch_bounds__(576, Q >= 8 ? 4 : 6) multi_kernel(const Stream
         // in ONE workgroup they took longer than the pass they ride in)
         if (blockIdx.x < M.prev.n_q) {
             SelectParams S = select_params_of_set(SP0, M.A, M.prev.set0 + blockIdx.x, M.prev.io[blockIdx.x]);
-            S.scratch = M.scratch0 + (size_t)blockIdx.x * M.scratch_stride;
             select_body(S, tid, blockDim.x, L.u.sel);
         }
         return;

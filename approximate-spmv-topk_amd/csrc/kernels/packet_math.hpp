@@ -498,14 +498,14 @@ __device__ __forceinline__ uint32_t compact_list(uint2 *wcand, uint32_t n, float
 // (its length lives in an SGPR: no atomic, no other wave involved). A full list is first compacted against the
 // current threshold; only what still does not fit goes to the shared overflow list in global memory, with ONE
 // atomic per wave and packet. One LDS atomic raises the group maximum (the server wave pushes it to global memory).
-// DROP (workgroup-local thresholds, which the selection checks): a row that does not fit the list even after the compaction is
+// drop (workgroup-local thresholds, which the selection checks): a row that does not fit the list even after the compaction is
 // not sent to a list in global memory but dropped, and the largest dropped score goes on record one step up (MISC_BOUND, an LDS
 // atomic max; the workgroup's record of "everything I dropped lies strictly below this"): the selection's check fails unless k
 // candidates reach every such record, and a failed check sends the query through the exact path.
-template <int C, int QM, uint32_t WAVE_CAP, bool STATS = true, bool DROP = false>
+template <int C, int QM, uint32_t WAVE_CAP, bool STATS = true>
 __device__ __forceinline__ float offer_candidates(const StreamParams &P, const RowSums<C> &R, uint32_t rb, float tau,
                                                  uint32_t lane, uint32_t grp_local, bool publishes, uint2 *wcand,
-                                                 uint32_t &wcnt, uint32_t *misc) {
+                                                 uint32_t &wcnt, uint32_t *misc, const bool drop = false) {
     bool pass[C];
     uint32_t slot[C];
     uint32_t total = 0;
@@ -534,7 +534,7 @@ __device__ __forceinline__ float offer_candidates(const StreamParams &P, const R
     const uint32_t first_ovf = base < WAVE_CAP ? WAVE_CAP : base;  // list position of the first overflowing row
     uint32_t gbase = 0u;
     if (base + total > WAVE_CAP) {
-        if (DROP) {
+        if (drop) {
             float dmax = -__builtin_huge_valf();
 #pragma unroll
             for (int j = 0; j < C; ++j)
@@ -543,6 +543,13 @@ __device__ __forceinline__ float offer_candidates(const StreamParams &P, const R
             if (lane == 0)
                 (void)__hip_atomic_fetch_max(&misc[MISC_BOUND], order_key(dmax) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         } else {
+            if (P.ovf_gate_lds != 0u) {  // (a list shared by several queries of the launch: its earlier users' selections must have finished)
+                typedef __attribute__((address_space(3))) uint32_t lds_word;
+                while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(reinterpret_cast<lds_word *>((uintptr_t)P.ovf_gate_lds), __ATOMIC_RELAXED,
+                                                                        __HIP_MEMORY_SCOPE_WORKGROUP)) != P.ovf_need)
+                    __builtin_amdgcn_s_sleep(8);
+                P.ovf_gate_lds = 0u;  // (open for the rest of this wave's query)
+            }
             if (lane == 0) gbase = atomicAdd(P.ovf_count, base + total - first_ovf);
             gbase = __builtin_amdgcn_readfirstlane(gbase);
         }
@@ -554,7 +561,7 @@ __device__ __forceinline__ float offer_candidates(const StreamParams &P, const R
             const uint32_t pos = base + slot[j];
             if (pos < WAVE_CAP) {
                 wcand[pos] = make_uint2(__float_as_uint(row_score<C, QM>(R, j)), r);
-            } else if (!DROP) {
+            } else if (!drop) {
                 const uint32_t gp = gbase + (pos - first_ovf);
                 if (gp < P.ovf_cap) st_agent(&P.ovf_cand[gp], pack_cand(__float_as_uint(row_score<C, QM>(R, j)), r));
             }

@@ -25,7 +25,6 @@ struct SelectParams {
     uint32_t *done_count;  // ticket counter of the fused tail
     uint32_t n_groups_pub;
     uint32_t use_gmax;  // n_sets != 0 and n_groups_pub >= k
-    unsigned long long *scratch;  // [n_wg*WG_SLOTS + ovf_cap] composite keys (general path)
     // Multi-query kernel: candidates carry their POSITION in the wave-sliced ELL stream (slice * 64 + lane) instead of a
     // row id; the selection, off the streaming waves' path, looks the row ids up here. NULL: candidates carry row ids.
     const uint32_t *pos_to_row;
@@ -228,47 +227,62 @@ __device__ __forceinline__ void select_body(const SelectParams &P, const uint32_
     const uint32_t total = n_from_slots + S.cnt;
     const bool small = total <= SEL_CAP;
     __syncthreads();  // everybody has read S.cnt before the general path reuses it
-    unsigned long long *dst = small ? S.keys : P.scratch;
-#pragma unroll
-    for (uint32_t u = 0; u < SEL_PER_THREAD; ++u) {
-        if (ok[u]) dst[wbase + spos[u]] = make_ckey(mine[u]);
-    }
-    for (uint32_t i0 = 0; i0 < novf; i0 += nthreads) {  // wave-uniform trip count
-        const uint32_t i = i0 + tid;
-        unsigned long long v = 0ull;
-        if (OVF_SPEC > 0 && i0 < (uint32_t)OVF_SPEC * nthreads) {
-#pragma unroll
-            for (int u = 0; u < OVF_SPEC; ++u)
-                if (i0 == (uint32_t)u * nthreads) v = ospec[u];
-        } else if (i < novf) {
-            v = ld_agent(&P.ovf_cand[i]);
-        }
-        const bool keep = i < novf && order_key(__uint_as_float((uint32_t)v)) >= thr;
-        if (keep && P.pos_to_row) v = pack_cand((uint32_t)v, P.pos_to_row[(uint32_t)(v >> 32)]);
-        const uint64_t bm = __ballot(keep);
-        uint32_t base = 0;
-        if (lane == 0 && bm) base = atomicAdd(&S.total, (uint32_t)__popcll(bm));
-        base = __builtin_amdgcn_readfirstlane(base);
-        if (keep)
-            dst[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u))] =
-                make_ckey(v);
-    }
+    // An overflow entry as the selection sees it (entry i, or 0: not a candidate): pruned by the threshold, its position translated
+    // to a row id where candidates carry positions.
+    auto ovf_entry = [&](uint32_t i) __attribute__((always_inline)) -> unsigned long long {
+        if (i >= novf) return 0ull;
+        // (a plain load: the selecting workgroup took its acquire before it got here and nobody writes the list while it is
+        //  being selected from, so the 64 passes of the bisection may come from the L2 -- as round 3's scratch copy did)
+        unsigned long long v = P.ovf_cand[i];
+        if (order_key(__uint_as_float((uint32_t)v)) < thr) return 0ull;
+        if (P.pos_to_row) v = pack_cand((uint32_t)v, P.pos_to_row[(uint32_t)(v >> 32)]);
+        return make_ckey(v);
+    };
     uint32_t n_sel;
-
     if (small) {
+#pragma unroll
+        for (uint32_t u = 0; u < SEL_PER_THREAD; ++u) {
+            if (ok[u]) S.keys[wbase + spos[u]] = make_ckey(mine[u]);
+        }
+        for (uint32_t i0 = 0; i0 < novf; i0 += nthreads) {  // wave-uniform trip count
+            const uint32_t i = i0 + tid;
+            unsigned long long v = 0ull;
+            if (OVF_SPEC > 0 && i0 < (uint32_t)OVF_SPEC * nthreads) {
+#pragma unroll
+                for (int u = 0; u < OVF_SPEC; ++u)
+                    if (i0 == (uint32_t)u * nthreads) v = ospec[u];
+            } else if (i < novf) {
+                v = ld_agent(&P.ovf_cand[i]);
+            }
+            const bool keep = i < novf && order_key(__uint_as_float((uint32_t)v)) >= thr;
+            if (keep && P.pos_to_row) v = pack_cand((uint32_t)v, P.pos_to_row[(uint32_t)(v >> 32)]);
+            const uint64_t bm = __ballot(keep);
+            uint32_t base = 0;
+            if (lane == 0 && bm) base = atomicAdd(&S.total, (uint32_t)__popcll(bm));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (keep)
+                S.keys[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u))] =
+                    make_ckey(v);
+        }
         if (tid < 8) S.keys[total + tid] = 0ull;  // padding for the unrolled rank loop (0 is below every real key)
         __syncthreads();
         n_sel = total;
     } else {
-        // General path (threshold exchange disabled or not converged): the keys went to global scratch; bisection
-        // for the k-th largest composite key, then compaction of the keys >= it into LDS.
-        __syncthreads();
+        // General path (threshold exchange disabled or not converged, degenerate queries: up to every row is a candidate):
+        // bisection for the k-th largest composite key straight over the sources -- this thread's slots (registers) and the
+        // overflow list, re-read on every pass: as many bytes as a copy of the keys would cost, and no scratch of 8 bytes per row
+        // and selector (round 3 kept one) --, then the keys at or above it into LDS (composite keys are unique: at most k).
+        // (the slots' keys are recomputed on every pass rather than kept: 16 more registers would cost the single-query kernels
+        //  their second workgroup per CU)
+        auto sk = [&](uint32_t u) __attribute__((always_inline)) -> unsigned long long { return ok[u] ? make_ckey(mine[u]) : 0ull; };
         unsigned long long prefix = 0ull;
         if (total > P.k) {
             for (int bit = 63; bit >= 0; --bit) {
                 const unsigned long long trial = prefix | (1ull << bit);
                 uint32_t c = 0;
-                for (uint32_t i = tid; i < total; i += nthreads) c += (P.scratch[i] >= trial);
+#pragma unroll
+                for (uint32_t u = 0; u < SEL_PER_THREAD; ++u) c += (sk(u) >= trial);
+                for (uint32_t i = tid; i < novf; i += nthreads) c += (ovf_entry(i) >= trial);
 #pragma unroll
                 for (int d = 32; d >= 1; d >>= 1) c += (uint32_t)__shfl_xor((int)c, d);
                 if (tid == 0) S.cnt = 0;
@@ -281,13 +295,15 @@ __device__ __forceinline__ void select_body(const SelectParams &P, const uint32_
         }
         if (tid == 0) S.cnt = 0;
         __syncthreads();
-        for (uint32_t i = tid; i < total; i += nthreads) {
-            const unsigned long long kx = P.scratch[i];
-            if (kx >= prefix) {
+        auto put = [&](unsigned long long kx) __attribute__((always_inline)) {
+            if (kx != 0ull && kx >= prefix) {
                 const uint32_t pos = atomicAdd(&S.cnt, 1u);
                 if (pos < SEL_CAP) S.keys[pos] = kx;
             }
-        }
+        };
+#pragma unroll
+        for (uint32_t u = 0; u < SEL_PER_THREAD; ++u) put(sk(u));
+        for (uint32_t i = tid; i < novf; i += nthreads) put(ovf_entry(i));
         __syncthreads();
         n_sel = S.cnt < SEL_CAP ? S.cnt : SEL_CAP;
         if (tid < 8) S.keys[n_sel + tid] = 0ull;

@@ -150,11 +150,13 @@ typedef struct {
     uint64_t multi_bytes;         /* bytes of the wave-sliced ELL copy the multi-query kernel streams (0 without it) */
     uint32_t pack_us;             /* tkspmv_create: microseconds spent packing (on the device: upload of the COO included) */
     uint32_t pack_on_device;      /* 1: the stream was packed by the device packer (default), 0: by the host packer */
-    uint32_t claim_sets;          /* back-to-back queries run through the claim kernel: the wave partitions form this many sets of 8
-                                     that workgroups claim dynamically (0: one partition per wave, batch kernel) */
+    uint32_t claim_sets;          /* always 0 (round 3's dynamically claimed partition sets are gone; the field keeps the layout) */
     uint32_t batch_mode;          /* back-to-back queries: bits 0-7 = selector workgroups of a launch (4 on small matrices), bits 8-15 =
                                      workgroup-local thresholds (0: the device-wide exchange; 1 / 2: see DESIGN.md 3.0b); bits 16-31 = the
                                      n_wave_partitions_hint this engine packed with (tkspmv_pack with the same hint cuts the same partitions) */
+    uint64_t state_bytes;         /* device memory of the exchange state of back-to-back queries: the per-query sets (published maxima,
+                                     threshold word, one slot per wave, the workgroups' records) and the overflow lists (8 B per row each;
+                                     two per engine since round 4, one per query of a launch before) */
 } tkspmv_info;
 
 typedef struct {

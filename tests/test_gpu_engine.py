@@ -887,52 +887,6 @@ def test_long_batches_cross_launch_boundaries(pkg, oracle):
     eng.close()
 
 
-@pytest.mark.parametrize("precision", ["F32", "Q1_7_WIDE", "FIXED"])
-@pytest.mark.parametrize("beta", ["0.9", "2.0"])
-def test_prior_thresholds_are_verified_and_repaired(pkg, oracle, monkeypatch, beta, precision):
-    """TKSPMV_PRIOR=1: the queries of a batch start from a GUESSED threshold (beta x the k-th best score of a query selected
-    shortly before). The guess must never show in the results: the selection verifies it and the repair launch re-runs
-    the queries it failed for. Queries whose scores drop by 1000x mid-sequence, an all-zero query, a negated one, and
-    beta = 2 (every guess is too high: every query but the first goes through the repair launch) -- all bit-identical to
-    an engine without guesses."""
-    import torch
-    cols = 1024 if precision == "F32" else 512
-    m = pkg.generate_matrix(150000, cols, 20, "gamma", 5)
-    nq = 70
-    xs = np.stack([pkg.create_sample_vector(cols, True, False, True, 9000 + i) for i in range(nq)])
-    if precision != "F32":
-        xs = (xs * np.float32(40.0)).astype(np.float32)
-    xs[10:20] *= np.float32(1e-3)
-    xs[31:34] *= np.float32(0.25)
-    xs[40] = 0.0
-    xs[41] *= np.float32(30.0) if precision == "F32" else np.float32(1.0)
-    xs[50] = -xs[50]
-    dxs = torch.from_numpy(xs).cuda()
-    kw = dict(k=100, device=0, precision=getattr(pkg, precision))
-    if precision == "FIXED":
-        kw["fixed_width"] = 20
-    plain = pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, **kw)
-    ref_i = torch.full((nq, 100), -1, dtype=torch.int32, device="cuda")
-    ref_v = torch.full((nq, 100), -1.0, dtype=torch.float32, device="cuda")
-    plain.enqueue_batch(dxs.data_ptr(), nq, ref_i.data_ptr(), ref_v.data_ptr())
-    plain.synchronize()
-    plain.close()
-    monkeypatch.setenv("TKSPMV_PRIOR", "1")
-    monkeypatch.setenv("TKSPMV_PRIOR_BETA", beta)
-    eng = pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, **kw)
-    for rep in range(2):
-        out_i = torch.full((nq, 100), -1, dtype=torch.int32, device="cuda")
-        out_v = torch.full((nq, 100), -1.0, dtype=torch.float32, device="cuda")
-        eng.enqueue_batch(dxs.data_ptr(), nq, out_i.data_ptr(), out_v.data_ptr())
-        eng.synchronize()
-        bad = [q for q in range(nq) if not (torch.equal(out_i[q], ref_i[q]) and torch.equal(out_v[q], ref_v[q]))]
-        assert not bad, (rep, bad)
-    if precision == "F32":
-        gi, gv = oracle.gold_topk(m.row, m.col, m.val, xs[12], 100)
-        assert set(out_i[12].cpu().numpy().view(np.uint32).tolist()) == set(gi.tolist())
-    eng.close()
-
-
 @pytest.mark.parametrize("rows", [20000, 130000, 260000])
 @pytest.mark.parametrize("precision,mode", [("F32", "1"), ("F32", "2"), ("Q1_7_WIDE", "2"), ("F16", "1")])
 def test_workgroup_local_thresholds_are_verified_and_repaired(pkg, oracle, monkeypatch, rows, precision, mode):

@@ -33,7 +33,8 @@ def test_streaming_kernels_do_not_spill_and_fit_two_workgroups_per_cu():
     assert len(stream) >= 30 and len(multi) == 12
     for n, v in {**stream, **multi}.items():
         tracing = re.search(r"stream_kernelILi4ELb0ELi1024ELi7ELi3ELb1E", n) or re.search(r"batch_kernelILi4ELi1024ELi[07]ELb1E", n)
-        if "kernelILi8E" not in n and not tracing:  # (the opt-in 8-entries-per-lane variants sit at the register limit; so do the tracing instantiations (TKSPMV_TRACE / TKSPMV_STATS runs only): the 12-bit layout's stream kernel, the batch kernels since round 3's checked thresholds)
+        fused_tail = re.search(r"stream_kernelILi4ELb0ELi1024ELi[07]ELi3ELb[01]E", n)  # (a word of the selection tail; the loop is checked on the ISA below)
+        if "kernelILi8E" not in n and not tracing and "batch_kernel" not in n and not fused_tail:  # (batch kernels: the ISA test below; the opt-in 8-entries-per-lane variants sit at the register limit; so do the tracing instantiations (TKSPMV_TRACE / TKSPMV_STATS runs only): the 12-bit layout's stream kernel, the batch kernels since round 3's checked thresholds)
             assert v["VGPRs Spill"] == 0, n
         assert v["AGPRs"] == 0, n
     for n, v in stream.items():
@@ -41,9 +42,12 @@ def test_streaming_kernels_do_not_spill_and_fit_two_workgroups_per_cu():
         scores = "stream_kernelILi4ELb1E" in n or "stream_kernelILi8ELb1E" in n  # SpMV-only variants: one workgroup per CU is fine
         c8 = "kernelILi8E" in n
         dbg = dbg or bool(re.search(r"stream_kernelILi4ELb0ELi1024ELi7ELi3ELb1E", n)) or bool(re.search(r"batch_kernelILi4ELi1024ELi[07]ELb1E", n))
-        if not dbg and not c8:
-            assert v["ScratchSize [bytes/lane]"] == 0, (n, v)
-        if not scores:
+        # (the batch kernels call their selections and their repair phase as functions since round 4: the scratch size is those
+        #  functions' stack; that the streaming loop itself touches no scratch is checked on the ISA below)
+        if not dbg and not c8 and "batch_kernel" not in n:
+            # (the single-query kernels keep a word or two of their selection tail in scratch; their loops are checked on the ISA too)
+            assert v["ScratchSize [bytes/lane]"] <= (16 if "stream_kernelILi4ELb0ELi1024" in n else 0), (n, v)
+        if not scores and not dbg:  # (the tracing instantiations of the single-query kernel may run one workgroup per CU)
             assert v["VGPRs"] <= 80, (n, v)
     # the headline kernels by name
     head = [n for n in stream if "12batch_kernelILi4ELi1024ELi7ELb0ELb0E" in n or "13stream_kernelILi4ELb0ELi1024ELi7ELi3ELb0E" in n
@@ -52,3 +56,61 @@ def test_streaming_kernels_do_not_spill_and_fit_two_workgroups_per_cu():
     for n, v in multi.items():
         q8 = "multi_kernelILi8E" in n
         assert v["VGPRs"] <= (128 if q8 else 80), (n, v)  # 8 queries per pass run 8-wave workgroups
+
+
+def test_batch_kernels_stream_without_touching_scratch(tmp_path):
+    """The batch kernel sits AT its register limit (80: two 576-thread workgroups per CU). Round 4 found out what one value too
+    many costs: three reloads from scratch memory per packet and twice the time per query, with every functional test green.
+    This compiles the instantiations on their own (seconds) and reads the ISA: no basic block that requests a packet
+    (non-temporal dwordx4 load) or runs the segmented scan (row_bcast) may contain a scratch instruction."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    tu = tmp_path / "tu.hip"
+    tu.write_text("""#include <hip/hip_runtime.h>
+#include <cstdint>
+#include "kernels/common.hpp"
+#include "kernels/select.hpp"
+#include "kernels/packet_math.hpp"
+#include "kernels/stream_kernel.hpp"
+#include "kernels/local.hpp"
+#include "kernels/batch_kernel.hpp"
+namespace tkspmv {
+template __global__ void batch_kernel<4, 1024, 0, false, false>(const BatchArgs);
+template __global__ void batch_kernel<4, 1024, 1, false, false>(const BatchArgs);
+template __global__ void batch_kernel<4, 1024, 2, false, false>(const BatchArgs);
+template __global__ void batch_kernel<4, 1024, 3, false, false>(const BatchArgs);
+template __global__ void batch_kernel<4, 1024, 4, false, false>(const BatchArgs);
+template __global__ void batch_kernel<4, 1024, 5, false, false>(const BatchArgs);
+template __global__ void batch_kernel<4, 1024, 6, false, false>(const BatchArgs);
+template __global__ void batch_kernel<4, 1024, 7, false, false>(const BatchArgs);
+template __global__ void batch_kernel<4, 1024, 8, false, false>(const BatchArgs);
+template __global__ void batch_kernel<4, 1024, 7, false, true>(const BatchArgs);
+template __global__ void stream_kernel<4, false, 1024, 7, 3, false>(const StreamParams, const SelectParams);
+template __global__ void stream_kernel<4, false, 1024, 0, 3, false>(const StreamParams, const SelectParams);
+}
+""")
+    asm = tmp_path / "tu.s"
+    subprocess.check_call([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "--cuda-device-only", "-S",
+                           "-I" + os.path.join(ROOT, "approximate-spmv-topk_amd", "csrc"), "-o", str(asm), str(tu)],
+                          stderr=subprocess.DEVNULL)
+    lines = asm.read_text().split("\n")
+    starts = [i for i, ln in enumerate(lines) if (ln.startswith("_ZN6tkspmv12batch_kernel") or ln.startswith("_ZN6tkspmv13stream_kernel")) and "@" in ln]
+    assert len(starts) == 12
+    for start in starts:
+        end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
+        blocks, cur = [], None
+        for ln in lines[start:end]:
+            if re.match(r"^\.LBB\d+_\d+:", ln):
+                cur = {"name": ln.split(":")[0], "scratch": 0, "hot": False}
+                blocks.append(cur)
+            elif cur is not None:
+                if "scratch_" in ln:
+                    cur["scratch"] += 1
+                if ("global_load_dword" in ln and " nt" in ln) or "row_bcast" in ln:
+                    cur["hot"] = True
+        hot = [b for b in blocks if b["hot"]]
+        assert len(hot) >= 3, "the streaming loop was not found in the ISA of " + lines[start].split(":")[0]
+        assert all(b["scratch"] == 0 for b in hot), (lines[start].split(":")[0], [b for b in hot if b["scratch"]])
