@@ -101,6 +101,9 @@ int tkspmv_enqueue_multi(tkspmv_t *h, const float *dev_xs, int32_t count, uint32
 int tkspmv_time_multi(tkspmv_t *h, const float *dev_xs, int32_t n_x, int32_t iters, double *ns_per_query) {
     ENGINE_CALL(time_multi(dev_xs, n_x, iters, ns_per_query, err))
 }
+int tkspmv_time_query_batches(tkspmv_t *h, const float *dev_xs, int32_t n_x, int32_t iters, int32_t reps, double *ns_per_query) {
+    ENGINE_CALL(time_query_batches(dev_xs, n_x, iters, reps, ns_per_query, err))
+}
 int tkspmv_time_queries(tkspmv_t *h, const float *dev_xs, int32_t n_x, int32_t iters, double *ns_per_query) {
     ENGINE_CALL(time_queries(dev_xs, n_x, iters, ns_per_query, err))
 }

@@ -175,7 +175,6 @@ struct EngineImpl {
     uint32_t *d_rec_used = nullptr;             // [batch_max][grid]
     uint32_t *d_ovf_epoch = nullptr;            // [ovf_lists] x 32 words
     uint32_t ovf_lists = 1;                     // overflow lists allocated (batch engines: 2, shared by the queries of a launch under flow control)
-    bool inline_repair = false;                 // the whole grid is resident at once: a launch repairs its failed checks itself
     uint32_t use_local = 0;  // workgroup-local thresholds (BatchParams::local: 0 off, 1 / 2: a wave's best / second best packet maximum)
     float *d_wg_prior = nullptr;  // [grid] + the countdown word (BatchParams::wg_prior / prior_block)
     bool carry_local = true;
@@ -398,17 +397,21 @@ struct EngineImpl {
         if (!fused) launch_select(out_idx, out_val, s);
     }
     typedef void (*batch_fn)(const BatchArgs);
-    batch_fn batch_kernel_for() const {  // can_batch: x of at most 1024 columns (it is held twice in LDS)
-        if (desc.precision == TKSPMV_Q1_7) return &batch_kernel<4, 1024, 1>;
-        if (desc.precision == TKSPMV_Q1_7_WIDE) return &batch_kernel<4, 1024, 2>;
-        if (desc.precision == TKSPMV_F16) return &batch_kernel<4, 1024, 3>;
+    // can_batch: x of at most 1024 columns (it is held twice in LDS). local: the kernel of the checked local thresholds.
+    template <bool LOCAL>
+    batch_fn batch_kernel_of() const {
+        if (desc.precision == TKSPMV_Q1_7) return &batch_kernel<4, 1024, 1, false, false, LOCAL>;
+        if (desc.precision == TKSPMV_Q1_7_WIDE) return &batch_kernel<4, 1024, 2, false, false, LOCAL>;
+        if (desc.precision == TKSPMV_F16) return &batch_kernel<4, 1024, 3, false, false, LOCAL>;
         if (desc.precision == TKSPMV_FIXED)
-            return pm.precision == Precision::FIXED20 ? &batch_kernel<4, 1024, 6> : (pm.precision == Precision::FIXED26 ? &batch_kernel<4, 1024, 8> : &batch_kernel<4, 1024, 4>);
-        if (desc.precision == TKSPMV_Q1_7_F32) return &batch_kernel<4, 1024, 5>;
-        if (info.packet_entries == 512) return &batch_kernel<8, 1024, 0>;
-        if (pm.precision == Precision::F32C12) return dbg_kernels ? &batch_kernel<4, 1024, 7, true> : &batch_kernel<4, 1024, 7>;
-        return dbg_kernels ? &batch_kernel<4, 1024, 0, true> : &batch_kernel<4, 1024, 0>;
+            return pm.precision == Precision::FIXED20 ? &batch_kernel<4, 1024, 6, false, false, LOCAL>
+                                                      : (pm.precision == Precision::FIXED26 ? &batch_kernel<4, 1024, 8, false, false, LOCAL> : &batch_kernel<4, 1024, 4, false, false, LOCAL>);
+        if (desc.precision == TKSPMV_Q1_7_F32) return &batch_kernel<4, 1024, 5, false, false, LOCAL>;
+        if (info.packet_entries == 512) return &batch_kernel<8, 1024, 0, false, false, LOCAL>;
+        if (pm.precision == Precision::F32C12) return dbg_kernels ? &batch_kernel<4, 1024, 7, true, false, LOCAL> : &batch_kernel<4, 1024, 7, false, false, LOCAL>;
+        return dbg_kernels ? &batch_kernel<4, 1024, 0, true, false, LOCAL> : &batch_kernel<4, 1024, 0, false, false, LOCAL>;
     }
+    batch_fn batch_kernel_for(bool local = false) const { return local ? batch_kernel_of<true>() : batch_kernel_of<false>(); }
     // n <= BATCH_MAX queries in one launch of the batch kernel; results complete in stream order after the launch.
     void launch_batch(const float *const *xs, uint32_t *const *out_idx, float *const *out_val, int n, hipStream_t s) const {
         drain(s);
@@ -453,13 +456,14 @@ struct EngineImpl {
         B.lused_stride = grid;
         B.ovf_epoch = d_ovf_epoch;
         B.ovf_lists = std::min(ovf_lists, 4u);  // (engines with one list per set -- the multi-query ones -- lend the batch kernel their first four)
-        B.inline_repair = inline_repair ? 1u : 0u;
         BatchArgs A{P, S, B};
-        hipLaunchKernelGGL(batch_kernel_for(), dim3(grid), dim3(block + 64), 0, s, A);
-        if (use_local && !inline_repair) {  // (a GPU that cannot hold the whole grid at once: the repair phase as a launch of its own)
+        if (use_local) {
+            // the kernel of the checked local thresholds, then the exact kernel for whatever failed its check (the launch is
+            // empty -- every workgroup reads the verdict word and leaves -- unless a query was unlike the ones before it)
+            hipLaunchKernelGGL(batch_kernel_for(true), dim3(grid), dim3(block + 64), 0, s, A);
             A.B.repair = 1u;
-            hipLaunchKernelGGL(batch_kernel_for(), dim3(grid), dim3(block + 64), 0, s, A);
         }
+        hipLaunchKernelGGL(batch_kernel_for(false), dim3(grid), dim3(block + 64), 0, s, A);
     }
     // A back-to-back sequence of queries given as pointer lists: batch kernel launches of up to BATCH_MAX queries
     // when it is available, else deferred selection.
@@ -651,9 +655,9 @@ struct EngineImpl {
         B.n_replicas = d_replicas.empty() ? 1u : (uint32_t)std::min<size_t>(d_replicas.size(), 8);
         for (uint32_t r = 0; r < 8u; ++r) B.replicas[r] = d_replicas.empty() ? d_packets : d_replicas[r % d_replicas.size()];
         if (pm.precision == Precision::F32C12)
-            hipLaunchKernelGGL((batch_kernel<4, 1024, 7, false, true>), dim3(grid), dim3(block + 64), 0, rstream, BatchArgs{P, S, B});
+            hipLaunchKernelGGL((batch_kernel<4, 1024, 7, false, true, false>), dim3(grid), dim3(block + 64), 0, rstream, BatchArgs{P, S, B});
         else
-            hipLaunchKernelGGL((batch_kernel<4, 1024, 0, false, true>), dim3(grid), dim3(block + 64), 0, rstream, BatchArgs{P, S, B});
+            hipLaunchKernelGGL((batch_kernel<4, 1024, 0, false, true, false>), dim3(grid), dim3(block + 64), 0, rstream, BatchArgs{P, S, B});
         e = hipGetLastError();
         resident_running = e == hipSuccess;
         return e;
@@ -1323,14 +1327,6 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
             HIP_TRY(hipMemset(m.d_rec_used, 0, ns * m.grid * 4));
             HIP_TRY(hipMalloc((void **)&m.d_alias_idx, (size_t)BATCH_MAX * d.k * 4));
             HIP_TRY(hipMalloc((void **)&m.d_alias_val, (size_t)BATCH_MAX * d.k * 4));
-            // A launch repairs its failed checks itself (every workgroup waits for the launch's verdict) only where the whole grid
-            // is resident at once: otherwise a workgroup waiting for the verdict could keep one that has not started yet -- and
-            // whose tickets the verdict needs -- from ever getting a slot.
-            int per_cu = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(m.batch_kernel_for()), (int)m.block + 64, 0) != hipSuccess) per_cu = 0;
-            (void)hipGetLastError();
-            m.inline_repair = (uint64_t)per_cu * num_cus >= m.grid;
-            if (const char *f = getenv("TKSPMV_INLINE_REPAIR")) m.inline_repair = m.inline_repair && atoi(f) != 0;
         }
         m.info.state_bytes = ns * (EngineImpl::GMAX_WORDS * 4 + 2 * EngineImpl::STATE_WORD_STRIDE * 4 + (uint64_t)m.grid * WG_SLOTS * 8) +
                              nl * ((uint64_t)m.ovf_cap * 8 + EngineImpl::STATE_WORD_STRIDE * 4) +
@@ -1924,6 +1920,43 @@ int Engine::time_queries(const float *dev_xs, int32_t n_x, int32_t iters, double
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, m.ev0, m.ev1));
     *ns_per_query = (double)ms * 1e6 / iters;
+    m.ran = true;
+    m.last_on_host = false;
+    return TKSPMV_OK;
+}
+
+// `reps` repetitions of `iters` back-to-back queries, ALL enqueued before the first wait, one hipEvent between consecutive
+// repetitions: ns_per_query[r] = the r-th repetition's time / iters. The GPU never idles between repetitions, so the figures
+// are the kernel's under sustained load -- what tkspmv_time_queries measures when it is called in a loop is the kernel right
+// after a host-side gap, 10-25 % slower for about a millisecond (power management: DESIGN.md).
+int Engine::time_query_batches(const float *dev_xs, int32_t n_x, int32_t iters, int32_t reps, double *ns_per_query, std::string &err) {
+    EngineImpl &m = *impl_;
+    if (!dev_xs || n_x < 1 || iters < 1 || reps < 1 || reps > 4096 || !ns_per_query) {
+        err = "bad arguments to time_query_batches";
+        return TKSPMV_ERR_INVALID;
+    }
+    HIP_TRY(hipSetDevice(m.device));
+    HIP_TRY(m.leave_resident_mode());
+    HIP_TRY(hipStreamSynchronize(m.stream));
+    std::vector<hipEvent_t> evs((size_t)reps + 1);
+    for (auto &e : evs) HIP_TRY(hipEventCreate(&e));
+    std::vector<const float *> xs;
+    std::vector<uint32_t *> oi;
+    std::vector<float *> ov;
+    sequence_lists(m, dev_xs, n_x, iters, m.d_out_idx, m.d_out_val, 0, xs, oi, ov);
+    HIP_TRY(hipEventRecord(evs[0], m.stream));
+    for (int r = 0; r < reps; ++r) {
+        m.launch_sequence(xs.data(), oi.data(), ov.data(), iters, m.stream);
+        HIP_TRY(hipEventRecord(evs[(size_t)r + 1], m.stream));
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventSynchronize(evs[(size_t)reps]));
+    for (int r = 0; r < reps; ++r) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, evs[(size_t)r], evs[(size_t)r + 1]));
+        ns_per_query[r] = (double)ms * 1e6 / iters;
+    }
+    for (auto &e : evs) (void)hipEventDestroy(e);
     m.ran = true;
     m.last_on_host = false;
     return TKSPMV_OK;

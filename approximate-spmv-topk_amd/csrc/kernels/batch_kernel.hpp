@@ -89,17 +89,13 @@ struct BatchParams : SetAddr {
     // in the previous query: pace_quads units of s_sleep(2) = 128 cycles, times pace_levels, pace_levels - 1, ..., 1 for the first,
     // second, ... eighth of the field (pace_levels = 3: three eighths pause).
     uint32_t pace_quads, pace_levels;
-    // ---- the verdict of a launch's checks and the repair phase ------------------------------------------------------------------
-    // Every checked selection of a launch adds 1 | failed << (32 + q) to the launch's verdict word (one 64-bit atomic: the count of
-    // finished selections and the set of failed queries travel together). When the count reaches n_q the launch knows which
-    // queries to run again with the device-wide exchange: inside the same launch (inline_repair = 1: every workgroup waits for
-    // the verdict when it has finished its queries -- nobody has anything else to do, the launch cannot end before its last
-    // selection anyway -- and almost always leaves at once), or, on a GPU that cannot hold the whole grid at once, in a second
-    // launch of the same kernel (repair = 1) that reads the completed word. Round 3 launched that second kernel behind EVERY
-    // batch launch: 4-5 us per 32 queries for nothing.
+    // ---- the verdict of a launch's checks and the repair launch -----------------------------------------------------------------
+    // Every checked selection of a LOCAL launch adds 1 | failed << (32 + q) to the launch's verdict word (one 64-bit atomic: the
+    // count of finished selections and the set of failed queries travel together). The exact launch behind it (repair = 1) reads the
+    // completed word and runs the named queries again with the device-wide exchange -- none, almost always.
     unsigned long long *verdict;       // this launch's word
     unsigned long long *verdict_next;  // the next launch's word: zeroed by this one
-    uint32_t inline_repair, repair;
+    uint32_t repair;
     // ---- overflow lists of the exact mode: ovf_lists of them (2), used round robin by the queries of a phase under flow control --
     // A list must be able to hold EVERY row (x = 0 makes every row a candidate and the result must still be exact): 8 bytes per
     // row. Round 3 kept one per query of a launch (256 MB at 1M rows, 2.6 GB at 10M); now query j of a phase uses list
@@ -215,27 +211,6 @@ __device__ __forceinline__ void finalize_local_wave(const unsigned long long *st
     }
 }
 
-// The two selections of the batch kernel as functions of their own (NOT inlined): inlined, their scalar state -- two parameter
-// blocks, a dozen pointers -- is spilled into vector registers that the whole kernel then reserves, the streaming loop included,
-// and the streaming waves have none to spare (80: two 576-thread workgroups per CU). Only selector workgroups ever call them.
-#ifndef TKSPMV_SELECT_INLINE
-#define TKSPMV_SELECT_INLINE 0
-#endif
-#if TKSPMV_SELECT_INLINE
-#define TKSPMV_SELECT_CALL __forceinline__
-#else
-#define TKSPMV_SELECT_CALL __attribute__((noinline))
-#endif
-template <class LDS>
-__device__ TKSPMV_SELECT_CALL bool batch_select_local(const LocalParams *G, const SelectParams *S, uint32_t n_stream, LDS *L, float out_scale,
-                                                             unsigned long long *stamps) {
-    return select_local(*G, *S, n_stream, threadIdx.x, blockDim.x, L->u.lsel, out_scale, stamps);
-}
-template <class LDS>
-__device__ TKSPMV_SELECT_CALL void batch_select_exact(const SelectParams *S, LDS *L, unsigned long long *stamps) {
-    select_body<false>(*S, threadIdx.x, blockDim.x, L->u.sel, 0u, stamps);
-}
-
 // The gate's bookkeeping (BatchParams::gate_parity), by ONE thread per launch: `failed` checks among the launch's n_q.
 __device__ __forceinline__ void gate_update(const BatchParams &B, uint32_t failed) {
     uint32_t *g = B.prior_block;
@@ -262,7 +237,7 @@ __device__ __forceinline__ void gate_update(const BatchParams &B, uint32_t faile
 // One PHASE of a launch: phase 0 = the launch's n_q queries in the mode the host chose (B.local, the gate permitting); phase 1 =
 // the queries whose check failed in phase 0 (L.rq), with the device-wide exchange. Returning from here ends the phase for the
 // calling wave; the kernel below puts the phases together.
-template <int C, int XCOLS, int QM, bool DBG, bool RESIDENT>
+template <int C, int XCOLS, int QM, bool DBG, bool RESIDENT, bool LOCAL>
 __device__ __forceinline__ void batch_phase(const StreamParams &P0, const SelectParams &SP0, const BatchParams &B, const bool repair,
                                             BatchLds<XCOLS, C> &L) {
     constexpr bool Q8 = QM == 1 || QM == 2;  // x staged as Q1.7 integers
@@ -275,16 +250,16 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t nwaves = (blockDim.x >> 6) - 1u;  // streaming waves
     const bool is_server = (wave == nwaves);
-    // (closed gate: the launch runs with the device-wide exchange, like a repair phase does)
-    const bool local_open = B.local != 0u && !(B.prior_block && B.prior_block[B.gate_parity ? 7 : 4] != 0u);
+    // (LOCAL: the kernel of the checked local thresholds -- the caller has looked at the gate; else the device-wide exchange)
+    constexpr bool local_open = LOCAL;
     const uint32_t nq = RESIDENT ? 0xFFFFFFF0u : (repair ? L.rq[BATCH_MAX] : B.n_q);
     // query q of THIS phase in the launch's argument block (repair: the q-th flagged query)
     auto qx = [&](uint32_t q) __attribute__((always_inline)) -> uint32_t { return repair ? L.rq[q] : q; };
     // exchange-state set / ticket counter of query q (resident: the sets are reused round robin -- one query is in flight)
     auto set_of = [&](uint32_t q) __attribute__((always_inline)) -> uint32_t { return RESIDENT ? q % (uint32_t)BATCH_MAX : qx(q); };
-    const bool local = !RESIDENT && !repair && local_open;
+    constexpr bool local = LOCAL;  // (compile-time: the two modes are two kernels, neither carries the other's code or registers)
     const bool local_top1 = B.local == 1u;  // a wave's word is its best packet maximum (1) or its second best (2)
-    const uint32_t pace_q = (RESIDENT || repair || !local_open) ? 0u : B.pace_quads;
+    const uint32_t pace_q = LOCAL ? B.pace_quads : 0u;
     // Overflow list of query q of this phase and the value its epoch word must show before anything may be appended: the
     // selections of the list's earlier users in this phase have finished (L.epoch0: the words as the phase found them).
     constexpr uint32_t n_lists = 4u;  // (BatchParams::ovf_lists: the engine allocates four)
@@ -377,7 +352,7 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
                 S.host_out = nullptr;
                 const float out_scale = __hip_atomic_load(B.unit_inv(set_of(q)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (tr_sel && tid == 0) P0.trace[10] = __builtin_amdgcn_s_memrealtime();
-                const bool bad = batch_select_local(&G, &S, n_stream, &L, out_scale, tr_sel ? P0.trace + 11 : nullptr);
+                const bool bad = select_local(G, S, n_stream, tid, blockDim.x, L.u.lsel, out_scale, tr_sel ? P0.trace + 11 : nullptr);
                 __syncthreads();
                 if (tid == 0 && B.verdict)
                     (void)__hip_atomic_fetch_add(B.verdict, 1ull | ((bad ? 1ull : 0ull) << (32u + q)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -400,8 +375,7 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
                 //  starts from it -- exact when the same vector comes back, tools/ablate_probe.py)
                 const uint32_t keep_tau = (DBG && (P0.dbg_flags & 16u)) ? __hip_atomic_load(S.tau_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
                 if (tr_sel && tid == 0) P0.trace[10] = __builtin_amdgcn_s_memrealtime();
-                if (RESIDENT) select_body<false>(S, tid, blockDim.x, L.u.sel, 0u, nullptr);  // (the resident kernel has one selection and no repair phase: inlined as it always was)
-                else batch_select_exact(&S, &L, tr_sel ? P0.trace + 8 : nullptr);
+                select_body<false>(S, tid, blockDim.x, L.u.sel, 0u, tr_sel ? P0.trace + 8 : nullptr);
                 // the list is free for its next user: its count was reset (written through) and drained above
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
@@ -411,9 +385,6 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
             if (tr_sel && tid == 0) P0.trace[15] = __builtin_amdgcn_s_memrealtime();
             if (P0.trace && tid == 0 && q < 8u) P0.trace[q] = __builtin_amdgcn_s_memrealtime();
         }
-        // (a launch behind a closed gate makes no checks and has no verdict: its last act is to count the closure down -- every
-        //  streaming workgroup has read the gate by now: this selector has seen all their tickets)
-        if (!RESIDENT && !repair && blockIdx.x == 0u && tid == 0u && B.local != 0u && !local_open && B.inline_repair != 0u) gate_update(B, 0u);
         return;
     }
     const uint32_t bid = blockIdx.x - nsel, n_wg = gridDim.x - nsel;
@@ -917,34 +888,23 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
 #undef TRSLOT
 }
 
-// The launch: phase 0, then -- if checks were made and some failed -- the repair phase (see BatchParams::verdict).
-// The kernel's arguments as ONE block: the repair phase is a function of its own (below) and reads them where the dispatch put
-// them (the kernarg segment) instead of having 1.5 KB of parameters copied for it.
+// The kernel's arguments as ONE block.
 struct BatchArgs {
     StreamParams P;
     SelectParams S;
     BatchParams B;
 };
 
-// The repair phase, NOT inlined. It runs in one launch of thousands; inlined -- as a second copy of the phase or as a loop around
-// the first -- it cost the streaming loop of EVERY launch three reloads from scratch memory per packet (the kernel has no register
-// to spare: 80, two 576-thread workgroups per CU; measured: twice the time per query). As a function it has its own
-// registers; the price is paid in the repair phase only -- its LDS object arrives as a generic pointer.
-template <int C, int XCOLS, int QM, bool DBG>
-__device__ __attribute__((noinline)) void batch_repair_phase(const BatchArgs *args, BatchLds<XCOLS, C> *L) {
-    const BatchArgs &A = *args;  // (the kernel's own argument block in the kernarg segment: the KERNEL takes its address)
-    StreamParams P0 = A.P;
-    if (!DBG) {
-        P0.trace = nullptr;
-        P0.dbg = nullptr;
-        P0.stamps = nullptr;
-        P0.dbg_flags = 0u;
-        P0.dbg_repeat = 0u;
-    }
-    batch_phase<C, XCOLS, QM, DBG, false>(P0, A.S, A.B, true, *L);
-}
-
-template <int C, int XCOLS, int QM, bool DBG = false, bool RESIDENT = false>
+// Two kernels, one per mode (round 4 first had both modes, both selections and an in-launch repair phase in ONE kernel: the
+// streaming loop, which has no register to spare -- 80: two 576-thread workgroups per CU --, paid for the other paths' scalar
+// state with reloads from scratch memory, twice the time per query; moved out of line, the rare paths still cost every launch
+// its scratch set-up and 3-8 % -- measured A/B on one box, tools/steps_probe.py):
+//   LOCAL = true : the checked local thresholds. Streams, delivers the workgroups' records, select_local checks them and adds to
+//                  the launch's verdict. Behind a closed gate it does nothing but report every query as failed.
+//   LOCAL = false: the device-wide exchange, exact on its own. B.repair = 0: the launch's n_q queries (engines that do not use
+//                  local thresholds); B.repair = 1: the queries the verdict of the LOCAL launch before it names -- none, almost
+//                  always: every workgroup reads one word and leaves -- and the gate's bookkeeping.
+template <int C, int XCOLS, int QM, bool DBG = false, bool RESIDENT = false, bool LOCAL = false>
 __global__ void __launch_bounds__(576, 6) batch_kernel(const BatchArgs A) {
     StreamParams P0 = A.P;
     const SelectParams &SP0 = A.S;
@@ -957,42 +917,40 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const BatchArgs A) {
         P0.dbg_repeat = 0u;
     }
     __shared__ BatchLds<XCOLS, C> L;
+    const uint32_t tid = threadIdx.x;
     if (RESIDENT) {
-        batch_phase<C, XCOLS, QM, DBG, RESIDENT>(P0, SP0, B, false, L);
+        batch_phase<C, XCOLS, QM, DBG, true, false>(P0, SP0, B, false, L);
         return;
     }
-    const uint32_t tid = threadIdx.x;
-    const bool checks = B.local != 0u && B.verdict != nullptr && !(B.prior_block && B.prior_block[B.gate_parity ? 7 : 4] != 0u);  // phase 0 of this launch makes checks
-    if (B.repair == 0u) {
+    if (LOCAL) {
         if (blockIdx.x == 0u && tid == 0u && B.verdict_next) __hip_atomic_store(B.verdict_next, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        batch_phase<C, XCOLS, QM, DBG, RESIDENT>(P0, SP0, B, false, L);
-        if (!checks || B.inline_repair == 0u) return;
-    }
-    // ---- the verdict: which queries of phase 0 failed their check? (a launch of its own for the repair phase: the word is
-    // complete; the same launch: wait for the last selection) ----------------------------------------------------------------
-    __syncthreads();
-    if (tid == 0u) {
-        unsigned long long v;
-        for (;;) {
-            v = __hip_atomic_load(B.verdict, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((uint32_t)v >= B.n_q || B.repair != 0u) break;
-            __builtin_amdgcn_s_sleep(32);
+        if (B.prior_block && B.prior_block[B.gate_parity ? 7 : 4] != 0u) {
+            // the gate is closed: nothing is streamed here; every query goes through the exact launch that follows
+            if (blockIdx.x == 0u && tid == 0u)
+                __hip_atomic_store(B.verdict, (unsigned long long)B.n_q | ((B.n_q >= 32u ? 0xFFFFFFFFull : ((1ull << B.n_q) - 1ull)) << 32), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            return;
         }
-        L.rq[BATCH_MAX + 1] = (uint32_t)(v >> 32);
+        batch_phase<C, XCOLS, QM, DBG, false, true>(P0, SP0, B, false, L);
+        return;
     }
-    __syncthreads();
-    const uint32_t mask = L.rq[BATCH_MAX + 1];
-    __syncthreads();
-    if (tid < 64u) {
-        const bool f = tid < B.n_q && ((mask >> tid) & 1u) != 0u;
-        const uint64_t bm = __ballot(f);
-        if (f) L.rq[__builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u))] = tid;
-        if (tid == 0) L.rq[BATCH_MAX] = (uint32_t)__popcll(bm);
+    if (B.repair != 0u) {
+        // ---- which queries of the LOCAL launch failed their check? (that launch is over: the word is complete) ------------------
+        const unsigned long long v = __hip_atomic_load(B.verdict, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t mask = (uint32_t)(v >> 32);
+        const bool gate_was_closed = B.prior_block && B.prior_block[B.gate_parity ? 7 : 4] != 0u;
+        if (tid < 64u) {
+            const bool f = tid < B.n_q && ((mask >> tid) & 1u) != 0u;
+            const uint64_t bm = __ballot(f);
+            if (f) L.rq[__builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u))] = tid;
+            if (tid == 0) L.rq[BATCH_MAX] = (uint32_t)__popcll(bm);
+        }
+        __syncthreads();
+        // (behind a closed gate the queries did not fail, they were never tried: the closure counts down)
+        if (blockIdx.x == 0u && tid == 0u && B.prior_block) gate_update(B, gate_was_closed ? 0u : L.rq[BATCH_MAX]);
+        if (L.rq[BATCH_MAX] == 0u) return;
     }
-    __syncthreads();
-    if (blockIdx.x == 0u && tid == 0u && B.prior_block && B.local != 0u) gate_update(B, L.rq[BATCH_MAX]);
-    if (L.rq[BATCH_MAX] == 0u) return;
-    batch_repair_phase<C, XCOLS, QM, DBG>(reinterpret_cast<const BatchArgs *>((uintptr_t)__builtin_amdgcn_kernarg_segment_ptr()), &L);
+    batch_phase<C, XCOLS, QM, DBG, false, false>(P0, SP0, B, B.repair != 0u, L);
 }
 
 }  // namespace tkspmv

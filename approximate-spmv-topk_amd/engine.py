@@ -112,6 +112,13 @@ class SpMV:
         _lib.check(_lib.lib().tkspmv_time_queries(self._h, C.c_void_p(int(dev_xs)), int(n_x), int(iters), C.byref(ns)))
         return ns.value
 
+    def time_query_batches(self, dev_xs, n_x, iters, reps):
+        """`reps` batches of `iters` back-to-back queries, all enqueued before the first wait: ns per query of every batch (the GPU
+        never idles between them: the kernel under sustained load)."""
+        out = (C.c_double * int(reps))()
+        _lib.check(_lib.lib().tkspmv_time_query_batches(self._h, C.c_void_p(int(dev_xs)), int(n_x), int(iters), int(reps), out))
+        return [float(v) for v in out]
+
     def time_stream_read(self, passes):
         """ns per pass of a kernel that only loads the engine's packet stream (engine geometry, one launch, rotating
         stream copies): the floor this GPU sets for any kernel that streams the matrix (measurement aid)."""

@@ -465,13 +465,45 @@ def bench_single(a, mod, torch, np, dev, local_rank):
     # ---- parity of the last timed query against the oracle
     val, idx = eng.read_result()
     parity_ok, parity = check_parity(mod, m, xs[(a.steps - 1) % a.queries], a.k, idx, val, eng)
-    # ---- repetitions (reference hygiene: >= 30 runs, first 2 dropped, host_spmv_bscsr.cpp:699)
+    # ---- repetitions (reference hygiene: >= 30 runs, first 2 dropped, host_spmv_bscsr.cpp:699). All repetitions are enqueued
+    # before the first wait (tkspmv_time_query_batches: one hipEvent between consecutive ones), so the GPU never idles between
+    # them: median / p95 of the kernel under sustained load. The same batch timed one call at a time -- each behind a
+    # synchronisation and a host-side gap, after which this GPU runs 10-25 % slower for about a millisecond -- is kept beside it.
+    counters = eng.debug_counters()  # (of the timed region and its warm-up: checks of the local thresholds, repairs, gate)
     n_rep = min(max(a.steps, 32), 512)
-    reps = [eng.time_queries(dxs.data_ptr(), a.queries, n_rep) / 1e3 for _ in range(max(a.reps, 30) + 2)][2:]
+    n_reps = max(a.reps, 30) + 2
+    reps = [v / 1e3 for v in eng.time_query_batches(dxs.data_ptr(), a.queries, n_rep, n_reps)][2:]
+    gap = [eng.time_queries(dxs.data_ptr(), a.queries, n_rep) / 1e3 for _ in range(10)][2:]
     timing = {"repetitions": len(reps), "dropped": 2, "queries_per_repetition": n_rep,
               "kernel_us_median": pct(reps, 50), "kernel_us_p95": pct(reps, 95), "kernel_us_mean": float(np.mean(reps)),
-              "frac_at_median": alg_bytes / (pct(reps, 50) * 1e3) / HBM_PEAK_GBS}
+              "p95_over_median": pct(reps, 95) / pct(reps, 50),
+              "frac_at_median": alg_bytes / (pct(reps, 50) * 1e3) / HBM_PEAK_GBS,
+              "method": "tkspmv_time_query_batches: every repetition enqueued before the first wait, a hipEvent between "
+                        "consecutive repetitions (no host-side gap between them)",
+              "one_call_per_repetition": {"repetitions": len(gap), "kernel_us_median": pct(gap, 50), "kernel_us_max": max(gap),
+                                          "note": "each repetition behind a synchronisation and a host-side gap"}}
     extra = {"parity_checked": parity_ok, "parity": parity, "timing": timing, "host_side": host_side}
+    extra["thresholds"] = {"checks_failed": counters["checks_failed"], "carried_thresholds_suspended_for": counters["suspended_for"],
+                           "gate_closed_for_launches": counters["local_off_for_launches"], "batch_launches": counters["batch_launches"],
+                           "note": "workgroup-local thresholds are checked by every selection; a failed check repeats the query inside "
+                                   "the same launch with the device-wide exchange (counters of the warm-up + timed region)"}
+    # ---- a stream of queries that is NOT stationary: the same matrix, every query scaled by 1, 0.01 or 3 (drawn per query):
+    # carried thresholds are invalidated again and again, checks fail, queries are repeated -- what the mode costs then
+    rng = np.random.default_rng(11)
+    sc = rng.choice([1.0, 0.01, 3.0], size=a.queries).astype(np.float32)
+    dxs_ns = torch.from_numpy(np.ascontiguousarray(xs * sc[:, None])).to(dev)
+    c0 = eng.debug_counters()
+    eng.time_queries(dxs_ns.data_ptr(), a.queries, 64)
+    ns_ns = [v / 1e3 for v in eng.time_query_batches(dxs_ns.data_ptr(), a.queries, n_rep, 8)][2:]
+    val_ns, idx_ns = eng.read_result()
+    ok_ns, _ = check_parity(mod, m, (xs * sc[:, None])[(n_rep - 1) % a.queries], a.k, idx_ns, val_ns, eng)
+    c1 = eng.debug_counters()
+    extra["nonstationary"] = {"kernel_us_median": pct(ns_ns, 50), "queries": 64 + 8 * n_rep, "scales": [1.0, 0.01, 3.0],
+                              "checks_failed": c1["checks_failed"] - c0["checks_failed"],
+                              "gate_closed_for_launches": c1["local_off_for_launches"], "parity_checked": ok_ns,
+                              "note": "same matrix, every query scaled by 1, 0.01 or 3 at random: a failed check costs the query a "
+                                      "second pass; a launch of which a quarter fails closes the gate (device-wide exchange) for 8+ launches"}
+    eng.time_queries(dxs.data_ptr(), a.queries, 256)  # (back to the stationary stream: thresholds carried again)
     # ---- what this GPU charges for only LOADING the same stream (engine geometry, no arithmetic): boxes differ by several %
     read_us = sorted(eng.time_stream_read(64) / 1e3 for _ in range(7))[3]
     c12 = os.environ.get("TKSPMV_F32_C12", "1") != "0" and a.cols <= 1024 and int(info["packet_entries"]) == 256
@@ -483,6 +515,7 @@ def bench_single(a, mod, torch, np, dev, local_rank):
                            "median of 7",
                  "headline_kernel_vs_read_only": read_us / (kernel_ns / 1e3),
                  "median_kernel_vs_read_only": read_us / pct(reps, 50)}
+    extra["exchange_state_bytes"] = int(info.get("state_bytes", 0))
     if not a.skip_warm:
         extra["single_query"] = single_query_leg(mod, m, xs, dxs, a, local_rank, eng, alg_bytes)
         prof = eng.profile(dxs.data_ptr(), a.queries, 100)
@@ -497,9 +530,14 @@ def bench_single(a, mod, torch, np, dev, local_rank):
         t1 = time.perf_counter()
         warm_ns = warm.time_queries(dxs.data_ptr(), a.queries, max(a.steps, 64))
         warm_elapsed = time.perf_counter() - t1
+        warm_ns = min(warm_ns, min(warm.time_query_batches(dxs.data_ptr(), a.queries, 256, 6)[2:]))
+        warm_read = sorted(warm.time_stream_read(64) / 1e3 for _ in range(5))[2]
         warm.close()
         extra["cache_warm"] = {"value": max(a.steps, 64) / warm_elapsed, "unit": "queries/s", "kernel_us": warm_ns / 1e3,
                                "achieved_GBps": alg_bytes / warm_ns,
+                               # the load-only probe over the SAME single copy (it fits the Infinity Cache): if it sits where the
+                               # cache-defeated floor sits, what bounds a streaming kernel here is not HBM but what the CUs can take in
+                               "read_only_us_per_pass": warm_read, "kernel_vs_read_only": warm_read / (warm_ns / 1e3),
                                "note": "one matrix (118 MB packed) re-read every query: served largely by the 256 MiB "
                                        "Infinity Cache, not comparable with the HBM roofline"}
         if a.multi_q:

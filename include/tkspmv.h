@@ -242,6 +242,10 @@ int tkspmv_debug_counters(tkspmv_t *e, uint64_t *out, int32_t n);
 /* `iters` queries back to back on the engine stream (cycling over n_x device-resident vectors), ONE hipEvent pair
  * around the batch: *ns_per_query = batch time / iters. Nothing else is launched (for profiler runs). */
 int tkspmv_time_queries(tkspmv_t *e, const float *dev_xs, int32_t n_x, int32_t iters, double *ns_per_query);
+/* `reps` such batches back to back, all enqueued before the first wait, a hipEvent between consecutive ones: ns_per_query[r] =
+ * time of batch r / iters. The GPU does not idle between batches (a batch that follows a host-side gap runs 10-25 % slower for
+ * about a millisecond: power management), so median and p95 of these are the kernel's under sustained load. reps <= 4096. */
+int tkspmv_time_query_batches(tkspmv_t *e, const float *dev_xs, int32_t n_x, int32_t iters, int32_t reps, double *ns_per_query);
 /* Measurement aid: `passes` passes over the engine's packet stream (rotating its stream copies) by a kernel with the
  * engine's launch geometry that only LOADS the packets -- no x, no arithmetic, no selection -- in ONE launch, inside one
  * hipEvent pair: *ns_per_pass = what moving the stream from HBM into registers costs on this GPU. bench.py prints the
