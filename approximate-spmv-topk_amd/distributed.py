@@ -167,11 +167,14 @@ class NativeShardedSpMV:
             for i, b in enumerate(t.cpu().tolist()):
                 idbuf[i] = b
         self._h = C.c_void_p()
-        _lib.check_dist(_lib.lib().tkspmv_dist_create(C.byref(self._h), engine._h, idbuf, rank, world))
+        try:
+            _lib.check_dist(_lib.lib().tkspmv_dist_create(C.byref(self._h), engine._h, idbuf, rank, world))
+        finally:
+            if host_exchange:  # (whatever tkspmv_dist_create did: a later communicator must not inherit the switch)
+                os.environ.pop("TKSPMV_DIST_NO_NCCL", None)
         self.world, self.rank = world, rank
         self._cb = None
         if host_exchange:
-            os.environ.pop("TKSPMV_DIST_NO_NCCL", None)
 
             def _allgather(send, recv, nbytes, user):  # noqa: ARG001
                 try:
