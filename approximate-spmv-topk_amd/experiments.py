@@ -63,9 +63,72 @@ def bscsr_packet_size(fixed_width):
     return (512 - 1) // (int(fixed_width) + 10 + 4)
 
 
-def hls_dataflow_topk(row, scores, rows, k, partitions=32, k_per_list=8, packet_entries=15, limited=4):
-    """The candidate set the reference's HLS cores deliver, from EXACT per-row scores (this engine's SpMV-only kernel in the same
-    arithmetic: `SpMV(..., precision=FIXED, fixed_width=W).scores()`): a host-side transform of the matrix's row structure.
+def _to_fixed(v, width):
+    """ap_ufixed<W,1,AP_TRN_ZERO> of a float as an integer in units of 2^-(W-1): negatives and NaN become 0, values of 2.0 and
+    above saturate at 2^W - 1, everything else is truncated (the conversion the reference's packer applies, types.hpp:57-79)."""
+    v = np.asarray(v, dtype=np.float64)
+    d = np.where(v > 0, v, 0.0) * float(1 << (width - 1))
+    return np.minimum(np.floor(d), float((1 << width) - 1)).astype(np.uint64)
+
+
+def _streamed_list(values, ids, k_per_list):
+    """One K-list of the reference's cores, entry by entry (spmv_bscsr_top_k_multicore.hpp:331-409): a zero-initialised list, an
+    offer replaces the current worst when it is >= it, the worst is the FIRST minimum. Returns the list's (values, ids)."""
+    res = [0] * k_per_list
+    idx = [0] * k_per_list
+    worst, worst_val = 0, 0
+    for v, i in zip(values.tolist(), ids.tolist()):
+        if v >= worst_val:
+            res[worst], idx[worst] = v, i
+            worst_val = min(res)
+            worst = res.index(worst_val)
+    return res, idx
+
+
+def _hls_lists(list_id, values, ids, k_per_list):
+    """The content of every K-list after its offers (given in arrival order; list_id sorted stably by the caller is not required).
+    Lists whose K-th value is shared by more offers than there are places left are replayed entry by entry (which of the equal
+    offers survive depends on the positions they landed in); all others are the K largest offers. Returns (list_id, value, id)
+    of the surviving entries, grouped by list."""
+    if values.shape[0] == 0:
+        return list_id, values, ids
+    arrival = np.arange(values.shape[0])
+    order = np.lexsort((arrival, list_id))
+    li, vi, ri = list_id[order], values[order], ids[order]
+    start = np.ones(li.shape[0], bool)
+    start[1:] = li[1:] != li[:-1]
+    g = np.cumsum(start) - 1
+    gstart = np.flatnonzero(start)
+    # rank from the top by value inside each list
+    o2 = np.lexsort((vi, g))
+    size = np.bincount(g)
+    pos = np.arange(li.shape[0]) - gstart[g[o2]]
+    from_top = size[g[o2]] - 1 - pos
+    keep_sorted = from_top < k_per_list
+    keep = np.zeros(li.shape[0], bool)
+    keep[o2[keep_sorted]] = True
+    # the K-th value of the lists that overflow, and how many offers share it
+    full = size > k_per_list
+    kth = np.zeros(size.shape[0], dtype=vi.dtype)
+    sel = from_top == k_per_list - 1
+    kth[g[o2][sel]] = vi[o2][sel]
+    at_kth = (vi == kth[g]) & full[g]
+    n_at = np.bincount(g, weights=at_kth, minlength=size.shape[0])
+    n_above = np.bincount(g, weights=(vi > kth[g]) & full[g], minlength=size.shape[0])
+    replay = np.flatnonzero(full & (n_at > k_per_list - n_above))
+    out_l, out_v, out_i = [li[keep & ~np.isin(g, replay)]], [vi[keep & ~np.isin(g, replay)]], [ri[keep & ~np.isin(g, replay)]]
+    for gg in replay:
+        a, b = gstart[gg], gstart[gg] + size[gg]
+        res, idx = _streamed_list(vi[a:b], ri[a:b], k_per_list)
+        out_l.append(np.full(k_per_list, li[a], dtype=li.dtype))
+        out_v.append(np.asarray(res, dtype=vi.dtype))
+        out_i.append(np.asarray(idx, dtype=ri.dtype))
+    return np.concatenate(out_l), np.concatenate(out_v), np.concatenate(out_i)
+
+
+def hls_dataflow_topk(row, scores, rows, k, partitions=32, k_per_list=8, packet_entries=15, limited=4, overfull="count",
+                      col=None, val=None, vec=None, fixed_width=0, ids="core"):
+    """The candidate set the reference's HLS cores deliver: a host-side transform of the matrix's row structure.
 
     The design keeps, per partition of ceil(rows / partitions) rows (host_spmv_bscsr.cpp:133-141), `limited` independent lists
     of k_per_list entries -- one per packet SLOT (spmv_bscsr_top_k_multicore.hpp:331-409): a row that finishes inside a packet
@@ -74,12 +137,34 @@ def hls_dataflow_topk(row, scores, rows, k, partitions=32, k_per_list=8, packet_
     that finish inside one packet are lost, and so is the last row of every partition (its flush is commented out, :396-403).
     The host keeps every list entry with a positive value, one per row id, and sorts (host_spmv_bscsr.cpp:399-448).
 
-    Not modelled here: a packet with MORE than `limited` row segments also drops the products of the segments beyond and
-    shifts the row ids the core reports for the rest of its partition (:104-149,246-326); `overfull_packets` counts them (0 on
-    the BASELINE matrices at 15 entries per packet) and oracle/hls_model.c restates that part too.
+    `limited` is LIMITED_FINISHED_ROWS (types.hpp:75-77). What a packet with MORE than `limited` row segments does is chosen by
+    `overfull`:
+
+      "count"  the STRUCTURAL reading: every row keeps its exact score (`scores[r]`: this engine's SpMV-only kernel in the same
+               arithmetic, `SpMV(..., precision=FIXED, fixed_width=W).scores()`) and its matrix row id; rows beyond the slot lists
+               are lost; `overfull_packets` counts the packets where the cores would do more than that.
+      "model"  the cores as written (spmv_bscsr_top_k_multicore.hpp:104-149,246-326): only the first `limited` segments of a packet
+               are aggregated -- the products of the segments beyond are DROPPED --, the last aggregated segment is taken for the
+               packet's unfinished row (so its sum is carried into the next packet: added to that packet's first segment, or offered
+               to list 0 if the next packet starts a new row), and the row counter advances by the aggregated segments only, so every
+               row id the core reports for the rest of its partition falls behind. Needs the entries (`col`, `val`), the query
+               (`vec`) and `fixed_width` (ap_ufixed<W,1> arithmetic: products truncated to W - 1 fraction bits, sums wrapping at
+               2.0; 0 = fp32, the USE_FLOAT build); `scores` is not used. ids = "core": the ids the core reports (first row of
+               the partition + its own counter: list for list what oracle/hls_model.c restates); ids = "matrix": the matrix row
+               behind each offer instead -- the same dataflow with a row counter that does not slip.
 
     row: row ids of the row-sorted COO; scores[r]: exact score of row r. Returns (idx, val, info): the merged top-k in
     sort_tuples order and info = {candidates, lost_rows, overfull_packets}."""
+    if overfull not in ("count", "model"):
+        raise ValueError("overfull: 'count' or 'model'")
+    if ids not in ("core", "matrix"):
+        raise ValueError("ids: 'core' or 'matrix'")
+    if not (1 <= limited <= packet_entries):
+        raise ValueError("limited: 1 .. packet_entries")
+    if overfull == "model":
+        if col is None or val is None or vec is None:
+            raise ValueError("overfull='model' needs col, val and vec (the products of dropped segments are what is modelled)")
+        return _hls_cores_as_written(row, col, val, vec, rows, k, partitions, k_per_list, packet_entries, limited, int(fixed_width), ids)
     row = np.asarray(row, dtype=np.int64)
     scores = np.asarray(scores, dtype=np.float32)
     per = (int(rows) + partitions - 1) // partitions
@@ -109,30 +194,131 @@ def hls_dataflow_topk(row, scores, rows, k, partitions=32, k_per_list=8, packet_
     ends_per_packet = np.bincount(pk_inv[ends], minlength=pk_ids.shape[0]) if ends.size else np.zeros(pk_ids.shape[0], np.int64)
     trailing = np.ones(pk_ids.shape[0], np.int64)
     trailing[pk_inv[ends[at_packet_end]]] = 0
-    overfull = int((ends_per_packet + trailing > limited).sum())
+    overfull_n = int((ends_per_packet + trailing > limited).sum())
     r_ids = row[ends]
-    val = scores[r_ids]
-    keep = offered & (val > 0)
+    val_r = scores[r_ids]
+    keep = offered & (val_r > 0)
     lists = part[ends] * limited + slot
-    cand_idx, cand_val = [], []
-    if keep.any():
-        li, ri, vi = lists[keep], r_ids[keep], val[keep]
-        order = np.lexsort((ri, vi, li))  # by list, then value, then row id (ascending)
-        li, ri, vi = li[order], ri[order], vi[order]
-        # rank from the top inside each list
-        idx_in = np.arange(li.shape[0])
-        start = np.ones(li.shape[0], bool)
-        start[1:] = li[1:] != li[:-1]
-        gstart = np.maximum.accumulate(np.where(start, idx_in, 0))
-        size = np.bincount(np.cumsum(start) - 1)[np.cumsum(start) - 1]
-        from_top = size - 1 - (idx_in - gstart)
-        top = from_top < k_per_list
-        cand_idx, cand_val = ri[top], vi[top]
+    _, cand_val, cand_idx = _hls_lists(lists[keep], val_r[keep], r_ids[keep], k_per_list)
     cand_idx = np.asarray(cand_idx, dtype=np.uint32)
     cand_val = np.asarray(cand_val, dtype=np.float32)
+    pos = cand_val > 0
+    cand_idx, cand_val = cand_idx[pos], cand_val[pos]
     order = np.lexsort((cand_idx, cand_val))[::-1][:k]  # (value desc, row id desc) = sort_tuples
-    info = {"candidates": int(cand_idx.shape[0]), "lost_rows": int((~offered).sum()), "overfull_packets": overfull}
+    info = {"candidates": int(cand_idx.shape[0]), "lost_rows": int((~offered).sum()), "overfull_packets": overfull_n}
     return cand_idx[order], cand_val[order], info
+
+
+def _hls_cores_as_written(row, col, val, vec, rows, k, partitions, k_per_list, B, limited, W, ids):
+    """overfull = "model" of hls_dataflow_topk: the packer's segments (host_spmv_bscsr.cpp:189-246), the aggregation of the
+    first `limited` of them (spmv_bscsr_top_k_multicore.hpp:104-149), loop 3's carry and row numbering (:246-326), loop 4's
+    lists (:331-409) and read_result's merge (host_spmv_bscsr.cpp:399-448), vectorised over all packets of all partitions."""
+    if W != 0 and not (8 <= W <= 32):
+        raise ValueError("fixed_width: 0 (fp32) or 8..32")
+    row = np.asarray(row, dtype=np.int64)
+    col = np.asarray(col, dtype=np.int64)
+    nnz = row.shape[0]
+    per = (int(rows) + partitions - 1) // partitions
+    part = row // per
+    first_of_part = np.searchsorted(part, np.arange(partitions + 1))
+    part_len = first_of_part[1:] - first_of_part[:-1]
+    n_pk = (part_len + B - 1) // B
+    pk_base = np.concatenate(([0], np.cumsum(n_pk)))
+    total_pk = int(pk_base[-1])
+    gp = pk_base[part] + (np.arange(nnz, dtype=np.int64) - first_of_part[part]) // B  # packet of every entry, numbered through
+    # segments: runs of one row inside one packet
+    seg_start = np.ones(nnz, bool)
+    seg_start[1:] = (row[1:] != row[:-1]) | (gp[1:] != gp[:-1])
+    seg_first = np.flatnonzero(seg_start)
+    seg_gp = gp[seg_first]
+    seg_row = row[seg_first]
+    pk_first_seg = np.searchsorted(seg_gp, np.arange(total_pk))
+    seg_s = np.arange(seg_first.shape[0], dtype=np.int64) - pk_first_seg[seg_gp]
+    nseg = np.bincount(seg_gp, minlength=total_pk)
+    nrip = np.minimum(nseg, limited)  # num_rows_in_packet: only the first `limited` segments are looked at
+    pk_part = np.repeat(np.arange(partitions), n_pk)
+    pk_first_entry = seg_first[pk_first_seg]
+    first_pk_of_part = np.zeros(total_pk, bool)
+    first_pk_of_part[pk_base[:-1][n_pk > 0]] = True
+    # xf: the packet's first entry starts a row other than the one the previous packet ended in; not looked at for packet 0 (:259)
+    starts_new = np.zeros(total_pk, bool)
+    nf = ~first_pk_of_part
+    starts_new[nf] = row[pk_first_entry[nf]] != row[pk_first_entry[nf] - 1]
+    # sums of the segments
+    if W:
+        mask = np.uint64((1 << W) - 1)
+        fv = _to_fixed(val, W)
+        fx = _to_fixed(vec, W)[col]
+        prod = ((fv * fx) >> np.uint64(W - 1)) & mask
+        seg_sum = np.add.reduceat(prod, seg_first) & mask
+    else:
+        prod = np.asarray(val, dtype=np.float32) * np.asarray(vec, dtype=np.float32)[col]
+        seg_len = np.diff(np.concatenate((seg_first, [nnz])))
+        seg_sum = np.zeros(seg_first.shape[0], np.float32)
+        for t in range(int(seg_len.max()) if seg_len.size else 0):  # entry by entry, like the core's adder
+            m = seg_len > t
+            seg_sum[m] = seg_sum[m] + prod[seg_first[m] + t]
+
+    def add(a, b):
+        return ((a + b) & mask) if W else (a + b).astype(np.float32)
+
+    # the carry: the sum of the last AGGREGATED segment, continued through packets that hold one segment of the same row
+    last_kept = pk_first_seg + nrip - 1
+    carry = seg_sum[last_kept].copy()
+    carry_row = seg_row[last_kept]
+    cont = (nrip == 1) & ~starts_new & nf
+    chain = np.zeros(total_pk, np.int64)  # position of a packet inside a run of continuing packets
+    idx_pk = np.arange(total_pk)
+    run_start = np.maximum.accumulate(np.where(~cont, idx_pk, 0))
+    chain[cont] = (idx_pk - run_start)[cont]
+    for d in range(1, int(chain.max()) + 1 if total_pk else 0):
+        m = np.flatnonzero(chain == d)
+        carry[m] = add(carry[m], carry[m - 1])
+    carry_in = np.zeros_like(carry)
+    carry_in[nf] = carry[np.flatnonzero(nf) - 1]
+    carry_in_row = np.full(total_pk, -1, np.int64)
+    carry_in_row[nf] = carry_row[np.flatnonzero(nf) - 1]
+    # loop 3's row numbering: the counter advances by the rows the core SAW finishing
+    finished_rows = nrip + starts_new - 1
+    before = np.cumsum(finished_rows) - finished_rows
+    before -= np.repeat(before[pk_base[:-1][n_pk > 0]], n_pk[n_pk > 0])  # restart in every partition
+    start_row = before + starts_new
+    first_row = np.zeros(partitions, np.int64)
+    first_row[n_pk > 0] = row[first_of_part[:-1][n_pk > 0]]
+    # offers: list 0 <- the carried row when the packet starts a new one; list j <- segment j - 1 for j < num_rows_in_packet
+    o0 = np.flatnonzero(starts_new)
+    sj = np.flatnonzero(seg_s < nrip[seg_gp] - 1)
+    sj_val = seg_sum[sj].copy()
+    joined = (seg_s[sj] == 0) & ~starts_new[seg_gp[sj]]
+    sj_val[joined] = add(sj_val[joined], carry_in[seg_gp[sj][joined]])
+    o_pk = np.concatenate((o0, seg_gp[sj]))
+    o_slot = np.concatenate((np.zeros(o0.shape[0], np.int64), seg_s[sj] + 1))
+    o_val = np.concatenate((carry_in[o0], sj_val))
+    o_core = np.concatenate((start_row[o0] - 1, start_row[seg_gp[sj]] + seg_s[sj])) + first_row[pk_part[o_pk]]
+    o_row = np.concatenate((carry_in_row[o0], seg_row[sj]))
+    arrival = np.lexsort((o_slot, o_pk))
+    o_pk, o_slot, o_val, o_core, o_row = o_pk[arrival], o_slot[arrival], o_val[arrival], o_core[arrival], o_row[arrival]
+    live = o_val > 0  # (an offer of 0 can only replace an entry of 0, and the host skips those)
+    o_id = o_core if ids == "core" else o_row
+    lists = pk_part[o_pk] * limited + o_slot
+    l_id, l_val, l_idx = _hls_lists(lists[live], o_val[live], o_id[live], k_per_list)
+    pos = l_val > 0
+    l_id, l_val, l_idx = l_id[pos], l_val[pos], l_idx[pos]
+    # read_result: lists in order, one entry per id (the first one wins)
+    order = np.lexsort((l_id,))
+    l_id, l_val, l_idx = l_id[order], l_val[order], l_idx[order]
+    _, first = np.unique(l_idx, return_index=True)
+    first.sort()
+    if W:
+        out_val = (l_val[first].astype(np.float64) * math.ldexp(1.0, -(W - 1))).astype(np.float32)
+    else:
+        out_val = l_val[first].astype(np.float32)
+    out_idx = l_idx[first].astype(np.uint32)
+    order = np.lexsort((out_idx, out_val))[::-1][:k]
+    offered_rows = np.unique(o_row[o_row >= 0])
+    info = {"candidates": int(out_idx.shape[0]), "lost_rows": int(np.unique(row).shape[0] - offered_rows.shape[0]),
+            "overfull_packets": int((nseg > limited).sum())}
+    return out_idx[order], out_val[order], info
 
 
 def read_result_csv(path):

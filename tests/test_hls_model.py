@@ -32,6 +32,14 @@ def test_hand_worked_partition(pkg, oracle):
     y = np.bincount(row, weights=val).astype(np.float32)
     _, _, info = ex.hls_dataflow_topk(row, y, 7, 4, partitions=1, k_per_list=2, packet_entries=4, limited=2)
     assert info["overfull_packets"] >= 1
+    # ... and models it when asked to: the same merged list as the restated cores, fp32 arithmetic
+    mi, mv, minfo = ex.hls_dataflow_topk(row, None, 7, 64, partitions=1, k_per_list=2, packet_entries=4, limited=2, overfull="model",
+                                         col=col, val=val, vec=x, fixed_width=0)
+    assert np.array_equal(mi, ci) and np.array_equal(mv.view(np.uint32), cv.view(np.uint32)) and minfo["overfull_packets"] == info["overfull_packets"]
+    # with the matrix's own row ids instead of the core's slipping counter: row 2 is reported as row 2, with the same (wrong) sum
+    ti, tv, _ = ex.hls_dataflow_topk(row, None, 7, 64, partitions=1, k_per_list=2, packet_entries=4, limited=2, overfull="model",
+                                     col=col, val=val, vec=x, fixed_width=0, ids="matrix")
+    assert 1 not in ti.tolist() and float(tv[ti == 2][0]) == 2.0
 
 
 @pytest.mark.parametrize("rows,nnz,dist,seed,W,P,K", [(20000, 20, "gamma", 3, 20, 32, 8), (9000, 20, "uniform", 5, 25, 32, 8),
@@ -71,3 +79,59 @@ def test_short_rows_overfill_packets_and_the_transform_says_so(pkg, oracle):
     _, _, info = ex.hls_dataflow_topk(m.row, y, m.rows, 100, partitions=8, k_per_list=8, packet_entries=15, limited=4)
     assert info["overfull_packets"] > 100
     assert (slot[np.unique(m.row)] == 0xFF).sum() > 100  # many rows are never offered to any list
+
+
+@pytest.mark.parametrize("rows,nnz,dist,seed,W,P,K,limited", [
+    (4000, 4, "gamma", 11, 20, 8, 8, 4), (4000, 4, "gamma", 11, 0, 8, 8, 4), (4000, 3, "uniform", 12, 25, 4, 8, 2),
+    (20000, 20, "gamma", 3, 20, 32, 8, 4), (3000, 2, "uniform", 5, 32, 3, 4, 3), (5000, 6, "gamma", 9, 12, 16, 16, 1),
+    (50000, 8, "gamma", 1, 20, 32, 8, 4)])
+def test_limited_finished_rows_modelled_equals_the_restated_dataflow(pkg, oracle, rows, nnz, dist, seed, W, P, K, limited):
+    """overfull = "model": LIMITED_FINISHED_ROWS as the cores implement it (products of the segments beyond dropped, the last
+    aggregated segment carried, the row counter slipping) -- the product's vectorised transform against the plain-C restatement,
+    list for list and bit for bit, on matrices where hundreds to thousands of packets are overfull; fp32 (W = 0) included."""
+    ex = import_module("approximate_spmv_topk_amd.experiments")
+    m = pkg.generate_matrix(rows, 1024, nnz, dist, seed)
+    x = pkg.create_sample_vector(1024, True, False, True, seed + 100)
+    B = ex.bscsr_packet_size(W) if W else 11
+    ci, cv, slot, local = oracle.hls_model_topk(m.row, m.col, m.val, x, m.rows, P, B, K, limited, W)
+    ei, ev, info = ex.hls_dataflow_topk(m.row, None, m.rows, 4096, partitions=P, k_per_list=K, packet_entries=B, limited=limited,
+                                        overfull="model", col=m.col, val=m.val, vec=x, fixed_width=W)
+    assert np.array_equal(ci, ei) and np.array_equal(cv.view(np.uint32), ev.view(np.uint32))
+    assert info["candidates"] == ci.shape[0] and info["lost_rows"] == int((slot[np.unique(m.row)] == 0xFF).sum())
+    if nnz < 10:
+        assert info["overfull_packets"] > 100
+
+
+@pytest.mark.parametrize("W,K", [(8, 8), (9, 4), (20, 8)])
+def test_modelled_dataflow_with_empty_rows_and_tied_scores(pkg, oracle, W, K):
+    """Rows without entries (the cores number the rows they SEE, so every reported id behind one is off) and 8/9-bit arithmetic
+    (dozens of equal scores at every list's K-th place: which of them survive depends on the positions they landed in -- those
+    lists are replayed entry by entry)."""
+    ex = import_module("approximate_spmv_topk_amd.experiments")
+    m = pkg.generate_matrix(30000, 1024, 5, "gamma", 21)
+    keep = (m.row % 7 != 3) & (m.row % 11 != 0)
+    r, c, v = m.row[keep], m.col[keep], m.val[keep]
+    x = pkg.create_sample_vector(1024, True, False, True, 5)
+    B = ex.bscsr_packet_size(W)
+    ci, cv, slot, local = oracle.hls_model_topk(r, c, v, x, 30000, 16, B, K, 4, W)
+    ei, ev, info = ex.hls_dataflow_topk(r, None, 30000, 4096, partitions=16, k_per_list=K, packet_entries=B, limited=4, overfull="model",
+                                        col=c, val=v, vec=x, fixed_width=W)
+    assert np.array_equal(ci, ei) and np.array_equal(cv.view(np.uint32), ev.view(np.uint32))
+
+
+def test_streamed_list_replay_matches_a_hand_trace():
+    """K = 3, offers 5 5 5 5 7 5: the list is [5 5 5] after three offers, the fourth replaces position 0 (first minimum), 7 replaces
+    position 0 again, the last 5 replaces position 1: ids 5, 6 and 3 survive -- not 'the latest' and not 'the largest ids'."""
+    ex = import_module("approximate_spmv_topk_amd.experiments")
+    res, idx = ex._streamed_list(np.array([5, 5, 5, 5, 7, 5]), np.array([1, 2, 3, 4, 5, 6]), 3)
+    assert res == [7, 5, 5] and idx == [5, 6, 3]
+    l, v, i = ex._hls_lists(np.zeros(6, np.int64), np.array([5, 5, 5, 5, 7, 5], np.uint64), np.array([1, 2, 3, 4, 5, 6]), 3)
+    assert sorted(i.tolist()) == [3, 5, 6]
+
+
+def test_model_mode_needs_the_entries():
+    ex = import_module("approximate_spmv_topk_amd.experiments")
+    with pytest.raises(ValueError):
+        ex.hls_dataflow_topk(np.zeros(4, np.uint32), None, 1, 1, overfull="model")
+    with pytest.raises(ValueError):
+        ex.hls_dataflow_topk(np.zeros(4, np.uint32), np.ones(1, np.float32), 1, 1, overfull="drop")
