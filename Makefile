@@ -21,7 +21,7 @@ HIPFLAGS := -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -ffp-contract=off -Wall 
 CXXFLAGS := -O2 -std=c++17 -fPIC -ffp-contract=off -Wall
 CFLAGS   := -O2 -std=c11 -fPIC -ffp-contract=off -Wall -pthread
 
-HOST_SRCS := $(CSRC)/wbscsr.cpp $(CSRC)/wsell.cpp $(CSRC)/host_utils.cpp $(CSRC)/c_api.cpp
+HOST_SRCS := $(CSRC)/wbscsr.cpp $(CSRC)/wsell.cpp $(CSRC)/host_utils.cpp $(CSRC)/options.cpp $(CSRC)/c_api.cpp
 HIP_SRCS  := $(CSRC)/engine.hip $(CSRC)/dist.hip $(CSRC)/device_pack.hip
 HDRS      := $(wildcard $(CSRC)/*.hpp) $(wildcard $(CSRC)/kernels/*.hpp) include/tkspmv.h
 

@@ -87,6 +87,7 @@ EXPORTED_SYMBOLS = [
     "tkspmv_dist_unique_id", "tkspmv_dist_create", "tkspmv_dist_set_batch", "tkspmv_dist_enqueue", "tkspmv_dist_run_many",
     "tkspmv_dist_synchronize", "tkspmv_dist_time_exchange", "tkspmv_dist_read", "tkspmv_dist_destroy", "tkspmv_dist_last_error",
     "tkspmv_merge_topk", "tkspmv_merge_topk_batch", "tkspmv_dist_set_host_exchange", "tkspmv_dist_read_batch",
+    "tkspmv_set_option", "tkspmv_get_option", "tkspmv_option_count", "tkspmv_option_info",
 ]
 
 _lib = None
@@ -167,6 +168,10 @@ def lib():
     L.tkspmv_merge_topk_batch.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp]
     L.tkspmv_dist_set_host_exchange.argtypes = [vp, HOST_ALLGATHER_FN, vp]
     L.tkspmv_dist_read_batch.argtypes = [vp, u32p, f32p, C.POINTER(C.c_int32)]
+    L.tkspmv_set_option.argtypes = [C.c_char_p, C.c_char_p]
+    L.tkspmv_get_option.argtypes = [C.c_char_p]
+    L.tkspmv_get_option.restype = C.c_char_p
+    L.tkspmv_option_info.argtypes = [C.c_int32] + [C.POINTER(C.c_char_p)] * 4
     _lib = L
     return L
 
@@ -174,6 +179,29 @@ def lib():
 def check(status):
     if status != OK:
         raise TkspmvError(status, lib().tkspmv_last_error().decode("utf-8", "replace"))
+
+
+def set_option(name, value):
+    """tkspmv_set_option: an engine option (include/tkspmv.h; `options()` lists them) for the engines created after this call.
+    value None: back to unset. Raises TkspmvError for a name that is not in the library's table."""
+    check(lib().tkspmv_set_option(name.encode(), None if value is None else str(value).encode()))
+
+
+def get_option(name):
+    v = lib().tkspmv_get_option(name.encode())
+    return None if v is None else v.decode()
+
+
+def options():
+    """The library's table of options: [{name, kind, values, doc, value}]."""
+    L = lib()
+    out = []
+    for i in range(L.tkspmv_option_count()):
+        f = [C.c_char_p() for _ in range(4)]
+        check(L.tkspmv_option_info(i, *[C.byref(x) for x in f]))
+        name, kind, values, doc = (x.value.decode() for x in f)
+        out.append({"name": name, "kind": kind, "values": values, "doc": doc, "value": get_option(name)})
+    return out
 
 
 def check_dist(status):

@@ -9,6 +9,7 @@
 #include "device_pack.hpp"
 #include "engine.hpp"
 #include "host_utils.hpp"
+#include "options.hpp"
 #include "wbscsr.hpp"
 #include "wsell.hpp"
 
@@ -100,6 +101,25 @@ int tkspmv_enqueue_multi(tkspmv_t *h, const float *dev_xs, int32_t count, uint32
 }
 int tkspmv_time_multi(tkspmv_t *h, const float *dev_xs, int32_t n_x, int32_t iters, double *ns_per_query) {
     ENGINE_CALL(time_multi(dev_xs, n_x, iters, ns_per_query, err))
+}
+int tkspmv_set_option(const char *name, const char *value) {
+    if (tkspmv::set_option(name, value) != 0) return fail(TKSPMV_ERR_INVALID, std::string("no such option: ") + (name ? name : "(null)"));
+    return TKSPMV_OK;
+}
+const char *tkspmv_get_option(const char *name) {
+    for (int i = 0; i < tkspmv::option_count(); ++i)
+        if (name && std::strcmp(tkspmv::option_def(i)->name, name) == 0) return tkspmv::opt(name);
+    return nullptr;
+}
+int tkspmv_option_count(void) { return tkspmv::option_count(); }
+int tkspmv_option_info(int32_t i, const char **name, const char **kind, const char **values, const char **doc) {
+    const tkspmv::OptionDef *o = tkspmv::option_def(i);
+    if (!o) return fail(TKSPMV_ERR_INVALID, "option index out of range");
+    if (name) *name = o->name;
+    if (kind) *kind = o->kind;
+    if (values) *values = o->values;
+    if (doc) *doc = o->doc;
+    return TKSPMV_OK;
 }
 int tkspmv_time_query_batches(tkspmv_t *h, const float *dev_xs, int32_t n_x, int32_t iters, int32_t reps, double *ns_per_query) {
     ENGINE_CALL(time_query_batches(dev_xs, n_x, iters, reps, ns_per_query, err))

@@ -18,6 +18,7 @@
 
 #include "../../include/tkspmv.h"
 #include "engine.hpp"
+#include "options.hpp"
 
 namespace tkspmv {
 
@@ -232,7 +233,7 @@ int tkspmv_dist_create(tkspmv_dist_t **out, tkspmv_t *engine, const uint8_t *id1
     } while (0)
     DHIP_OR_BAIL(hipSetDevice(d.device));
     // (TKSPMV_DIST_NO_NCCL=1: no communicator -- the exchange goes through tkspmv_dist_set_host_exchange's callback)
-    d.use_nccl = (world > 1 && getenv("TKSPMV_DIST_NO_NCCL") == nullptr) || getenv("TKSPMV_DIST_FORCE_NCCL") != nullptr;
+    d.use_nccl = (world > 1 && opt("DIST_NO_NCCL") == nullptr) || opt("DIST_FORCE_NCCL") != nullptr;
     if (d.use_nccl) {
         if (!id128) return bail(TKSPMV_ERR_INVALID, "world > 1 needs the unique id of rank 0");
         std::string err;
@@ -246,7 +247,7 @@ int tkspmv_dist_create(tkspmv_dist_t **out, tkspmv_t *engine, const uint8_t *id1
                                                (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?"));
         }
     }
-    if (const char *e = getenv("TKSPMV_DIST_BATCH")) d.batch = atoi(e);
+    if (const char *e = opt("DIST_BATCH")) d.batch = atoi(e);
     if (d.batch < 1) d.batch = 1;
     if (d.batch > MAX_BATCH) d.batch = MAX_BATCH;
     DHIP_OR_BAIL(hipStreamCreateWithFlags(&d.compute, hipStreamNonBlocking));

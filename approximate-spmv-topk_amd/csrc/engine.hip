@@ -31,6 +31,7 @@
 
 #include "device_pack.hpp"
 #include "engine.hpp"
+#include "options.hpp"
 #include "wsell.hpp"
 
 #include "kernels/common.hpp"
@@ -177,13 +178,11 @@ struct EngineImpl {
     uint32_t ovf_lists = 1;                     // overflow lists allocated (batch engines: 2, shared by the queries of a launch under flow control)
     uint32_t use_local = 0;  // workgroup-local thresholds (BatchParams::local: 0 off, 1 / 2: a wave's best / second best packet maximum)
     float *d_wg_prior = nullptr;  // [grid] + the countdown word (BatchParams::wg_prior / prior_block)
-    bool carry_local = true;
     float local_beta = 1.0f;
     uint32_t pace_quads = 0, pace_levels = 3; // pacing by rank (BatchParams::pace_quads, pace_levels)
     mutable uint64_t batch_launches = 0;
     uint32_t n_sel_wg = 1;   // selector workgroups of a batch launch (BatchParams::n_selectors): 4 on small matrices
     uint32_t groups_with_rows = 0;  // publishing groups that own at least one wave partition
-    uint32_t n_reducers = 0;  // TKSPMV_REDUCERS (tuning): workgroups whose server derives tau from all maxima itself
     float *d_out_val = nullptr, *d_scores = nullptr;
     unsigned long long *d_stats = nullptr;
     uint32_t grid = 0, block = 0, gpw = 1, n_sets = 0, n_groups_pub = 0, cand_cap = 0, ovf_cap = 0, lds_bytes = 0,
@@ -196,8 +195,6 @@ struct EngineImpl {
     bool collect_stamps = false;
     unsigned long long *d_trace = nullptr;  // TKSPMV_TRACE=1: 4 launches x [grid+1][9][8] stamps
     size_t trace_words = 0;
-    uint32_t dbg_flags = 0;
-    uint32_t dbg_repeat = 0;
     bool have_query = false;
     bool ran = false;
     bool packed_on_device = false;  // the stream was built by device_pack.hip
@@ -236,7 +233,7 @@ struct EngineImpl {
         P.fixed_mask = pm.fixed_width ? fixed_mask(pm.fixed_width) : 0u;
         P.gmax = E.gmax;
         P.tau_g = E.tau_g;
-        P.n_reducers = n_reducers ? n_reducers : (grid < 8u ? grid : 8u);
+        P.n_reducers = grid < 8u ? grid : 8u;
         P.tau_possible = groups_with_rows >= (uint32_t)desc.k ? 1u : 0u;
 
         P.wg_cand = E.wg_cand;
@@ -250,10 +247,6 @@ struct EngineImpl {
         P.dbg = collect_stats ? d_stats + 4 : nullptr;
         P.stamps = collect_stamps ? d_stats + 16 : nullptr;
         P.trace = d_trace ? d_trace + (launch_counter % 4) * trace_words : nullptr;
-        P.dbg_flags = dbg_flags;
-        P.dbg_repeat = dbg_repeat;
-        for (int r = 0; r < 4; ++r)
-            P.rep_packets[r] = d_replicas.empty() ? d_packets : d_replicas[(launch_counter + r) % d_replicas.size()];
         return P;
     }
     SelectParams select_params(uint32_t *out_idx, float *out_val, int set = 0) const {
@@ -446,7 +439,7 @@ struct EngineImpl {
         B.verdict = d_verdict + 16 * (batch_launches & 1u);
         B.verdict_next = d_verdict + 16 * ((batch_launches + 1u) & 1u);
         ++batch_launches;
-        if (use_local && carry_local) {
+        if (use_local) {
             B.wg_prior = d_wg_prior;
             B.local_beta = local_beta;
         }
@@ -565,7 +558,7 @@ struct EngineImpl {
         LocalParams G{};
         G.slots = d_lslots;
         G.used = d_lused;
-        G.wg_prior = carry_local ? d_lprior : nullptr;
+        G.wg_prior = d_lprior;
         G.prior_block = reinterpret_cast<uint32_t *>(d_lprior + grid);
         G.status = d_lstatus;
         G.mode = use_local;
@@ -792,10 +785,8 @@ Engine::~Engine() {
 // it is not cached in the per-XCD L2s, so a poll never hits a stale copy (with ordinary memory an agent-scope load can
 // keep returning the old value until the line happens to be evicted: milliseconds on an idle L2).
 static hipError_t malloc_exchange(void **p, size_t bytes) {
-    if (getenv("TKSPMV_COARSE_EXCHANGE") == nullptr &&
-        hipExtMallocWithFlags(p, bytes, hipDeviceMallocFinegrained) == hipSuccess)
-        return hipSuccess;
-    if (getenv("TKSPMV_DEBUG_OCC")) fprintf(stderr, "[tkspmv] fine-grained allocation unavailable, using hipMalloc\n");
+    if (hipExtMallocWithFlags(p, bytes, hipDeviceMallocFinegrained) == hipSuccess) return hipSuccess;
+    if (opt("DEBUG_OCC")) fprintf(stderr, "[tkspmv] fine-grained allocation unavailable, using hipMalloc\n");
     (void)hipGetLastError();
     return hipMalloc(p, bytes);
 }
@@ -807,16 +798,16 @@ static hipError_t malloc_exchange(void **p, size_t bytes) {
 // exchange is as fast and checks nothing. Returns the selector workgroups of a batch launch for this matrix and geometry
 // (TKSPMV_SELECTORS overrides; the matrix unknown -- nnz = 0 --: 1). TKSPMV_SMALL_PACKETS: both limits (0: round 2's behaviour).
 static uint64_t local_matrix_packets() {
-    if (const char *f = getenv("TKSPMV_SMALL_PACKETS")) return (uint64_t)atoll(f);
+    if (const char *f = opt("SMALL_PACKETS")) return (uint64_t)atoll(f);
     return LOCAL_MATRIX_PACKETS;
 }
 static uint32_t small_matrix_settings(const tkspmv_desc &d, uint32_t grid, bool defer_capable, uint32_t C, bool *small_out) {
     const uint64_t packets_lb = d.nnz / (64u * (uint64_t)std::max(C, 1u));
     const bool small = defer_capable && grid >= 64u && d.nnz != 0 && d.cols <= 1024u && d.impl == TKSPMV_IMPL_STREAM && d.multi_q == 0 &&
-                       d.partitions <= 1 && packets_lb <= local_matrix_packets() && !getenv("TKSPMV_MULTI_Q");
+                       d.partitions <= 1 && packets_lb <= local_matrix_packets() && !opt("MULTI_Q");
     if (small_out) *small_out = small;
     uint32_t n = small ? 4u : 1u;
-    if (const char *f = getenv("TKSPMV_SELECTORS")) n = (uint32_t)std::max(1, std::min(8, atoi(f)));
+    if (const char *f = opt("SELECTORS")) n = (uint32_t)std::max(1, std::min(8, atoi(f)));
     if (!defer_capable || grid < 2u * n) n = 1u;
     return n;
 }
@@ -906,7 +897,7 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
     if (prepacked && prepacked->part_first.size() > (size_t)(m.grid - m.n_sel_wg) * waves_per_wg) m.n_sel_wg = 1u;
     const uint32_t n_stream_waves = (m.grid - (defer_capable ? m.n_sel_wg : 0u)) * waves_per_wg;
     // (TKSPMV_PARTITIONS_HINT: measurement aid of the load-only probe -- more partitions than waves; such an engine runs no queries)
-    const uint32_t n_parts_hint = getenv("TKSPMV_PARTITIONS_HINT") ? (uint32_t)atoi(getenv("TKSPMV_PARTITIONS_HINT")) : n_stream_waves;
+    const uint32_t n_parts_hint = opt("PARTITIONS_HINT") ? (uint32_t)atoi(opt("PARTITIONS_HINT")) : n_stream_waves;
     if (prepacked) {
         // A matrix packed earlier (tkspmv_pack / a .tkspmv file): it must describe the same problem and must not have
         // more partitions than this launch geometry has streaming waves (the batch kernel gives every wave one).
@@ -933,14 +924,14 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
         // The packer runs on the device by default (device_pack.hip: same bytes as the host packer, which stays available
         // with TKSPMV_DEVICE_PACK=0 and serves tkspmv_pack / the .tkspmv files).
         bool on_device = d.nnz > 0;
-        if (const char *f = getenv("TKSPMV_DEVICE_PACK")) on_device = on_device && atoi(f) != 0;
+        if (const char *f = opt("DEVICE_PACK")) on_device = on_device && atoi(f) != 0;
         const uint32_t min_packets = min_packets_per_partition_for(d.nnz, C, d.cols);
         const auto t_pack = std::chrono::steady_clock::now();
         std::string perr;
         if (on_device) {
             DevicePacked dp;
             // (a multi-query engine packs the same COO a second time below: leave its columns and values in HBM until then)
-            dp.keep_coo = d.cols <= SELL_XCOLS && (d.multi_q != 0 || d.impl == TKSPMV_IMPL_ROW_PER_LANE || getenv("TKSPMV_MULTI_Q"));
+            dp.keep_coo = d.cols <= SELL_XCOLS && (d.multi_q != 0 || d.impl == TKSPMV_IMPL_ROW_PER_LANE || opt("MULTI_Q"));
             perr = pack_wbscsr_device(d.rows, d.cols, d.nnz, d.row, d.col, d.val, stream_precision_of(d), C,
                                       n_parts_hint, min_packets, fixed_width_of(d), dp, kind);
             if (perr.empty()) {
@@ -1042,7 +1033,7 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
     std::vector<uint32_t>().swap(m.pm.pkt_row);
 
     HIP_TRY(hipMalloc((void **)&m.d_x, (size_t)d.cols * 4));
-    if (const char *f = getenv("TKSPMV_HOST_PATH")) m.host_path = atoi(f);
+    if (const char *f = opt("HOST_PATH")) m.host_path = atoi(f);
     {
         // Host stores into device memory: only where the runtime reports a large BAR, and only after a round trip has shown that a
         // value stored by the CPU is the value a device-side copy reads back.
@@ -1050,7 +1041,7 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
         if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, dev) != hipSuccess) large_bar = 0;
         (void)hipGetLastError();
         bool want = large_bar != 0 && m.host_path != 0;
-        if (const char *f = getenv("TKSPMV_BAR_X")) want = want && atoi(f) != 0;
+        if (const char *f = opt("BAR_X")) want = want && atoi(f) != 0;
         if (want) {
             HIP_TRY(hipMemset(m.d_x, 0, (size_t)d.cols * 4));
             HIP_TRY(hipDeviceSynchronize());
@@ -1067,10 +1058,10 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
         }
     }
     if (m.host_path) {  // pinned staging copy of x and the host-visible result block (optional: the plain path needs neither)
-        if (const char *f = getenv("TKSPMV_HOST_X")) m.host_x_direct = std::string(f) == "direct" || std::string(f) == "direct_nc";
-        if (const char *f = getenv("TKSPMV_RUN_EVENTS")) m.run_events = atoi(f) != 0;
+        if (const char *f = opt("HOST_X")) m.host_x_direct = std::string(f) == "direct" || std::string(f) == "direct_nc";
+        if (const char *f = opt("RUN_EVENTS")) m.run_events = atoi(f) != 0;
         {
-            const char *f = getenv("TKSPMV_HOST_X");
+            const char *f = opt("HOST_X");
             const unsigned flags = (f && std::string(f) == "direct_nc") ? (hipHostMallocMapped | hipHostMallocNonCoherent) : hipHostMallocMapped;
             if (hipHostMalloc((void **)&m.h_x, (size_t)d.cols * 4, flags) != hipSuccess) m.h_x = nullptr;
             if (m.h_x && hipHostGetDevicePointer((void **)&m.h_x_dev, m.h_x, 0) != hipSuccess) m.host_x_direct = false;
@@ -1086,9 +1077,7 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
     HIP_TRY(hipMalloc((void **)&m.d_out_idx, (size_t)d.k * 4));
     HIP_TRY(hipMalloc((void **)&m.d_out_val, (size_t)d.k * 4));
     HIP_TRY(hipMalloc((void **)&m.d_stats, 32 * 8));
-    m.collect_stats = getenv("TKSPMV_STATS") != nullptr;
-    if (const char *f = getenv("TKSPMV_DBG_FLAGS")) m.dbg_flags = (uint32_t)atoi(f);
-    if (const char *f = getenv("TKSPMV_DBG_REPEAT")) m.dbg_repeat = (uint32_t)atoi(f);
+    m.collect_stats = opt("STATS") != nullptr;
     HIP_TRY(malloc_exchange((void **)&m.d_tstart, 128));
     HIP_TRY(hipMemset(m.d_tstart, 0, 128));
     HIP_TRY(malloc_exchange((void **)&m.d_done, 9 * 128));
@@ -1097,15 +1086,13 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
     // registers per thread.
     m.fused = (uint64_t)m.grid * WG_SLOTS <= (uint64_t)SEL_PER_THREAD * (m.block + 64);
     m.can_defer = defer_capable;
-    if (const char *f = getenv("TKSPMV_FUSED")) m.fused = m.fused && atoi(f) != 0;
-    if (const char *f = getenv("TKSPMV_REDUCERS")) m.n_reducers = (uint32_t)atoi(f);
-    if (const char *f = getenv("TKSPMV_DEFER")) m.can_defer = m.can_defer && atoi(f) != 0;
+    if (const char *f = opt("FUSED")) m.fused = m.fused && atoi(f) != 0;
     m.can_batch = m.can_defer && m.n_sets != 0u && m.xcols <= 1024u && (C == 4u || (C == 8u && d.precision == TKSPMV_F32));  // larger x: two workgroups no longer fit a CU
-    if (const char *f = getenv("TKSPMV_BATCH")) m.can_batch = m.can_batch && atoi(f) != 0;
+    if (const char *f = opt("BATCH")) m.can_batch = m.can_batch && atoi(f) != 0;
     // Large k: the scores + radix-select path wherever the threshold exchange is off or next to useless (k above
     // 3/8 of the publishing groups: measured cross-over on the BASELINE matrix, tools/k_probe.py). TKSPMV_RADIX=0/1 forces.
     m.use_radix = m.n_sets == 0u || (uint64_t)d.k * 8u > (uint64_t)m.n_groups_pub * 3u || d.impl == TKSPMV_IMPL_SCORES_SELECT;
-    if (const char *f = getenv("TKSPMV_RADIX")) m.use_radix = atoi(f) != 0;
+    if (const char *f = opt("RADIX")) m.use_radix = atoi(f) != 0;
     if (m.approx_parts) m.use_radix = true;  // scores, then the per-partition selection instead of the radix select
     if (m.use_radix) {
         m.can_defer = m.can_batch = false;
@@ -1124,7 +1111,7 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
     {
         int mq = d.multi_q;
         if (d.impl == TKSPMV_IMPL_ROW_PER_LANE && mq == 0) mq = 1;
-        if (const char *f = getenv("TKSPMV_MULTI_Q")) mq = atoi(f);
+        if (const char *f = opt("MULTI_Q")) mq = atoi(f);
         if (mq != 0 && mq != 1 && mq != 2 && mq != 4 && mq != 8) {
             err = "multi_q must be 0 (off), 1, 2, 4 or 8";
             return TKSPMV_ERR_INVALID;
@@ -1195,7 +1182,7 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
         HIP_TRY(hipStreamCreateWithFlags(&m.side, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&m.ev_fork, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&m.ev_join, hipEventDisableTiming));
-        if (const char *f = getenv("TKSPMV_MULTI_CHAINS")) m.multi_chains = atoi(f) >= 2 ? 2 : 1;
+        if (const char *f = opt("MULTI_CHAINS")) m.multi_chains = atoi(f) >= 2 ? 2 : 1;
         if (d.stream_replicas > 1) {
             m.d_sell_replicas.push_back(m.d_sell_packets);
             for (int r = 1; r < d.stream_replicas; ++r) {
@@ -1221,8 +1208,8 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
         HIP_TRY(malloc_exchange((void **)&m.d_dev_epoch, 64));
         HIP_TRY(hipMemset(m.d_dev_epoch, 0, 64));
         HIP_TRY(hipStreamCreateWithFlags(&m.rstream, hipStreamNonBlocking));
-        m.resident_stats = getenv("TKSPMV_RESIDENT_STATS") != nullptr;
-        if (const char *f = getenv("TKSPMV_RESIDENT_IDLE_MS")) m.resident_idle_ticks = (uint32_t)std::max(1, atoi(f)) * 100000u;
+        m.resident_stats = opt("RESIDENT_STATS") != nullptr;
+        if (const char *f = opt("RESIDENT_IDLE_MS")) m.resident_idle_ticks = (uint32_t)std::max(1, atoi(f)) * 100000u;
     }
     HIP_TRY(malloc_exchange((void **)&m.d_tickets, BATCH_MAX * 32 * 4));
     HIP_TRY(hipMemset(m.d_tickets, 0, BATCH_MAX * 32 * 4));
@@ -1247,15 +1234,14 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
         const double p1 = n_wg * (std::pow(lam, a) + tail9);
         const double p2 = n_wg * (std::pow(per_part < 1.5 ? lam : std::min(1.0, 0.5 * lam * lam), a) + tail9);
         m.use_local = (!small_matrix || m.grid > 512u) ? 0u : (p1 <= 1e-4 ? 1u : (p2 <= 1e-3 ? 2u : 0u));  // (512: select_body's first cut)
-        if (getenv("TKSPMV_DEBUG_OCC"))
+        if (opt("DEBUG_OCC"))
             fprintf(stderr, "[tkspmv] small matrix %d: %u selector workgroups, %.0f partitions of %.1f packets, %.0f per workgroup; local thresholds fail with p = %.2e (mode 1) / %.2e (mode 2): mode %u\n",
                     (int)small_matrix, m.n_sel_wg, n_parts, per_part, a, p1, p2, m.use_local);
     }
     HIP_TRY(malloc_exchange((void **)&m.d_wg_prior, ((size_t)m.grid + 32) * 4));  // priors | countdown words
     HIP_TRY(hipMemset(m.d_wg_prior, 0, ((size_t)m.grid + 32) * 4));
-    if (const char *f = getenv("TKSPMV_LOCAL_CARRY")) m.carry_local = atoi(f) != 0;
-    if (const char *f = getenv("TKSPMV_LOCAL_BETA")) m.local_beta = (float)atof(f);
-    if (const char *f = getenv("TKSPMV_LOCAL")) m.use_local = m.grid > 512u ? 0u : (uint32_t)std::max(0, std::min(2, atoi(f)));
+    if (const char *f = opt("LOCAL_BETA")) m.local_beta = (float)atof(f);
+    if (const char *f = opt("LOCAL")) m.use_local = m.grid > 512u ? 0u : (uint32_t)std::max(0, std::min(2, atoi(f)));
     // Pacing by rank, with local thresholds only (with the device-wide exchange the cold phase of every query is governor enough, §3.0):
     // the longer the partitions, the longer the pause (size sweeps on two boxes, tools/ab_rank.sh: best at 0 / 1 / 2 units of 256 cycles
     // up to 575k / 830k / 1.3M rows of 20 non-zeros).
@@ -1263,14 +1249,14 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
     // at 1M rows against 16.3 at 2 units and 16.7 with the device-wide exchange).
     // (units of 128 cycles per level)
     if (m.use_local) m.pace_quads = m.pm.n_packets <= 45000u ? 0u : (m.pm.n_packets <= 65000u ? 2u : 2u * std::max(1u, (m.pm.packet_bytes + 352u) / 704u));
-    if (const char *f = getenv("TKSPMV_PACE_LEVELS")) m.pace_levels = (uint32_t)std::max(1, std::min(8, atoi(f)));
-    if (const char *f = getenv("TKSPMV_PACE")) m.pace_quads = (uint32_t)std::max(0, std::min(32, atoi(f)));
+    if (const char *f = opt("PACE_LEVELS")) m.pace_levels = (uint32_t)std::max(1, std::min(8, atoi(f)));
+    if (const char *f = opt("PACE")) m.pace_quads = (uint32_t)std::max(0, std::min(32, atoi(f)));
     // single_kernel serves tkspmv_run where the engine streams with local thresholds: fp32 values, 4 entries per lane, x of at most
     // 1024 columns, at most 512 workgroups (select_local's first cut), one partition per wave of ITS launch (8 waves x grid).
     m.can_single = m.use_local != 0u && d.precision == TKSPMV_F32 && C == 4u && m.xcols <= 1024u && m.grid <= 512u && m.block == 512u &&
                    d.impl == TKSPMV_IMPL_STREAM && !m.use_radix && m.fused && m.host_path && m.h_res != nullptr &&
                    m.pm.part_first.size() <= (size_t)m.grid * 8u;
-    if (const char *f = getenv("TKSPMV_SINGLE")) m.can_single = m.can_single && atoi(f) != 0;
+    if (const char *f = opt("SINGLE")) m.can_single = m.can_single && atoi(f) != 0;
     if (m.can_single) {
         HIP_TRY(hipMalloc((void **)&m.d_lslots, (size_t)m.grid * WG_SLOTS * 8));
         HIP_TRY(hipMemset(m.d_lslots, 0xFF, (size_t)m.grid * WG_SLOTS * 8));
@@ -1290,7 +1276,7 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
         // under flow control (BatchParams::ovf_epoch), and the general path of the selection needs no scratch copy any more
         // (select_body): 32 MB at 1M rows, 320 MB at 10M. Multi-query engines keep one list per set (their groups' selections are
         // owed across launches).
-        if (const char *f = getenv("TKSPMV_BATCH_MAX")) m.batch_max = std::max(1, std::min(BATCH_MAX, atoi(f)));
+        if (const char *f = opt("BATCH_MAX")) m.batch_max = std::max(1, std::min(BATCH_MAX, atoi(f)));
         const int n_sets_alloc = (m.can_multi || m.resident_capable) ? EngineImpl::N_STATE : (m.can_batch ? m.batch_max : (m.can_defer ? 2 : 1));
         const size_t ns = (size_t)n_sets_alloc;
         m.ovf_lists = m.can_multi ? (uint32_t)n_sets_alloc : (uint32_t)std::min(4, n_sets_alloc);
@@ -1333,20 +1319,20 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
                              (m.can_batch ? ns * ((uint64_t)m.grid * WG_SLOTS * 8 + (uint64_t)m.grid * 4) : 0);
     }
     HIP_TRY(hipMemset(m.d_stats, 0, 32 * 8));
-    m.collect_stamps = getenv("TKSPMV_STAMPS") != nullptr;
-    if (getenv("TKSPMV_TRACE")) {
+    m.collect_stamps = opt("STAMPS") != nullptr;
+    if (opt("TRACE")) {
         m.trace_words = (size_t)(m.grid + 1) * 9 * 8;
         HIP_TRY(hipMalloc((void **)&m.d_trace, m.trace_words * 4 * 8));
         HIP_TRY(hipMemset(m.d_trace, 0, m.trace_words * 4 * 8));
     }
     HIP_TRY(hipMemset(m.d_out_idx, 0, (size_t)d.k * 4));
     HIP_TRY(hipMemset(m.d_out_val, 0, (size_t)d.k * 4));
-    m.dbg_kernels = m.collect_stats || m.collect_stamps || m.d_trace != nullptr || m.dbg_flags != 0u || m.dbg_repeat != 0u;
+    m.dbg_kernels = m.collect_stats || m.collect_stamps || m.d_trace != nullptr;
     if (m.dbg_kernels && (d.precision != TKSPMV_F32 || C != 4u || m.xcols > 1024u))
         fprintf(stderr, "[tkspmv] tracing / statistics hooks exist in the fp32, 4-entries-per-lane, <= 1024-column kernels only: "
                         "this engine runs without them\n");
 
-    if (getenv("TKSPMV_DEBUG_OCC")) {
+    if (opt("DEBUG_OCC")) {
         int n1 = -1, n2 = -1;
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n1, reinterpret_cast<const void *>(m.kernel_for(false)), (int)m.block + 64, 0);
         if (m.can_batch)
@@ -1982,7 +1968,7 @@ int Engine::time_stream_read(int32_t passes, double *ns_per_pass, std::string &e
     R.part_count = m.d_part_count;
     R.n_parts = (uint32_t)m.pm.part_first.size();
     R.n_pass = (uint32_t)passes;
-    if (const char *f = getenv("TKSPMV_READ_PROBE_MAP")) R.map = (uint32_t)atoi(f);
+    if (const char *f = opt("READ_PROBE_MAP")) R.map = (uint32_t)atoi(f);
     struct SinkGuard {  // freed on every return path
         uint32_t *p = nullptr;
         ~SinkGuard() {
@@ -1993,7 +1979,7 @@ int Engine::time_stream_read(int32_t passes, double *ns_per_pass, std::string &e
     HIP_TRY(hipMalloc((void **)&sink.p, (size_t)m.grid * 16 * 4 + (size_t)(passes + 2) * 128 + n_end * 8));
     R.sink = sink.p;
     R.claim = sink.p + (size_t)m.grid * 16;
-    const bool want_ends = getenv("TKSPMV_READ_PROBE_ENDS") != nullptr;  // (tuning runs: when did the waves of each XCD finish?)
+    const bool want_ends = opt("READ_PROBE_ENDS") != nullptr;  // (tuning runs: when did the waves of each XCD finish?)
     R.t_end = want_ends ? reinterpret_cast<unsigned long long *>(R.claim + (size_t)(passes + 2) * 32) : nullptr;
     void (*fn)(ReadProbeParams) = nullptr;
     switch (m.pm.packet_bytes / 64u) {
@@ -2005,7 +1991,7 @@ int Engine::time_stream_read(int32_t passes, double *ns_per_pass, std::string &e
         case 12: fn = read_probe_kernel<12>; break;
         default: break;
     }
-    if (const char *f = getenv("TKSPMV_READ_PROBE")) {  // "depth,work" (tuning runs; fp32 packets only)
+    if (const char *f = opt("READ_PROBE")) {  // "depth,work" (tuning runs; fp32 packets only)
         int depth = 8, work = 0;
         sscanf(f, "%d,%d", &depth, &work);
         if (m.pm.packet_bytes == 1536u) {

@@ -1,5 +1,6 @@
 // host_utils.cpp -- see host_utils.hpp for the reference interfaces mirrored here.
 #include "host_utils.hpp"
+#include "options.hpp"
 
 #include <getopt.h>
 
@@ -459,7 +460,7 @@ void fill_rows(uint32_t r0, uint32_t r1, uint32_t cols, uint64_t seed, const uin
 }
 unsigned host_threads() {
     unsigned n = std::thread::hardware_concurrency();
-    if (const char *e = getenv("TKSPMV_HOST_THREADS")) n = (unsigned)atoi(e);
+    if (const char *e = opt("HOST_THREADS")) n = (unsigned)atoi(e);
     return n < 1 ? 1u : (n > 64 ? 64u : n);
 }
 template <class F>

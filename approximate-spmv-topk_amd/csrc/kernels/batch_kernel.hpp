@@ -1,6 +1,7 @@
 // kernels/batch_kernel.hpp -- batch_kernel: up to 32 queries per launch, one pass over the wave-BSCSR stream per query (the headline path).
 // Part of engine.hip (one translation unit: included there in this order; device code only).
 #pragma once
+#include <cstddef>
 #include "stream_kernel.hpp"
 #include "local.hpp"
 
@@ -230,7 +231,7 @@ __device__ __forceinline__ void gate_update(const BatchParams &B, uint32_t faile
     g[B.gate_parity ? 4 : 7] = next;
 }
 
-// DBG = false (production): the tracing / statistics / ablation hooks of StreamParams (trace, dbg, dbg_flags) are compiled
+// DBG = false (production): the tracing / statistics / ablation hooks of StreamParams (trace, dbg, stamps) are compiled
 // out -- no per-packet compare of a tracing word or an ablation flag, and the scalar registers they held are free. The
 // engine launches the DBG = true instantiation only when TKSPMV_TRACE / TKSPMV_STATS / TKSPMV_DBG_FLAGS ask for it.
 //
@@ -250,8 +251,6 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t nwaves = (blockDim.x >> 6) - 1u;  // streaming waves
     const bool is_server = (wave == nwaves);
-    // (LOCAL: the kernel of the checked local thresholds -- the caller has looked at the gate; else the device-wide exchange)
-    constexpr bool local_open = LOCAL;
     const uint32_t nq = RESIDENT ? 0xFFFFFFF0u : (repair ? L.rq[BATCH_MAX] : B.n_q);
     // query q of THIS phase in the launch's argument block (repair: the q-th flagged query)
     auto qx = [&](uint32_t q) __attribute__((always_inline)) -> uint32_t { return repair ? L.rq[q] : q; };
@@ -371,16 +370,12 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
                     S.host_epoch = B.epoch0 + q + 1u;  // (host_out comes with SP0)
                     S.t_seen = t_seen;                 // (wave 0 holds it; thread 0 reports the query's device time)
                 }
-                // (timing aid, TKSPMV_DBG_FLAGS & 16: the set keeps its final threshold, and the next query that uses the set
-                //  starts from it -- exact when the same vector comes back, tools/ablate_probe.py)
-                const uint32_t keep_tau = (DBG && (P0.dbg_flags & 16u)) ? __hip_atomic_load(S.tau_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
                 if (tr_sel && tid == 0) P0.trace[10] = __builtin_amdgcn_s_memrealtime();
-                select_body<false>(S, tid, blockDim.x, L.u.sel, 0u, tr_sel ? P0.trace + 8 : nullptr);
+                select_body<0>(S, tid, blockDim.x, L.u.sel, tr_sel ? P0.trace + 8 : nullptr);
                 // the list is free for its next user: its count was reset (written through) and drained above
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
                 if (tid == 0) (void)__hip_atomic_fetch_add(B.ovf_epoch + l, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (DBG && (P0.dbg_flags & 16u) && tid == 0) *S.tau_g = keep_tau;
             }
             if (tr_sel && tid == 0) P0.trace[15] = __builtin_amdgcn_s_memrealtime();
             if (P0.trace && tid == 0 && q < 8u) P0.trace[q] = __builtin_amdgcn_s_memrealtime();
@@ -535,10 +530,6 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
                         carried_key = order_key(t0);  // (on record with the thresholds the waves form: MISC_TAUKEY)
                     }
                 }
-                if (DBG && (P0.dbg_flags & 16u)) {
-                    const uint32_t kx = __hip_atomic_load(B.tau_g(set_of(staged)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (kx && key_to_float(kx) > tau_init) tau_init = key_to_float(kx);
-                }
                 if (lane == 0) {
                     mp[MISC_TAU] = __float_as_uint(tau_init);
                     mp[MISC_MINU] = __float_as_uint(min_units_q[par]);
@@ -553,7 +544,7 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
             // half of the waves have left it, then the next (whose waves need a threshold most).
             if (local) {
                 // (workgroup-local thresholds are formed by the streaming waves themselves, in LDS: nothing to do here)
-            } else if (P0.n_sets != 0u && !(P0.dbg_flags & 4u)) {
+            } else if (P0.n_sets != 0u) {
                 // (the overflow lists' epoch words for the streaming waves: loaded with this turn's exchange traffic, stored below)
                 const uint32_t e_now = lane < n_lists ? __hip_atomic_load(B.ovf_epoch + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
                 uint32_t hq = tail;
@@ -785,7 +776,7 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
             const float tau = __uint_as_float(tau_bits);
             const Reduced<C> Rd = reduce_packet<C, QM>(cur, carry, xbase, P0.fixed_mask);
             const float trig = trigger_of<C, INT>(Rd);
-            if (__any(trig >= tau) && !(P0.dbg_flags & 2u)) {
+            if (__any(trig >= tau)) {
                 float tau_now = tau;
                 // Long partitions only (more rows per wave and query than its list holds: from ~1.5M rows on 256 CUs). A
                 // wave that runs ahead of its workgroup's exchange has no threshold yet: every row passes, and once the
@@ -836,7 +827,7 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
                     // BATCH_TAU_WAIT the wave goes on without one, so progress never depends on other workgroups being
                     // resident. (On a small matrix every wave is in that position: 100+ us per query without this wait.)
                     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-                    while (lds_load(&mp[MISC_TAU]) == __float_as_uint(min_units) && !(P0.dbg_flags & 4u) &&
+                    while (lds_load(&mp[MISC_TAU]) == __float_as_uint(min_units) &&
                            __builtin_amdgcn_s_memrealtime() - t0 < (local ? LOCAL_TAU_WAIT : BATCH_TAU_WAIT))
                         __builtin_amdgcn_s_sleep(4);
                     if (DBG && P0.dbg && lane == 0) {  // TKSPMV_STATS=1
@@ -913,10 +904,12 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const BatchArgs A) {
         P0.trace = nullptr;
         P0.dbg = nullptr;
         P0.stamps = nullptr;
-        P0.dbg_flags = 0u;
-        P0.dbg_repeat = 0u;
     }
     __shared__ BatchLds<XCOLS, C> L;
+    // (reduce_packet forms LDS addresses of x as (word & 0xFFC) | base: x must sit on a 4 KiB boundary -- this object is the
+    //  kernel's ONLY __shared__ block, so it starts at LDS address 0, and x is its first member)
+    using LdsBlock = BatchLds<XCOLS, C>;
+    static_assert(offsetof(LdsBlock, u) == 0 && offsetof(decltype(LdsBlock::u), w) == 0 && offsetof(decltype(LdsBlock::u.w), x) == 0, "x must be the first member of the kernel's LDS block");
     const uint32_t tid = threadIdx.x;
     if (RESIDENT) {
         batch_phase<C, XCOLS, QM, DBG, true, false>(P0, SP0, B, false, L);

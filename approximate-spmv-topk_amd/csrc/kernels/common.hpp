@@ -57,9 +57,6 @@ struct StreamParams {
     uint32_t deferred;
     float *unit_inv_out;  // 1 / (score units per 1.0) of this query, for a selection that runs in a later launch
     float *scores;  // SCORES variant only
-    uint32_t dbg_flags;       // ablation switches (TKSPMV_DBG_FLAGS): 1 no publish, 2 no offers, 4 no tau duty, 8 no flush
-    const uint8_t *rep_packets[4];  // experiment (TKSPMV_DBG_REPEAT): stream copies the repeats rotate over
-    uint32_t dbg_repeat;            // experiment: passes over the partition within ONE launch (0/1 = normal)
     unsigned long long *trace;   // optional (TKSPMV_TRACE=1): per-wave s_memrealtime stamps, [grid+1][9 waves][8]
     unsigned long long *stamps;  // optional (TKSPMV_STAMPS=1): s_memtime stamps of the selection tail, last workgroup
     unsigned long long *dbg;  // optional counters (TKSPMV_STATS=1): [0] slow-path executions, [1] appended rows

@@ -2,6 +2,7 @@
 // workgroup's eight ordered slots, select_local) and single_kernel, the one-query launch built on them (tkspmv_run).
 // Part of engine.hip (one translation unit: included there in this order; device code only).
 #pragma once
+#include <cstddef>
 #include "packet_math.hpp"
 
 namespace tkspmv {
@@ -483,6 +484,7 @@ __global__ void __launch_bounds__(512, 4) single_kernel(const StreamParams P, co
     constexpr int VT = value_type_of(QM);
     constexpr uint32_t WAVE_CAP = ListGeom<1024>::WAVE_CAP;
     __shared__ SingleLds L;
+    static_assert(offsetof(SingleLds, u) == 0 && offsetof(decltype(SingleLds::u), w) == 0 && offsetof(decltype(SingleLds::u.w), x) == 0, "x must be the first member of the kernel's only LDS block (reduce_packet's address trick)");
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t bid = blockIdx.x, n_wg = gridDim.x;

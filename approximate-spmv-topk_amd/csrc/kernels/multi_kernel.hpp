@@ -404,7 +404,7 @@ __global__ void __launch_bounds__(576, Q >= 8 ? 4 : 6) multi_kernel(const Stream
                     for (int q = 0; q < Q; ++q) {
                         if ((uint32_t)q < nq) {
                             const float tau = __uint_as_float(lds_load(&L.misc[q][MISC_TAU]));
-                            if (__any(acc[q] >= tau) && !(P0.dbg_flags & 2u))
+                            if (__any(acc[q] >= tau))
                                 offer_rows<MULTI_WAVE_CAP>(M.A, set0 + q, P0.ovf_cap, acc[q], (slice + n_done) * 64u, tau,
                                                            lane, grp_local, publishes, L.u.w.cand[wave][q], wcnt[q], L.misc[q], P0.dbg);
                         }
@@ -430,7 +430,7 @@ __global__ void __launch_bounds__(576, Q >= 8 ? 4 : 6) multi_kernel(const Stream
                 for (int q = 0; q < Q; ++q) {
                     if ((uint32_t)q < nq) {
                         const float tau = __uint_as_float(lds_load(&L.misc[q][MISC_TAU]));
-                        if (__any(held[d][q] >= tau) && !(P0.dbg_flags & 2u))
+                        if (__any(held[d][q] >= tau))
                             offer_rows<MULTI_WAVE_CAP>(M.A, set0 + q, P0.ovf_cap, held[d][q], (slice + (uint32_t)d) * 64u, tau,
                                                        lane, grp_local, publishes, L.u.w.cand[wave][q], wcnt[q], L.misc[q],
                                                        P0.dbg ? P0.dbg + 4 : nullptr);

@@ -44,21 +44,6 @@ struct SelectParams {
     // 100 MHz) and the selecting workgroup reports end - start in host_out[2k + 1] -- the kernel's own duration, so that
     // tkspmv_run needs no hipEvent pair around the launch (two records and a query: ~6 us of the 67 us a query took end to end).
     unsigned long long *t_start;
-    // Prior thresholds (batch kernel, round 3): a query may START with a guessed threshold -- a fraction of the k-th best score of
-    // a query selected shortly before. tau0_g: order key of the largest guess any workgroup used for THIS query (atomic max by
-    // the servers; 0 = none). The guess was harmless iff at least k candidates reach it (then the k-th best score does too, and
-    // no row of the result was dropped below it); otherwise the selection raises *repair_flag and the query is run again
-    // without a guess by the repair launch that follows every batch launch. prior_word receives the order key of this
-    // query's k-th best score as it is reported, folded into a lower envelope (the next guesses derive from it).
-    uint32_t *tau0_g;
-    uint32_t *repair_flag;
-    uint32_t *prior_word;
-    float prior_rise;
-    // Workgroup-local thresholds (batch kernel): nobody has computed a device-wide threshold, but slot 0 of every workgroup
-    // holds its best row -- the k-th largest of those (distinct rows) is a lower bound of the k-th best score: the first cut.
-    uint32_t local_thr;
-    // (batch kernel, local thresholds carried from query to query: a failed check suspends them for the next 16 .. 4096 selections)
-    uint32_t *prior_block;
 };
 
 constexpr int MAX_GM = 16;  // n_groups_pub <= 1024 => at most 16 published maxima per lane
@@ -108,48 +93,18 @@ __device__ __forceinline__ uint32_t kth_largest_prefix(const uint32_t (&gk)[MAX_
     return prefix;
 }
 
-// VERIFY: the batch kernel's checked thresholds (tau0_g / repair_flag / prior_word / local_thr) are compiled in; the other kernels
-// never set those fields and do without the code (and its registers).
 // OVF_SPEC: the first OVF_SPEC x nthreads entries of the overflow list are loaded BLINDLY with the slots (before the list's length
 // is known): the single-query launches, whose tail this selection is, save the two trips through memory that counting and
 // placing a short overflow list cost otherwise (it holds ~100 entries at 1M rows). 0: the batch kernel (its selections run
 // beside the stream, and it has no registers to spare).
-template <bool VERIFY = false, int OVF_SPEC = 0>
+template <int OVF_SPEC = 0>
 __device__ __forceinline__ void select_body(const SelectParams &P, const uint32_t tid, const uint32_t nthreads,
-                                            SelectShared &S, const uint32_t dbg_flags = 0u,
+                                            SelectShared &S,
                                             unsigned long long *stamps = nullptr, const float out_scale_override = 0.0f) {
     const float out_scale =
         out_scale_override != 0.0f ? out_scale_override : (P.unit_inv_in ? __hip_atomic_load(P.unit_inv_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : P.out_scale);
     const uint32_t lane = tid & 63u;
-    uint32_t n_slots = P.n_wg * WG_SLOTS;  // host guarantees n_slots <= SEL_PER_THREAD * nthreads
-    // (opaque to the compiler: inside the batch kernel's query loop it would otherwise hoist the bounds checks of the slot loops
-    //  below out of the loop -- sixteen lane masks in SGPR pairs, kept alive across the whole selection and spilled)
-    if (VERIFY) asm volatile("" : "+s"(n_slots));
-
-    // (local thresholds: a round trip of its own ahead of the slots' -- held together they cost more registers than the
-    //  kernel has; with several selector workgroups the selection's latency is not what bounds a launch)
-    uint32_t thr_local = 0u;
-    if (VERIFY && P.local_thr) {  // (wave-uniform)
-        if (tid < 64u) {  // (the host switches local thresholds on for at most 512 workgroups: 8 slots per lane, loads back to back)
-            uint32_t gk[MAX_GM];
-            unsigned long long first[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const uint32_t w = lane + 64u * (uint32_t)i;
-                first[i] = ld_agent(&P.wg_cand[(size_t)(w < P.n_wg ? w : 0u) * WG_SLOTS]);
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const uint32_t w = lane + 64u * (uint32_t)i;
-                gk[i] = (w < P.n_wg && (uint32_t)(first[i] >> 32) != SLOT_INVALID) ? order_key(__uint_as_float((uint32_t)first[i])) : 0u;
-            }
-            const uint32_t t = kth_largest_prefix<8, 17>(gk, P.k);
-            if (tid == 0) S.thr = t;
-        }
-        __syncthreads();
-        thr_local = S.thr;
-    }
-
+    const uint32_t n_slots = P.n_wg * WG_SLOTS;  // host guarantees n_slots <= SEL_PER_THREAD * nthreads
     // One round trip: every thread loads its slots, the overflow count and (wave 0) the group maxima blindly.
     unsigned long long mine[SEL_PER_THREAD];
     bool ok[SEL_PER_THREAD];
@@ -176,18 +131,11 @@ __device__ __forceinline__ void select_body(const SelectParams &P, const uint32_
     }
     // The reducer servers keep the k-th largest published maximum in tau_g: a valid lower bound of the k-th best
     // score (slightly stale, never too high). It prunes what was appended while the threshold was converging.
-    // (the recorded guess of this query, for the check further down: its round trip rides with the loads above)
-    const uint32_t t0 = (VERIFY && P.repair_flag && P.tau0_g) ? __hip_atomic_load(P.tau0_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-    const uint32_t thr = (VERIFY && P.local_thr) ? thr_local : (P.use_gmax ? __hip_atomic_load(P.tau_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u);
+    const uint32_t thr = P.use_gmax ? __hip_atomic_load(P.tau_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
 
     uint32_t novf = __hip_atomic_load(P.ovf_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     novf = novf < P.ovf_cap ? novf : P.ovf_cap;
     if (stamps && tid == 0) stamps[4] = __builtin_amdgcn_s_memtime() + (mine[0] & 1ull) * 0ull;  // after the loads returned
-    if (dbg_flags & 256u) {  // timing aid: stop once the loads have landed
-        if (mine[0] == 1234567ull && thr == 7654321u) P.out_idx[0] = novf;
-        if (tid == 0) for (uint32_t c = 0; c < 9u; ++c) P.done_count[32u * c] = 0u;
-        return;
-    }
     if (tid == 0) {
         S.cnt = 0;
         S.total = 0;
@@ -311,46 +259,6 @@ __device__ __forceinline__ void select_body(const SelectParams &P, const uint32_
     }
     if (stamps && tid == 0) stamps[5] = __builtin_amdgcn_s_memtime();  // keys in LDS
 
-    // Prior threshold of this query, if any: did at least k candidates reach it?
-    if (VERIFY && P.repair_flag) {
-        if (tid == 0) S.cnt = 0;
-        __syncthreads();
-        uint32_t c = 0;
-        for (uint32_t i = tid; i < n_sel; i += nthreads) c += ((uint32_t)(S.keys[i] >> 32) >= t0) ? 1u : 0u;
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) c += (uint32_t)__shfl_xor((int)c, d);
-        if (lane == 0 && c) atomicAdd(&S.cnt, c);
-        __syncthreads();
-        if (tid == 0) {
-            // (n_sel is capped at SEL_CAP >= k: a cap hit still proves k candidates when they all reach the guess)
-            const uint32_t bad = (t0 != 0u && S.cnt < P.k) ? 1u : 0u;
-            __hip_atomic_store(P.repair_flag, bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (P.prior_block) {
-                // word 0: selections to go without carried thresholds; word 1: how many a failure costs -- doubled by every
-                // failure (16 .. 4096: data on which carried thresholds keep failing ends up paying a repair per 4096 queries),
-                // halved by every 64 checks passed in a row with them (word 2).
-                if (bad) {
-                    (void)__hip_atomic_fetch_add(P.prior_block + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (word 3: checks failed so far -- tkspmv_debug_counters)
-                    const uint32_t len = __hip_atomic_load(P.prior_block + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const uint32_t nl = len < 16u ? 16u : (len >= 2048u ? 4096u : 2u * len);
-                    __hip_atomic_store(P.prior_block + 1, nl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(P.prior_block + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(P.prior_block, nl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                } else if (__hip_atomic_load(P.prior_block, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-                    (void)__hip_atomic_fetch_sub(P.prior_block, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                } else if (t0 != 0u) {
-                    const uint32_t ok_run = __hip_atomic_fetch_add(P.prior_block + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-                    if ((ok_run & 63u) == 0u) {
-                        const uint32_t len = __hip_atomic_load(P.prior_block + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (len > 16u) __hip_atomic_store(P.prior_block + 1, len / 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                }
-            }
-            if (P.tau0_g) __hip_atomic_store(P.tau0_g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __syncthreads();
-    }
-
     // Rank by counting: keys are unique (distinct rows), rank r = number of larger keys. G threads share one key
     // (each counts a slice of the list, partial counts meet through quad/oct shuffles) so the whole workgroup works.
     uint32_t G = 1;
@@ -368,14 +276,6 @@ __device__ __forceinline__ void select_body(const SelectParams &P, const uint32_
             for (uint32_t u = 0; u < 8; ++u) r += (S.keys[blk * 8u + u] > kx);
         }
         for (uint32_t d = 1; d < G; d <<= 1) r += (uint32_t)__shfl_xor((int)r, (int)d);
-        if (VERIFY && active && part == 0u && r + 1u == P.k && P.prior_word) {
-            // The next guesses derive from a LOWER ENVELOPE of the k-th best scores seen so far: it drops to this query's at once
-            // and rises by prior_rise per query otherwise -- a repair costs a whole query, a low guess a few candidates.
-            const float kth = key_to_float((uint32_t)(kx >> 32)) * out_scale;
-            const uint32_t old = __hip_atomic_load(P.prior_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const float env = old ? fminf(kth, key_to_float(old) * P.prior_rise) : kth;
-            __hip_atomic_store(P.prior_word, env > 0.0f ? order_key(env) : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
         if (active && part == 0u && r < P.k) {
             const uint32_t oi = (uint32_t)(kx & 0xFFFFFFFFull) + P.first_row;
             const float ov = key_to_float((uint32_t)(kx >> 32)) * out_scale;

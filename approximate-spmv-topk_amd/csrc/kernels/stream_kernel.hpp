@@ -1,6 +1,7 @@
 // kernels/stream_kernel.hpp -- stream_kernel: one query per launch (fused selection tail, deferred selection, or SpMV-only scores).
 // Part of engine.hip (one translation unit: included there in this order; device code only).
 #pragma once
+#include <cstddef>
 #include "packet_math.hpp"
 
 namespace tkspmv {
@@ -43,8 +44,6 @@ struct StreamLds {
 template <int C, bool SCORES, int XCOLS, int QM = 0, int NBUF = TKSPMV_NBUF, bool DBG = false>
 __global__ void __launch_bounds__(576, ((C == 8 && !SCORES) || QM == 7) ? 6 : 5) stream_kernel(const StreamParams P, const SelectParams SP) {
     // (constants, not a modified copy of P: a copy that is passed on by reference ends up in scratch memory)
-    const uint32_t dbg_flags = DBG ? P.dbg_flags : 0u;
-    const uint32_t dbg_repeat = DBG ? P.dbg_repeat : 0u;
     unsigned long long *const dbg_trace = DBG ? P.trace : nullptr;
     unsigned long long *const dbg_stamps = DBG ? P.stamps : nullptr;
     unsigned long long *const dbg_counters = DBG ? P.dbg : nullptr;
@@ -57,6 +56,10 @@ __global__ void __launch_bounds__(576, ((C == 8 && !SCORES) || QM == 7) ? 6 : 5)
     // (at most 1024 columns: two -- the third would push the 16-bit layouts past 80 registers; the 12-bit layout keeps one)
     constexpr int DEFER_C = (C == 8 || QM == 7) ? 1 : (XCOLS <= 1024 ? DEFER : DEFER + 1);
     __shared__ StreamLds<XCOLS> L;
+    // (reduce_packet forms LDS addresses of x as (word & 0xFFC) | base: x must sit on a 4 KiB boundary -- this object is the
+    //  kernel's ONLY __shared__ block, so it starts at LDS address 0, and x is its first member)
+    using LdsBlock = StreamLds<XCOLS>;
+    static_assert(offsetof(LdsBlock, u) == 0 && offsetof(decltype(LdsBlock::u), w) == 0 && offsetof(decltype(LdsBlock::u.w), x) == 0, "x must be the first member of the kernel's LDS block");
     float *x_lds = L.u.w.x;
     const uint32_t xbase = lds_addr_of(L.u.w.x);  // (0: the object is the kernel's only LDS block and x its first member)
     uint2 *cand = L.u.w.cand;
@@ -79,7 +82,7 @@ __global__ void __launch_bounds__(576, ((C == 8 && !SCORES) || QM == 7) ? 6 : 5)
         // one partition per streaming wave of grid - 1 workgroups, so nothing waits for a free slot: the selection
         // runs during the launch's start-up, when the memory system is still idle.
         if (bid == 0u) {
-            if (SP.n_wg != 0u) select_body<false, 1>(SP, tid, blockDim.x, sel_sh);
+            if (SP.n_wg != 0u) select_body<1>(SP, tid, blockDim.x, sel_sh);
             if (tr && lane == 0) {
                 tr[0] = tr0;
                 tr[5] = __builtin_amdgcn_s_memrealtime();
@@ -170,9 +173,9 @@ __global__ void __launch_bounds__(576, ((C == 8 && !SCORES) || QM == 7) ? 6 : 5)
     if (tr) tr1 = __builtin_amdgcn_s_memrealtime();
 
     if (is_server) {
-        if (!SCORES && P.n_sets != 0u && !(dbg_flags & 4u)) {
+        if (!SCORES && P.n_sets != 0u) {
             for (;;) {
-                if (!(dbg_flags & 1u)) publish_group_max(P, bid, lane, misc);
+                publish_group_max(P, bid, lane, misc);
                 // Only a few servers read all published maxima (many readers of those 16 lines slow the whole
                 // stream down: measured); the others read the one word the reducers keep up to date.
                 float t;
@@ -262,9 +265,6 @@ __global__ void __launch_bounds__(576, ((C == 8 && !SCORES) || QM == 7) ? 6 : 5)
         // Two packets in flight behind the one being reduced. The buffers rotate by NAME (the loop is unrolled by
         // NBUF): copying a freshly loaded buffer into another would wait for the youngest load and drain the
         // prefetch queue every iteration.
-        const uint32_t np_one = np;
-        if (dbg_repeat > 1u) np *= dbg_repeat;  // experiment: what a persistent multi-query kernel would stream
-        uint32_t ia_cur = NBUF - 1 < np_one ? NBUF - 1 : 0u, ia_rep = 0u;
         for (uint32_t i0 = 0; i0 < np; i0 += NBUF) {
 #if TKSPMV_STREAM_TURNS
             // The two workgroups of a CU take turns at the higher priority (see batch_kernel.hpp): at equal priority the
@@ -287,20 +287,8 @@ __global__ void __launch_bounds__(576, ((C == 8 && !SCORES) || QM == 7) ? 6 : 5)
             {
                 // Unconditional (index clamped to the last packet): a fixed number of younger loads lets the
                 // compiler wait with a counted vmcnt instead of vmcnt(0).
-                uint32_t ia = (i + (NBUF - 1) < np) ? (i + (NBUF - 1)) : (np - 1);
-                const uint8_t *pk_a = pk;
-                if (dbg_repeat > 1u) {
-                    ia = ia_cur;
-                    pk_a = P.rep_packets[ia_rep & 3u] + (size_t)p0 * P.packet_bytes;
-                    if (i + (NBUF - 1) < np) {
-                        ++ia_cur;
-                        if (ia_cur == np_one) {
-                            ia_cur = 0u;
-                            ++ia_rep;
-                        }
-                    }
-                }
-                load_packet<C, VT>(pk_a + (size_t)ia * P.packet_bytes, lane, ahead);
+                const uint32_t ia = (i + (NBUF - 1) < np) ? (i + (NBUF - 1)) : (np - 1);
+                load_packet<C, VT>(pk + (size_t)ia * P.packet_bytes, lane, ahead);
                 rb_ahead = SCORES ? P.pkt_row[p0 + ia] : scalar_load(P.pkt_row + p0 + ia);
             }
             float tau = 0.0f;
@@ -336,7 +324,7 @@ __global__ void __launch_bounds__(576, ((C == 8 && !SCORES) || QM == 7) ? 6 : 5)
                     if (lane == 0 && publishes && wmax >= min_units)
                         (void)__hip_atomic_fetch_max(&misc[MISC_GRPMAX + grp_local], order_key(wmax), __ATOMIC_RELAXED,
                                                      __HIP_MEMORY_SCOPE_WORKGROUP);
-                } else if (__any(trigger_of<C, INT>(Rd) >= tau) && !(dbg_flags & 2u)) {
+                } else if (__any(trigger_of<C, INT>(Rd) >= tau)) {
                     // (the trigger bounds every finished row of its lane from above: packet_math.hpp)
                     const RowSums<C> R = expand<C, INT>(Rd, packet_flags<C, QM>(cur));
                     offer_candidates<C, QM, ListGeom<XCOLS>::WAVE_CAP, DBG>(P, R, rb_cur, tau, lane, grp_local, publishes, wcand, wcnt, misc);
@@ -373,7 +361,6 @@ __global__ void __launch_bounds__(576, ((C == 8 && !SCORES) || QM == 7) ? 6 : 5)
     if (tr) tr4 = __builtin_amdgcn_s_memrealtime();
     const unsigned long long ts_stream_end = dbg_stamps ? __builtin_amdgcn_s_memtime() : 0ull;
     if (!is_server && lane == 0) atomicAdd(&misc[MISC_DONE], 1u);
-    if (dbg_flags & 8u) return;
 
     // ---- flush: every wave on its own, no workgroup synchronisation. What still clears the (now much tighter)
     // threshold leaves the wave's private list: the first survivor to this wave's fixed slot, further ones to the
@@ -426,7 +413,7 @@ __global__ void __launch_bounds__(576, ((C == 8 && !SCORES) || QM == 7) ? 6 : 5)
                 __hip_atomic_fetch_add(&SP.done_count[32u * 8u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             last = (t2 == n_groups - 1u) ? 1u : 0u;
         }
-        if (last && !(dbg_flags & 32u)) {
+        if (last) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -434,7 +421,7 @@ __global__ void __launch_bounds__(576, ((C == 8 && !SCORES) || QM == 7) ? 6 : 5)
     }
     __syncthreads();
     const unsigned long long ts_ticket = dbg_stamps ? __builtin_amdgcn_s_memtime() : 0ull;
-    if (sel_sh.last && !(dbg_flags & 16u)) select_body<false, 1>(SP, tid, blockDim.x, sel_sh, dbg_flags, dbg_stamps, inv_unit);
+    if (sel_sh.last) select_body<1>(SP, tid, blockDim.x, sel_sh, dbg_stamps, inv_unit);
     if (dbg_stamps && sel_sh.last && tid == 0) {
         dbg_stamps[0] = ts_stream_end;
         dbg_stamps[1] = ts_flush_issued;

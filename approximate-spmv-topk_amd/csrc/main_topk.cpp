@@ -303,6 +303,16 @@ void report_verbose(const Verdict &v, const IterationTimes &t, const TopK &sw, c
 }  // namespace
 
 int main(int argc, char *argv[]) {
+    if (argc == 2 && std::string(argv[1]) == "--options") {  // the library's documented options (include/tkspmv.h: tkspmv_set_option)
+        for (int i = 0; i < tkspmv_option_count(); ++i) {
+            const char *name, *kind, *values, *doc;
+            tkspmv_option_info(i, &name, &kind, &values, &doc);
+            std::cout << "TKSPMV_" << name << "  [" << kind << "]  " << values << "\n    " << doc << "\n";
+        }
+        std::cout << "this program only: TKSPMV_FIXED_WIDTH (8..32: fixed-point values of that width), TKSPMV_INDEX_BASE (0 | 1 | auto), "
+                     "TKSPMV_SEED (query vector), TKSPMV_CACHE_DIR (packed-matrix cache)\n";
+        return 0;
+    }
     const RunConfig cfg(argc, argv);
     const int debug = cfg.opt.debug;
     const int k = cfg.opt.top_k_value;

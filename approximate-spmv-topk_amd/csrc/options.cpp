@@ -1,0 +1,97 @@
+#include "options.hpp"
+
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+
+namespace tkspmv {
+
+static const OptionDef k_options[] = {
+    // ---- behaviour: which path answers a query ----
+    {"LOCAL", "behaviour", "0 | 1 | 2 (default: by matrix size)",
+     "threshold scheme of the batch and single-query kernels: 0 = device-wide exchange (exact by construction); 1 / 2 = workgroup-local "
+     "thresholds from each wave's best / second-best packet maximum, carried from query to query and CHECKED by the selection (a failed "
+     "check repairs the query through the exact kernel). Ignored above 512 workgroups."},
+    {"LOCAL_BETA", "tuning", "float (default 1.0)", "factor applied to a carried workgroup threshold before the next query uses it"},
+    {"SINGLE", "behaviour", "0 | 1 (default 1)", "0: tkspmv_run uses the stream kernel with the device-wide exchange instead of the single-query kernel with local thresholds"},
+    {"BATCH", "behaviour", "0 | 1 (default 1)", "0: tkspmv_enqueue_batch / _many launch one kernel per query"},
+    {"BATCH_MAX", "tuning", "1..32 (default 32, 12 for small matrices)", "queries per batch launch"},
+    {"SELECTORS", "tuning", "1..8 (default 4 up to LOCAL_MATRIX_PACKETS, else 1)", "selection workgroups a batch launch keeps in flight"},
+    {"PACE", "tuning", "0..32 (default by size)", "pacing quantum of the batch kernel's workgroups by rank (s_sleep units); 0 = none"},
+    {"PACE_LEVELS", "tuning", "1..8", "number of distinct pacing ranks"},
+    {"FUSED", "behaviour", "0 | 1 (default 1 where the selection fits one workgroup)", "0: stream and selection as two launches"},
+    {"RADIX", "behaviour", "0 | 1 (default: k above 3/8 of the publishing groups)", "1: scores + radix select instead of thresholded streaming"},
+    {"MULTI_Q", "behaviour", "0 | 1 | 3 | 5 | 8 (default by size; desc.multi_q wins)", "queries per pass of the small-matrix kernel (multi_kernel); 0 = off"},
+    {"MULTI_CHAINS", "tuning", "1 | 2 (default 2)", "independent launch chains tkspmv_enqueue_multi alternates between"},
+    {"SMALL_PACKETS", "tuning", "packets (default LOCAL_MATRIX_PACKETS)", "size up to which a matrix gets the small-matrix settings (4 selectors, 1-2 packet partitions, local thresholds); 0 = round 2's behaviour"},
+    {"MIN_PACKETS", "tuning", ">= 1", "minimum packets per wave partition"},
+    {"PARTITIONS_HINT", "diagnostic", "count", "wave partitions to pack (read probe experiments; an engine whose partitions exceed its streaming waves does not batch)"},
+    {"DEVICE_PACK", "behaviour", "0 | 1 (default 1)", "0: pack the matrix on the host instead of on the device"},
+    {"HOST_PATH", "behaviour", "0 | 1 (default 1)", "0: no host-visible result block / mapped x (tkspmv_run and tkspmv_read go through hipMemcpy)"},
+    {"BAR_X", "behaviour", "0 | 1 (default 1 where the device reports a large BAR and a round trip verifies)", "0: tkspmv_set_query stages x through pinned memory instead of storing into device memory"},
+    {"HOST_X", "behaviour", "copy | direct | direct_nc (default copy)", "direct: kernels read x from mapped host memory (direct_nc: non-coherent mapping)"},
+    {"RUN_EVENTS", "behaviour", "0 | 1 (default 0)", "1: tkspmv_run returns a hipEvent bracket instead of the kernel's own device-clock span"},
+    {"RESIDENT_IDLE_MS", "tuning", "ms", "how long the resident kernel waits for a query before it retires"},
+    {"HOST_THREADS", "tuning", "count", "threads of the host-side packer and generators"},
+    // ---- layout ----
+    {"F32_C12", "layout", "0 | 1 (default 1 for <= 4096 columns)", "fp32 values with 12-bit column words (1408-byte packets)"},
+    {"SELL_C12", "layout", "0 | 1", "12-bit column words in the row-per-lane (SELL) layout"},
+    {"FIXED_UNPACKED", "layout", "set = on", "fixed-point values as one u32 per entry instead of the packed 20..26-bit streams"},
+    // ---- multi-GPU ----
+    {"DIST_NO_NCCL", "behaviour", "set = on", "shard merge through the host instead of RCCL (CPU rehearsal, tests)"},
+    {"DIST_FORCE_NCCL", "behaviour", "set = on", "RCCL even at world size 1"},
+    {"DIST_BATCH", "tuning", "queries", "queries per exchange of the sharded engine"},
+    // ---- diagnostics (DBG instantiations of the kernels; never on by default) ----
+    {"STATS", "diagnostic", "set = on", "per-launch counters (offers, triggers) in tkspmv_debug_counters"},
+    {"STAMPS", "diagnostic", "set = on", "device-clock stamps of the kernel phases"},
+    {"TRACE", "diagnostic", "set = on", "per-wave trace buffer for tkspmv_debug_trace"},
+    {"RESIDENT_STATS", "diagnostic", "set = on", "counters of the resident kernel"},
+    {"DEBUG_OCC", "diagnostic", "set = on", "print launch geometry and occupancy at creation"},
+    {"READ_PROBE", "diagnostic", "depth,work", "load-only probe: loads in flight and arithmetic per packet"},
+    {"READ_PROBE_MAP", "diagnostic", "0..3", "load-only probe: workgroup -> partition map"},
+    {"READ_PROBE_ENDS", "diagnostic", "set = on", "load-only probe: record when each XCD's waves finished"},
+};
+
+static std::mutex &lock() {
+    static std::mutex m;
+    return m;
+}
+static std::map<std::string, std::string> &overrides() {
+    static std::map<std::string, std::string> m;
+    return m;
+}
+
+int option_count() { return (int)(sizeof(k_options) / sizeof(k_options[0])); }
+const OptionDef *option_def(int i) { return i >= 0 && i < option_count() ? &k_options[i] : nullptr; }
+
+static const OptionDef *find(const char *name) {
+    if (!name) return nullptr;
+    for (const OptionDef &o : k_options)
+        if (std::strcmp(o.name, name) == 0) return &o;
+    return nullptr;
+}
+
+const char *opt(const char *name) {
+    if (!find(name)) {
+        std::fprintf(stderr, "[tkspmv] internal error: option %s is not in the table of options.cpp\n", name ? name : "(null)");
+        std::abort();
+    }
+    {
+        std::lock_guard<std::mutex> g(lock());
+        auto it = overrides().find(name);
+        if (it != overrides().end()) return it->second.c_str();  // (stable until the same option is set again)
+    }
+    return std::getenv((std::string("TKSPMV_") + name).c_str());
+}
+
+int set_option(const char *name, const char *value) {
+    if (!find(name)) return -1;
+    std::lock_guard<std::mutex> g(lock());
+    if (value) overrides()[name] = value;
+    else overrides().erase(name);
+    return 0;
+}
+
+}  // namespace tkspmv

@@ -36,11 +36,11 @@ uint32_t fill_partitions(const std::vector<uint32_t> &len, uint64_t cap, std::ve
 }  // namespace
 
 uint64_t small_matrix_packets() {
-    if (const char *f = getenv("TKSPMV_SMALL_PACKETS")) return (uint64_t)atoll(f);
+    if (const char *f = opt("SMALL_PACKETS")) return (uint64_t)atoll(f);
     return SMALL_MATRIX_PACKETS;
 }
 uint32_t min_packets_per_partition_for(uint64_t nnz, uint32_t C, uint32_t cols) {
-    if (const char *f = getenv("TKSPMV_MIN_PACKETS")) return (uint32_t)std::max(1, atoi(f));
+    if (const char *f = opt("MIN_PACKETS")) return (uint32_t)std::max(1, atoi(f));
     const uint64_t packets = nnz / (64u * (uint64_t)std::max(C, 1u));
     if (cols > 1024u || packets > small_matrix_packets()) return 4u;
     return packets <= small_matrix_packets() / 10u ? 1u : 2u;  // (up to ~2 packets per streaming wave: one each)

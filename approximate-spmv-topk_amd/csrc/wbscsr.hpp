@@ -27,6 +27,8 @@
 #include <string>
 #include <vector>
 
+#include "options.hpp"
+
 // The conversions and the slot arithmetic below are shared, source for source, by the host packer (wbscsr.cpp) and the
 // device packer (device_pack.hip): one definition, so the two cannot drift apart.
 #if defined(__HIP__)
@@ -156,16 +158,16 @@ inline Precision stream_precision(int32_t api_precision, uint32_t fixed_width = 
     // fp32 values over few columns travel with 12-bit column words (C = entries per lane; 0: not known, keep 16 bits)
     // (TKSPMV_F32_C12=0 keeps 16-bit column words: 8.3 % more bytes, 2.7 % slower back-to-back queries)
     if (api_precision == 0 && C == 4 && cols >= 1 && cols <= F32C12_MAX_COLS) {
-        const char *f = getenv("TKSPMV_F32_C12");
+        const char *f = opt("F32_C12");
         if (!f || atoi(f) != 0) return Precision::F32C12;
     }
     // narrow fixed point with few columns travels bit-packed (TKSPMV_FIXED_UNPACKED=1 keeps one u32 per value + a column word)
     if (api_precision == 4 && fixed_width >= 8 && fixed_width <= FIXED20_MAX_WIDTH && cols >= 1 && cols <= FIXED20_MAX_COLS &&
-        getenv("TKSPMV_FIXED_UNPACKED") == nullptr)
+        opt("FIXED_UNPACKED") == nullptr)
         return Precision::FIXED20;
     // 21..26 bits: five bytes per entry (4 entries per lane; C = 0: not known, the one-u32-per-value stream)
     if (api_precision == 4 && C == 4 && fixed_width > FIXED20_MAX_WIDTH && fixed_width <= FIXED26_MAX_WIDTH && cols >= 1 && cols <= FIXED26_MAX_COLS &&
-        getenv("TKSPMV_FIXED_UNPACKED") == nullptr)
+        opt("FIXED_UNPACKED") == nullptr)
         return Precision::FIXED26;
     switch (api_precision) {
         case 0: return Precision::F32;

@@ -190,7 +190,7 @@ std::string pack_wsell(uint32_t rows, uint32_t cols, uint64_t nnz, const uint32_
 }
 
 bool sell_c12_wanted() {
-    const char *f = getenv("TKSPMV_SELL_C12");
+    const char *f = opt("SELL_C12");
     return !f || atoi(f) != 0;
 }
 

@@ -256,6 +256,19 @@ int tkspmv_time_stream_read(tkspmv_t *e, int32_t passes, double *ns_per_pass);
  * back-to-back on the engine stream, timed with hipEvents on that stream. */
 int tkspmv_profile(tkspmv_t *e, const float *dev_xs, int32_t n_x, int32_t iters, tkspmv_timing *out);
 
+/* Engine options (no reference counterpart: the reference fixes its variants at compile time, types.hpp / the Makefile's -D flags).
+ * Every switch that changes what an engine does is one row of a documented table (csrc/options.cpp; tkspmv_option_info lists it at
+ * run time: `bin/approximate-spmv-mi355x-topk --options` prints it): threshold scheme, batching, layouts, host hand-off, multi-GPU
+ * merge, diagnostics. An option is read when an engine, a packed matrix or a communicator is CREATED; tkspmv_set_option(name, value)
+ * sets it for the creations that follow in this process (value NULL: back to unset = the engine's own default), and the
+ * environment variable TKSPMV_<NAME> is the same option for shell-driven runs (a value set through this call wins).
+ * Returns TKSPMV_ERR_INVALID for a name that is not in the table. tkspmv_get_option: the current value or NULL.
+ * tkspmv_option_info(i, ...): row i of the table (0 <= i < tkspmv_option_count()); any out pointer may be NULL. */
+int tkspmv_set_option(const char *name, const char *value);
+const char *tkspmv_get_option(const char *name);
+int tkspmv_option_count(void);
+int tkspmv_option_info(int32_t i, const char **name, const char **kind, const char **values, const char **doc);
+
 const char *tkspmv_last_error(void);
 int tkspmv_device_count(void);
 

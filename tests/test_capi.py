@@ -104,3 +104,34 @@ def test_reference_side_host_program_builds_against_the_reference_headers(pkg):
         r = subprocess.run([exe, "-m", os.path.join(ROOT, "tests", "golden", "small_0indexed.mtx"), "-k", "8", "-t", "1"],
                            capture_output=True, text=True)
         assert r.returncode == 1 and "no HIP device" in r.stderr
+
+
+def test_options_are_one_documented_table_settable_through_the_abi(pkg, monkeypatch):
+    """tkspmv_set_option / tkspmv_get_option / tkspmv_option_info (include/tkspmv.h): every switch the library reads is a row of
+    csrc/options.cpp's table; the environment is the same option for shell-driven runs and a value set through the call wins; a
+    name outside the table is refused; and no library source calls getenv for an engine option anywhere else."""
+    import glob
+    import os
+    import re
+    opts = {o["name"]: o for o in pkg.options()}
+    assert {"LOCAL", "BATCH", "SELECTORS", "BAR_X", "DIST_NO_NCCL", "TRACE"} <= set(opts)
+    assert all(o["doc"] and o["values"] and o["kind"] in ("behaviour", "layout", "tuning", "diagnostic") for o in opts.values())
+    monkeypatch.delenv("TKSPMV_SELECTORS", raising=False)
+    assert pkg.get_option("SELECTORS") is None
+    monkeypatch.setenv("TKSPMV_SELECTORS", "2")
+    assert pkg.get_option("SELECTORS") == "2"
+    pkg.set_option("SELECTORS", 3)
+    assert pkg.get_option("SELECTORS") == "3"
+    pkg.set_option("SELECTORS", None)
+    assert pkg.get_option("SELECTORS") == "2"
+    with pytest.raises(pkg.TkspmvError):
+        pkg.set_option("NO_SUCH_SWITCH", 1)
+    assert pkg.get_option("NO_SUCH_SWITCH") is None
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "approximate-spmv-topk_amd", "csrc")
+    used = set()
+    for path in glob.glob(os.path.join(csrc, "**", "*.*"), recursive=True):
+        src = open(path).read()
+        if os.path.basename(path) not in ("options.cpp", "main_topk.cpp"):  # (main_topk.cpp: the host PROGRAM's own four settings)
+            assert "getenv" not in src, f"{path} reads the environment behind the option table's back"
+        used |= set(re.findall(r'\bopt(?:_set|_int)?\("([A-Z0-9_]+)"', src))
+    assert used == set(opts), (used - set(opts), set(opts) - used)  # no undocumented switch, no documented ghost

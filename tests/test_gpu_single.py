@@ -131,3 +131,43 @@ def test_headline_size_default_engine_under_a_stream_that_breaks_carried_thresho
     assert c["checks_failed"] > 0, c
     print(f"\n[configs[1], default engine, scales 1 / 0.01 / 3, x = 0, -x] {n_q} queries exact; {c}")
     eng.close()
+
+
+@pytest.mark.parametrize("local", ["1", "2", "0"])
+def test_engine_owned_result_buffer_holds_the_last_query_whatever_was_repaired(pkg, oracle, monkeypatch, local):
+    """tkspmv_enqueue_batch with NULL result pointers: 'engine buffers, last query wins' (include/tkspmv.h). Every query of such a
+    launch names the same buffer, several selections run at once, and a query whose check failed is answered again by the exact
+    launch AFTER the last one was selected -- the engine redirects all but the last query of a launch to a side buffer. The stream
+    makes earlier queries fail (scale 3 -> 0.01: carried thresholds far too high) while the last one passes; what tkspmv_read
+    returns must be the LAST query's list, bit for bit, for every batch length."""
+    import torch
+    monkeypatch.setenv("TKSPMV_LOCAL", local)
+    k = 100
+    m = pkg.generate_matrix(300000, 1024, 20, "gamma", 7)
+    eng = pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, k=k, device=0)
+    packed, raw, C = _packed_raw(pkg, m, eng, k)
+    failed_before = 0
+    for n_q, scales in ((6, [3, 3, 3, 3, 0.01, 0.01]), (12, [1] * 6 + [3] * 4 + [0.01] * 2), (5, [3, 0.01, 3, 0.01, 0.01]), (1, [3]),
+                        (9, [3, 3, 3, 3, 3, 3, 3, 0.01, 1])):
+        xs = np.stack([pkg.create_sample_vector(1024, True, False, True, 700 + n_q * 16 + i) * np.float32(scales[i]) for i in range(n_q)]).astype(np.float32)
+        dxs = torch.from_numpy(np.ascontiguousarray(xs)).cuda()
+        torch.cuda.synchronize()
+        eng.enqueue_batch(dxs.data_ptr(), n_q)
+        eng.synchronize()
+        val, idx = eng.read_result()
+        _exact(pkg, oracle, m, eng, xs[-1], k, idx, val, raw, C, gold=False)
+    c = eng.debug_counters()
+    if local != "0":
+        assert c["checks_failed"] > failed_before, c  # (repairs did run behind the last selection)
+    eng.close()
+
+
+def test_exchange_state_stays_small_at_the_headline_size(pkg):
+    """tkspmv_info.state_bytes: everything the engine allocates besides the matrix, x and the result buffers -- slots, records,
+    overflow lists, thresholds, tickets. Round 3 held 256 MB of overflow lists + 32 MB of selection scratch at 10^6 rows; the lists
+    are shared round-robin with flow control now."""
+    m = pkg.generate_matrix(1000000, 1024, 20, "gamma", 2)
+    eng = pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, k=100, device=0, stream_replicas=4)
+    sb = eng.info()["state_bytes"]
+    eng.close()
+    assert 0 < sb <= 40 * 1024 * 1024, sb
