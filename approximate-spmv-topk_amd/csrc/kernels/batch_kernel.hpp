@@ -411,7 +411,11 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
         n_active = (uint32_t)__popcll(__ballot(wave_has));
     }
     // what the epoch word of query q's overflow list must show before anything is appended to the list
+#ifdef TKSPMV_X_NOGATE  // (timing experiment only: no flow control on the overflow lists)
+    auto ovf_need = [&](uint32_t q) __attribute__((always_inline)) -> uint32_t { return L.epoch_now[list_of(q)]; };
+#else
     auto ovf_need = [&](uint32_t q) __attribute__((always_inline)) -> uint32_t { return L.epoch0[list_of(q)] + q / n_lists; };
+#endif
     // (the streaming waves look at the server wave's LDS copy of the epoch words, refreshed once per turn of its loop)
     auto ovf_wait = [&](uint32_t q) __attribute__((always_inline)) {
         const uint32_t need = ovf_need(q);
@@ -428,6 +432,7 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
         // (local thresholds: the query is short and the workgroup's waves wait for this wave's next x: it must not queue behind them)
         if (reducer || local) __builtin_amdgcn_s_setprio(3);
         uint32_t staged = 0u, tail = 0u;
+        uint32_t gate_seen = 0u;  // (exact mode: queries [0, gate_seen) have had their overflow list seen free by this wave)
         const bool carry_local = local && B.wg_prior != nullptr;
         float wg_prior = carry_local ? B.wg_prior[bid] : 0.0f;  // (reported-score units; 0: none)
 
@@ -545,8 +550,14 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
             if (local) {
                 // (workgroup-local thresholds are formed by the streaming waves themselves, in LDS: nothing to do here)
             } else if (P0.n_sets != 0u) {
-                // (the overflow lists' epoch words for the streaming waves: loaded with this turn's exchange traffic, stored below)
-                const uint32_t e_now = lane < n_lists ? __hip_atomic_load(B.ovf_epoch + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                // The overflow lists' epoch words for the streaming waves (L.epoch_now): loaded with this turn's exchange traffic and
+                // stored below -- but only while the list of a query in flight has not been SEEN free yet (gate_seen: the queries, in
+                // order, whose lists this wave has seen free). In the steady state that is one load per query: 512 servers polling
+                // the four words every turn doubled the traffic on the exchange's memory channel, thresholds arrived late, and a
+                // query of 19 packets per wave took 27-36 us instead of 18 (round 4, 1M rows with the device-wide exchange).
+                while (gate_seen < staged && __builtin_amdgcn_readfirstlane(lds_load(&L.epoch_now[list_of(gate_seen)])) == ovf_need(gate_seen)) ++gate_seen;
+                const bool poll_epochs = gate_seen < staged;
+                const uint32_t e_now = (poll_epochs && lane < n_lists) ? __hip_atomic_load(B.ovf_epoch + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
                 uint32_t hq = tail;
                 if (tail + 1u < staged &&
                     2u * __builtin_amdgcn_readfirstlane(lds_load(&L.misc[tail & 1u][MISC_DONE])) >= n_active)
@@ -570,7 +581,7 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
                         const uint32_t kx = __hip_atomic_load(P.tau_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         t = kx ? key_to_float(kx) : min_units;
                     }
-                    if (lane < n_lists) L.epoch_now[lane] = e_now;
+                    if (poll_epochs && lane < n_lists) L.epoch_now[lane] = e_now;
                     if (lane == 0) {
                         const float cur_tau = __uint_as_float(lds_load(&mp[MISC_TAU]));
                         if (t > cur_tau)
@@ -587,7 +598,19 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
             {
                 const uint32_t tp = tail & 1u;
                 uint32_t *mp = L.misc[tp];
-                if (tail < staged && __builtin_amdgcn_readfirstlane(lds_load(&mp[MISC_DONE])) >= n_active) {
+                bool deliver = tail < staged && __builtin_amdgcn_readfirstlane(lds_load(&mp[MISC_DONE])) >= n_active;
+                // Exact mode: staged rows beyond the workgroup's 8 slots go to the query's overflow list, which it shares with the
+                // queries 4, 8, ... before it -- their selections must have finished (flow control). This wave never WAITS for
+                // that: a waiting server stops publishing its workgroup's maxima for the younger query, everybody's threshold for
+                // that query forms later, more rows survive everywhere, more workgroups need the lists -- 27-36 us per query at 1M
+                // rows where 18-20 is the norm (round 4). It puts the hand-over off to a later turn and keeps the exchange going.
+                uint32_t n_have = 0u;
+                if (!local && deliver) {
+                    const uint32_t c = lane < nwaves ? (L.stg_cnt[tp][lane] < 8u ? L.stg_cnt[tp][lane] : 8u) : 0u;  // (as the hand-over below counts them)
+                    n_have = wave_sum_u32(c);
+                    if (n_have > WG_SLOTS && __builtin_amdgcn_readfirstlane(lds_load(&L.epoch_now[list_of(tail)])) != ovf_need(tail)) deliver = false;
+                }
+                if (deliver) {
                     asm volatile("" ::: "memory");
                     StreamParams P = P0;
                     P.gmax = B.gmax(set_of(tail));
@@ -615,10 +638,8 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
                         const unsigned long long v = have ? L.stg[tp][w][e] : 0ull;
                         const uint64_t bh = __ballot(have);
                         const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(bh >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bh, 0u));
-                        const uint32_t n_have = (uint32_t)__popcll(bh);
                         if (have && pos < WG_SLOTS) st_agent(B.wg_cand(set_of(tail)) + (size_t)bid * WG_SLOTS + pos, v);
-                        if (n_have > WG_SLOTS) {
-                            ovf_wait(tail);
+                        if (n_have > WG_SLOTS) {  // (the list was seen free above)
                             uint32_t gbase = 0u;
                             if (lane == 0) gbase = atomicAdd(B.ovf_list_count(list_of(tail)), n_have - WG_SLOTS);
                             gbase = __builtin_amdgcn_readfirstlane(gbase);
