@@ -175,7 +175,7 @@ struct EngineImpl {
     unsigned long long *d_rec_slots = nullptr;  // [batch_max][grid][WG_SLOTS]
     uint32_t *d_rec_used = nullptr;             // [batch_max][grid]
     uint32_t *d_ovf_epoch = nullptr;            // [ovf_lists] x 32 words
-    uint32_t ovf_lists = 1;                     // overflow lists allocated (batch engines: 2, shared by the queries of a launch under flow control)
+    uint32_t ovf_lists = 1;                     // overflow lists allocated (batch engines: 4, or 2 with local thresholds; shared by the queries of a launch under flow control)
     uint32_t use_local = 0;  // workgroup-local thresholds (BatchParams::local: 0 off, 1 / 2: a wave's best / second best packet maximum)
     float *d_wg_prior = nullptr;  // [grid] + the countdown word (BatchParams::wg_prior / prior_block)
     float local_beta = 1.0f;
@@ -1279,7 +1279,11 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
         if (const char *f = opt("BATCH_MAX")) m.batch_max = std::max(1, std::min(BATCH_MAX, atoi(f)));
         const int n_sets_alloc = (m.can_multi || m.resident_capable) ? EngineImpl::N_STATE : (m.can_batch ? m.batch_max : (m.can_defer ? 2 : 1));
         const size_t ns = (size_t)n_sets_alloc;
-        m.ovf_lists = m.can_multi ? (uint32_t)n_sets_alloc : (uint32_t)std::min(4, n_sets_alloc);
+        // (engines that stream with checked local thresholds use the lists for repairs and behind a closed gate only: two; a power of two)
+        int want_lists = m.use_local ? 2 : 4;
+        if (const char *f = opt("OVF_LISTS")) want_lists = atoi(f);
+        want_lists = std::min(std::min(want_lists, 4), n_sets_alloc);
+        m.ovf_lists = m.can_multi ? (uint32_t)n_sets_alloc : (want_lists >= 4 ? 4u : (want_lists >= 2 ? 2u : 1u));
         const size_t nl = m.ovf_lists;
         EngineImpl::ExState &E0 = m.st[0];
         HIP_TRY(malloc_exchange((void **)&E0.gmax, ns * EngineImpl::GMAX_WORDS * 4));

@@ -261,14 +261,17 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
     const uint32_t pace_q = LOCAL ? B.pace_quads : 0u;
     // Overflow list of query q of this phase and the value its epoch word must show before anything may be appended: the
     // selections of the list's earlier users in this phase have finished (L.epoch0: the words as the phase found them).
-    constexpr uint32_t n_lists = 4u;  // (BatchParams::ovf_lists: the engine allocates four)
-    auto list_of = [&](uint32_t q) __attribute__((always_inline)) -> uint32_t { return q % n_lists; };
+    // (BatchParams::ovf_lists: 4, or 2 where the exact kernel only repairs behind the kernel of local thresholds -- a power of two)
+    const uint32_t n_lists = local ? 4u : B.ovf_lists, lists_shift = n_lists >= 4u ? 2u : (n_lists >> 1);
+    auto list_of = [&](uint32_t q) __attribute__((always_inline)) -> uint32_t { return q & (n_lists - 1u); };
 
     const uint32_t nsel = B.n_selectors;  // (>= 1)
     if (blockIdx.x < nsel) {
         // ---- selector workgroups -----------------------------------------------------------------------------
         if (RESIDENT && blockIdx.x != 0u) return;  // (one query in flight: one selector, who is also the doorman)
         const uint32_t n_stream = gridDim.x - nsel;
+        // (the lists' epoch words as the phase found them -- read before any selection of the phase can have finished)
+        if (!local && tid < 4u) L.epoch0[tid] = tid < n_lists ? __hip_atomic_load(B.ovf_epoch + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
         for (uint32_t q = RESIDENT ? 0u : blockIdx.x; q < nq; q += RESIDENT ? 1u : nsel) {
             unsigned long long t_seen = 0ull;
             if (RESIDENT) {
@@ -357,6 +360,16 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
                     (void)__hip_atomic_fetch_add(B.verdict, 1ull | ((bad ? 1ull : 0ull) << (32u + q)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else {
                 const uint32_t l = list_of(q);
+                // Fewer lists than selector workgroups: the list's previous user may be with ANOTHER selector, still selecting --
+                // its entries and its count are in the list until that selection has reset them (with as many lists as selectors
+                // a list always comes back to the same workgroup, and this is true at once). Nobody has appended for q meanwhile:
+                // appending waits for the same word.
+                if (tid == 0) {
+                    const uint32_t need = L.epoch0[l] + (q >> lists_shift);
+                    while (__hip_atomic_load(B.ovf_epoch + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != need) __builtin_amdgcn_s_sleep(8);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                }
+                __syncthreads();
                 S.wg_cand = B.wg_cand(set_of(q));
                 S.ovf_cand = B.ovf_list(l);
                 S.ovf_count = B.ovf_list_count(l);
@@ -411,11 +424,7 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
         n_active = (uint32_t)__popcll(__ballot(wave_has));
     }
     // what the epoch word of query q's overflow list must show before anything is appended to the list
-#ifdef TKSPMV_X_NOGATE  // (timing experiment only: no flow control on the overflow lists)
-    auto ovf_need = [&](uint32_t q) __attribute__((always_inline)) -> uint32_t { return L.epoch_now[list_of(q)]; };
-#else
-    auto ovf_need = [&](uint32_t q) __attribute__((always_inline)) -> uint32_t { return L.epoch0[list_of(q)] + q / n_lists; };
-#endif
+    auto ovf_need = [&](uint32_t q) __attribute__((always_inline)) -> uint32_t { return L.epoch0[list_of(q)] + (q >> lists_shift); };
     // (the streaming waves look at the server wave's LDS copy of the epoch words, refreshed once per turn of its loop)
     auto ovf_wait = [&](uint32_t q) __attribute__((always_inline)) {
         const uint32_t need = ovf_need(q);
@@ -555,7 +564,7 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
                 // order, whose lists this wave has seen free). In the steady state that is one load per query: 512 servers polling
                 // the four words every turn doubled the traffic on the exchange's memory channel, thresholds arrived late, and a
                 // query of 19 packets per wave took 27-36 us instead of 18 (round 4, 1M rows with the device-wide exchange).
-                while (gate_seen < staged && __builtin_amdgcn_readfirstlane(lds_load(&L.epoch_now[list_of(gate_seen)])) == ovf_need(gate_seen)) ++gate_seen;
+                while (gate_seen < staged && (int32_t)(__builtin_amdgcn_readfirstlane(lds_load(&L.epoch_now[list_of(gate_seen)])) - ovf_need(gate_seen)) >= 0) ++gate_seen;
                 const bool poll_epochs = gate_seen < staged;
                 const uint32_t e_now = (poll_epochs && lane < n_lists) ? __hip_atomic_load(B.ovf_epoch + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
                 uint32_t hq = tail;

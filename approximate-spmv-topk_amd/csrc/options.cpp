@@ -19,6 +19,7 @@ static const OptionDef k_options[] = {
     {"BATCH", "behaviour", "0 | 1 (default 1)", "0: tkspmv_enqueue_batch / _many launch one kernel per query"},
     {"BATCH_MAX", "tuning", "1..32 (default 32, 12 for small matrices)", "queries per batch launch"},
     {"SELECTORS", "tuning", "1..8 (default 4 up to LOCAL_MATRIX_PACKETS, else 1)", "selection workgroups a batch launch keeps in flight"},
+    {"OVF_LISTS", "tuning", "1 | 2 | 4 (default 4; 2 for engines that stream with local thresholds)", "overflow lists of the exact kernel (8 bytes per row each), shared round robin by the queries of a launch under flow control"},
     {"PACE", "tuning", "0..32 (default by size)", "pacing quantum of the batch kernel's workgroups by rank (s_sleep units); 0 = none"},
     {"PACE_LEVELS", "tuning", "1..8", "number of distinct pacing ranks"},
     {"FUSED", "behaviour", "0 | 1 (default 1 where the selection fits one workgroup)", "0: stream and selection as two launches"},
