@@ -65,3 +65,42 @@ def test_round3_batch_modes_equal_the_device_wide_exchange(pkg, monkeypatch, see
             sc = {int(i): float(v) for i, v in zip(r2[0][q], r2[1][q])}
             sc.update({int(i): float(v) for i, v in zip(r3[0][q], r3[1][q])})
             assert all(abs(sc[r] - kth) <= 2e-5 * max(abs(kth), 1e-30) for r in diff), (desc, q, sorted(diff)[:6])
+
+
+@pytest.mark.parametrize("lists", [1, 2, 4])
+def test_overflow_lists_shared_by_the_queries_of_a_launch(pkg, monkeypatch, lists):
+    """The exact kernel's overflow lists are shared round robin by the queries of a launch under flow control (OVF_LISTS: 2 behind
+    the kernel of local thresholds, 4 else). Round 4 found two selections on ONE list at a time mixing their candidates when the
+    lists were fewer than the selector workgroups (330 000 x 512 Q1.7, k = 1: a query reported another query's best row). The case
+    that showed it -- half of the checks fail, the gate closes, every query of the second pass goes through the exact kernel --
+    with 1, 2 and 4 lists against the engine of the device-wide exchange, bit for bit, twice."""
+    import torch
+    m = pkg.generate_matrix(330000, 512, 24, "gamma", 51)
+    nq, k = 40, 1
+    rng = np.random.default_rng(1001)
+    xs = np.stack([pkg.create_sample_vector(512, True, False, True, 3097 + i) for i in range(nq)]) * np.float32(30.0)
+    xs = (xs * rng.choice([1.0, 1.0, 0.2, 3.0], size=nq).astype(np.float32)[:, None]).astype(np.float32)
+    xs[7] *= np.float32(-1.0)
+    dxs = torch.from_numpy(np.ascontiguousarray(xs)).cuda()
+
+    def run():
+        eng = pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, k=k, device=0, precision=pkg.Q1_7)
+        oi = torch.full((nq, k), -1, dtype=torch.int32, device="cuda")
+        ov = torch.full((nq, k), -1.0, dtype=torch.float32, device="cuda")
+        out = []
+        for rep in range(3):
+            eng.enqueue_batch(dxs.data_ptr(), nq, oi.data_ptr(), ov.data_ptr())
+            eng.synchronize()
+            out.append((oi.cpu().numpy().copy(), ov.cpu().numpy().copy()))
+        c = eng.debug_counters()
+        eng.close()
+        return out, c
+
+    monkeypatch.setenv("TKSPMV_LOCAL", "0")
+    ref, _ = run()
+    monkeypatch.delenv("TKSPMV_LOCAL")
+    monkeypatch.setenv("TKSPMV_OVF_LISTS", str(lists))
+    out, c = run()
+    for rep in range(3):
+        assert np.array_equal(ref[0][0], out[rep][0]) and np.array_equal(ref[0][1].view(np.uint32), out[rep][1].view(np.uint32)), (lists, rep, c)
+    assert c["checks_failed"] > 0, c  # (the exact kernel did run behind the local one)

@@ -54,10 +54,24 @@ def pct(v, name):
 
 
 if a.plain:
+    # The reference's loop, literally: reset(x) from HOST memory, operator(), read_result() -- N times. Under rocprofv3
+    # --kernel-trace --stats the trace's average duration of single_kernel is the clock of record; what this prints beside it are the
+    # kernel's own stamp (tkspmv_run's return value: first workgroup's entry to the result flag, 100 MHz device clock) and the host
+    # clock around the three calls, all from the SAME launches.
     eng = engine()
+    own, e2e = [], []
     for i in range(a.plain):
-        eng.reset_device(dxs[i % 8].data_ptr())
-        eng()
+        t0 = time.perf_counter()
+        eng.reset(xs[i % 8])
+        ns = eng()
+        val, idx = eng.read_result()
+        e2e.append((time.perf_counter() - t0) * 1e6)
+        own.append(ns / 1e3)
+    own, e2e = np.array(own[2:]), np.array(e2e[2:])
+    print(f"{a.plain} queries through reset / operator() / read_result (2 dropped), {a.rows} x {a.cols}, k = {a.k}:")
+    print(f"  device_us_self_stamped (tkspmv_run's return value): median {np.median(own):.2f}  p95 {np.percentile(own, 95):.2f}  min {own.min():.2f}")
+    print(f"  end_to_end_us (host clock around the three calls):  median {np.median(e2e):.2f}  p95 {np.percentile(e2e, 95):.2f}  min {e2e.min():.2f}")
+    print(f"  counters: {eng.debug_counters()}")
     eng.close()
     sys.exit(0)
 

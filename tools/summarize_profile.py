@@ -65,40 +65,53 @@ for sub, stem in (("shard125k", f"{tag}_shard125k"), ("config3", f"{tag}_config3
         if lines:
             open(os.path.join(dst, stem + "_under_rocprofv3.json"), "w").write(lines[-1] + "\n")
 
+for rows in (125000, 250000, 500000):  # the one-GPU rehearsal of a strong-scaled run's shards; the size sweep
+    p = os.path.join(out, f"shard_rehearsal_{rows}.json")
+    if os.path.exists(p):
+        lines = [l for l in open(p).read().splitlines() if l.startswith("{")]
+        if lines:
+            open(os.path.join(dst, f"{tag}_shard_rehearsal_{rows}.json"), "w").write(lines[-1] + "\n")
+if os.path.exists(os.path.join(out, "size_sweep.txt")):
+    shutil.copy(os.path.join(out, "size_sweep.txt"), os.path.join(dst, f"{tag}_size_sweep.txt"))
+
 summary = {}
+QUERIES_PER_LAUNCH = 32  # bench.py's profiled runs use whole launches of the batch kernel (--steps / --warmup multiples of 32)
 for d in sorted(glob.glob(os.path.join(out, "pmc*"))):
     if not os.path.isdir(d):
         continue
-    # queries the profiled run executed: warm-up + timed steps + the repetitions of `timing` (bench.py --skip-warm)
-    n_queries = None
-    try:
-        line = [l for l in open(d + ".json").read().splitlines() if l.startswith("{")][-1]
-        j = json.loads(line)
-        tm = j.get("timing", {})
-        n_queries = j["warmup"] + j["steps"] + (tm.get("repetitions", 0) + tm.get("dropped", 0)) * tm.get("queries_per_repetition", 0)
-    except Exception:
-        pass
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
-        acc = {}
+        # Per launch and kernel: the counter summed over its rows (one per XCD / instance). Two kernels stream the matrix for the
+        # headline: batch_kernel<..., true> (local thresholds: one pass per query) and, behind every such launch, batch_kernel<...,
+        # false> with repair = 1 (empty unless a check failed). A run also holds other launches of these kernels (short batches of
+        # the warm-up, the nonstationary leg with its repairs), so the per-query figure is the MEDIAN full launch / 32, plus the
+        # median launch of the exact kernel / 32 -- not a sum over the run divided by a query count reconstructed from the line.
+        per = {}
         for row in csv.DictReader(open(f)):
             kn = row.get("Kernel_Name", "")
-            # the kernels that stream the matrix for a top-k query: batch_kernel (up to 32 queries per launch) and
-            # stream_kernel<.., false, ..> (one query); Lb1E = the SpMV-only variant
-            if not (("batch_kernel" in kn) or ("stream_kernel" in kn and "Lb1E" not in kn and "true" not in kn)):
+            if "batch_kernel" not in kn:
                 continue
-            acc.setdefault(row["Counter_Name"], {}).setdefault(row["Dispatch_Id"], 0.0)
-            acc[row["Counter_Name"]][row["Dispatch_Id"]] += float(row["Counter_Value"])
-        for name, per in acc.items():
-            total = sum(per.values())
-            summary[name] = {"launches": len(per), "queries": n_queries, "sum": total,
-                             "mean_per_query": total / n_queries if n_queries else None}
-json.dump(summary, open(os.path.join(dst, f"{tag}_pmc_summary.json"), "w"), indent=1)
+            which = "local" if kn.rstrip(">)").split(",")[-1].strip().startswith("true") or ", true>" in kn else "exact"
+            key = (row["Counter_Name"], which, row["Dispatch_Id"])
+            per[key] = per.get(key, 0.0) + float(row["Counter_Value"])
+        for name in sorted({k[0] for k in per}):
+            loc = sorted(v for (n, w, _), v in per.items() if n == name and w == "local")
+            exa = sorted(v for (n, w, _), v in per.items() if n == name and w == "exact")
+            if not loc:
+                continue
+            med_loc = loc[len(loc) // 2]
+            med_exa = exa[len(exa) // 2] if exa else 0.0
+            summary[name] = {"local_launches": len(loc), "exact_launches": len(exa), "median_per_local_launch": med_loc,
+                             "median_per_exact_launch": med_exa, "queries_per_launch": QUERIES_PER_LAUNCH,
+                             "mean_per_query": (med_loc + med_exa) / QUERIES_PER_LAUNCH}
+if summary:  # (a run of part B only has no counter passes: leave part A's file alone)
+    json.dump(summary, open(os.path.join(dst, f"{tag}_pmc_summary.json"), "w"), indent=1)
 if "FETCH_SIZE" in summary and "WRITE_SIZE" in summary:
     fetch = summary["FETCH_SIZE"]["mean_per_query"] * 1024.0 * 2.0  # KiB -> B, x2: gfx950 tallies 128-B requests at 64 B
     write = summary["WRITE_SIZE"]["mean_per_query"] * 1024.0
     json.dump({"stream_kernel_hbm_bytes_per_launch": fetch + write, "unit": "bytes per query (a batch launch streams the matrix once per query)", "fetch_bytes_corrected": fetch, "write_bytes": write,
                "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on bench.py --skip-warm, tag {tag}; "
-                         "FETCH_SIZE x 1024 x 2 (gfx950 correction, MI355X_MICROARCH.md) + WRITE_SIZE x 1024, summed over the launches and divided by the queries they served"},
+                         "FETCH_SIZE x 1024 x 2 (gfx950 correction, MI355X_MICROARCH.md) + WRITE_SIZE x 1024: the median 32-query launch of the "
+                         "batch kernel plus the median (empty) launch of the exact kernel behind it, divided by 32"},
               open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
 print(json.dumps({k: round(v["mean_per_query"] or 0, 2) for k, v in summary.items()}))
 print(open(os.path.join(dst, f"{tag}_bench_plain.json")).read()[:600] if os.path.exists(os.path.join(dst, f"{tag}_bench_plain.json")) else "no plain bench line")
