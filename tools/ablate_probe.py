@@ -2,7 +2,10 @@
 results, timing only; 4: no threshold duty; 16: every state set keeps its final threshold and the same vector comes back
 to it: an exact threshold from a query's first packet), one engine per setting; `None` = the production instantiation,
 with single launches and the SpMV-only kernel beside it (MULTI=1,4,8 adds the multi-query path; STATS=1 the counters).
-  python tools/ablate_probe.py ROWS COLS NNZ [flags ... | none]"""
+  python tools/ablate_probe.py ROWS COLS NNZ [flags ... | none]
+Round 4 removed the ablation switches from the library (what they showed is in DESIGN.md section 9): in this tree only `none` --
+the production kernel beside its load-only floor, which tools/ab_variants.sh runs interleaved with an older tree under _ab/ --
+does anything; the flags still work when the probe runs inside such an older tree."""
 import os
 import sys
 
