@@ -33,6 +33,10 @@ for run in list(res):
             n = j["warmup"] + j["steps"]
             if "timing" in j:  # the headline run repeats its timed batch (repetitions + 2 dropped ones)
                 n += (j["timing"]["repetitions"] + j["timing"]["dropped"]) * j["timing"]["queries_per_repetition"]
+                n += 8 * min(max(j["steps"], 32), 512)  # (timing.one_call_per_repetition: 10 calls, 2 of them not reported)... 10 calls in all
+                n += 2 * min(max(j["steps"], 32), 512)
+            if "nonstationary" in j:  # (round 4: the leg with queries of changing scale runs on the same engine)
+                n += j["nonstationary"]["queries"] + 2 * min(max(j["steps"], 32), 512)  # (+ its two dropped repetitions)
             break
         except Exception:  # noqa: BLE001
             pass
