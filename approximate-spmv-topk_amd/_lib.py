@@ -80,7 +80,7 @@ class OptionsC(C.Structure):
 EXPORTED_SYMBOLS = [
     "tkspmv_create", "tkspmv_destroy", "tkspmv_get_info", "tkspmv_set_query", "tkspmv_set_query_device",
     "tkspmv_run", "tkspmv_enqueue", "tkspmv_enqueue_many", "tkspmv_enqueue_batch", "tkspmv_synchronize", "tkspmv_read", "tkspmv_result_device", "tkspmv_scores", "tkspmv_debug_trace", "tkspmv_debug_counters",
-    "tkspmv_time_queries", "tkspmv_time_query_batches", "tkspmv_time_stream_read", "tkspmv_enqueue_multi", "tkspmv_time_multi", "tkspmv_profile", "tkspmv_last_error", "tkspmv_device_count", "tkspmv_mtx_read", "tkspmv_mtx_free",
+    "tkspmv_time_queries", "tkspmv_time_host_loop", "tkspmv_time_query_batches", "tkspmv_time_stream_read", "tkspmv_enqueue_multi", "tkspmv_time_multi", "tkspmv_profile", "tkspmv_last_error", "tkspmv_device_count", "tkspmv_mtx_read", "tkspmv_mtx_free",
     "tkspmv_mtx_write", "tkspmv_sample_vector", "tkspmv_generate", "tkspmv_generate_rows", "tkspmv_generate_degrees", "tkspmv_options_parse", "tkspmv_pack", "tkspmv_pack_device",
     "tkspmv_sell_roundtrip", "tkspmv_sell_pack_device_check", "tkspmv_packed_info", "tkspmv_packed_decode", "tkspmv_packed_raw", "tkspmv_packed_free", "tkspmv_wave_partitions", "tkspmv_packed_save", "tkspmv_packed_load",
     "tkspmv_create_packed",
@@ -126,6 +126,7 @@ def lib():
     L.tkspmv_debug_trace.argtypes = [vp, C.POINTER(C.c_uint64), C.c_uint64, C.POINTER(C.c_uint64)]
     L.tkspmv_debug_counters.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int32]
     L.tkspmv_time_queries.argtypes = [vp, vp, C.c_int32, C.c_int32, C.POINTER(C.c_double)]
+    L.tkspmv_time_host_loop.argtypes = [vp, f32p, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.tkspmv_time_query_batches.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double)]
     L.tkspmv_time_stream_read.argtypes = [vp, C.c_int32, C.POINTER(C.c_double)]
     L.tkspmv_enqueue_multi.argtypes = [vp, vp, C.c_int32, vp, vp, vp]

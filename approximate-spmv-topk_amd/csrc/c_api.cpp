@@ -124,6 +124,9 @@ int tkspmv_option_info(int32_t i, const char **name, const char **kind, const ch
 int tkspmv_time_query_batches(tkspmv_t *h, const float *dev_xs, int32_t n_x, int32_t iters, int32_t reps, double *ns_per_query) {
     ENGINE_CALL(time_query_batches(dev_xs, n_x, iters, reps, ns_per_query, err))
 }
+int tkspmv_time_host_loop(tkspmv_t *h, const float *host_xs, int32_t n_x, int32_t iters, double *loop_ns, double *kernel_ns) {
+    ENGINE_CALL(time_host_loop(host_xs, n_x, iters, loop_ns, kernel_ns, err))
+}
 int tkspmv_time_queries(tkspmv_t *h, const float *dev_xs, int32_t n_x, int32_t iters, double *ns_per_query) {
     ENGINE_CALL(time_queries(dev_xs, n_x, iters, ns_per_query, err))
 }

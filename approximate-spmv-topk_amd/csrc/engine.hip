@@ -2178,4 +2178,30 @@ int Engine::profile(const float *dev_xs, int32_t n_x, int32_t iters, tkspmv_timi
     return TKSPMV_OK;
 }
 
+// The reference's loop -- reset(x) from host memory, operator(), read_result() (host_spmv_bscsr.cpp:602-632) -- `iters` times in
+// native code, cycling over n_x host vectors: loop_ns[i] = the host's steady clock around the three calls of iteration i,
+// kernel_ns[i] = what tkspmv_run returned for it. What a C++ host of the reference sees per iteration; a Python caller adds a
+// ctypes transition per call to it.
+int Engine::time_host_loop(const float *host_xs, int32_t n_x, int32_t iters, double *loop_ns, double *kernel_ns, std::string &err) {
+    if (!host_xs || n_x < 1 || iters < 1 || !loop_ns) {
+        err = "time_host_loop: NULL or empty arguments";
+        return TKSPMV_ERR_INVALID;
+    }
+    EngineImpl &m = *impl_;
+    std::vector<uint32_t> idx((size_t)m.desc.k);
+    std::vector<float> val((size_t)m.desc.k);
+    for (int32_t i = 0; i < iters; ++i) {
+        const auto t0 = std::chrono::steady_clock::now();
+        double set_ns = 0.0, k_ns = 0.0;
+        int32_t n = 0;
+        int st = set_query(host_xs + (size_t)(i % n_x) * m.desc.cols, &set_ns, err);
+        if (st == TKSPMV_OK) st = run(&k_ns, err);
+        if (st == TKSPMV_OK) st = read(idx.data(), val.data(), &n, err);
+        if (st != TKSPMV_OK) return st;
+        loop_ns[i] = std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - t0).count();
+        if (kernel_ns) kernel_ns[i] = k_ns;
+    }
+    return TKSPMV_OK;
+}
+
 }  // namespace tkspmv

@@ -47,6 +47,7 @@ class Engine {
     int read_trace(unsigned long long *host, size_t max_words, size_t *words, std::string &err);
     int debug_counters(unsigned long long *out, int n, std::string &err);
     int time_queries(const float *dev_xs, int32_t n_x, int32_t iters, double *ns_per_query, std::string &err);
+    int time_host_loop(const float *host_xs, int32_t n_x, int32_t iters, double *loop_ns, double *kernel_ns, std::string &err);
     int time_query_batches(const float *dev_xs, int32_t n_x, int32_t iters, int32_t reps, double *ns_per_query, std::string &err);
     int time_stream_read(int32_t passes, double *ns_per_pass, std::string &err);
     int profile(const float *dev_xs, int32_t n_x, int32_t iters, tkspmv_timing *out, std::string &err);

@@ -112,6 +112,16 @@ class SpMV:
         _lib.check(_lib.lib().tkspmv_time_queries(self._h, C.c_void_p(int(dev_xs)), int(n_x), int(iters), C.byref(ns)))
         return ns.value
 
+    def time_host_loop(self, host_xs, iters):
+        """The reference's reset / operator() / read_result loop run natively `iters` times over the rows of host_xs (float32,
+        [n_x, cols]): (loop_us[iters], kernel_us[iters]) -- the host clock around the three calls, and tkspmv_run's own figure."""
+        xs = np.ascontiguousarray(host_xs, dtype=np.float32)
+        loop = np.zeros(int(iters), dtype=np.float64)
+        kern = np.zeros(int(iters), dtype=np.float64)
+        _lib.check(_lib.lib().tkspmv_time_host_loop(self._h, xs.ctypes.data_as(C.POINTER(C.c_float)), int(xs.shape[0]), int(iters),
+                                                    loop.ctypes.data_as(C.POINTER(C.c_double)), kern.ctypes.data_as(C.POINTER(C.c_double))))
+        return loop / 1e3, kern / 1e3
+
     def time_query_batches(self, dev_xs, n_x, iters, reps):
         """`reps` batches of `iters` back-to-back queries, all enqueued before the first wait: ns per query of every batch (the GPU
         never idles between them: the kernel under sustained load)."""

@@ -281,6 +281,14 @@ def single_query_leg(mod, m, xs, dxs, a, device, eng, alg_bytes):
     ok, par = check_parity(mod, m, xs[(n - 1) % xs.shape[0]], a.k, idx, val, eng)
     kern, e2e = kern[2:], e2e[2:]
     med = float(np.median(kern))
+    # the same loop in native code (tkspmv_time_host_loop): what a C++ host like the reference's sees per iteration -- the
+    # Python figure above carries three ctypes transitions and the result arrays' allocation on top
+    native = None
+    if hasattr(eng, "time_host_loop"):
+        lp, kn = eng.time_host_loop(xs, n)
+        native = {"end_to_end_us": float(np.median(lp[2:])), "end_to_end_us_p95": pct(list(lp[2:]), 95),
+                  "device_us_self_stamped": float(np.median(kn[2:])),
+                  "note": "tkspmv_set_query + tkspmv_run + tkspmv_read per iteration inside ONE native call, host steady clock per iteration"}
     counters = eng.debug_counters()
     single = counters.get("single_launches", 0) > 0
     # The same loop served by the resident kernel (desc.impl = TKSPMV_IMPL_RESIDENT): one launch stays on the GPU, queries
@@ -316,6 +324,8 @@ def single_query_leg(mod, m, xs, dxs, a, device, eng, alg_bytes):
             "runs": len(kern), "dropped": 2, "device_us_self_stamped": med, "device_us_self_stamped_p95": pct(kern, 95),
             "kernel_us": med, "kernel_us_p95": pct(kern, 95), "frac": alg_bytes / (med * 1e3) / HBM_PEAK_GBS,
             "end_to_end_us": float(np.median(e2e)), "end_to_end_us_p95": pct(e2e, 95), "parity_checked": ok,
+            "end_to_end_clock": "host clock of THIS Python process around reset / __call__ / read_result (ctypes); `native_loop` is the same loop in C",
+            "native_loop": native,
             "counters": {k_: counters[k_] for k_ in ("single_launches", "single_repairs", "single_checks_failed") if k_ in counters},
             "clock": "kernel_us = device_us_self_stamped: the launch's own s_memrealtime span at 100 MHz (10 ns ticks), first "
                      "workgroup's entry to the result flag; it excludes dispatch latency and the instructions behind the flag",

@@ -246,6 +246,12 @@ int tkspmv_time_queries(tkspmv_t *e, const float *dev_xs, int32_t n_x, int32_t i
  * time of batch r / iters. The GPU does not idle between batches (a batch that follows a host-side gap runs 10-25 % slower for
  * about a millisecond: power management), so median and p95 of these are the kernel's under sustained load. reps <= 4096. */
 int tkspmv_time_query_batches(tkspmv_t *e, const float *dev_xs, int32_t n_x, int32_t iters, int32_t reps, double *ns_per_query);
+/* Measurement aid: the reference's loop -- reset(x) from host memory, operator(), read_result(): host_spmv_bscsr.cpp:602-632 --
+ * run `iters` times in native code over n_x host vectors (stride cols floats): loop_ns[i] = the host's steady clock around
+ * tkspmv_set_query + tkspmv_run + tkspmv_read of iteration i (what the reference reports as hw_full_exec_time + its reset),
+ * kernel_ns[i] (may be NULL) = tkspmv_run's own figure. A caller that goes through a foreign-function layer pays that layer's
+ * transitions on top (three per iteration). */
+int tkspmv_time_host_loop(tkspmv_t *e, const float *host_xs, int32_t n_x, int32_t iters, double *loop_ns, double *kernel_ns);
 /* Measurement aid: `passes` passes over the engine's packet stream (rotating its stream copies) by a kernel with the
  * engine's launch geometry that only LOADS the packets -- no x, no arithmetic, no selection -- in ONE launch, inside one
  * hipEvent pair: *ns_per_pass = what moving the stream from HBM into registers costs on this GPU. bench.py prints the

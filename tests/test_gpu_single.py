@@ -171,3 +171,19 @@ def test_exchange_state_stays_small_at_the_headline_size(pkg):
     sb = eng.info()["state_bytes"]
     eng.close()
     assert 0 < sb <= 40 * 1024 * 1024, sb
+
+
+def test_native_host_loop_times_the_reference_loop_and_leaves_the_last_result(pkg, oracle):
+    """tkspmv_time_host_loop: reset / operator() / read_result in native code, a host clock per iteration. The last iteration's
+    list stays readable and is exact; every iteration went through the single-query kernel."""
+    k = 100
+    m = pkg.generate_matrix(250000, 1024, 20, "gamma", 2)
+    eng = pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, k=k, device=0)
+    packed, raw, C = _packed_raw(pkg, m, eng, k)
+    xs = np.stack([pkg.create_sample_vector(1024, True, False, True, 4000 + i) for i in range(5)])
+    loop_us, kern_us = eng.time_host_loop(xs, 23)
+    assert loop_us.shape == (23,) and np.all(loop_us > 0) and np.all(kern_us > 0) and np.all(loop_us >= kern_us)
+    val, idx = eng.read_result()
+    _exact(pkg, oracle, m, eng, xs[22 % 5], k, idx, val, raw, C)
+    assert eng.debug_counters()["single_launches"] == 23
+    eng.close()

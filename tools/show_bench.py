@@ -8,6 +8,8 @@ print("thresholds", d["thresholds"]["checks_failed"], "nonstationary", {k: v for
 if "single_query" in d:
     s = d["single_query"]
     print("single", {k: (round(v, 2) if isinstance(v, float) else v) for k, v in s.items() if k in ("kernel_us", "end_to_end_us", "frac", "counters", "parity_checked")})
+    if s.get("native_loop"):
+        print("single, native loop", {k: round(v, 2) for k, v in s["native_loop"].items() if isinstance(v, float)})
     print("resident", {k: (round(v, 2) if isinstance(v, float) else v) for k, v in s["resident"].items() if k in ("device_us", "end_to_end_us", "error")})
     print("cache_warm", {k: (round(v, 3) if isinstance(v, float) else v) for k, v in d["cache_warm"].items() if k != "note"})
     for c in d["configs"]:

@@ -71,6 +71,9 @@ if a.plain:
     print(f"{a.plain} queries through reset / operator() / read_result (2 dropped), {a.rows} x {a.cols}, k = {a.k}:")
     print(f"  device_us_self_stamped (tkspmv_run's return value): median {np.median(own):.2f}  p95 {np.percentile(own, 95):.2f}  min {own.min():.2f}")
     print(f"  end_to_end_us (host clock around the three calls):  median {np.median(e2e):.2f}  p95 {np.percentile(e2e, 95):.2f}  min {e2e.min():.2f}")
+    lp, kn = eng.time_host_loop(xs, a.plain)
+    print(f"  the same loop in native code (tkspmv_time_host_loop): end to end median {np.median(lp[2:]):.2f}  p95 {np.percentile(lp[2:], 95):.2f}  min {lp[2:].min():.2f}; "
+          f"own stamp median {np.median(kn[2:]):.2f}")
     print(f"  counters: {eng.debug_counters()}")
     eng.close()
     sys.exit(0)
