@@ -443,7 +443,8 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
         uint32_t staged = 0u, tail = 0u;
         uint32_t gate_seen = 0u;  // (exact mode: queries [0, gate_seen) have had their overflow list seen free by this wave)
         const bool carry_local = local && B.wg_prior != nullptr;
-        float wg_prior = carry_local ? B.wg_prior[bid] : 0.0f;  // (reported-score units; 0: none)
+        float wg_prior = carry_local ? B.wg_prior[bid] : 0.0f;  // (reported-score units per unit of the query's L1 norm; 0: none)
+        float xnorm_q[2] = {0.0f, 0.0f};  // sum |x| of the queries in flight (carried thresholds are relative to it: scores are linear in x)
 
         uint32_t published = RESIDENT ? 0u : nq;  // queries whose x is available (resident: as the doorman publishes them)
         float inv_unit_q[2] = {1.0f, 1.0f}, min_units_q[2] = {0.0f, 0.0f};
@@ -510,6 +511,7 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
                 inv_unit_q[par] = 1.0f / unit_scale;
                 min_units_q[par] = P0.min_score * unit_scale;
                 float *xl = L.u.w.x[par];
+                float xabs = 0.0f;
 #pragma unroll 1
                 for (uint32_t b0 = 0; b0 < (uint32_t)XCOLS; b0 += 1024u) {  // 16 loads in flight per lane
                     float r[16];
@@ -517,6 +519,10 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
                     for (int u = 0; u < 16; ++u) {
                         const uint32_t i = b0 + lane + 64u * (uint32_t)u;
                         r[u] = (i < P0.cols) ? x_at(i) : 0.0f;
+                    }
+                    if (carry_local) {
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) xabs += fabsf(r[u]);
                     }
 #pragma unroll
                     for (int u = 0; u < 16; ++u) {
@@ -537,8 +543,9 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                 float tau_init = min_units_q[par];
                 uint32_t carried_key = 0u;
+                if (carry_local) xnorm_q[par] = wave_sum_f32(xabs);  // (a fixed summation order: the same value in every run)
                 if (prior_blocked == 0u && wg_prior > 0.0f) {
-                    const float t0 = wg_prior * unit_scale * B.local_beta;
+                    const float t0 = wg_prior * xnorm_q[par] * unit_scale * B.local_beta;
                     if (t0 > tau_init) {
                         tau_init = t0;
                         carried_key = order_key(t0);  // (on record with the thresholds the waves form: MISC_TAUKEY)
@@ -637,7 +644,7 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
                                             B.lslots + (size_t)set_of(tail) * B.lslots_stride + (size_t)bid * WG_SLOTS, used, next_prior);
                         if (lane == 8u)
                             __hip_atomic_store(B.lused + (size_t)set_of(tail) * B.lused_stride + bid, used, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (carry_local && next_prior >= 0.0f) wg_prior = next_prior * inv_unit_q[tp];
+                        if (carry_local && next_prior >= 0.0f && xnorm_q[tp] > 0.0f) wg_prior = next_prior * inv_unit_q[tp] / xnorm_q[tp];
                     } else {
                         if (P0.n_sets != 0u) publish_group_max(P, bid, lane, mp);  // complete maxima (fire and forget)
                         // lane l looks at entry (l % 8) of wave (l / 8): the staged rows go to the workgroup's 8 slots, in any

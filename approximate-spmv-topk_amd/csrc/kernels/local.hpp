@@ -21,7 +21,7 @@ namespace tkspmv {
 struct LocalParams {
     unsigned long long *slots;  // [n_wg][WG_SLOTS] {score bits | row << 32}, row SLOT_INVALID = empty; all 8 written by every workgroup
     uint32_t *used;             // [n_wg] order key above everything the workgroup dropped (0: it dropped nothing)
-    float *wg_prior;            // [n_wg] what the workgroup's next query starts from (reported-score units; 0: nothing). NULL: no carrying
+    float *wg_prior;            // [n_wg] what the workgroup's next query starts from, relative to sum |x| (reported-score units per unit of L1 norm; 0: nothing). NULL: no carrying
     uint32_t *prior_block;      // [0] selections to go without carried thresholds, [1] what a failure costs, [2] clean run, [3] failures so far
     uint32_t *status;           // device word: 1 = the check of this launch failed (a repair launch behind it reads it), else 0
     uint32_t mode;              // 1: a wave's word is its best packet maximum, 2: its second best
@@ -62,6 +62,17 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
     v = mv(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_ROW_BCAST15, 0xA, 0xF, false));
     v = mv(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, DPP_ROW_BCAST31, 0xC, 0xF, false));
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// (fp32 sum of a wave in a FIXED order -- the DPP tree -- so that a value derived from it is the same in every run)
+__device__ __forceinline__ float wave_sum_f32(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), DPP_ROW_SHR1, 0xF, 0xF, true));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), DPP_ROW_SHR2, 0xF, 0xF, true));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), DPP_ROW_SHR4, 0xF, 0xF, true));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), DPP_ROW_SHR8, 0xF, 0xF, true));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), DPP_ROW_BCAST15, 0xA, 0xF, true));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), DPP_ROW_BCAST31, 0xC, 0xF, true));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {  // (DPP prefix sum; the total is read from lane 63)
@@ -475,6 +486,7 @@ struct SingleLds {
     unsigned long long stg[8 * STG_N];
     uint32_t stg_cnt[8];
     uint32_t rank[64];  // ranks of the staged rows (the workgroup's record)
+    float xnorm[8];     // per wave: sum |x| over the words it loaded (carried thresholds are kept relative to the query's L1 norm)
 };
 
 template <int QM>
@@ -520,24 +532,38 @@ __global__ void __launch_bounds__(512, 4) single_kernel(const StreamParams P, co
         wave_has = lane < 8u && pw < P.n_parts && (P.uni_ppp != 0u || P.part_count[pw] != 0u);
     }
     const float min_units = P.min_score;  // (fp32 scores: one unit = 1.0)
-    // the carried threshold of this workgroup, unless a failed check has suspended carrying
-    float tau_init = min_units;
-    uint32_t carried_key = 0u;
+    // The carried threshold of this workgroup (unless a failed check has suspended carrying): what it delivered as its 8th best
+    // row for the previous query, kept RELATIVE to that query's L1 norm -- scores are linear in x, so a query three times as
+    // large, or a hundred times smaller, starts from a threshold that fits it (round 4; before, every change of scale was a failed
+    // check or a useless threshold). The loads of the prior are issued here, ahead of x; the threshold itself needs sum |x|.
+    float prior = 0.0f;
+    uint32_t blocked = 1u;
     if (G.wg_prior) {
-        const float prior = __uint_as_float(scalar_load(reinterpret_cast<const uint32_t *>(G.wg_prior) + bid));
-        const uint32_t blocked = scalar_load(G.prior_block);
-        const float t0 = prior * G.beta;
-        if (blocked == 0u && prior > 0.0f && t0 > tau_init) {
-            tau_init = t0;
-            carried_key = order_key(t0);
-        }
+        prior = __uint_as_float(scalar_load(reinterpret_cast<const uint32_t *>(G.wg_prior) + bid));
+        blocked = scalar_load(G.prior_block);
     }
-    if (tid < (uint32_t)MISC_WORDS) L.misc[tid] = tid == (uint32_t)MISC_TAU ? __float_as_uint(tau_init) : (tid == (uint32_t)MISC_TAUKEY ? carried_key : 0u);
+    if (tid < (uint32_t)MISC_WORDS) L.misc[tid] = tid == (uint32_t)MISC_TAU ? __float_as_uint(min_units) : 0u;
     if (tid < 8u) L.stg_cnt[tid] = 0u;
     if (tid < 64u) L.rank[tid] = 0u;
     L.u.w.x[tid] = x0;
     L.u.w.x[tid + 512u] = x1;
+    {
+        const float wsum = wave_sum_f32(fabsf(x0) + fabsf(x1));
+        if (lane == 0) L.xnorm[wave] = wsum;
+    }
     __syncthreads();
+    // (every wave adds the eight partial sums in the same order: the same value everywhere, in every run)
+    float xnorm = 0.0f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) xnorm += L.xnorm[w];
+    if (wave == 0u && blocked == 0u && prior > 0.0f) {
+        const float t0 = prior * xnorm * G.beta;
+        if (t0 > min_units && lane == 0) {
+            // (a wave that has already started sees it a packet or two late: what it drops meanwhile it drops against a LOWER value)
+            (void)__hip_atomic_fetch_max(&L.misc[MISC_TAUKEY], order_key(t0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(&L.misc[MISC_TAU], __float_as_uint(t0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
     if (tr) tr1 = __builtin_amdgcn_s_memrealtime();
     const uint32_t xbase = lds_addr_of(L.u.w.x);
     uint32_t *misc = L.misc;
@@ -645,7 +671,7 @@ __global__ void __launch_bounds__(512, 4) single_kernel(const StreamParams P, co
         }
         if (tr) tr6 = __builtin_amdgcn_s_memrealtime();
         if (lane == 8u) __hip_atomic_store(&G.used[bid], used, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (lane == 9u && G.wg_prior && next_prior >= 0.0f) G.wg_prior[bid] = next_prior;  // (read by the NEXT launch)
+        if (lane == 9u && G.wg_prior && next_prior >= 0.0f && xnorm > 0.0f) G.wg_prior[bid] = next_prior / xnorm;  // (relative to sum |x|; read by the NEXT launch)
         // Hand-off (cdna_hip_programming.md Guideline 16): the record is made of write-through stores; drain them, then ONE
         // relaxed agent-scope ticket add (two levels: 8 group counters and a top counter on separate 128-byte lines); the workgroup
         // whose add came last takes an agent-scope acquire and only then loads what the others stored.

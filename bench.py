@@ -541,19 +541,36 @@ def bench_single(a, mod, torch, np, dev, local_rank):
     # whatever is measured behind it.)
     rng = np.random.default_rng(11)
     sc = rng.choice([1.0, 0.01, 3.0], size=a.queries).astype(np.float32)
-    dxs_ns = torch.from_numpy(np.ascontiguousarray(xs * sc[:, None])).to(dev)
+    # (round 4: carried thresholds are relative to the query's L1 norm, so scales alone no longer invalidate them; what does is a
+    #  change of the query's DIRECTION: every 16th query here has its sign flipped, every 16th is concentrated on 32 columns)
+    xs_ns = xs * sc[:, None]
+    c_sc0 = eng.debug_counters()
+    dxs_sc = torch.from_numpy(np.ascontiguousarray(xs_ns)).to(dev)  # (scales only, first: its failures -- none expected -- would suspend carrying)
+    eng.time_queries(dxs_sc.data_ptr(), a.queries, 64)
+    sc_ns = [v / 1e3 for v in eng.time_query_batches(dxs_sc.data_ptr(), a.queries, n_rep, 8)][2:]
+    c_sc1 = eng.debug_counters()
+    xs_ns[5::16] *= np.float32(-1.0)
+    for j in range(11, xs_ns.shape[0], 16):
+        keep = rng.choice(xs_ns.shape[1], size=32, replace=False)
+        mask = np.zeros(xs_ns.shape[1], dtype=bool)
+        mask[keep] = True
+        xs_ns[j, ~mask] = 0.0
+    dxs_ns = torch.from_numpy(np.ascontiguousarray(xs_ns)).to(dev)
     c0 = eng.debug_counters()
     eng.time_queries(dxs_ns.data_ptr(), a.queries, 64)
     ns_ns = [v / 1e3 for v in eng.time_query_batches(dxs_ns.data_ptr(), a.queries, n_rep, 8)][2:]
     val_ns, idx_ns = eng.read_result()
-    ok_ns, _ = check_parity(mod, m, (xs * sc[:, None])[(n_rep - 1) % a.queries], a.k, idx_ns, val_ns, eng)
+    ok_ns, _ = check_parity(mod, m, xs_ns[(n_rep - 1) % a.queries], a.k, idx_ns, val_ns, eng)
     c1 = eng.debug_counters()
     extra["nonstationary"] = {"kernel_us_median": pct(ns_ns, 50), "queries": 64 + 8 * n_rep, "scales": [1.0, 0.01, 3.0],
                               "checks_failed": c1["checks_failed"] - c0["checks_failed"],
                               "gate_closed_for_launches": c1["local_off_for_launches"], "parity_checked": ok_ns,
                               "carried_thresholds_suspended_for_after": c1["suspended_for"],
-                              "note": "same matrix, every query scaled by 1, 0.01 or 3 at random: a failed check costs the query a "
-                                      "second pass; a launch of which a quarter fails closes the gate (device-wide exchange) for 8+ launches"}
+                              "direction_changes": "every 16th query sign-flipped, every 16th concentrated on 32 of the columns",
+                              "scales_only": {"kernel_us_median": pct(sc_ns, 50), "checks_failed": c_sc1["checks_failed"] - c_sc0["checks_failed"]},
+                              "note": "same matrix, every query scaled by 1, 0.01 or 3 at random (harmless: thresholds are carried relative to "
+                                      "the query's L1 norm) and one query in eight changed in direction (which is not): a failed check costs "
+                                      "the query a second pass; a launch of which a quarter fails closes the gate for 8+ launches"}
     eng.close()
     if not a.skip_warm:
         # the same workload with 16-bit column words (TKSPMV_F32_C12=0: 6 instead of 5.5 bytes per nnz, same bits)

@@ -59,8 +59,8 @@ def test_reference_loop_through_the_single_query_kernel(pkg, oracle, rows):
 
 
 def test_single_query_kernel_survives_queries_that_break_its_thresholds(pkg, oracle):
-    """Scales 1 / 0.01 / 3, x = 0, -x and a min_score in the way: carried thresholds are invalidated again and again; every list
-    must still be exact, failed checks must have happened, and each of them must have gone through the exact launch."""
+    """Scales 1 / 0.01 / 3 (harmless since thresholds are carried relative to the query's L1 norm), x = 0 and -x (which is
+    not): every list must be exact, failed checks must have happened, and each of them must have gone through the exact launch."""
     k, rows = 100, 300000
     m = pkg.generate_matrix(rows, 1024, 20, "gamma", 7)
     eng = pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, k=k, device=0)
@@ -139,7 +139,8 @@ def test_engine_owned_result_buffer_holds_the_last_query_whatever_was_repaired(p
     launch names the same buffer, several selections run at once, and a query whose check failed is answered again by the exact
     launch AFTER the last one was selected -- the engine redirects all but the last query of a launch to a side buffer. The stream
     makes earlier queries fail (scale 3 -> 0.01: carried thresholds far too high) while the last one passes; what tkspmv_read
-    returns must be the LAST query's list, bit for bit, for every batch length."""
+    returns must be the LAST query's list, bit for bit, for every batch length. (Round 4: what breaks a carried threshold here is
+    a change of SIGN -- -x: no row reaches the threshold carried from +x --, scales do not any more.)"""
     import torch
     monkeypatch.setenv("TKSPMV_LOCAL", local)
     k = 100
@@ -147,8 +148,9 @@ def test_engine_owned_result_buffer_holds_the_last_query_whatever_was_repaired(p
     eng = pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, k=k, device=0)
     packed, raw, C = _packed_raw(pkg, m, eng, k)
     failed_before = 0
-    for n_q, scales in ((6, [3, 3, 3, 3, 0.01, 0.01]), (12, [1] * 6 + [3] * 4 + [0.01] * 2), (5, [3, 0.01, 3, 0.01, 0.01]), (1, [3]),
-                        (9, [3, 3, 3, 3, 3, 3, 3, 0.01, 1])):
+    # (scales alone no longer break a carried threshold -- it is kept relative to the query's L1 norm --, a change of sign does)
+    for n_q, scales in ((6, [3, 3, 3, -3, 0.01, 0.01]), (12, [1] * 6 + [3, -3, 3, -0.01] + [0.01] * 2), (5, [3, -0.01, 3, -1, 0.01]), (1, [3]),
+                        (9, [3, 3, 3, 3, -3, 3, 3, -0.01, 1])):
         xs = np.stack([pkg.create_sample_vector(1024, True, False, True, 700 + n_q * 16 + i) * np.float32(scales[i]) for i in range(n_q)]).astype(np.float32)
         dxs = torch.from_numpy(np.ascontiguousarray(xs)).cuda()
         torch.cuda.synchronize()
