@@ -556,12 +556,15 @@ __global__ void __launch_bounds__(512, 4) single_kernel(const StreamParams P, co
     float xnorm = 0.0f;
 #pragma unroll
     for (int w = 0; w < 8; ++w) xnorm += L.xnorm[w];
-    if (wave == 0u && blocked == 0u && prior > 0.0f) {
+    if (blocked == 0u && prior > 0.0f) {
+        // Every wave installs the (same) value before its own first packet -- its LDS operations execute in order, so it streams
+        // against it from the start; the rule is the one thresholds are raised by further down (record the largest in MISC_TAUKEY,
+        // store only what raises it), so a wave that starts late never lowers what faster waves have already formed.
         const float t0 = prior * xnorm * G.beta;
         if (t0 > min_units && lane == 0) {
-            // (a wave that has already started sees it a packet or two late: what it drops meanwhile it drops against a LOWER value)
-            (void)__hip_atomic_fetch_max(&L.misc[MISC_TAUKEY], order_key(t0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_store(&L.misc[MISC_TAU], __float_as_uint(t0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const uint32_t k0 = order_key(t0);
+            const uint32_t old = __hip_atomic_fetch_max(&L.misc[MISC_TAUKEY], k0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (k0 > old) __hip_atomic_store(&L.misc[MISC_TAU], __float_as_uint(t0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
     if (tr) tr1 = __builtin_amdgcn_s_memrealtime();
