@@ -17,7 +17,7 @@ static const OptionDef k_options[] = {
     {"LOCAL_BETA", "tuning", "float (default 1.0)", "factor applied to a carried workgroup threshold before the next query uses it"},
     {"SINGLE", "behaviour", "0 | 1 (default 1)", "0: tkspmv_run uses the stream kernel with the device-wide exchange instead of the single-query kernel with local thresholds"},
     {"BATCH", "behaviour", "0 | 1 (default 1)", "0: tkspmv_enqueue_batch / _many launch one kernel per query"},
-    {"BATCH_MAX", "tuning", "1..32 (default 32, 12 for small matrices)", "queries per batch launch"},
+    {"BATCH_MAX", "tuning", "1..32 (default 32)", "queries per batch launch"},
     {"SELECTORS", "tuning", "1..8 (default 4 up to LOCAL_MATRIX_PACKETS, else 1)", "selection workgroups a batch launch keeps in flight"},
     {"OVF_LISTS", "tuning", "1 | 2 | 4 (default 4; 2 for engines that stream with local thresholds)", "overflow lists of the exact kernel (8 bytes per row each), shared round robin by the queries of a launch under flow control"},
     {"PACE", "tuning", "0..32 (default by size)", "pacing quantum of the batch kernel's workgroups by rank (s_sleep units); 0 = none"},
