@@ -177,7 +177,10 @@ int tkspmv_create(tkspmv_t **out, const tkspmv_desc *desc);
 void tkspmv_destroy(tkspmv_t *e);
 int tkspmv_get_info(const tkspmv_t *e, tkspmv_info *info);
 
-/* Install a new query vector (host pointer, `cols` floats): H2D copy. Returns ns in *elapsed_ns if non-NULL. */
+/* Install a new query vector (host pointer, `cols` floats) -- the reference's reset(vec), host_spmv_bscsr.cpp:354-358. Where the
+ * device exposes its memory through a large PCIe BAR (checked by a round trip at create time; option BAR_X) x is stored straight
+ * into device memory with CPU stores and a store fence; else it goes through a pinned staging copy and an asynchronous upload.
+ * Returns ns in *elapsed_ns if non-NULL. */
 int tkspmv_set_query(tkspmv_t *e, const float *host_x, double *elapsed_ns);
 /* Same, but x already lives in device memory (no copy; pointer must stay valid until the run completes). */
 int tkspmv_set_query_device(tkspmv_t *e, const float *dev_x);
@@ -193,9 +196,10 @@ int tkspmv_run(tkspmv_t *e, double *kernel_ns);
  * dev_idx/dev_val: optional device output buffers of k entries (NULL => engine-owned result buffers). */
 int tkspmv_enqueue(tkspmv_t *e, const float *dev_x, uint32_t *dev_idx, float *dev_val, void *stream);
 /* Enqueue `count` queries back to back (query i uses dev_xs + (i % n_x) * cols), no host sync; the engine-owned
- * result buffers end up holding the last query's top-k. In a back-to-back sequence the selection of query i runs
- * inside the launch of query i+1 (deferred selection) and a small closing launch serves the last one, so the
- * sequence is complete in stream order when the call returns. */
+ * result buffers end up holding the last query's top-k. Launch scheme: the batch kernel, up to 32 queries per launch,
+ * selections running beside the stream inside the launch (wide x or large k: one launch per query with
+ * the selection of query i inside the launch of query i+1 and a small closing launch); the sequence is complete in stream
+ * order when the call returns. */
 int tkspmv_enqueue_many(tkspmv_t *e, const float *dev_xs, int32_t n_x, int32_t count, void *stream);
 /* A batch of `count` queries (the loop of the reference's drivers, host_spmv_bscsr.cpp main: for each test vector
  * reset -> operator() -> read_result): query i = dev_xs + i * cols, its k results go to dev_idx + i * k and
