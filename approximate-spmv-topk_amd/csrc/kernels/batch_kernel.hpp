@@ -300,7 +300,8 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
 #pragma unroll
                         for (int u = 0; u < XCOLS / 64; ++u) {
                             const uint32_t i = lane + 64u * (uint32_t)u;
-                            r[u] = i < P0.cols ? __hip_atomic_load(reinterpret_cast<const uint32_t *>(B.host_x) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0u;
+                            const uint32_t w = __hip_atomic_load(reinterpret_cast<const uint32_t *>(B.host_x) + (i < P0.cols ? i : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            r[u] = i < P0.cols ? w : 0u;  // (clamped address, masked value: sixteen loads in flight, not sixteen branches)
                         }
 #pragma unroll
                         for (int u = 0; u < XCOLS / 64; ++u)
@@ -489,10 +490,10 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
 #pragma unroll
                         for (int u = 0; u < 16; ++u) {
                             const uint32_t i = b0 + lane + 64u * (uint32_t)u;
-                            r[u] = (i < P0.cols) ? x_at(i) : 0.0f;
+                            r[u] = x_at(i < P0.cols ? i : 0u);  // (always a valid address: see the staging loop below)
                         }
 #pragma unroll
-                        for (int u = 0; u < 16; ++u) lm = fmaxf(lm, r[u]);
+                        for (int u = 0; u < 16; ++u) lm = fmaxf(lm, (b0 + lane + 64u * (uint32_t)u) < P0.cols ? r[u] : 0.0f);
                     }
                     const float xmax = wave_max(lm);
                     int sh = 0;
@@ -515,10 +516,21 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
 #pragma unroll 1
                 for (uint32_t b0 = 0; b0 < (uint32_t)XCOLS; b0 += 1024u) {  // 16 loads in flight per lane
                     float r[16];
+                    // (Written as "in range ? load : 0" every load sat in a branch of its own behind an s_waitcnt vmcnt(0) -- sixteen
+                    //  trips through memory one after the other per staging, 6-16 us: what a small shard's query took altogether, and
+                    //  on the device-wide exchange the reason thresholds arrived late. A full-width x -- every BASELINE matrix this
+                    //  kernel streams -- needs no check at all: ONE branch, one base address, sixteen immediate offsets, sixteen loads
+                    //  in flight; else the address is clamped and the VALUE masked, which costs an address per load.)
+                    if (!LOCAL && P0.cols == (uint32_t)XCOLS) {  // (the kernel of local thresholds measured FASTER with the clamped form: 16.8-17.0 against 17.5 us per query at 1M rows)
 #pragma unroll
-                    for (int u = 0; u < 16; ++u) {
-                        const uint32_t i = b0 + lane + 64u * (uint32_t)u;
-                        r[u] = (i < P0.cols) ? x_at(i) : 0.0f;
+                        for (int u = 0; u < 16; ++u) r[u] = x_at(b0 + lane + 64u * (uint32_t)u);
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) {
+                            const uint32_t i = b0 + lane + 64u * (uint32_t)u;
+                            const float xv = x_at(i < P0.cols ? i : 0u);
+                            r[u] = i < P0.cols ? xv : 0.0f;
+                        }
                     }
                     if (carry_local) {
 #pragma unroll

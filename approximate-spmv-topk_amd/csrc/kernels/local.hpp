@@ -507,8 +507,10 @@ __global__ void __launch_bounds__(512, 4) single_kernel(const StreamParams P, co
         __hip_atomic_store(SP.t_start, (unsigned long long)__builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
     // x first (two words per thread: they return ahead of the packets), then this wave's first packets
-    const float x0 = tid < P.cols ? P.x[tid] : 0.0f;
-    const float x1 = tid + 512u < P.cols ? P.x[tid + 512u] : 0.0f;
+    // (clamped addresses, masked values: two loads in flight, no branch around either)
+    const float xa = P.x[tid < P.cols ? tid : 0u], xb = P.x[tid + 512u < P.cols ? tid + 512u : 0u];
+    const float x0 = tid < P.cols ? xa : 0.0f;
+    const float x1 = tid + 512u < P.cols ? xb : 0.0f;
     const uint32_t q = wave * n_wg + bid;
     uint32_t p0 = 0, np = 0;
     if (q < P.n_parts) TKSPMV_PARTITION_RANGE(P, q, p0, np);

@@ -205,13 +205,39 @@ __global__ void __launch_bounds__(576, Q >= 8 ? 4 : 6) multi_kernel(const Stream
     auto x_slot = [&](uint32_t q, uint32_t col) __attribute__((always_inline)) -> float & {
         return L.u.w.x[IL ? col * (uint32_t)Q + q : q * (SELL_XCOLS + 8u) + col];
     };
-    for (uint32_t q = 0; q < (uint32_t)Q; ++q) {  // queries beyond nq (a partial group): zeros, their sums are never looked at
-        const float *xg = M.cur.io[q < nq ? q : 0u].x;
-        for (uint32_t i = tid; i < SELL_XCOLS; i += blockDim.x)
-            x_slot(q, i) = (i < P0.cols && q < nq) ? (BYTES ? xg[i] * Q17_UNIT : xg[i]) : 0.0f;
-        if (tid == 0) {
-            x_slot(q, PAD_NEUTRAL) = -0.0f;
-            x_slot(q, PAD_ONE) = BYTES ? -__builtin_huge_valf() : 1.0f;  // byte chunks: a lane without a row starts with byte 1
+    // x of the group's queries into LDS. ALL loads first (Q x 2 per thread at 512+ threads), then the LDS writes: written as "load,
+    // convert, store" per element the compiler waited for every load before it issued the next one -- 2 Q trips through memory one
+    // after the other at the head of every launch (round 4 found the same in the batch kernel's staging). Addresses are clamped and
+    // values masked, so no load sits in a branch. Queries beyond nq (a partial group): zeros, their sums are never looked at.
+    {
+        // (one query per pass -- configs[4] -- measured the other way: 19.05 against 19.28 us with two loads waited for one by one; it keeps them)
+        constexpr uint32_t XI = Q >= 2 ? 2u : 0u;  // elements per thread and query held in registers (1024 columns, >= 512 threads)
+        float xr[Q][XI > 0 ? XI : 1];
+#pragma unroll
+        for (uint32_t q = 0; q < (uint32_t)Q; ++q) {
+            const float *xg = M.cur.io[q < nq ? q : 0u].x;
+#pragma unroll
+            for (uint32_t it = 0; it < XI; ++it) {
+                const uint32_t i = tid + it * blockDim.x;
+                xr[q][it] = xg[i < P0.cols ? i : 0u];
+            }
+        }
+#pragma unroll
+        for (uint32_t q = 0; q < (uint32_t)Q; ++q) {
+#pragma unroll
+            for (uint32_t it = 0; it < XI; ++it) {
+                const uint32_t i = tid + it * blockDim.x;
+                if (i < SELL_XCOLS) x_slot(q, i) = (i < P0.cols && q < nq) ? (BYTES ? xr[q][it] * Q17_UNIT : xr[q][it]) : 0.0f;
+            }
+            const float *xg = M.cur.io[q < nq ? q : 0u].x;
+            for (uint32_t i = tid + XI * blockDim.x; i < SELL_XCOLS; i += blockDim.x) {  // (workgroups of fewer than 512 threads)
+                const float xw = xg[i < P0.cols ? i : 0u];
+                x_slot(q, i) = (i < P0.cols && q < nq) ? (BYTES ? xw * Q17_UNIT : xw) : 0.0f;
+            }
+            if (tid == 0) {
+                x_slot(q, PAD_NEUTRAL) = -0.0f;
+                x_slot(q, PAD_ONE) = BYTES ? -__builtin_huge_valf() : 1.0f;  // byte chunks: a lane without a row starts with byte 1
+            }
         }
     }
     __syncthreads();

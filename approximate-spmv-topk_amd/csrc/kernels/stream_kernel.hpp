@@ -158,7 +158,8 @@ __global__ void __launch_bounds__(576, ((C == 8 && !SCORES) || QM == 7) ? 6 : 5)
     const float inv_unit = 1.0f / unit_scale;             // exact: unit_scale is a power of two
     const float min_units = P.min_score * unit_scale;
     for (uint32_t i = tid; i < (uint32_t)XCOLS; i += blockDim.x) {
-        const float xv = (i < P.cols) ? P.x[i] : 0.0f;
+        const float xw = P.x[i < P.cols ? i : 0u];  // (clamped address, masked value: the loads are issued back to back)
+        const float xv = (i < P.cols) ? xw : 0.0f;
         if (Q8)
             reinterpret_cast<uint32_t *>(x_lds)[i] = to_q1_7_dev(xv * x_scale);  // x quantised like the matrix values
         else if (QM == 6)  // bit-packed narrow fixed point: x as a 20-bit integer
