@@ -297,11 +297,19 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // x was written before the request
                         uint32_t *dst = B.xr + (size_t)(q & 1u) * XCOLS;
                         uint32_t r[XCOLS / 64];
+                        // (sixteen reads of HOST memory: they must be in flight together -- one base address and immediate offsets for a
+                        //  full-width x; else clamped addresses and masked values, which the compiler may issue one by one)
+                        if (P0.cols == (uint32_t)XCOLS) {
 #pragma unroll
-                        for (int u = 0; u < XCOLS / 64; ++u) {
-                            const uint32_t i = lane + 64u * (uint32_t)u;
-                            const uint32_t w = __hip_atomic_load(reinterpret_cast<const uint32_t *>(B.host_x) + (i < P0.cols ? i : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                            r[u] = i < P0.cols ? w : 0u;  // (clamped address, masked value: sixteen loads in flight, not sixteen branches)
+                            for (int u = 0; u < XCOLS / 64; ++u)
+                                r[u] = __hip_atomic_load(reinterpret_cast<const uint32_t *>(B.host_x) + lane + 64u * (uint32_t)u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        } else {
+#pragma unroll
+                            for (int u = 0; u < XCOLS / 64; ++u) {
+                                const uint32_t i = lane + 64u * (uint32_t)u;
+                                const uint32_t w = __hip_atomic_load(reinterpret_cast<const uint32_t *>(B.host_x) + (i < P0.cols ? i : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                r[u] = i < P0.cols ? w : 0u;
+                            }
                         }
 #pragma unroll
                         for (int u = 0; u < XCOLS / 64; ++u)
@@ -531,6 +539,8 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
                             const float xv = x_at(i < P0.cols ? i : 0u);
                             r[u] = i < P0.cols ? xv : 0.0f;
                         }
+                        // (in the exact kernel the compiler issues these one at a time all the same -- an address pair per load
+                        //  is more registers than it has there: narrow x on the device-wide exchange stages x in sixteen trips)
                     }
                     if (carry_local) {
 #pragma unroll

@@ -229,11 +229,13 @@ __global__ void __launch_bounds__(576, Q >= 8 ? 4 : 6) multi_kernel(const Stream
                 const uint32_t i = tid + it * blockDim.x;
                 if (i < SELL_XCOLS) x_slot(q, i) = (i < P0.cols && q < nq) ? (BYTES ? xr[q][it] * Q17_UNIT : xr[q][it]) : 0.0f;
             }
-            const float *xg = M.cur.io[q < nq ? q : 0u].x;
-            for (uint32_t i = tid + XI * blockDim.x; i < SELL_XCOLS; i += blockDim.x) {  // (workgroups of fewer than 512 threads)
-                const float xw = xg[i < P0.cols ? i : 0u];
-                x_slot(q, i) = (i < P0.cols && q < nq) ? (BYTES ? xw * Q17_UNIT : xw) : 0.0f;
-            }
+            if (XI == 0u) {  // (one query per pass)
+                const float *xg = M.cur.io[q < nq ? q : 0u].x;
+                for (uint32_t i = tid; i < SELL_XCOLS; i += blockDim.x) {
+                    const float xw = xg[i < P0.cols ? i : 0u];
+                    x_slot(q, i) = (i < P0.cols && q < nq) ? (BYTES ? xw * Q17_UNIT : xw) : 0.0f;
+                }
+            }  // (else: the host launches this kernel with 512 or 576 threads -- 2 x blockDim covers the 1024 columns)
             if (tid == 0) {
                 x_slot(q, PAD_NEUTRAL) = -0.0f;
                 x_slot(q, PAD_ONE) = BYTES ? -__builtin_huge_valf() : 1.0f;  // byte chunks: a lane without a row starts with byte 1

@@ -111,15 +111,18 @@ __device__ __forceinline__ void select_body(const SelectParams &P, const uint32_
 #pragma unroll
     for (uint32_t u = 0; u < SEL_PER_THREAD; ++u) {
         const uint32_t f = tid + u * nthreads;
-        mine[u] = ~0ull;
-        if (f < n_slots) mine[u] = ld_agent(&P.wg_cand[f]);
+        // (clamped address, masked value: as "if in range, load" the compiler put every load into a branch of its own behind an
+        //  s_waitcnt vmcnt(0) in some instantiations -- eight trips through memory one after the other per selection)
+        const unsigned long long w = ld_agent(&P.wg_cand[f < n_slots ? f : 0u]);
+        mine[u] = f < n_slots ? w : ~0ull;
     }
     unsigned long long ospec[OVF_SPEC > 0 ? OVF_SPEC : 1];
     if (OVF_SPEC > 0) {
 #pragma unroll
         for (int u = 0; u < OVF_SPEC; ++u) {
             const uint32_t i = tid + (uint32_t)u * nthreads;
-            ospec[u] = i < P.ovf_cap ? ld_agent(&P.ovf_cand[i]) : 0ull;
+            const unsigned long long w = ld_agent(&P.ovf_cand[i < P.ovf_cap ? i : 0u]);
+            ospec[u] = i < P.ovf_cap ? w : 0ull;
         }
     }
     if (P.pos_to_row) {

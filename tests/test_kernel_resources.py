@@ -107,3 +107,65 @@ template __global__ void stream_kernel<4, false, 1024, 0, 3, false>(const Stream
         hot = [b for b in blocks if b["hot"]]
         assert len(hot) >= 3, "the streaming loop was not found in the ISA of " + lines[start].split(":")[0]
         assert all(b["scratch"] == 0 for b in hot), (lines[start].split(":")[0], [b for b in hot if b["scratch"]])
+
+
+def test_no_chain_of_loads_waited_for_one_by_one(tmp_path):
+    """Round 4 found the server wave staging x with sixteen loads each behind its own `s_waitcnt vmcnt(0)` -- sixteen trips through
+    memory in a row, 6-16 us per query, invisible to every functional test (the compiler had put each 'in range ? load : 0' into a
+    branch of its own). This compiles the headline kernels on their own and looks for runs of (wait for everything, ONE load) in
+    the ISA: none of 6 or more may exist in the kernel of local thresholds, the single-query kernel and the multi-query kernels;
+    the exact kernel may keep ONE such run -- the staging of an x narrower than 1024 columns (it has no registers for sixteen
+    clamped addresses; a full-width x takes the branch with immediate offsets)."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    tu = tmp_path / "tu.hip"
+    tu.write_text("""#include <hip/hip_runtime.h>
+#include <cstdint>
+#include "kernels/common.hpp"
+#include "kernels/select.hpp"
+#include "kernels/packet_math.hpp"
+#include "kernels/stream_kernel.hpp"
+#include "kernels/local.hpp"
+#include "kernels/batch_kernel.hpp"
+#include "kernels/multi_kernel.hpp"
+namespace tkspmv {
+template __global__ void batch_kernel<4, 1024, 7, false, false, true>(const BatchArgs);
+template __global__ void batch_kernel<4, 1024, 7, false, false, false>(const BatchArgs);
+template __global__ void batch_kernel<4, 1024, 3, false, false, true>(const BatchArgs);
+template __global__ void single_kernel<7>(const StreamParams, const SelectParams, const LocalParams);
+template __global__ void multi_kernel<8, 0>(const StreamParams, const SelectParams, const MultiParams);
+template __global__ void multi_kernel<4, 0>(const StreamParams, const SelectParams, const MultiParams);
+}
+""")
+    asm = tmp_path / "tu.s"
+    subprocess.check_call([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "--cuda-device-only", "-S",
+                           "-I" + os.path.join(ROOT, "approximate-spmv-topk_amd", "csrc"), "-I" + os.path.join(ROOT, "include"),
+                           "-o", str(asm), str(tu)], stderr=subprocess.DEVNULL)
+    fn, seq, chains = None, [], {}
+
+    def flush():
+        if fn:
+            chains[fn] = [len(m.group(0)) // 2 for m in re.finditer(r"(?:WL){6,}", "".join(seq))]
+
+    for ln in asm.read_text().split("\n"):
+        if re.match(r"^_ZN6tkspmv\w+:", ln):
+            flush()
+            fn, seq = ln.split(":")[0], []
+        t = ln.strip().split(";")[0].strip()
+        if not ln.startswith("\t") or not t:
+            continue
+        if t.startswith(("global_load", "buffer_load", "flat_load")):
+            seq.append("L")
+        elif t.startswith("s_waitcnt") and "vmcnt(0)" in t:
+            seq.append("W")
+        elif t.startswith(("global_store", "global_atomic", "s_sleep")):
+            seq.append("x")
+    flush()
+    chains = {n: r for n, r in chains.items() if "select_kernel" not in n and "select_group_kernel" not in n}  # (non-template kernels of the headers)
+    assert len(chains) == 6, sorted(chains)
+    for name, runs in chains.items():
+        exact = "batch_kernelILi4ELi1024ELi7ELb0ELb0ELb0E" in name
+        assert len(runs) <= (1 if exact else 0), (name, runs)
