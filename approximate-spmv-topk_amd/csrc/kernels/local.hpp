@@ -228,8 +228,7 @@ __device__ __forceinline__ bool select_local(const LocalParams &G, const SelectP
 #pragma unroll
     for (uint32_t u = 0; u < 8; ++u) {
         const uint32_t f = tid + u * nthreads;
-        const unsigned long long w = ld_agent(&G.slots[f < n_slots ? f : 0u]);  // (clamped address, masked value: no branch around the load)
-        mine[u] = f < n_slots ? w : ~0ull;
+        mine[u] = f < n_slots ? ld_agent(&G.slots[f]) : ~0ull;  // (eight loads in flight as the compiler emits it: checked on the ISA, tests/test_kernel_resources.py)
     }
     uint32_t my_used = 0u;
     for (uint32_t w = tid; w < n_wg; w += nthreads) {
