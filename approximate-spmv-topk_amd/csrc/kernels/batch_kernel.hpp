@@ -412,7 +412,7 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
     if (tid < 2u * MISC_WORDS) (&L.misc[0][0])[tid] = 0u;
     if (tid < 16u) (&L.stg_cnt[0][0])[tid] = 0u;
     if (tid == 0u) L.pace = 0u;
-    if (tid < 4u) {
+    if (!local && tid < 4u) {  // (local mode appends nothing to global memory: no lists, no epochs -- one trip through memory less at the head of the launch)
         const uint32_t e = tid < n_lists ? __hip_atomic_load(B.ovf_epoch + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
         L.epoch0[tid] = e;
         L.epoch_now[tid] = e;
