@@ -143,50 +143,6 @@ __device__ __forceinline__ void stage_wave_local(const uint2 *wcand, uint32_t wc
     if (lane == 0) *stg_cnt = surv;
 }
 
-// One wave finalises a query of its workgroup: of the up to 8 x STG_N staged rows (lane l looks at entry l % 8 of wave l / 8) the
-// 8 best are returned IN ORDER -- lane r < 8 holds the r-th best (row SLOT_INVALID where there are fewer): the workgroup's slots
-// --, the rest is dropped. `used` (wave-uniform): the order key above everything this workgroup dropped -- the thresholds it
-// filtered with (MISC_TAUKEY), what its waves dropped (MISC_BOUND), what did not fit the 8 slots. `next_prior`: what its next
-// query may start from, in this query's score units (negative: nothing new to go by).
-__device__ __forceinline__ unsigned long long finalize_local(const unsigned long long *stg, const uint32_t *stg_cnt, const uint32_t *misc,
-                                                             uint32_t lane, float min_units, uint32_t &used, float &next_prior) {
-    const float NEG_INF = -__builtin_huge_valf();
-    const uint32_t w = lane >> 3, e = lane & 7u;
-    const bool have = e < stg_cnt[w];
-    const unsigned long long v = have ? stg[w * STG_N + e] : 0ull;
-    const float f = have ? __uint_as_float((uint32_t)v) : NEG_INF;
-    bool taken = !have;
-    unsigned long long mine = pack_cand(0u, SLOT_INVALID);
-    float kept_last = 0.0f;
-    uint32_t n_kept = 0u, bound = 0u;
-#pragma unroll 1
-    for (uint32_t r = 0; r <= WG_SLOTS; ++r) {
-        const float mx = wave_max(taken ? NEG_INF : f);
-        const uint64_t bm = __ballot(!taken && f == mx);
-        if (bm == 0ull) break;  // fewer entries than slots
-        const uint32_t first = (uint32_t)__builtin_ctzll(bm);
-        if (r == WG_SLOTS) {
-            bound = order_key(mx) + 1u;  // the best row that did not fit, one step up (a dropped row may tie with it)
-        } else {
-            const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, (int)first);
-            const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), (int)first);
-            if (lane == r) mine = (unsigned long long)lo | ((unsigned long long)hi << 32);
-            if (lane == first) taken = true;
-            kept_last = mx;
-            ++n_kept;
-        }
-    }
-    const uint32_t k_thr = __hip_atomic_load(&misc[MISC_TAUKEY], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    const uint32_t k_drop = __hip_atomic_load(&misc[MISC_BOUND], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    used = __builtin_amdgcn_readfirstlane(k_thr > k_drop ? k_thr : k_drop);
-    used = used > bound ? used : bound;
-    // the next query starts from the score of the last row kept when the slots filled up; else from the threshold in force (it
-    // let fewer than 8 rows through: high enough), a little lower
-    const float t_end = __uint_as_float(__hip_atomic_load(&misc[MISC_TAU], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-    next_prior = n_kept == WG_SLOTS ? kept_last : (t_end > min_units ? t_end * 0.95f : -1.0f);
-    return mine;
-}
-
 // The bookkeeping of carried thresholds after a selection's check (thread 0 of the selecting workgroup): a failed check suspends
 // them for the next 16 .. 4096 selections (word 0 counts down; word 1: what a failure costs -- doubled by every failure, halved by
 // every 64 checks passed in a row with them, word 2); word 3 counts the failures (tkspmv_debug_counters).
