@@ -531,7 +531,13 @@ __global__ void __launch_bounds__(512, 4) single_kernel(const StreamParams P, co
     uint2 *wcand = L.u.w.cand + wave * WAVE_CAP;
 
     if (np != 0u) {
-        __builtin_amdgcn_s_setprio(1);
+        // The workgroup that arrived SECOND on its CU (the dispatcher places workgroups 0 .. n/2-1 first, one per CU) loses the
+        // arbitration to the older one and finished ~1.8 us later at equal priorities (traced, tools/single_trace.py): it streams at
+        // the higher issue priority. 26.4 against 27.0 us per launch (the kernel's own stamp, p95 27.2 against 28.3; three alternating
+        // runs on one box); priority 3 instead of 2, or a further step for the younger waves of a SIMD, gave the same. (Round 2's
+        // alternating turns -- the batch kernel's way -- had lost on the single-query kernel: one query has no turn to alternate.)
+        if (bid >= n_wg / 2u) __builtin_amdgcn_s_setprio(2);
+        else __builtin_amdgcn_s_setprio(1);
         float carry = 0.0f;
         uint32_t wcnt = 0u;
         float top1 = -__builtin_huge_valf(), top2 = -__builtin_huge_valf();
