@@ -177,6 +177,7 @@ struct EngineImpl {
     uint32_t *d_ovf_epoch = nullptr;            // [ovf_lists] x 32 words
     uint32_t ovf_lists = 1;                     // overflow lists allocated (batch engines: 4, or 2 with local thresholds; shared by the queries of a launch under flow control)
     uint32_t use_local = 0;  // workgroup-local thresholds (BatchParams::local: 0 off, 1 / 2: a wave's best / second best packet maximum)
+    uint32_t single_mode = 0;  // the same choice for ONE query per launch (single_kernel): by the failure estimate alone, whatever the size
     float *d_wg_prior = nullptr;  // [grid] + the countdown word (BatchParams::wg_prior / prior_block)
     float local_beta = 1.0f;
     uint32_t pace_quads = 0, pace_levels = 3; // pacing by rank (BatchParams::pace_quads, pace_levels)
@@ -561,7 +562,7 @@ struct EngineImpl {
         G.wg_prior = d_lprior;
         G.prior_block = reinterpret_cast<uint32_t *>(d_lprior + grid);
         G.status = d_lstatus;
-        G.mode = use_local;
+        G.mode = single_mode;
         G.beta = local_beta;
         G.trace = d_trace ? d_trace + (launch_counter % 4) * trace_words : nullptr;
         ++launch_counter;
@@ -1233,7 +1234,12 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
         tail9 = std::max(tail9, 0.0);
         const double p1 = n_wg * (std::pow(lam, a) + tail9);
         const double p2 = n_wg * (std::pow(per_part < 1.5 ? lam : std::min(1.0, 0.5 * lam * lam), a) + tail9);
-        m.use_local = (!small_matrix || m.grid > 512u) ? 0u : (p1 <= 1e-4 ? 1u : (p2 <= 1e-3 ? 2u : 0u));  // (512: select_body's first cut)
+        m.single_mode = m.grid > 512u ? 0u : (p1 <= 1e-4 ? 1u : (p2 <= 1e-3 ? 2u : 0u));  // (512: select_local's record count)
+        // Back-to-back queries: beyond ~1.3M rows the device-wide exchange is as fast and checks nothing (small_matrix). ONE query per
+        // launch has no such cross-over -- without a previous query in flight the exchange's threshold arrives a third into the
+        // partition, a carried local one is there from the first packet: 58.4 against 67.5 us at 3M rows -- so single_kernel serves
+        // tkspmv_run wherever the failure estimate allows it.
+        m.use_local = small_matrix ? m.single_mode : 0u;
         if (opt("DEBUG_OCC"))
             fprintf(stderr, "[tkspmv] small matrix %d: %u selector workgroups, %.0f partitions of %.1f packets, %.0f per workgroup; local thresholds fail with p = %.2e (mode 1) / %.2e (mode 2): mode %u\n",
                     (int)small_matrix, m.n_sel_wg, n_parts, per_part, a, p1, p2, m.use_local);
@@ -1241,7 +1247,7 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
     HIP_TRY(malloc_exchange((void **)&m.d_wg_prior, ((size_t)m.grid + 32) * 4));  // priors | countdown words
     HIP_TRY(hipMemset(m.d_wg_prior, 0, ((size_t)m.grid + 32) * 4));
     if (const char *f = opt("LOCAL_BETA")) m.local_beta = (float)atof(f);
-    if (const char *f = opt("LOCAL")) m.use_local = m.grid > 512u ? 0u : (uint32_t)std::max(0, std::min(2, atoi(f)));
+    if (const char *f = opt("LOCAL")) m.use_local = m.single_mode = m.grid > 512u ? 0u : (uint32_t)std::max(0, std::min(2, atoi(f)));
     // Pacing by rank, with local thresholds only (with the device-wide exchange the cold phase of every query is governor enough, §3.0):
     // the longer the partitions, the longer the pause (size sweeps on two boxes, tools/ab_rank.sh: best at 0 / 1 / 2 units of 256 cycles
     // up to 575k / 830k / 1.3M rows of 20 non-zeros).
@@ -1253,7 +1259,7 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
     if (const char *f = opt("PACE")) m.pace_quads = (uint32_t)std::max(0, std::min(32, atoi(f)));
     // single_kernel serves tkspmv_run where the engine streams with local thresholds: fp32 values, 4 entries per lane, x of at most
     // 1024 columns, at most 512 workgroups (select_local's first cut), one partition per wave of ITS launch (8 waves x grid).
-    m.can_single = m.use_local != 0u && d.precision == TKSPMV_F32 && C == 4u && m.xcols <= 1024u && m.grid <= 512u && m.block == 512u &&
+    m.can_single = m.single_mode != 0u && d.precision == TKSPMV_F32 && C == 4u && m.xcols <= 1024u && m.grid <= 512u && m.block == 512u &&
                    d.impl == TKSPMV_IMPL_STREAM && !m.use_radix && m.fused && m.host_path && m.h_res != nullptr &&
                    m.pm.part_first.size() <= (size_t)m.grid * 8u;
     if (const char *f = opt("SINGLE")) m.can_single = m.can_single && atoi(f) != 0;

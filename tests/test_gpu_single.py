@@ -189,3 +189,26 @@ def test_native_host_loop_times_the_reference_loop_and_leaves_the_last_result(pk
     _exact(pkg, oracle, m, eng, xs[22 % 5], k, idx, val, raw, C)
     assert eng.debug_counters()["single_launches"] == 23
     eng.close()
+
+
+def test_single_query_kernel_serves_large_matrices_too(pkg, oracle):
+    """3M rows: back-to-back queries run on the device-wide exchange there (batch_mode bits 8-15 = 0: as fast and nothing to
+    check), ONE query per launch still goes through single_kernel -- a carried local threshold is there from the first packet,
+    the exchange's arrives a third into the partition (58 against 67 us). Exact against the gold and the order-matched oracle."""
+    k, rows = 100, 3000000
+    m = pkg.generate_matrix(rows, 1024, 20, "gamma", 2)
+    eng = pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, k=k, device=0)
+    assert (eng.info()["batch_mode"] >> 8) & 0xFF == 0
+    packed, raw, C = _packed_raw(pkg, m, eng, k)
+    n = 10
+    for i in range(n):
+        x = pkg.create_sample_vector(1024, True, False, True, 8800 + i)
+        if i == 6:
+            x = (x * np.float32(-1.0)).astype(np.float32)  # (a failed check on the way: repaired through the exact launch)
+        eng.reset(x)
+        eng()
+        val, idx = eng.read_result()
+        _exact(pkg, oracle, m, eng, x, k, idx, val, raw, C, gold=i != 6)
+    c = eng.debug_counters()
+    assert c["single_launches"] == n and c["single_repairs"] == c["single_checks_failed"] >= 1, c
+    eng.close()
