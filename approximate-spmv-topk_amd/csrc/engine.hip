@@ -145,6 +145,8 @@ struct EngineImpl {
     // drain()). Groups alternate between the exchange-state sets [0, MULTI_Q_MAX) and [MULTI_Q_MAX, 2 * MULTI_Q_MAX).
     bool can_multi = false;
     int multi_q = 0;
+    // queries per multi-query LAUNCH (= its selector workgroups): multi_q, or with one query per pass up to MULTI_Q_MAX passes
+    int multi_group = 0;
     // Large k (see radix_hist_kernel): every query = scores kernel + radix select + the selection kernel
     bool use_radix = false;
     bool approx_parts = false;    // partitions > 1 with k > k_per_partition: the reference's lossy per-partition lists
@@ -311,7 +313,7 @@ struct EngineImpl {
         A.ovf_stride = ovf_cap;
         return A;
     }
-    // n <= multi_q queries in ONE pass over the matrix; their selection is owed (pending_group) to the next multi launch
+    // n <= multi_group queries in ONE launch (multi_q per pass over the matrix); their selection is owed (pending_group) to the next multi launch
     // or to drain().
     void launch_multi(const float *const *xs, uint32_t *const *out_idx, float *const *out_val, int n, hipStream_t s, int chain = 0) const {
         if (pending) {  // a deferred single-query selection uses sets 0/1: settle it first
@@ -329,19 +331,19 @@ struct EngineImpl {
         MultiParams M{};
         M.A = set_addr(0);
         M.part_slice0 = d_sell_part_slice0;
-        M.n_sel = (uint32_t)multi_q;
+        M.n_sel = (uint32_t)multi_group;
         M.prev = pending_group[chain];
         M.cur.n_q = (uint32_t)n;
         M.cur.set0 = (uint32_t)((2 * chain + multi_parity[chain]) * MULTI_Q_MAX);
-        const uint8_t *pk = d_sell_replicas.empty() ? d_sell_packets : d_sell_replicas[launch_counter % d_sell_replicas.size()];
-        for (int q = 0; q < n; ++q) {
+        for (int q = 0; q < n; ++q) {  // (one copy of the stream per PASS: the queries of a pass share it)
             BatchIO &Q = M.cur.io[q];
             Q.x = xs[q];
-            Q.packets = pk;
+            Q.packets = d_sell_replicas.empty() ? d_sell_packets : d_sell_replicas[launch_counter % d_sell_replicas.size()];
             Q.out_idx = out_idx[q];
             Q.out_val = out_val[q];
+            if (multi_q == 1) ++launch_counter;
         }
-        ++launch_counter;
+        if (multi_q != 1) ++launch_counter;
         SelectParams S = select_params(nullptr, nullptr, 0);
         S.pos_to_row = d_sell_rows;
         const dim3 mblock(multi_stream_waves * 64u + 64u);
@@ -362,8 +364,8 @@ struct EngineImpl {
             return;
         }
         // (two chains only with per-query result buffers: with the engine-owned pair "the last query wins" must hold)
-        if (multi_chains < 2 || n <= 2 * multi_q || out_idx[0] == out_idx[1]) {
-            for (int i = 0; i < n; i += multi_q) launch_multi(xs + i, out_idx + i, out_val + i, std::min(multi_q, n - i), s);
+        if (multi_chains < 2 || n <= 2 * multi_group || out_idx[0] == out_idx[1]) {
+            for (int i = 0; i < n; i += multi_group) launch_multi(xs + i, out_idx + i, out_val + i, std::min(multi_group, n - i), s);
             drain(s);
             return;
         }
@@ -371,8 +373,8 @@ struct EngineImpl {
         (void)hipEventRecord(ev_fork, s);
         (void)hipStreamWaitEvent(side, ev_fork, 0);
         int g = 0;
-        for (int i = 0; i < n; i += multi_q, ++g)
-            launch_multi(xs + i, out_idx + i, out_val + i, std::min(multi_q, n - i), (g & 1) ? side : s, g & 1);
+        for (int i = 0; i < n; i += multi_group, ++g)
+            launch_multi(xs + i, out_idx + i, out_val + i, std::min(multi_group, n - i), (g & 1) ? side : s, g & 1);
         drain(s);  // both chains' last selections, then the caller's stream waits for the side stream
     }
     // One query, its result complete in stream order right after these launches: the stream kernel and, unless
@@ -1123,6 +1125,13 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
         // wait and then poured its rows into the overflow list, 2 ms per query. Such engines run 4 queries per pass.
         if (mq == 8 && (uint32_t)d.k * 4u > m.n_groups_pub) mq = 4;
         m.multi_q = mq;
+        // One query per pass: a launch makes up to MULTI_PASSES passes (default 8), each with its own query and exchange-state set
+        m.multi_group = mq;
+        if (mq == 1) {
+            int passes = MULTI_Q_MAX;
+            if (const char *f = opt("MULTI_PASSES")) passes = std::min(std::max(atoi(f), 1), (int)MULTI_Q_MAX);
+            m.multi_group = passes;
+        }
         // 8 queries per pass need 91 registers: with 9 waves per workgroup only one workgroup fits a CU (the dispatcher wants
         // 6 waves on one SIMD for two); with 8 waves -- 7 streaming + the server -- two fit at up to 128 registers.
         m.multi_stream_waves = (m.multi_q >= 8 && waves_per_wg == 8u) ? 7u : waves_per_wg;
@@ -1137,8 +1146,8 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
                       (uint64_t)m.grid * WG_SLOTS <= (uint64_t)SEL_PER_THREAD * (m.multi_stream_waves * 64u + 64u);
     }
     if (m.can_multi) {
-        // the first multi_q workgroups of a multi-query launch are its selectors (one per query of a pass), the others stream
-        const uint32_t n_multi_waves = (m.grid - (uint32_t)m.multi_q) * m.multi_stream_waves;
+        // the first multi_group workgroups of a multi-query launch are its selectors (one per query of the previous launch), the others stream
+        const uint32_t n_multi_waves = (m.grid - (uint32_t)m.multi_group) * m.multi_stream_waves;
         SellMatrix sm;
         std::string perr;
         const auto t_sell = std::chrono::steady_clock::now();

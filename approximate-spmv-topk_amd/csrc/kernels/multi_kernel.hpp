@@ -152,15 +152,14 @@ __global__ void __launch_bounds__(576, Q >= 8 ? 4 : 6) multi_kernel(const Stream
     constexpr uint32_t PAD_NEUTRAL = VT == 5 ? 1022u : SELL_PAD_NEUTRAL, PAD_ONE = VT == 5 ? 1023u : SELL_PAD_ONE;
     constexpr uint32_t MULTI_WAVE_CAP = MultiGeom<Q>::WAVE_CAP;
     __shared__ MultiLds<Q> L;
-    const uint32_t tid = threadIdx.x;
-    const uint32_t lane = tid & 63u;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t tid0 = threadIdx.x;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
     if (blockIdx.x < M.n_sel) {
         // selector workgroups: workgroup q selects query q of the previous group (all of them at once: one after the other
         // in ONE workgroup they took longer than the pass they ride in)
         if (blockIdx.x < M.prev.n_q) {
             SelectParams S = select_params_of_set(SP0, M.A, M.prev.set0 + blockIdx.x, M.prev.io[blockIdx.x]);
-            select_body(S, tid, blockDim.x, L.u.sel);
+            select_body(S, tid0, blockDim.x, L.u.sel);
         }
         return;
     }
@@ -189,107 +188,135 @@ __global__ void __launch_bounds__(576, Q >= 8 ? 4 : 6) multi_kernel(const Stream
             slice = M.part_slice0[part];
         }
     }
-    const uint8_t *pk = M.cur.io[0].packets + (size_t)p0 * P0.packet_bytes;
+    // One query per pass (Q == 1): the launch makes M.cur.n_q PASSES, one query each, with exchange-state set set0 + pass and
+    // M.cur.io[pass] (round 4: BASELINE configs[4] -- the launch's ramp, its partition lookup and its tail are paid once per
+    // n_q queries; the next pass's first chunks and its x are requested before the barrier that ends the current one).
+    // Q >= 2: one pass, queries set0 .. set0 + n_q - 1 share it.
+    const uint32_t n_pass = Q == 1 ? M.cur.n_q : 1u;
     Pkt<C, VT> buf[NBUF];
-#pragma unroll
-    for (int u = 0; u < NBUF - 1; ++u) {
-        if (np > 0u) {
-            const uint32_t iu = ((uint32_t)u < np) ? (uint32_t)u : (np - 1u);
-            load_packet<C, VT>(pk + (size_t)iu * P0.packet_bytes, lane, buf[u]);
-        }
-    }
-
-    for (uint32_t i = tid; i < (uint32_t)Q * MISC_WORDS; i += blockDim.x)
-        (&L.misc[0][0])[i] = (i % MISC_WORDS) == (uint32_t)MISC_TAU ? __float_as_uint(min_units) : 0u;
     constexpr bool IL = Q >= 8;  // interleaved x: measured faster for 8 queries (5.99 against 7.09 us per query), slower for 4 (9.43 against 7.59)
     auto x_slot = [&](uint32_t q, uint32_t col) __attribute__((always_inline)) -> float & {
         return L.u.w.x[IL ? col * (uint32_t)Q + q : q * (SELL_XCOLS + 8u) + col];
     };
-    // x of the group's queries into LDS. ALL loads first (Q x 2 per thread at 512+ threads), then the LDS writes: written as "load,
-    // convert, store" per element the compiler waited for every load before it issued the next one -- 2 Q trips through memory one
-    // after the other at the head of every launch (round 4 found the same in the batch kernel's staging). Addresses are clamped and
-    // values masked, so no load sits in a branch. Queries beyond nq (a partial group): zeros, their sums are never looked at.
-    {
-        // (one query per pass -- configs[4] -- measured the other way: 19.05 against 19.28 us with two loads waited for one by one; it keeps them)
-        constexpr uint32_t XI = Q >= 2 ? 2u : 0u;  // elements per thread and query held in registers (1024 columns, >= 512 threads)
-        float xr[Q][XI > 0 ? XI : 1];
+    // x of the pass's queries: ALL loads first (Q x 2 per thread at 512+ threads: 2 x blockDim covers the 1024 columns), the LDS
+    // writes later: written as "load, convert, store" per element the compiler waited for every load before it issued the next
+    // one -- 2 Q trips through memory one after the other (round 4 found the same in the batch kernel's staging). Addresses are
+    // clamped and values masked, so no load sits in a branch. Queries beyond nq (a partial group): zeros, their sums are never
+    // looked at.
+    constexpr uint32_t XI = 2u;
+    float xr[Q][XI];
+    auto request = [&](uint32_t pass, uint32_t tid) __attribute__((always_inline)) {  // the pass's first chunks, then its x
+        const uint32_t lane = tid & 63u;
+        const uint8_t *pkp = M.cur.io[Q == 1 ? pass : 0u].packets + (size_t)p0 * P0.packet_bytes;
+#pragma unroll
+        for (int u = 0; u < NBUF - 1; ++u) {
+            if (np > 0u) {
+                const uint32_t iu = ((uint32_t)u < np) ? (uint32_t)u : (np - 1u);
+                load_packet<C, VT>(pkp + (size_t)iu * P0.packet_bytes, lane, buf[u]);
+            }
+        }
 #pragma unroll
         for (uint32_t q = 0; q < (uint32_t)Q; ++q) {
-            const float *xg = M.cur.io[q < nq ? q : 0u].x;
+            const float *xg = M.cur.io[Q == 1 ? pass : (q < nq ? q : 0u)].x;
 #pragma unroll
             for (uint32_t it = 0; it < XI; ++it) {
                 const uint32_t i = tid + it * blockDim.x;
                 xr[q][it] = xg[i < P0.cols ? i : 0u];
             }
         }
+    };
+    request(0u, tid0);
+    // The head of a pass: the workgroup's words, then x from the registers request() filled.
+    auto commit = [&](uint32_t tid) __attribute__((always_inline)) {
+        for (uint32_t i = tid; i < (uint32_t)Q * MISC_WORDS; i += blockDim.x)
+            (&L.misc[0][0])[i] = (i % MISC_WORDS) == (uint32_t)MISC_TAU ? __float_as_uint(min_units) : 0u;
 #pragma unroll
         for (uint32_t q = 0; q < (uint32_t)Q; ++q) {
 #pragma unroll
             for (uint32_t it = 0; it < XI; ++it) {
                 const uint32_t i = tid + it * blockDim.x;
-                if (i < SELL_XCOLS) x_slot(q, i) = (i < P0.cols && q < nq) ? (BYTES ? xr[q][it] * Q17_UNIT : xr[q][it]) : 0.0f;
+                // (12-bit column words keep the two padding slots INSIDE the 1024 columns: they are thread 0's to write, below)
+                if (i < SELL_XCOLS && i != PAD_NEUTRAL && i != PAD_ONE)
+                    x_slot(q, i) = (i < P0.cols && q < nq) ? (BYTES ? xr[q][it] * Q17_UNIT : xr[q][it]) : 0.0f;
             }
-            if (XI == 0u) {  // (one query per pass)
-                const float *xg = M.cur.io[q < nq ? q : 0u].x;
-                for (uint32_t i = tid; i < SELL_XCOLS; i += blockDim.x) {
-                    const float xw = xg[i < P0.cols ? i : 0u];
-                    x_slot(q, i) = (i < P0.cols && q < nq) ? (BYTES ? xw * Q17_UNIT : xw) : 0.0f;
-                }
-            }  // (else: the host launches this kernel with 512 or 576 threads -- 2 x blockDim covers the 1024 columns)
             if (tid == 0) {
                 x_slot(q, PAD_NEUTRAL) = -0.0f;
                 x_slot(q, PAD_ONE) = BYTES ? -__builtin_huge_valf() : 1.0f;  // byte chunks: a lane without a row starts with byte 1
             }
         }
-    }
-    __syncthreads();
-
+    };
+    // The server wave and the streaming waves run their OWN loops over the passes (the same two barriers per pass in both): in one
+    // loop with a branch inside, the server's registers were allocated across the streaming loop and the kernel spilled 40.
     if (is_server) {
-        // Threshold exchange of all nq queries at once: lane l serves (query l / 8, local group l % 8), so a round costs one
-        // store and one load round trip however many queries share the pass (query by query, a round took nq round trips
-        // and a threshold needed three rounds -- publish, reduce, fetch -- to reach a workgroup: most of the pass). Each
-        // reducer workgroup searches the k-th largest maximum of ONE query per round (~2.5 us).
-        const uint32_t q_l = lane >> 3, g_l = lane & 7u;
-        const bool q_ok = q_l < nq;
-        uint32_t *mp_l = L.misc[q_ok ? q_l : 0u];
-        const uint32_t grp = bid * P0.gpw + g_l;
-        const bool pub_lane = q_ok && g_l < P0.gpw && grp < P0.n_groups_pub;
-        uint32_t *gmax_l = M.A.gmax(set0 + (q_ok ? q_l : 0u));
-        uint32_t *tau_g_l = M.A.tau_g(set0 + (q_ok ? q_l : 0u));
-        const uint32_t rq = bid % nq;  // the query this workgroup reduces (if it is a reducer)
-        auto publish_all = [&]() __attribute__((always_inline)) {
-            if (pub_lane) {
-                const uint32_t key = lds_load(&mp_l[MISC_GRPMAX + g_l]);
-                if (key > mp_l[MISC_PUBLISHED + g_l]) {
-                    mp_l[MISC_PUBLISHED + g_l] = key;
-                    __hip_atomic_store(&gmax_l[grp], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // single writer per slot
+#pragma unroll 1
+        for (uint32_t pass = 0; pass < n_pass; ++pass) {
+            uint32_t tid = tid0;
+            asm volatile("" : "+v"(tid));  // (as in the streaming waves' loop below)
+            const uint32_t lane = tid & 63u;
+            const uint32_t setb = set0 + (Q == 1 ? pass : 0u);
+            commit(tid);
+            __syncthreads();
+            // Threshold exchange of all nq queries at once: lane l serves (query l / 8, local group l % 8), so a round costs one
+            // store and one load round trip however many queries share the pass (query by query, a round took nq round trips
+            // and a threshold needed three rounds -- publish, reduce, fetch -- to reach a workgroup: most of the pass). Each
+            // reducer workgroup searches the k-th largest maximum of ONE query per round (~2.5 us).
+            const uint32_t q_l = lane >> 3, g_l = lane & 7u;
+            const bool q_ok = q_l < nq;
+            uint32_t *mp_l = L.misc[q_ok ? q_l : 0u];
+            const uint32_t grp = bid * P0.gpw + g_l;
+            const bool pub_lane = q_ok && g_l < P0.gpw && grp < P0.n_groups_pub;
+            uint32_t *gmax_l = M.A.gmax(setb + (q_ok ? q_l : 0u));
+            uint32_t *tau_g_l = M.A.tau_g(setb + (q_ok ? q_l : 0u));
+            const uint32_t rq = bid % nq;  // the query this workgroup reduces (if it is a reducer)
+            auto publish_all = [&]() __attribute__((always_inline)) {
+                if (pub_lane) {
+                    const uint32_t key = lds_load(&mp_l[MISC_GRPMAX + g_l]);
+                    if (key > mp_l[MISC_PUBLISHED + g_l]) {
+                        mp_l[MISC_PUBLISHED + g_l] = key;
+                        __hip_atomic_store(&gmax_l[grp], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // single writer per slot
+                    }
                 }
+            };
+            for (;;) {
+                publish_all();
+                if (reducer) {
+                    StreamParams P = P0;
+                    P.gmax = M.A.gmax(setb + rq);
+                    TauRegs tr_;
+                    tau_issue(P, lane, tr_);
+                    const float t = tau_from_maxima(P, tr_, min_units);
+                    if (lane == 0 && t > min_units)
+                        __hip_atomic_fetch_max(M.A.tau_g(setb + rq), order_key(t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (q_ok && g_l == 0u) {
+                    const uint32_t kx = __hip_atomic_load(tau_g_l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const float t = kx ? key_to_float(kx) : min_units;
+                    const float cur_tau = __uint_as_float(lds_load(&mp_l[MISC_TAU]));
+                    if (t > cur_tau) __hip_atomic_store(&mp_l[MISC_TAU], __float_as_uint(t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                // every streaming wave counts itself out and none of them waits for this wave: the loop always ends
+                if (__builtin_amdgcn_readfirstlane(lds_load(&L.misc[0][MISC_DONE])) >= nwaves) break;
+                __builtin_amdgcn_s_sleep(8);
             }
-        };
-        for (;;) {
-            publish_all();
-            if (reducer) {
-                StreamParams P = P0;
-                P.gmax = M.A.gmax(set0 + rq);
-                TauRegs tr_;
-                tau_issue(P, lane, tr_);
-                const float t = tau_from_maxima(P, tr_, min_units);
-                if (lane == 0 && t > min_units)
-                    __hip_atomic_fetch_max(M.A.tau_g(set0 + rq), order_key(t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            publish_all();  // the workgroup's complete maxima (fire and forget)
+            if (pass + 1u < n_pass) {
+                request(pass + 1u, tid);  // (x only: the server has no partition)
+                __syncthreads();
             }
-            if (q_ok && g_l == 0u) {
-                const uint32_t kx = __hip_atomic_load(tau_g_l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const float t = kx ? key_to_float(kx) : min_units;
-                const float cur_tau = __uint_as_float(lds_load(&mp_l[MISC_TAU]));
-                if (t > cur_tau) __hip_atomic_store(&mp_l[MISC_TAU], __float_as_uint(t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-            // every streaming wave counts itself out and none of them waits for this wave: the loop always ends
-            if (__builtin_amdgcn_readfirstlane(lds_load(&L.misc[0][MISC_DONE])) >= nwaves) break;
-            __builtin_amdgcn_s_sleep(8);
         }
-        publish_all();  // the workgroup's complete maxima (fire and forget)
         return;
     }
+#pragma unroll 1
+    for (uint32_t pass = 0; pass < n_pass; ++pass) {
+    // (the thread's index is taken afresh in every pass: whatever depends on it is then computed inside the pass, where it is
+    //  needed, instead of ahead of the pass loop and kept in registers through the streaming loop -- measured: 40 spilled registers)
+    uint32_t tid = tid0;
+    asm volatile("" : "+v"(tid));
+    const uint32_t lane = tid & 63u;
+    const uint32_t setb = set0 + (Q == 1 ? pass : 0u);
+    const uint8_t *pk = M.cur.io[Q == 1 ? pass : 0u].packets + (size_t)p0 * P0.packet_bytes;
+    commit(tid);
+    __syncthreads();
 
     // ---- streaming waves ---------------------------------------------------------------------------------------
     float acc[Q];              // this lane's row of the current slice, one running sum per query
@@ -433,7 +460,7 @@ __global__ void __launch_bounds__(576, Q >= 8 ? 4 : 6) multi_kernel(const Stream
                         if ((uint32_t)q < nq) {
                             const float tau = __uint_as_float(lds_load(&L.misc[q][MISC_TAU]));
                             if (__any(acc[q] >= tau))
-                                offer_rows<MULTI_WAVE_CAP>(M.A, set0 + q, P0.ovf_cap, acc[q], (slice + n_done) * 64u, tau,
+                                offer_rows<MULTI_WAVE_CAP>(M.A, setb + q, P0.ovf_cap, acc[q], (slice + n_done) * 64u, tau,
                                                            lane, grp_local, publishes, L.u.w.cand[wave][q], wcnt[q], L.misc[q], P0.dbg);
                         }
                     }
@@ -444,6 +471,9 @@ __global__ void __launch_bounds__(576, Q >= 8 ? 4 : 6) multi_kernel(const Stream
             }
         }
     }
+    // (what follows runs once per pass: its lane-dependent addresses are computed here, not ahead of the streaming loop)
+    uint32_t lane_t = lane;
+    asm volatile("" : "+v"(lane_t));
     // The held slices. A short partition (small matrix) gets here before any threshold exists: give the exchange a moment,
     // bounded, and only where a threshold can form at all.
     if (np > 0u) {
@@ -459,15 +489,15 @@ __global__ void __launch_bounds__(576, Q >= 8 ? 4 : 6) multi_kernel(const Stream
                     if ((uint32_t)q < nq) {
                         const float tau = __uint_as_float(lds_load(&L.misc[q][MISC_TAU]));
                         if (__any(held[d][q] >= tau))
-                            offer_rows<MULTI_WAVE_CAP>(M.A, set0 + q, P0.ovf_cap, held[d][q], (slice + (uint32_t)d) * 64u, tau,
-                                                       lane, grp_local, publishes, L.u.w.cand[wave][q], wcnt[q], L.misc[q],
+                            offer_rows<MULTI_WAVE_CAP>(M.A, setb + q, P0.ovf_cap, held[d][q], (slice + (uint32_t)d) * 64u, tau,
+                                                       lane_t, grp_local, publishes, L.u.w.cand[wave][q], wcnt[q], L.misc[q],
                                                        P0.dbg ? P0.dbg + 4 : nullptr);
                     }
                 }
             }
         }
     }
-    if (lane == 0) atomicAdd(&L.misc[0][MISC_DONE], 1u);
+    if (lane_t == 0) atomicAdd(&L.misc[0][MISC_DONE], 1u);
 
     // ---- flush: what still clears the final threshold leaves the wave's lists (first survivor to the wave's slot,
     // further ones to the query's overflow list); complete at the end of the launch, selected by the next launch.
@@ -476,15 +506,15 @@ __global__ void __launch_bounds__(576, Q >= 8 ? 4 : 6) multi_kernel(const Stream
         if ((uint32_t)q < nq) {
             const float tau = __uint_as_float(lds_load(&L.misc[q][MISC_TAU]));
             ListScan<MULTI_WAVE_CAP / 64u> LS;
-            const uint32_t surv = scan_list<MULTI_WAVE_CAP / 64u>(L.u.w.cand[wave][q], wcnt[q], tau, lane, LS);
+            const uint32_t surv = scan_list<MULTI_WAVE_CAP / 64u>(L.u.w.cand[wave][q], wcnt[q], tau, lane_t, LS);
             if (surv != 0u) {
                 uint32_t gbase = 0u;
                 if (surv > 1u) {
-                    if (lane == 0) gbase = atomicAdd(M.A.ovf_count(set0 + q), surv - 1u);
+                    if (lane_t == 0) gbase = atomicAdd(M.A.ovf_count(setb + q), surv - 1u);
                     gbase = __builtin_amdgcn_readfirstlane(gbase);
                 }
-                unsigned long long *slot = M.A.wg_cand(set0 + q) + (size_t)bid * WG_SLOTS + wave;
-                unsigned long long *ovf = M.A.ovf_cand(set0 + q);
+                unsigned long long *slot = M.A.wg_cand(setb + q) + (size_t)bid * WG_SLOTS + wave;
+                unsigned long long *ovf = M.A.ovf_cand(setb + q);
 #pragma unroll
                 for (uint32_t e = 0; e < MULTI_WAVE_CAP / 64u; ++e) {
                     if (LS.keep[e]) {
@@ -496,6 +526,11 @@ __global__ void __launch_bounds__(576, Q >= 8 ? 4 : 6) multi_kernel(const Stream
             }
         }
     }
+    if (pass + 1u < n_pass) {
+        request(pass + 1u, tid);
+        __syncthreads();  // every wave is through with this pass's x, lists and words
+    }
+    }  // (passes)
 }
 
 }  // namespace tkspmv

@@ -719,6 +719,54 @@ def test_multi_query_passes_are_bit_identical_to_the_gold_order(pkg, oracle, mq,
     eng.close()
 
 
+@pytest.mark.parametrize("precision", ["F32", "Q1_7_F32"])
+@pytest.mark.parametrize("rows,passes", [(3000, None), (120000, None), (120000, "3"), (120000, "1"), (600000, None)])
+def test_one_query_per_pass_launches_make_several_passes(pkg, oracle, precision, rows, passes):
+    """multi_q = 1 (BASELINE configs[4]'s path): one launch of the row-per-lane kernel makes up to MULTI_PASSES passes, one query
+    each, every pass with its own exchange-state set, x and result buffers; 37 queries = five launches on two chains, the
+    last one partial. Every query's list equals the exact selection over the gold-order scores, bit for bit, whatever
+    the number of passes per launch; a 3000-row matrix leaves most waves without a partition (they still meet the
+    barriers of every pass)."""
+    import torch
+    nq, k, cols = 37, 50, 512
+    m = pkg.generate_matrix(rows, cols, 40, "gamma", 91)
+    vals = oracle.round_to_q17(m.val) if precision == "Q1_7_F32" else m.val
+    xs = np.stack([pkg.create_sample_vector(cols, True, False, True, 4100 + i) for i in range(nq)])
+    xs[5] *= np.float32(0.01)
+    xs[6] = -xs[6]
+    dxs = torch.from_numpy(xs).cuda()
+    if passes is not None:
+        pkg.set_option("MULTI_PASSES", passes)
+    try:
+        eng = pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, k=k, device=0, stream_replicas=3, multi_q=1,
+                       precision=getattr(pkg, precision), min_score=-100.0)
+    finally:
+        if passes is not None:
+            pkg.set_option("MULTI_PASSES", None)
+    assert eng.info()["multi_q"] == 1
+    want = []
+    for q in range(nq):
+        y, present = oracle.scores_f32_segmented(m.row, m.col, vals, xs[q], m.rows)
+        want.append(oracle.select_topk(y, present, k, min_score=-100.0))
+    out_i = torch.full((nq, k), -1, dtype=torch.int32, device="cuda")
+    out_v = torch.full((nq, k), -1.0, dtype=torch.float32, device="cuda")
+    for n in (nq, 8, 9, 1, 17):
+        out_i.fill_(-1)
+        out_v.fill_(-1.0)
+        eng.enqueue_multi(dxs.data_ptr(), n, out_i.data_ptr(), out_v.data_ptr())
+        eng.synchronize()
+        for q in range(n):
+            ei, ev = want[q]
+            assert np.array_equal(out_i[q].cpu().numpy().view(np.uint32), ei), (n, q)
+            assert np.array_equal(out_v[q].cpu().numpy().view(np.uint32), ev.view(np.uint32)), (n, q)
+        assert int((out_i[n:] != -1).sum()) == 0
+    eng.time_multi(dxs.data_ptr(), nq, 100)  # (the timing entry point: engine-owned result buffers, two launches in flight)
+    eng.enqueue_multi(dxs.data_ptr(), 11)  # the engine-owned pair: the last query wins
+    val, idx = eng.read_result()
+    assert np.array_equal(idx, want[10][0]) and np.array_equal(val.view(np.uint32), want[10][1].view(np.uint32))
+    eng.close()
+
+
 def test_multi_query_scores_are_the_reference_golds(pkg, oracle):
     """Against the gold itself (spmv_coo_gold_top_k + sort_tuples restated; the reference's own when oracle/_ref is
     present): same rows in the same order; score BITS equal for every row of at most 64 entries (longer rows are summed
