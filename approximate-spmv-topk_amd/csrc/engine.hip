@@ -338,12 +338,11 @@ struct EngineImpl {
         for (int q = 0; q < n; ++q) {  // (one copy of the stream per PASS: the queries of a pass share it)
             BatchIO &Q = M.cur.io[q];
             Q.x = xs[q];
-            Q.packets = d_sell_replicas.empty() ? d_sell_packets : d_sell_replicas[launch_counter % d_sell_replicas.size()];
+            Q.packets = d_sell_replicas.empty() ? d_sell_packets : d_sell_replicas[(launch_counter + (uint64_t)(q / multi_q)) % d_sell_replicas.size()];
             Q.out_idx = out_idx[q];
             Q.out_val = out_val[q];
-            if (multi_q == 1) ++launch_counter;
         }
-        if (multi_q != 1) ++launch_counter;
+        launch_counter += (uint64_t)((n + multi_q - 1) / multi_q);
         SelectParams S = select_params(nullptr, nullptr, 0);
         S.pos_to_row = d_sell_rows;
         const dim3 mblock(multi_stream_waves * 64u + 64u);
@@ -1125,12 +1124,13 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
         // wait and then poured its rows into the overflow list, 2 ms per query. Such engines run 4 queries per pass.
         if (mq == 8 && (uint32_t)d.k * 4u > m.n_groups_pub) mq = 4;
         m.multi_q = mq;
-        // One query per pass: a launch makes up to MULTI_PASSES passes (default 8), each with its own query and exchange-state set
+        // One or two queries per pass: a launch makes several passes (MULTI_PASSES; default: as many as the MULTI_Q_MAX queries of
+        // a group allow -- 8 or 4), each pass with its own queries and exchange-state sets. (4 and 8 per pass: one pass per launch.)
         m.multi_group = mq;
-        if (mq == 1) {
-            int passes = MULTI_Q_MAX;
-            if (const char *f = opt("MULTI_PASSES")) passes = std::min(std::max(atoi(f), 1), (int)MULTI_Q_MAX);
-            m.multi_group = passes;
+        if (mq == 1 || mq == 2) {
+            int passes = MULTI_Q_MAX / mq;
+            if (const char *f = opt("MULTI_PASSES")) passes = std::min(std::max(atoi(f), 1), passes);
+            m.multi_group = passes * mq;
         }
         // 8 queries per pass need 91 registers: with 9 waves per workgroup only one workgroup fits a CU (the dispatcher wants
         // 6 waves on one SIMD for two); with 8 waves -- 7 streaming + the server -- two fit at up to 128 registers.

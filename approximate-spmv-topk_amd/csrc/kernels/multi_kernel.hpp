@@ -166,7 +166,6 @@ __global__ void __launch_bounds__(576, Q >= 8 ? 4 : 6) multi_kernel(const Stream
     const uint32_t bid = blockIdx.x - M.n_sel, n_wg = gridDim.x - M.n_sel;
     const uint32_t nwaves = (blockDim.x >> 6) - 1u;  // streaming waves
     const bool is_server = (wave == nwaves);
-    const uint32_t nq = M.cur.n_q < (uint32_t)Q ? M.cur.n_q : (uint32_t)Q;
     const uint32_t set0 = M.cur.set0;
     const uint32_t grp_local = is_server ? 0u : wave * P0.gpw / nwaves;
     const bool publishes = (bid * P0.gpw + grp_local) < P0.n_groups_pub;
@@ -188,11 +187,17 @@ __global__ void __launch_bounds__(576, Q >= 8 ? 4 : 6) multi_kernel(const Stream
             slice = M.part_slice0[part];
         }
     }
-    // One query per pass (Q == 1): the launch makes M.cur.n_q PASSES, one query each, with exchange-state set set0 + pass and
-    // M.cur.io[pass] (round 4: BASELINE configs[4] -- the launch's ramp, its partition lookup and its tail are paid once per
-    // n_q queries; the next pass's first chunks and its x are requested before the barrier that ends the current one).
-    // Q >= 2: one pass, queries set0 .. set0 + n_q - 1 share it.
-    const uint32_t n_pass = Q == 1 ? M.cur.n_q : 1u;
+    // A launch makes ceil(M.cur.n_q / Q) PASSES over the matrix, Q queries each (the last one maybe fewer): pass p serves queries
+    // p Q .. p Q + Q - 1 of the group, exchange-state sets set0 + p Q + q, M.cur.io[p Q + q] (round 4, for BASELINE configs[4] at one
+    // query per pass: the launch's ramp, its partition lookup and its tail are paid once per eight queries; the next pass's first
+    // chunks and its x are requested before the barrier that ends the current one).
+    // (4 and 8 queries per pass: ONE pass per launch, known at compile time -- their register budgets have no room for a loop
+    //  around the pass: 16 and 57 spilled registers when tried)
+    const uint32_t n_pass = Q >= 4 ? 1u : (M.cur.n_q + (uint32_t)Q - 1u) / (uint32_t)Q;
+    auto nq_of = [&](uint32_t pass) __attribute__((always_inline)) -> uint32_t {
+        const uint32_t left = M.cur.n_q - pass * (uint32_t)Q;
+        return left < (uint32_t)Q ? left : (uint32_t)Q;
+    };
     Pkt<C, VT> buf[NBUF];
     constexpr bool IL = Q >= 8;  // interleaved x: measured faster for 8 queries (5.99 against 7.09 us per query), slower for 4 (9.43 against 7.59)
     auto x_slot = [&](uint32_t q, uint32_t col) __attribute__((always_inline)) -> float & {
@@ -206,8 +211,8 @@ __global__ void __launch_bounds__(576, Q >= 8 ? 4 : 6) multi_kernel(const Stream
     constexpr uint32_t XI = 2u;
     float xr[Q][XI];
     auto request = [&](uint32_t pass, uint32_t tid) __attribute__((always_inline)) {  // the pass's first chunks, then its x
-        const uint32_t lane = tid & 63u;
-        const uint8_t *pkp = M.cur.io[Q == 1 ? pass : 0u].packets + (size_t)p0 * P0.packet_bytes;
+        const uint32_t lane = tid & 63u, nq = nq_of(pass);
+        const uint8_t *pkp = M.cur.io[pass * (uint32_t)Q].packets + (size_t)p0 * P0.packet_bytes;
 #pragma unroll
         for (int u = 0; u < NBUF - 1; ++u) {
             if (np > 0u) {
@@ -217,7 +222,7 @@ __global__ void __launch_bounds__(576, Q >= 8 ? 4 : 6) multi_kernel(const Stream
         }
 #pragma unroll
         for (uint32_t q = 0; q < (uint32_t)Q; ++q) {
-            const float *xg = M.cur.io[Q == 1 ? pass : (q < nq ? q : 0u)].x;
+            const float *xg = M.cur.io[pass * (uint32_t)Q + (q < nq ? q : 0u)].x;
 #pragma unroll
             for (uint32_t it = 0; it < XI; ++it) {
                 const uint32_t i = tid + it * blockDim.x;
@@ -227,7 +232,7 @@ __global__ void __launch_bounds__(576, Q >= 8 ? 4 : 6) multi_kernel(const Stream
     };
     request(0u, tid0);
     // The head of a pass: the workgroup's words, then x from the registers request() filled.
-    auto commit = [&](uint32_t tid) __attribute__((always_inline)) {
+    auto commit = [&](uint32_t tid, uint32_t nq) __attribute__((always_inline)) {
         for (uint32_t i = tid; i < (uint32_t)Q * MISC_WORDS; i += blockDim.x)
             (&L.misc[0][0])[i] = (i % MISC_WORDS) == (uint32_t)MISC_TAU ? __float_as_uint(min_units) : 0u;
 #pragma unroll
@@ -253,8 +258,8 @@ __global__ void __launch_bounds__(576, Q >= 8 ? 4 : 6) multi_kernel(const Stream
             uint32_t tid = tid0;
             asm volatile("" : "+v"(tid));  // (as in the streaming waves' loop below)
             const uint32_t lane = tid & 63u;
-            const uint32_t setb = set0 + (Q == 1 ? pass : 0u);
-            commit(tid);
+            const uint32_t setb = set0 + pass * (uint32_t)Q, nq = nq_of(pass);
+            commit(tid, nq);
             __syncthreads();
             // Threshold exchange of all nq queries at once: lane l serves (query l / 8, local group l % 8), so a round costs one
             // store and one load round trip however many queries share the pass (query by query, a round took nq round trips
@@ -313,9 +318,9 @@ __global__ void __launch_bounds__(576, Q >= 8 ? 4 : 6) multi_kernel(const Stream
     uint32_t tid = tid0;
     asm volatile("" : "+v"(tid));
     const uint32_t lane = tid & 63u;
-    const uint32_t setb = set0 + (Q == 1 ? pass : 0u);
-    const uint8_t *pk = M.cur.io[Q == 1 ? pass : 0u].packets + (size_t)p0 * P0.packet_bytes;
-    commit(tid);
+    const uint32_t setb = set0 + pass * (uint32_t)Q, nq = nq_of(pass);
+    const uint8_t *pk = M.cur.io[pass * (uint32_t)Q].packets + (size_t)p0 * P0.packet_bytes;
+    commit(tid, nq);
     __syncthreads();
 
     // ---- streaming waves ---------------------------------------------------------------------------------------

@@ -26,7 +26,7 @@ static const OptionDef k_options[] = {
     {"RADIX", "behaviour", "0 | 1 (default: k above 3/8 of the publishing groups)", "1: scores + radix select instead of thresholded streaming"},
     {"MULTI_Q", "behaviour", "0 | 1 | 3 | 5 | 8 (default by size; desc.multi_q wins)", "queries per pass of the small-matrix kernel (multi_kernel); 0 = off"},
     {"MULTI_CHAINS", "tuning", "1 | 2 (default 2)", "independent launch chains tkspmv_enqueue_multi alternates between"},
-    {"MULTI_PASSES", "tuning", "1..8 (default 8)", "passes (one query each) a launch of the one-query-per-pass row-per-lane kernel makes"},
+    {"MULTI_PASSES", "tuning", "1..8 (default 8)", "passes a launch of the row-per-lane kernel makes at one or two queries per pass (8 / 4 by default)"},
     {"SMALL_PACKETS", "tuning", "packets (default LOCAL_MATRIX_PACKETS)", "size up to which a matrix gets the small-matrix settings (4 selectors, 1-2 packet partitions, local thresholds); 0 = round 2's behaviour"},
     {"MIN_PACKETS", "tuning", ">= 1", "minimum packets per wave partition"},
     {"PARTITIONS_HINT", "diagnostic", "count", "wave partitions to pack (read probe experiments; an engine whose partitions exceed its streaming waves does not batch)"},
