@@ -25,6 +25,8 @@ namespace tkspmv {
 // CU (the host packs the stream for that many partitions).
 // ------------------------------------------------------------------------------------------------------------
 constexpr int MULTI_Q_MAX = 8;
+constexpr int MISC_NEED = 28;  // multi-query kernel: a streaming wave of the workgroup has been waiting for a threshold for NEED_AFTER
+constexpr unsigned long long NEED_AFTER = 500;  // x 10 ns
 #ifndef TKSPMV_SELL_BYTE_NBUF
 #define TKSPMV_SELL_BYTE_NBUF 5
 #endif
@@ -169,7 +171,11 @@ __global__ void __launch_bounds__(576, Q >= 8 ? 4 : 6) multi_kernel(const Stream
     const uint32_t set0 = M.cur.set0;
     const uint32_t grp_local = is_server ? 0u : wave * P0.gpw / nwaves;
     const bool publishes = (bid * P0.gpw + grp_local) < P0.n_groups_pub;
-    const bool reducer = bid < P0.n_reducers;
+    // Reducers: the first workgroups of the grid; with several passes per launch four spread over the dispatch order instead (passes
+    // are not synchronised across workgroups, and a pass needs a reducer that is IN it; the first eight alone left whole runs
+    // without thresholds on most boxes, 50 or 150 us per query; 8, 16 or 56 spread reducers: 19.4 / 19.6 / 21.0 against 19.3 us; the
+    // first eight AND four spread ones: 19.5 against 19.2).
+    const bool reducer = Q <= 2 ? (bid % ((n_wg >> 2) + 1u) == 0u) : (bid < P0.n_reducers);
     const float min_units = P0.min_score;  // fp32 values only: one score unit is 1.0
     // Every server wave outranks the streaming waves here: with several queries per chunk those hardly ever wait for
     // memory, and a server at a lower priority does not get to publish its workgroup's maxima (or to fetch the threshold)
@@ -273,6 +279,7 @@ __global__ void __launch_bounds__(576, Q >= 8 ? 4 : 6) multi_kernel(const Stream
             uint32_t *gmax_l = M.A.gmax(setb + (q_ok ? q_l : 0u));
             uint32_t *tau_g_l = M.A.tau_g(setb + (q_ok ? q_l : 0u));
             const uint32_t rq = bid % nq;  // the query this workgroup reduces (if it is a reducer)
+            uint32_t *misc0 = L.misc[0];
             auto publish_all = [&]() __attribute__((always_inline)) {
                 if (pub_lane) {
                     const uint32_t key = lds_load(&mp_l[MISC_GRPMAX + g_l]);
@@ -282,16 +289,33 @@ __global__ void __launch_bounds__(576, Q >= 8 ? 4 : 6) multi_kernel(const Stream
                     }
                 }
             };
+            // Passes are not synchronised across workgroups: the reducers may be a pass ahead of this workgroup or behind it, and then
+            // nobody searches a threshold for ITS pass while it runs (measured with the first eight workgroups as the reducers:
+            // whole runs at 50 or 150 us per query -- every wave ran into its bounded wait at the end of the pass and then judged
+            // its rows without a threshold, a million candidates per query for the selection). The reducers are spread over the
+            // grid, and as the net under that a workgroup one of whose waves has WAITED 5 us for a threshold (MISC_NEED) searches
+            // it itself, from whatever maxima have been published for the pass: valid as any other, and shared through tau_g.
+            // (Not earlier: a pass holds all its slices back, so a threshold is needed at its end only -- every workgroup searching
+            // one after five rounds cost 9 us per query, at the first wait 3 us.)
             for (;;) {
                 publish_all();
-                if (reducer) {
+                uint32_t rq_now = rq;
+                bool reduce_now = reducer;
+                if (Q <= 2 && !reducer && P0.tau_possible && lds_load(&misc0[MISC_NEED]) != 0u) {  // (4 and 8 per pass: one pass per launch)
+                    const uint64_t lack = __ballot(q_ok && g_l == 0u && lds_load(&mp_l[MISC_TAU]) == __float_as_uint(min_units));
+                    if (lack != 0ull) {
+                        reduce_now = true;
+                        rq_now = (uint32_t)__builtin_ctzll(lack) >> 3;  // (lane 8 q asks for query q)
+                    }
+                }
+                if (reduce_now) {
                     StreamParams P = P0;
-                    P.gmax = M.A.gmax(setb + rq);
+                    P.gmax = M.A.gmax(setb + rq_now);
                     TauRegs tr_;
                     tau_issue(P, lane, tr_);
                     const float t = tau_from_maxima(P, tr_, min_units);
                     if (lane == 0 && t > min_units)
-                        __hip_atomic_fetch_max(M.A.tau_g(setb + rq), order_key(t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_fetch_max(M.A.tau_g(setb + rq_now), order_key(t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 if (q_ok && g_l == 0u) {
                     const uint32_t kx = __hip_atomic_load(tau_g_l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -453,7 +477,11 @@ __global__ void __launch_bounds__(576, Q >= 8 ? 4 : 6) multi_kernel(const Stream
                     // on the exchange.
                     if (P0.tau_possible && !gave_up && no_tau()) {
                         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-                        while (no_tau() && __builtin_amdgcn_s_memrealtime() - t0 < FLUSH_TAU_WAIT) __builtin_amdgcn_s_sleep(8);
+                        while (no_tau() && __builtin_amdgcn_s_memrealtime() - t0 < FLUSH_TAU_WAIT) {
+                            if (Q <= 2 && lane == 0 && __builtin_amdgcn_s_memrealtime() - t0 > NEED_AFTER)
+                                __hip_atomic_store(&L.misc[0][MISC_NEED], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            __builtin_amdgcn_s_sleep(8);
+                        }
                         gave_up = no_tau();  // one bounded wait per pass: a threshold that cannot form must not cost one per slice
                         if (P0.dbg && lane == 0) {
                             atomicAdd(&P0.dbg[8], 1ull);
@@ -484,7 +512,11 @@ __global__ void __launch_bounds__(576, Q >= 8 ? 4 : 6) multi_kernel(const Stream
     if (np > 0u) {
         if (P0.tau_possible && !gave_up) {
             const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-            while (no_tau() && __builtin_amdgcn_s_memrealtime() - t0 < FLUSH_TAU_WAIT) __builtin_amdgcn_s_sleep(4);
+            while (no_tau() && __builtin_amdgcn_s_memrealtime() - t0 < FLUSH_TAU_WAIT) {
+                if (Q <= 2 && lane_t == 0 && __builtin_amdgcn_s_memrealtime() - t0 > NEED_AFTER)
+                    __hip_atomic_store(&L.misc[0][MISC_NEED], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __builtin_amdgcn_s_sleep(4);
+            }
         }
 #pragma unroll
         for (int d = 0; d < DEFER_S; ++d) {

@@ -214,7 +214,9 @@ int tkspmv_enqueue_batch(tkspmv_t *e, const float *dev_xs, int32_t count, uint32
  * gold (gold_algorithms.hpp:188-246): scores are bit-identical to the gold's sequential fp32 sums (tkspmv_run's differ
  * from those in the last bits: its sums follow the packet layout). Engines without the kernel (info.multi_q == 0:
  * desc.multi_q = 0, reduced precisions, more than 1024 columns, fewer publishing groups than k) run the ordinary
- * back-to-back sequence. dev_xs = NULL with count = 1: the vector installed by tkspmv_set_query. */
+ * back-to-back sequence. dev_xs = NULL with count = 1: the vector installed by tkspmv_set_query.
+ * At multi_q = 1 or 2 a launch makes several passes (8 / 4; option MULTI_PASSES), each over its own queries: invisible to the
+ * caller, results and their order are the same. */
 int tkspmv_enqueue_multi(tkspmv_t *e, const float *dev_xs, int32_t count, uint32_t *dev_idx, float *dev_val, void *stream);
 /* tkspmv_time_queries for the multi-query path: *ns_per_query = time of the whole sequence / iters. */
 int tkspmv_time_multi(tkspmv_t *e, const float *dev_xs, int32_t n_x, int32_t iters, double *ns_per_query);
