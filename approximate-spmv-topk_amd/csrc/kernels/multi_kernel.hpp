@@ -26,7 +26,7 @@ namespace tkspmv {
 // ------------------------------------------------------------------------------------------------------------
 constexpr int MULTI_Q_MAX = 8;
 constexpr int MISC_NEED = 28;  // multi-query kernel: a streaming wave of the workgroup has been waiting for a threshold for NEED_AFTER
-constexpr unsigned long long NEED_AFTER = 500;  // x 10 ns
+constexpr unsigned long long NEED_AFTER = 1000;  // x 10 ns
 #ifndef TKSPMV_SELL_BYTE_NBUF
 #define TKSPMV_SELL_BYTE_NBUF 5
 #endif
@@ -171,11 +171,7 @@ __global__ void __launch_bounds__(576, Q >= 8 ? 4 : 6) multi_kernel(const Stream
     const uint32_t set0 = M.cur.set0;
     const uint32_t grp_local = is_server ? 0u : wave * P0.gpw / nwaves;
     const bool publishes = (bid * P0.gpw + grp_local) < P0.n_groups_pub;
-    // Reducers: the first workgroups of the grid; with several passes per launch four spread over the dispatch order instead (passes
-    // are not synchronised across workgroups, and a pass needs a reducer that is IN it; the first eight alone left whole runs
-    // without thresholds on most boxes, 50 or 150 us per query; 8, 16 or 56 spread reducers: 19.4 / 19.6 / 21.0 against 19.3 us; the
-    // first eight AND four spread ones: 19.5 against 19.2).
-    const bool reducer = Q <= 2 ? (bid % ((n_wg >> 2) + 1u) == 0u) : (bid < P0.n_reducers);
+    const bool reducer = bid < P0.n_reducers;
     const float min_units = P0.min_score;  // fp32 values only: one score unit is 1.0
     // Every server wave outranks the streaming waves here: with several queries per chunk those hardly ever wait for
     // memory, and a server at a lower priority does not get to publish its workgroup's maxima (or to fetch the threshold)
@@ -289,14 +285,17 @@ __global__ void __launch_bounds__(576, Q >= 8 ? 4 : 6) multi_kernel(const Stream
                     }
                 }
             };
-            // Passes are not synchronised across workgroups: the reducers may be a pass ahead of this workgroup or behind it, and then
-            // nobody searches a threshold for ITS pass while it runs (measured with the first eight workgroups as the reducers:
-            // whole runs at 50 or 150 us per query -- every wave ran into its bounded wait at the end of the pass and then judged
-            // its rows without a threshold, a million candidates per query for the selection). The reducers are spread over the
-            // grid, and as the net under that a workgroup one of whose waves has WAITED 5 us for a threshold (MISC_NEED) searches
-            // it itself, from whatever maxima have been published for the pass: valid as any other, and shared through tau_g.
-            // (Not earlier: a pass holds all its slices back, so a threshold is needed at its end only -- every workgroup searching
-            // one after five rounds cost 9 us per query, at the first wait 3 us.)
+            // Passes are not synchronised across workgroups. The reducers are the first workgroups dispatched, the leaders of the
+            // launch; a workgroup behind them enters a pass after they have left it and finds the threshold of their LAST search
+            // there -- none at all if fewer than k groups had published by then (measured: whole runs at 50 or 150 us per query on
+            // most boxes; every wave ran into its bounded wait at the end of the pass and then judged its rows without a threshold,
+            // a million candidates per query for the selection). Two remedies, both below: a reducer keeps searching for the passes
+            // it has left; and, as the net under that, a workgroup one of whose waves has WAITED 10 us for a threshold (MISC_NEED)
+            // searches it itself from whatever has been published for the pass -- valid as any other, and shared through tau_g.
+            // Tried instead: reducers spread over the dispatch order (4, 8, 16, 56 of them: 19.3 / 19.4 / 19.6 / 21.0 us per query
+            // where this scheme runs 18.5-18.9 -- a reducer's workgroup streams more slowly, and only the leaders can afford that);
+            // every workgroup searching after five rounds (+9 us), or as soon as a wave waits (+3 us).
+            uint32_t rounds = 0u;
             for (;;) {
                 publish_all();
                 uint32_t rq_now = rq;
@@ -317,6 +316,21 @@ __global__ void __launch_bounds__(576, Q >= 8 ? 4 : 6) multi_kernel(const Stream
                     if (lane == 0 && t > min_units)
                         __hip_atomic_fetch_max(M.A.tau_g(setb + rq_now), order_key(t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
+                // The reducers are the first workgroups dispatched, the leaders of the launch: the workgroups behind them enter a
+                // pass after the reducers have left it, and find the threshold of the reducers' LAST search there -- none at all if
+                // fewer than k groups had published by then. So a reducer keeps searching for the passes it has left, one of them
+                // per round in turn (the maxima published since are in gmax): every set of the launch is revisited until it ends.
+                if (Q <= 2 && reducer && pass != 0u) {  // (every round: on alternate rounds only, 18.9-19.1 against 18.5-18.9 us per query)
+                    const uint32_t older = set0 + (rounds % pass) * (uint32_t)Q + rq % (uint32_t)Q;
+                    StreamParams P = P0;
+                    P.gmax = M.A.gmax(older);
+                    TauRegs tr_;
+                    tau_issue(P, lane, tr_);
+                    const float t = tau_from_maxima(P, tr_, min_units);
+                    if (lane == 0 && t > min_units)
+                        __hip_atomic_fetch_max(M.A.tau_g(older), order_key(t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                ++rounds;
                 if (q_ok && g_l == 0u) {
                     const uint32_t kx = __hip_atomic_load(tau_g_l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     const float t = kx ? key_to_float(kx) : min_units;
