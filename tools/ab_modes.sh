@@ -1,5 +1,7 @@
 #!/bin/bash
 # exact mode (device-wide exchange) at 1M rows: selector workgroups 1 / 4, this build against round 3's, same box
+# (needs the other tree next to this one: git worktree add -f _ab/r3 <round 3's last commit> && make -C _ab/r3; _ab/ is git-ignored
+#  and travels to the GPU box with the snapshot; git worktree remove --force _ab/r3 afterwards)
 set -u
 OUT=gpurun_out/exact; mkdir -p $OUT
 cat > /tmp/exact.py <<'PY'
