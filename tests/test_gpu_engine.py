@@ -767,6 +767,22 @@ def test_one_query_per_pass_launches_make_several_passes(pkg, oracle, precision,
     eng.close()
 
 
+def test_passes_that_drift_apart_still_find_their_thresholds(pkg):
+    """BASELINE configs[4]'s shape. The passes of a launch are not synchronised across workgroups: with the first workgroups
+    as the only reducers and no second look at the passes they had left, a third of all timed runs went at 50 or 150 us per
+    query instead of 18-19 (no threshold for most workgroups: bounded waits, then a million candidates per query). Twelve
+    runs must stay within 1.6 x their median."""
+    import torch
+    m = pkg.generate_matrix(1000000, 512, 40, "gamma", 5)
+    xs = np.stack([pkg.create_sample_vector(512, True, False, True, 1000 + i) for i in range(16)])
+    dxs = torch.from_numpy(xs).cuda()
+    eng = pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, k=100, device=0, precision=pkg.Q1_7_F32, multi_q=1, stream_replicas=4)
+    eng.time_multi(dxs.data_ptr(), 16, 512)
+    runs = sorted(eng.time_multi(dxs.data_ptr(), 16, 512) / 1e3 for _ in range(12))
+    eng.close()
+    assert runs[-1] <= 1.6 * runs[6], runs
+
+
 def test_multi_query_scores_are_the_reference_golds(pkg, oracle):
     """Against the gold itself (spmv_coo_gold_top_k + sort_tuples restated; the reference's own when oracle/_ref is
     present): same rows in the same order; score BITS equal for every row of at most 64 entries (longer rows are summed
