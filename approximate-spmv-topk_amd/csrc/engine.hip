@@ -51,6 +51,15 @@ __global__ void __launch_bounds__(576) null_kernel(const uint32_t *p) {
     if (p == nullptr && threadIdx.x == 123456u) __builtin_trap();
 }
 
+// What a KERNEL sees of words the CPU stored into device memory through the PCIe BAR (tkspmv_create's check of the BAR path of
+// tkspmv_set_query): plain loads, through the same caches a streaming kernel's loads of x go through.
+__global__ void bar_check_kernel(const uint32_t *x, uint32_t last, uint32_t *out) {
+    if (threadIdx.x == 0) {
+        out[0] = x[0];
+        out[1] = x[last];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // Host side
 // ------------------------------------------------------------------------------------------------------------
@@ -91,6 +100,15 @@ struct EngineImpl {
     // through the PCIe aperture -- 0.5 us for 4 KiB, no copy kernel ahead of the query's launch (that copy, 3-10 us of device time
     // plus a dispatch, stood between set_query and every tkspmv_run). Posted writes stay ordered with the launch's doorbell.
     bool bar_x = false;
+    // CPU stores through the BAR pass the host data path (HDP) on their way to memory: the documented protocol ends them with a
+    // write to the device's HDP_MEM_COHERENCY_FLUSH_CNTL register and a read back of it (what ROCclr does behind its own large-BAR
+    // copies); the register's address comes from hipDeviceAttributeHdpMemFlushCntl. No address, no BAR path.
+    volatile uint32_t *hdp_flush = nullptr;
+    void flush_hdp() const {
+        __builtin_ia32_sfence();
+        *hdp_flush = 1u;
+        (void)*hdp_flush;  // (the read completes only behind the posted writes before it)
+    }
     int host_path = 1;                  // TKSPMV_HOST_PATH=0: the plain path (stream synchronisation + copies)
     // Resident kernel (desc.impl = TKSPMV_IMPL_RESIDENT; batch_kernel<.., RESIDENT = true>): one launch that stays on the
     // GPU and serves tkspmv_run queries as the host submits them through pinned memory -- see BatchParams.
@@ -671,7 +689,11 @@ struct EngineImpl {
     bool result_block_complete(uint32_t epoch) const {
         const size_t k = (size_t)desc.k;
         const volatile uint32_t *r = h_res;
-        uint32_t sum = epoch * 0x9E3779B1u + (r[2 * k + 5] != 0u ? 0xBADC0DE5u : 0u);  // (word 2k + 5: the status of single_kernel's check)
+        // (word 2k + 5: the status of single_kernel's check. A FAILED check writes no payload -- the block still holds the previous
+        //  query's list -- and its checksum covers the epoch and the status alone: summing the stale payload here never matched,
+        //  and every failed check cost tkspmv_run its 2 s flag timeout before the repair)
+        if (r[2 * k + 5] != 0u) return r[2 * k + 4] == epoch * 0x9E3779B1u + 0xBADC0DE5u;
+        uint32_t sum = epoch * 0x9E3779B1u;
         for (size_t i = 0; i < k; ++i) sum += result_checksum_term(r[i], r[k + i], (uint32_t)i);
         return r[2 * k + 4] == sum;
     }
@@ -1045,16 +1067,34 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
         bool want = large_bar != 0 && m.host_path != 0;
         if (const char *f = opt("BAR_X")) want = want && atoi(f) != 0;
         if (want) {
+            uint32_t *reg = nullptr;  // (the attribute is returned through the int pointer as an address)
+            if (hipDeviceGetAttribute(reinterpret_cast<int *>(&reg), hipDeviceAttributeHdpMemFlushCntl, dev) != hipSuccess) reg = nullptr;
+            (void)hipGetLastError();
+            m.hdp_flush = reg;
+            want = reg != nullptr;
+        }
+        if (want) {
+            // Four rounds with changing values: the CPU stores two words and flushes the HDP, a KERNEL loads them (a copy engine
+            // reading them back proves nothing about what a kernel's loads see behind its caches) -- after a kernel of an
+            // earlier round has had the old values in its caches.
+            uint32_t *d_back = nullptr;
+            HIP_TRY(hipMalloc((void **)&d_back, 8));
             HIP_TRY(hipMemset(m.d_x, 0, (size_t)d.cols * 4));
             HIP_TRY(hipDeviceSynchronize());
             volatile uint32_t *px = reinterpret_cast<volatile uint32_t *>(m.d_x);
-            px[0] = 0x5A17C0DEu;
-            px[d.cols - 1] = 0xC0DE5A17u ^ d.cols;
-            __builtin_ia32_sfence();
-            uint32_t back[2] = {0, 0};
-            HIP_TRY(hipMemcpy(&back[0], m.d_x, 4, hipMemcpyDeviceToHost));
-            HIP_TRY(hipMemcpy(&back[1], m.d_x + (d.cols - 1), 4, hipMemcpyDeviceToHost));
-            m.bar_x = back[0] == 0x5A17C0DEu && (d.cols == 1 || back[1] == (0xC0DE5A17u ^ d.cols));
+            bool ok = true;
+            for (uint32_t round = 0; round < 4u && ok; ++round) {
+                const uint32_t a = 0x5A17C0DEu + 0x01010101u * round, b = (0xC0DE5A17u ^ d.cols) + 0x00010001u * round;
+                px[0] = a;
+                px[d.cols - 1] = b;
+                m.flush_hdp();
+                hipLaunchKernelGGL(bar_check_kernel, dim3(1), dim3(64), 0, nullptr, reinterpret_cast<const uint32_t *>(m.d_x), d.cols - 1u, d_back);
+                uint32_t back[2] = {0, 0};
+                HIP_TRY(hipMemcpy(back, d_back, 8, hipMemcpyDeviceToHost));
+                ok = back[0] == (d.cols == 1 ? b : a) && back[1] == b;
+            }
+            m.bar_x = ok;
+            (void)hipFree(d_back);
             HIP_TRY(hipMemset(m.d_x, 0, (size_t)d.cols * 4));
             HIP_TRY(hipDeviceSynchronize());
         }
@@ -1143,7 +1183,11 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
         m.can_multi = mq > 0 && !m.use_radix && m.can_defer && m.n_sets != 0u && d.cols <= SELL_XCOLS &&
                       (d.precision == TKSPMV_F32 || d.precision == TKSPMV_Q1_7_F32) && m.pm.nnz > 0 &&
                       m.grid > 2u * (uint32_t)MULTI_Q_MAX && (uint32_t)d.k * 2u <= m.n_groups_pub &&
-                      (uint64_t)m.grid * WG_SLOTS <= (uint64_t)SEL_PER_THREAD * (m.multi_stream_waves * 64u + 64u);
+                      (uint64_t)m.grid * WG_SLOTS <= (uint64_t)SEL_PER_THREAD * (m.multi_stream_waves * 64u + 64u) &&
+                      // (the kernel stages x with TWO words per thread -- multi_kernel's XI --: a workgroup narrower than 512 threads
+                      //  would leave the columns from 2 x blockDim on unwritten in LDS and score against garbage, ADVICE r4;
+                      //  such geometries -- threads_per_wg <= 384 -- keep the ordinary sequence)
+                      2u * (m.multi_stream_waves * 64u + 64u) >= SELL_XCOLS;
     }
     if (m.can_multi) {
         // the first multi_group workgroups of a multi-query launch are its selectors (one per query of the previous launch), the others stream
@@ -1297,6 +1341,9 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
         // (engines that stream with checked local thresholds use the lists for repairs and behind a closed gate only: two; a power of two)
         int want_lists = m.use_local ? 2 : 4;
         if (const char *f = opt("OVF_LISTS")) want_lists = atoi(f);
+        // (the deferred scheme streams query i + 1 into one set while workgroup 0 selects query i from the other: its two sets need
+        //  private lists -- with OVF_LISTS=1 they shared one, the stream appended while the selection read and reset it)
+        if (m.can_defer) want_lists = std::max(want_lists, 2);
         want_lists = std::min(std::min(want_lists, 4), n_sets_alloc);
         m.ovf_lists = m.can_multi ? (uint32_t)n_sets_alloc : (want_lists >= 4 ? 4u : (want_lists >= 2 ? 2u : 1u));
         const size_t nl = m.ovf_lists;
@@ -1420,7 +1467,7 @@ int Engine::set_query(const float *host_x, double *elapsed_ns, std::string &err)
         // (a launch enqueued earlier may still be reading d_x: tkspmv_run clears x_pending, the asynchronous entry points do not)
         if (m.x_pending) HIP_TRY(hipStreamSynchronize(m.stream));
         std::memcpy(m.d_x, host_x, (size_t)m.desc.cols * 4);
-        __builtin_ia32_sfence();
+        m.flush_hdp();  // (sfence, HDP flush register written and read back: the stores are in memory before the launch's doorbell)
         m.x_pending = true;
         m.x_on_host_only = false;
         m.d_x_cur = m.d_x;

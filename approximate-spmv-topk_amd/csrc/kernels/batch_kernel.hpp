@@ -25,6 +25,14 @@ namespace tkspmv {
 // workgroup that never block on anything but memory.
 // ------------------------------------------------------------------------------------------------------------
 constexpr int BATCH_MAX = 32;
+// Attribution ladder (tools/ladder.sh; never defined in the product build): what the kernel of local thresholds costs rung by rung,
+// measured on timing-only builds of the library. 1: packets loaded, unpacked, gathered, multiplied, scanned, trigger formed -- and
+// never taken; 2: + the candidate path, the thresholds and everything a workgroup does in LDS for its record (staging, ranking);
+// 3: + the record stored and drained before the ticket; 4 and up: + the selections (the product; pacing is the PACE option).
+// Rungs below 4 return no results.
+#ifndef TKSPMV_LADDER
+#define TKSPMV_LADDER 9
+#endif
 #ifndef TKSPMV_TAU_WAIT
 #define TKSPMV_TAU_WAIT 3000
 #endif
@@ -174,8 +182,8 @@ __device__ __forceinline__ void finalize_local_wave(const unsigned long long *st
     next_prior = -1.0f;
     if (n_valid <= WG_SLOTS) {  // (wave-uniform)
         const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(bv >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bv, 0u));
-        if (valid) st_agent(slots + pos, v);
-        if (lane < WG_SLOTS && lane >= n_valid) st_agent(slots + lane, pack_cand(0u, SLOT_INVALID));
+        if (TKSPMV_LADDER >= 3 && valid) st_agent(slots + pos, v);
+        if (TKSPMV_LADDER >= 3 && lane < WG_SLOTS && lane >= n_valid) st_agent(slots + lane, pack_cand(0u, SLOT_INVALID));
         if (n_valid == WG_SLOTS) next_prior = -wave_max(valid ? -__uint_as_float((uint32_t)v) : -__builtin_huge_valf());  // the smallest of the 8
     } else {
         const uint32_t mk = valid ? order_key(__uint_as_float((uint32_t)v)) : 0u;
@@ -194,7 +202,7 @@ __device__ __forceinline__ void finalize_local_wave(const unsigned long long *st
             __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
             __builtin_amdgcn_sched_group_barrier(0x002, 96, 0);
         }
-        if (valid && r < WG_SLOTS) st_agent(slots + r, v);
+        if (TKSPMV_LADDER >= 3 && valid && r < WG_SLOTS) st_agent(slots + r, v);
         const uint64_t b8 = __ballot(valid && r == WG_SLOTS);  // the best row that did not fit, one step up (a dropped row may tie with it)
         if (b8 != 0ull) used = order_key(__uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, (int)__builtin_ctzll(b8)))) + 1u;
         const uint64_t b7 = __ballot(valid && r == WG_SLOTS - 1u);
@@ -363,7 +371,7 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
                 S.host_out = nullptr;
                 const float out_scale = __hip_atomic_load(B.unit_inv(set_of(q)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (tr_sel && tid == 0) P0.trace[10] = __builtin_amdgcn_s_memrealtime();
-                const bool bad = select_local(G, S, n_stream, tid, blockDim.x, L.u.lsel, out_scale, tr_sel ? P0.trace + 11 : nullptr);
+                const bool bad = TKSPMV_LADDER < 4 ? false : select_local(G, S, n_stream, tid, blockDim.x, L.u.lsel, out_scale, tr_sel ? P0.trace + 11 : nullptr);
                 __syncthreads();
                 if (tid == 0 && B.verdict)
                     (void)__hip_atomic_fetch_add(B.verdict, 1ull | ((bad ? 1ull : 0ull) << (32u + q)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -664,7 +672,7 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
                         float next_prior = -1.0f;
                         finalize_local_wave(&L.stg[tp][0][0], L.stg_cnt[tp], L.ck, mp, lane, min_units_q[tp],
                                             B.lslots + (size_t)set_of(tail) * B.lslots_stride + (size_t)bid * WG_SLOTS, used, next_prior);
-                        if (lane == 8u)
+                        if (TKSPMV_LADDER >= 3 && lane == 8u)
                             __hip_atomic_store(B.lused + (size_t)set_of(tail) * B.lused_stride + bid, used, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         if (carry_local && next_prior >= 0.0f && xnorm_q[tp] > 0.0f) wg_prior = next_prior * inv_unit_q[tp] / xnorm_q[tp];
                     } else {
@@ -835,7 +843,9 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
             const float tau = __uint_as_float(tau_bits);
             const Reduced<C> Rd = reduce_packet<C, QM>(cur, carry, xbase, P0.fixed_mask);
             const float trig = trigger_of<C, INT>(Rd);
-            if (__any(trig >= tau)) {
+            if (TKSPMV_LADDER < 2) {  // (timing-only build: the trigger is formed and kept alive, never taken)
+                top1 = max2(top1, trig);
+            } else if (__any(trig >= tau)) {
                 float tau_now = tau;
                 // Long partitions only (more rows per wave and query than its list holds: from ~1.5M rows on 256 CUs). A
                 // wave that runs ahead of its workgroup's exchange has no threshold yet: every row passes, and once the
@@ -923,6 +933,7 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
                         if (lane == 0) L.stg_cnt[qc & 1u][wave] = surv < STG_N ? surv : STG_N;
                     }
                 }
+                if (TKSPMV_LADDER < 2 && top1 == 12345.0f) L.ck[lane] = __float_as_uint(top1);  // (keeps rung 1's arithmetic alive)
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 if (lane == 0) atomicAdd(&mp[MISC_DONE], 1u);
                 if (trw && lane == 0 && TRSLOT(qc) < 3u) trw[4 + TRSLOT(qc)] = __builtin_amdgcn_s_memrealtime();

@@ -210,7 +210,7 @@ __global__ void __launch_bounds__(576, Q >= 8 ? 4 : 6) multi_kernel(const Stream
     // one -- 2 Q trips through memory one after the other (round 4 found the same in the batch kernel's staging). Addresses are
     // clamped and values masked, so no load sits in a branch. Queries beyond nq (a partial group): zeros, their sums are never
     // looked at.
-    constexpr uint32_t XI = 2u;
+    constexpr uint32_t XI = 2u;  // (the host launches this kernel only with 2 x blockDim >= SELL_XCOLS: engine.hip, can_multi)
     float xr[Q][XI];
     auto request = [&](uint32_t pass, uint32_t tid) __attribute__((always_inline)) {  // the pass's first chunks, then its x
         const uint32_t lane = tid & 63u, nq = nq_of(pass);

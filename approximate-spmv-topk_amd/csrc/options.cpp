@@ -4,6 +4,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <set>
 #include <string>
 
 namespace tkspmv {
@@ -19,7 +20,7 @@ static const OptionDef k_options[] = {
     {"BATCH", "behaviour", "0 | 1 (default 1)", "0: tkspmv_enqueue_batch / _many launch one kernel per query"},
     {"BATCH_MAX", "tuning", "1..32 (default 32)", "queries per batch launch"},
     {"SELECTORS", "tuning", "1..8 (default 4 up to LOCAL_MATRIX_PACKETS, else 1)", "selection workgroups a batch launch keeps in flight"},
-    {"OVF_LISTS", "tuning", "1 | 2 | 4 (default 4; 2 for engines that stream with local thresholds)", "overflow lists of the exact kernel (8 bytes per row each), shared round robin by the queries of a launch under flow control"},
+    {"OVF_LISTS", "tuning", "1 | 2 | 4 (default 4; 2 for engines that stream with local thresholds; at least 2 wherever the deferred scheme can run)", "overflow lists of the exact kernel (8 bytes per row each), shared round robin by the queries of a launch under flow control"},
     {"PACE", "tuning", "0..32 (default by size)", "pacing quantum of the batch kernel's workgroups by rank (s_sleep units); 0 = none"},
     {"PACE_LEVELS", "tuning", "1..8", "number of distinct pacing ranks"},
     {"FUSED", "behaviour", "0 | 1 (default 1 where the selection fits one workgroup)", "0: stream and selection as two launches"},
@@ -32,7 +33,7 @@ static const OptionDef k_options[] = {
     {"PARTITIONS_HINT", "diagnostic", "count", "wave partitions to pack (read probe experiments; an engine whose partitions exceed its streaming waves does not batch)"},
     {"DEVICE_PACK", "behaviour", "0 | 1 (default 1)", "0: pack the matrix on the host instead of on the device"},
     {"HOST_PATH", "behaviour", "0 | 1 (default 1)", "0: no host-visible result block / mapped x (tkspmv_run and tkspmv_read go through hipMemcpy)"},
-    {"BAR_X", "behaviour", "0 | 1 (default 1 where the device reports a large BAR and a round trip verifies)", "0: tkspmv_set_query stages x through pinned memory instead of storing into device memory"},
+    {"BAR_X", "behaviour", "0 | 1 (default 1 where the device reports a large BAR and its HDP flush register, and a kernel reads back what the CPU stored)", "0: tkspmv_set_query stages x through pinned memory instead of storing into device memory"},
     {"HOST_X", "behaviour", "copy | direct | direct_nc (default copy)", "direct: kernels read x from mapped host memory (direct_nc: non-coherent mapping)"},
     {"RUN_EVENTS", "behaviour", "0 | 1 (default 0)", "1: tkspmv_run returns a hipEvent bracket instead of the kernel's own device-clock span"},
     {"RESIDENT_IDLE_MS", "tuning", "ms", "how long the resident kernel waits for a query before it retires"},
@@ -60,8 +61,14 @@ static std::mutex &lock() {
     static std::mutex m;
     return m;
 }
-static std::map<std::string, std::string> &overrides() {
-    static std::map<std::string, std::string> m;
+// (values are interned in a node-based set that only grows: a pointer opt() / tkspmv_get_option has handed out stays valid
+//  whatever another thread sets afterwards)
+static std::set<std::string> &value_pool() {
+    static std::set<std::string> p;
+    return p;
+}
+static std::map<std::string, const std::string *> &overrides() {
+    static std::map<std::string, const std::string *> m;
     return m;
 }
 
@@ -83,7 +90,7 @@ const char *opt(const char *name) {
     {
         std::lock_guard<std::mutex> g(lock());
         auto it = overrides().find(name);
-        if (it != overrides().end()) return it->second.c_str();  // (stable until the same option is set again)
+        if (it != overrides().end()) return it->second->c_str();  // (interned: stable for the life of the process)
     }
     return std::getenv((std::string("TKSPMV_") + name).c_str());
 }
@@ -91,7 +98,7 @@ const char *opt(const char *name) {
 int set_option(const char *name, const char *value) {
     if (!find(name)) return -1;
     std::lock_guard<std::mutex> g(lock());
-    if (value) overrides()[name] = value;
+    if (value) overrides()[name] = &*value_pool().insert(value).first;
     else overrides().erase(name);
     return 0;
 }

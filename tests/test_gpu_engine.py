@@ -864,6 +864,21 @@ def test_multi_query_falls_back_where_the_kernel_does_not_apply(pkg):
     eng.close()
     with pytest.raises(pkg.TkspmvError):
         pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, k=50, device=0, multi_q=3)
+    # Workgroups narrower than 512 threads: the multi-query kernel stages x with two words per thread, so 1024 columns
+    # need 2 x blockDim >= 1024 -- such geometries must keep the ordinary sequence instead of scoring against unwritten LDS.
+    m = pkg.generate_matrix(60000, 1024, 20, "gamma", 6)
+    xs = np.stack([pkg.create_sample_vector(1024, True, False, True, 70 + i) for i in range(5)])
+    dxs = torch.from_numpy(xs).cuda()
+    eng = pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, k=50, device=0, multi_q=4, threads_per_wg=256, waves_per_cu=4)
+    assert eng.info()["multi_q"] == 0, eng.info()
+    eng.enqueue_multi(dxs.data_ptr(), 5, out_i.data_ptr(), out_v.data_ptr())
+    eng.synchronize()
+    for q in range(5):
+        eng.reset_device(dxs[q].data_ptr())
+        eng()
+        val, idx = eng.read_result()
+        assert np.array_equal(out_i[q].cpu().numpy().view(np.uint32), idx) and np.array_equal(out_v[q].cpu().numpy(), val)
+    eng.close()
 
 
 # ---- batches: the selection of query i rides inside the launch of query i+1 (deferred selection) ----------------------

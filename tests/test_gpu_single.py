@@ -66,15 +66,24 @@ def test_single_query_kernel_survives_queries_that_break_its_thresholds(pkg, ora
     eng = pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, k=k, device=0)
     assert (eng.info()["batch_mode"] >> 8) & 0xFF
     packed, raw, C = _packed_raw(pkg, m, eng, k)
+    import time
     scales = [1, 1, 1, 0.01, 0.01, 3, 3, 1, 0, 1, -1, 1, 1, 0.01, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1]
+    slowest, kernel_ns = 0.0, []
     for i, sc in enumerate(scales):
         x = (pkg.create_sample_vector(1024, True, False, True, 500 + i) * np.float32(sc)).astype(np.float32)
         eng.reset(x)
-        eng()
+        t0 = time.perf_counter()
+        kernel_ns.append(eng())
+        slowest = max(slowest, time.perf_counter() - t0)
         val, idx = eng.read_result()
         _exact(pkg, oracle, m, eng, x, k, idx, val, raw, C, gold=sc > 0)
     c = eng.debug_counters()
     assert c["single_checks_failed"] > 0 and c["single_repairs"] == c["single_checks_failed"], c
+    # A failed check must cost a second launch, not the 2 s timeout of the result flag (the host summed the stale
+    # payload of a block whose writer had checksummed the status alone). The bound is three orders of magnitude above a launch.
+    assert slowest < 0.25, f"a tkspmv_run took {slowest:.3f} s: a failed check is waiting for the flag's timeout"
+    # ... and the reported device time of a repaired query is both launches' spans (the repaired ones are the slowest by far)
+    assert max(kernel_ns) < 5e6 and max(kernel_ns) > 1.5 * float(np.median(kernel_ns)), kernel_ns
     print(f"\n[thresholds broken on purpose] {len(scales)} queries: {c}")
     eng.close()
 
