@@ -25,6 +25,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <limits>
 #include <string>
 #include <vector>
@@ -192,6 +193,32 @@ struct EngineImpl {
     // checked local thresholds of the batch kernel (BatchParams): the launches' verdict words (two, by launch parity), the workgroups'
     // records per exchange-state set, the epoch words of the overflow lists' flow control
     unsigned long long *d_verdict = nullptr;
+    // The host's side of the verdicts (round 5; BatchParams::verdict_host): a ring of host-visible words, one per batch launch on
+    // the engine's own stream, and the launches whose word has not been looked at yet. While the verdicts the host has SEEN are
+    // clean, a local launch goes out alone and settle() -- called wherever the host has just waited for the engine's stream --
+    // repairs what a check flagged after all (an exact launch of the flagged queries, then one more wait). An observed failure
+    // puts the in-stream repair launch back behind the next DISTRUST_LAUNCHES launches (it also keeps the gate's books).
+    // Launches on a caller's stream are never trusted: nobody tells the engine when the caller has waited.
+    static constexpr uint32_t VERDICT_RING = 1024, DISTRUST_LAUNCHES = 64;
+    unsigned long long *h_verdict = nullptr, *h_verdict_dev = nullptr;
+    struct PendingCheck {
+        BatchArgs A;
+        uint32_t slot;
+        bool trusted;  // no repair launch went out behind it
+    };
+    mutable std::deque<PendingCheck> pending_checks;
+    mutable uint64_t verdict_seq = 0, late_repairs = 0, trusted_launches = 0;
+    mutable uint32_t clean_seen = 0, distrust_left = 0;
+    // Two launches in flight (round 5): a launch of 32 queries pays ~35 us beyond its queries -- 5 us before the first packet is
+    // reduced, the wait for its last workgroup, the last selection, the gap to the next launch -- and an in-order stream pays them
+    // once per launch. Consecutive launches of ONE sequence alternate between the engine's stream and `bside`: the workgroups of the
+    // next launch are dispatched as the CUs of the previous one fall free, its ramp fills the other's tail. Only while launches are
+    // trusted (no exact launch behind them: two of those would share the exchange state); per-launch state (records, tickets,
+    // scale words, scratch results, verdict words) exists once per parity.
+    hipStream_t bside = nullptr;
+    hipEvent_t ev_bfork = nullptr, ev_bjoin = nullptr;
+    bool overlap_launches = false;  // option OVERLAP=1 (measured slower with rank pacing as it is: DESIGN.md section 9)
+    bool repair_by_host = true;  // option REPAIR=stream: the exact launch always follows in the stream (round 4's behaviour)
     unsigned long long *d_rec_slots = nullptr;  // [batch_max][grid][WG_SLOTS]
     uint32_t *d_rec_used = nullptr;             // [batch_max][grid]
     uint32_t *d_ovf_epoch = nullptr;            // [ovf_lists] x 32 words
@@ -200,7 +227,10 @@ struct EngineImpl {
     uint32_t single_mode = 0;  // the same choice for ONE query per launch (single_kernel): by the failure estimate alone, whatever the size
     float *d_wg_prior = nullptr;  // [grid] + the countdown word (BatchParams::wg_prior / prior_block)
     float local_beta = 1.0f;
-    uint32_t pace_quads = 0, pace_levels = 3; // pacing by rank (BatchParams::pace_quads, pace_levels)
+    uint32_t pace_tuned_us = 0;  // 0: the pacing is the static default (or an option); else what tkspmv_create's measurement took
+    uint32_t pace_quads = 0, pace_levels = 3, pace_base = 0; // pacing by rank (BatchParams::pace_quads, pace_levels, pace_base)
+    unsigned long long *d_wg_times = nullptr;  // option WG_TIMES: BatchParams::wg_times of the LAST batch launch (read through tkspmv_debug_trace)
+    uint32_t *d_wg_pace = nullptr;  // [grid] the pause every workgroup ended its last launch with (BatchParams::wg_pace)
     mutable uint64_t batch_launches = 0;
     uint32_t n_sel_wg = 1;   // selector workgroups of a batch launch (BatchParams::n_selectors): 4 on small matrices
     uint32_t groups_with_rows = 0;  // publishing groups that own at least one wave partition
@@ -426,15 +456,17 @@ struct EngineImpl {
     }
     batch_fn batch_kernel_for(bool local = false) const { return local ? batch_kernel_of<true>() : batch_kernel_of<false>(); }
     // n <= BATCH_MAX queries in one launch of the batch kernel; results complete in stream order after the launch.
-    void launch_batch(const float *const *xs, uint32_t *const *out_idx, float *const *out_val, int n, hipStream_t s) const {
-        drain(s);
+    void launch_batch(const float *const *xs, uint32_t *const *out_idx, float *const *out_val, int n, hipStream_t s, uint32_t parity = 0u,
+                      bool final_launch = true) const {
+        if (s != bside) drain(s);
         StreamParams P = stream_params(xs[0], 0);
         P.fused = 0u;
         SelectParams S = select_params(out_idx[0], out_val[0], 0);
         BatchParams B{};
         B.n_q = (uint32_t)n;
-        B.tickets = d_tickets;
+        B.tickets = d_tickets + (size_t)parity * BATCH_MAX * 32;
         static_cast<SetAddr &>(B) = set_addr(0);
+        B.unit_inv0 += (size_t)parity * BATCH_MAX * STATE_WORD_STRIDE;
         for (int q = 0; q < n; ++q) {
             BatchIO &Q = B.io[q];
             Q.x = xs[q];
@@ -444,9 +476,10 @@ struct EngineImpl {
             // Result buffers shared by several queries of the launch (the engine-owned pair: "the last query wins"): selections run
             // concurrently and a repair phase writes after the fact, so only the LAST query may keep such a buffer -- the earlier
             // ones write to a scratch block nobody reads.
-            if (q + 1 < n && out_idx[q] == out_idx[n - 1]) {
-                Q.out_idx = d_alias_idx + (size_t)q * desc.k;
-                Q.out_val = d_alias_val + (size_t)q * desc.k;
+            // (a launch that overlaps with its successor: its last query too, if it names the engine's own pair)
+            if ((q + 1 < n && out_idx[q] == out_idx[n - 1]) || (!final_launch && out_idx[q] == d_out_idx)) {
+                Q.out_idx = d_alias_idx + ((size_t)parity * BATCH_MAX + q) * desc.k;
+                Q.out_val = d_alias_val + ((size_t)parity * BATCH_MAX + q) * desc.k;
             }
         }
         launch_counter += (uint64_t)n;
@@ -454,21 +487,44 @@ struct EngineImpl {
         B.local = use_local;
         B.pace_quads = pace_quads;
         B.pace_levels = pace_levels;
+        B.pace_base = pace_base;
+        B.wg_pace = d_wg_pace;
+        B.wg_times = d_wg_times;
         B.prior_block = reinterpret_cast<uint32_t *>(d_wg_prior + grid);
         B.gate_parity = (uint32_t)(batch_launches & 1u);
-        B.verdict = d_verdict + 16 * (batch_launches & 1u);
-        B.verdict_next = d_verdict + 16 * ((batch_launches + 1u) & 1u);
+        // (four words: a launch zeroes the word of the launch after the next -- its successor on the same stream --, so the scheme
+        //  holds with one launch at a time and with two in flight)
+        B.verdict = d_verdict + 16 * (batch_launches & 3u);
+        B.verdict_next = d_verdict + 16 * ((batch_launches + 2u) & 3u);
         ++batch_launches;
         if (use_local) {
             B.wg_prior = d_wg_prior;
             B.local_beta = local_beta;
         }
-        B.lslots = d_rec_slots;
-        B.lused = d_rec_used;
+        B.lslots = d_rec_slots + (size_t)parity * BATCH_MAX * grid * WG_SLOTS;
+        B.lused = d_rec_used + (size_t)parity * BATCH_MAX * grid;
         B.lslots_stride = grid * WG_SLOTS;
         B.lused_stride = grid;
         B.ovf_epoch = d_ovf_epoch;
         B.ovf_lists = std::min(ovf_lists, 4u);  // (engines with one list per set -- the multi-query ones -- lend the batch kernel their first four)
+        if (use_local && (s == stream || s == bside) && h_verdict && pending_checks.size() + 1u < VERDICT_RING) {
+            const uint32_t slot = (uint32_t)(verdict_seq++ % VERDICT_RING);
+            h_verdict[slot] = 0ull;
+            B.verdict_host = h_verdict_dev + slot;
+            const bool trusted = repair_by_host && clean_seen != 0u && distrust_left == 0u;
+            BatchArgs A{P, S, B};
+            hipLaunchKernelGGL(batch_kernel_for(true), dim3(grid), dim3(block + 64), 0, s, A);
+            if (!trusted) {
+                BatchArgs R = A;
+                R.B.repair = 1u;
+                hipLaunchKernelGGL(batch_kernel_for(false), dim3(grid), dim3(block + 64), 0, s, R);
+                if (distrust_left != 0u) --distrust_left;
+            } else {
+                ++trusted_launches;
+            }
+            pending_checks.push_back(PendingCheck{A, slot, trusted});
+            return;
+        }
         BatchArgs A{P, S, B};
         if (use_local) {
             // the kernel of the checked local thresholds, then the exact kernel for whatever failed its check (the launch is
@@ -478,6 +534,45 @@ struct EngineImpl {
         }
         hipLaunchKernelGGL(batch_kernel_for(false), dim3(grid), dim3(block + 64), 0, s, A);
     }
+    // The host has just waited for the engine's stream: look at the verdicts of the launches enqueued since it last did. A flagged
+    // query of a TRUSTED launch (no repair launch behind it) is repaired now -- exact launch of the flagged queries, one more wait --;
+    // any failure brings the in-stream repair launch back for a while. Returns hipSuccess, or the error of the repair's wait.
+    hipError_t settle() const {
+        bool late = false;
+        const size_t n_pending = pending_checks.size();
+        for (size_t i = 0; i < n_pending; ++i) {
+            PendingCheck &pc = pending_checks[i];
+            const unsigned long long v = const_cast<volatile unsigned long long *>(h_verdict)[pc.slot];
+            const uint32_t mask = (uint32_t)(v >> 32);
+            // (a word that is not complete: the launch was not waited for after all -- a caller polling an event of its own; such a
+            //  launch counts as a failure of trust, not of a check: everything of it is run again below if nobody repaired it)
+            const bool complete = (uint32_t)v == pc.A.B.n_q;
+            if (complete && mask == 0u) {
+                if (clean_seen != 0xFFFFFFFFu) ++clean_seen;
+                continue;
+            }
+            clean_seen = 0u;
+            distrust_left = DISTRUST_LAUNCHES;
+            if (!pc.trusted) continue;  // (its in-stream repair launch has dealt with it)
+            BatchArgs R = pc.A;
+            R.B.repair = 2u;
+            R.B.repair_mask = complete ? mask : (R.B.n_q >= 32u ? 0xFFFFFFFFu : ((1u << R.B.n_q) - 1u));
+            R.B.verdict_host = nullptr;
+            // "the last query wins" for the engine-owned result pair: a launch that was not the last one enqueued must not write
+            // there again after the fact
+            if (i + 1u < n_pending)
+                for (uint32_t q = 0; q < R.B.n_q; ++q)
+                    if (R.B.io[q].out_idx == d_out_idx) {
+                        R.B.io[q].out_idx = d_alias_idx + (size_t)q * desc.k;
+                        R.B.io[q].out_val = d_alias_val + (size_t)q * desc.k;
+                    }
+            hipLaunchKernelGGL(batch_kernel_for(false), dim3(grid), dim3(block + 64), 0, stream, R);
+            ++late_repairs;
+            late = true;
+        }
+        pending_checks.clear();
+        return late ? hipStreamSynchronize(stream) : hipSuccess;
+    }
     // A back-to-back sequence of queries given as pointer lists: batch kernel launches of up to BATCH_MAX queries
     // when it is available, else deferred selection.
     void launch_sequence(const float *const *xs, uint32_t *const *out_idx, float *const *out_val, int n, hipStream_t s) const {
@@ -486,8 +581,24 @@ struct EngineImpl {
             drain(s);
             return;
         }
-        for (int i = 0; i < n; i += batch_max) {
-            launch_batch(xs + i, out_idx + i, out_val + i, std::min(batch_max, n - i), s);
+        // Two launches in flight where every launch of the sequence goes out trusted (see bside): fork, alternate, join -- the
+        // caller's view of the engine's stream is unchanged (everything enqueued here is complete when the stream is).
+        const int n_launches = (n + batch_max - 1) / batch_max;
+        const bool overlap = overlap_launches && bside && use_local && s == stream && n_launches >= 2 && repair_by_host && h_verdict &&
+                             clean_seen != 0u && distrust_left == 0u && pending_checks.size() + (size_t)n_launches + 1u < VERDICT_RING;
+        if (overlap) {
+            drain(s);
+            (void)hipEventRecord(ev_bfork, s);
+            (void)hipStreamWaitEvent(bside, ev_bfork, 0);
+        }
+        int l = 0;
+        for (int i = 0; i < n; i += batch_max, ++l) {
+            const bool odd = overlap && (l & 1);
+            launch_batch(xs + i, out_idx + i, out_val + i, std::min(batch_max, n - i), odd ? bside : s, odd ? 1u : 0u, !overlap || i + batch_max >= n);
+        }
+        if (overlap) {
+            (void)hipEventRecord(ev_bjoin, bside);
+            (void)hipStreamWaitEvent(s, ev_bjoin, 0);
         }
     }
     // One query of a back-to-back sequence: its selection runs inside the NEXT deferred launch (or in drain()).
@@ -770,7 +881,7 @@ Engine::~Engine() {
     void *bufs[] = {m.d_packets, m.d_pkt_row, m.d_part_first, m.d_part_count, m.d_x,
                     m.d_out_idx, m.d_out_val, m.d_scores,     m.d_stats,      m.d_done, m.d_trace, m.d_tickets,
                     m.d_tstart, m.d_verdict, m.d_wg_prior, m.d_rec_slots, m.d_rec_used, m.d_ovf_epoch, m.d_alias_idx, m.d_alias_val,
-                    m.d_lslots,  m.d_lused, m.d_lprior, m.d_lstatus};
+                    m.d_lslots,  m.d_lused, m.d_lprior, m.d_lstatus, m.d_wg_pace, m.d_wg_times};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     {
@@ -785,6 +896,7 @@ Engine::~Engine() {
     if (m.d_dev_epoch) (void)hipFree(m.d_dev_epoch);
     if (m.h_x) (void)hipHostFree(m.h_x);
     if (m.h_res) (void)hipHostFree(m.h_res);
+    if (m.h_verdict) (void)hipHostFree(m.h_verdict);
     for (size_t r = 1; r < m.d_replicas.size(); ++r) (void)hipFree(m.d_replicas[r]);
     for (size_t r = 1; r < m.d_sell_replicas.size(); ++r) (void)hipFree(m.d_sell_replicas[r]);
     {
@@ -797,6 +909,12 @@ Engine::~Engine() {
     if (m.ev2) (void)hipEventDestroy(m.ev2);
     if (m.ev_fork) (void)hipEventDestroy(m.ev_fork);
     if (m.ev_join) (void)hipEventDestroy(m.ev_join);
+    if (m.bside) {
+        (void)hipStreamSynchronize(m.bside);
+        (void)hipStreamDestroy(m.bside);
+    }
+    if (m.ev_bfork) (void)hipEventDestroy(m.ev_bfork);
+    if (m.ev_bjoin) (void)hipEventDestroy(m.ev_bjoin);
     if (m.side) {
         (void)hipStreamSynchronize(m.side);
         (void)hipStreamDestroy(m.side);
@@ -1265,10 +1383,20 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
         m.resident_stats = opt("RESIDENT_STATS") != nullptr;
         if (const char *f = opt("RESIDENT_IDLE_MS")) m.resident_idle_ticks = (uint32_t)std::max(1, atoi(f)) * 100000u;
     }
-    HIP_TRY(malloc_exchange((void **)&m.d_tickets, BATCH_MAX * 32 * 4));
-    HIP_TRY(hipMemset(m.d_tickets, 0, BATCH_MAX * 32 * 4));
-    HIP_TRY(malloc_exchange((void **)&m.d_verdict, 256));
-    HIP_TRY(hipMemset(m.d_verdict, 0, 256));
+    HIP_TRY(malloc_exchange((void **)&m.d_tickets, 2 * BATCH_MAX * 32 * 4));  // (one block per launch parity: EngineImpl::bside)
+    HIP_TRY(hipMemset(m.d_tickets, 0, 2 * BATCH_MAX * 32 * 4));
+    HIP_TRY(malloc_exchange((void **)&m.d_verdict, 512));
+    HIP_TRY(hipMemset(m.d_verdict, 0, 512));
+    // the host's side of the verdicts (EngineImpl::settle); without it every local launch keeps its repair launch in the stream
+    if (const char *f = opt("REPAIR")) m.repair_by_host = std::string(f) != "stream";
+    if (hipHostMalloc((void **)&m.h_verdict, (size_t)EngineImpl::VERDICT_RING * 8, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+        hipHostGetDevicePointer((void **)&m.h_verdict_dev, m.h_verdict, 0) != hipSuccess) {
+        if (m.h_verdict) (void)hipHostFree(m.h_verdict);
+        m.h_verdict = m.h_verdict_dev = nullptr;
+        (void)hipGetLastError();
+    } else {
+        std::memset(m.h_verdict, 0, (size_t)EngineImpl::VERDICT_RING * 8);
+    }
     {
         // Workgroup-local thresholds pay when they practically never fail the selection's check (a failure costs the query a
         // second pass). The workgroup's threshold is the smallest of its waves' words; it exceeds the k-th best score when EVERY
@@ -1310,6 +1438,11 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
     if (m.use_local) m.pace_quads = m.pm.n_packets <= 45000u ? 0u : (m.pm.n_packets <= 65000u ? 2u : 2u * std::max(1u, (m.pm.packet_bytes + 352u) / 704u));
     if (const char *f = opt("PACE_LEVELS")) m.pace_levels = (uint32_t)std::max(1, std::min(8, atoi(f)));
     if (const char *f = opt("PACE")) m.pace_quads = (uint32_t)std::max(0, std::min(32, atoi(f)));
+    if (const char *f = opt("PACE_BASE")) m.pace_base = (uint32_t)std::max(0, std::min(64, atoi(f)));
+    if (m.use_local && m.pace_quads != 0u) {
+        HIP_TRY(hipMalloc((void **)&m.d_wg_pace, (size_t)m.grid * 4));
+        HIP_TRY(hipMemset(m.d_wg_pace, 0, (size_t)m.grid * 4));
+    }
     // single_kernel serves tkspmv_run where the engine streams with local thresholds: fp32 values, 4 entries per lane, x of at most
     // 1024 columns, at most 512 workgroups (select_local's first cut), one partition per wave of ITS launch (8 waves x grid).
     m.can_single = m.single_mode != 0u && d.precision == TKSPMV_F32 && C == 4u && m.xcols <= 1024u && m.grid <= 512u && m.block == 512u &&
@@ -1357,8 +1490,9 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
         HIP_TRY(hipMalloc((void **)&E0.wg_cand, ns * m.grid * WG_SLOTS * 8));
         HIP_TRY(hipMemset(E0.wg_cand, 0xFF, ns * m.grid * WG_SLOTS * 8));
         HIP_TRY(hipMalloc((void **)&E0.ovf, nl * m.ovf_cap * 8));
-        HIP_TRY(hipMalloc((void **)&E0.unit_inv, ns * EngineImpl::STATE_WORD_STRIDE * 4));
-        std::vector<float> ones(ns * EngineImpl::STATE_WORD_STRIDE, 1.0f);
+        const size_t n_unit = std::max(ns, 2 * (size_t)BATCH_MAX);  // (the batch kernel's scale words: one block per launch parity)
+        HIP_TRY(hipMalloc((void **)&E0.unit_inv, n_unit * EngineImpl::STATE_WORD_STRIDE * 4));
+        std::vector<float> ones(n_unit * EngineImpl::STATE_WORD_STRIDE, 1.0f);
         HIP_TRY(hipMemcpy(E0.unit_inv, ones.data(), ones.size() * 4, hipMemcpyHostToDevice));
         for (int si = 1; si < n_sets_alloc; ++si) {
             EngineImpl::ExState &E = m.st[si];
@@ -1373,19 +1507,31 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
         HIP_TRY(hipMemset(m.d_ovf_epoch, 0, 128));
         if (m.can_batch) {
             // the workgroups' records of local mode, one block per set; the scratch results of queries that share the last one's buffer
-            HIP_TRY(hipMalloc((void **)&m.d_rec_slots, ns * m.grid * WG_SLOTS * 8));
-            HIP_TRY(hipMemset(m.d_rec_slots, 0xFF, ns * m.grid * WG_SLOTS * 8));
-            HIP_TRY(hipMalloc((void **)&m.d_rec_used, ns * m.grid * 4));
-            HIP_TRY(hipMemset(m.d_rec_used, 0, ns * m.grid * 4));
-            HIP_TRY(hipMalloc((void **)&m.d_alias_idx, (size_t)BATCH_MAX * d.k * 4));
-            HIP_TRY(hipMalloc((void **)&m.d_alias_val, (size_t)BATCH_MAX * d.k * 4));
+            // (twice BATCH_MAX sets each: one block per launch parity, EngineImpl::bside)
+            const size_t nr = 2 * (size_t)BATCH_MAX;
+            HIP_TRY(hipMalloc((void **)&m.d_rec_slots, nr * m.grid * WG_SLOTS * 8));
+            HIP_TRY(hipMemset(m.d_rec_slots, 0xFF, nr * m.grid * WG_SLOTS * 8));
+            HIP_TRY(hipMalloc((void **)&m.d_rec_used, nr * m.grid * 4));
+            HIP_TRY(hipMemset(m.d_rec_used, 0, nr * m.grid * 4));
+            HIP_TRY(hipMalloc((void **)&m.d_alias_idx, nr * d.k * 4));
+            HIP_TRY(hipMalloc((void **)&m.d_alias_val, nr * d.k * 4));
+            if (m.use_local) {
+                if (const char *f = opt("OVERLAP")) m.overlap_launches = atoi(f) != 0;
+                HIP_TRY(hipStreamCreateWithFlags(&m.bside, hipStreamNonBlocking));
+                HIP_TRY(hipEventCreateWithFlags(&m.ev_bfork, hipEventDisableTiming));
+                HIP_TRY(hipEventCreateWithFlags(&m.ev_bjoin, hipEventDisableTiming));
+            }
         }
         m.info.state_bytes = ns * (EngineImpl::GMAX_WORDS * 4 + 2 * EngineImpl::STATE_WORD_STRIDE * 4 + (uint64_t)m.grid * WG_SLOTS * 8) +
                              nl * ((uint64_t)m.ovf_cap * 8 + EngineImpl::STATE_WORD_STRIDE * 4) +
-                             (m.can_batch ? ns * ((uint64_t)m.grid * WG_SLOTS * 8 + (uint64_t)m.grid * 4) : 0);
+                             (m.can_batch ? 2 * (uint64_t)BATCH_MAX * ((uint64_t)m.grid * WG_SLOTS * 8 + (uint64_t)m.grid * 4) : 0);
     }
     HIP_TRY(hipMemset(m.d_stats, 0, 32 * 8));
     m.collect_stamps = opt("STAMPS") != nullptr;
+    if (opt("WG_TIMES") && m.use_local) {
+        HIP_TRY(hipMalloc((void **)&m.d_wg_times, (size_t)(BATCH_MAX + 1) * m.grid * 8));
+        HIP_TRY(hipMemset(m.d_wg_times, 0, (size_t)(BATCH_MAX + 1) * m.grid * 8));
+    }
     if (opt("TRACE")) {
         m.trace_words = (size_t)(m.grid + 1) * 9 * 8;
         HIP_TRY(hipMalloc((void **)&m.d_trace, m.trace_words * 4 * 8));
@@ -1421,6 +1567,71 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
     m.info.multi_pack_us = m.sell_pack_us;
     m.info.pack_on_device = m.packed_on_device ? 1u : 0u;
     m.info.claim_sets = 0u;
+    // ---- pacing, tuned on THIS box for THIS matrix (round 5) ----------------------------------------------------------------------
+    // The pause per packet of the workgroups that lead the field (BatchParams::pace_quads x pace_levels) decides whether the eight
+    // XCDs share the memory system evenly -- unpaced, four of them stream a query in 12 us and the other four in 22-26
+    // (tools/wg_times.py) -- and its best setting moves with the box: quantum 2 over 6 eighths on the pool's fast boxes (16.3 us per
+    // query, 17.6 at round 4's 4 over 3), 2 over 7 on its slow ones (17.4 against 18.9 and 20.0). So the engine measures: a handful of
+    // settings, three launches of 32 synthetic queries each, twice through, ~10 ms of tkspmv_create.
+    if (m.use_local && m.can_batch && m.pace_quads != 0u && !opt("PACE") && !opt("PACE_LEVELS") && !opt("PACE_BASE") &&
+        (!opt("AUTOTUNE") || atoi(opt("AUTOTUNE")) != 0) && m.pm.packet_bytes == 1408u) {
+        const int nq = BATCH_MAX;
+        std::vector<float> hx((size_t)nq * d.cols);
+        uint32_t lcg = 0x1234567u;
+        for (float &v : hx) {
+            lcg = lcg * 1664525u + 1013904223u;
+            v = (float)(lcg >> 8) * (1.0f / 16777216.0f);
+        }
+        float *d_tx = nullptr;
+        HIP_TRY(hipMalloc((void **)&d_tx, hx.size() * 4));
+        HIP_TRY(hipMemcpy(d_tx, hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
+        std::vector<const float *> xs(nq);
+        std::vector<uint32_t *> oi(nq, m.d_out_idx);
+        std::vector<float *> ov(nq, m.d_out_val);
+        for (int i = 0; i < nq; ++i) xs[i] = d_tx + (size_t)i * d.cols;
+        static const uint32_t cand[][2] = {{2, 6}, {2, 7}, {3, 5}, {4, 4}, {2, 5}, {4, 3}};
+        constexpr int NC = (int)(sizeof(cand) / sizeof(cand[0]));
+        float best_ms[NC];
+        for (float &b : best_ms) b = 1e30f;
+        const auto t_tune = std::chrono::steady_clock::now();
+        for (int pass = 0; pass < 2; ++pass)
+            for (int c = 0; c < NC; ++c) {
+                m.pace_quads = cand[c][0];
+                m.pace_levels = cand[c][1];
+                m.launch_batch(xs.data(), oi.data(), ov.data(), nq, m.stream);  // (settles the pauses the setting leads to)
+                HIP_TRY(hipEventRecord(m.ev0, m.stream));
+                m.launch_batch(xs.data(), oi.data(), ov.data(), nq, m.stream);
+                m.launch_batch(xs.data(), oi.data(), ov.data(), nq, m.stream);
+                HIP_TRY(hipEventRecord(m.ev1, m.stream));
+                HIP_TRY(hipEventSynchronize(m.ev1));
+                HIP_TRY(m.settle());
+                float ms = 0;
+                HIP_TRY(hipEventElapsedTime(&ms, m.ev0, m.ev1));
+                best_ms[c] = std::min(best_ms[c], ms);
+            }
+        int best = 0;
+        for (int c = 1; c < NC; ++c)
+            if (best_ms[c] < best_ms[best]) best = c;
+        m.pace_quads = cand[best][0];
+        m.pace_levels = cand[best][1];
+        const uint32_t tune_us = (uint32_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_tune).count();
+        // the engine starts as if nothing had run: no carried thresholds, no pauses, no counters, no trust
+        HIP_TRY(hipMemset(m.d_wg_prior, 0, ((size_t)m.grid + 32) * 4));
+        if (m.d_wg_pace) HIP_TRY(hipMemset(m.d_wg_pace, 0, (size_t)m.grid * 4));
+        m.clean_seen = m.distrust_left = 0u;
+        m.trusted_launches = m.late_repairs = 0;
+        m.batch_launches = 0;
+        HIP_TRY(hipMemset(m.d_verdict, 0, 512));
+        HIP_TRY(hipMemset(m.d_out_idx, 0, (size_t)d.k * 4));
+        HIP_TRY(hipMemset(m.d_out_val, 0, (size_t)d.k * 4));
+        (void)hipFree(d_tx);
+        m.pace_tuned_us = tune_us ? tune_us : 1u;
+        if (opt("DEBUG_OCC")) {
+            fprintf(stderr, "[tkspmv] pacing tuned in %u us:", tune_us);
+            for (int c = 0; c < NC; ++c) fprintf(stderr, " %ux%u %.2f us/q%s", cand[c][0], cand[c][1], best_ms[c] * 1e3 / (2 * nq), c == best ? "*" : "");
+            fprintf(stderr, "\n");
+        }
+    }
     m.info.batch_mode = (m.can_batch ? (m.n_sel_wg | (m.use_local << 8)) : 0u) | (std::min<uint32_t>(n_parts_hint, 0xFFFFu) << 16);
     HIP_TRY(hipDeviceSynchronize());
     return TKSPMV_OK;
@@ -1657,6 +1868,7 @@ int Engine::time_multi(const float *dev_xs, int32_t n_x, int32_t iters, double *
     HIP_TRY(hipSetDevice(m.device));
     HIP_TRY(m.leave_resident_mode());
     HIP_TRY(hipStreamSynchronize(m.stream));
+    HIP_TRY(m.settle());
     HIP_TRY(hipEventRecord(m.ev0, m.stream));
     {
         std::vector<const float *> xs;
@@ -1820,6 +2032,7 @@ int Engine::run(double *kernel_ns, std::string &err) {
     HIP_TRY(hipGetLastError());
     if (events) HIP_TRY(hipEventRecord(m.ev1, m.stream));
     if (!seen) HIP_TRY(hipStreamSynchronize(m.stream));
+    HIP_TRY(m.settle());
     m.x_pending = false;  // the kernel has read x: the staging copy is free again
     if (kernel_ns && !events) {
         // the kernels' own durations, or the host clock if the flag never came
@@ -1849,6 +2062,7 @@ int Engine::synchronize(std::string &err) {
     HIP_TRY(impl_->leave_resident_mode());
     impl_->drain(impl_->stream);
     HIP_TRY(hipStreamSynchronize(impl_->stream));
+    HIP_TRY(impl_->settle());
     return TKSPMV_OK;
 }
 
@@ -1866,6 +2080,7 @@ int Engine::read(uint32_t *idx, float *val, int32_t *n, std::string &err) {
     }
     HIP_TRY(hipSetDevice(m.device));
     HIP_TRY(hipStreamSynchronize(m.stream));
+    HIP_TRY(m.settle());
     m.x_pending = false;
     if (idx) HIP_TRY(hipMemcpy(idx, m.d_out_idx, (size_t)m.desc.k * 4, hipMemcpyDeviceToHost));
     if (val) HIP_TRY(hipMemcpy(val, m.d_out_val, (size_t)m.desc.k * 4, hipMemcpyDeviceToHost));
@@ -1884,6 +2099,7 @@ int Engine::debug_counters(unsigned long long *out, int n, std::string &err) {
     }
     HIP_TRY(hipSetDevice(m.device));
     if (m.stream) HIP_TRY(hipStreamSynchronize(m.stream));
+    HIP_TRY(m.settle());
     uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (m.d_wg_prior) HIP_TRY(hipMemcpy(w, m.d_wg_prior + m.grid, sizeof(w), hipMemcpyDeviceToHost));
     out[0] = w[3];
@@ -1900,11 +2116,27 @@ int Engine::debug_counters(unsigned long long *out, int n, std::string &err) {
         out[8] = s[3];
         out[9] = s[0];
     }
+    if (n >= 12) {  // round 5: batch launches that went out without a repair launch behind them, and the late repairs they cost
+        out[10] = m.trusted_launches;
+        out[11] = m.late_repairs;
+    }
+    if (n >= 14) {  // the pacing in force: quantum | levels << 8 | base << 16, and what tkspmv_create's measurement of it took (us; 0: not measured)
+        out[12] = m.pace_quads | (m.pace_levels << 8) | (m.pace_base << 16);
+        out[13] = m.pace_tuned_us;
+    }
     return TKSPMV_OK;
 }
 
 int Engine::read_trace(unsigned long long *host, size_t max_words, size_t *words, std::string &err) {
     EngineImpl &m = *impl_;
+    if (!m.d_trace && m.d_wg_times) {  // option WG_TIMES: [BATCH_MAX + 1][grid] hand-over stamps of the last batch launch
+        HIP_TRY(hipSetDevice(m.device));
+        HIP_TRY(hipDeviceSynchronize());
+        const size_t n = std::min(max_words, (size_t)(BATCH_MAX + 1) * m.grid);
+        HIP_TRY(hipMemcpy(host, m.d_wg_times, n * 8, hipMemcpyDeviceToHost));
+        if (words) *words = n;
+        return TKSPMV_OK;
+    }
     if (!m.d_trace) {
         err = "tracing is off (set TKSPMV_TRACE=1 before tkspmv_create)";
         return TKSPMV_ERR_STATE;
@@ -1938,6 +2170,7 @@ int Engine::scores(float *host_y, std::string &err) {
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(host_y, m.d_scores, (size_t)m.desc.rows * 4, hipMemcpyDeviceToHost, m.stream));
     HIP_TRY(hipStreamSynchronize(m.stream));
+    HIP_TRY(m.settle());
     return TKSPMV_OK;
 }
 
@@ -1969,6 +2202,7 @@ int Engine::time_queries(const float *dev_xs, int32_t n_x, int32_t iters, double
             break;
         }
     }
+    HIP_TRY(m.settle());  // (the end event has passed: the stream is idle; a flagged query is repaired outside the event bracket)
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, m.ev0, m.ev1));
     *ns_per_query = (double)ms * 1e6 / iters;
@@ -1990,6 +2224,7 @@ int Engine::time_query_batches(const float *dev_xs, int32_t n_x, int32_t iters, 
     HIP_TRY(hipSetDevice(m.device));
     HIP_TRY(m.leave_resident_mode());
     HIP_TRY(hipStreamSynchronize(m.stream));
+    HIP_TRY(m.settle());
     std::vector<hipEvent_t> evs((size_t)reps + 1);
     for (auto &e : evs) HIP_TRY(hipEventCreate(&e));
     std::vector<const float *> xs;
@@ -2003,6 +2238,7 @@ int Engine::time_query_batches(const float *dev_xs, int32_t n_x, int32_t iters, 
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventSynchronize(evs[(size_t)reps]));
+    HIP_TRY(m.settle());
     for (int r = 0; r < reps; ++r) {
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, evs[(size_t)r], evs[(size_t)r + 1]));
@@ -2073,6 +2309,7 @@ int Engine::time_stream_read(int32_t passes, double *ns_per_pass, std::string &e
         return TKSPMV_ERR_UNSUPPORTED;
     }
     HIP_TRY(hipStreamSynchronize(m.stream));
+    HIP_TRY(m.settle());
     R.n_pass = 2;  // (warm-up: code object, clocks)
     HIP_TRY(hipMemsetAsync(R.claim, 0, (size_t)(passes + 2) * 128, m.stream));
     hipLaunchKernelGGL(fn, dim3(m.grid), dim3(stream_block), 0, m.stream, R);
@@ -2133,6 +2370,7 @@ int Engine::profile(const float *dev_xs, int32_t n_x, int32_t iters, tkspmv_timi
     HIP_TRY(hipSetDevice(m.device));
     HIP_TRY(m.leave_resident_mode());
     HIP_TRY(hipStreamSynchronize(m.stream));
+    HIP_TRY(m.settle());
     unsigned long long st0[8], st1[8];
     HIP_TRY(hipMemcpy(st0, m.d_stats, sizeof(st0), hipMemcpyDeviceToHost));
     const size_t stride = m.desc.cols;
@@ -2208,6 +2446,7 @@ int Engine::profile(const float *dev_xs, int32_t n_x, int32_t iters, tkspmv_timi
             if (!m.fused && !m.use_radix) m.launch_select(m.d_out_idx, m.d_out_val, m.stream);
         }
         HIP_TRY(hipStreamSynchronize(m.stream));
+        HIP_TRY(m.settle());
         for (int i = 0; i < n; ++i) {
             float a = 0;
             HIP_TRY(hipEventElapsedTime(&a, evs[2 * i], evs[2 * i + 1]));

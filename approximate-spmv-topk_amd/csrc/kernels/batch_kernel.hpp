@@ -98,13 +98,23 @@ struct BatchParams : SetAddr {
     // in the previous query: pace_quads units of s_sleep(2) = 128 cycles, times pace_levels, pace_levels - 1, ..., 1 for the first,
     // second, ... eighth of the field (pace_levels = 3: three eighths pause).
     uint32_t pace_quads, pace_levels;
+    uint32_t pace_base;   // units every workgroup pauses per packet whatever its rank (a uniform throttle; PACE_BASE, tuning runs)
+    unsigned long long *wg_times;  // optional (option WG_TIMES): [BATCH_MAX + 1][n_wg] s_memrealtime at every hand-over (row q) and at the workgroup's entry (row BATCH_MAX)
+    uint32_t *wg_pace;    // [n_wg] the pause a workgroup ended the previous launch with: its first query here starts from it (NULL: from none)
     // ---- the verdict of a launch's checks and the repair launch -----------------------------------------------------------------
     // Every checked selection of a LOCAL launch adds 1 | failed << (32 + q) to the launch's verdict word (one 64-bit atomic: the
     // count of finished selections and the set of failed queries travel together). The exact launch behind it (repair = 1) reads the
     // completed word and runs the named queries again with the device-wide exchange -- none, almost always.
     unsigned long long *verdict;       // this launch's word
     unsigned long long *verdict_next;  // the next launch's word: zeroed by this one
-    uint32_t repair;
+    // Round 5: the exact launch behind EVERY local launch (6 us per launch to find out that nothing failed: 1.6 % of the driver's
+    // 20-query region) is gone from the stream once the host has seen clean verdicts: the selection that completes the launch's
+    // verdict also stores it in host-visible memory (verdict_host), and the host looks at it when it next waits for the stream
+    // (EngineImpl::settle) -- a flagged query is then repaired by an exact launch with repair = 2, which takes the queries from
+    // repair_mask instead of the (long reused) device word. repair = 1: the in-stream repair launch as before (caller's streams,
+    // the launches after an observed failure, engines that have seen nothing yet).
+    unsigned long long *verdict_host;
+    uint32_t repair, repair_mask;
     // ---- overflow lists of the exact mode: ovf_lists of them (2), used round robin by the queries of a phase under flow control --
     // A list must be able to hold EVERY row (x = 0 makes every row a candidate and the result must still be exact): 8 bytes per
     // row. Round 3 kept one per query of a launch (256 MB at 1M rows, 2.6 GB at 10M); now query j of a phase uses list
@@ -373,8 +383,12 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
                 if (tr_sel && tid == 0) P0.trace[10] = __builtin_amdgcn_s_memrealtime();
                 const bool bad = TKSPMV_LADDER < 4 ? false : select_local(G, S, n_stream, tid, blockDim.x, L.u.lsel, out_scale, tr_sel ? P0.trace + 11 : nullptr);
                 __syncthreads();
-                if (tid == 0 && B.verdict)
-                    (void)__hip_atomic_fetch_add(B.verdict, 1ull | ((bad ? 1ull : 0ull) << (32u + q)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (tid == 0 && B.verdict) {
+                    const unsigned long long add = 1ull | ((bad ? 1ull : 0ull) << (32u + q));
+                    const unsigned long long done = __hip_atomic_fetch_add(B.verdict, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + add;
+                    // (the selection that completes the word tells the host; read there only after the launch has ended)
+                    if (B.verdict_host && (uint32_t)done == B.n_q) __hip_atomic_store(B.verdict_host, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
             } else {
                 const uint32_t l = list_of(q);
                 // Fewer lists than selector workgroups: the list's previous user may be with ANOTHER selector, still selecting --
@@ -419,7 +433,7 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
     if (trw && lane == 0 && !repair) trw[0] = __builtin_amdgcn_s_memrealtime();
     if (tid < 2u * MISC_WORDS) (&L.misc[0][0])[tid] = 0u;
     if (tid < 16u) (&L.stg_cnt[0][0])[tid] = 0u;
-    if (tid == 0u) L.pace = 0u;
+    if (tid == 0u) L.pace = (LOCAL && B.wg_pace && B.pace_quads != 0u && !repair) ? B.wg_pace[blockIdx.x - B.n_selectors] : 0u;
     if (!local && tid < 4u) {  // (local mode appends nothing to global memory: no lists, no epochs -- one trip through memory less at the head of the launch)
         const uint32_t e = tid < n_lists ? __hip_atomic_load(B.ovf_epoch + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
         L.epoch0[tid] = e;
@@ -457,6 +471,7 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
         // the default priority got ONE pass per query (traced), i.e. the threshold arrived when the query was over.
         // (local thresholds: the query is short and the workgroup's waves wait for this wave's next x: it must not queue behind them)
         if (reducer || local) __builtin_amdgcn_s_setprio(3);
+        if (LOCAL && B.wg_times && lane == 0) B.wg_times[(size_t)BATCH_MAX * gridDim.x + bid] = __builtin_amdgcn_s_memrealtime();
         uint32_t staged = 0u, tail = 0u;
         uint32_t gate_seen = 0u;  // (exact mode: queries [0, gate_seen) have had their overflow list seen free by this wave)
         const bool carry_local = local && B.wg_prior != nullptr;
@@ -712,10 +727,13 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
                         // the pause per packet of the next query (bits 0-7, units of pace_quads x 128 cycles): 3, 2, 1 for the first
                         // three eighths of the field; bit 8: the last third gets the higher issue priority
                         const uint32_t e8 = 8u * rank / n_wg;  // 0..7
-                        const uint32_t lvl = (e8 < B.pace_levels ? B.pace_levels - e8 : 0u) | (3u * rank >= 2u * n_wg ? 256u : 0u);
+                        uint32_t units = (e8 < B.pace_levels ? (B.pace_levels - e8) * pace_q : 0u) + B.pace_base;  // (per packet, units of s_sleep(2) = 128 cycles)
+                        units = units > 255u ? 255u : units;
+                        const uint32_t lvl = units | (3u * rank >= 2u * n_wg ? 256u : 0u);
                         if (lane == 0) __hip_atomic_store(&L.pace, lvl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     } else if (lane == 0)
                         (void)__hip_atomic_fetch_add(B.tickets + 32u * set_of(tail), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (LOCAL && B.wg_times && lane == 0) B.wg_times[(size_t)set_of(tail) * gridDim.x + bid] = __builtin_amdgcn_s_memrealtime();
                     if (trw && lane == 0 && TRSLOT(tail) < 3u) trw[4 + TRSLOT(tail)] = __builtin_amdgcn_s_memrealtime();
                     if (trw && lane == 0 && TRSLOT(tail) == 1u) {
                         trw[3] = dbg_first_duty;
@@ -726,6 +744,7 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
             }
             if (tail == nq) {
                 if (carry_local && lane == 0) B.wg_prior[bid] = wg_prior;
+                if (pace_q != 0u && B.wg_pace && lane == 0 && !repair) B.wg_pace[bid] = lds_load(&L.pace);
                 break;
             }
             if (local) __builtin_amdgcn_s_sleep(2);
@@ -746,39 +765,45 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
     constexpr bool INT = int_sums<QM>();
 
     Pkt<C, VT> buf[NBUF];
-    uint32_t rbs[NBUF];
-    // Requests run NBUF - 1 packets ahead of the reduction, through the queries of the phase in order. Two running pointers and a
-    // down-counter per request; past the end of the phase the last packet is requested again (a fixed number of younger loads
-    // lets the compiler wait with a counted vmcnt).
+    // Requests run NBUF - 1 packets ahead of the reduction, through the queries of the phase in order. Per request (round 5: 5
+    // scalar instructions where round 4 spent ~25 and three 64-bit vector adds): a down-counter, one scalar add on the packet's byte
+    // offset; the query's stream copy changes behind the counter's zero. Past the end of the phase the last packet is requested
+    // again (step 0: a fixed number of younger loads lets the compiler wait with a counted vmcnt). fp32 streams are fetched with
+    // buffer loads (load_packet_buf): resource = this wave's partition in the query's stream copy. The row base of a packet is
+    // looked up on the candidate path only (pkt_row[p0 + jc], a scalar load where round 4 carried one per packet).
+    constexpr bool BUF = C == 4 && (VT == 0 || VT == 4);
     auto stream_of = [&](uint32_t q) __attribute__((always_inline)) -> const uint8_t * {
         return RESIDENT ? B.replicas[q % B.n_replicas] : B.io[qx(q)].packets;
     };
     const size_t part_off = (size_t)p0 * P0.packet_bytes;
-    const uint8_t *pk_a = stream_of(0u) + part_off;
-    const uint32_t *row_a = P0.pkt_row + p0;
-    uint32_t qa = 0u, req_left = np;
-    bool req_done = false;
-#define TKSPMV_REQUEST(dst, rb_dst)                                                                                   \
+    const uint32_t part_bytes = np * P0.packet_bytes;
+    const uint8_t *pk_a = stream_of(0u) + part_off;  // first byte of this wave's partition in the stream copy of the query being requested
+    __amdgpu_buffer_rsrc_t rsrc = stream_resource(pk_a, part_bytes);
+    LaneOffsets lo{0u, 0u};
+    if constexpr (BUF) lo = lane_offsets<C, VT>(lane);
+    uint32_t qa = 0u, req_left = np, req_off = 0u, req_step = P0.packet_bytes;
+#define TKSPMV_REQUEST(dst)                                                                                           \
     do {                                                                                                              \
-        if (req_left == 0u && !req_done) { /* the previous request was the last of its query */                        \
+        if (req_left == 0u) { /* the previous request was the last of its query */                                     \
             ++qa;                                                                                                     \
-            if (!RESIDENT && qa == nq) req_done = true;                                                               \
-            else {                                                                                                    \
+            if (!RESIDENT && qa == nq) { /* the phase's last packet, again and again */                                \
+                req_off -= req_step;                                                                                  \
+                req_step = 0u;                                                                                        \
+                req_left = 0x7FFFFFFFu;                                                                               \
+            } else {                                                                                                  \
                 req_left = np;                                                                                        \
+                req_off = 0u;                                                                                         \
                 pk_a = stream_of(qa) + part_off;                                                                      \
-                row_a = P0.pkt_row + p0;                                                                              \
+                if constexpr (BUF) rsrc = stream_resource(pk_a, part_bytes);                                          \
             }                                                                                                         \
         }                                                                                                             \
-        load_packet<C, VT>(pk_a, lane, dst);                                                                          \
-        rb_dst = scalar_load(row_a);                                                                                  \
-        if (!req_done && --req_left != 0u) {                                                                          \
-            pk_a += P0.packet_bytes;                                                                                  \
-            ++row_a;                                                                                                  \
-        }                                                                                                             \
+        if constexpr (BUF) load_packet_buf<C, VT>(rsrc, req_off, lo, dst);                                            \
+        else load_packet<C, VT>(pk_a + req_off, lane, dst);                                                           \
+        --req_left;                                                                                                   \
+        req_off += req_step;                                                                                          \
     } while (0)
 #pragma unroll
-    for (int u = 0; u < NBUF - 1; ++u) TKSPMV_REQUEST(buf[u], rbs[u]);
-    rbs[NBUF - 1] = 0u;
+    for (int u = 0; u < NBUF - 1; ++u) TKSPMV_REQUEST(buf[u]);
 
     uint32_t qc = 0u, jc = 0u;  // query / packet being reduced
     float carry = 0.0f, min_units = 0.0f;
@@ -795,8 +820,7 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
 #pragma unroll
         for (int u = 0; u < NBUF; ++u) {
             const Pkt<C, VT> &cur = buf[u];
-            const uint32_t rb_cur = rbs[u];
-            TKSPMV_REQUEST(buf[(u + NBUF - 1) % NBUF], rbs[(u + NBUF - 1) % NBUF]);
+            TKSPMV_REQUEST(buf[(u + NBUF - 1) % NBUF]);
             if (jc == 0u) {  // a new query starts: its x must have been staged
                 carry = 0.0f;  // (a partition starts on a row boundary)
                 mp = L.misc[qc & 1u];
@@ -838,7 +862,7 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
             }
             // a workgroup ahead of the field yields: fewer requests from it, more bandwidth for the XCDs that lag
 #pragma unroll 1
-            for (uint32_t z = pace * pace_q; z != 0u; --z) __builtin_amdgcn_s_sleep(2);
+            for (uint32_t z = pace; z != 0u; --z) __builtin_amdgcn_s_sleep(2);
             const uint32_t tau_bits = lds_load(&mp[MISC_TAU]);
             const float tau = __uint_as_float(tau_bits);
             const Reduced<C> Rd = reduce_packet<C, QM>(cur, carry, xbase, P0.fixed_mask);
@@ -862,6 +886,7 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
                 }
                 if (tau_now == tau || __any(trig >= tau_now)) {
                     const RowSums<C> R = expand<C, INT>(Rd, packet_flags<C, QM>(cur));
+                    const uint32_t rb_cur = scalar_load(P0.pkt_row + p0 + jc);  // (row of the first row end of this packet)
                     // (local: what does not fit the list is dropped under a recorded bound, not appended to global memory)
                     const float wm = offer_candidates<C, QM, WAVE_CAP>(P, R, rb_cur, tau_now, lane, grp_local, publishes, wcand, wcnt, mp, local);
                     if (local && wm > top2 && wm >= min_units) {
@@ -989,9 +1014,11 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const BatchArgs A) {
         if (blockIdx.x == 0u && tid == 0u && B.verdict_next) __hip_atomic_store(B.verdict_next, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (B.prior_block && B.prior_block[B.gate_parity ? 7 : 4] != 0u) {
             // the gate is closed: nothing is streamed here; every query goes through the exact launch that follows
-            if (blockIdx.x == 0u && tid == 0u)
-                __hip_atomic_store(B.verdict, (unsigned long long)B.n_q | ((B.n_q >= 32u ? 0xFFFFFFFFull : ((1ull << B.n_q) - 1ull)) << 32), __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
+            if (blockIdx.x == 0u && tid == 0u) {
+                const unsigned long long all = (unsigned long long)B.n_q | ((B.n_q >= 32u ? 0xFFFFFFFFull : ((1ull << B.n_q) - 1ull)) << 32);
+                __hip_atomic_store(B.verdict, all, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (B.verdict_host) __hip_atomic_store(B.verdict_host, all, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
             return;
         }
         batch_phase<C, XCOLS, QM, DBG, false, true>(P0, SP0, B, false, L);
@@ -999,9 +1026,12 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const BatchArgs A) {
     }
     if (B.repair != 0u) {
         // ---- which queries of the LOCAL launch failed their check? (that launch is over: the word is complete) ------------------
-        const unsigned long long v = __hip_atomic_load(B.verdict, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t mask = (uint32_t)(v >> 32);
-        const bool gate_was_closed = B.prior_block && B.prior_block[B.gate_parity ? 7 : 4] != 0u;
+        // (repair = 2: a late repair from the host's side of the verdict -- the device word has been reused since; the gate's
+        //  bookkeeping stays with the in-stream launches that follow an observed failure)
+        const bool late = B.repair == 2u;
+        const unsigned long long v = late ? 0ull : __hip_atomic_load(B.verdict, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t mask = late ? B.repair_mask : (uint32_t)(v >> 32);
+        const bool gate_was_closed = !late && B.prior_block && B.prior_block[B.gate_parity ? 7 : 4] != 0u;
         if (tid < 64u) {
             const bool f = tid < B.n_q && ((mask >> tid) & 1u) != 0u;
             const uint64_t bm = __ballot(f);
@@ -1010,7 +1040,7 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const BatchArgs A) {
         }
         __syncthreads();
         // (behind a closed gate the queries did not fail, they were never tried: the closure counts down)
-        if (blockIdx.x == 0u && tid == 0u && B.prior_block) gate_update(B, gate_was_closed ? 0u : L.rq[BATCH_MAX]);
+        if (!late && blockIdx.x == 0u && tid == 0u && B.prior_block) gate_update(B, gate_was_closed ? 0u : L.rq[BATCH_MAX]);
         if (L.rq[BATCH_MAX] == 0u) return;
     }
     batch_phase<C, XCOLS, QM, DBG, false, false>(P0, SP0, B, B.repair != 0u, L);

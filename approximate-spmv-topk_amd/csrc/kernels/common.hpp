@@ -204,6 +204,38 @@ __device__ __forceinline__ void load_packet(const uint8_t *__restrict__ pk, uint
     }
 }
 
+// The same packet through BUFFER loads (round 5; fp32 streams of 4 entries per lane: value types 0 and 4). A buffer load takes its
+// address as resource (4 SGPRs: the partition's first byte in the stream copy of the query, its length) + SGPR byte offset (the
+// packet) + VGPR byte offset (the lane's share, the same for every packet): nothing is added per packet on the vector unit -- the
+// flat form spent three 64-bit vector adds per packet on the two addresses --, and the packet pointer is ONE scalar add. Loads
+// beyond the partition's length return 0 (never requested: the kernels clamp to the last packet).
+struct LaneOffsets {
+    uint32_t v, c;  // byte offsets of the lane's 16 bytes of values / of its column words inside a packet
+};
+template <int C, int VT>
+__device__ __forceinline__ LaneOffsets lane_offsets(uint32_t lane) {
+    static_assert(C == 4 && (VT == 0 || VT == 4), "buffer-load packets: fp32 values, 4 entries per lane");
+    LaneOffsets o;
+    o.v = lane * 16u;
+    o.c = VT == 4 ? (uint32_t)C * 256u + (lane >> 1) * 12u + (lane & 1u) * 4u : (uint32_t)C * 256u + lane * 8u;
+    return o;
+}
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t stream_resource(const uint8_t *first_byte, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(first_byte), 0, (int)bytes, 0x00020000);  // (raw buffer, 32-bit data format)
+}
+template <int C, int VT>
+__device__ __forceinline__ void load_packet_buf(__amdgpu_buffer_rsrc_t rsrc, uint32_t packet_off, const LaneOffsets &lo, Pkt<C, VT> &o) {
+    const u32x4 f = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lo.v, packet_off, 2);  // (aux 2: non-temporal, like the flat form)
+    o.v[0] = __uint_as_float(f.x);
+    o.v[VT == 0 || VT == 4 ? 1 : 0] = __uint_as_float(f.y);
+    o.v[VT == 0 || VT == 4 ? 2 : 0] = __uint_as_float(f.z);
+    o.v[VT == 0 || VT == 4 ? 3 : 0] = __uint_as_float(f.w);
+    const u32x2 c = __builtin_amdgcn_raw_buffer_load_b64(rsrc, lo.c, packet_off, 2);
+    o.cw[0] = c.x;
+    o.cw[1] = c.y;
+}
+
 // Q1.7 helpers (restating ap_ufixed<8,1,AP_TRN_ZERO>, fpga_types.hpp:20: 1 integer + 7 fraction bits, truncation).
 // Conversion from float saturates at the top of the range (the HLS type would wrap there; inputs are expected in
 // [0, 2)). Products are truncated to Q1.7 and wrap to 8 bits; sums wrap to 8 bits (mod 2.0).

@@ -192,20 +192,24 @@ __device__ __forceinline__ Reduced<C> reduce_core(float (&p)[C], const uint32_t 
 
     // Lane masks of the clipped scan, computed once on the scalar unit from H = lanes holding a row end:
     //   M_d  : no row end in lanes (l-d, l]                     (steps row_shr:1,2,4,8)
-    //   P16  : no row end in [first lane of l's 16-lane row, l]  (step row_bcast:15)
-    //   P32  : no row end in [first lane of l's 32-lane half, l] (step row_bcast:31)
+    //   P16  : no row end in [first lane of l's 16-lane row, l]  (step row_bcast:15; only rows 1 and 3 have a source)
+    //   P32  : no row end in [lane 32, l]                        (step row_bcast:31; only lanes 32..63 have a source)
+    // Round 5: 15 scalar instructions where round 4's doubling chain with its clipping constants took 25.
+    // * M_d is the plain doubling chain M_2d = M_d & (M_d << d). It runs across the 16-lane rows, which is immaterial: the lanes it
+    //   concerns (lane % 16 < d) receive 0 from the DPP shift whatever their mask says.
+    // * P16 and P32 are "trailing ones" of a field of M1 = ~H: f & ~(f + 1) keeps exactly the ones below the field's first zero --
+    //   the lanes from the row's (half's) first lane up to the first row end. One add serves both 16-bit fields (rows 1 and 3; the
+    //   fields between them are cleared first, so a carry out of row 1 stops in row 2's empty field); P32 is the same on the upper
+    //   32-bit word.
     const uint64_t H = __ballot(has_end);
     const uint64_t M1 = ~H;
-    // One doubling chain serves all steps: its links are clipped at the start of every 16-lane row (the constants fill the
-    // bits shifted in there), which is what P16 needs; for the row_shr steps the clipping is immaterial, because the
-    // lanes it concerns (lane % 16 < d) receive 0 from the DPP shift whatever their mask says.
-    const uint64_t M2 = M1 & ((M1 << 1) | 0x0001000100010001ull);
-    const uint64_t M4 = M2 & ((M2 << 2) | 0x0003000300030003ull);
-    const uint64_t M8 = M4 & ((M4 << 4) | 0x000F000F000F000Full);
-    const uint64_t P16 = M8 & ((M8 << 8) | 0x00FF00FF00FF00FFull);
-    // upper row of each half also needs the whole lower row clear: bit 15 / 47 of P16
-    const uint64_t low_clear = ((P16 >> 15) & 0x0000000100000001ull) * 0xFFFF0000ull;
-    const uint64_t P32 = P16 & (low_clear | 0x0000FFFF0000FFFFull);
+    const uint64_t M2 = M1 & (M1 << 1);
+    const uint64_t M4 = M2 & (M2 << 2);
+    const uint64_t M8 = M4 & (M4 << 4);
+    const uint64_t X16 = M1 & 0xFFFF0000FFFF0000ull;
+    const uint64_t P16 = X16 & ~(X16 + 0x0001000000010000ull);
+    const uint32_t Z32 = (uint32_t)(M1 >> 32);
+    const uint64_t P32 = (uint64_t)(Z32 & ~(Z32 + 1u)) << 32;
 
     float vv = tail;
     {
@@ -224,10 +228,10 @@ __device__ __forceinline__ Reduced<C> reduce_core(float (&p)[C], const uint32_t 
         // register written by the previous vector instruction needs two wait states; the compiler does not look inside asm.)
         if (INT) asm("s_nop 1\n\tv_add_u32_dpp %0, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(t) : "v"(vv));
         else asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(t) : "v"(vv));  // lane 15 -> row 1, lane 47 -> row 3
-        vv = __builtin_amdgcn_inverse_ballot_w64(P16 & 0xFFFF0000FFFF0000ull) ? t : vv;
+        vv = __builtin_amdgcn_inverse_ballot_w64(P16) ? t : vv;
         if (INT) asm("s_nop 1\n\tv_add_u32_dpp %0, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(t) : "v"(vv));
         else asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(t) : "v"(vv));  // lane 31 -> rows 2 and 3
-        vv = __builtin_amdgcn_inverse_ballot_w64(P32 & 0xFFFFFFFF00000000ull) ? t : vv;
+        vv = __builtin_amdgcn_inverse_ballot_w64(P32) ? t : vv;
     }
     const float cin = dpp_zero<DPP_WAVE_SHR1, 0xF>(vv);  // lane l-1's inclusive sum; 0 for lane 0
     R.S = add_rn<INT>(cin, head);

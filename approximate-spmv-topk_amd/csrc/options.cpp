@@ -23,6 +23,13 @@ static const OptionDef k_options[] = {
     {"OVF_LISTS", "tuning", "1 | 2 | 4 (default 4; 2 for engines that stream with local thresholds; at least 2 wherever the deferred scheme can run)", "overflow lists of the exact kernel (8 bytes per row each), shared round robin by the queries of a launch under flow control"},
     {"PACE", "tuning", "0..32 (default by size)", "pacing quantum of the batch kernel's workgroups by rank (s_sleep units); 0 = none"},
     {"PACE_LEVELS", "tuning", "1..8", "number of distinct pacing ranks"},
+    {"AUTOTUNE", "behaviour", "0 | 1 (default 1)", "1: tkspmv_create measures a handful of pacing settings on the matrix it has just packed (engines of checked local thresholds that pace at all; ~10 ms) and keeps the fastest; PACE / PACE_LEVELS / PACE_BASE switch it off"},
+    {"PACE_BASE", "tuning", "0..64 (default 0)", "pause per packet (s_sleep units) of EVERY workgroup of the batch kernel, whatever its rank: a uniform throttle (tuning runs)"},
+    {"REPAIR", "behaviour", "host | stream (default host)",
+     "who looks at the verdict of a launch of checked local thresholds: host = the launch goes out alone once the verdicts the host has seen are clean, "
+     "and tkspmv_synchronize / tkspmv_read (any engine call that waits for the engine's stream) repair a flagged query with an exact launch; "
+     "stream = the exact launch follows every local launch in the stream (always so on a caller's stream and for 64 launches after an observed failure)"},
+    {"OVERLAP", "behaviour", "0 | 1 (default 1)", "1: consecutive launches of one sequence of checked local thresholds alternate between two streams while they go out trusted (REPAIR=host): the next launch's ramp fills the previous one's tail; 0: one launch at a time"},
     {"FUSED", "behaviour", "0 | 1 (default 1 where the selection fits one workgroup)", "0: stream and selection as two launches"},
     {"RADIX", "behaviour", "0 | 1 (default: k above 3/8 of the publishing groups)", "1: scores + radix select instead of thresholded streaming"},
     {"MULTI_Q", "behaviour", "0 | 1 | 3 | 5 | 8 (default by size; desc.multi_q wins)", "queries per pass of the small-matrix kernel (multi_kernel); 0 = off"},
@@ -49,6 +56,7 @@ static const OptionDef k_options[] = {
     // ---- diagnostics (DBG instantiations of the kernels; never on by default) ----
     {"STATS", "diagnostic", "set = on", "per-launch counters (offers, triggers) in tkspmv_debug_counters"},
     {"STAMPS", "diagnostic", "set = on", "device-clock stamps of the kernel phases"},
+    {"WG_TIMES", "diagnostic", "set = on", "the batch kernel of local thresholds stamps every workgroup's hand-overs of its last launch ([33][grid] ticks of 10 ns, read through tkspmv_debug_trace): who leads, who lags (tools/wg_times.py)"},
     {"TRACE", "diagnostic", "set = on", "per-wave trace buffer for tkspmv_debug_trace"},
     {"RESIDENT_STATS", "diagnostic", "set = on", "counters of the resident kernel"},
     {"DEBUG_OCC", "diagnostic", "set = on", "print launch geometry and occupancy at creation"},

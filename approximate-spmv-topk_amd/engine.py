@@ -162,14 +162,20 @@ class SpMV:
     def debug_counters(self):
         """Checked thresholds of back-to-back queries (info()["batch_mode"]): how many selections failed their check so far (and
         sent their query through the repair launch), the suspension state of carried thresholds, batch launches so far."""
-        out = (C.c_uint64 * 10)()
-        _lib.check(_lib.lib().tkspmv_debug_counters(self._h, out, 10))
+        out = (C.c_uint64 * 14)()
+        _lib.check(_lib.lib().tkspmv_debug_counters(self._h, out, 14))
         return {"checks_failed": int(out[0]), "suspension_length": int(out[1]), "suspended_for": int(out[2]), "batch_launches": int(out[3]),
                 "local_off_for_launches": int(out[4]), "local_off_length": int(out[5]),
                 # tkspmv_run through the single-query kernel (local thresholds, checked): launches, queries repeated through the
                 # exact launch because their check failed, and the suspension of carried thresholds that follows a failure
                 "single_launches": int(out[6]), "single_repairs": int(out[7]), "single_checks_failed": int(out[8]),
-                "single_suspended_for": int(out[9])}
+                "single_suspended_for": int(out[9]),
+                # batch launches that went out without a repair launch behind them (the host looks at their verdicts when it waits),
+                # and the repairs that had to follow after all
+                "trusted_launches": int(out[10]), "late_repairs": int(out[11]),
+                # the pacing of back-to-back queries in force and what tkspmv_create's measurement of it took (0: static default)
+                "pace_quantum": int(out[12]) & 0xFF, "pace_levels": (int(out[12]) >> 8) & 0xFF, "pace_base": (int(out[12]) >> 16) & 0xFF,
+                "pace_tuned_us": int(out[13])}
 
     def synchronize(self):
         _lib.check(_lib.lib().tkspmv_synchronize(self._h))

@@ -198,8 +198,8 @@ int tkspmv_enqueue(tkspmv_t *e, const float *dev_x, uint32_t *dev_idx, float *de
 /* Enqueue `count` queries back to back (query i uses dev_xs + (i % n_x) * cols), no host sync; the engine-owned
  * result buffers end up holding the last query's top-k. Launch scheme: the batch kernel, up to 32 queries per launch,
  * selections running beside the stream inside the launch (wide x or large k: one launch per query with
- * the selection of query i inside the launch of query i+1 and a small closing launch); the sequence is complete in stream
- * order when the call returns. */
+ * the selection of query i inside the launch of query i+1 and a small closing launch); on a caller's stream the sequence is
+ * complete in stream order when the call returns, on the engine's stream after tkspmv_synchronize (see there). */
 int tkspmv_enqueue_many(tkspmv_t *e, const float *dev_xs, int32_t n_x, int32_t count, void *stream);
 /* A batch of `count` queries (the loop of the reference's drivers, host_spmv_bscsr.cpp main: for each test vector
  * reset -> operator() -> read_result): query i = dev_xs + i * cols, its k results go to dev_idx + i * k and
@@ -220,6 +220,13 @@ int tkspmv_enqueue_batch(tkspmv_t *e, const float *dev_xs, int32_t count, uint32
 int tkspmv_enqueue_multi(tkspmv_t *e, const float *dev_xs, int32_t count, uint32_t *dev_idx, float *dev_val, void *stream);
 /* tkspmv_time_queries for the multi-query path: *ns_per_query = time of the whole sequence / iters. */
 int tkspmv_time_multi(tkspmv_t *e, const float *dev_xs, int32_t n_x, int32_t iters, double *ns_per_query);
+/* Waits for the engine's stream. Results of queries enqueued with stream = NULL (the engine's own stream) are FINAL when this call
+ * (or tkspmv_read, or any other engine call that waits for that stream) has returned: engines that stream with checked
+ * workgroup-local thresholds (tkspmv_info.batch_mode bits 8-15) look at their launches' verdicts here and run a query whose check
+ * failed again through the exact kernel -- the device-side equivalent of the reference's wait() after operator()
+ * (host_spmv_bscsr.cpp:354-358). The query vectors of such launches must stay unchanged until then. (Option REPAIR=stream keeps the
+ * exact launch behind every local launch in the stream, as it always is on a caller's stream: results are then final in stream
+ * order, for 1-2 % of the time per query.) */
 int tkspmv_synchronize(tkspmv_t *e);
 
 /* Copy back the k results of the last completed query, sorted by (score desc, row desc)
@@ -242,7 +249,11 @@ int tkspmv_debug_trace(tkspmv_t *e, uint64_t *host, uint64_t max_words, uint64_t
  * for 8 .. 1024 launches: data that keeps its best rows together), out[5] = the length of the latest such closure. n >= 6.
  * With n >= 10 also tkspmv_run's single-query kernel (workgroup-local thresholds, checked by its selection): out[6] = its
  * launches, out[7] = queries run again through the exact launch because the check failed, out[8] = failed checks as the device
- * counted them, out[9] = selections to go until carried thresholds are used again. Synchronises the engine's stream. */
+ * counted them, out[9] = selections to go until carried thresholds are used again. With n >= 12: out[10] = batch launches that
+ * went out without a repair launch behind them (see tkspmv_synchronize), out[11] = the late repairs that had to follow after all.
+ * With n >= 14: out[12] = the pacing of back-to-back queries in force (pause quantum | levels << 8 | uniform pause << 16; units of
+ * 128 cycles per packet), out[13] = microseconds tkspmv_create spent measuring it on this box (option AUTOTUNE; 0: static default).
+ * Synchronises the engine's stream. */
 int tkspmv_debug_counters(tkspmv_t *e, uint64_t *out, int32_t n);
 
 /* `iters` queries back to back on the engine stream (cycling over n_x device-resident vectors), ONE hipEvent pair

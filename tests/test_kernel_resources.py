@@ -102,7 +102,7 @@ template __global__ void stream_kernel<4, false, 1024, 0, 3, false>(const Stream
             elif cur is not None:
                 if "scratch_" in ln:
                     cur["scratch"] += 1
-                if ("global_load_dword" in ln and " nt" in ln) or "v_add_f32_dpp" in ln:  # (a packet request; the fp32 scan)
+                if (("global_load_dword" in ln or "buffer_load_dword" in ln) and " nt" in ln) or "v_add_f32_dpp" in ln:  # (a packet request -- flat or, since round 5, buffer loads; the fp32 scan)
                     cur["hot"] = True
         hot = [b for b in blocks if b["hot"]]
         assert len(hot) >= 3, "the streaming loop was not found in the ISA of " + lines[start].split(":")[0]
