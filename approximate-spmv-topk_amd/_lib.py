@@ -10,7 +10,7 @@ LIB_PATH = os.environ.get("TKSPMV_LIB") or os.path.join(_HERE, "libtkspmv.so")  
 
 OK, ERR_INVALID, ERR_NOT_SORTED, ERR_DEVICE, ERR_NOMEM, ERR_IO, ERR_UNSUPPORTED, ERR_STATE = range(8)
 F32, Q1_7, Q1_7_WIDE, F16, FIXED, Q1_7_F32 = 0, 1, 2, 3, 4, 5
-IMPL_STREAM, IMPL_ROW_PER_LANE, IMPL_SCORES_SELECT, IMPL_RESIDENT = 0, 1, 2, 3
+IMPL_STREAM, IMPL_ROW_PER_LANE, IMPL_SCORES_SELECT = 0, 1, 2
 MAX_COLS = 16384
 MAX_K = 1024
 

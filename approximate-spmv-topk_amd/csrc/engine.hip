@@ -111,22 +111,6 @@ struct EngineImpl {
         (void)*hdp_flush;  // (the read completes only behind the posted writes before it)
     }
     int host_path = 1;                  // TKSPMV_HOST_PATH=0: the plain path (stream synchronisation + copies)
-    // Resident kernel (desc.impl = TKSPMV_IMPL_RESIDENT; batch_kernel<.., RESIDENT = true>): one launch that stays on the
-    // GPU and serves tkspmv_run queries as the host submits them through pinned memory -- see BatchParams.
-    struct ResidentCtl {
-        volatile uint32_t request;  // host -> device: epoch of the newest submitted query, or RESIDENT_QUIT
-        uint32_t pad0[31];
-        volatile uint32_t exited;   // device -> host: 1 once the kernel has left (quit request or idle timeout)
-        uint32_t pad1[31];
-    };
-    ResidentCtl *h_ctl = nullptr, *h_ctl_dev = nullptr;
-    uint32_t *d_xr = nullptr, *d_dev_epoch = nullptr;
-    hipStream_t rstream = nullptr;
-    bool resident_capable = false;
-    mutable bool resident_running = false;
-    bool x_on_host_only = false;        // set_query left x in h_x without uploading it (resident engines): see ensure_x
-    bool resident_stats = false;
-    double rs_n = 0, rs_host = 0, rs_dev = 0, rs_pub = 0, rs_tick = 0;
     float *h_x_dev = nullptr;           // h_x as the device sees it (TKSPMV_HOST_X=direct: kernels read x from host memory)
     bool host_x_direct = false;
     bool run_events = false;            // TKSPMV_RUN_EVENTS=1: tkspmv_run brackets the fused launch with a hipEvent pair instead of taking the kernel's own duration
@@ -443,16 +427,16 @@ struct EngineImpl {
     // can_batch: x of at most 1024 columns (it is held twice in LDS). local: the kernel of the checked local thresholds.
     template <bool LOCAL>
     batch_fn batch_kernel_of() const {
-        if (desc.precision == TKSPMV_Q1_7) return &batch_kernel<4, 1024, 1, false, false, LOCAL>;
-        if (desc.precision == TKSPMV_Q1_7_WIDE) return &batch_kernel<4, 1024, 2, false, false, LOCAL>;
-        if (desc.precision == TKSPMV_F16) return &batch_kernel<4, 1024, 3, false, false, LOCAL>;
+        if (desc.precision == TKSPMV_Q1_7) return &batch_kernel<4, 1024, 1, false, LOCAL>;
+        if (desc.precision == TKSPMV_Q1_7_WIDE) return &batch_kernel<4, 1024, 2, false, LOCAL>;
+        if (desc.precision == TKSPMV_F16) return &batch_kernel<4, 1024, 3, false, LOCAL>;
         if (desc.precision == TKSPMV_FIXED)
-            return pm.precision == Precision::FIXED20 ? &batch_kernel<4, 1024, 6, false, false, LOCAL>
-                                                      : (pm.precision == Precision::FIXED26 ? &batch_kernel<4, 1024, 8, false, false, LOCAL> : &batch_kernel<4, 1024, 4, false, false, LOCAL>);
-        if (desc.precision == TKSPMV_Q1_7_F32) return &batch_kernel<4, 1024, 5, false, false, LOCAL>;
-        if (info.packet_entries == 512) return &batch_kernel<8, 1024, 0, false, false, LOCAL>;
-        if (pm.precision == Precision::F32C12) return dbg_kernels ? &batch_kernel<4, 1024, 7, true, false, LOCAL> : &batch_kernel<4, 1024, 7, false, false, LOCAL>;
-        return dbg_kernels ? &batch_kernel<4, 1024, 0, true, false, LOCAL> : &batch_kernel<4, 1024, 0, false, false, LOCAL>;
+            return pm.precision == Precision::FIXED20 ? &batch_kernel<4, 1024, 6, false, LOCAL>
+                                                      : (pm.precision == Precision::FIXED26 ? &batch_kernel<4, 1024, 8, false, LOCAL> : &batch_kernel<4, 1024, 4, false, LOCAL>);
+        if (desc.precision == TKSPMV_Q1_7_F32) return &batch_kernel<4, 1024, 5, false, LOCAL>;
+        if (info.packet_entries == 512) return &batch_kernel<8, 1024, 0, false, LOCAL>;
+        if (pm.precision == Precision::F32C12) return dbg_kernels ? &batch_kernel<4, 1024, 7, true, LOCAL> : &batch_kernel<4, 1024, 7, false, LOCAL>;
+        return dbg_kernels ? &batch_kernel<4, 1024, 0, true, LOCAL> : &batch_kernel<4, 1024, 0, false, LOCAL>;
     }
     batch_fn batch_kernel_for(bool local = false) const { return local ? batch_kernel_of<true>() : batch_kernel_of<false>(); }
     // n <= BATCH_MAX queries in one launch of the batch kernel; results complete in stream order after the launch.
@@ -749,52 +733,6 @@ struct EngineImpl {
         S.unit_inv_in = st[set].unit_inv;  // written by the (unfused) stream kernel of that query
         hipLaunchKernelGGL(select_kernel, dim3(1), dim3(SEL_THREADS), 0, s, S);
     }
-    // ---- resident kernel -------------------------------------------------------------------------------------------------
-    hipError_t start_resident() const {
-        hipError_t e = hipMemsetAsync(d_dev_epoch, 0, 64, rstream);
-        if (e != hipSuccess) return e;
-        h_ctl->exited = 0u;
-        h_ctl->request = host_epoch;  // nothing pending: the next query is host_epoch + 1
-        std::atomic_thread_fence(std::memory_order_seq_cst);
-        StreamParams P = stream_params(nullptr, 0);
-        P.fused = 0u;
-        SelectParams S = select_params(d_out_idx, d_out_val, 0);
-        S.host_out = h_res_dev;
-        BatchParams B{};
-        static_cast<SetAddr &>(B) = set_addr(0);
-        B.n_q = 0u;
-        B.n_selectors = n_sel_wg;  // (only the first one works in this mode; the others leave -- the partitions were dealt for grid - n_sel_wg)
-        B.ovf_epoch = d_ovf_epoch;
-        B.ovf_lists = std::min(ovf_lists, 4u);  // (engines with one list per set -- the multi-query ones -- lend the batch kernel their first four)
-        B.tickets = d_tickets;
-        B.io[0].out_idx = d_out_idx;
-        B.io[0].out_val = d_out_val;
-        B.host_request = const_cast<const uint32_t *>(&h_ctl_dev->request);
-        B.host_exited = const_cast<uint32_t *>(&h_ctl_dev->exited);
-        B.host_x = h_x_dev;
-        B.xr = d_xr;
-        B.dev_epoch = d_dev_epoch;
-        B.epoch0 = host_epoch;
-        B.idle_ticks = resident_idle_ticks;
-        B.n_replicas = d_replicas.empty() ? 1u : (uint32_t)std::min<size_t>(d_replicas.size(), 8);
-        for (uint32_t r = 0; r < 8u; ++r) B.replicas[r] = d_replicas.empty() ? d_packets : d_replicas[r % d_replicas.size()];
-        if (pm.precision == Precision::F32C12)
-            hipLaunchKernelGGL((batch_kernel<4, 1024, 7, false, true, false>), dim3(grid), dim3(block + 64), 0, rstream, BatchArgs{P, S, B});
-        else
-            hipLaunchKernelGGL((batch_kernel<4, 1024, 0, false, true, false>), dim3(grid), dim3(block + 64), 0, rstream, BatchArgs{P, S, B});
-        e = hipGetLastError();
-        resident_running = e == hipSuccess;
-        return e;
-    }
-    // Ask the resident kernel to leave and wait for it (bounded: it also leaves by itself after its idle timeout).
-    hipError_t stop_resident() const {
-        if (!resident_running) return hipSuccess;
-        h_ctl->request = RESIDENT_QUIT;
-        std::atomic_thread_fence(std::memory_order_seq_cst);
-        const hipError_t e = hipStreamSynchronize(rstream);
-        resident_running = false;
-        return e;
-    }
     // Does the host-visible result block add up to the checksum its writer left behind the flag (result_checksum_term)? The block
     // is written with relaxed system-scope stores; the flag alone proves nothing by the memory model.
     bool result_block_complete(uint32_t epoch) const {
@@ -808,28 +746,12 @@ struct EngineImpl {
         for (size_t i = 0; i < k; ++i) sum += result_checksum_term(r[i], r[k + i], (uint32_t)i);
         return r[2 * k + 4] == sum;
     }
-    uint32_t resident_idle_ticks = 10000000u;  // 100 ms without a query: the kernel leaves (relaunched on demand)
-    // x of the last tkspmv_set_query into device memory, if a resident engine left it in pinned memory only
-    hipError_t ensure_x() {
-        if (!x_on_host_only) return hipSuccess;
-        x_on_host_only = false;
-        x_pending = true;
-        const hipError_t e = hipMemcpyAsync(d_x, h_x, (size_t)desc.cols * 4, hipMemcpyHostToDevice, stream);
-        return e != hipSuccess ? e : hipEventRecord(ev2, stream);
-    }
     // tkspmv_set_query enqueues the upload of x on the engine's stream and does not wait for it. A launch that reads d_x from
     // ANOTHER stream (tkspmv_enqueue with a caller's stream and dev_x = NULL) has no ordering against that copy -- the
     // engine's stream is non-blocking -- so it waits for the event recorded behind the copy.
     hipError_t order_x(const float *x, hipStream_t s) const {
         if (x != d_x || !x_pending || s == stream || bar_x) return hipSuccess;  // (bar_x: the host wrote x itself, nothing is enqueued)
         return hipStreamWaitEvent(s, ev2, 0);
-    }
-    // Every entry point other than set_query / run / read: the resident kernel must have left (it shares the exchange
-    // state and would compete for the whole GPU), and x must be where the launch schemes expect it.
-    hipError_t leave_resident_mode() {
-        hipError_t e = stop_resident();
-        if (e != hipSuccess) return e;
-        return ensure_x();
     }
 };
 
@@ -872,11 +794,6 @@ Engine::~Engine() {
     if (!impl_) return;
     EngineImpl &m = *impl_;
     (void)hipSetDevice(m.device);
-    (void)m.stop_resident();  // before anything is freed (hipFree would wait for it, then free what it reads)
-    if (m.resident_stats && m.rs_n > 0)
-        fprintf(stderr, "[tkspmv resident, %.0f queries, us] host: request -> flag seen %.2f | device: request seen -> x published %.2f, "
-                        "-> every workgroup delivered %.2f, -> flag raised %.2f\n",
-                m.rs_n, m.rs_host / m.rs_n / 1e3, m.rs_pub / m.rs_n / 1e3, m.rs_tick / m.rs_n / 1e3, m.rs_dev / m.rs_n / 1e3);
     if (m.stream) (void)hipStreamSynchronize(m.stream);
     void *bufs[] = {m.d_packets, m.d_pkt_row, m.d_part_first, m.d_part_count, m.d_x,
                     m.d_out_idx, m.d_out_val, m.d_scores,     m.d_stats,      m.d_done, m.d_trace, m.d_tickets,
@@ -890,10 +807,6 @@ Engine::~Engine() {
         for (void *b : eb)
             if (b) (void)hipFree(b);
     }
-    if (m.rstream) (void)hipStreamDestroy(m.rstream);
-    if (m.h_ctl) (void)hipHostFree((void *)m.h_ctl);
-    if (m.d_xr) (void)hipFree(m.d_xr);
-    if (m.d_dev_epoch) (void)hipFree(m.d_dev_epoch);
     if (m.h_x) (void)hipHostFree(m.h_x);
     if (m.h_res) (void)hipHostFree(m.h_res);
     if (m.h_verdict) (void)hipHostFree(m.h_verdict);
@@ -968,8 +881,12 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
         err = "unknown precision";
         return TKSPMV_ERR_INVALID;
     }
-    if (d.impl != TKSPMV_IMPL_STREAM && d.impl != TKSPMV_IMPL_ROW_PER_LANE && d.impl != TKSPMV_IMPL_SCORES_SELECT && d.impl != TKSPMV_IMPL_RESIDENT) {
-        err = "unknown impl (0 = stream, 1 = row per lane, 2 = scores + select, 3 = resident)";
+    if (d.impl == 3) {  // (rounds 2-4: a resident kernel serving tkspmv_run; slower than a launch per query since round 4, removed in round 5)
+        err = "impl 3 (the resident kernel) was removed: tkspmv_run through impl 0 (single_kernel) is faster";
+        return TKSPMV_ERR_UNSUPPORTED;
+    }
+    if (d.impl != TKSPMV_IMPL_STREAM && d.impl != TKSPMV_IMPL_ROW_PER_LANE && d.impl != TKSPMV_IMPL_SCORES_SELECT) {
+        err = "unknown impl (0 = stream, 1 = row per lane, 2 = scores + select)";
         return TKSPMV_ERR_INVALID;
     }
     if (d.precision == TKSPMV_FIXED ? (d.fixed_width != 0 && (d.fixed_width < 8 || d.fixed_width > 32)) : d.fixed_width != 0) {
@@ -1369,20 +1286,6 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
     if (m.d_coo_val) (void)hipFree(m.d_coo_val);
     m.d_coo_col = nullptr;
     m.d_coo_val = nullptr;
-    m.resident_capable = d.impl == TKSPMV_IMPL_RESIDENT && m.can_batch && d.precision == TKSPMV_F32 && C == 4u && m.xcols <= 1024u &&
-                         m.h_res != nullptr && m.h_x != nullptr && m.h_x_dev != nullptr;
-    if (m.resident_capable) {
-        HIP_TRY(hipHostMalloc((void **)&m.h_ctl, sizeof(EngineImpl::ResidentCtl), hipHostMallocMapped | hipHostMallocCoherent));
-        std::memset((void *)m.h_ctl, 0, sizeof(EngineImpl::ResidentCtl));
-        HIP_TRY(hipHostGetDevicePointer((void **)&m.h_ctl_dev, m.h_ctl, 0));
-        HIP_TRY(malloc_exchange((void **)&m.d_xr, 2 * 1024 * 4));
-        HIP_TRY(hipMemset(m.d_xr, 0, 2 * 1024 * 4));
-        HIP_TRY(malloc_exchange((void **)&m.d_dev_epoch, 64));
-        HIP_TRY(hipMemset(m.d_dev_epoch, 0, 64));
-        HIP_TRY(hipStreamCreateWithFlags(&m.rstream, hipStreamNonBlocking));
-        m.resident_stats = opt("RESIDENT_STATS") != nullptr;
-        if (const char *f = opt("RESIDENT_IDLE_MS")) m.resident_idle_ticks = (uint32_t)std::max(1, atoi(f)) * 100000u;
-    }
     HIP_TRY(malloc_exchange((void **)&m.d_tickets, 2 * BATCH_MAX * 32 * 4));  // (one block per launch parity: EngineImpl::bside)
     HIP_TRY(hipMemset(m.d_tickets, 0, 2 * BATCH_MAX * 32 * 4));
     HIP_TRY(malloc_exchange((void **)&m.d_verdict, 512));
@@ -1469,7 +1372,7 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
         // (select_body): 32 MB at 1M rows, 320 MB at 10M. Multi-query engines keep one list per set (their groups' selections are
         // owed across launches).
         if (const char *f = opt("BATCH_MAX")) m.batch_max = std::max(1, std::min(BATCH_MAX, atoi(f)));
-        const int n_sets_alloc = (m.can_multi || m.resident_capable) ? EngineImpl::N_STATE : (m.can_batch ? m.batch_max : (m.can_defer ? 2 : 1));
+        const int n_sets_alloc = m.can_multi ? EngineImpl::N_STATE : (m.can_batch ? m.batch_max : (m.can_defer ? 2 : 1));
         const size_t ns = (size_t)n_sets_alloc;
         // (engines that stream with checked local thresholds use the lists for repairs and behind a closed gate only: two; a power of two)
         int want_lists = m.use_local ? 2 : 4;
@@ -1674,13 +1577,12 @@ int Engine::set_query(const float *host_x, double *elapsed_ns, std::string &err)
     }
     auto t0 = std::chrono::high_resolution_clock::now();
     HIP_TRY(hipSetDevice(m.device));
-    if (m.bar_x && !m.resident_capable) {
+    if (m.bar_x) {
         // (a launch enqueued earlier may still be reading d_x: tkspmv_run clears x_pending, the asynchronous entry points do not)
         if (m.x_pending) HIP_TRY(hipStreamSynchronize(m.stream));
         std::memcpy(m.d_x, host_x, (size_t)m.desc.cols * 4);
         m.flush_hdp();  // (sfence, HDP flush register written and read back: the stores are in memory before the launch's doorbell)
         m.x_pending = true;
-        m.x_on_host_only = false;
         m.d_x_cur = m.d_x;
         m.have_query = true;
         if (elapsed_ns)
@@ -1691,14 +1593,11 @@ int Engine::set_query(const float *host_x, double *elapsed_ns, std::string &err)
         // (an earlier upload from the staging copy must have been consumed before it is overwritten)
         if (m.x_pending) HIP_TRY(hipStreamSynchronize(m.stream));
         std::memcpy(m.h_x, host_x, (size_t)m.desc.cols * 4);
-        // resident engines: the kernel fetches x from the pinned copy itself; the upload happens only if another entry
-        // point needs x in device memory (ensure_x)
-        m.x_on_host_only = m.resident_capable;
-        if (!m.host_x_direct && !m.x_on_host_only) {
+        if (!m.host_x_direct) {
             HIP_TRY(hipMemcpyAsync(m.d_x, m.h_x, (size_t)m.desc.cols * 4, hipMemcpyHostToDevice, m.stream));
             HIP_TRY(hipEventRecord(m.ev2, m.stream));  // a launch on another stream waits for this upload (order_x)
         }
-        m.x_pending = !m.x_on_host_only;
+        m.x_pending = true;
         m.d_x_cur = m.host_x_direct ? m.h_x_dev : m.d_x;
         m.have_query = true;
         if (elapsed_ns)
@@ -1723,7 +1622,6 @@ int Engine::set_query_device(const float *dev_x, std::string &err) {
         return TKSPMV_ERR_INVALID;
     }
     impl_->d_x_cur = dev_x;
-    impl_->x_on_host_only = false;
     impl_->have_query = true;
     return TKSPMV_OK;
 }
@@ -1737,7 +1635,6 @@ int Engine::enqueue(const float *dev_x, uint32_t *dev_idx, float *dev_val, void 
     }
     hipStream_t s = stream ? (hipStream_t)stream : m.stream;
     HIP_TRY(hipSetDevice(m.device));
-    HIP_TRY(m.leave_resident_mode());
     HIP_TRY(m.order_x(x, s));
     m.launch_query(x, dev_idx ? dev_idx : m.d_out_idx, dev_val ? dev_val : m.d_out_val, s);
     HIP_TRY(hipGetLastError());
@@ -1768,7 +1665,6 @@ int Engine::enqueue_many(const float *dev_xs, int32_t n_x, int32_t count, void *
     }
     hipStream_t s = stream ? (hipStream_t)stream : m.stream;
     HIP_TRY(hipSetDevice(m.device));
-    HIP_TRY(m.leave_resident_mode());
     std::vector<const float *> xs;
     std::vector<uint32_t *> oi;
     std::vector<float *> ov;
@@ -1789,7 +1685,6 @@ int Engine::enqueue_batch(const float *dev_xs, int32_t count, uint32_t *dev_idx,
     }
     hipStream_t s = stream ? (hipStream_t)stream : m.stream;
     HIP_TRY(hipSetDevice(m.device));
-    HIP_TRY(m.leave_resident_mode());
     std::vector<const float *> xs;
     std::vector<uint32_t *> oi;
     std::vector<float *> ov;
@@ -1811,7 +1706,6 @@ int Engine::enqueue_list(const float *const *dev_xs, uint32_t *const *dev_idx, f
     }
     hipStream_t s = stream ? (hipStream_t)stream : m.stream;
     HIP_TRY(hipSetDevice(m.device));
-    HIP_TRY(m.leave_resident_mode());
     m.launch_sequence(dev_xs, dev_idx, dev_val, count, s);
     HIP_TRY(hipGetLastError());
     m.ran = true;
@@ -1829,7 +1723,6 @@ int Engine::enqueue_multi(const float *dev_xs, int32_t count, uint32_t *dev_idx,
     }
     hipStream_t s = stream ? (hipStream_t)stream : m.stream;
     HIP_TRY(hipSetDevice(m.device));
-    HIP_TRY(m.leave_resident_mode());
     std::vector<const float *> xs;
     std::vector<uint32_t *> oi;
     std::vector<float *> ov;
@@ -1851,7 +1744,6 @@ int Engine::enqueue_multi_list(const float *const *dev_xs, uint32_t *const *dev_
     }
     hipStream_t s = stream ? (hipStream_t)stream : m.stream;
     HIP_TRY(hipSetDevice(m.device));
-    HIP_TRY(m.leave_resident_mode());
     m.launch_multi_sequence(dev_xs, dev_idx, dev_val, count, s);
     HIP_TRY(hipGetLastError());
     m.ran = true;
@@ -1866,7 +1758,6 @@ int Engine::time_multi(const float *dev_xs, int32_t n_x, int32_t iters, double *
         return TKSPMV_ERR_INVALID;
     }
     HIP_TRY(hipSetDevice(m.device));
-    HIP_TRY(m.leave_resident_mode());
     HIP_TRY(hipStreamSynchronize(m.stream));
     HIP_TRY(m.settle());
     HIP_TRY(hipEventRecord(m.ev0, m.stream));
@@ -1912,7 +1803,6 @@ int Engine::enqueue_deferred(const float *dev_x, uint32_t *dev_idx, float *dev_v
     }
     hipStream_t s = stream ? (hipStream_t)stream : m.stream;
     HIP_TRY(hipSetDevice(m.device));
-    HIP_TRY(m.leave_resident_mode());
     m.launch_deferred(dev_x, dev_idx ? dev_idx : m.d_out_idx, dev_val ? dev_val : m.d_out_val, s);
     HIP_TRY(hipGetLastError());
     m.ran = true;
@@ -1924,7 +1814,6 @@ int Engine::drain(void *stream, std::string &err) {
     EngineImpl &m = *impl_;
     hipStream_t s = stream ? (hipStream_t)stream : m.stream;
     HIP_TRY(hipSetDevice(m.device));
-    HIP_TRY(m.leave_resident_mode());
     m.drain(s);
     HIP_TRY(hipGetLastError());
     return TKSPMV_OK;
@@ -1937,59 +1826,6 @@ int Engine::run(double *kernel_ns, std::string &err) {
         return TKSPMV_ERR_STATE;
     }
     HIP_TRY(hipSetDevice(m.device));
-    if (m.resident_capable && m.x_on_host_only) {
-        // ---- resident kernel: submit through pinned memory, poll the result flag ----------------------------------------
-        if (!m.resident_running || m.h_ctl->exited) {
-            if (m.resident_running) HIP_TRY(hipStreamSynchronize(m.rstream));
-            m.drain(m.stream);
-            HIP_TRY(hipStreamSynchronize(m.stream));  // the sets and result buffers are shared with the other launch schemes
-            HIP_TRY(m.start_resident());
-        }
-        const uint32_t epoch = ++m.host_epoch;
-        std::atomic_thread_fence(std::memory_order_release);  // x (h_x) before the request
-        m.h_ctl->request = epoch;
-        volatile uint32_t *flag = m.h_res + 2 * (size_t)m.desc.k;
-        const auto t0 = std::chrono::steady_clock::now();
-        bool seen = false;
-        for (uint64_t spins = 0;; ++spins) {
-            if (*flag == epoch && m.result_block_complete(epoch)) {
-                seen = true;
-                break;
-            }
-            __builtin_ia32_pause();
-            if ((spins & 0x3FFu) == 0x3FFu) {
-                if (m.h_ctl->exited && *flag != epoch) {
-                    // the kernel's idle timeout fired just before this request: start it again, the request stands
-                    HIP_TRY(hipStreamSynchronize(m.rstream));
-                    --m.host_epoch;  // start_resident numbers the next query host_epoch + 1 = epoch
-                    HIP_TRY(m.start_resident());
-                    m.host_epoch = epoch;
-                    m.h_ctl->request = epoch;
-                }
-                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) break;  // never hang on the flag
-            }
-        }
-        if (!seen) {
-            (void)m.stop_resident();
-            err = "the resident kernel did not answer within 5 s";
-            return TKSPMV_ERR_DEVICE;
-        }
-        std::atomic_thread_fence(std::memory_order_acquire);
-        if (kernel_ns) *kernel_ns = (double)m.h_res[2 * (size_t)m.desc.k + 1] * 10.0;  // device time of the query (100 MHz ticks)
-        if (m.resident_stats) {  // TKSPMV_RESIDENT_STATS=1: where a resident query's time goes (printed when the engine is destroyed)
-            const double host_ns = (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
-            const uint32_t *hr = m.h_res + 2 * (size_t)m.desc.k;
-            m.rs_n += 1.0;
-            m.rs_host += host_ns;
-            m.rs_dev += hr[1] * 10.0;
-            m.rs_pub += hr[2] * 10.0;
-            m.rs_tick += hr[3] * 10.0;
-        }
-        m.ran = true;
-        m.last_on_host = true;
-        return TKSPMV_OK;
-    }
-    HIP_TRY(m.leave_resident_mode());
     // The fused single launch can hand its result to the host itself (see h_res); the other launch schemes (radix select,
     // row per lane, unfused selection) complete in stream order and are waited for with the event.
     const bool to_host = m.host_path && m.h_res && m.fused && !m.use_radix && !(m.desc.impl == TKSPMV_IMPL_ROW_PER_LANE && m.can_multi);
@@ -2059,7 +1895,6 @@ int Engine::run(double *kernel_ns, std::string &err) {
 
 int Engine::synchronize(std::string &err) {
     HIP_TRY(hipSetDevice(impl_->device));
-    HIP_TRY(impl_->leave_resident_mode());
     impl_->drain(impl_->stream);
     HIP_TRY(hipStreamSynchronize(impl_->stream));
     HIP_TRY(impl_->settle());
@@ -2142,7 +1977,6 @@ int Engine::read_trace(unsigned long long *host, size_t max_words, size_t *words
         return TKSPMV_ERR_STATE;
     }
     HIP_TRY(hipSetDevice(m.device));
-    HIP_TRY(m.leave_resident_mode());
     HIP_TRY(hipDeviceSynchronize());
     const size_t n = std::min(max_words, m.trace_words * 4);
     HIP_TRY(hipMemcpy(host, m.d_trace, n * 8, hipMemcpyDeviceToHost));
@@ -2163,7 +1997,6 @@ int Engine::scores(float *host_y, std::string &err) {
         return TKSPMV_ERR_STATE;
     }
     HIP_TRY(hipSetDevice(m.device));
-    HIP_TRY(m.leave_resident_mode());
     if (!m.d_scores) HIP_TRY(hipMalloc((void **)&m.d_scores, std::max<size_t>(m.desc.rows, 1) * 4));
     HIP_TRY(hipMemsetAsync(m.d_scores, 0, std::max<size_t>(m.desc.rows, 1) * 4, m.stream));
     m.launch_scores(m.d_x_cur, m.stream);
@@ -2181,7 +2014,6 @@ int Engine::time_queries(const float *dev_xs, int32_t n_x, int32_t iters, double
         return TKSPMV_ERR_INVALID;
     }
     HIP_TRY(hipSetDevice(m.device));
-    HIP_TRY(m.leave_resident_mode());
     HIP_TRY(hipStreamSynchronize(m.stream));
     HIP_TRY(hipEventRecord(m.ev0, m.stream));
     {
@@ -2222,7 +2054,6 @@ int Engine::time_query_batches(const float *dev_xs, int32_t n_x, int32_t iters, 
         return TKSPMV_ERR_INVALID;
     }
     HIP_TRY(hipSetDevice(m.device));
-    HIP_TRY(m.leave_resident_mode());
     HIP_TRY(hipStreamSynchronize(m.stream));
     HIP_TRY(m.settle());
     std::vector<hipEvent_t> evs((size_t)reps + 1);
@@ -2261,7 +2092,6 @@ int Engine::time_stream_read(int32_t passes, double *ns_per_pass, std::string &e
         return TKSPMV_OK;
     }
     HIP_TRY(hipSetDevice(m.device));
-    HIP_TRY(m.leave_resident_mode());
     const uint32_t stream_block = m.block;  // the streaming waves of a workgroup (the server wave of a sequence launch aside)
     ReadProbeParams R{};
     R.n_replicas = m.d_replicas.empty() ? 1u : (uint32_t)std::min<size_t>(m.d_replicas.size(), 8);
@@ -2368,7 +2198,6 @@ int Engine::profile(const float *dev_xs, int32_t n_x, int32_t iters, tkspmv_timi
     }
     std::memset(out, 0, sizeof(*out));
     HIP_TRY(hipSetDevice(m.device));
-    HIP_TRY(m.leave_resident_mode());
     HIP_TRY(hipStreamSynchronize(m.stream));
     HIP_TRY(m.settle());
     unsigned long long st0[8], st1[8];

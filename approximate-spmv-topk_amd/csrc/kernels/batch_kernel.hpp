@@ -126,25 +126,7 @@ struct BatchParams : SetAddr {
     uint32_t ovf_lists;
     __device__ __forceinline__ unsigned long long *ovf_list(uint32_t l) const { return ovf_cand0 + (size_t)l * ovf_stride; }
     __device__ __forceinline__ uint32_t *ovf_list_count(uint32_t l) const { return ovf_count0 + (size_t)l * word_stride; }
-    // ---- resident mode (RESIDENT = true; tkspmv_run with desc.impl = TKSPMV_IMPL_RESIDENT) -------------------------------
-    // ONE launch serves queries as the host submits them: no launch, no copy engine, no stream synchronisation per query.
-    // The host writes x into pinned memory and raises `request` (an epoch counter); the doorman -- wave 0 of the selector
-    // workgroup, idle between selections anyway -- polls it, copies x into one of two device-side buffers and publishes the
-    // query number in `dev_epoch`, which the server waves poll; the query then runs exactly like a query of a batch (its
-    // exchange-state set is q mod BATCH_MAX, its stream copy q mod n_replicas); the selection writes the k results and the
-    // epoch to pinned host memory (SelectParams::host_out), where the host polls. The kernel leaves when the host asks
-    // (request = RESIDENT_QUIT) or when no request has arrived for idle_ticks: every wait of every wave ends with it.
-    const uint32_t *host_request;  // pinned host word: epoch of the newest submitted query, or RESIDENT_QUIT
-    uint32_t *host_exited;         // pinned host word: set to 1 when the kernel has left
-    const float *host_x;           // pinned host copy of x (XCOLS floats)
-    uint32_t *xr;                  // fine-grained device memory: [2][XCOLS] query vectors as the doorman copied them
-    uint32_t *dev_epoch;           // fine-grained device word: queries published so far (local numbering), or RESIDENT_QUIT
-    uint32_t epoch0;               // host epoch of local query q is epoch0 + q + 1
-    uint32_t idle_ticks;           // x 10 ns
-    uint32_t n_replicas;
-    const uint8_t *replicas[8];
 };
-constexpr uint32_t RESIDENT_QUIT = 0xFFFFFFFFu;
 
 template <int XCOLS, int C = 4>
 struct BatchLds {
@@ -256,7 +238,7 @@ __device__ __forceinline__ void gate_update(const BatchParams &B, uint32_t faile
 // One PHASE of a launch: phase 0 = the launch's n_q queries in the mode the host chose (B.local, the gate permitting); phase 1 =
 // the queries whose check failed in phase 0 (L.rq), with the device-wide exchange. Returning from here ends the phase for the
 // calling wave; the kernel below puts the phases together.
-template <int C, int XCOLS, int QM, bool DBG, bool RESIDENT, bool LOCAL>
+template <int C, int XCOLS, int QM, bool DBG, bool LOCAL>
 __device__ __forceinline__ void batch_phase(const StreamParams &P0, const SelectParams &SP0, const BatchParams &B, const bool repair,
                                             BatchLds<XCOLS, C> &L) {
     constexpr bool Q8 = QM == 1 || QM == 2;  // x staged as Q1.7 integers
@@ -269,11 +251,11 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t nwaves = (blockDim.x >> 6) - 1u;  // streaming waves
     const bool is_server = (wave == nwaves);
-    const uint32_t nq = RESIDENT ? 0xFFFFFFF0u : (repair ? L.rq[BATCH_MAX] : B.n_q);
+    const uint32_t nq = repair ? L.rq[BATCH_MAX] : B.n_q;
     // query q of THIS phase in the launch's argument block (repair: the q-th flagged query)
     auto qx = [&](uint32_t q) __attribute__((always_inline)) -> uint32_t { return repair ? L.rq[q] : q; };
-    // exchange-state set / ticket counter of query q (resident: the sets are reused round robin -- one query is in flight)
-    auto set_of = [&](uint32_t q) __attribute__((always_inline)) -> uint32_t { return RESIDENT ? q % (uint32_t)BATCH_MAX : qx(q); };
+    // exchange-state set / ticket counter of query q
+    auto set_of = [&](uint32_t q) __attribute__((always_inline)) -> uint32_t { return qx(q); };
     constexpr bool local = LOCAL;  // (compile-time: the two modes are two kernels, neither carries the other's code or registers)
     const bool local_top1 = B.local == 1u;  // a wave's word is its best packet maximum (1) or its second best (2)
     const uint32_t pace_q = LOCAL ? B.pace_quads : 0u;
@@ -286,68 +268,10 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
     const uint32_t nsel = B.n_selectors;  // (>= 1)
     if (blockIdx.x < nsel) {
         // ---- selector workgroups -----------------------------------------------------------------------------
-        if (RESIDENT && blockIdx.x != 0u) return;  // (one query in flight: one selector, who is also the doorman)
         const uint32_t n_stream = gridDim.x - nsel;
         // (the lists' epoch words as the phase found them -- read before any selection of the phase can have finished)
         if (!local && tid < 4u) L.epoch0[tid] = tid < n_lists ? __hip_atomic_load(B.ovf_epoch + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-        for (uint32_t q = RESIDENT ? 0u : blockIdx.x; q < nq; q += RESIDENT ? 1u : nsel) {
-            unsigned long long t_seen = 0ull;
-            if (RESIDENT) {
-                // doorman: wait for the host to submit query q (bounded), fetch its x, publish it to the server waves
-                if (wave == 0u) {
-                    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-                    uint32_t quit = 0u;
-                    for (;;) {
-                        const uint32_t r = __hip_atomic_load(B.host_request, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                        if (r == RESIDENT_QUIT) {
-                            quit = 1u;
-                            break;
-                        }
-                        if ((int32_t)(r - (B.epoch0 + q + 1u)) >= 0) break;
-                        if (__builtin_amdgcn_s_memrealtime() - t0 > (unsigned long long)B.idle_ticks) {
-                            quit = 1u;
-                            break;
-                        }
-                        __builtin_amdgcn_s_sleep(8);
-                    }
-                    t_seen = __builtin_amdgcn_s_memrealtime();
-                    if (!quit) {
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // x was written before the request
-                        uint32_t *dst = B.xr + (size_t)(q & 1u) * XCOLS;
-                        uint32_t r[XCOLS / 64];
-                        // (sixteen reads of HOST memory: they must be in flight together -- one base address and immediate offsets for a
-                        //  full-width x; else clamped addresses and masked values, which the compiler may issue one by one)
-                        if (P0.cols == (uint32_t)XCOLS) {
-#pragma unroll
-                            for (int u = 0; u < XCOLS / 64; ++u)
-                                r[u] = __hip_atomic_load(reinterpret_cast<const uint32_t *>(B.host_x) + lane + 64u * (uint32_t)u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                        } else {
-#pragma unroll
-                            for (int u = 0; u < XCOLS / 64; ++u) {
-                                const uint32_t i = lane + 64u * (uint32_t)u;
-                                const uint32_t w = __hip_atomic_load(reinterpret_cast<const uint32_t *>(B.host_x) + (i < P0.cols ? i : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                                r[u] = i < P0.cols ? w : 0u;
-                            }
-                        }
-#pragma unroll
-                        for (int u = 0; u < XCOLS / 64; ++u)
-                            __hip_atomic_store(&dst[lane + 64u * (uint32_t)u], r[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    }
-                    if (lane == 0) {
-                        __hip_atomic_store(B.dev_epoch, quit ? RESIDENT_QUIT : q + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        L.u.sel.last = quit;
-                        if (!quit && SP0.host_out)  // diagnostics: ticks from "request seen" to "x published"
-                            __hip_atomic_store(&SP0.host_out[2u * SP0.k + 2u], (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_seen), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    }
-                }
-                __syncthreads();
-                if (L.u.sel.last) {
-                    if (tid == 0) __hip_atomic_store(B.host_exited, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    return;
-                }
-                __syncthreads();
-            }
+        for (uint32_t q = blockIdx.x; q < nq; q += nsel) {
             const bool tr_sel = P0.trace && q == 4u;  // (tools/batch_trace.py, NQ=8: the phases of one selection)
             if (tr_sel && tid == 0) {
                 P0.trace[8] = __builtin_amdgcn_s_memrealtime();
@@ -360,17 +284,15 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
                 // in this XCD's L2 (seen: 33 ms on an otherwise idle L2).
                 // (the last query's selection is the launch's tail: poll it faster)
                 while (atomicCAS(t, n_stream, 0u) != n_stream) {
-                    if (RESIDENT || local || q + nsel >= nq) __builtin_amdgcn_s_sleep(4);
+                    if (local || q + nsel >= nq) __builtin_amdgcn_s_sleep(4);
                     else __builtin_amdgcn_s_sleep(32);
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                if (RESIDENT && SP0.host_out)  // diagnostics: ticks from "request seen" to "every workgroup has delivered"
-                    __hip_atomic_store(&SP0.host_out[2u * SP0.k + 3u], (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_seen), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
             __syncthreads();
             SelectParams S = SP0;
-            S.out_idx = B.io[RESIDENT ? 0u : qx(q)].out_idx;
-            S.out_val = B.io[RESIDENT ? 0u : qx(q)].out_val;
+            S.out_idx = B.io[qx(q)].out_idx;
+            S.out_val = B.io[qx(q)].out_val;
             if (local) {
                 // the workgroups' records of this query, checked: a failed check goes into the launch's verdict
                 LocalParams G{};
@@ -407,13 +329,8 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
                 S.gmax = B.gmax(set_of(q));
                 S.tau_g = B.tau_g(set_of(q));
                 S.unit_inv_in = B.unit_inv(set_of(q));
-                // The sets and lists are reused INSIDE a launch (a repair phase behind phase 0, the lists round robin, the resident
-                // kernel): the resets at the end of a selection are written through and drained before anybody is told.
+                // The sets and lists are reused INSIDE a launch (a repair phase behind phase 0, the lists round robin): the resets at the end of a selection are written through and drained before anybody is told.
                 S.wt_reset = 1u;
-                if (RESIDENT) {
-                    S.host_epoch = B.epoch0 + q + 1u;  // (host_out comes with SP0)
-                    S.t_seen = t_seen;                 // (wave 0 holds it; thread 0 reports the query's device time)
-                }
                 if (tr_sel && tid == 0) P0.trace[10] = __builtin_amdgcn_s_memrealtime();
                 select_body<0>(S, tid, blockDim.x, L.u.sel, tr_sel ? P0.trace + 8 : nullptr);
                 // the list is free for its next user: its count was reset (written through) and drained above
@@ -478,40 +395,15 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
         float wg_prior = carry_local ? B.wg_prior[bid] : 0.0f;  // (reported-score units per unit of the query's L1 norm; 0: none)
         float xnorm_q[2] = {0.0f, 0.0f};  // sum |x| of the queries in flight (carried thresholds are relative to it: scores are linear in x)
 
-        uint32_t published = RESIDENT ? 0u : nq;  // queries whose x is available (resident: as the doorman publishes them)
         float inv_unit_q[2] = {1.0f, 1.0f}, min_units_q[2] = {0.0f, 0.0f};
         unsigned long long dbg_first_duty = 0ull;
         uint32_t dbg_iters = 0u;
         for (;;) {
-            if (RESIDENT && tail == staged) {
-                // Nothing in flight in this workgroup: look for the next query (only then: 512 servers polling one word
-                // while the matrix streams would take bandwidth from the stream). RESIDENT_QUIT: tell the streaming waves
-                // -- they wait on the x flags -- and leave.
-                const uint32_t e = __hip_atomic_load(B.dev_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (e == RESIDENT_QUIT) {
-                    if (lane == 0) {
-                        __hip_atomic_store(&L.misc[0][MISC_XREADY], RESIDENT_QUIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        __hip_atomic_store(&L.misc[1][MISC_XREADY], RESIDENT_QUIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    }
-                    return;
-                }
-                published = e;
-                if (published == staged) {
-                    __builtin_amdgcn_s_sleep(16);
-                    continue;
-                }
-            }
-            if (staged < nq && staged < published && staged - tail < 2u) {
+            if (staged < nq && staged - tail < 2u) {
                 const uint32_t par = staged & 1u;
-                const float *xg = RESIDENT ? reinterpret_cast<const float *>(B.xr + (size_t)par * XCOLS) : B.io[qx(staged)].x;
+                const float *xg = B.io[qx(staged)].x;
                 const uint32_t prior_blocked = carry_local ? __hip_atomic_load(B.prior_block, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1u;
-                // (resident: the two device-side copies of x are rewritten in place query after query; they live in fine-
-                //  grained memory and are read with agent-scope loads, so no cache can serve a previous query's x)
-                auto x_at = [&](uint32_t i) __attribute__((always_inline)) -> float {
-                    if (RESIDENT)
-                        return __uint_as_float(__hip_atomic_load(reinterpret_cast<const uint32_t *>(xg) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                    return xg[i];
-                };
+                auto x_at = [&](uint32_t i) __attribute__((always_inline)) -> float { return xg[i]; };
                 float x_scale = 1.0f, unit_scale = 1.0f;
                 if (QM == 2) {
                     float lm = 0.0f;
@@ -773,7 +665,7 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
     // looked up on the candidate path only (pkt_row[p0 + jc], a scalar load where round 4 carried one per packet).
     constexpr bool BUF = C == 4 && (VT == 0 || VT == 4);
     auto stream_of = [&](uint32_t q) __attribute__((always_inline)) -> const uint8_t * {
-        return RESIDENT ? B.replicas[q % B.n_replicas] : B.io[qx(q)].packets;
+        return B.io[qx(q)].packets;
     };
     const size_t part_off = (size_t)p0 * P0.packet_bytes;
     const uint32_t part_bytes = np * P0.packet_bytes;
@@ -786,7 +678,7 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
     do {                                                                                                              \
         if (req_left == 0u) { /* the previous request was the last of its query */                                     \
             ++qa;                                                                                                     \
-            if (!RESIDENT && qa == nq) { /* the phase's last packet, again and again */                                \
+            if (qa == nq) { /* the phase's last packet, again and again */                                             \
                 req_off -= req_step;                                                                                  \
                 req_step = 0u;                                                                                        \
                 req_left = 0x7FFFFFFFu;                                                                               \
@@ -828,7 +720,6 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
                 for (;;) {
                     const uint32_t xr_ = lds_load(&mp[MISC_XREADY]);
                     if (xr_ == qc + 1u) break;
-                    if (RESIDENT && xr_ == RESIDENT_QUIT) return;  // the kernel is leaving (host request or idle timeout)
                     __builtin_amdgcn_s_sleep(2);
                 }
                 asm volatile("" ::: "memory");
@@ -963,7 +854,7 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
                 if (lane == 0) atomicAdd(&mp[MISC_DONE], 1u);
                 if (trw && lane == 0 && TRSLOT(qc) < 3u) trw[4 + TRSLOT(qc)] = __builtin_amdgcn_s_memrealtime();
                 ++qc;
-                if (!RESIDENT && qc == nq) return;
+                if (qc == nq) return;
                 jc = 0u;
             } else {
                 ++jc;
@@ -990,7 +881,7 @@ struct BatchArgs {
 //   LOCAL = false: the device-wide exchange, exact on its own. B.repair = 0: the launch's n_q queries (engines that do not use
 //                  local thresholds); B.repair = 1: the queries the verdict of the LOCAL launch before it names -- none, almost
 //                  always: every workgroup reads one word and leaves -- and the gate's bookkeeping.
-template <int C, int XCOLS, int QM, bool DBG = false, bool RESIDENT = false, bool LOCAL = false>
+template <int C, int XCOLS, int QM, bool DBG = false, bool LOCAL = false>
 __global__ void __launch_bounds__(576, 6) batch_kernel(const BatchArgs A) {
     StreamParams P0 = A.P;
     const SelectParams &SP0 = A.S;
@@ -1006,10 +897,6 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const BatchArgs A) {
     using LdsBlock = BatchLds<XCOLS, C>;
     static_assert(offsetof(LdsBlock, u) == 0 && offsetof(decltype(LdsBlock::u), w) == 0 && offsetof(decltype(LdsBlock::u.w), x) == 0, "x must be the first member of the kernel's LDS block");
     const uint32_t tid = threadIdx.x;
-    if (RESIDENT) {
-        batch_phase<C, XCOLS, QM, DBG, true, false>(P0, SP0, B, false, L);
-        return;
-    }
     if (LOCAL) {
         if (blockIdx.x == 0u && tid == 0u && B.verdict_next) __hip_atomic_store(B.verdict_next, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (B.prior_block && B.prior_block[B.gate_parity ? 7 : 4] != 0u) {
@@ -1021,7 +908,7 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const BatchArgs A) {
             }
             return;
         }
-        batch_phase<C, XCOLS, QM, DBG, false, true>(P0, SP0, B, false, L);
+        batch_phase<C, XCOLS, QM, DBG, true>(P0, SP0, B, false, L);
         return;
     }
     if (B.repair != 0u) {
@@ -1043,7 +930,7 @@ __global__ void __launch_bounds__(576, 6) batch_kernel(const BatchArgs A) {
         if (!late && blockIdx.x == 0u && tid == 0u && B.prior_block) gate_update(B, gate_was_closed ? 0u : L.rq[BATCH_MAX]);
         if (L.rq[BATCH_MAX] == 0u) return;
     }
-    batch_phase<C, XCOLS, QM, DBG, false, false>(P0, SP0, B, B.repair != 0u, L);
+    batch_phase<C, XCOLS, QM, DBG, false>(P0, SP0, B, B.repair != 0u, L);
 }
 
 }  // namespace tkspmv

@@ -34,10 +34,9 @@ struct SelectParams {
     // device-to-host copy, no stream synchronisation on the host's critical path.
     uint32_t *host_out;
     uint32_t host_epoch;
-    // Resident kernel: the exchange-state sets are reused WITHIN one launch, so the resets at the end of a selection must be
-    // written through (no kernel boundary flushes them) and drained BEFORE the host learns that the query is complete (it
-    // may submit the next one at once). t_seen: s_memrealtime stamp of the moment the query was seen on the device;
-    // host_out[2k + 1] receives the device time of the query in 10 ns ticks.
+    // Batch kernel: the exchange-state sets and overflow lists are reused WITHIN one launch, so the resets at the end of a selection
+    // must be written through (no kernel boundary flushes them) and drained before the next user is told. t_seen: s_memrealtime
+    // stamp a caller may pass for host_out[2k + 1] (the device time of the query in 10 ns ticks; 0: the launch's own start stamp).
     uint32_t wt_reset;
     unsigned long long t_seen;
     // Fused single launch with the host-visible result (tkspmv_run): workgroup 0 stamps the launch's start here (s_memrealtime,

@@ -12,9 +12,7 @@
 //
 //   -i N   engine variant (the reference's GPU_IMPL selector, options.hpp:35): 0 = fused streaming kernel (default),
 //          1 = one row per lane over the wave-sliced ELL copy, 2 = full y = A.x + radix select (the reference GPU host's
-//          structure: SpMV, then a selection over all rows), 3 = resident kernel (one launch stays on the GPU and serves
-//          the reset / run / read loop through pinned memory: no launch, copy or synchronisation per query).
-//          Same index lists from all of them.
+//          structure: SpMV, then a selection over all rows). Same index lists from all of them.
 //   -a     fp16 values (the comparator's half mode)
 //
 // Environment (additions, the flag surface is unchanged):
@@ -74,8 +72,8 @@ struct RunConfig {
             }
             precision = TKSPMV_FIXED;
         }
-        if (opt.gpu_impl < 0 || opt.gpu_impl > 3) {
-            std::cerr << "-i/--gpu_impl must be 0 (streaming kernel), 1 (row per lane), 2 (scores + select) or 3 (resident kernel)" << std::endl;
+        if (opt.gpu_impl < 0 || opt.gpu_impl > 2) {
+            std::cerr << "-i/--gpu_impl must be 0 (streaming kernel), 1 (row per lane) or 2 (scores + select)" << std::endl;
             exit(1);
         }
         impl = opt.gpu_impl;

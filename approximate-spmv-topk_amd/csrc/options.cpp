@@ -43,7 +43,6 @@ static const OptionDef k_options[] = {
     {"BAR_X", "behaviour", "0 | 1 (default 1 where the device reports a large BAR and its HDP flush register, and a kernel reads back what the CPU stored)", "0: tkspmv_set_query stages x through pinned memory instead of storing into device memory"},
     {"HOST_X", "behaviour", "copy | direct | direct_nc (default copy)", "direct: kernels read x from mapped host memory (direct_nc: non-coherent mapping)"},
     {"RUN_EVENTS", "behaviour", "0 | 1 (default 0)", "1: tkspmv_run returns a hipEvent bracket instead of the kernel's own device-clock span"},
-    {"RESIDENT_IDLE_MS", "tuning", "ms", "how long the resident kernel waits for a query before it retires"},
     {"HOST_THREADS", "tuning", "count", "threads of the host-side packer and generators"},
     // ---- layout ----
     {"F32_C12", "layout", "0 | 1 (default 1 for <= 4096 columns)", "fp32 values with 12-bit column words (1408-byte packets)"},
@@ -58,7 +57,6 @@ static const OptionDef k_options[] = {
     {"STAMPS", "diagnostic", "set = on", "device-clock stamps of the kernel phases"},
     {"WG_TIMES", "diagnostic", "set = on", "the batch kernel of local thresholds stamps every workgroup's hand-overs of its last launch ([33][grid] ticks of 10 ns, read through tkspmv_debug_trace): who leads, who lags (tools/wg_times.py)"},
     {"TRACE", "diagnostic", "set = on", "per-wave trace buffer for tkspmv_debug_trace"},
-    {"RESIDENT_STATS", "diagnostic", "set = on", "counters of the resident kernel"},
     {"DEBUG_OCC", "diagnostic", "set = on", "print launch geometry and occupancy at creation"},
     {"READ_PROBE", "diagnostic", "depth,work", "load-only probe: loads in flight and arithmetic per packet"},
     {"READ_PROBE_MAP", "diagnostic", "0..3", "load-only probe: workgroup -> partition map"},

@@ -291,36 +291,10 @@ def single_query_leg(mod, m, xs, dxs, a, device, eng, alg_bytes):
                   "note": "tkspmv_set_query + tkspmv_run + tkspmv_read per iteration inside ONE native call, host steady clock per iteration"}
     counters = eng.debug_counters()
     single = counters.get("single_launches", 0) > 0
-    # The same loop served by the resident kernel (desc.impl = TKSPMV_IMPL_RESIDENT): one launch stays on the GPU, queries
-    # arrive and results leave through pinned memory -- no launch, copy engine or stream synchronisation per query.
-    resident = None
-    try:
-        reng = mod.SpMV(m.row, m.col, m.val, m.rows, m.cols, k=a.k, device=device, stream_replicas=a.replicas, impl=mod._lib.IMPL_RESIDENT)
-        rk, re2e = [], []
-        for i in range(n):
-            x = xs[i % xs.shape[0]]
-            t0 = time.perf_counter()
-            reng.reset(x)
-            ns = reng()
-            rval, ridx = reng.read_result()
-            re2e.append((time.perf_counter() - t0) * 1e6)
-            rk.append(ns / 1e3)
-        rok, _ = check_parity(mod, m, xs[(n - 1) % xs.shape[0]], a.k, ridx, rval, reng)
-        reng.close()
-        rk, re2e = rk[2:], re2e[2:]
-        resident = {"kernel": "tkspmv::batch_kernel<4,1024,7,false,true> (resident: one launch serves the loop)",
-                    "device_us": float(np.median(rk)), "device_us_p95": pct(rk, 95),
-                    "frac": alg_bytes / (float(np.median(rk)) * 1e3) / HBM_PEAK_GBS,
-                    "end_to_end_us": float(np.median(re2e)), "end_to_end_us_p95": pct(re2e, 95), "parity_checked": rok,
-                    "note": "device_us = from the moment the kernel sees the request to the raising of the result flag "
-                            "(its own 100 MHz clock); end_to_end_us = host clock around set_query + run + read"}
-    except Exception as e:  # noqa: BLE001 -- a side leg must not cost the bench line
-        resident = {"error": f"{type(e).__name__}: {e}"}
     return {"kernel": ("tkspmv::single_kernel<7> (one launch per query: workgroup-local thresholds carried from the previous query, "
                        "one record per workgroup, selection in the workgroup that draws the last ticket; a failed check repeats "
                        "the query through tkspmv::stream_kernel)") if single else
                       "tkspmv::stream_kernel<4,false,1024,7,3> (one fused launch per query: stream, flush, in-launch selection)",
-            "resident": resident,
             "runs": len(kern), "dropped": 2, "device_us_self_stamped": med, "device_us_self_stamped_p95": pct(kern, 95),
             "kernel_us": med, "kernel_us_p95": pct(kern, 95), "frac": alg_bytes / (med * 1e3) / HBM_PEAK_GBS,
             "end_to_end_us": float(np.median(e2e)), "end_to_end_us_p95": pct(e2e, 95), "parity_checked": ok,
@@ -618,7 +592,7 @@ def bench_single(a, mod, torch, np, dev, local_rank):
         "roofline": {"bound": "hbm", "achieved": alg_bytes / kernel_ns, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": alg_bytes / kernel_ns / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": source,
                      "traffic_detail": detail,
-                     "kernel": "tkspmv::batch_kernel<4,1024,7,false,false,true> (fp32, 12-bit column words, workgroup-local thresholds; up to 32 "
+                     "kernel": "tkspmv::batch_kernel<4,1024,7,false,true> (fp32, 12-bit column words, workgroup-local thresholds; up to 32 "
                                "queries per launch; figures are per query and include the exact kernel launched behind it for failed checks)",
                      "algorithmic_bytes": int(alg_bytes), "kernel_us": kernel_ns / 1e3, "read_only": read_only,
                      # what the memory system physically moves (the stream is 5.5 B/nnz, the algorithmic figure counts 6): the

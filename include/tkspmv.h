@@ -83,16 +83,10 @@ typedef enum {
     TKSPMV_IMPL_ROW_PER_LANE = 1,  /* one row per lane over the wave-sliced ELL copy (the multi-query kernel with one query
                                       per pass; scores in the gold's summation order). Engines it does not apply to
                                       (reduced precisions, > 1024 columns, ...) run the default. */
-    TKSPMV_IMPL_SCORES_SELECT = 2, /* full y = A.x, then an exact radix select over all rows: the structure of the
+    TKSPMV_IMPL_SCORES_SELECT = 2  /* full y = A.x, then an exact radix select over all rows: the structure of the
                                       reference's GPU host (cusparseSpMV + sort, host_spmv_topk_csr_gpu.cu:171-231) */
-    TKSPMV_IMPL_RESIDENT = 3       /* the literal loop of the reference's hosts -- reset(vec), operator()(), read_result() one
-                                      query at a time (host_spmv_bscsr.cpp:602-632) -- served by ONE resident launch:
-                                      tkspmv_set_query writes x into pinned memory, tkspmv_run raises a request word the
-                                      kernel polls and then polls the result flag the kernel raises; tkspmv_read copies from
-                                      the pinned result block. No kernel launch, no copy engine and no stream synchronisation
-                                      per query. The kernel holds the whole GPU while it waits; it leaves after 100 ms without a
-                                      query (TKSPMV_RESIDENT_IDLE_MS) and whenever any other entry point is used, and is
-                                      started again on demand. fp32 values, <= 1024 columns; elsewhere: the default. */
+    /* (3 was rounds 2-4's resident kernel -- one launch serving the reset / run / read loop through pinned memory; since round 4 a launch
+       per query through single_kernel is faster on the device and end to end: removed in round 5, tkspmv_create answers TKSPMV_ERR_UNSUPPORTED) */
 } tkspmv_impl;
 
 typedef struct tkspmv_engine tkspmv_t;

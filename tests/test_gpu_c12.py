@@ -77,17 +77,3 @@ def test_device_packer_and_file_round_trip(pkg, monkeypatch, tmp_path):
         out.append(e.read_result())
         e.close()
     assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][0].view(np.uint32), out[1][0].view(np.uint32))
-
-
-def test_resident_kernel_with_12_bit_column_words(pkg, oracle, monkeypatch):
-    m = pkg.generate_matrix(300000, 1024, 20, "gamma", 12)
-    xs = [pkg.create_sample_vector(1024, True, False, True, 40 + i) for i in range(5)]
-    eng = pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, vec=xs[0], k=100, device=0, impl=pkg._lib.IMPL_RESIDENT)
-    assert eng.info()["packed_bytes"] < 0.93 * 6.3 * m.nnz
-    for x in xs:
-        eng.reset(x)
-        eng()
-        val, idx = eng.read_result()
-        gi, gv = oracle.gold_topk(m.row, m.col, m.val, x, 100)
-        assert set(idx.tolist()) == set(gi.tolist()) and np.allclose(val, gv, rtol=1e-4, atol=0)
-    eng.close()

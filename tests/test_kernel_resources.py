@@ -52,7 +52,7 @@ def test_streaming_kernels_do_not_spill_and_fit_two_workgroups_per_cu():
     # the headline kernels by name
     head = [n for n in stream if "12batch_kernelILi4ELi1024ELi7ELb0ELb0E" in n or "13stream_kernelILi4ELb0ELi1024ELi7ELi3ELb0E" in n
             or "12batch_kernelILi4ELi1024ELi7ELb0ELb1E" in n]
-    assert len(head) == 4  # (the batch kernel of local mode, the exact one, the resident one, the single-query stream kernel)
+    assert len(head) == 3  # (the batch kernel of local thresholds, the exact one, the single-query stream kernel)
     for n, v in multi.items():
         q8 = "multi_kernelILi8E" in n
         assert v["VGPRs"] <= (128 if q8 else 80), (n, v)  # 8 queries per pass run 8-wave workgroups
@@ -78,9 +78,8 @@ def test_batch_kernels_stream_without_touching_scratch(tmp_path):
 #include "kernels/local.hpp"
 #include "kernels/batch_kernel.hpp"
 namespace tkspmv {
-#define INST(QM) template __global__ void batch_kernel<4, 1024, QM, false, false, false>(const BatchArgs); template __global__ void batch_kernel<4, 1024, QM, false, false, true>(const BatchArgs);
+#define INST(QM) template __global__ void batch_kernel<4, 1024, QM, false, false>(const BatchArgs); template __global__ void batch_kernel<4, 1024, QM, false, true>(const BatchArgs);
 INST(0) INST(1) INST(2) INST(3) INST(4) INST(5) INST(6) INST(7) INST(8)
-template __global__ void batch_kernel<4, 1024, 7, false, true, false>(const BatchArgs);
 template __global__ void stream_kernel<4, false, 1024, 7, 3, false>(const StreamParams, const SelectParams);
 template __global__ void stream_kernel<4, false, 1024, 0, 3, false>(const StreamParams, const SelectParams);
 }
@@ -91,7 +90,7 @@ template __global__ void stream_kernel<4, false, 1024, 0, 3, false>(const Stream
                           stderr=subprocess.DEVNULL)
     lines = asm.read_text().split("\n")
     starts = [i for i, ln in enumerate(lines) if (ln.startswith("_ZN6tkspmv12batch_kernel") or ln.startswith("_ZN6tkspmv13stream_kernel")) and "@" in ln]
-    assert len(starts) == 21
+    assert len(starts) == 20
     for start in starts:
         end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
         blocks, cur = [], None
@@ -132,9 +131,9 @@ def test_no_chain_of_loads_waited_for_one_by_one(tmp_path):
 #include "kernels/batch_kernel.hpp"
 #include "kernels/multi_kernel.hpp"
 namespace tkspmv {
-template __global__ void batch_kernel<4, 1024, 7, false, false, true>(const BatchArgs);
-template __global__ void batch_kernel<4, 1024, 7, false, false, false>(const BatchArgs);
-template __global__ void batch_kernel<4, 1024, 3, false, false, true>(const BatchArgs);
+template __global__ void batch_kernel<4, 1024, 7, false, true>(const BatchArgs);
+template __global__ void batch_kernel<4, 1024, 7, false, false>(const BatchArgs);
+template __global__ void batch_kernel<4, 1024, 3, false, true>(const BatchArgs);
 template __global__ void single_kernel<7>(const StreamParams, const SelectParams, const LocalParams);
 template __global__ void multi_kernel<8, 0>(const StreamParams, const SelectParams, const MultiParams);
 template __global__ void multi_kernel<4, 0>(const StreamParams, const SelectParams, const MultiParams);
@@ -167,5 +166,5 @@ template __global__ void multi_kernel<4, 0>(const StreamParams, const SelectPara
     chains = {n: r for n, r in chains.items() if "select_kernel" not in n and "select_group_kernel" not in n}  # (non-template kernels of the headers)
     assert len(chains) == 6, sorted(chains)
     for name, runs in chains.items():
-        exact = "batch_kernelILi4ELi1024ELi7ELb0ELb0ELb0E" in name
+        exact = "batch_kernelILi4ELi1024ELi7ELb0ELb0E" in name
         assert len(runs) <= (1 if exact else 0), (name, runs)

@@ -43,6 +43,8 @@ def main():
     signal.signal(signal.SIGINT, lambda *_: stop.update(now=True))
     t0 = time.time()
     with open(out, "w") as f:
+        # (which card is whose: the PCI address behind every card; tools/ladder_probe.py prints the address of the GPU it ran on)
+        f.write("# " + " ".join(f"card{i}={os.path.basename(os.path.realpath(dev))}" for i, (dev, _) in enumerate(cards)) + "\n")
         f.write("t_s" + "".join(f",card{i}_sclk_MHz,card{i}_mclk_MHz,card{i}_fclk_MHz,card{i}_power_W,card{i}_temp_C" for i in range(len(cards))) + "\n")
         while not stop["now"] and not os.path.exists(out + ".stop"):
             row = [f"{time.time() - t0:.3f}"]

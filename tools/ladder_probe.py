@@ -21,6 +21,15 @@ def pct(v, p):
     return float(np.percentile(np.asarray(v, dtype=np.float64), p))
 
 
+def pci_address():
+    """PCI address of the GPU this process runs on (matches the card list in tools/clock_sampler.py's header)."""
+    try:
+        p = torch.cuda.get_device_properties(0)
+        return f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def main():
     name = sys.argv[1] if len(sys.argv) > 1 else "?"
     rows, cols, nnz = (int(v) for v in sys.argv[2:5]) if len(sys.argv) >= 5 else (1000000, 1024, 20)
@@ -53,7 +62,8 @@ def main():
            "read_only_us": floor, "driver_line_kernel_us": drv, "driver_line_host_us": drv_host,
            "algorithmic_bytes": int(info["algorithmic_bytes"]),
            "frac_at_median": info["algorithmic_bytes"] / (pct(reps + reps2, 50) * 1e3) / 8000.0,
-           "checks_failed": c.get("checks_failed"), "pace": os.environ.get("TKSPMV_PACE", "default")}
+           "checks_failed": c.get("checks_failed"), "pace": os.environ.get("TKSPMV_PACE", "default"),
+           "pace_in_force": f"{c.get('pace_quantum')}x{c.get('pace_levels')}", "pace_tuned_us": c.get("pace_tuned_us"), "pci": pci_address()}
     print(json.dumps(out))
     eng.close()
 

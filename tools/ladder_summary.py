@@ -29,8 +29,20 @@ def main():
         prev = m
     p = os.path.join(d, "clocks.csv")
     if os.path.exists(p):
-        rows = list(csv.DictReader(open(p)))
+        lines = open(p).read().split("\n")
+        mine = None
+        if lines and lines[0].startswith("#"):  # card list of the sampler: keep only the card the probes ran on
+            pci = next((r.get("pci") for r in runs if r.get("pci")), None)
+            for tok in lines[0][1:].split():
+                c, _, addr = tok.partition("=")
+                if pci and addr.lower() == pci.lower():
+                    mine = c
+            lines = lines[1:]
+        rows = list(csv.DictReader(lines))
         if rows:
+            if mine:
+                print(f"\n(the probes ran on {mine} = {pci}: its columns only)")
+                rows = [{k: v for k, v in r.items() if k == "t_s" or k.startswith(mine + "_")} for r in rows]
             print(f"\nclocks ({len(rows)} samples over {float(rows[-1]['t_s']):.0f} s, sysfs):")
             for key in rows[0]:
                 if key == "t_s":

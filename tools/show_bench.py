@@ -10,7 +10,6 @@ if "single_query" in d:
     print("single", {k: (round(v, 2) if isinstance(v, float) else v) for k, v in s.items() if k in ("kernel_us", "end_to_end_us", "frac", "counters", "parity_checked")})
     if s.get("native_loop"):
         print("single, native loop", {k: round(v, 2) for k, v in s["native_loop"].items() if isinstance(v, float)})
-    print("resident", {k: (round(v, 2) if isinstance(v, float) else v) for k, v in s["resident"].items() if k in ("device_us", "end_to_end_us", "error")})
     print("cache_warm", {k: (round(v, 3) if isinstance(v, float) else v) for k, v in d["cache_warm"].items() if k != "note"})
     for c in d["configs"]:
         print(c["workload"][:44], round(c.get("kernel_us", 0), 2), round(c.get("roofline", {}).get("frac", 0), 3), c.get("parity_checked"), c.get("error"))
