@@ -210,6 +210,7 @@ struct EngineImpl {
     uint32_t use_local = 0;  // workgroup-local thresholds (BatchParams::local: 0 off, 1 / 2: a wave's best / second best packet maximum)
     uint32_t single_mode = 0;  // the same choice for ONE query per launch (single_kernel): by the failure estimate alone, whatever the size
     float *d_wg_prior = nullptr;  // [grid] + the countdown word (BatchParams::wg_prior / prior_block)
+    float *d_wg_sig = nullptr;    // [grid][8] the signatures of the remembered priors and the second prior (BatchParams::wg_sig; option SIGNATURES=0: none)
     float local_beta = 1.0f;
     uint32_t pace_tuned_us = 0;  // 0: the pacing is the static default (or an option); else what tkspmv_create's measurement took
     uint32_t pace_quads = 0, pace_levels = 3, pace_base = 0; // pacing by rank (BatchParams::pace_quads, pace_levels, pace_base)
@@ -483,6 +484,7 @@ struct EngineImpl {
         ++batch_launches;
         if (use_local) {
             B.wg_prior = d_wg_prior;
+            B.wg_sig = d_wg_sig;
             B.local_beta = local_beta;
         }
         B.lslots = d_rec_slots + (size_t)parity * BATCH_MAX * grid * WG_SLOTS;
@@ -798,7 +800,7 @@ Engine::~Engine() {
     void *bufs[] = {m.d_packets, m.d_pkt_row, m.d_part_first, m.d_part_count, m.d_x,
                     m.d_out_idx, m.d_out_val, m.d_scores,     m.d_stats,      m.d_done, m.d_trace, m.d_tickets,
                     m.d_tstart, m.d_verdict, m.d_wg_prior, m.d_rec_slots, m.d_rec_used, m.d_ovf_epoch, m.d_alias_idx, m.d_alias_val,
-                    m.d_lslots,  m.d_lused, m.d_lprior, m.d_lstatus, m.d_wg_pace, m.d_wg_times};
+                    m.d_lslots,  m.d_lused, m.d_lprior, m.d_lstatus, m.d_wg_pace, m.d_wg_times, m.d_wg_sig};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     {
@@ -1330,6 +1332,10 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
     }
     HIP_TRY(malloc_exchange((void **)&m.d_wg_prior, ((size_t)m.grid + 32) * 4));  // priors | countdown words
     HIP_TRY(hipMemset(m.d_wg_prior, 0, ((size_t)m.grid + 32) * 4));
+    if (!opt("SIGNATURES") || atoi(opt("SIGNATURES")) != 0) {
+        HIP_TRY(hipMalloc((void **)&m.d_wg_sig, (size_t)m.grid * 8 * 4));
+        HIP_TRY(hipMemset(m.d_wg_sig, 0, (size_t)m.grid * 8 * 4));
+    }
     if (const char *f = opt("LOCAL_BETA")) m.local_beta = (float)atof(f);
     if (const char *f = opt("LOCAL")) m.use_local = m.single_mode = m.grid > 512u ? 0u : (uint32_t)std::max(0, std::min(2, atoi(f)));
     // Pacing by rank, with local thresholds only (with the device-wide exchange the cold phase of every query is governor enough, §3.0):
@@ -1521,6 +1527,7 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
         // the engine starts as if nothing had run: no carried thresholds, no pauses, no counters, no trust
         HIP_TRY(hipMemset(m.d_wg_prior, 0, ((size_t)m.grid + 32) * 4));
         if (m.d_wg_pace) HIP_TRY(hipMemset(m.d_wg_pace, 0, (size_t)m.grid * 4));
+        if (m.d_wg_sig) HIP_TRY(hipMemset(m.d_wg_sig, 0, (size_t)m.grid * 8 * 4));
         m.clean_seen = m.distrust_left = 0u;
         m.trusted_launches = m.late_repairs = 0;
         m.batch_launches = 0;

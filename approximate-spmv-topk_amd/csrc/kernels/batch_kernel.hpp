@@ -83,6 +83,15 @@ struct BatchParams : SetAddr {
     // streams faster than that (below ~500k rows).
     uint32_t n_selectors;
     float *wg_prior;        // [n_wg] what a workgroup's next query starts from, kept between launches (NULL: no carrying)
+    // Round 5: a carried threshold belongs to queries that LOOK like the one it came from. While the server wave stages x it also
+    // forms the query's signature -- rho = sum x / sum |x| (a change of sign turns it round) and pr = (sum |x|)^2 / (cols sum x^2)
+    // (the share of the columns that carry the query: a query concentrated on a few columns has a small one); both are invariant
+    // under scaling, like the carried threshold itself. A workgroup remembers TWO priors with their signatures and starts a query
+    // from the one that matches (|rho - rho'| <= 0.25, pr within a factor of 2), or from none: the query that changed direction runs
+    // without a carried threshold -- slower by a few us, exact, its check passes -- where round 4 let it fail its check and then
+    // suspended carrying for the next 16 .. 4096 selections; the stream's usual direction finds its own prior again right behind it.
+    // [n_wg][8]: rho0, pr0 (signature of wg_prior) | prior1, rho1, pr1 (the other one) | unused.
+    float *wg_sig;
     uint32_t *prior_block;  // [0..3] suspension of carried thresholds after a failed check (prior_block_update), [4..7] the gate
     // The gate of the local thresholds: a launch of which a quarter or more failed its checks closes it for 8, 16, ... 1024 launches
     // (the matrix keeps its best rows together: a workgroup's 8 slots cannot hold them, whatever the thresholds do); it counts down
@@ -394,6 +403,23 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
         const bool carry_local = local && B.wg_prior != nullptr;
         float wg_prior = carry_local ? B.wg_prior[bid] : 0.0f;  // (reported-score units per unit of the query's L1 norm; 0: none)
         float xnorm_q[2] = {0.0f, 0.0f};  // sum |x| of the queries in flight (carried thresholds are relative to it: scores are linear in x)
+        // the two remembered priors with their signatures (slot 0: wg_prior, the most recently used), and per query in flight: its
+        // signature and the slot it started from (2: none)
+        // (signatures are formed from the fp32 copy of x in LDS: the integer-staged value types keep round 4's behaviour)
+        const bool sigs = carry_local && B.wg_sig != nullptr && !Q8 && QM != 4 && QM != 6 && QM != 8;
+        float p_rho[2] = {0.0f, 0.0f}, p_pr[2] = {0.0f, 0.0f}, prior1 = 0.0f;
+        // (wave-uniform values: kept in scalar registers -- as vector registers they cost the kernel 60 spilled registers)
+        auto uni = [](float v) __attribute__((always_inline)) -> float { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); };
+        if (sigs) {
+            const uint32_t *g = reinterpret_cast<const uint32_t *>(B.wg_sig + (size_t)bid * 8u);
+            p_rho[0] = __uint_as_float(scalar_load(g + 0));
+            p_pr[0] = __uint_as_float(scalar_load(g + 1));
+            prior1 = __uint_as_float(scalar_load(g + 2));
+            p_rho[1] = __uint_as_float(scalar_load(g + 3));
+            p_pr[1] = __uint_as_float(scalar_load(g + 4));
+        }
+        float q_rho[2] = {0.0f, 0.0f}, q_pr[2] = {0.0f, 0.0f};
+        uint32_t q_slot[2] = {2u, 2u};
 
         float inv_unit_q[2] = {1.0f, 1.0f}, min_units_q[2] = {0.0f, 0.0f};
         unsigned long long dbg_first_duty = 0ull;
@@ -435,7 +461,7 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
                 inv_unit_q[par] = 1.0f / unit_scale;
                 min_units_q[par] = P0.min_score * unit_scale;
                 float *xl = L.u.w.x[par];
-                float xabs = 0.0f;
+                float xabs = 0.0f, xsum = 0.0f, xsq = 0.0f;
 #pragma unroll 1
                 for (uint32_t b0 = 0; b0 < (uint32_t)XCOLS; b0 += 1024u) {  // 16 loads in flight per lane
                     float r[16];
@@ -461,6 +487,7 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
 #pragma unroll
                         for (int u = 0; u < 16; ++u) xabs += fabsf(r[u]);
                     }
+
 #pragma unroll
                     for (int u = 0; u < 16; ++u) {
                         const uint32_t i = b0 + lane + 64u * (uint32_t)u;
@@ -481,8 +508,39 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
                 float tau_init = min_units_q[par];
                 uint32_t carried_key = 0u;
                 if (carry_local) xnorm_q[par] = wave_sum_f32(xabs);  // (a fixed summation order: the same value in every run)
-                if (prior_blocked == 0u && wg_prior > 0.0f) {
-                    const float t0 = wg_prior * xnorm_q[par] * unit_scale * B.local_beta;
+                float use_prior = wg_prior;
+                if (sigs) {
+                    // (the signature's sums come from the staged copy in LDS, behind the loads -- inside the staging loop they cost the
+                    //  kernel 60 spilled registers --, and from a QUARTER of the columns: four 64-column blocks, 256 values; the chain
+                    //  from the last load to the x-ready flag is what the workgroup's fastest waves wait for)
+                    float xabs_s = 0.0f;
+#pragma unroll
+                    for (uint32_t i = lane; i < (uint32_t)XCOLS; i += (uint32_t)XCOLS / 4u) {
+                        const float v = xl[i];
+                        xsum += v;
+                        xabs_s += fabsf(v);
+                        xsq += v * v;
+                    }
+                    const float s1 = wave_sum_f32(xsum), s2 = wave_sum_f32(xsq), n1 = wave_sum_f32(xabs_s);
+                    const float n_cols = (float)(P0.cols < (uint32_t)XCOLS ? (P0.cols + 3u) / 4u : (uint32_t)XCOLS / 4u);
+                    const float rho = uni(n1 > 0.0f ? s1 / n1 : 0.0f);
+                    const float pr = uni(s2 > 0.0f ? n1 * n1 / (n_cols * s2) : 0.0f);
+                    q_rho[par] = rho;
+                    q_pr[par] = pr;
+                    auto like = [&](float r2, float p2) __attribute__((always_inline)) -> bool {
+                        return n1 > 0.0f && fabsf(rho - r2) <= 0.25f && pr <= 2.0f * p2 && p2 <= 2.0f * pr;
+                    };
+                    if (wg_prior > 0.0f && like(p_rho[0], p_pr[0])) q_slot[par] = 0u;
+                    else if (prior1 > 0.0f && like(p_rho[1], p_pr[1])) {
+                        q_slot[par] = 1u;
+                        use_prior = prior1;
+                    } else {
+                        q_slot[par] = 2u;
+                        use_prior = 0.0f;  // (a query unlike both remembered ones starts without a carried threshold)
+                    }
+                }
+                if (prior_blocked == 0u && use_prior > 0.0f) {
+                    const float t0 = use_prior * xnorm_q[par] * unit_scale * B.local_beta;
                     if (t0 > tau_init) {
                         tau_init = t0;
                         carried_key = order_key(t0);  // (on record with the thresholds the waves form: MISC_TAUKEY)
@@ -581,7 +639,28 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
                                             B.lslots + (size_t)set_of(tail) * B.lslots_stride + (size_t)bid * WG_SLOTS, used, next_prior);
                         if (TKSPMV_LADDER >= 3 && lane == 8u)
                             __hip_atomic_store(B.lused + (size_t)set_of(tail) * B.lused_stride + bid, used, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (carry_local && next_prior >= 0.0f && xnorm_q[tp] > 0.0f) wg_prior = next_prior * inv_unit_q[tp] / xnorm_q[tp];
+                        if (carry_local && next_prior >= 0.0f && xnorm_q[tp] > 0.0f) {
+                            const float np_rel = sigs ? uni(next_prior * inv_unit_q[tp] / xnorm_q[tp]) : next_prior * inv_unit_q[tp] / xnorm_q[tp];
+                            if (!sigs) {
+                                wg_prior = np_rel;
+                            } else {
+                                // The refreshed prior becomes slot 0 (the most recently used) with the query's own signature; if the
+                                // query started from slot 1 or from neither, the old slot 0 moves down (the other one is forgotten).
+                                // The other query in flight chose its slot by the old numbering: renumbered with the slots -- only
+                                // which slot it will push out depends on that, a value always travels with its signature.
+                                const uint32_t sl = q_slot[tp];
+                                if (sl != 0u) {
+                                    prior1 = wg_prior;
+                                    p_rho[1] = p_rho[0];
+                                    p_pr[1] = p_pr[0];
+                                    const uint32_t o = q_slot[tp ^ 1u];
+                                    q_slot[tp ^ 1u] = o == 0u ? 1u : (o == 1u ? (sl == 1u ? 0u : 2u) : 2u);
+                                }
+                                wg_prior = np_rel;
+                                p_rho[0] = q_rho[tp];
+                                p_pr[0] = q_pr[tp];
+                            }
+                        }
                     } else {
                         if (P0.n_sets != 0u) publish_group_max(P, bid, lane, mp);  // complete maxima (fire and forget)
                         // lane l looks at entry (l % 8) of wave (l / 8): the staged rows go to the workgroup's 8 slots, in any
@@ -636,6 +715,14 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
             }
             if (tail == nq) {
                 if (carry_local && lane == 0) B.wg_prior[bid] = wg_prior;
+                if (sigs && lane == 0) {
+                    float *g = B.wg_sig + (size_t)bid * 8u;
+                    g[0] = p_rho[0];
+                    g[1] = p_pr[0];
+                    g[2] = prior1;
+                    g[3] = p_rho[1];
+                    g[4] = p_pr[1];
+                }
                 if (pace_q != 0u && B.wg_pace && lane == 0 && !repair) B.wg_pace[bid] = lds_load(&L.pace);
                 break;
             }

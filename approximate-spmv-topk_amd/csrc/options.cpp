@@ -15,6 +15,7 @@ static const OptionDef k_options[] = {
      "threshold scheme of the batch and single-query kernels: 0 = device-wide exchange (exact by construction); 1 / 2 = workgroup-local "
      "thresholds from each wave's best / second-best packet maximum, carried from query to query and CHECKED by the selection (a failed "
      "check repairs the query through the exact kernel). Ignored above 512 workgroups."},
+    {"SIGNATURES", "behaviour", "0 | 1 (default 1)", "1: a carried workgroup threshold is used only for a query whose signature (sum x / sum |x|, share of the columns that carry it) matches the query it came from, two priors remembered per workgroup; 0: round 4's behaviour (every query starts from the last prior; a failed check suspends carrying)"},
     {"LOCAL_BETA", "tuning", "float (default 1.0)", "factor applied to a carried workgroup threshold before the next query uses it"},
     {"SINGLE", "behaviour", "0 | 1 (default 1)", "0: tkspmv_run uses the stream kernel with the device-wide exchange instead of the single-query kernel with local thresholds"},
     {"BATCH", "behaviour", "0 | 1 (default 1)", "0: tkspmv_enqueue_batch / _many launch one kernel per query"},

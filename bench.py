@@ -587,14 +587,26 @@ def bench_single(a, mod, torch, np, dev, local_rank):
                               "wave_partitions": info["n_wave_partitions"], "packet_entries": info["packet_entries"],
                               # (tkspmv_info.batch_mode: how the engine runs back-to-back queries on this matrix)
                               "selector_workgroups": info.get("batch_mode", 0) & 0xFF,
-                              "thresholds": {0: "device-wide exchange", 1: "workgroup-local (best packet maximum per wave), checked by the selection; the exact kernel behind every launch repeats what failed (empty almost always)",
-                                             2: "workgroup-local (second best packet maximum per wave), checked by the selection; the exact kernel behind every launch repeats what failed (empty almost always)"}[(info.get("batch_mode", 0) >> 8) & 0xFF]}},
+                              "thresholds": {0: "device-wide exchange", 1: "workgroup-local (best packet maximum per wave), checked by the selection; an exact launch repeats what failed",
+                                             2: "workgroup-local (second best packet maximum per wave), checked by the selection; an exact launch repeats what failed"}[(info.get("batch_mode", 0) >> 8) & 0xFF]}},
         "roofline": {"bound": "hbm", "achieved": alg_bytes / kernel_ns, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": alg_bytes / kernel_ns / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": source,
                      "traffic_detail": detail,
                      "kernel": "tkspmv::batch_kernel<4,1024,7,false,true> (fp32, 12-bit column words, workgroup-local thresholds; up to 32 "
-                               "queries per launch; figures are per query and include the exact kernel launched behind it for failed checks)",
-                     "algorithmic_bytes": int(alg_bytes), "kernel_us": kernel_ns / 1e3, "read_only": read_only,
+                               "queries per launch; figures are per query; a failed check is repaired by an exact launch -- in the stream while "
+                               "the host has not seen clean verdicts, from the host's next wait otherwise: `late_repairs`)",
+                     "algorithmic_bytes": int(alg_bytes), "kernel_us": kernel_ns / 1e3,
+                     # scalar keys (nested objects do not survive into the driver's record): the load-only floor of this
+                     # box, the kernel against it, the kernel under sustained load, the checks of the timed region and its warm-up
+                     "read_only_us": read_us, "kernel_vs_read_only": read_us / (kernel_ns / 1e3),
+                     "sustained_median_us": pct(reps, 50), "sustained_p95_us": pct(reps, 95),
+                     "p95_over_median": pct(reps, 95) / pct(reps, 50),
+                     "sustained_frac": alg_bytes / (pct(reps, 50) * 1e3) / HBM_PEAK_GBS,
+                     "sustained_vs_read_only": read_us / pct(reps, 50),
+                     "checks_failed": int(counters["checks_failed"]), "late_repairs": int(counters.get("late_repairs", 0)),
+                     "launches_without_repair_launch": int(counters.get("trusted_launches", 0)),
+                     "pacing": f"{counters.get('pace_quantum')}x{counters.get('pace_levels')}" + (f" (measured at create, {counters.get('pace_tuned_us')} us)" if counters.get("pace_tuned_us") else " (static)"),
+                     "read_only": read_only,
                      # what the memory system physically moves (the stream is 5.5 B/nnz, the algorithmic figure counts 6): the
                      # measured traffic, or the stream's size, over the same kernel time -- `frac` above is the SURVEY 8(d) figure
                      "physical": {"bytes": float(traffic) if traffic else float(stream_bytes),

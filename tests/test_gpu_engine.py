@@ -342,7 +342,7 @@ def test_reference_side_host_program(pkg):
     exe = os.path.join(ROOT, "oracle", "_ref", "host_spmv_topk_mi355x")
     if not os.path.exists(exe):
         pytest.skip("oracle/_ref was not built (no reference tree at build time)")
-    for impl in ("0", "1", "2", "3"):
+    for impl in ("0", "1", "2"):
         r = subprocess.run([exe, "-m", os.path.join(GOLD, "small_0indexed.mtx"), "-k", "20", "-t", "4", "-i", impl],
                            capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, (impl, r.stdout[-500:], r.stderr[-500:])

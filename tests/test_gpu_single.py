@@ -109,12 +109,16 @@ def test_single_query_kernel_where_nearly_every_check_fails(pkg, oracle, monkeyp
         eng.close()
 
 
-def test_headline_size_default_engine_under_a_stream_that_breaks_carried_thresholds(pkg, oracle):
+@pytest.mark.parametrize("signatures", ["1", "0"])
+def test_headline_size_default_engine_under_a_stream_that_breaks_carried_thresholds(pkg, oracle, monkeypatch, signatures):
     """BASELINE configs[1] at full size, the engine and the mode bench.py reports (stream_replicas = 4, workgroup-local thresholds
     carried from query to query, paced by rank), 96 queries through tkspmv_enqueue_batch whose scales jump between 1, 0.01 and 3, with
     an x = 0 and a -x inside: every list against the gold and bit for bit against the order-matched oracle; checks must have failed
     (the repairs are what is being tested) and the results must still be exact."""
     import torch
+    # signatures = 1 (the default since round 5): a carried threshold is only used for a query that looks like the one it came from,
+    # so -x and x = 0 start without one and pass their checks; signatures = 0: round 4's behaviour, the checks fail and are repaired.
+    monkeypatch.setenv("TKSPMV_SIGNATURES", signatures)
     n_q, k = 96, 100
     m = pkg.generate_matrix(1000000, 1024, 20, "gamma", 2)
     xs = np.stack([pkg.create_sample_vector(1024, True, False, True, 1000 + i) for i in range(n_q)])
@@ -138,8 +142,11 @@ def test_headline_size_default_engine_under_a_stream_that_breaks_carried_thresho
     for q in range(n_q):
         _exact(pkg, oracle, m, eng, xs[q], k, gi_all[q], gv_all[q], raw, C, gold=q not in (40, 70))
     c = eng.debug_counters()
-    assert c["checks_failed"] > 0, c
-    print(f"\n[configs[1], default engine, scales 1 / 0.01 / 3, x = 0, -x] {n_q} queries exact; {c}")
+    if signatures == "0":
+        assert c["checks_failed"] > 0, c
+    else:
+        assert c["checks_failed"] <= 1, c  # (the changes of direction are seen before they can fail a check)
+    print(f"\n[configs[1], default engine, signatures {signatures}, scales 1 / 0.01 / 3, x = 0, -x] {n_q} queries exact; {c}")
     eng.close()
 
 
@@ -153,6 +160,7 @@ def test_engine_owned_result_buffer_holds_the_last_query_whatever_was_repaired(p
     a change of SIGN -- -x: no row reaches the threshold carried from +x --, scales do not any more.)"""
     import torch
     monkeypatch.setenv("TKSPMV_LOCAL", local)
+    monkeypatch.setenv("TKSPMV_SIGNATURES", "0")  # (round 5's signatures would keep -x from failing its check: the repairs are what is tested here)
     k = 100
     m = pkg.generate_matrix(300000, 1024, 20, "gamma", 7)
     eng = pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, k=k, device=0)
@@ -183,6 +191,7 @@ def test_launches_without_a_repair_launch_are_repaired_when_the_host_waits(pkg, 
     round 4), and an observed failure puts the in-stream repair launch back for the launches that follow."""
     import torch
     monkeypatch.setenv("TKSPMV_REPAIR", repair)
+    monkeypatch.setenv("TKSPMV_SIGNATURES", "0")  # (with signatures a change of direction no longer fails its check: the repairs are what is tested)
     k, rows, n_q = 100, 300000, 80
     m = pkg.generate_matrix(rows, 1024, 20, "gamma", 7)
     eng = pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, k=k, device=0)
