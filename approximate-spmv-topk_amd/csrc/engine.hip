@@ -163,6 +163,7 @@ struct EngineImpl {
     bool sell_c12 = false;          // ... with 12-bit column words: 640-byte chunks (at most 1022 columns)
     uint64_t sell_bytes = 0;
     uint32_t *d_multi_out_idx = nullptr;  // [2 * MULTI_Q_MAX][k] results of tkspmv_time_multi
+    uint64_t multi_stat_queries = 0, multi_waits = 0, multi_wait_ticks = 0, multi_rows_offered = 0, multi_rows_overflowed = 0;  // option STATS, summed over tkspmv_time_multi calls
     float *d_multi_out_val = nullptr;
     // Two independent chains of multi-query launches (TKSPMV_MULTI_CHAINS=1 switches the second off): chain c runs on its own
     // stream with its own exchange-state sets [16c, 16c + 16), so the start-up of one chain's launch fills the tail of the
@@ -1269,7 +1270,6 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
         HIP_TRY(hipMemcpy(m.d_sell_part_count, sm.part_count.data(), (size_t)m.sell_parts * 4, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(m.d_sell_part_slice0, sm.part_slice0.data(), (size_t)m.sell_parts * 4, hipMemcpyHostToDevice));
         HIP_TRY(hipMalloc((void **)&m.d_multi_out_idx, 2 * (size_t)MULTI_Q_MAX * d.k * 4));
-        HIP_TRY(hipMalloc((void **)&m.d_multi_out_val, 2 * (size_t)MULTI_Q_MAX * d.k * 4));
         HIP_TRY(hipStreamCreateWithFlags(&m.side, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&m.ev_fork, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&m.ev_join, hipEventDisableTiming));
@@ -1795,6 +1795,13 @@ int Engine::time_multi(const float *dev_xs, int32_t n_x, int32_t iters, double *
                         "(tau<=0: %.1f) overflowed %.1f | waits %.1f, %.2f us each\n",
                 st[4] / n, st[5] / n, st[6] / n, st[7] / n, st[8] / n, st[9] / n, st[10] / n, st[11] / n, st[12] / n,
                 st[12] ? st[13] * 0.01 / st[12] : 0.0);
+        // (kept for tkspmv_debug_counters: the guard of the passes' threshold exchange is a COUNT -- waves that ran into their
+        //  bounded wait, rows that overflowed a list -- not a wall clock)
+        m.multi_stat_queries += (uint64_t)iters;
+        m.multi_waits += st[12];
+        m.multi_wait_ticks += st[13];
+        m.multi_rows_offered += st[5] + st[9];
+        m.multi_rows_overflowed += st[7] + st[11];
         HIP_TRY(hipMemset(m.d_stats, 0, 32 * 8));
     }
     m.ran = true;
@@ -1965,6 +1972,13 @@ int Engine::debug_counters(unsigned long long *out, int n, std::string &err) {
     if (n >= 14) {  // the pacing in force: quantum | levels << 8 | base << 16, and what tkspmv_create's measurement of it took (us; 0: not measured)
         out[12] = m.pace_quads | (m.pace_levels << 8) | (m.pace_base << 16);
         out[13] = m.pace_tuned_us;
+    }
+    if (n >= 19) {  // option STATS, summed over the tkspmv_time_multi calls so far: queries, bounded waits for a threshold (count, ticks of 10 ns), rows offered / overflowed
+        out[14] = m.multi_stat_queries;
+        out[15] = m.multi_waits;
+        out[16] = m.multi_wait_ticks;
+        out[17] = m.multi_rows_offered;
+        out[18] = m.multi_rows_overflowed;
     }
     return TKSPMV_OK;
 }

@@ -162,8 +162,8 @@ class SpMV:
     def debug_counters(self):
         """Checked thresholds of back-to-back queries (info()["batch_mode"]): how many selections failed their check so far (and
         sent their query through the repair launch), the suspension state of carried thresholds, batch launches so far."""
-        out = (C.c_uint64 * 14)()
-        _lib.check(_lib.lib().tkspmv_debug_counters(self._h, out, 14))
+        out = (C.c_uint64 * 19)()
+        _lib.check(_lib.lib().tkspmv_debug_counters(self._h, out, 19))
         return {"checks_failed": int(out[0]), "suspension_length": int(out[1]), "suspended_for": int(out[2]), "batch_launches": int(out[3]),
                 "local_off_for_launches": int(out[4]), "local_off_length": int(out[5]),
                 # tkspmv_run through the single-query kernel (local thresholds, checked): launches, queries repeated through the
@@ -175,7 +175,11 @@ class SpMV:
                 "trusted_launches": int(out[10]), "late_repairs": int(out[11]),
                 # the pacing of back-to-back queries in force and what tkspmv_create's measurement of it took (0: static default)
                 "pace_quantum": int(out[12]) & 0xFF, "pace_levels": (int(out[12]) >> 8) & 0xFF, "pace_base": (int(out[12]) >> 16) & 0xFF,
-                "pace_tuned_us": int(out[13])}
+                "pace_tuned_us": int(out[13]),
+                # option STATS, summed over the time_multi calls so far (the multi-query kernel's threshold exchange): queries, waves that
+                # ran into their bounded wait for a threshold and the ticks (10 ns) they spent there, rows offered to / overflowed from the lists
+                "multi_stat_queries": int(out[14]), "multi_waits": int(out[15]), "multi_wait_ticks": int(out[16]),
+                "multi_rows_offered": int(out[17]), "multi_rows_overflowed": int(out[18])}
 
     def synchronize(self):
         _lib.check(_lib.lib().tkspmv_synchronize(self._h))

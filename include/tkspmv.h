@@ -247,6 +247,9 @@ int tkspmv_debug_trace(tkspmv_t *e, uint64_t *host, uint64_t max_words, uint64_t
  * went out without a repair launch behind them (see tkspmv_synchronize), out[11] = the late repairs that had to follow after all.
  * With n >= 14: out[12] = the pacing of back-to-back queries in force (pause quantum | levels << 8 | uniform pause << 16; units of
  * 128 cycles per packet), out[13] = microseconds tkspmv_create spent measuring it on this box (option AUTOTUNE; 0: static default).
+ * With n >= 19 and option STATS, summed over the tkspmv_time_multi calls so far: out[14] = queries, out[15] = waves of the multi-query
+ * kernel that ran into their bounded wait for a threshold, out[16] = the ticks (10 ns) spent there, out[17] / out[18] = rows offered
+ * to / overflowed from the candidate lists.
  * Synchronises the engine's stream. */
 int tkspmv_debug_counters(tkspmv_t *e, uint64_t *out, int32_t n);
 
