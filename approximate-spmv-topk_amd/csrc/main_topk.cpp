@@ -22,6 +22,9 @@
 //   TKSPMV_SEED       = n              seed for the query vectors (iteration i uses n+i); default random_device
 //   TKSPMV_FIXED_WIDTH= W              the FPGA builds' fixed-point real_type of W bits (8..32)
 //   TKSPMV_CACHE_DIR  = dir            keep the packed matrix there between runs
+//   TKSPMV_GENERATE   = rows,cols,nnz,dist,seed   no file at all: the matrix is generated in memory (dist: uniform | gamma; the
+//                                      distributions of create_matrices.py) -- the reference's grid reaches 15M rows x 40 non-zeros,
+//                                      7 GB of MatrixMarket text per matrix (test_spmv_topk.py:12-47); -m is ignored
 #include <sys/stat.h>
 
 #include <algorithm>
@@ -112,6 +115,19 @@ struct MatrixSource {
 
     explicit MatrixSource(const RunConfig &c) {
         const auto t0 = Clock::now();
+        if (const char *g = getenv("TKSPMV_GENERATE")) {  // rows,cols,nnz,dist,seed
+            unsigned long long rows = 0, cols = 0, nnz = 0, seed = 1;
+            char dist[32] = "gamma";
+            if (sscanf(g, "%llu,%llu,%llu,%31[a-z],%llu", &rows, &cols, &nnz, dist, &seed) < 3 || rows == 0 || cols == 0 || nnz == 0 ||
+                (std::string(dist) != "uniform" && std::string(dist) != "gamma")) {
+                std::cerr << "TKSPMV_GENERATE must be rows,cols,nnz[,uniform|gamma[,seed]]" << std::endl;
+                exit(1);
+            }
+            tkspmv::generate_matrix((uint32_t)rows, (uint32_t)cols, (uint32_t)nnz, std::string(dist) == "gamma" ? 1 : 0, seed, coo);
+            if (c.opt.ignore_matrix_values) std::fill(coo.val.begin(), coo.val.end(), 1.0f);
+            load_ms = ms_since(t0);
+            return;
+        }
         const std::string path = c.matrix_path();
         struct stat sb;
         if (!c.cache_dir.empty() && stat(path.c_str(), &sb) == 0) {
@@ -308,7 +324,7 @@ int main(int argc, char *argv[]) {
             std::cout << "TKSPMV_" << name << "  [" << kind << "]  " << values << "\n    " << doc << "\n";
         }
         std::cout << "this program only: TKSPMV_FIXED_WIDTH (8..32: fixed-point values of that width), TKSPMV_INDEX_BASE (0 | 1 | auto), "
-                     "TKSPMV_SEED (query vector), TKSPMV_CACHE_DIR (packed-matrix cache)\n";
+                     "TKSPMV_SEED (query vector), TKSPMV_CACHE_DIR (packed-matrix cache), TKSPMV_GENERATE (rows,cols,nnz,dist,seed: matrix generated in memory)\n";
         return 0;
     }
     const RunConfig cfg(argc, argv);

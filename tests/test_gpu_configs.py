@@ -159,3 +159,34 @@ def test_experiment_driver_on_a_small_grid(tmp_path):
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         t2 = json.load(open(o2 / "accuracy.json"))
         assert len(t2) == 1 and t2[0]["prec_100"] == 1.0 and t2[0]["kendall_100"] > 0.999
+
+
+def test_reference_grid_largest_matrix_against_the_gold(pkg, oracle):
+    """The far corner of the reference's grid (test_spmv_topk.py:12-47): 15M rows x 1024 columns x 40 non-zeros per row, 600M
+    non-zeros -- the first matrix past 2^31 bytes of values and 2^29 entries: tkspmv_run and a batch of queries against the CPU gold
+    (gold_algorithms.hpp:188-246 restated and pinned; ~6 s per query on one core, hence two queries)."""
+    import torch
+    k = 100
+    m = pkg.generate_matrix(15000000, 1024, 40, "gamma", 9)
+    assert m.nnz > 2 ** 29
+    xs = np.stack([pkg.create_sample_vector(1024, True, False, True, 7000 + i) for i in range(4)])
+    eng = pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, k=k, device=0)
+    assert eng.info()["packed_bytes"] > 2 ** 31
+    golds = [oracle.gold_topk(m.row, m.col, m.val, xs[q], k) for q in range(2)]
+    for q in range(2):
+        eng.reset(xs[q])
+        ns = eng()
+        val, idx = eng.read_result()
+        gi, gv = golds[q]
+        assert set(idx.tolist()) == set(gi.tolist()), q
+        assert np.allclose(np.sort(val)[::-1], np.sort(gv)[::-1], rtol=1e-4, atol=0)
+    dxs = torch.from_numpy(xs).cuda()
+    out_i = torch.zeros(4, k, dtype=torch.int32, device="cuda")
+    out_v = torch.zeros(4, k, dtype=torch.float32, device="cuda")
+    eng.enqueue_batch(dxs.data_ptr(), 4, out_i.data_ptr(), out_v.data_ptr())
+    eng.synchronize()
+    for q in range(2):
+        gi, gv = golds[q]
+        assert set(out_i[q].cpu().numpy().astype(np.uint32).tolist()) == set(gi.tolist()), q
+    print(f"\n[15M x 1024 x 40: {m.nnz} nnz, {eng.info()['packed_bytes'] / 1e9:.2f} GB packed] tkspmv_run {ns / 1e3:.0f} us per query")
+    eng.close()

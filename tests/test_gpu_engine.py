@@ -335,6 +335,20 @@ def test_drop_in_executable_csv(pkg, oracle, tmp_path):
     assert r.returncode == 1 and "TKSPMV_FIXED_WIDTH" in r.stderr
 
 
+def test_executable_generates_its_matrix_in_memory():
+    """TKSPMV_GENERATE=rows,cols,nnz,dist,seed: the drop-in executable without a MatrixMarket file (the reference's grid reaches 7 GB
+    of text per matrix). 2M rows x 20 = 40M non-zeros: the size from which the per-iteration software gold forms its row sums with
+    several threads -- every iteration's list must equal that gold's, index for index."""
+    exe = os.path.join(ROOT, "bin", "approximate-spmv-mi355x-topk")
+    env = dict(os.environ, TKSPMV_GENERATE="2000000,1024,20,gamma,3", TKSPMV_SEED="5")
+    r = subprocess.run([exe, "-t", "3", "-k", "100", "-r"], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-500:])
+    lines = [ln.split(",") for ln in r.stdout.strip().split("\n") if ln and ln[0].isdigit()]
+    assert len(lines) == 3 and all(int(f[1]) == 0 for f in lines), r.stdout[:600]
+    r = subprocess.run([exe, "-t", "1", "-k", "100"], capture_output=True, text=True, env=dict(env, TKSPMV_GENERATE="12,x"), timeout=60)
+    assert r.returncode == 1 and "TKSPMV_GENERATE" in r.stderr
+
+
 def test_reference_side_host_program(pkg):
     """oracle/_ref/host_spmv_topk_mi355x (built in the build container from oracle/ref_host_mi355x.cpp against the
     reference's OWN headers: its Options, readMtx, coo_t, create_sample_vector, gold and checks around this engine's C ABI,
