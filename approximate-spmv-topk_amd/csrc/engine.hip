@@ -245,6 +245,7 @@ struct EngineImpl {
     uint32_t *d_lused = nullptr;             // [grid]
     float *d_lprior = nullptr;               // [grid] carried thresholds | 32 words: the suspension counters (LocalParams::prior_block)
     uint32_t *d_lstatus = nullptr;           // [0] 1: the last single launch failed its check
+    uint32_t *d_lready = nullptr;            // [grid] the streaming workgroups' flags (LocalParams::ready; NULL: the last workgroup selects)
     mutable uint64_t single_launches = 0, single_repairs = 0;
     uint32_t uni_ppp = 0, uni_last = 0;  // uniform partition table (StreamParams::uni_ppp): partition q = packets [q * uni_ppp, ...)
 
@@ -679,6 +680,8 @@ struct EngineImpl {
         G.wg_prior = d_lprior;
         G.prior_block = reinterpret_cast<uint32_t *>(d_lprior + grid);
         G.status = d_lstatus;
+        G.ready = d_lready;
+        G.epoch = (uint32_t)(single_launches + 1u) | 0x80000000u;  // (never 0, never the previous launch's)
         G.mode = single_mode;
         G.beta = local_beta;
         G.trace = d_trace ? d_trace + (launch_counter % 4) * trace_words : nullptr;
@@ -801,7 +804,7 @@ Engine::~Engine() {
     void *bufs[] = {m.d_packets, m.d_pkt_row, m.d_part_first, m.d_part_count, m.d_x,
                     m.d_out_idx, m.d_out_val, m.d_scores,     m.d_stats,      m.d_done, m.d_trace, m.d_tickets,
                     m.d_tstart, m.d_verdict, m.d_wg_prior, m.d_rec_slots, m.d_rec_used, m.d_ovf_epoch, m.d_alias_idx, m.d_alias_val,
-                    m.d_lslots,  m.d_lused, m.d_lprior, m.d_lstatus, m.d_wg_pace, m.d_wg_times, m.d_wg_sig};
+                    m.d_lslots,  m.d_lused, m.d_lprior, m.d_lstatus, m.d_wg_pace, m.d_wg_times, m.d_wg_sig, m.d_lready};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     {
@@ -1359,8 +1362,14 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
                    m.pm.part_first.size() <= (size_t)m.grid * 8u;
     if (const char *f = opt("SINGLE")) m.can_single = m.can_single && atoi(f) != 0;
     if (m.can_single) {
-        HIP_TRY(hipMalloc((void **)&m.d_lslots, (size_t)m.grid * WG_SLOTS * 8));
-        HIP_TRY(hipMemset(m.d_lslots, 0xFF, (size_t)m.grid * WG_SLOTS * 8));
+        HIP_TRY(hipMalloc((void **)&m.d_lslots, (size_t)m.grid * SINGLE_REC_STRIDE * 8));  // (a 128-byte line per workgroup: single_kernel's selector)
+        HIP_TRY(hipMemset(m.d_lslots, 0xFF, (size_t)m.grid * SINGLE_REC_STRIDE * 8));
+        // workgroup 0 selects (LocalParams::ready) where the partitions fit the grid's other workgroups; option SINGLE_SELECTOR=0:
+        // round 4's scheme (every workgroup streams, the one that draws the last ticket selects)
+        if (m.pm.part_first.size() <= (size_t)(m.grid - 1u) * 8u && m.grid >= 2u && (!opt("SINGLE_SELECTOR") || atoi(opt("SINGLE_SELECTOR")) != 0)) {
+            HIP_TRY(malloc_exchange((void **)&m.d_lready, (size_t)m.grid * 4));
+            HIP_TRY(hipMemset(m.d_lready, 0, (size_t)m.grid * 4));
+        }
         HIP_TRY(hipMalloc((void **)&m.d_lused, (size_t)m.grid * 4));
         HIP_TRY(hipMemset(m.d_lused, 0, (size_t)m.grid * 4));
         HIP_TRY(malloc_exchange((void **)&m.d_lprior, ((size_t)m.grid + 32) * 4));

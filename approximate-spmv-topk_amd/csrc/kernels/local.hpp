@@ -28,6 +28,12 @@ struct LocalParams {
     float beta;                 // carried thresholds start at beta x the recorded score
     unsigned long long *trace;  // optional (TKSPMV_TRACE=1): [grid][8 waves][8] s_memrealtime stamps
     uint32_t shared_bookkeeping;  // 1: several selections run at once (batch kernel): prior_block is updated with atomics
+    // single_kernel (round 5): workgroup 0 of the launch is the SELECTOR; a streaming workgroup that has stored its record and
+    // drained the stores raises ready[its number] to the launch's epoch and leaves -- no ticket, no atomic round trip behind its
+    // stream --, and the selector, which has polled the flags all along, loads each record as its flag comes up: when the last
+    // workgroup is through, one record is left to load, not 4096 slots.
+    uint32_t *ready;  // [n_wg]
+    uint32_t epoch;   // != 0, different from launch to launch
 };
 
 constexpr uint32_t STG_N = 8;         // survivors a wave stages per query (64 lanes = 8 waves x 8 when one wave finalises)
@@ -174,22 +180,30 @@ __device__ __forceinline__ void prior_block_update(uint32_t *pb, bool bad, bool 
 // whether the check failed.
 // SP.host_out != NULL: the k results also go to host-visible memory with the epoch flag, the launch's own duration, the status
 // of the check and the checksum.
+// pre / pre_used (single_kernel's selector): the calling thread already holds eight slots and the largest `used` of the records it
+// looked at -- nothing is loaded here.
 __device__ __forceinline__ bool select_local(const LocalParams &G, const SelectParams &SP, const uint32_t n_wg, const uint32_t tid,
                                              const uint32_t nthreads, LocalSelectShared &S, const float out_scale,
-                                             unsigned long long *stamps = nullptr) {
+                                             unsigned long long *stamps = nullptr, const unsigned long long *pre = nullptr,
+                                             const uint32_t pre_used = 0u) {
     const uint32_t lane = tid & 63u;
     const bool HOST = SP.host_out != nullptr;
     const uint32_t n_slots = n_wg * WG_SLOTS;  // (host: n_wg <= 512, n_slots <= 8 * nthreads)
     unsigned long long mine[8];
+    uint32_t my_used = pre_used;
+    if (pre) {
 #pragma unroll
-    for (uint32_t u = 0; u < 8; ++u) {
-        const uint32_t f = tid + u * nthreads;
-        mine[u] = f < n_slots ? ld_agent(&G.slots[f]) : ~0ull;  // (eight loads in flight as the compiler emits it: checked on the ISA, tests/test_kernel_resources.py)
-    }
-    uint32_t my_used = 0u;
-    for (uint32_t w = tid; w < n_wg; w += nthreads) {
-        const uint32_t uw = __hip_atomic_load(&G.used[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        my_used = uw > my_used ? uw : my_used;
+        for (uint32_t u = 0; u < 8; ++u) mine[u] = pre[u];
+    } else {
+#pragma unroll
+        for (uint32_t u = 0; u < 8; ++u) {
+            const uint32_t f = tid + u * nthreads;
+            mine[u] = f < n_slots ? ld_agent(&G.slots[f]) : ~0ull;  // (eight loads in flight as the compiler emits it: checked on the ISA, tests/test_kernel_resources.py)
+        }
+        for (uint32_t w = tid; w < n_wg; w += nthreads) {
+            const uint32_t uw = __hip_atomic_load(&G.used[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            my_used = uw > my_used ? uw : my_used;
+        }
     }
     // (the bookkeeping thread reads the suspension counters with the records: single writer -- one selection at a time --, so
     //  what follows the check is stores only, no trip through memory behind it)
@@ -445,6 +459,7 @@ struct SingleLds {
     float xnorm[8];     // per wave: sum |x| over the words it loaded (carried thresholds are kept relative to the query's L1 norm)
 };
 
+constexpr uint32_t SINGLE_REC_STRIDE = 16;  // 64-bit words between the records of consecutive workgroups when workgroup 0 selects (LocalParams::ready)
 template <int QM>
 __global__ void __launch_bounds__(512, 4) single_kernel(const StreamParams P, const SelectParams SP, const LocalParams G) {
     static_assert(QM == 0 || QM == 7, "single_kernel: fp32 values, 4 entries per lane, at most 1024 columns");
@@ -455,12 +470,54 @@ __global__ void __launch_bounds__(512, 4) single_kernel(const StreamParams P, co
     static_assert(offsetof(SingleLds, u) == 0 && offsetof(decltype(SingleLds::u), w) == 0 && offsetof(decltype(SingleLds::u.w), x) == 0, "x must be the first member of the kernel's only LDS block (reduce_packet's address trick)");
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t bid = blockIdx.x, n_wg = gridDim.x;
-    unsigned long long *tr = G.trace ? G.trace + ((size_t)bid * 8u + wave) * 8u : nullptr;
+    // G.ready != NULL (round 5): workgroup 0 is the launch's selector, workgroups 1 .. grid - 1 stream (LocalParams::ready)
+    const bool dedicated = G.ready != nullptr;
+    const uint32_t bid = dedicated ? blockIdx.x - 1u : blockIdx.x, n_wg = dedicated ? gridDim.x - 1u : gridDim.x;
+    unsigned long long *tr = G.trace ? G.trace + ((size_t)blockIdx.x * 8u + wave) * 8u : nullptr;
     unsigned long long tr0 = 0, tr1 = 0, tr2 = 0, tr3 = 0;
     if (tr) tr0 = __builtin_amdgcn_s_memrealtime();
-    if (SP.t_start && bid == 0u && tid == 0u)  // (workgroup 0 is dispatched first: the launch's start within a microsecond)
+    if (SP.t_start && blockIdx.x == 0u && tid == 0u)  // (workgroup 0 is dispatched first: the launch's start within a microsecond)
         __hip_atomic_store(SP.t_start, (unsigned long long)__builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (dedicated && blockIdx.x == 0u) {
+        // ---- the selector: thread t waits for the record of streaming workgroup t (its flag at this launch's epoch: the record's
+        // stores were drained before the flag was raised) and loads it at once -- 64 contiguous bytes it has never touched in this
+        // launch, so no cache of this XCD can hold an older copy. Flags are polled with an atomic (executed at the device-wide
+        // coherence point; a load, even agent-scope, was seen to return a stale line for milliseconds: batch_kernel.hpp). Bounded:
+        // 20 ms without the last flag and the launch reports a failed check (the host repeats the query through the exact kernel).
+        unsigned long long rec[8];
+        uint32_t my_used = 0u;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) rec[u] = ~0ull;
+        bool have = tid >= n_wg;
+        const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
+        bool timed_out = false;
+        for (;;) {
+            if (!have) {
+                const uint32_t f = __hip_atomic_fetch_or(&G.ready[tid], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (f == G.epoch) {
+                    // (a record has a 128-byte line of its own -- 8 slots, then `used` --: no other thread's load can have brought
+                    //  it into a cache before its flag was up)
+                    const unsigned long long *src = G.slots + (size_t)tid * SINGLE_REC_STRIDE;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) rec[u] = ld_agent(src + u);
+                    my_used = __hip_atomic_load(reinterpret_cast<const uint32_t *>(src + WG_SLOTS), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    have = true;
+                }
+            }
+            if (__ballot(!have) == 0ull) break;
+            if (__builtin_amdgcn_s_memrealtime() - t_begin > 2000000ull) {
+                timed_out = true;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+        }
+        unsigned long long *sel_stamps = G.trace ? G.trace + (size_t)gridDim.x * 64u : nullptr;  // (behind the per-wave rows)
+        if (sel_stamps && tid == 0) sel_stamps[7] = __builtin_amdgcn_s_memrealtime();  // this wave holds its 64 records
+        if (timed_out) my_used = 0xFFFFFFFFu;  // (above every key: fewer than k rows reach it -- the check fails, nothing is written)
+        (void)select_local(G, SP, n_wg, tid, blockDim.x, L.u.sel, 1.0f, sel_stamps, rec, my_used);
+        if (sel_stamps && tid == 0) sel_stamps[5] = __builtin_amdgcn_s_memrealtime();
+        return;
+    }
 
     // x first (two words per thread: they return ahead of the packets), then this wave's first packets
     // (clamped addresses, masked values: two loads in flight, no branch around either)
@@ -470,19 +527,21 @@ __global__ void __launch_bounds__(512, 4) single_kernel(const StreamParams P, co
     const uint32_t q = wave * n_wg + bid;
     uint32_t p0 = 0, np = 0;
     if (q < P.n_parts) TKSPMV_PARTITION_RANGE(P, q, p0, np);
+    // (round 5, as in the batch kernel: buffer loads -- resource = this wave's partition, scalar byte offset per packet, the lane's
+    //  share as a constant vector offset: no vector address arithmetic per packet --, and the row base of a packet looked up on the
+    //  candidate path only)
     Pkt<C, VT> buf[NBUF];
-    uint32_t rbs[NBUF];
     const uint8_t *pk = P.packets + (size_t)p0 * P.packet_bytes;
+    const __amdgpu_buffer_rsrc_t rsrc = stream_resource(pk, np * P.packet_bytes);
+    const LaneOffsets lo = lane_offsets<C, VT>(lane);
 #pragma unroll
     for (int u = 0; u < NBUF - 1; ++u) {
-        rbs[u] = 0u;
         if (np > 0) {
             const uint32_t iu = ((uint32_t)u < np) ? (uint32_t)u : (np - 1);
-            load_packet<C, VT>(pk + (size_t)iu * P.packet_bytes, lane, buf[u]);
-            rbs[u] = scalar_load(P.pkt_row + p0 + iu);
+            load_packet_buf<C, VT>(rsrc, iu * P.packet_bytes, lo, buf[u]);
         }
     }
-    rbs[NBUF - 1] = 0u;
+    uint32_t req_off = (np > (uint32_t)(NBUF - 1) ? (uint32_t)(NBUF - 1) : (np > 0u ? np - 1u : 0u)) * P.packet_bytes;  // the next request's packet
     // which waves of this workgroup stream (lane w < 8 looks at wave w): the workgroup's threshold is the smallest of THEIR words
     bool wave_has = false;
     {
@@ -548,19 +607,18 @@ __global__ void __launch_bounds__(512, 4) single_kernel(const StreamParams P, co
                 const uint32_t i = i0 + (uint32_t)u;
                 if (i >= np) break;
                 const Pkt<C, VT> &cur = buf[u];
-                const uint32_t rb_cur = rbs[u];
                 {
-                    // Unconditional (index clamped to the last packet): a fixed number of younger loads lets the compiler wait
+                    // Unconditional (offset clamped to the last packet): a fixed number of younger loads lets the compiler wait
                     // with a counted vmcnt instead of vmcnt(0).
-                    const uint32_t ia = (i + (NBUF - 1) < np) ? (i + (NBUF - 1)) : (np - 1);
-                    load_packet<C, VT>(pk + (size_t)ia * P.packet_bytes, lane, buf[(u + NBUF - 1) % NBUF]);
-                    rbs[(u + NBUF - 1) % NBUF] = scalar_load(P.pkt_row + p0 + ia);
+                    load_packet_buf<C, VT>(rsrc, req_off, lo, buf[(u + NBUF - 1) % NBUF]);
+                    if (i + (uint32_t)NBUF < np) req_off += P.packet_bytes;
                 }
                 const float tau = __uint_as_float(__hip_atomic_load(&misc[MISC_TAU], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
                 const Reduced<C> Rd = reduce_packet<C, QM>(cur, carry, xbase, 0u);
                 if (tr && i == 0u) tr2 = __builtin_amdgcn_s_memrealtime() + (__float_as_uint(Rd.S) & 0u);
                 if (__any(trigger_of<C, false>(Rd) >= tau)) {
                     const RowSums<C> R = expand<C, false>(Rd, packet_flags<C, QM>(cur));
+                    const uint32_t rb_cur = scalar_load(P.pkt_row + p0 + i);  // (row of the first row end of this packet)
                     const float wm = offer_candidates<C, QM, WAVE_CAP, false>(P, R, rb_cur, tau, lane, 0u, false, wcand, wcnt, misc, true);
                     if (wm > top2 && wm >= min_units) {
                         // (a wave with a single packet has no second maximum: it stands for one row)
@@ -615,8 +673,9 @@ __global__ void __launch_bounds__(512, 4) single_kernel(const StreamParams P, co
         const uint32_t r = valid ? L.rank[lane] : 0xFFFFu;
         const unsigned long long v = L.stg[lane];
         const uint32_t n_valid = (uint32_t)__popcll(__ballot(valid));
-        if (valid && r < WG_SLOTS) st_agent(G.slots + (size_t)bid * WG_SLOTS + r, v);
-        if (lane < WG_SLOTS && lane >= n_valid) st_agent(G.slots + (size_t)bid * WG_SLOTS + lane, pack_cand(0u, SLOT_INVALID));
+        unsigned long long *my_slots = G.slots + (size_t)bid * (dedicated ? SINGLE_REC_STRIDE : WG_SLOTS);
+        if (valid && r < WG_SLOTS) st_agent(my_slots + r, v);
+        if (lane < WG_SLOTS && lane >= n_valid) st_agent(my_slots + lane, pack_cand(0u, SLOT_INVALID));
         // what did not fit the 8 slots goes on record one step up (a dropped row may tie with the best of them)
         uint32_t used = 0u;
         const uint64_t b8 = __ballot(valid && r == WG_SLOTS);
@@ -637,7 +696,7 @@ __global__ void __launch_bounds__(512, 4) single_kernel(const StreamParams P, co
             if (t_end > min_units) next_prior = t_end * 0.95f;
         }
         if (tr) tr6 = __builtin_amdgcn_s_memrealtime();
-        if (lane == 8u) __hip_atomic_store(&G.used[bid], used, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 8u) __hip_atomic_store(dedicated ? reinterpret_cast<uint32_t *>(my_slots + WG_SLOTS) : &G.used[bid], used, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (lane == 9u && G.wg_prior && next_prior >= 0.0f && xnorm > 0.0f) G.wg_prior[bid] = next_prior / xnorm;  // (relative to sum |x|; read by the NEXT launch)
         // Hand-off (cdna_hip_programming.md Guideline 16): the record is made of write-through stores; drain them, then ONE
         // relaxed agent-scope ticket add (two levels: 8 group counters and a top counter on separate 128-byte lines); the workgroup
@@ -645,7 +704,10 @@ __global__ void __launch_bounds__(512, 4) single_kernel(const StreamParams P, co
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (tr) tr7 = __builtin_amdgcn_s_memrealtime();  // record drained
         uint32_t last = 0u;
-        if (lane == 0) {
+        if (dedicated) {  // (the selector polls this word: nothing to wait for, the workgroup is through)
+            if (lane == 0) __hip_atomic_store(&G.ready[bid], G.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) L.u.sel.last = 0u;
+        } else if (lane == 0) {
             const uint32_t g = bid & 7u;
             const uint32_t n_in_group = (n_wg - g + 7u) >> 3;
             const uint32_t n_groups = n_wg < 8u ? n_wg : 8u;

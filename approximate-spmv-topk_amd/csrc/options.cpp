@@ -17,6 +17,7 @@ static const OptionDef k_options[] = {
      "check repairs the query through the exact kernel). Ignored above 512 workgroups."},
     {"SIGNATURES", "behaviour", "0 | 1 (default 1)", "1: a carried workgroup threshold is used only for a query whose signature (sum x / sum |x|, share of the columns that carry it) matches the query it came from, two priors remembered per workgroup; 0: round 4's behaviour (every query starts from the last prior; a failed check suspends carrying)"},
     {"LOCAL_BETA", "tuning", "float (default 1.0)", "factor applied to a carried workgroup threshold before the next query uses it"},
+    {"SINGLE_SELECTOR", "behaviour", "0 | 1 (default 1)", "1: workgroup 0 of a single-query launch only selects -- it polls the other workgroups' flags and loads each record as it is delivered; 0: round 4's scheme (every workgroup streams, the one that draws the last ticket selects)"},
     {"SINGLE", "behaviour", "0 | 1 (default 1)", "0: tkspmv_run uses the stream kernel with the device-wide exchange instead of the single-query kernel with local thresholds"},
     {"BATCH", "behaviour", "0 | 1 (default 1)", "0: tkspmv_enqueue_batch / _many launch one kernel per query"},
     {"BATCH_MAX", "tuning", "1..32 (default 32)", "queries per batch launch"},

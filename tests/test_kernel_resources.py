@@ -96,13 +96,18 @@ template __global__ void stream_kernel<4, false, 1024, 0, 3, false>(const Stream
         blocks, cur = [], None
         for ln in lines[start:end]:
             if re.match(r"^\.LBB\d+_\d+:", ln):
-                cur = {"name": ln.split(":")[0], "scratch": 0, "hot": False}
+                cur = {"name": ln.split(":")[0], "scratch": 0, "hot": False, "dpp": False, "max3": False}
                 blocks.append(cur)
             elif cur is not None:
                 if "scratch_" in ln:
                     cur["scratch"] += 1
-                if (("global_load_dword" in ln or "buffer_load_dword" in ln) and " nt" in ln) or "v_add_f32_dpp" in ln:  # (a packet request -- flat or, since round 5, buffer loads; the fp32 scan)
+                if ("global_load_dword" in ln or "buffer_load_dword" in ln) and " nt" in ln:  # (a packet request -- flat or, since round 5, buffer loads)
                     cur["hot"] = True
+                # (the fp32 scan: DPP adds WITH the trigger's v_max3 behind them -- the server wave's sums of x use DPP adds too, round 5)
+                cur["dpp"] = cur["dpp"] or "v_add_f32_dpp" in ln
+                cur["max3"] = cur["max3"] or "v_max3_f32" in ln
+        for b in blocks:
+            b["hot"] = b["hot"] or (b["dpp"] and b["max3"])
         hot = [b for b in blocks if b["hot"]]
         assert len(hot) >= 3, "the streaming loop was not found in the ISA of " + lines[start].split(":")[0]
         assert all(b["scratch"] == 0 for b in hot), (lines[start].split(":")[0], [b for b in hot if b["scratch"]])
