@@ -216,6 +216,7 @@ struct EngineImpl {
     uint32_t pace_tuned_us = 0;  // 0: the pacing is the static default (or an option); else what tkspmv_create's measurement took
     uint32_t pace_quads = 0, pace_levels = 3, pace_base = 0; // pacing by rank (BatchParams::pace_quads, pace_levels, pace_base)
     unsigned long long *d_wg_times = nullptr;  // option WG_TIMES: BatchParams::wg_times of the LAST batch launch (read through tkspmv_debug_trace)
+    bool pace_carry = true;  // option PACE_CARRY=0: every launch starts unpaced
     uint32_t *d_wg_pace = nullptr;  // [grid] the pause every workgroup ended its last launch with (BatchParams::wg_pace)
     mutable uint64_t batch_launches = 0;
     uint32_t n_sel_wg = 1;   // selector workgroups of a batch launch (BatchParams::n_selectors): 4 on small matrices
@@ -475,7 +476,7 @@ struct EngineImpl {
         B.pace_quads = pace_quads;
         B.pace_levels = pace_levels;
         B.pace_base = pace_base;
-        B.wg_pace = d_wg_pace;
+        B.wg_pace = pace_carry ? d_wg_pace : nullptr;
         B.wg_times = d_wg_times;
         B.prior_block = reinterpret_cast<uint32_t *>(d_wg_prior + grid);
         B.gate_parity = (uint32_t)(batch_launches & 1u);
@@ -1273,6 +1274,7 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
         HIP_TRY(hipMemcpy(m.d_sell_part_count, sm.part_count.data(), (size_t)m.sell_parts * 4, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(m.d_sell_part_slice0, sm.part_slice0.data(), (size_t)m.sell_parts * 4, hipMemcpyHostToDevice));
         HIP_TRY(hipMalloc((void **)&m.d_multi_out_idx, 2 * (size_t)MULTI_Q_MAX * d.k * 4));
+        HIP_TRY(hipMalloc((void **)&m.d_multi_out_val, 2 * (size_t)MULTI_Q_MAX * d.k * 4));
         HIP_TRY(hipStreamCreateWithFlags(&m.side, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&m.ev_fork, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&m.ev_join, hipEventDisableTiming));
@@ -1351,6 +1353,7 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
     if (const char *f = opt("PACE_LEVELS")) m.pace_levels = (uint32_t)std::max(1, std::min(8, atoi(f)));
     if (const char *f = opt("PACE")) m.pace_quads = (uint32_t)std::max(0, std::min(32, atoi(f)));
     if (const char *f = opt("PACE_BASE")) m.pace_base = (uint32_t)std::max(0, std::min(64, atoi(f)));
+    if (const char *f = opt("PACE_CARRY")) m.pace_carry = atoi(f) != 0;
     if (m.use_local && m.pace_quads != 0u) {
         HIP_TRY(hipMalloc((void **)&m.d_wg_pace, (size_t)m.grid * 4));
         HIP_TRY(hipMemset(m.d_wg_pace, 0, (size_t)m.grid * 4));
@@ -1490,10 +1493,10 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
     // XCDs share the memory system evenly -- unpaced, four of them stream a query in 12 us and the other four in 22-26
     // (tools/wg_times.py) -- and its best setting moves with the box: quantum 2 over 6 eighths on the pool's fast boxes (16.3 us per
     // query, 17.6 at round 4's 4 over 3), 2 over 7 on its slow ones (17.4 against 18.9 and 20.0). So the engine measures: a handful of
-    // settings, three launches of 32 synthetic queries each, twice through, ~10 ms of tkspmv_create.
+    // settings, three launches of 32 synthetic queries each, twice through, behind 64 launches of warm-up: ~55 ms of tkspmv_create.
     if (m.use_local && m.can_batch && m.pace_quads != 0u && !opt("PACE") && !opt("PACE_LEVELS") && !opt("PACE_BASE") &&
         (!opt("AUTOTUNE") || atoi(opt("AUTOTUNE")) != 0) && m.pm.packet_bytes == 1408u) {
-        const int nq = BATCH_MAX;
+        const int nq = std::min((int)BATCH_MAX, m.batch_max);
         std::vector<float> hx((size_t)nq * d.cols);
         uint32_t lcg = 0x1234567u;
         for (float &v : hx) {
@@ -1512,6 +1515,13 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
         float best_ms[NC];
         for (float &b : best_ms) b = 1e30f;
         const auto t_tune = std::chrono::steady_clock::now();
+        // (a GPU that has idled streams 10-15 % slower for its first ~20 ms -- 19.4 us per query falling to 16.7 over thirty launches,
+        //  tools/launch_series.py --: the settings are compared on a GPU that has been busy for 64 launches)
+        m.pace_quads = cand[0][0];
+        m.pace_levels = cand[0][1];
+        for (int w = 0; w < 64; ++w) m.launch_batch(xs.data(), oi.data(), ov.data(), nq, m.stream);
+        HIP_TRY(hipStreamSynchronize(m.stream));
+        HIP_TRY(m.settle());
         for (int pass = 0; pass < 2; ++pass)
             for (int c = 0; c < NC; ++c) {
                 m.pace_quads = cand[c][0];

@@ -26,6 +26,7 @@ static const OptionDef k_options[] = {
     {"PACE", "tuning", "0..32 (default by size)", "pacing quantum of the batch kernel's workgroups by rank (s_sleep units); 0 = none"},
     {"PACE_LEVELS", "tuning", "1..8", "number of distinct pacing ranks"},
     {"AUTOTUNE", "behaviour", "0 | 1 (default 1)", "1: tkspmv_create measures a handful of pacing settings on the matrix it has just packed (engines of checked local thresholds that pace at all; ~10 ms) and keeps the fastest; PACE / PACE_LEVELS / PACE_BASE switch it off"},
+    {"PACE_CARRY", "tuning", "0 | 1 (default 1)", "1: a workgroup starts a launch with the pause it ended the previous launch with; 0: every launch starts unpaced"},
     {"PACE_BASE", "tuning", "0..64 (default 0)", "pause per packet (s_sleep units) of EVERY workgroup of the batch kernel, whatever its rank: a uniform throttle (tuning runs)"},
     {"REPAIR", "behaviour", "host | stream (default host)",
      "who looks at the verdict of a launch of checked local thresholds: host = the launch goes out alone once the verdicts the host has seen are clean, "

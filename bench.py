@@ -194,7 +194,8 @@ def live_traffic(a, n_queries=128):
                    str(a.cols), "--nnz", str(a.nnz), "--k", str(a.k), "--replicas", str(a.replicas), "--queries", str(a.queries),
                    "--nnz-per-lane", str(a.nnz_per_lane), "--waves-per-cu", str(a.waves_per_cu), "--threads-per-wg",
                    str(a.threads_per_wg)]
-            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=240)
+            # (TKSPMV_AUTOTUNE=0: the launches tkspmv_create measures its pacing with would be summed into the traffic)
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp", TKSPMV_AUTOTUNE="0"), capture_output=True, text=True, timeout=240)
             if r.returncode != 0:
                 return None, f"rocprofv3 --pmc {counter} failed (rc {r.returncode}): {(r.stderr or r.stdout)[-200:]}"
             total, launches = 0.0, set()
@@ -254,6 +255,12 @@ def multi_query_leg(mod, m, dxs, a, device, alg_bytes):
             "note": "a pass is bound by LDS reads and instruction issue, not by HBM: per-query algorithmic GB/s is not an "
                     "HBM figure here and is not compared with the roofline",
             "runs": out}
+
+
+def _mark(what):
+    """TKSPMV_BENCH_TRACE=1: a line on stderr as every leg begins (which leg was running when something went wrong)."""
+    if os.environ.get("TKSPMV_BENCH_TRACE"):
+        print(f"[bench {time.strftime('%H:%M:%S')}] {what}", file=sys.stderr, flush=True)
 
 
 def single_query_leg(mod, m, xs, dxs, a, device, eng, alg_bytes):
@@ -437,6 +444,7 @@ def bench_single(a, mod, torch, np, dev, local_rank):
     info = eng.info()
     alg_bytes = info["algorithmic_bytes"]
     # ---- warm-up, then EXACTLY `steps` queries between two device synchronisations (+ a hipEvent pair on the engine stream)
+    _mark('headline: warm-up + timed region')
     if a.warmup > 0:  # (through the very call the timed region uses: its host path -- ctypes, events -- is warm as well)
         eng.time_queries(dxs.data_ptr(), a.queries, a.warmup)
     # (torch.cuda.synchronize() waits for the whole device, the engine's own stream included: one synchronisation per side)
@@ -456,9 +464,13 @@ def bench_single(a, mod, torch, np, dev, local_rank):
     # before the first wait (tkspmv_time_query_batches: one hipEvent between consecutive ones), so the GPU never idles between
     # them: median / p95 of the kernel under sustained load. The same batch timed one call at a time -- each behind a
     # synchronisation and a host-side gap, after which this GPU runs 10-25 % slower for about a millisecond -- is kept beside it.
+    _mark('repetitions')
     counters = eng.debug_counters()  # (of the timed region and its warm-up: checks of the local thresholds, repairs, gate)
     n_rep = min(max(a.steps, 32), 512)
     n_reps = max(a.reps, 30) + 2
+    # (a GPU that has idled -- the parity check above runs on the host for a second -- streams 10-15 % slower for its first ~20 ms: the
+    #  sustained figures are taken behind 96 launches of the same work, tools/launch_series.py)
+    eng.time_query_batches(dxs.data_ptr(), a.queries, n_rep, 96)
     reps = [v / 1e3 for v in eng.time_query_batches(dxs.data_ptr(), a.queries, n_rep, n_reps)][2:]
     gap = [eng.time_queries(dxs.data_ptr(), a.queries, n_rep) / 1e3 for _ in range(10)][2:]
     timing = {"repetitions": len(reps), "dropped": 2, "queries_per_repetition": n_rep,
@@ -475,6 +487,7 @@ def bench_single(a, mod, torch, np, dev, local_rank):
                            "note": "workgroup-local thresholds are checked by every selection; a failed check repeats the query inside "
                                    "the same launch with the device-wide exchange (counters of the warm-up + timed region)"}
     # ---- what this GPU charges for only LOADING the same stream (engine geometry, no arithmetic): boxes differ by several %
+    _mark('load-only floor')
     read_us = sorted(eng.time_stream_read(64) / 1e3 for _ in range(7))[3]
     c12 = os.environ.get("TKSPMV_F32_C12", "1") != "0" and a.cols <= 1024 and int(info["packet_entries"]) == 256
     stream_bytes = int(info["n_packets"]) * (1408 if c12 else int(info["packet_entries"]) * 6)  # 12-bit column words: 5.5 B per entry
@@ -487,13 +500,16 @@ def bench_single(a, mod, torch, np, dev, local_rank):
                  "median_kernel_vs_read_only": read_us / pct(reps, 50)}
     extra["exchange_state_bytes"] = int(info.get("state_bytes", 0))
     if not a.skip_warm:
+        _mark('single query leg')
         extra["single_query"] = single_query_leg(mod, m, xs, dxs, a, local_rank, eng, alg_bytes)
+        _mark('profile()')
         prof = eng.profile(dxs.data_ptr(), a.queries, 100)
         extra["kernels_us"] = {"query_back_to_back": prof["query_ns"] / 1e3,
                                "single_query_launch_with_event_bracket": prof["stream_kernel_ns"] / 1e3,
                                "event_bracket_around_an_empty_kernel": prof["event_bracket_ns"] / 1e3,
                                "spmv_only_variant": prof["scores_kernel_ns"] / 1e3}
         # same matrix every query (fits the Infinity Cache): the steady state of a deployed single-matrix service
+        _mark('cache-warm engine')
         warm = mod.SpMV(m.row, m.col, m.val, m.rows, m.cols, k=a.k, device=local_rank)
         warm.enqueue_many(dxs.data_ptr(), a.queries, max(a.warmup, 32))
         warm.synchronize()
@@ -511,11 +527,13 @@ def bench_single(a, mod, torch, np, dev, local_rank):
                                "note": "one matrix (118 MB packed) re-read every query: served largely by the 256 MiB "
                                        "Infinity Cache, not comparable with the HBM roofline"}
         if a.multi_q:
+            _mark('multi-query leg')
             extra["multi_query"] = multi_query_leg(mod, m, dxs, a, local_rank, alg_bytes)
     # ---- a stream of queries that is NOT stationary: the same matrix, every query scaled by 1, 0.01 or 3 (drawn per query):
     # carried thresholds are invalidated again and again, checks fail, queries are repeated -- what the mode costs then. (The last
     # leg on this engine: every failed check suspends carried thresholds for 16 .. 4096 further selections, which would colour
     # whatever is measured behind it.)
+    _mark('nonstationary leg')
     rng = np.random.default_rng(11)
     sc = rng.choice([1.0, 0.01, 3.0], size=a.queries).astype(np.float32)
     # (round 4: carried thresholds are relative to the query's L1 norm, so scales alone no longer invalidate them; what does is a
@@ -551,6 +569,7 @@ def bench_single(a, mod, torch, np, dev, local_rank):
     eng.close()
     if not a.skip_warm:
         # the same workload with 16-bit column words (TKSPMV_F32_C12=0: 6 instead of 5.5 bytes per nnz, same bits)
+        _mark('16-bit column words leg')
         os.environ["TKSPMV_F32_C12"] = "0"
         try:
             e16 = mod.SpMV(m.row, m.col, m.val, m.rows, m.cols, k=a.k, device=local_rank, stream_replicas=a.replicas)
@@ -566,10 +585,12 @@ def bench_single(a, mod, torch, np, dev, local_rank):
         except Exception as e:  # noqa: BLE001
             extra["f32_c16"] = {"error": str(e)}
         del os.environ["TKSPMV_F32_C12"]
+        _mark('configs legs')
         extra["configs"] = config_legs(mod, a, local_rank)
     # ---- HBM traffic of the headline kernel
     traffic, source, detail = None, "off", None
     if a.traffic in ("auto", "live") and not a.skip_warm:
+        _mark('live traffic (rocprofv3 --pmc child)')
         traffic, detail = live_traffic(a)
         source = "live" if traffic is not None else "static"
         if traffic is None:
