@@ -427,9 +427,21 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
         for (;;) {
             if (staged < nq && staged - tail < 2u) {
                 const uint32_t par = staged & 1u;
-                const float *xg = B.io[qx(staged)].x;
+                // (wave-uniform, and said so: a resource descriptor the compiler cannot prove uniform gets a loop of readfirstlanes around
+                //  EVERY load -- the sixteen loads of x one by one again)
+                const float *xg;
+                {
+                    const uint64_t xa = (uint64_t)(uintptr_t)B.io[qx(staged)].x;
+                    // (the builtin returns int: through uint32_t, or a low word with its top bit set sign-extends into the high one)
+                    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(xa >> 32));
+                    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)xa);
+                    xg = reinterpret_cast<const float *>((uintptr_t)(((uint64_t)hi << 32) | (uint64_t)lo));
+                }
                 const uint32_t prior_blocked = carry_local ? __hip_atomic_load(B.prior_block, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1u;
-                auto x_at = [&](uint32_t i) __attribute__((always_inline)) -> float { return xg[i]; };
+                const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(xg), 0, (int)(P0.cols * 4u), 0x00020000);
+                auto x_at = [&](uint32_t i) __attribute__((always_inline)) -> float {  // x[i], 0 beyond the columns (the resource's bounds check)
+                    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xres, i * 4u, 0, 0));
+                };
                 float x_scale = 1.0f, unit_scale = 1.0f;
                 if (QM == 2) {
                     float lm = 0.0f;
@@ -439,7 +451,7 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
 #pragma unroll
                         for (int u = 0; u < 16; ++u) {
                             const uint32_t i = b0 + lane + 64u * (uint32_t)u;
-                            r[u] = x_at(i < P0.cols ? i : 0u);  // (always a valid address: see the staging loop below)
+                            r[u] = x_at(i);
                         }
 #pragma unroll
                         for (int u = 0; u < 16; ++u) lm = fmaxf(lm, (b0 + lane + 64u * (uint32_t)u) < P0.cols ? r[u] : 0.0f);
@@ -465,24 +477,13 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
 #pragma unroll 1
                 for (uint32_t b0 = 0; b0 < (uint32_t)XCOLS; b0 += 1024u) {  // 16 loads in flight per lane
                     float r[16];
-                    // (Written as "in range ? load : 0" every load sat in a branch of its own behind an s_waitcnt vmcnt(0) -- sixteen
-                    //  trips through memory one after the other per staging, 6-16 us: what a small shard's query took altogether, and
-                    //  on the device-wide exchange the reason thresholds arrived late. A full-width x -- every BASELINE matrix this
-                    //  kernel streams -- needs no check at all: ONE branch, one base address, sixteen immediate offsets, sixteen loads
-                    //  in flight; else the address is clamped and the VALUE masked, which costs an address per load.)
-                    if (!LOCAL && P0.cols == (uint32_t)XCOLS) {  // (the kernel of local thresholds measured FASTER with the clamped form: 16.8-17.0 against 17.5 us per query at 1M rows)
+                    // (Round 4 found these sixteen loads issued one by one -- "in range ? load : 0" put each into a branch of its own behind
+                    //  an s_waitcnt vmcnt(0): 6-16 us per staging -- and cured it with clamped addresses and masked values, an address pair
+                    //  per load: registers the exact kernel did not have. Round 5: BUFFER loads -- the resource carries x's length, a load
+                    //  beyond it returns 0 by itself; one lane offset, sixteen immediate offsets, sixteen loads in flight whatever the
+                    //  number of columns, in both kernels.)
 #pragma unroll
-                        for (int u = 0; u < 16; ++u) r[u] = x_at(b0 + lane + 64u * (uint32_t)u);
-                    } else {
-#pragma unroll
-                        for (int u = 0; u < 16; ++u) {
-                            const uint32_t i = b0 + lane + 64u * (uint32_t)u;
-                            const float xv = x_at(i < P0.cols ? i : 0u);
-                            r[u] = i < P0.cols ? xv : 0.0f;
-                        }
-                        // (in the exact kernel the compiler issues these one at a time all the same -- an address pair per load
-                        //  is more registers than it has there: narrow x on the device-wide exchange stages x in sixteen trips)
-                    }
+                    for (int u = 0; u < 16; ++u) r[u] = x_at(b0 + lane + 64u * (uint32_t)u);
                     if (carry_local) {
 #pragma unroll
                         for (int u = 0; u < 16; ++u) xabs += fabsf(r[u]);

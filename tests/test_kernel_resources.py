@@ -117,9 +117,8 @@ def test_no_chain_of_loads_waited_for_one_by_one(tmp_path):
     """Round 4 found the server wave staging x with sixteen loads each behind its own `s_waitcnt vmcnt(0)` -- sixteen trips through
     memory in a row, 6-16 us per query, invisible to every functional test (the compiler had put each 'in range ? load : 0' into a
     branch of its own). This compiles the headline kernels on their own and looks for runs of (wait for everything, ONE load) in
-    the ISA: none of 6 or more may exist in the kernel of local thresholds, the single-query kernel and the multi-query kernels;
-    the exact kernel may keep ONE such run -- the staging of an x narrower than 1024 columns (it has no registers for sixteen
-    clamped addresses; a full-width x takes the branch with immediate offsets)."""
+    the ISA: none of 6 or more may exist in the batch kernels (x staged with buffer loads since round 5: the resource's bounds check
+    replaces clamped addresses, narrow x included), the single-query kernel and the multi-query kernels."""
     import shutil
     import subprocess
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
@@ -170,6 +169,5 @@ template __global__ void multi_kernel<4, 0>(const StreamParams, const SelectPara
     flush()
     chains = {n: r for n, r in chains.items() if "select_kernel" not in n and "select_group_kernel" not in n}  # (non-template kernels of the headers)
     assert len(chains) == 6, sorted(chains)
-    for name, runs in chains.items():
-        exact = "batch_kernelILi4ELi1024ELi7ELb0ELb0E" in name
-        assert len(runs) <= (1 if exact else 0), (name, runs)
+    for name, runs in chains.items():  # (round 5: x is staged with buffer loads -- no clamped addresses --, the exact kernel has no such run either)
+        assert len(runs) == 0, (name, runs)
