@@ -184,7 +184,7 @@ struct EngineImpl {
     // repairs what a check flagged after all (an exact launch of the flagged queries, then one more wait). An observed failure
     // puts the in-stream repair launch back behind the next DISTRUST_LAUNCHES launches (it also keeps the gate's books).
     // Launches on a caller's stream are never trusted: nobody tells the engine when the caller has waited.
-    static constexpr uint32_t VERDICT_RING = 1024, DISTRUST_LAUNCHES = 64;
+    static constexpr uint32_t VERDICT_RING = 8192, DISTRUST_LAUNCHES = 64;  // (launches the host may enqueue between two waits and still look at every verdict)
     unsigned long long *h_verdict = nullptr, *h_verdict_dev = nullptr;
     struct PendingCheck {
         BatchArgs A;

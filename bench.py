@@ -61,6 +61,9 @@ def parse():
     ap.add_argument("--nnz-per-lane", type=int, default=0, help="entries per lane and packet (0 = the engine's default)")
     ap.add_argument("--waves-per-cu", type=int, default=0, help="streaming waves per CU (0 = the engine's default)")
     ap.add_argument("--threads-per-wg", type=int, default=0, help="streaming threads per workgroup (0 = the engine's default)")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="profiler runs: nothing but the headline's queries (warm-up, timed region, repetitions) -- no side leg, no nonstationary "
+                         "stream, no CPU baseline, no traffic pass; the kernel trace of such a run holds the headline kernel alone")
     ap.add_argument("--skip-warm", action="store_true",
                     help="profiler runs: nothing but the headline queries (no side legs, homogeneous launches for rocprofv3)")
     ap.add_argument("--multi-q", type=int, nargs="*", default=[4, 8],
@@ -71,7 +74,10 @@ def parse():
                     help="roofline.traffic: a live rocprofv3 --pmc pass over a child run (auto: when rocprofv3 is on PATH), "
                          "or the figure committed under profiles/ (labelled static)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # the child of the live traffic pass
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.headline_only:
+        a.skip_warm = True
+    return a
 
 
 def workload_name(rows, cols, nnz_per_row, nnz, k, replicas):
@@ -299,8 +305,8 @@ def single_query_leg(mod, m, xs, dxs, a, device, eng, alg_bytes):
     counters = eng.debug_counters()
     single = counters.get("single_launches", 0) > 0
     return {"kernel": ("tkspmv::single_kernel<7> (one launch per query: workgroup-local thresholds carried from the previous query, "
-                       "one record per workgroup, selection in the workgroup that draws the last ticket; a failed check repeats "
-                       "the query through tkspmv::stream_kernel)") if single else
+                       "one record per workgroup, workgroup 0 selects -- it loads every record as the workgroup's flag comes up; a failed "
+                       "check repeats the query through tkspmv::stream_kernel)") if single else
                       "tkspmv::stream_kernel<4,false,1024,7,3> (one fused launch per query: stream, flush, in-launch selection)",
             "runs": len(kern), "dropped": 2, "device_us_self_stamped": med, "device_us_self_stamped_p95": pct(kern, 95),
             "kernel_us": med, "kernel_us_p95": pct(kern, 95), "frac": alg_bytes / (med * 1e3) / HBM_PEAK_GBS,
@@ -423,6 +429,17 @@ def config_legs(mod, a, device):
     return out
 
 
+def _finish_headline_only(a, info, alg_bytes, kernel_ns, elapsed, reps, read_us, counters, eng):
+    """--headline-only: a short line (the run exists for the profiler's trace, not for the record)."""
+    eng.close()
+    print(json.dumps({"metric": "queries_per_sec", "mode": "headline_only", "value": a.steps / elapsed, "unit": "queries/s", "steps": a.steps,
+                      "warmup": a.warmup, "kernel_us": kernel_ns / 1e3, "frac": alg_bytes / kernel_ns / HBM_PEAK_GBS,
+                      "sustained_median_us": pct(reps, 50), "p95_over_median": pct(reps, 95) / pct(reps, 50), "read_only_us": read_us,
+                      "checks_failed": int(counters["checks_failed"]),
+                      "pacing": f"{counters.get('pace_quantum')}x{counters.get('pace_levels')}", "pace_tuned_us": counters.get("pace_tuned_us"),
+                      "launches_of_the_pacing_measurement": 100 if counters.get("pace_tuned_us") else 0}))
+
+
 # ---- N = 1: BASELINE configs[1] ---------------------------------------------------------------------------------------------
 def bench_single(a, mod, torch, np, dev, local_rank):
     m = mod.generate_matrix(a.rows, a.cols, a.nnz, "gamma", 2)
@@ -484,8 +501,10 @@ def bench_single(a, mod, torch, np, dev, local_rank):
     extra = {"parity_checked": parity_ok, "parity": parity, "timing": timing, "host_side": host_side}
     extra["thresholds"] = {"checks_failed": counters["checks_failed"], "carried_thresholds_suspended_for": counters["suspended_for"],
                            "gate_closed_for_launches": counters["local_off_for_launches"], "batch_launches": counters["batch_launches"],
-                           "note": "workgroup-local thresholds are checked by every selection; a failed check repeats the query inside "
-                                   "the same launch with the device-wide exchange (counters of the warm-up + timed region)"}
+                           "late_repairs": counters.get("late_repairs", 0), "launches_without_repair_launch": counters.get("trusted_launches", 0),
+                           "note": "workgroup-local thresholds are checked by every selection; a failed check repeats the query through the "
+                                   "exact kernel -- behind the launch in the stream while the host has not seen clean verdicts, from the host's "
+                                   "next wait otherwise (counters of the warm-up + timed region)"}
     # ---- what this GPU charges for only LOADING the same stream (engine geometry, no arithmetic): boxes differ by several %
     _mark('load-only floor')
     read_us = sorted(eng.time_stream_read(64) / 1e3 for _ in range(7))[3]
@@ -533,6 +552,8 @@ def bench_single(a, mod, torch, np, dev, local_rank):
     # carried thresholds are invalidated again and again, checks fail, queries are repeated -- what the mode costs then. (The last
     # leg on this engine: every failed check suspends carried thresholds for 16 .. 4096 further selections, which would colour
     # whatever is measured behind it.)
+    if a.headline_only:
+        return _finish_headline_only(a, info, alg_bytes, kernel_ns, elapsed, reps, read_us, counters, eng)
     _mark('nonstationary leg')
     rng = np.random.default_rng(11)
     sc = rng.choice([1.0, 0.01, 3.0], size=a.queries).astype(np.float32)

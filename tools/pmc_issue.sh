@@ -16,7 +16,7 @@ i=0
 for counters in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD" \
                 "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS" "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM GRBM_GUI_ACTIVE"; do
     i=$((i + 1))
-    rocprofv3 --pmc $counters --kernel-trace --output-format csv -d "$OUT/batch$i" -- python3 "$REPO/bench.py" --steps 320 --warmup 32 --cpu-seconds 0 --skip-warm > "$OUT/batch$i.json" 2> "$OUT/batch$i.err"
+    TKSPMV_AUTOTUNE=0 TKSPMV_PACE=2 TKSPMV_PACE_LEVELS=6 rocprofv3 --pmc $counters --kernel-trace --output-format csv -d "$OUT/batch$i" -- python3 "$REPO/bench.py" --steps 320 --warmup 32 --headline-only > "$OUT/batch$i.json" 2> "$OUT/batch$i.err"
     for q in 8 4; do
         rocprofv3 --pmc $counters --kernel-trace --output-format csv -d "$OUT/multi${q}_$i" -- python3 "$REPO/bench.py" --multi-only $q --steps 320 --warmup 32 > "$OUT/multi${q}_$i.json" 2> "$OUT/multi${q}_$i.err"
     done

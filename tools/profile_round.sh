@@ -23,11 +23,13 @@ python3 bench.py --steps 3000 --warmup 300 > "$OUT/bench_plain.json" 2> "$OUT/be
 # (the driver's own command line: ONE launch of 20 queries, start-up and tail included)
 python3 bench.py --gpus 1 --steps 20 --warmup 5 --skip-warm --cpu-seconds 0 --traffic off > "$OUT/bench_steps20.json" 2> "$OUT/bench_steps20.err"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/ktrace" -- python3 "$REPO/bench.py" --steps 2048 --warmup 256 --cpu-seconds 0 --skip-warm > "$OUT/bench_under_rocprofv3.json" 2> "$OUT/ktrace.err"
+# (--headline-only: the trace holds nothing but headline queries -- VERDICT r4 --, plus the 100 launches tkspmv_create measures its pacing
+#  with, which tools/summarize_profile.py leaves out of <tag>_headline_launches.json)
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/ktrace" -- python3 "$REPO/bench.py" --steps 2048 --warmup 256 --headline-only > "$OUT/bench_under_rocprofv3.json" 2> "$OUT/ktrace.err"
 i=0
 for counters in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
     i=$((i + 1))
-    rocprofv3 --pmc $counters --kernel-trace --output-format csv -d "$OUT/pmc$i" -- python3 "$REPO/bench.py" --steps 320 --warmup 32 --cpu-seconds 0 --skip-warm > "$OUT/pmc$i.json" 2> "$OUT/pmc$i.err"
+    TKSPMV_AUTOTUNE=0 TKSPMV_PACE=2 TKSPMV_PACE_LEVELS=6 rocprofv3 --pmc $counters --kernel-trace --output-format csv -d "$OUT/pmc$i" -- python3 "$REPO/bench.py" --steps 320 --warmup 32 --headline-only > "$OUT/pmc$i.json" 2> "$OUT/pmc$i.err"
 done
 fi
 if [ "$PART" = A ]; then cd "$REPO"; python3 tools/summarize_profile.py "$OUT" "$TAG"; exit 0; fi

@@ -36,6 +36,34 @@ for src, name in (("bench_plain.json", f"{tag}_bench_plain.json"),
         if lines:
             open(os.path.join(dst, name), "w").write(lines[-1] + "\n")
 
+# The headline kernel alone, launch by launch (the kernel trace of a --headline-only run): the first 100 launches of the kernel of
+# local thresholds are tkspmv_create's pacing measurement (synthetic queries, six settings), left out; the rest are warm-up, timed
+# region and repetitions -- 32 real queries each.
+kt = find("ktrace/**/*kernel_trace.csv")
+if kt:
+    rows = [r for r in csv.DictReader(open(kt)) if "batch_kernel" in r.get("Kernel_Name", "")]
+    def is_local(n):
+        return n.rstrip(">)").split(",")[-1].strip().startswith("true") or ", true>" in n
+    loc = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows if is_local(r["Kernel_Name"]))
+    exa = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows if not is_local(r["Kernel_Name"])]
+    line = {}
+    p = os.path.join(out, "bench_under_rocprofv3.json")
+    if os.path.exists(p):
+        ls = [l for l in open(p).read().splitlines() if l.startswith("{")]
+        line = json.loads(ls[-1]) if ls else {}
+    skip = int(line.get("launches_of_the_pacing_measurement", 100))
+    kept = [e - s for s, e in loc[skip:]]
+    full = sorted(d for d in kept if d > 0.6 * sorted(kept)[len(kept) // 2]) if kept else []  # (the warm-up's and the region's last launches may be shorter)
+    if full:
+        json.dump({"kernel": "tkspmv::batch_kernel<4,1024,7,false,true>", "source": "rocprofv3 --kernel-trace of bench.py --headline-only (this tag's bench_under_rocprofv3.json)",
+                   "launches_in_trace": len(loc), "launches_left_out": skip, "why": "tkspmv_create measures its pacing with them (synthetic queries)",
+                   "full_launches": len(full), "queries_per_launch": 32, "mean_launch_us": sum(full) / len(full) / 1e3,
+                   "median_launch_us": full[len(full) // 2] / 1e3, "p95_launch_us": full[int(0.95 * (len(full) - 1))] / 1e3,
+                   "mean_us_per_query": sum(full) / len(full) / 1e3 / 32, "median_us_per_query": full[len(full) // 2] / 1e3 / 32,
+                   "exact_kernel_launches": len(exa), "exact_kernel_mean_us": (sum(exa) / len(exa) / 1e3) if exa else None,
+                   "bench_line_of_the_same_run": {k: line.get(k) for k in ("kernel_us", "sustained_median_us", "p95_over_median", "read_only_us", "pacing", "checks_failed")}},
+                  open(os.path.join(dst, f"{tag}_headline_launches.json"), "w"), indent=1)
+
 for q in (8, 4):  # the multi-query path alone: per-kernel summary + the JSON line of that profiled run
     src = find(f"mtrace{q}/**/*kernel_stats.csv")
     if src:
