@@ -840,8 +840,18 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
                 }
             }
             // a workgroup ahead of the field yields: fewer requests from it, more bandwidth for the XCDs that lag
+            // (the pause's bits, one s_sleep each -- units of 128 cycles: a loop of s_sleep(2) spent four scalar instructions per unit,
+            //  a quarter of the kernel's scalar instructions with six eighths of the field pausing)
+            if (pace != 0u) {
+                if (pace & 1u) __builtin_amdgcn_s_sleep(2);
+                if (pace & 2u) __builtin_amdgcn_s_sleep(4);
+                if (pace & 4u) __builtin_amdgcn_s_sleep(8);
+                if (pace & 8u) __builtin_amdgcn_s_sleep(16);
+                if (pace & 16u) __builtin_amdgcn_s_sleep(32);
+                if (pace & 32u) __builtin_amdgcn_s_sleep(64);
 #pragma unroll 1
-            for (uint32_t z = pace; z != 0u; --z) __builtin_amdgcn_s_sleep(2);
+                for (uint32_t z = pace >> 6; z != 0u; --z) __builtin_amdgcn_s_sleep(127);
+            }
             const uint32_t tau_bits = lds_load(&mp[MISC_TAU]);
             const float tau = __uint_as_float(tau_bits);
             const Reduced<C> Rd = reduce_packet<C, QM>(cur, carry, xbase, P0.fixed_mask);

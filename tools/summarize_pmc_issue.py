@@ -45,6 +45,39 @@ for run in list(res):
         for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD"):
             if k in res[run]:
                 res[run][k + "_per_query"] = res[run][k] / n
+# The headline kernel launch by launch (round 5: the profiled run is bench.py --headline-only, whose launches the line above does not
+# count): per counter the MEDIAN launch of the kernel of local thresholds (32 queries each) / 32 -- and per packet of the matrix.
+per = {}
+for d in sorted(glob.glob(os.path.join(out, "batch*"))):
+    if not os.path.isdir(d):
+        continue
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            kn = row.get("Kernel_Name", "")
+            if "batch_kernel" not in kn or not (kn.rstrip(">)").split(",")[-1].strip().startswith("true") or ", true>" in kn):
+                continue
+            key = (row["Counter_Name"], row["Dispatch_Id"])
+            per[key] = per.get(key, 0.0) + float(row["Counter_Value"])
+if per and "batch" in res:
+    med = {}
+    for name in sorted({k[0] for k in per}):
+        v = sorted(x for (n, _), x in per.items() if n == name)
+        med[name] = v[len(v) // 2]
+    n_packets = None
+    for f in sorted(glob.glob(os.path.join(out, "batch*.json"))):
+        try:
+            j = json.loads([l for l in open(f).read().splitlines() if l.startswith("{")][-1])
+            n_packets = j.get("n_packets") or n_packets
+        except Exception:  # noqa: BLE001
+            pass
+    n_packets = n_packets or 76404  # (BASELINE configs[1]: 19 501 236 nnz in packets of 256 entries, partitions padded to whole packets)
+    res["batch"]["median_local_launch"] = {k: v for k, v in med.items()}
+    res["batch"]["per_query_from_the_median_launch"] = {k: v / 32.0 for k, v in med.items()}
+    res["batch"]["per_packet_from_the_median_launch"] = {k: v / 32.0 / n_packets for k, v in med.items() if k.startswith("SQ_INSTS")}
+    res["batch"]["packets_per_query"] = n_packets
+    for k in list(res["batch"]):  # (the per-query figures above divide by a query count the headline-only line does not carry)
+        if k.endswith("_per_query") or k == "queries":
+            del res["batch"][k]
 for run, r in res.items():
     wc = r.get("SQ_WAVE_CYCLES")
     if wc:
