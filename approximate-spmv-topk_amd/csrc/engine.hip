@@ -17,6 +17,7 @@
 //   select tail   : (last workgroup to finish, or select_kernel) exact top-k of the surviving candidates, ordered (score desc, row desc) = sort_tuples
 //                   (src/common/utils/evaluation_utils.hpp:40-62); pads with (0, 0.0f) like the gold's
 //                   zero-initialised list (gold_algorithms.hpp:203-206).
+#include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -218,6 +219,12 @@ struct EngineImpl {
     unsigned long long *d_wg_times = nullptr;  // option WG_TIMES: BatchParams::wg_times of the LAST batch launch (read through tkspmv_debug_trace)
     bool pace_carry = true;  // option PACE_CARRY=0: every launch starts unpaced
     uint32_t *d_wg_pace = nullptr;  // [grid] the pause every workgroup ended its last launch with (BatchParams::wg_pace)
+    // time_queries: the events of its bracket ride on the region's first and last kernel (hipExtLaunchKernelGGL: the dispatch's own
+    // start and end stamps -- what rocprofv3 reports) instead of being recorded around them: a start event recorded on an idle stream
+    // is stamped before the host has written the dispatch packet (1.6 us of host time inside a 350 us bracket, tools/probes/event_probe.cpp)
+    mutable hipEvent_t ext_start = nullptr, ext_stop = nullptr;
+    mutable bool ext_last = false;  // (launch_sequence: the launch_batch being made is the region's last)
+    uint32_t pace_period_ns = 0;  // pacing by the clock (BatchParams::pace_period): ns per query of every wave's timetable; 0: pacing by rank
     mutable uint64_t batch_launches = 0;
     uint32_t n_sel_wg = 1;   // selector workgroups of a batch launch (BatchParams::n_selectors): 4 on small matrices
     uint32_t groups_with_rows = 0;  // publishing groups that own at least one wave partition
@@ -446,6 +453,14 @@ struct EngineImpl {
     // n <= BATCH_MAX queries in one launch of the batch kernel; results complete in stream order after the launch.
     void launch_batch(const float *const *xs, uint32_t *const *out_idx, float *const *out_val, int n, hipStream_t s, uint32_t parity = 0u,
                       bool final_launch = true) const {
+        // (first: the region's start event goes with this kernel, if one is waiting; last: the stop event, if this is the region's final launch)
+        auto go = [&](void (*fn)(BatchArgs), const BatchArgs &args, bool last) {
+            hipEvent_t a = ext_start, b = (last && ext_last) ? ext_stop : nullptr;
+            ext_start = nullptr;
+            if (b) ext_stop = nullptr;
+            if (a || b) hipExtLaunchKernelGGL(fn, dim3(grid), dim3(block + 64), 0, s, a, b, 0, args);
+            else hipLaunchKernelGGL(fn, dim3(grid), dim3(block + 64), 0, s, args);
+        };
         if (s != bside) drain(s);
         StreamParams P = stream_params(xs[0], 0);
         P.fused = 0u;
@@ -476,6 +491,7 @@ struct EngineImpl {
         B.pace_quads = pace_quads;
         B.pace_levels = pace_levels;
         B.pace_base = pace_base;
+        B.pace_period = (uint32_t)std::min<uint64_t>(0xFFFFFF00ull, (uint64_t)pace_period_ns * 256u / 10u);
         B.wg_pace = pace_carry ? d_wg_pace : nullptr;
         B.wg_times = d_wg_times;
         B.prior_block = reinterpret_cast<uint32_t *>(d_wg_prior + grid);
@@ -502,11 +518,11 @@ struct EngineImpl {
             B.verdict_host = h_verdict_dev + slot;
             const bool trusted = repair_by_host && clean_seen != 0u && distrust_left == 0u;
             BatchArgs A{P, S, B};
-            hipLaunchKernelGGL(batch_kernel_for(true), dim3(grid), dim3(block + 64), 0, s, A);
+            go(batch_kernel_for(true), A, trusted);
             if (!trusted) {
                 BatchArgs R = A;
                 R.B.repair = 1u;
-                hipLaunchKernelGGL(batch_kernel_for(false), dim3(grid), dim3(block + 64), 0, s, R);
+                go(batch_kernel_for(false), R, true);
                 if (distrust_left != 0u) --distrust_left;
             } else {
                 ++trusted_launches;
@@ -518,10 +534,10 @@ struct EngineImpl {
         if (use_local) {
             // the kernel of the checked local thresholds, then the exact kernel for whatever failed its check (the launch is
             // empty -- every workgroup reads the verdict word and leaves -- unless a query was unlike the ones before it)
-            hipLaunchKernelGGL(batch_kernel_for(true), dim3(grid), dim3(block + 64), 0, s, A);
+            go(batch_kernel_for(true), A, false);
             A.B.repair = 1u;
         }
-        hipLaunchKernelGGL(batch_kernel_for(false), dim3(grid), dim3(block + 64), 0, s, A);
+        go(batch_kernel_for(false), A, true);
     }
     // The host has just waited for the engine's stream: look at the verdicts of the launches enqueued since it last did. A flagged
     // query of a TRUSTED launch (no repair launch behind it) is repaired now -- exact launch of the flagged queries, one more wait --;
@@ -583,6 +599,7 @@ struct EngineImpl {
         int l = 0;
         for (int i = 0; i < n; i += batch_max, ++l) {
             const bool odd = overlap && (l & 1);
+            ext_last = i + batch_max >= n;
             launch_batch(xs + i, out_idx + i, out_val + i, std::min(batch_max, n - i), odd ? bside : s, odd ? 1u : 0u, !overlap || i + batch_max >= n);
         }
         if (overlap) {
@@ -1354,6 +1371,7 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
     if (const char *f = opt("PACE")) m.pace_quads = (uint32_t)std::max(0, std::min(32, atoi(f)));
     if (const char *f = opt("PACE_BASE")) m.pace_base = (uint32_t)std::max(0, std::min(64, atoi(f)));
     if (const char *f = opt("PACE_CARRY")) m.pace_carry = atoi(f) != 0;
+    if (const char *f = opt("PACE_PERIOD")) m.pace_period_ns = (uint32_t)std::max(0, std::min(10000000, atoi(f)));
     if (m.use_local && m.pace_quads != 0u) {
         HIP_TRY(hipMalloc((void **)&m.d_wg_pace, (size_t)m.grid * 4));
         HIP_TRY(hipMemset(m.d_wg_pace, 0, (size_t)m.grid * 4));
@@ -1542,6 +1560,53 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
             if (best_ms[c] < best_ms[best]) best = c;
         m.pace_quads = cand[best][0];
         m.pace_levels = cand[best][1];
+        // ---- the timetable (pacing by the clock, BatchParams::pace_period) ------------------------------------------------------
+        // Its period must be what THIS box sustains with THIS kernel: a per cent too short and the waves fall behind, nobody pauses
+        // and the XCDs are back to sharing unevenly (+5 %); too long costs what it is too long by. The best period sits 5-6 % under
+        // the time per query of the pauses by rank just measured (15.8 us on the pool's fast boxes, 16.0 on a medium one): a coarse
+        // grid around that, then half a per cent either side of its best; kept only if it beats the pauses by rank.
+        float period_ms = 1e30f;
+        uint32_t period_ns = 0;
+        if (!opt("PACE_PERIOD")) {
+            auto measure = [&](uint32_t ns) -> float {
+                m.pace_period_ns = ns;
+                float b = 1e30f;
+                for (int pass = 0; pass < 2; ++pass) {
+                    m.launch_batch(xs.data(), oi.data(), ov.data(), nq, m.stream);
+                    (void)hipEventRecord(m.ev0, m.stream);
+                    m.launch_batch(xs.data(), oi.data(), ov.data(), nq, m.stream);
+                    m.launch_batch(xs.data(), oi.data(), ov.data(), nq, m.stream);
+                    (void)hipEventRecord(m.ev1, m.stream);
+                    (void)hipEventSynchronize(m.ev1);
+                    (void)m.settle();
+                    float ms = 0;
+                    (void)hipEventElapsedTime(&ms, m.ev0, m.ev1);
+                    b = std::min(b, ms);
+                }
+                return b;
+            };
+            const double rank_ns = (double)best_ms[best] * 1e6 / (2.0 * nq);  // per query
+            static const double grid[] = {0.90, 0.915, 0.93, 0.945, 0.96, 0.975};
+            for (double g : grid) {
+                const uint32_t ns = (uint32_t)(rank_ns * g);
+                const float ms = measure(ns);
+                if (ms < period_ms) {
+                    period_ms = ms;
+                    period_ns = ns;
+                }
+            }
+            const uint32_t centre = period_ns;
+            for (double g : {0.995, 1.005}) {
+                const uint32_t ns = (uint32_t)((double)centre * g);
+                const float ms = measure(ns);
+                // (of two periods that measure alike the longer one: falling behind costs five times what waiting does)
+                if (ms < period_ms * (ns > period_ns ? 1.0015f : 0.9985f)) {
+                    period_ms = ms;
+                    period_ns = ns;
+                }
+            }
+            m.pace_period_ns = period_ms < best_ms[best] * 0.999f ? period_ns : 0u;
+        }
         const uint32_t tune_us = (uint32_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_tune).count();
         // the engine starts as if nothing had run: no carried thresholds, no pauses, no counters, no trust
         HIP_TRY(hipMemset(m.d_wg_prior, 0, ((size_t)m.grid + 32) * 4));
@@ -1558,7 +1623,7 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
         if (opt("DEBUG_OCC")) {
             fprintf(stderr, "[tkspmv] pacing tuned in %u us:", tune_us);
             for (int c = 0; c < NC; ++c) fprintf(stderr, " %ux%u %.2f us/q%s", cand[c][0], cand[c][1], best_ms[c] * 1e3 / (2 * nq), c == best ? "*" : "");
-            fprintf(stderr, "\n");
+            fprintf(stderr, "; timetable %u ns: %.2f us/q%s\n", period_ns, period_ms * 1e3 / (2 * nq), m.pace_period_ns ? " (kept)" : " (pauses by rank kept)");
         }
     }
     m.info.batch_mode = (m.can_batch ? (m.n_sel_wg | (m.use_local << 8)) : 0u) | (std::min<uint32_t>(n_parts_hint, 0xFFFFu) << 16);
@@ -1989,7 +2054,7 @@ int Engine::debug_counters(unsigned long long *out, int n, std::string &err) {
         out[11] = m.late_repairs;
     }
     if (n >= 14) {  // the pacing in force: quantum | levels << 8 | base << 16, and what tkspmv_create's measurement of it took (us; 0: not measured)
-        out[12] = m.pace_quads | (m.pace_levels << 8) | (m.pace_base << 16);
+        out[12] = m.pace_quads | (m.pace_levels << 8) | (m.pace_base << 16) | ((uint64_t)m.pace_period_ns << 32);  // (upper half: the timetable's period, ns per query; 0: pauses by rank)
         out[13] = m.pace_tuned_us;
     }
     if (n >= 19) {  // option STATS, summed over the tkspmv_time_multi calls so far: queries, bounded waits for a threshold (count, ticks of 10 ns), rows offered / overflowed
@@ -2055,7 +2120,14 @@ int Engine::time_queries(const float *dev_xs, int32_t n_x, int32_t iters, double
     }
     HIP_TRY(hipSetDevice(m.device));
     HIP_TRY(hipStreamSynchronize(m.stream));
-    HIP_TRY(hipEventRecord(m.ev0, m.stream));
+    // (batch launches on one stream: the bracket's events travel with the first and the last kernel; any other path records them)
+    const bool ext = m.can_batch && !(m.overlap_launches && m.bside) && (!opt("EXT_EVENTS") || atoi(opt("EXT_EVENTS")) != 0);
+    if (ext) {
+        m.ext_start = m.ev0;
+        m.ext_stop = m.ev1;
+    } else {
+        HIP_TRY(hipEventRecord(m.ev0, m.stream));
+    }
     {
         std::vector<const float *> xs;
         std::vector<uint32_t *> oi;
@@ -2063,7 +2135,12 @@ int Engine::time_queries(const float *dev_xs, int32_t n_x, int32_t iters, double
         sequence_lists(m, dev_xs, n_x, iters, m.d_out_idx, m.d_out_val, 0, xs, oi, ov);
         m.launch_sequence(xs.data(), oi.data(), ov.data(), iters, m.stream);
     }
-    HIP_TRY(hipEventRecord(m.ev1, m.stream));
+    if (!ext) HIP_TRY(hipEventRecord(m.ev1, m.stream));
+    if (m.ext_start || m.ext_stop) {  // (cannot happen: every batch path launches through launch_batch)
+        m.ext_start = m.ext_stop = nullptr;
+        err = "time_queries: the region's events were not attached to its launches";
+        return TKSPMV_ERR_STATE;
+    }
     // (polled: a blocking wait adds 10-20 us of wake-up latency to a region that may be as short as 400 us)
     for (uint32_t spins = 0;; ++spins) {
         const hipError_t q = hipEventQuery(m.ev1);

@@ -108,6 +108,11 @@ struct BatchParams : SetAddr {
     // second, ... eighth of the field (pace_levels = 3: three eighths pause).
     uint32_t pace_quads, pace_levels;
     uint32_t pace_base;   // units every workgroup pauses per packet whatever its rank (a uniform throttle; PACE_BASE, tuning runs)
+    // Pacing by the clock (pace_period != 0; replaces the pauses by rank): every streaming wave keeps a timetable -- packet j of its
+    // query q is due at (its first query's start) + (q x packets + j) x pace_period / packets, in 10 ns ticks << 8 -- and sleeps off
+    // whatever it is ahead of it; a wave behind its timetable never pauses. The whole field then asks for the stream at the rate the
+    // memory system can give: nobody queues, so nobody is favoured, and the workgroups end a launch together.
+    uint32_t pace_period;  // ticks << 8 per query (0: off)
     unsigned long long *wg_times;  // optional (option WG_TIMES): [BATCH_MAX + 1][n_wg] s_memrealtime at every hand-over (row q) and at the workgroup's entry (row BATCH_MAX)
     uint32_t *wg_pace;    // [n_wg] the pause a workgroup ended the previous launch with: its first query here starts from it (NULL: from none)
     // ---- the verdict of a launch's checks and the repair launch -----------------------------------------------------------------
@@ -692,6 +697,7 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
                     // more that shows: with the candidate path switched off the median wave streams a query in 11.5 us while a
                     // tenth of the workgroups take 26-28 us, and the launch waits for them (tools/batch_trace.py). The rank is
                     // the feedback: an early workgroup pauses a little per packet, a late one gets the higher issue priority.
+                    uint32_t paced_units = 0u;  // (option WG_TIMES: the pause chosen here travels in the stamp's top byte)
                     if (pace_q != 0u) {
                         uint32_t rank = 0u;
                         if (lane == 0) rank = __hip_atomic_fetch_add(B.tickets + 32u * set_of(tail), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -702,10 +708,12 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
                         uint32_t units = (e8 < B.pace_levels ? (B.pace_levels - e8) * pace_q : 0u) + B.pace_base;  // (per packet, units of s_sleep(2) = 128 cycles)
                         units = units > 255u ? 255u : units;
                         const uint32_t lvl = units | (3u * rank >= 2u * n_wg ? 256u : 0u);
+                        paced_units = units;
                         if (lane == 0) __hip_atomic_store(&L.pace, lvl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     } else if (lane == 0)
                         (void)__hip_atomic_fetch_add(B.tickets + 32u * set_of(tail), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (LOCAL && B.wg_times && lane == 0) B.wg_times[(size_t)set_of(tail) * gridDim.x + bid] = __builtin_amdgcn_s_memrealtime();
+                    if (LOCAL && B.wg_times && lane == 0)
+                        B.wg_times[(size_t)set_of(tail) * gridDim.x + bid] = (__builtin_amdgcn_s_memrealtime() & 0x00FFFFFFFFFFFFFFull) | ((unsigned long long)paced_units << 56);
                     if (trw && lane == 0 && TRSLOT(tail) < 3u) trw[4 + TRSLOT(tail)] = __builtin_amdgcn_s_memrealtime();
                     if (trw && lane == 0 && TRSLOT(tail) == 1u) {
                         trw[3] = dbg_first_duty;
@@ -790,6 +798,9 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
     float top1 = 0.0f, top2 = 0.0f;  // local thresholds: the two largest packet maxima of this wave in the current query
     uint32_t wcnt = 0u;
     uint32_t pace = 0u;  // this query's pause per packet, units of pace_quads x 128 cycles (the server: from the workgroup's rank in the previous query)
+    const uint32_t tpkt_fp = (LOCAL && B.pace_period != 0u && np != 0u) ? (uint32_t)((float)B.pace_period / (float)np) : 0u;  // a packet's slot on the timetable
+    uint32_t sched_fp = 0u;  // when the packet being reduced is due (ticks << 8, low 32 bits)
+    uint32_t pace_rank = 0u;  // (timetable: the pause by rank, which takes over while the wave is more than half a query behind)
     bool waited = false;  // this wave has used its bounded wait for a threshold in the current query (long partitions)
     const bool long_partition = np * (uint32_t)(C / 4) >= 28u;  // ~14 rows finish per 256 entries: > 1.5 lists per query
     uint32_t *mp = L.misc[0];
@@ -822,9 +833,10 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
                 wcnt = 0u;
                 top1 = top2 = -__builtin_huge_valf();
                 waited = false;
+                if (tpkt_fp != 0u && qc == 0u) sched_fp = (uint32_t)__builtin_amdgcn_s_memrealtime() << 8;
                 if (pace_q != 0u) {
                     const uint32_t pw = __builtin_amdgcn_readfirstlane(lds_load(&L.pace));
-                    pace = pw & 255u;
+                    pace = pace_rank = pw & 255u;
                     if (pw & 256u) __builtin_amdgcn_s_setprio(2);
                     else __builtin_amdgcn_s_setprio(1);
                 } else {
@@ -842,6 +854,20 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
             // a workgroup ahead of the field yields: fewer requests from it, more bandwidth for the XCDs that lag
             // (the pause's bits, one s_sleep each -- units of 128 cycles: a loop of s_sleep(2) spent four scalar instructions per unit,
             //  a quarter of the kernel's scalar instructions with six eighths of the field pausing)
+            if (tpkt_fp != 0u) {
+                sched_fp += tpkt_fp;
+                const int32_t ahead = (int32_t)(sched_fp - ((uint32_t)__builtin_amdgcn_s_memrealtime() << 8));  // ticks << 8
+                // (128 cycles per unit, 24 cycles per tick at 2.4 GHz: 3/16 units per tick)
+                pace = ahead > 0 ? (uint32_t)(((uint32_t)ahead * 3u) >> 12) : 0u;
+                pace = pace > 1023u ? 1023u : pace;
+                // A timetable nobody can keep (the GPU streams slower than when the period was measured: a change of power state, the
+                // first milliseconds after an idle period) would leave the field unpaced: a wave more than half a query behind paces
+                // by its workgroup's rank as if there were no timetable, and its debt stops growing at one query.
+                if (ahead < -(int32_t)(B.pace_period >> 1)) {
+                    pace = pace_rank;
+                    if (ahead < -(int32_t)B.pace_period) sched_fp -= (uint32_t)(ahead + (int32_t)B.pace_period);
+                }
+            }
             if (pace != 0u) {
                 if (pace & 1u) __builtin_amdgcn_s_sleep(2);
                 if (pace & 2u) __builtin_amdgcn_s_sleep(4);

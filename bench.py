@@ -647,7 +647,8 @@ def bench_single(a, mod, torch, np, dev, local_rank):
                      "sustained_vs_read_only": read_us / pct(reps, 50),
                      "checks_failed": int(counters["checks_failed"]), "late_repairs": int(counters.get("late_repairs", 0)),
                      "launches_without_repair_launch": int(counters.get("trusted_launches", 0)),
-                     "pacing": f"{counters.get('pace_quantum')}x{counters.get('pace_levels')}" + (f" (measured at create, {counters.get('pace_tuned_us')} us)" if counters.get("pace_tuned_us") else " (static)"),
+                     "pacing": (f"timetable of {counters.get('pace_period_ns')} ns per query, pauses by rank {counters.get('pace_quantum')}x{counters.get('pace_levels')} behind it" if counters.get("pace_period_ns")
+                                else f"{counters.get('pace_quantum')}x{counters.get('pace_levels')}") + (f" (measured at create, {counters.get('pace_tuned_us')} us)" if counters.get("pace_tuned_us") else " (static)"),
                      "read_only": read_only,
                      # what the memory system physically moves (the stream is 5.5 B/nnz, the algorithmic figure counts 6): the
                      # measured traffic, or the stream's size, over the same kernel time -- `frac` above is the SURVEY 8(d) figure

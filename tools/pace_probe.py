@@ -48,7 +48,7 @@ def main():
             res[s]["sustained"].append(float(np.median(reps)))
             res[s]["floor"].append(sorted(eng.time_stream_read(64) / 1e3 for _ in range(3))[1])
             c = eng.debug_counters()
-            res[s].setdefault("pace", []).append(f"{c.get('pace_quantum')}x{c.get('pace_levels')}" + (f"(tuned {c.get('pace_tuned_us')}us)" if c.get("pace_tuned_us") else ""))
+            res[s].setdefault("pace", []).append(f"{c.get('pace_quantum')}x{c.get('pace_levels')}/T{c.get('pace_period_ns')}" + (f"(tuned {c.get('pace_tuned_us')}us)" if c.get("pace_tuned_us") else ""))
             eng.close()
     for s in settings:
         r = res[s]

@@ -38,7 +38,9 @@ def main():
     buf = np.zeros(words, dtype=np.uint64)
     got = C.c_uint64()
     _lib.check(_lib.lib().tkspmv_debug_trace(eng._h, buf.ctypes.data_as(C.POINTER(C.c_uint64)), words, C.byref(got)))
-    t = buf.reshape(33, grid).astype(np.int64)
+    raw = buf.reshape(33, grid)
+    U = (raw >> np.uint64(56)).astype(np.int64)  # the pause (units per packet) each workgroup chose at that hand-over
+    t = (raw & np.uint64(0x00FFFFFFFFFFFFFF)).astype(np.int64)
     n_sel = int((t[32] == 0).sum())  # (rows are indexed by streaming workgroup: the last n_selectors columns stay empty)
     n_wg = grid - n_sel
     entry = t[32, :n_wg]
@@ -69,8 +71,10 @@ def main():
     print(f"rank correlation of a workgroup's duration in consecutive queries: median {np.median(cors):+.2f} (two apart: {np.median(cors2):+.2f})")
     tot = T[n_q - 1] - E
     print(f"whole launch per workgroup: median {np.median(tot):.1f}, min {tot.min():.1f}, max {tot.max():.1f} us; the launch waits {tot.max() - np.median(tot):.1f} us for its last workgroup")
+    Un = U[:n_q, :n_wg]
+    print("pause chosen at the hand-over (units per packet), by query: median / p90 / max:", " ".join(f"{int(np.median(Un[q]))}/{int(np.percentile(Un[q], 90))}/{int(Un[q].max())}" for q in range(n_q)))
     if out:
-        np.savez_compressed(out, T=T, E=E, us_per_query=us)
+        np.savez_compressed(out, T=T, E=E, U=Un, us_per_query=us)
     eng.close()
 
 
