@@ -1568,10 +1568,10 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
         float period_ms = 1e30f;
         uint32_t period_ns = 0;
         if (!opt("PACE_PERIOD")) {
-            auto measure = [&](uint32_t ns) -> float {
+            auto measure = [&](uint32_t ns, int passes) -> float {
                 m.pace_period_ns = ns;
                 float b = 1e30f;
-                for (int pass = 0; pass < 2; ++pass) {
+                for (int pass = 0; pass < passes; ++pass) {
                     m.launch_batch(xs.data(), oi.data(), ov.data(), nq, m.stream);
                     (void)hipEventRecord(m.ev0, m.stream);
                     m.launch_batch(xs.data(), oi.data(), ov.data(), nq, m.stream);
@@ -1589,18 +1589,20 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
             static const double grid[] = {0.90, 0.915, 0.93, 0.945, 0.96, 0.975};
             for (double g : grid) {
                 const uint32_t ns = (uint32_t)(rank_ns * g);
-                const float ms = measure(ns);
+                const float ms = measure(ns, 2);
                 if (ms < period_ms) {
                     period_ms = ms;
                     period_ns = ns;
                 }
             }
+            // (five periods half a per cent apart around the grid's best, three measurements each; of two that measure alike the
+            //  longer one: falling behind costs five times what waiting does)
             const uint32_t centre = period_ns;
-            for (double g : {0.995, 1.005}) {
+            period_ms = 1e30f;
+            for (double g : {1.01, 1.005, 1.0, 0.995, 0.99}) {
                 const uint32_t ns = (uint32_t)((double)centre * g);
-                const float ms = measure(ns);
-                // (of two periods that measure alike the longer one: falling behind costs five times what waiting does)
-                if (ms < period_ms * (ns > period_ns ? 1.0015f : 0.9985f)) {
+                const float ms = measure(ns, 3);
+                if (ms < period_ms * 0.9985f) {
                     period_ms = ms;
                     period_ns = ns;
                 }

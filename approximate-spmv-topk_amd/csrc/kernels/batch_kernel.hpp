@@ -33,6 +33,9 @@ constexpr int BATCH_MAX = 32;
 #ifndef TKSPMV_LADDER
 #define TKSPMV_LADDER 9
 #endif
+#ifndef TKSPMV_CLOCK_STRIDE
+#define TKSPMV_CLOCK_STRIDE 2  // (a power of two; same box, sustained / the driver's 20-query launch: 1: 16.8-17.0 / 17.2, 2: 16.8-17.1 / 17.0, 4: 17.1-17.5 / 17.7, 8: 17.3-18.2 / 17.8 us per query)
+#endif
 #ifndef TKSPMV_TAU_WAIT
 #define TKSPMV_TAU_WAIT 3000
 #endif
@@ -302,6 +305,7 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
                     else __builtin_amdgcn_s_sleep(32);
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                if (LOCAL && B.wg_times) B.wg_times[(size_t)set_of(q) * gridDim.x + n_stream] = __builtin_amdgcn_s_memrealtime();  // (option WG_TIMES: all tickets seen)
             }
             __syncthreads();
             SelectParams S = SP0;
@@ -324,6 +328,7 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
                     const unsigned long long done = __hip_atomic_fetch_add(B.verdict, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + add;
                     // (the selection that completes the word tells the host; read there only after the launch has ended)
                     if (B.verdict_host && (uint32_t)done == B.n_q) __hip_atomic_store(B.verdict_host, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if (LOCAL && B.wg_times) B.wg_times[(size_t)set_of(q) * gridDim.x + n_stream + 1u] = __builtin_amdgcn_s_memrealtime();  // (option WG_TIMES: selection done)
                 }
             } else {
                 const uint32_t l = list_of(q);
@@ -402,7 +407,7 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
         // the default priority got ONE pass per query (traced), i.e. the threshold arrived when the query was over.
         // (local thresholds: the query is short and the workgroup's waves wait for this wave's next x: it must not queue behind them)
         if (reducer || local) __builtin_amdgcn_s_setprio(3);
-        if (LOCAL && B.wg_times && lane == 0) B.wg_times[(size_t)BATCH_MAX * gridDim.x + bid] = __builtin_amdgcn_s_memrealtime();
+        const unsigned long long t_wg_entry = (LOCAL && B.wg_times) ? __builtin_amdgcn_s_memrealtime() : 0ull;  // (option WG_TIMES)
         uint32_t staged = 0u, tail = 0u;
         uint32_t gate_seen = 0u;  // (exact mode: queries [0, gate_seen) have had their overflow list seen free by this wave)
         const bool carry_local = local && B.wg_prior != nullptr;
@@ -560,6 +565,10 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 if (lane == 0) __hip_atomic_store(&mp[MISC_XREADY], staged + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (trw && lane == 0 && TRSLOT(staged) < 3u) trw[1 + TRSLOT(staged)] = __builtin_amdgcn_s_memrealtime();
+                if (LOCAL && B.wg_times && staged == 0u && lane == 0) {  // the entry stamp, and in its top byte how long the first x took (0.1 us)
+                    const unsigned long long d = (__builtin_amdgcn_s_memrealtime() - t_wg_entry) / 10ull;
+                    B.wg_times[(size_t)BATCH_MAX * gridDim.x + bid] = (t_wg_entry & 0x00FFFFFFFFFFFFFFull) | ((d > 255ull ? 255ull : d) << 56);
+                }
                 ++staged;
             }
             // Threshold exchange of the query this workgroup's waves are streaming: the oldest unfinished one until
@@ -801,6 +810,7 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
     const uint32_t tpkt_fp = (LOCAL && B.pace_period != 0u && np != 0u) ? (uint32_t)((float)B.pace_period / (float)np) : 0u;  // a packet's slot on the timetable
     uint32_t sched_fp = 0u;  // when the packet being reduced is due (ticks << 8, low 32 bits)
     uint32_t pace_rank = 0u;  // (timetable: the pause by rank, which takes over while the wave is more than half a query behind)
+    bool behind = false;
     bool waited = false;  // this wave has used its bounded wait for a threshold in the current query (long partitions)
     const bool long_partition = np * (uint32_t)(C / 4) >= 28u;  // ~14 rows finish per 256 entries: > 1.5 lists per query
     uint32_t *mp = L.misc[0];
@@ -855,17 +865,24 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
             // (the pause's bits, one s_sleep each -- units of 128 cycles: a loop of s_sleep(2) spent four scalar instructions per unit,
             //  a quarter of the kernel's scalar instructions with six eighths of the field pausing)
             if (tpkt_fp != 0u) {
-                sched_fp += tpkt_fp;
-                const int32_t ahead = (int32_t)(sched_fp - ((uint32_t)__builtin_amdgcn_s_memrealtime() << 8));  // ticks << 8
-                // (128 cycles per unit, 24 cycles per tick at 2.4 GHz: 3/16 units per tick)
-                pace = ahead > 0 ? (uint32_t)(((uint32_t)ahead * 3u) >> 12) : 0u;
-                pace = pace > 1023u ? 1023u : pace;
-                // A timetable nobody can keep (the GPU streams slower than when the period was measured: a change of power state, the
-                // first milliseconds after an idle period) would leave the field unpaced: a wave more than half a query behind paces
-                // by its workgroup's rank as if there were no timetable, and its debt stops growing at one query.
-                if (ahead < -(int32_t)(B.pace_period >> 1)) {
-                    pace = pace_rank;
-                    if (ahead < -(int32_t)B.pace_period) sched_fp -= (uint32_t)(ahead + (int32_t)B.pace_period);
+                // (the clock is read every TKSPMV_CLOCK_STRIDE packets and what the wave is ahead by slept off in one go: half the scalar
+                //  instructions of a look at every packet; requests in bursts of four packets or more measure slower)
+                pace = behind ? pace_rank : 0u;
+                if ((jc & (uint32_t)(TKSPMV_CLOCK_STRIDE - 1)) == 0u) {
+                    const uint32_t left = np - jc;
+                    sched_fp += tpkt_fp * (left < (uint32_t)TKSPMV_CLOCK_STRIDE ? left : (uint32_t)TKSPMV_CLOCK_STRIDE);
+                    const int32_t ahead = (int32_t)(sched_fp - ((uint32_t)__builtin_amdgcn_s_memrealtime() << 8));  // ticks << 8
+                    // (128 cycles per unit, 24 cycles per tick at 2.4 GHz: 3/16 units per tick)
+                    pace = ahead > 0 ? (uint32_t)(((uint32_t)ahead * 3u) >> 12) : 0u;
+                    pace = pace > 1023u ? 1023u : pace;
+                    // A timetable nobody can keep (the GPU streams slower than when the period was measured: a change of power state,
+                    // the first milliseconds after an idle period) would leave the field unpaced: a wave more than half a query behind
+                    // paces by its workgroup's rank as if there were no timetable, and its debt stops growing at one query.
+                    behind = ahead < -(int32_t)(B.pace_period >> 1);
+                    if (behind) {
+                        pace = pace_rank;
+                        if (ahead < -(int32_t)B.pace_period) sched_fp -= (uint32_t)(ahead + (int32_t)B.pace_period);
+                    }
                 }
             }
             if (pace != 0u) {

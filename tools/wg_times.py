@@ -41,9 +41,11 @@ def main():
     raw = buf.reshape(33, grid)
     U = (raw >> np.uint64(56)).astype(np.int64)  # the pause (units per packet) each workgroup chose at that hand-over
     t = (raw & np.uint64(0x00FFFFFFFFFFFFFF)).astype(np.int64)
-    n_sel = int((t[32] == 0).sum())  # (rows are indexed by streaming workgroup: the last n_selectors columns stay empty)
+    n_sel = int((t[32] == 0).sum())  # (rows are indexed by streaming workgroup; the last n_selectors columns of a query's row hold the selector's stamps)
     n_wg = grid - n_sel
     entry = t[32, :n_wg]
+    x0 = U[32, :n_wg] * 0.1  # the entry row's top byte: how long the first x took to stage (us)
+    sel_seen, sel_done = t[:n_q, n_wg], t[:n_q, n_wg + 1]  # per query: all tickets seen by its selector / its selection done
     t0 = entry[entry > 0].min()
     T = (t[:n_q, :n_wg] - t0) * 0.01  # us
     E = (entry - t0) * 0.01
@@ -71,6 +73,13 @@ def main():
     print(f"rank correlation of a workgroup's duration in consecutive queries: median {np.median(cors):+.2f} (two apart: {np.median(cors2):+.2f})")
     tot = T[n_q - 1] - E
     print(f"whole launch per workgroup: median {np.median(tot):.1f}, min {tot.min():.1f}, max {tot.max():.1f} us; the launch waits {tot.max() - np.median(tot):.1f} us for its last workgroup")
+    print(f"first x staged after the workgroup's entry: median {np.median(x0):.1f}, p95 {np.percentile(x0, 95):.1f}, max {x0.max():.1f} us")
+    if n_sel >= 2 and sel_seen[n_q - 1] > 0:
+        ls = (sel_seen - t0) * 0.01
+        ld = (sel_done - t0) * 0.01
+        print("selections: last ticket -> seen by the selector -> done (us after the last hand-over of the query): " +
+              " ".join(f"{ls[q] - T[q].max():.1f}/{ld[q] - T[q].max():.1f}" for q in range(n_q)))
+        print(f"the launch's last selection is done at {ld[n_q - 1]:.2f} us; event pair: {us * n_q:.2f} us")
     Un = U[:n_q, :n_wg]
     print("pause chosen at the hand-over (units per packet), by query: median / p90 / max:", " ".join(f"{int(np.median(Un[q]))}/{int(np.percentile(Un[q], 90))}/{int(Un[q].max())}" for q in range(n_q)))
     if out:
