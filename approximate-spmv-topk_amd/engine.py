@@ -176,7 +176,7 @@ class SpMV:
                 # the pacing of back-to-back queries in force and what tkspmv_create's measurement of it took (0: static default)
                 "pace_quantum": int(out[12]) & 0xFF, "pace_levels": (int(out[12]) >> 8) & 0xFF, "pace_base": (int(out[12]) >> 16) & 0xFF,
                 "pace_period_ns": int(out[12]) >> 32,
-                "pace_tuned_us": int(out[13]),
+                "pace_tuned_us": int(out[13]) & 0xFFFFFFFF, "pace_tune_launches": int(out[13]) >> 32,
                 # option STATS, summed over the time_multi calls so far (the multi-query kernel's threshold exchange): queries, waves that
                 # ran into their bounded wait for a threshold and the ticks (10 ns) they spent there, rows offered to / overflowed from the lists
                 "multi_stat_queries": int(out[14]), "multi_waits": int(out[15]), "multi_wait_ticks": int(out[16]),

@@ -436,8 +436,8 @@ def _finish_headline_only(a, info, alg_bytes, kernel_ns, elapsed, reps, read_us,
                       "warmup": a.warmup, "kernel_us": kernel_ns / 1e3, "frac": alg_bytes / kernel_ns / HBM_PEAK_GBS,
                       "sustained_median_us": pct(reps, 50), "p95_over_median": pct(reps, 95) / pct(reps, 50), "read_only_us": read_us,
                       "checks_failed": int(counters["checks_failed"]),
-                      "pacing": f"{counters.get('pace_quantum')}x{counters.get('pace_levels')}", "pace_tuned_us": counters.get("pace_tuned_us"),
-                      "launches_of_the_pacing_measurement": 100 if counters.get("pace_tuned_us") else 0}))
+                      "pacing": f"{counters.get('pace_quantum')}x{counters.get('pace_levels')}", "pace_period_ns": counters.get("pace_period_ns"), "pace_tuned_us": counters.get("pace_tuned_us"),
+                      "launches_of_the_pacing_measurement": counters.get("pace_tune_launches", 0)}))
 
 
 # ---- N = 1: BASELINE configs[1] ---------------------------------------------------------------------------------------------
@@ -647,6 +647,7 @@ def bench_single(a, mod, torch, np, dev, local_rank):
                      "sustained_vs_read_only": read_us / pct(reps, 50),
                      "checks_failed": int(counters["checks_failed"]), "late_repairs": int(counters.get("late_repairs", 0)),
                      "launches_without_repair_launch": int(counters.get("trusted_launches", 0)),
+                     "pace_period_ns": counters.get("pace_period_ns"),
                      "pacing": (f"timetable of {counters.get('pace_period_ns')} ns per query, pauses by rank {counters.get('pace_quantum')}x{counters.get('pace_levels')} behind it" if counters.get("pace_period_ns")
                                 else f"{counters.get('pace_quantum')}x{counters.get('pace_levels')}") + (f" (measured at create, {counters.get('pace_tuned_us')} us)" if counters.get("pace_tuned_us") else " (static)"),
                      "read_only": read_only,

@@ -26,10 +26,12 @@ cd /tmp && export TMPDIR=/tmp
 # (--headline-only: the trace holds nothing but headline queries -- VERDICT r4 --, plus the 100 launches tkspmv_create measures its pacing
 #  with, which tools/summarize_profile.py leaves out of <tag>_headline_launches.json)
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/ktrace" -- python3 "$REPO/bench.py" --steps 2048 --warmup 256 --headline-only > "$OUT/bench_under_rocprofv3.json" 2> "$OUT/ktrace.err"
+# (the counter passes run without tkspmv_create's measurement -- its launches would be counted --: with the period the plain run found)
+PERIOD=$(python3 -c "import json,sys; print(json.loads([l for l in open('$OUT/bench_plain.json').read().splitlines() if l.startswith('{')][-1])['roofline'].get('pace_period_ns') or 0)")
 i=0
 for counters in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
     i=$((i + 1))
-    TKSPMV_AUTOTUNE=0 TKSPMV_PACE=2 TKSPMV_PACE_LEVELS=6 rocprofv3 --pmc $counters --kernel-trace --output-format csv -d "$OUT/pmc$i" -- python3 "$REPO/bench.py" --steps 320 --warmup 32 --headline-only > "$OUT/pmc$i.json" 2> "$OUT/pmc$i.err"
+    TKSPMV_AUTOTUNE=0 TKSPMV_PACE=2 TKSPMV_PACE_LEVELS=6 TKSPMV_PACE_PERIOD=$PERIOD rocprofv3 --pmc $counters --kernel-trace --output-format csv -d "$OUT/pmc$i" -- python3 "$REPO/bench.py" --steps 320 --warmup 32 --headline-only > "$OUT/pmc$i.json" 2> "$OUT/pmc$i.err"
 done
 fi
 if [ "$PART" = A ]; then cd "$REPO"; python3 tools/summarize_profile.py "$OUT" "$TAG"; exit 0; fi
