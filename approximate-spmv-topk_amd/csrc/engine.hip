@@ -215,6 +215,7 @@ struct EngineImpl {
     float *d_wg_sig = nullptr;    // [grid][8] the signatures of the remembered priors and the second prior (BatchParams::wg_sig; option SIGNATURES=0: none)
     float local_beta = 1.0f;
     uint32_t pace_tuned_us = 0;  // 0: the pacing is the static default (or an option); else what tkspmv_create's measurement took
+    uint32_t pace_tune_launches = 0;  // ... and the batch launches it made (synthetic queries: a kernel trace of a run holds them)
     uint32_t pace_quads = 0, pace_levels = 3, pace_base = 0; // pacing by rank (BatchParams::pace_quads, pace_levels, pace_base)
     unsigned long long *d_wg_times = nullptr;  // option WG_TIMES: BatchParams::wg_times of the LAST batch launch (read through tkspmv_debug_trace)
     bool pace_carry = true;  // option PACE_CARRY=0: every launch starts unpaced
@@ -1619,12 +1620,14 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
         if (m.d_wg_sig) HIP_TRY(hipMemset(m.d_wg_sig, 0, (size_t)m.grid * 8 * 4));
         m.clean_seen = m.distrust_left = 0u;
         m.trusted_launches = m.late_repairs = 0;
+        const uint64_t tune_launches = m.batch_launches;
         m.batch_launches = 0;
         HIP_TRY(hipMemset(m.d_verdict, 0, 512));
         HIP_TRY(hipMemset(m.d_out_idx, 0, (size_t)d.k * 4));
         HIP_TRY(hipMemset(m.d_out_val, 0, (size_t)d.k * 4));
         (void)hipFree(d_tx);
         m.pace_tuned_us = tune_us ? tune_us : 1u;
+        m.pace_tune_launches = (uint32_t)tune_launches;
         if (opt("DEBUG_OCC")) {
             fprintf(stderr, "[tkspmv] pacing tuned in %u us:", tune_us);
             for (int c = 0; c < NC; ++c) fprintf(stderr, " %ux%u %.2f us/q%s", cand[c][0], cand[c][1], best_ms[c] * 1e3 / (2 * nq), c == best ? "*" : "");
@@ -2060,7 +2063,7 @@ int Engine::debug_counters(unsigned long long *out, int n, std::string &err) {
     }
     if (n >= 14) {  // the pacing in force: quantum | levels << 8 | base << 16, and what tkspmv_create's measurement of it took (us; 0: not measured)
         out[12] = m.pace_quads | (m.pace_levels << 8) | (m.pace_base << 16) | ((uint64_t)m.pace_period_ns << 32);  // (upper half: the timetable's period, ns per query; 0: pauses by rank)
-        out[13] = m.pace_tuned_us;
+        out[13] = m.pace_tuned_us | ((uint64_t)m.pace_tune_launches << 32);  // (upper half: the batch launches the measurement made)
     }
     if (n >= 19) {  // option STATS, summed over the tkspmv_time_multi calls so far: queries, bounded waits for a threshold (count, ticks of 10 ns), rows offered / overflowed
         out[14] = m.multi_stat_queries;
