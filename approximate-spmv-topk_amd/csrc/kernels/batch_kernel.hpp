@@ -864,14 +864,23 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
             // a workgroup ahead of the field yields: fewer requests from it, more bandwidth for the XCDs that lag
             // (the pause's bits, one s_sleep each -- units of 128 cycles: a loop of s_sleep(2) spent four scalar instructions per unit,
             //  a quarter of the kernel's scalar instructions with six eighths of the field pausing)
+            // (the clock is asked for here and looked at behind the packet's arithmetic: a wave that is behind its timetable -- the one the
+            //  launch waits for -- must not stand still for the answer)
+            const bool look = tpkt_fp != 0u && (jc & (uint32_t)(TKSPMV_CLOCK_STRIDE - 1)) == 0u;
+            uint32_t clk_now = 0u;
+            if (look) clk_now = (uint32_t)__builtin_amdgcn_s_memrealtime();
+            const uint32_t tau_bits = lds_load(&mp[MISC_TAU]);
+            const float tau = __uint_as_float(tau_bits);
+            const Reduced<C> Rd = reduce_packet<C, QM>(cur, carry, xbase, P0.fixed_mask);
+            const float trig = trigger_of<C, INT>(Rd);
             if (tpkt_fp != 0u) {
                 // (the clock is read every TKSPMV_CLOCK_STRIDE packets and what the wave is ahead by slept off in one go: half the scalar
                 //  instructions of a look at every packet; requests in bursts of four packets or more measure slower)
                 pace = behind ? pace_rank : 0u;
-                if ((jc & (uint32_t)(TKSPMV_CLOCK_STRIDE - 1)) == 0u) {
+                if (look) {
                     const uint32_t left = np - jc;
                     sched_fp += tpkt_fp * (left < (uint32_t)TKSPMV_CLOCK_STRIDE ? left : (uint32_t)TKSPMV_CLOCK_STRIDE);
-                    const int32_t ahead = (int32_t)(sched_fp - ((uint32_t)__builtin_amdgcn_s_memrealtime() << 8));  // ticks << 8
+                    const int32_t ahead = (int32_t)(sched_fp - (clk_now << 8));  // ticks << 8
                     // (128 cycles per unit, 24 cycles per tick at 2.4 GHz: 3/16 units per tick)
                     pace = ahead > 0 ? (uint32_t)(((uint32_t)ahead * 3u) >> 12) : 0u;
                     pace = pace > 1023u ? 1023u : pace;
@@ -895,10 +904,6 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
 #pragma unroll 1
                 for (uint32_t z = pace >> 6; z != 0u; --z) __builtin_amdgcn_s_sleep(127);
             }
-            const uint32_t tau_bits = lds_load(&mp[MISC_TAU]);
-            const float tau = __uint_as_float(tau_bits);
-            const Reduced<C> Rd = reduce_packet<C, QM>(cur, carry, xbase, P0.fixed_mask);
-            const float trig = trigger_of<C, INT>(Rd);
             if (TKSPMV_LADDER < 2) {  // (timing-only build: the trigger is formed and kept alive, never taken)
                 top1 = max2(top1, trig);
             } else if (__any(trig >= tau)) {
