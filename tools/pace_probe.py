@@ -46,6 +46,7 @@ def main():
                 eng.time_query_batches(dxs.data_ptr(), nq, 256, 8)
             reps = [v / 1e3 for v in eng.time_query_batches(dxs.data_ptr(), nq, 256, 26)][2:]
             res[s]["sustained"].append(float(np.median(reps)))
+            res[s].setdefault("launch20", []).append(sorted(eng.time_queries(dxs.data_ptr(), nq, 20) / 1e3 for _ in range(9))[4])  # (ONE launch of 20, each behind a wait: median of 9)
             res[s]["floor"].append(sorted(eng.time_stream_read(64) / 1e3 for _ in range(3))[1])
             c = eng.debug_counters()
             res[s].setdefault("pace", []).append(f"{c.get('pace_quantum')}x{c.get('pace_levels')}/T{c.get('pace_period_ns')}" + (f"(tuned {c.get('pace_tuned_us')}us)" if c.get("pace_tuned_us") else ""))
@@ -55,6 +56,7 @@ def main():
         print(json.dumps({"name": name, "setting": s or "defaults", "instances": n_inst,
                           "sustained_us": [round(float(np.median(r["sustained"])), 2), round(min(r["sustained"]), 2), round(max(r["sustained"]), 2)],
                           "driver_line_us": [round(float(np.median(r["driver"])), 2), round(min(r["driver"]), 2), round(max(r["driver"]), 2)],
+                          "launch_of_20_us": [round(float(np.median(r["launch20"])), 2), round(min(r["launch20"]), 2), round(max(r["launch20"]), 2)],
                           "floor_us": round(float(np.median(r["floor"])), 2), "pace": r.get("pace")}))
 
 
