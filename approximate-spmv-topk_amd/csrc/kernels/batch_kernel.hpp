@@ -844,6 +844,8 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
                 top1 = top2 = -__builtin_huge_valf();
                 waited = false;
                 if (tpkt_fp != 0u && qc == 0u) sched_fp = (uint32_t)__builtin_amdgcn_s_memrealtime() << 8;
+                if (tpkt_fp != 0u && (np & (uint32_t)(TKSPMV_CLOCK_STRIDE - 1)) != 0u)  // (the query's last look covers fewer packets than it books)
+                    sched_fp -= tpkt_fp * ((uint32_t)TKSPMV_CLOCK_STRIDE - (np & (uint32_t)(TKSPMV_CLOCK_STRIDE - 1)));
                 if (pace_q != 0u) {
                     const uint32_t pw = __builtin_amdgcn_readfirstlane(lds_load(&L.pace));
                     pace = pace_rank = pw & 255u;
@@ -878,19 +880,22 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
                 //  instructions of a look at every packet; requests in bursts of four packets or more measure slower)
                 pace = behind ? pace_rank : 0u;
                 if (look) {
-                    const uint32_t left = np - jc;
-                    sched_fp += tpkt_fp * (left < (uint32_t)TKSPMV_CLOCK_STRIDE ? left : (uint32_t)TKSPMV_CLOCK_STRIDE);
+                    sched_fp += tpkt_fp * (uint32_t)TKSPMV_CLOCK_STRIDE;  // (a query of an odd number of packets: evened out where the query starts)
                     const int32_t ahead = (int32_t)(sched_fp - (clk_now << 8));  // ticks << 8
-                    // (128 cycles per unit, 24 cycles per tick at 2.4 GHz: 3/16 units per tick)
-                    pace = ahead > 0 ? (uint32_t)(((uint32_t)ahead * 3u) >> 12) : 0u;
-                    pace = pace > 1023u ? 1023u : pace;
+                    // The wave sleeps in steps of 512 cycles (21 ticks at 2.4 GHz; what is left over the next look sees: the timetable is
+                    // absolute, nothing adds up) -- one short loop instead of a test per bit of the count.
+                    if (!behind) {
+#pragma unroll 1
+                        for (int32_t z = ahead; z > (int32_t)(11u << 8); z -= (int32_t)(21u << 8)) __builtin_amdgcn_s_sleep(8);
+                    }
                     // A timetable nobody can keep (the GPU streams slower than when the period was measured: a change of power state,
                     // the first milliseconds after an idle period) would leave the field unpaced: a wave more than half a query behind
-                    // paces by its workgroup's rank as if there were no timetable, and its debt stops growing at one query.
-                    behind = ahead < -(int32_t)(B.pace_period >> 1);
-                    if (behind) {
-                        pace = pace_rank;
+                    // (looked at where a query starts) paces by its workgroup's rank as if there were no timetable, and its debt stops
+                    // growing at one query.
+                    if (jc == 0u) {
+                        behind = ahead < -(int32_t)(B.pace_period >> 1);
                         if (ahead < -(int32_t)B.pace_period) sched_fp -= (uint32_t)(ahead + (int32_t)B.pace_period);
+                        if (behind) pace = pace_rank;
                     }
                 }
             }
