@@ -1367,7 +1367,10 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
     // The pause follows the packet's size (fp32 values with 12-bit columns, 1408 bytes: 2 units; fp16, 896 bytes: 1 -- 15.4 us per query
     // at 1M rows against 16.3 at 2 units and 16.7 with the device-wide exchange).
     // (units of 128 cycles per level)
-    if (m.use_local) m.pace_quads = m.pm.n_packets <= 45000u ? 0u : (m.pm.n_packets <= 65000u ? 2u : 2u * std::max(1u, (m.pm.packet_bytes + 352u) / 704u));
+    // (round 5, with the pause behind the packet's arithmetic: from ~330k rows up a pause of ONE unit per level pays -- 500k rows: 9.03
+    //  against 9.86 us per query unpaced, 10.0 at two units; 250k rows: 5.8 either way -- and tkspmv_create's measurement may still
+    //  choose none)
+    if (m.use_local) m.pace_quads = m.pm.n_packets <= 25000u ? 0u : (m.pm.n_packets <= 45000u ? 1u : (m.pm.n_packets <= 65000u ? 2u : 2u * std::max(1u, (m.pm.packet_bytes + 352u) / 704u)));
     if (const char *f = opt("PACE_LEVELS")) m.pace_levels = (uint32_t)std::max(1, std::min(8, atoi(f)));
     if (const char *f = opt("PACE")) m.pace_quads = (uint32_t)std::max(0, std::min(32, atoi(f)));
     if (const char *f = opt("PACE_BASE")) m.pace_base = (uint32_t)std::max(0, std::min(64, atoi(f)));
@@ -1529,7 +1532,7 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
         std::vector<uint32_t *> oi(nq, m.d_out_idx);
         std::vector<float *> ov(nq, m.d_out_val);
         for (int i = 0; i < nq; ++i) xs[i] = d_tx + (size_t)i * d.cols;
-        static const uint32_t cand[][2] = {{2, 6}, {2, 7}, {3, 5}, {4, 4}, {2, 5}, {4, 3}};
+        static const uint32_t cand[][2] = {{2, 6}, {2, 7}, {3, 5}, {4, 4}, {2, 5}, {4, 3}, {1, 6}, {1, 4}, {0, 3}};  // ({0, .}: unpaced)
         constexpr int NC = (int)(sizeof(cand) / sizeof(cand[0]));
         float best_ms[NC];
         for (float &b : best_ms) b = 1e30f;
