@@ -803,6 +803,8 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
     for (int u = 0; u < NBUF - 1; ++u) TKSPMV_REQUEST(buf[u]);
 
     uint32_t qc = 0u, jc = 0u;  // query / packet being reduced
+    const bool rows_in_lanes = LOCAL && np <= 64u;
+    const uint32_t row_base_v = (rows_in_lanes && lane < np) ? P0.pkt_row[p0 + lane] : 0u;
     float carry = 0.0f, min_units = 0.0f;
     float top1 = 0.0f, top2 = 0.0f;  // local thresholds: the two largest packet maxima of this wave in the current query
     uint32_t wcnt = 0u;
@@ -928,7 +930,9 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
                 }
                 if (tau_now == tau || __any(trig >= tau_now)) {
                     const RowSums<C> R = expand<C, INT>(Rd, packet_flags<C, QM>(cur));
-                    const uint32_t rb_cur = scalar_load(P0.pkt_row + p0 + jc);  // (row of the first row end of this packet)
+                    // (row of the first row end of this packet: lane j holds packet j's since the launch began -- a partition of up to 64
+                    //  packets; the load from the side table costs the candidate path a trip through the scalar cache otherwise)
+                    const uint32_t rb_cur = rows_in_lanes ? (uint32_t)__builtin_amdgcn_readlane((int)row_base_v, (int)jc) : scalar_load(P0.pkt_row + p0 + jc);
                     // (local: what does not fit the list is dropped under a recorded bound, not appended to global memory)
                     const float wm = offer_candidates<C, QM, WAVE_CAP>(P, R, rb_cur, tau_now, lane, grp_local, publishes, wcand, wcnt, mp, local);
                     if (local && wm > top2 && wm >= min_units) {

@@ -601,6 +601,8 @@ __global__ void __launch_bounds__(512, 4) single_kernel(const StreamParams P, co
         uint32_t wcnt = 0u;
         float top1 = -__builtin_huge_valf(), top2 = -__builtin_huge_valf();
         const bool top1_mode = G.mode == 1u;
+        const bool rows_in_lanes = np <= 64u;
+        const uint32_t row_base_v = (rows_in_lanes && lane < np) ? P.pkt_row[p0 + lane] : 0u;
         for (uint32_t i0 = 0; i0 < np; i0 += NBUF) {
 #pragma unroll
             for (int u = 0; u < NBUF; ++u) {
@@ -618,7 +620,8 @@ __global__ void __launch_bounds__(512, 4) single_kernel(const StreamParams P, co
                 if (tr && i == 0u) tr2 = __builtin_amdgcn_s_memrealtime() + (__float_as_uint(Rd.S) & 0u);
                 if (__any(trigger_of<C, false>(Rd) >= tau)) {
                     const RowSums<C> R = expand<C, false>(Rd, packet_flags<C, QM>(cur));
-                    const uint32_t rb_cur = scalar_load(P.pkt_row + p0 + i);  // (row of the first row end of this packet)
+                    // (row of the first row end of this packet: lane j has held packet j's since the wave's first loads, batch_kernel.hpp)
+                    const uint32_t rb_cur = rows_in_lanes ? (uint32_t)__builtin_amdgcn_readlane((int)row_base_v, (int)i) : scalar_load(P.pkt_row + p0 + i);
                     const float wm = offer_candidates<C, QM, WAVE_CAP, false>(P, R, rb_cur, tau, lane, 0u, false, wcand, wcnt, misc, true);
                     if (wm > top2 && wm >= min_units) {
                         // (a wave with a single packet has no second maximum: it stands for one row)
