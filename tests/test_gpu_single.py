@@ -248,6 +248,50 @@ def test_launches_without_a_repair_launch_are_repaired_when_the_host_waits(pkg, 
     eng.close()
 
 
+@pytest.mark.parametrize("period", ["measured", "16000", "3000", "0"])
+def test_pacing_by_the_clock_changes_when_a_wave_asks_not_what_it_finds(pkg, oracle, monkeypatch, period):
+    """Round 5's timetable: every streaming wave sleeps off what it is ahead of a per-packet schedule on
+    the device clock. `measured`: the period tkspmv_create finds on this box (or none: then the pauses by rank stay); 16000 ns: a
+    period in force whatever the box; 3000 ns: a timetable nobody can keep (every wave falls behind, the pauses by rank take over and
+    the debt is cut at one query); 0: pauses by rank only. 64 queries back to back at BASELINE configs[1]'s size, each list against
+    the gold and bit for bit against the order-matched oracle; no check may fail; the counters say which pacing ran; and the two event
+    brackets of tkspmv_time_queries (EXT_EVENTS) agree with each other."""
+    import torch
+    if period != "measured":
+        monkeypatch.setenv("TKSPMV_PACE_PERIOD", period)
+    n_q, k = 64, 100
+    m = pkg.generate_matrix(1000000, 1024, 20, "gamma", 2)
+    xs = np.stack([pkg.create_sample_vector(1024, True, False, True, 7000 + i) for i in range(n_q)])
+    dxs = torch.from_numpy(np.ascontiguousarray(xs)).cuda()
+    out_i = torch.zeros(n_q, k, dtype=torch.int32, device="cuda")
+    out_v = torch.zeros(n_q, k, dtype=torch.float32, device="cuda")
+    eng = pkg.SpMV(m.row, m.col, m.val, m.rows, m.cols, k=k, device=0, stream_replicas=4)
+    packed, raw, C = _packed_raw(pkg, m, eng, k)
+    torch.cuda.synchronize()
+    eng.enqueue_batch(dxs.data_ptr(), n_q, out_i.data_ptr(), out_v.data_ptr())
+    eng.synchronize()
+    gi_all = out_i.cpu().numpy().astype(np.uint32)
+    gv_all = out_v.cpu().numpy()
+    for q in range(n_q):
+        _exact(pkg, oracle, m, eng, xs[q], k, gi_all[q], gv_all[q], raw, C, gold=q % 8 == 0)
+    c = eng.debug_counters()
+    assert c["checks_failed"] == 0, c
+    if period == "measured":
+        assert c["pace_tuned_us"] > 0 and c["pace_tune_launches"] > 0, c
+    else:
+        assert c["pace_period_ns"] == int(period), c
+    us = {}
+    for ext in ("1", "0"):  # (the bracket's events on the region's first and last kernel / recorded around them)
+        monkeypatch.setenv("TKSPMV_EXT_EVENTS", ext)
+        eng.time_queries(dxs.data_ptr(), n_q, 64)
+        us[ext] = min(eng.time_queries(dxs.data_ptr(), n_q, 64) for _ in range(3)) / 1e3
+    assert 10.0 < us["1"] < 40.0 and 10.0 < us["0"] < 40.0, us
+    assert us["1"] <= us["0"] * 1.08 and us["1"] >= us["0"] * 0.85, us  # (the recorded pair holds ~1.6 us of host time more per region; runs differ by a few per cent)
+    print(f"\n[timetable {period}] {n_q} queries exact; period in force {c['pace_period_ns']} ns, pauses by rank {c['pace_quantum']}x{c['pace_levels']}; "
+          f"us per query by the two event brackets: {us}")
+    eng.close()
+
+
 def test_exchange_state_stays_small_at_the_headline_size(pkg):
     """tkspmv_info.state_bytes: everything the engine allocates besides the matrix, x and the result buffers -- slots, records,
     overflow lists, thresholds, tickets. Round 3 held 256 MB of overflow lists + 32 MB of selection scratch at 10^6 rows; the lists
