@@ -1517,7 +1517,7 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
     // query, 17.6 at round 4's 4 over 3), 2 over 7 on its slow ones (17.4 against 18.9 and 20.0). So the engine measures: a handful of
     // settings, three launches of 32 synthetic queries each, twice through, behind 64 launches of warm-up: ~55 ms of tkspmv_create.
     if (m.use_local && m.can_batch && m.pace_quads != 0u && !opt("PACE") && !opt("PACE_LEVELS") && !opt("PACE_BASE") &&
-        (!opt("AUTOTUNE") || atoi(opt("AUTOTUNE")) != 0) && m.pm.packet_bytes == 1408u) {
+        (!opt("AUTOTUNE") || atoi(opt("AUTOTUNE")) != 0)) {  // (every packet size since the pause sits behind the arithmetic: fp16 and the fixed-point streams gain as fp32 does)
         const int nq = std::min((int)BATCH_MAX, m.batch_max);
         std::vector<float> hx((size_t)nq * d.cols);
         uint32_t lcg = 0x1234567u;
