@@ -1518,7 +1518,9 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
     // settings, three launches of 32 synthetic queries each, twice through, behind 64 launches of warm-up: ~55 ms of tkspmv_create.
     if (m.use_local && m.can_batch && m.pace_quads != 0u && !opt("PACE") && !opt("PACE_LEVELS") && !opt("PACE_BASE") &&
         (!opt("AUTOTUNE") || atoi(opt("AUTOTUNE")) != 0)) {  // (every packet size since the pause sits behind the arithmetic: fp16 and the fixed-point streams gain as fp32 does)
-        const int nq = std::min((int)BATCH_MAX, m.batch_max);
+        // (launches of 32 queries up to the headline's size; fewer queries per launch on larger matrices, so that the measurement stays
+        //  at ~150 ms of streaming: 10M rows -- 5.3 ms per launch of 32 -- would spend 1.3 s on it)
+        const int nq = std::max(4, std::min(std::min((int)BATCH_MAX, m.batch_max), (int)(32ull * 80000ull / std::max<uint64_t>(m.pm.n_packets, 1))));
         std::vector<float> hx((size_t)nq * d.cols);
         uint32_t lcg = 0x1234567u;
         for (float &v : hx) {

@@ -288,8 +288,10 @@ struct PackedMatrix {
 // 1 up to a tenth of that.
 // (TKSPMV_MIN_PACKETS / TKSPMV_SMALL_PACKETS: tuning runs.)
 constexpr uint64_t SMALL_MATRIX_PACKETS = 55000;
-// (up to this many packets -- ~1.3M rows of 20 non-zeros -- the batch kernel runs with workgroup-local thresholds: engine.hip)
-constexpr uint64_t LOCAL_MATRIX_PACKETS = 100000;
+// (up to this many packets the batch kernel runs with workgroup-local thresholds: engine.hip. Rounds 3-5a: 100000, ~1.3M rows of 20
+//  non-zeros -- beyond, the device-wide exchange was as fast. With the timetable of round 5 the local kernel wins at every size
+//  measured: 24.4 against 25.9 us per query at 1.5M rows, 32.9 / 34.3 at 2M, 48.6 / 52.4 at 3M, 83.7 / 86.2 at 5M, 159.4 / 172.1 at 10M.)
+constexpr uint64_t LOCAL_MATRIX_PACKETS = 4000000;
 uint64_t small_matrix_packets();
 uint32_t min_packets_per_partition_for(uint64_t nnz, uint32_t C, uint32_t cols);
 
