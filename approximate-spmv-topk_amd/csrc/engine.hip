@@ -877,14 +877,16 @@ static hipError_t malloc_exchange(void **p, size_t bytes) {
 // (create_impl) the same settings win up to LOCAL_MATRIX_PACKETS -- the headline's 1M rows included; beyond, the device-wide
 // exchange is as fast and checks nothing. Returns the selector workgroups of a batch launch for this matrix and geometry
 // (TKSPMV_SELECTORS overrides; the matrix unknown -- nnz = 0 --: 1). TKSPMV_SMALL_PACKETS: both limits (0: round 2's behaviour).
-static uint64_t local_matrix_packets() {
+// (fp32 and fp16 values: every size, wbscsr.hpp; byte and fixed-point values keep round 4's limit -- their kernels are bound by
+//  arithmetic, and there the local thresholds lose beyond it: Q1.7 bytes at 1M x 512 x 40, 154k packets: 33.0 against 24.7 us)
+static uint64_t local_matrix_packets(int32_t precision) {
     if (const char *f = opt("SMALL_PACKETS")) return (uint64_t)atoll(f);
-    return LOCAL_MATRIX_PACKETS;
+    return (precision == TKSPMV_F32 || precision == TKSPMV_F16) ? LOCAL_MATRIX_PACKETS : 100000ull;
 }
 static uint32_t small_matrix_settings(const tkspmv_desc &d, uint32_t grid, bool defer_capable, uint32_t C, bool *small_out) {
     const uint64_t packets_lb = d.nnz / (64u * (uint64_t)std::max(C, 1u));
     const bool small = defer_capable && grid >= 64u && d.nnz != 0 && d.cols <= 1024u && d.impl == TKSPMV_IMPL_STREAM && d.multi_q == 0 &&
-                       d.partitions <= 1 && packets_lb <= local_matrix_packets() && !opt("MULTI_Q");
+                       d.partitions <= 1 && packets_lb <= local_matrix_packets(d.precision) && !opt("MULTI_Q");
     if (small_out) *small_out = small;
     uint32_t n = small ? 4u : 1u;
     if (const char *f = opt("SELECTORS")) n = (uint32_t)std::max(1, std::min(8, atoi(f)));
