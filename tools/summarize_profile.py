@@ -93,6 +93,25 @@ for sub, stem in (("shard125k", f"{tag}_shard125k"), ("config3", f"{tag}_config3
         if lines:
             open(os.path.join(dst, stem + "_under_rocprofv3.json"), "w").write(lines[-1] + "\n")
 
+# configs[3] (10M rows): the launches of 32 queries alone -- tkspmv_create's pacing measurement launches 4 queries at a time there,
+# and the kernel statistics above average over both kinds
+kt3 = find("config3/**/*kernel_trace.csv")
+if kt3:
+    rows3 = [r for r in csv.DictReader(open(kt3)) if "batch_kernel" in r.get("Kernel_Name", "")]
+    dur = {True: [], False: []}
+    for r in rows3:
+        n = r["Kernel_Name"]
+        dur[n.rstrip(">)").split(",")[-1].strip().startswith("true") or ", true>" in n].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    out3 = {}
+    for local, name in ((True, "checked local thresholds (batch_kernel<..., true>)"), (False, "device-wide exchange (batch_kernel<..., false>)")):
+        d3 = sorted(dur[local])
+        full = [x for x in d3 if x > 0.6 * d3[-1]] if d3 else []
+        if full and full[-1] > 2e6:  # (launches of 32 queries at 10M rows take milliseconds: the empty repair launches do not count)
+            out3[name] = {"launches_of_32_queries": len(full), "mean_launch_us": sum(full) / len(full) / 1e3, "median_launch_us": full[len(full) // 2] / 1e3,
+                          "mean_us_per_query": sum(full) / len(full) / 1e3 / 32, "median_us_per_query": full[len(full) // 2] / 1e3 / 32, "other_launches_of_that_kernel": len(d3) - len(full)}
+    if out3:
+        json.dump(out3, open(os.path.join(dst, f"{tag}_config3_10M_launches.json"), "w"), indent=1)
+
 for rows in (125000, 250000, 500000):  # the one-GPU rehearsal of a strong-scaled run's shards; the size sweep
     p = os.path.join(out, f"shard_rehearsal_{rows}.json")
     if os.path.exists(p):
