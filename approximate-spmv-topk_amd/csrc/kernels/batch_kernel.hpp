@@ -36,6 +36,9 @@ constexpr int BATCH_MAX = 32;
 #ifndef TKSPMV_CLOCK_STRIDE
 #define TKSPMV_CLOCK_STRIDE 2  // (a power of two; same box, sustained / the driver's 20-query launch: 1: 16.8-17.0 / 17.2, 2: 16.8-17.1 / 17.0, 4: 17.1-17.5 / 17.7, 8: 17.3-18.2 / 17.8 us per query)
 #endif
+#ifndef TKSPMV_ORIGIN_OFFSET
+#define TKSPMV_ORIGIN_OFFSET 0
+#endif
 #ifndef TKSPMV_TAU_WAIT
 #define TKSPMV_TAU_WAIT 3000
 #endif
@@ -809,6 +812,7 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
     float top1 = 0.0f, top2 = 0.0f;  // local thresholds: the two largest packet maxima of this wave in the current query
     uint32_t wcnt = 0u;
     uint32_t pace = 0u;  // this query's pause per packet, units of pace_quads x 128 cycles (the server: from the workgroup's rank in the previous query)
+    const uint32_t wave_entry_fp = (LOCAL && B.pace_period != 0u) ? ((uint32_t)__builtin_amdgcn_s_memrealtime() << 8) : 0u;
     const uint32_t tpkt_fp = (LOCAL && B.pace_period != 0u && np != 0u) ? (uint32_t)((float)B.pace_period / (float)np) : 0u;  // a packet's slot on the timetable
     uint32_t sched_fp = 0u;  // when the packet being reduced is due (ticks << 8, low 32 bits)
     uint32_t pace_rank = 0u;  // (timetable: the pause by rank, which takes over while the wave is more than half a query behind)
@@ -845,7 +849,12 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
                 wcnt = 0u;
                 top1 = top2 = -__builtin_huge_valf();
                 waited = false;
-                if (tpkt_fp != 0u && qc == 0u) sched_fp = (uint32_t)__builtin_amdgcn_s_memrealtime() << 8;
+                // The timetable starts where the wave ENTERED the kernel, not where the first x became ready 3-5 us later: the wave is behind
+                // it from its first packet and runs unpaused until it has caught up (a query or two), and the launch -- which ends a
+                // fixed number of periods behind the timetable's start -- ends that much earlier: 16.5-16.7 against 16.8-16.9 us per
+                // query sustained, a launch of 20 queries 16.8-16.9 against 17.1 on one box (TKSPMV_ORIGIN_OFFSET ticks: 0; +200 as before,
+                // -300 / -600 measured too).
+                if (tpkt_fp != 0u && qc == 0u) sched_fp = wave_entry_fp + (uint32_t)((int32_t)TKSPMV_ORIGIN_OFFSET * 256);
                 if (tpkt_fp != 0u && (np & (uint32_t)(TKSPMV_CLOCK_STRIDE - 1)) != 0u)  // (the query's last look covers fewer packets than it books)
                     sched_fp -= tpkt_fp * ((uint32_t)TKSPMV_CLOCK_STRIDE - (np & (uint32_t)(TKSPMV_CLOCK_STRIDE - 1)));
                 if (pace_q != 0u) {
