@@ -462,7 +462,7 @@ struct EngineImpl {
             if (a || b) hipExtLaunchKernelGGL(fn, dim3(grid), dim3(block + 64), 0, s, a, b, 0, args);
             else hipLaunchKernelGGL(fn, dim3(grid), dim3(block + 64), 0, s, args);
         };
-        if (s != bside) drain(s);
+        if (!bside || s != bside) drain(s);
         StreamParams P = stream_params(xs[0], 0);
         P.fused = 0u;
         SelectParams S = select_params(out_idx[0], out_val[0], 0);
@@ -513,7 +513,7 @@ struct EngineImpl {
         B.lused_stride = grid;
         B.ovf_epoch = d_ovf_epoch;
         B.ovf_lists = std::min(ovf_lists, 4u);  // (engines with one list per set -- the multi-query ones -- lend the batch kernel their first four)
-        if (use_local && (s == stream || s == bside) && h_verdict && pending_checks.size() + 1u < VERDICT_RING) {
+        if (use_local && (s == stream || (bside && s == bside)) && h_verdict && pending_checks.size() + 1u < VERDICT_RING) {
             const uint32_t slot = (uint32_t)(verdict_seq++ % VERDICT_RING);
             h_verdict[slot] = 0ull;
             B.verdict_host = h_verdict_dev + slot;
@@ -1462,9 +1462,11 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
             HIP_TRY(hipMalloc((void **)&m.d_alias_val, nr * d.k * 4));
             if (m.use_local) {
                 if (const char *f = opt("OVERLAP")) m.overlap_launches = atoi(f) != 0;
-                HIP_TRY(hipStreamCreateWithFlags(&m.bside, hipStreamNonBlocking));
-                HIP_TRY(hipEventCreateWithFlags(&m.ev_bfork, hipEventDisableTiming));
-                HIP_TRY(hipEventCreateWithFlags(&m.ev_bjoin, hipEventDisableTiming));
+                if (m.overlap_launches) {  // (the second stream exists only where it is used: every stream is one more for a device-wide wait to visit)
+                    HIP_TRY(hipStreamCreateWithFlags(&m.bside, hipStreamNonBlocking));
+                    HIP_TRY(hipEventCreateWithFlags(&m.ev_bfork, hipEventDisableTiming));
+                    HIP_TRY(hipEventCreateWithFlags(&m.ev_bjoin, hipEventDisableTiming));
+                }
             }
         }
         m.info.state_bytes = ns * (EngineImpl::GMAX_WORDS * 4 + 2 * EngineImpl::STATE_WORD_STRIDE * 4 + (uint64_t)m.grid * WG_SLOTS * 8) +
