@@ -2135,8 +2135,12 @@ int Engine::time_queries(const float *dev_xs, int32_t n_x, int32_t iters, double
         err = "bad arguments to time_queries";
         return TKSPMV_ERR_INVALID;
     }
+    const bool host_times = opt("HOST_TIMES") != nullptr;  // (diagnostic: where the host's microseconds around the region go, to stderr)
+    auto now_us = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double h0 = host_times ? now_us() : 0.0;
     HIP_TRY(hipSetDevice(m.device));
     HIP_TRY(hipStreamSynchronize(m.stream));
+    const double h1 = host_times ? now_us() : 0.0;
     // (batch launches on one stream: the bracket's events travel with the first and the last kernel; any other path records them)
     const bool ext = m.can_batch && !(m.overlap_launches && m.bside) && (!opt("EXT_EVENTS") || atoi(opt("EXT_EVENTS")) != 0);
     if (ext) {
@@ -2153,6 +2157,7 @@ int Engine::time_queries(const float *dev_xs, int32_t n_x, int32_t iters, double
         m.launch_sequence(xs.data(), oi.data(), ov.data(), iters, m.stream);
     }
     if (!ext) HIP_TRY(hipEventRecord(m.ev1, m.stream));
+    const double h2 = host_times ? now_us() : 0.0;
     if (m.ext_start || m.ext_stop) {  // (cannot happen: every batch path launches through launch_batch)
         m.ext_start = m.ext_stop = nullptr;
         err = "time_queries: the region's events were not attached to its launches";
@@ -2168,9 +2173,14 @@ int Engine::time_queries(const float *dev_xs, int32_t n_x, int32_t iters, double
             break;
         }
     }
+    const double h3 = host_times ? now_us() : 0.0;
     HIP_TRY(m.settle());  // (the end event has passed: the stream is idle; a flagged query is repaired outside the event bracket)
+    const double h4 = host_times ? now_us() : 0.0;
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, m.ev0, m.ev1));
+    if (host_times)
+        fprintf(stderr, "[tkspmv] time_queries(%d): entry + wait for the idle stream %.1f us, lists + launches %.1f, until the end event is seen %.1f (the region itself %.1f), verdicts %.1f, elapsed time %.1f\n",
+                iters, h1 - h0, h2 - h1, h3 - h2, (double)ms * 1e3, h4 - h3, now_us() - h4);
     *ns_per_query = (double)ms * 1e6 / iters;
     m.ran = true;
     m.last_on_host = false;
