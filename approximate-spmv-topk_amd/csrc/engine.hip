@@ -225,6 +225,7 @@ struct EngineImpl {
     // is stamped before the host has written the dispatch packet (1.6 us of host time inside a 350 us bracket, tools/probes/event_probe.cpp)
     mutable hipEvent_t ext_start = nullptr, ext_stop = nullptr;
     mutable bool ext_last = false;  // (launch_sequence: the launch_batch being made is the region's last)
+    mutable bool ext_record = false;  // the same two events RECORDED right in front of the first and right behind the last launch (EXT_EVENTS=2)
     uint32_t pace_period_ns = 0;  // pacing by the clock (BatchParams::pace_period): ns per query of every wave's timetable; 0: pacing by rank
     mutable uint64_t batch_launches = 0;
     uint32_t n_sel_wg = 1;   // selector workgroups of a batch launch (BatchParams::n_selectors): 4 on small matrices
@@ -459,8 +460,15 @@ struct EngineImpl {
             hipEvent_t a = ext_start, b = (last && ext_last) ? ext_stop : nullptr;
             ext_start = nullptr;
             if (b) ext_stop = nullptr;
-            if (a || b) hipExtLaunchKernelGGL(fn, dim3(grid), dim3(block + 64), 0, s, a, b, 0, args);
-            else hipLaunchKernelGGL(fn, dim3(grid), dim3(block + 64), 0, s, args);
+            if (ext_record) {
+                if (a) (void)hipEventRecord(a, s);
+                hipLaunchKernelGGL(fn, dim3(grid), dim3(block + 64), 0, s, args);
+                if (b) (void)hipEventRecord(b, s);
+            } else if (a || b) {
+                hipExtLaunchKernelGGL(fn, dim3(grid), dim3(block + 64), 0, s, a, b, 0, args);
+            } else {
+                hipLaunchKernelGGL(fn, dim3(grid), dim3(block + 64), 0, s, args);
+            }
         };
         if (!bside || s != bside) drain(s);
         StreamParams P = stream_params(xs[0], 0);
@@ -2142,7 +2150,9 @@ int Engine::time_queries(const float *dev_xs, int32_t n_x, int32_t iters, double
     HIP_TRY(hipStreamSynchronize(m.stream));
     const double h1 = host_times ? now_us() : 0.0;
     // (batch launches on one stream: the bracket's events travel with the first and the last kernel; any other path records them)
-    const bool ext = m.can_batch && !(m.overlap_launches && m.bside) && (!opt("EXT_EVENTS") || atoi(opt("EXT_EVENTS")) != 0);
+    const int ext_mode = opt("EXT_EVENTS") ? atoi(opt("EXT_EVENTS")) : 1;
+    const bool ext = m.can_batch && !(m.overlap_launches && m.bside) && ext_mode != 0;
+    m.ext_record = ext && ext_mode == 2;
     if (ext) {
         m.ext_start = m.ev0;
         m.ext_stop = m.ev1;
