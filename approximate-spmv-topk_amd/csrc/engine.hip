@@ -893,8 +893,11 @@ static uint64_t local_matrix_packets(int32_t precision) {
 }
 static uint32_t small_matrix_settings(const tkspmv_desc &d, uint32_t grid, bool defer_capable, uint32_t C, bool *small_out) {
     const uint64_t packets_lb = d.nnz / (64u * (uint64_t)std::max(C, 1u));
+    // (partitions with k <= k_per_partition: the union of the per-partition lists holds the global top-k -- the ordinary kernels'
+    //  result IS the partitioned one, create_impl --, so such engines take the settings of an unpartitioned one: BASELINE configs[2])
+    const bool plain_topk = d.partitions <= 1 || d.k <= (d.k_per_partition > 0 ? d.k_per_partition : d.k);
     const bool small = defer_capable && grid >= 64u && d.nnz != 0 && d.cols <= 1024u && d.impl == TKSPMV_IMPL_STREAM && d.multi_q == 0 &&
-                       d.partitions <= 1 && packets_lb <= local_matrix_packets(d.precision) && !opt("MULTI_Q");
+                       plain_topk && packets_lb <= local_matrix_packets(d.precision) && !opt("MULTI_Q");
     if (small_out) *small_out = small;
     uint32_t n = small ? 4u : 1u;
     if (const char *f = opt("SELECTORS")) n = (uint32_t)std::max(1, std::min(8, atoi(f)));
