@@ -501,6 +501,9 @@ struct EngineImpl {
         B.pace_levels = pace_levels;
         B.pace_base = pace_base;
         B.pace_period = (uint32_t)std::min<uint64_t>(0xFFFFFF00ull, (uint64_t)pace_period_ns * 256u / 10u);
+        // (the waves keep the timetable in 32 bits of ticks << 8: 168 ms to the wrap. A launch that could last a quarter of that -- 32
+        //  queries of 1.3 ms: 80M rows -- paces by rank instead)
+        if ((uint64_t)pace_period_ns * (uint64_t)n > 40000000ull) B.pace_period = 0u;
         B.wg_pace = pace_carry ? d_wg_pace : nullptr;
         B.wg_times = d_wg_times;
         B.prior_block = reinterpret_cast<uint32_t *>(d_wg_prior + grid);

@@ -895,9 +895,13 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
                     const int32_t ahead = (int32_t)(sched_fp - (clk_now << 8));  // ticks << 8
                     // The wave sleeps in steps of 512 cycles (21 ticks at 2.4 GHz; what is left over the next look sees: the timetable is
                     // absolute, nothing adds up) -- one short loop instead of a test per bit of the count.
+                    // (never longer than one period per look: a wave cannot be that far ahead of a timetable it follows -- whatever says
+                    //  so, a clock that wrapped, a period of another matrix, costs a bounded pause and not a launch that stands still)
                     if (!behind) {
+                        const int32_t cap = (int32_t)B.pace_period;
 #pragma unroll 1
-                        for (int32_t z = ahead; z > (int32_t)(11u << 8); z -= (int32_t)(21u << 8)) __builtin_amdgcn_s_sleep(8);
+                        for (int32_t z = ahead < cap ? ahead : cap; z > (int32_t)(11u << 8); z -= (int32_t)(21u << 8)) __builtin_amdgcn_s_sleep(8);
+                        if (ahead > 2 * cap) sched_fp = clk_now << 8;
                     }
                     // A timetable nobody can keep (the GPU streams slower than when the period was measured: a change of power state,
                     // the first milliseconds after an idle period) would leave the field unpaced: a wave more than half a query behind
