@@ -1,6 +1,6 @@
 """The cases of tests/test_gpu_local_fuzz.py for seeds beyond the committed 32 (a one-off soak after kernel changes): the default
 engine against the engine of the device-wide exchange on the same partition cut, bit for bit, two passes per case.
-  python tools/fuzz_soak.py FIRST LAST"""
+  [BIG=1] python tools/fuzz_soak.py FIRST LAST"""
 import os
 import sys
 
@@ -17,12 +17,17 @@ bad_cases = 0
 for seed in range(first, last):
     rng = np.random.default_rng(1000 + seed)
     rows = int(rng.choice([900, 5000, 23000, 70000, 160000, 330000]))
+    if os.environ.get("BIG"):  # (round 5: the checked local thresholds serve every size -- BIG=1 draws 1.5M .. 4M rows of fp32 / fp16 values)
+        rows = int(rng.choice([1500000, 2500000, 4000000]))
     cols = int(rng.choice([64, 300, 512, 1024]))
     nnz = int(rng.choice([1, 3, 12, 20, 45]))
     k = int(rng.choice([1, 8, 100, 100, 250]))
     prec = str(rng.choice(["F32", "F32", "F16", "Q1_7", "Q1_7_WIDE", "FIXED"]))
     dist = str(rng.choice(["gamma", "uniform"]))
-    if rows * nnz > 8_000_000:
+    if os.environ.get("BIG"):
+        prec = str(rng.choice(["F32", "F32", "F16"]))
+        nnz = int(rng.choice([8, 20]))
+    elif rows * nnz > 8_000_000:
         nnz = max(1, 8_000_000 // rows)
     m = pkg.generate_matrix(rows, cols, nnz, dist, 50 + seed)
     nq = 40
