@@ -163,11 +163,17 @@ struct CutsOut {
 
 // The greedy cuts of fill_partitions(): a partition takes rows while their expanded entries fit `cap`; at least one row.
 // part tables are written for up to P_max partitions; returns the number of partitions the capacity leads to.
+// bal_B != 0: balanced cuts (wbscsr.cpp, fill_partitions_balanced) -- partition p may take PE x (floor((p + 1) B / P) - floor(p B / P))
+// entries instead of `cap`.
 __device__ uint32_t cut_pass(const unsigned long long *__restrict__ S, uint32_t n_rows, unsigned long long cap, uint32_t P_max,
-                             uint32_t *__restrict__ part_row0, uint32_t lane) {
+                             uint32_t *__restrict__ part_row0, uint32_t lane, unsigned long long bal_B = 0ull, unsigned long long PE = 0ull) {
     uint32_t a = 0, parts = 0;
     while (a < n_rows) {
         if (parts < P_max && lane == 0) part_row0[parts] = a;
+        if (bal_B != 0ull) {
+            const unsigned long long p = parts, P = P_max;
+            cap = PE * (p < P ? ((p + 1ull) * bal_B) / P - (p * bal_B) / P : (bal_B + P - 1ull) / P);
+        }
         ++parts;
         if (parts > P_max) return parts;  // too many: the caller grows the capacity
         const unsigned long long target = S[a] + cap;
@@ -186,7 +192,7 @@ __device__ uint32_t cut_pass(const unsigned long long *__restrict__ S, uint32_t 
 }
 
 __global__ void __launch_bounds__(64) cuts_kernel(const unsigned long long *__restrict__ S, uint32_t n_rows, uint32_t PE,
-                                                  uint32_t P_hint, uint32_t min_packets, uint32_t *__restrict__ part_row0,
+                                                  uint32_t P_hint, uint32_t min_packets, uint32_t balanced, uint32_t *__restrict__ part_row0,
                                                   uint32_t *__restrict__ part_rows, uint32_t *__restrict__ part_first,
                                                   uint32_t *__restrict__ part_count, CutsOut *__restrict__ out) {
     const uint32_t lane = threadIdx.x;
@@ -202,6 +208,16 @@ __global__ void __launch_bounds__(64) cuts_kernel(const unsigned long long *__re
         used = cut_pass(S, n_rows, m * PE, P, part_row0, lane);
         if (used <= P) break;
         ++m;  // padding pushed the cuts over the wave count: allow one more packet per partition
+    }
+    // balanced cuts where the uniform ones miss P by more than 1/8 (wbscsr.cpp: the same rule, the same arithmetic)
+    if (balanced != 0u && P >= 2u && total_packets_lb >= 2ull * P && (unsigned long long)used * 8ull < (unsigned long long)P * 7ull) {
+        unsigned long long B = total_packets_lb > P ? total_packets_lb : P;
+        for (;;) {
+            used = cut_pass(S, n_rows, 0ull, P, part_row0, lane, B, PE);
+            if (used <= P) break;
+            B += (B / 64ull) > 1ull ? (B / 64ull) : 1ull;
+        }
+        m = (B + P - 1ull) / P;
     }
     __threadfence();  // lane 0's table writes are read by the other lanes below
     __syncthreads();
@@ -441,8 +457,9 @@ std::string pack_wbscsr_device(uint32_t rows, uint32_t cols, uint64_t nnz, const
     DP_TRY(hipMalloc(&d_pfirst.p, (size_t)P_cap * 4));
     DP_TRY(hipMalloc(&d_pcount.p, (size_t)P_cap * 4));
     DP_TRY(hipMalloc(&d_cuts.p, sizeof(CutsOut)));
+    const uint32_t balanced = (opt("BALANCED_CUTS") && atoi(opt("BALANCED_CUTS")) == 0) ? 0u : 1u;
     hipLaunchKernelGGL(cuts_kernel, dim3(1), dim3(64), 0, 0, d_exp_start.as<unsigned long long>(), n_rows, PE, n_partitions_hint,
-                       min_packets_per_partition, d_pr0.as<uint32_t>(), d_prows.as<uint32_t>(), d_pfirst.as<uint32_t>(),
+                       min_packets_per_partition, balanced, d_pr0.as<uint32_t>(), d_prows.as<uint32_t>(), d_pfirst.as<uint32_t>(),
                        d_pcount.as<uint32_t>(), d_cuts.as<CutsOut>());
     CutsOut cuts{};
     DP_TRY(hipMemcpy(&cuts, d_cuts.p, sizeof(cuts), hipMemcpyDeviceToHost));
