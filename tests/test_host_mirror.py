@@ -147,6 +147,34 @@ def test_pack_decode_round_trip(pkg, C, parts):
     assert p.info()["packed_entries"] - g.nnz <= p.info()["n_wave_partitions"] * 64 * C
 
 
+@pytest.mark.parametrize("rows,hint", [(125000, 4064), (30000, 1016), (47000, 1504)])
+def test_balanced_cuts_fill_the_waves_asked_for_and_lose_nothing(pkg, monkeypatch, rows, hint):
+    """Round 5 (wbscsr.cpp, fill_partitions_balanced): partitions of equal capacity fill 79 % of the waves of a 125k-row shard (3229
+    partitions of 3 packets for 4064 waves: a batch launch's workgroups stream 6 or 7 each); where that share is under 7/8 and a
+    partition holds two packets or more, the packets are dealt out over the count asked for, floor or ceil of the mean each. The
+    stream decodes to the matrix either way, every partition starts on a row boundary, and the tables stay consistent."""
+    m = pkg.generate_matrix(rows, 1024, 20, "gamma", 2)
+    res = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("TKSPMV_BALANCED_CUTS", flag)
+        p = pkg.Packed(m, nnz_per_lane=4, n_wave_partitions=hint)
+        dr, dc, dv = p.decode()
+        assert np.array_equal(dr, m.row) and np.array_equal(dc, m.col) and np.array_equal(dv, m.val)
+        packets, packet_bytes, pkt_row, part_first, part_count = p.raw()
+        assert part_count.sum() == p.info()["n_packets"] and np.all(part_first[1:] == np.cumsum(part_count)[:-1])
+        assert np.all(np.diff(pkt_row.astype(np.int64)) >= 0) and len(part_count) <= hint
+        res[flag] = part_count
+    uniform, balanced = res["0"], res["1"]
+    assert len(uniform) * 8 < hint * 7, "the case is meant to be one the uniform cut leaves waves idle in"
+    assert len(balanced) > len(uniform) and len(balanced) * 16 >= hint * 15  # (the waves asked for, or a handful fewer)
+    assert balanced.max() - balanced.min() <= 2 and balanced.min() >= 1  # (floor / ceil of the mean; a long row may add a packet)
+    # a batch launch gives wave w of workgroup b partition w * n_wg + b: the packets per workgroup are within a few of each other
+    n_wg = hint // 8
+    per_wg = np.array([balanced[b::n_wg].sum() for b in range(n_wg)])
+    per_wg_u = np.array([uniform[b::n_wg].sum() for b in range(n_wg)])
+    assert per_wg.max() - per_wg.min() <= 8 and per_wg.max() < per_wg_u.max()
+
+
 def test_shortest_partition_depends_on_the_matrix_size_alone(pkg, monkeypatch):
     """wbscsr.hpp: min_packets_per_partition_for -- every packer (host, device, tkspmv_pack, the engine) must cut the same
     partitions from the same hint. Small matrices (the shards of a strong-scaled run) get partitions from one or two packets
