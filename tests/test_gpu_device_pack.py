@@ -39,7 +39,8 @@ def _coo(pkg, lens, cols, seed=0):
 
 @pytest.mark.parametrize("precision,width", [("F32", 0), ("F16", 0), ("Q1_7", 0), ("Q1_7_F32", 0), ("FIXED", 20), ("FIXED", 32)])
 @pytest.mark.parametrize("rows,cols,nnz,dist,seed,hint", [(20000, 1024, 20, "gamma", 1, 4088), (3000, 512, 40, "uniform", 2, 4088),
-                                                          (150000, 300, 25, "gamma", 3, 512), (700, 64, 5, "uniform", 4, 4088)])
+                                                          (150000, 300, 25, "gamma", 3, 512), (700, 64, 5, "uniform", 4, 4088),
+                                                          (125000, 1024, 20, "gamma", 5, 4064), (40000, 512, 40, "uniform", 6, 1200)])  # (the last two: balanced cuts)
 def test_generated_matrices_pack_identically(pkg, precision, width, rows, cols, nnz, dist, seed, hint):
     m = pkg.generate_matrix(rows, cols, nnz, dist, seed)
     kw = dict(k=100, nnz_per_lane=4, n_wave_partitions=hint, precision=getattr(pkg, precision), fixed_width=width)
