@@ -226,6 +226,8 @@ struct EngineImpl {
     mutable hipEvent_t ext_start = nullptr, ext_stop = nullptr;
     mutable bool ext_last = false;  // (launch_sequence: the launch_batch being made is the region's last)
     mutable bool ext_record = false;  // the same two events RECORDED right in front of the first and right behind the last launch (EXT_EVENTS=2)
+    uint32_t *d_pace_adapt = nullptr;  // [0] what launches add to the period, [1] late waves of the launch in flight (BatchParams::pace_adapt)
+    bool pace_adapt_on = true;         // option PACE_ADAPT=0: the period stays what tkspmv_create measured
     uint32_t pace_period_ns = 0;  // pacing by the clock (BatchParams::pace_period): ns per query of every wave's timetable; 0: pacing by rank
     mutable uint64_t batch_launches = 0;
     uint32_t n_sel_wg = 1;   // selector workgroups of a batch launch (BatchParams::n_selectors): 4 on small matrices
@@ -504,6 +506,7 @@ struct EngineImpl {
         // (the waves keep the timetable in 32 bits of ticks << 8: 168 ms to the wrap. A launch that could last a quarter of that -- 32
         //  queries of 1.3 ms: 80M rows -- paces by rank instead)
         if ((uint64_t)pace_period_ns * (uint64_t)n > 40000000ull) B.pace_period = 0u;
+        B.pace_adapt = pace_adapt_on ? d_pace_adapt : nullptr;
         B.wg_pace = pace_carry ? d_wg_pace : nullptr;
         B.wg_times = d_wg_times;
         B.prior_block = reinterpret_cast<uint32_t *>(d_wg_prior + grid);
@@ -834,7 +837,7 @@ Engine::~Engine() {
     void *bufs[] = {m.d_packets, m.d_pkt_row, m.d_part_first, m.d_part_count, m.d_x,
                     m.d_out_idx, m.d_out_val, m.d_scores,     m.d_stats,      m.d_done, m.d_trace, m.d_tickets,
                     m.d_tstart, m.d_verdict, m.d_wg_prior, m.d_rec_slots, m.d_rec_used, m.d_ovf_epoch, m.d_alias_idx, m.d_alias_val,
-                    m.d_lslots,  m.d_lused, m.d_lprior, m.d_lstatus, m.d_wg_pace, m.d_wg_times, m.d_wg_sig, m.d_lready};
+                    m.d_lslots,  m.d_lused, m.d_lprior, m.d_lstatus, m.d_wg_pace, m.d_wg_times, m.d_wg_sig, m.d_lready, m.d_pace_adapt};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     {
@@ -1391,9 +1394,12 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
     if (const char *f = opt("PACE")) m.pace_quads = (uint32_t)std::max(0, std::min(32, atoi(f)));
     if (const char *f = opt("PACE_BASE")) m.pace_base = (uint32_t)std::max(0, std::min(64, atoi(f)));
     if (const char *f = opt("PACE_CARRY")) m.pace_carry = atoi(f) != 0;
+    if (const char *f = opt("PACE_ADAPT")) m.pace_adapt_on = atoi(f) != 0;
     if (const char *f = opt("PACE_PERIOD")) m.pace_period_ns = (uint32_t)std::max(0, std::min(10000000, atoi(f)));
     if (m.use_local && m.pace_quads != 0u) {
         HIP_TRY(hipMalloc((void **)&m.d_wg_pace, (size_t)m.grid * 4));
+        HIP_TRY(malloc_exchange((void **)&m.d_pace_adapt, 128));
+        HIP_TRY(hipMemset(m.d_pace_adapt, 0, 128));
         HIP_TRY(hipMemset(m.d_wg_pace, 0, (size_t)m.grid * 4));
     }
     // single_kernel serves tkspmv_run where the engine streams with local thresholds: fp32 values, 4 entries per lane, x of at most
@@ -1557,6 +1563,8 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
         float best_ms[NC];
         for (float &b : best_ms) b = 1e30f;
         const auto t_tune = std::chrono::steady_clock::now();
+        const bool adapt_was = m.pace_adapt_on;
+        m.pace_adapt_on = false;  // (the periods are measured as they are given)
         // (a GPU that has idled streams 10-15 % slower for its first ~20 ms -- 19.4 us per query falling to 16.7 over thirty launches,
         //  tools/launch_series.py --: the settings are compared on a GPU that has been busy for 64 launches)
         m.pace_quads = cand[0][0];
@@ -1651,6 +1659,7 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
         (void)hipFree(d_tx);
         m.pace_tuned_us = tune_us ? tune_us : 1u;
         m.pace_tune_launches = (uint32_t)tune_launches;
+        m.pace_adapt_on = adapt_was;
         if (opt("DEBUG_OCC")) {
             fprintf(stderr, "[tkspmv] pacing tuned in %u us:", tune_us);
             for (int c = 0; c < NC; ++c) fprintf(stderr, " %ux%u %.2f us/q%s", cand[c][0], cand[c][1], best_ms[c] * 1e3 / (2 * nq), c == best ? "*" : "");

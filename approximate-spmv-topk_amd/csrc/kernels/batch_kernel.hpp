@@ -119,6 +119,11 @@ struct BatchParams : SetAddr {
     // whatever it is ahead of it; a wave behind its timetable never pauses. The whole field then asks for the stream at the rate the
     // memory system can give: nobody queues, so nobody is favoured, and the workgroups end a launch together.
     uint32_t pace_period;  // ticks << 8 per query (0: off)
+    // A period that follows the GPU: [0] what the waves add to pace_period (ticks << 8, >= 0), [1] the waves of this launch that
+    // started its last query more than a quarter of a period behind their timetable. The selection that completes a launch of 8+
+    // queries lengthens the period by 1/64 when a quarter of the waves were that late (the GPU streams slower than when the period was
+    // measured) and takes 1/256 back when next to none were; never below what tkspmv_create measured, never more than 1/8 above.
+    uint32_t *pace_adapt;
     unsigned long long *wg_times;  // optional (option WG_TIMES): [BATCH_MAX + 1][n_wg] s_memrealtime at every hand-over (row q) and at the workgroup's entry (row BATCH_MAX)
     uint32_t *wg_pace;    // [n_wg] the pause a workgroup ended the previous launch with: its first query here starts from it (NULL: from none)
     // ---- the verdict of a launch's checks and the repair launch -----------------------------------------------------------------
@@ -331,6 +336,16 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
                     const unsigned long long done = __hip_atomic_fetch_add(B.verdict, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + add;
                     // (the selection that completes the word tells the host; read there only after the launch has ended)
                     if (B.verdict_host && (uint32_t)done == B.n_q) __hip_atomic_store(B.verdict_host, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if (LOCAL && B.pace_adapt && B.pace_period != 0u && (uint32_t)done == B.n_q && B.n_q >= 8u) {
+                        // (every streaming wave has long passed the start of its last query: the count is complete)
+                        const uint32_t late = __hip_atomic_exchange(B.pace_adapt + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const uint32_t n_waves = n_stream * 8u, adj = B.pace_adapt[0];
+                        uint32_t next = adj;
+                        if (4u * late > n_waves) next = adj + (B.pace_period >> 6);
+                        else if (64u * late < n_waves) next = adj > (B.pace_period >> 8) ? adj - (B.pace_period >> 8) : 0u;
+                        if (next > (B.pace_period >> 3)) next = B.pace_period >> 3;
+                        if (next != adj) B.pace_adapt[0] = next;
+                    }
                     if (LOCAL && B.wg_times) B.wg_times[(size_t)set_of(q) * gridDim.x + n_stream + 1u] = __builtin_amdgcn_s_memrealtime();  // (option WG_TIMES: selection done)
                 }
             } else {
@@ -813,7 +828,8 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
     uint32_t wcnt = 0u;
     uint32_t pace = 0u;  // this query's pause per packet, units of pace_quads x 128 cycles (the server: from the workgroup's rank in the previous query)
     const uint32_t wave_entry_fp = (LOCAL && B.pace_period != 0u) ? ((uint32_t)__builtin_amdgcn_s_memrealtime() << 8) : 0u;
-    const uint32_t tpkt_fp = (LOCAL && B.pace_period != 0u && np != 0u) ? (uint32_t)((float)B.pace_period / (float)np) : 0u;  // a packet's slot on the timetable
+    const uint32_t period_fp = (LOCAL && B.pace_period != 0u) ? B.pace_period + (B.pace_adapt ? scalar_load(B.pace_adapt) : 0u) : 0u;
+    const uint32_t tpkt_fp = (period_fp != 0u && np != 0u) ? (uint32_t)((float)period_fp / (float)np) : 0u;  // a packet's slot on the timetable
     uint32_t sched_fp = 0u;  // when the packet being reduced is due (ticks << 8, low 32 bits)
     uint32_t pace_rank = 0u;  // (timetable: the pause by rank, which takes over while the wave is more than half a query behind)
     bool behind = false;
@@ -911,6 +927,9 @@ __device__ __forceinline__ void batch_phase(const StreamParams &P0, const Select
                         behind = ahead < -(int32_t)(B.pace_period >> 1);
                         if (ahead < -(int32_t)B.pace_period) sched_fp -= (uint32_t)(ahead + (int32_t)B.pace_period);
                         if (behind) pace = pace_rank;
+                        // (the launch's last query: a wave a quarter of a period behind says so -- BatchParams::pace_adapt)
+                        if (B.pace_adapt && qc + 1u == nq && nq >= 8u && ahead < -(int32_t)(B.pace_period >> 2) && lane == 0)
+                            (void)__hip_atomic_fetch_add(B.pace_adapt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                 }
             }
