@@ -210,7 +210,8 @@ __global__ void __launch_bounds__(64) cuts_kernel(const unsigned long long *__re
         ++m;  // padding pushed the cuts over the wave count: allow one more packet per partition
     }
     // balanced cuts where the uniform ones miss P by more than 1/8 (wbscsr.cpp: the same rule, the same arithmetic)
-    if (balanced != 0u && P >= 2u && total_packets_lb >= 2ull * P && (unsigned long long)used * 8ull < (unsigned long long)P * 7ull) {
+    if (balanced != 0u && P >= 2u && total_packets_lb >= 2ull * P &&
+        (balanced == 2u ? (unsigned long long)used * 32ull < (unsigned long long)P * 31ull : (unsigned long long)used * 8ull < (unsigned long long)P * 7ull)) {
         unsigned long long B = total_packets_lb > P ? total_packets_lb : P;
         for (;;) {
             used = cut_pass(S, n_rows, 0ull, P, part_row0, lane, B, PE);
@@ -457,7 +458,7 @@ std::string pack_wbscsr_device(uint32_t rows, uint32_t cols, uint64_t nnz, const
     DP_TRY(hipMalloc(&d_pfirst.p, (size_t)P_cap * 4));
     DP_TRY(hipMalloc(&d_pcount.p, (size_t)P_cap * 4));
     DP_TRY(hipMalloc(&d_cuts.p, sizeof(CutsOut)));
-    const uint32_t balanced = (opt("BALANCED_CUTS") && atoi(opt("BALANCED_CUTS")) == 0) ? 0u : 1u;
+    const uint32_t balanced = opt("BALANCED_CUTS") ? (uint32_t)std::max(0, std::min(2, atoi(opt("BALANCED_CUTS")))) : 1u;
     hipLaunchKernelGGL(cuts_kernel, dim3(1), dim3(64), 0, 0, d_exp_start.as<unsigned long long>(), n_rows, PE, n_partitions_hint,
                        min_packets_per_partition, balanced, d_pr0.as<uint32_t>(), d_prows.as<uint32_t>(), d_pfirst.as<uint32_t>(),
                        d_pcount.as<uint32_t>(), d_cuts.as<CutsOut>());

@@ -30,7 +30,7 @@ static const OptionDef k_options[] = {
     {"HOST_TIMES", "diagnostic", "set = on", "tkspmv_time_queries prints to stderr where the host's microseconds around the timed region go"},
     {"EXT_EVENTS", "diagnostic", "0 | 1 | 2 (default 1; 2 = the pair recorded right in front of the first and right behind the last launch: 7 us more per region than 1, and the device-wide wait behind the call 11 us cheaper)", "tkspmv_time_queries: 1 = the event pair travels with the region's first and last kernel (hipExtLaunchKernelGGL: the dispatches' own start and end stamps, what rocprofv3 reports); 0 = hipEventRecord before and after (the start stamp then precedes the host's writing of the first dispatch packet: +1.6 us)"},
     {"PACE_PERIOD", "tuning", "ns per query (default: measured at create; 0 = pacing by rank)", "pacing by the clock: every streaming wave keeps a timetable of this many ns per query and sleeps off what it is ahead of it (replaces the pauses by rank)"},
-    {"BALANCED_CUTS", "layout", "0 | 1 (default 1)", "1: where partitions of equal capacity come to fewer than the waves asked for by more than 1/8, the packets are dealt out over exactly that many partitions (floor or ceil of the mean each): every workgroup of the batch kernel then streams the same number of partitions; 0: equal capacities always (rounds 1-4)"},
+    {"BALANCED_CUTS", "layout", "0 | 1 | 2 (default 1; 2 = already where the uniform cut misses the count by 1/32: tuning runs)", "1: where partitions of equal capacity come to fewer than the waves asked for by more than 1/8, the packets are dealt out over exactly that many partitions (floor or ceil of the mean each): every workgroup of the batch kernel then streams the same number of partitions; 0: equal capacities always (rounds 1-4)"},
     {"PACE_ADAPT", "behaviour", "0 | 1 (default 1)", "1: the timetable's period lengthens by 1/64 per launch while a quarter of the waves start a launch's last query more than a quarter of a period late (the GPU streams slower than when tkspmv_create measured), and comes back by 1/256 per launch when next to none do; 0: the period stays as measured"},
     {"PACE_BASE", "tuning", "0..64 (default 0)", "pause per packet (s_sleep units) of EVERY workgroup of the batch kernel, whatever its rank: a uniform throttle (tuning runs)"},
     {"REPAIR", "behaviour", "host | stream (default host)",

@@ -141,7 +141,9 @@ std::string pack_wbscsr(uint32_t rows, uint32_t cols, uint64_t nnz, const uint32
     // table, from which the kernels derive a wave's range without a load.)
     uint32_t used_uniform = fill_partitions(len, m * PE, nullptr);
     // (not below two packets per partition: 50k rows dealt out one packet per wave measure 3.88 against 3.66 us per query)
-    if (P >= 2 && total_packets_lb >= 2u * (uint64_t)P && (uint64_t)used_uniform * 8u < (uint64_t)P * 7u && !(opt("BALANCED_CUTS") && atoi(opt("BALANCED_CUTS")) == 0)) {
+    const int bal_opt = opt("BALANCED_CUTS") ? atoi(opt("BALANCED_CUTS")) : 1;  // (2: already where the uniform cut misses P by 1/32 -- tuning runs)
+    if (P >= 2 && total_packets_lb >= 2u * (uint64_t)P && bal_opt != 0 &&
+        (bal_opt == 2 ? (uint64_t)used_uniform * 32u < (uint64_t)P * 31u : (uint64_t)used_uniform * 8u < (uint64_t)P * 7u)) {
         uint64_t B = std::max<uint64_t>(total_packets_lb, P);
         for (;;) {
             if (fill_partitions_balanced(len, PE, B, P, nullptr) <= P) break;
