@@ -1637,7 +1637,9 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
             for (double g : {1.03, 1.02, 1.01, 1.0, 0.99}) {
                 const uint32_t ns = (uint32_t)((double)centre * g);
                 const float ms = measure(ns, 2, 8);
-                if (ms < period_ms * 0.9985f) {
+                // (from the longest period down: a shorter one must measure 0.3 % better to be taken -- a single launch at a period
+                //  close to what the kernel sustains runs 4-5 % long one time in eight, which a mean over eight launches half hides)
+                if (ms < period_ms * 0.997f) {
                     period_ms = ms;
                     period_ns = ns;
                 }
