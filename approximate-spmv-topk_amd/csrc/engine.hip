@@ -2272,6 +2272,7 @@ int Engine::time_stream_read(int32_t passes, double *ns_per_pass, std::string &e
     R.n_parts = (uint32_t)m.pm.part_first.size();
     R.n_pass = (uint32_t)passes;
     if (const char *f = opt("READ_PROBE_MAP")) R.map = (uint32_t)atoi(f);
+    if (const char *f = opt("READ_PROBE_PERIOD")) R.period = (uint32_t)std::min<uint64_t>(0xFFFFFF00ull, (uint64_t)std::max(0, atoi(f)) * 256u / 10u);  // ns per pass: the probe on a timetable
     struct SinkGuard {  // freed on every return path
         uint32_t *p = nullptr;
         ~SinkGuard() {

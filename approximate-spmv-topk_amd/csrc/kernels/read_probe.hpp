@@ -22,6 +22,12 @@ struct ReadProbeParams {
     uint32_t *sink;  // [grid * waves]
     uint32_t *claim;  // map 3: [n_pass] counters, 32 words apart, zeroed: waves claim their partitions instead of owning them
     unsigned long long *t_end;  // [grid * waves] (optional) s_memrealtime when the wave has finished its last pass
+    // Round 5: the probe on a timetable (batch_kernel.hpp, BatchParams::pace_period). Left alone the probe's waves ask for all they
+    // can get and the memory system serves four XCDs at twice the others' rate -- on some boxes the "floor" it measures is a pass the
+    // paced product beats. period != 0 (ticks << 8 per pass): a wave sleeps off what it is ahead of packet j's slot, (its start) +
+    // (pass x packets + j) x period / packets, looked at every DEPTH packets. The smallest time over a handful of periods is the
+    // figure bench.py reports as `read_only.paced_us`.
+    uint32_t period;
 };
 
 template <int BPL>  // bytes per lane and packet: 22 (fp32 + 12-bit column words), 24 (fp32, C = 4), 48 (fp32, C = 8), 16 (FIXED20), 12 (byte / half values)
@@ -60,6 +66,7 @@ __global__ void __launch_bounds__(1024) read_probe_kernel(const ReadProbeParams 
     constexpr uint32_t PB = (BPL == 22 && WORK == 1 ? 24 : BPL) * 64u;  // (22 with WORK 1: 1408-byte packets read out of a 1536-byte stream)
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
     uint32_t acc = 0u;
+    uint32_t sched_fp = 0u;  // (the probe's timetable: ReadProbeParams::period)
     __shared__ float xl[WORK < 0 ? 1024 : 1];
     if (WORK < 0) {
         for (uint32_t i = threadIdx.x; i < 1024u; i += blockDim.x) xl[i] = 1.0f + (float)(i & 7u);
@@ -138,11 +145,18 @@ __global__ void __launch_bounds__(1024) read_probe_kernel(const ReadProbeParams 
                 }
             } else if (WORK == 0) {
                 uint32_t i = 0;
+                const uint32_t tpkt_fp = (R.period != 0u && count != 0u) ? (uint32_t)((float)R.period / (float)count) : 0u;
+                if (tpkt_fp != 0u && pass == 0u && p == p_first) sched_fp = (uint32_t)__builtin_amdgcn_s_memrealtime() << 8;
                 for (; i + DEPTH <= count; i += DEPTH) {
 #pragma unroll
                     for (int j = 0; j < DEPTH; ++j) acc ^= read_probe_packet<BPL>(pk + (size_t)(i + j) * PB, lane);
+                    if (tpkt_fp != 0u) {  // (polled: the probe has no arithmetic to hide the clock's answer behind, and nothing else to do)
+                        sched_fp += tpkt_fp * (uint32_t)DEPTH;
+                        while ((int32_t)(sched_fp - ((uint32_t)__builtin_amdgcn_s_memrealtime() << 8)) > (int32_t)(8u << 8)) __builtin_amdgcn_s_sleep(4);
+                    }
                 }
                 for (; i < count; ++i) acc ^= read_probe_packet<BPL>(pk + (size_t)i * PB, lane);
+                if (tpkt_fp != 0u) sched_fp += tpkt_fp * (count % (uint32_t)DEPTH);
             } else {  // a rotating window of DEPTH requests, WORK dependent multiply-adds on every packet as it arrives
                 uint32_t buf[DEPTH];
 #pragma unroll

@@ -45,6 +45,7 @@ static const OptionDef k_options[] = {
     {"MULTI_PASSES", "tuning", "1..8 (default 8)", "passes a launch of the row-per-lane kernel makes at one or two queries per pass (8 / 4 by default)"},
     {"SMALL_PACKETS", "tuning", "packets (default LOCAL_MATRIX_PACKETS)", "size up to which a matrix gets the small-matrix settings (4 selectors, 1-2 packet partitions, local thresholds); 0 = round 2's behaviour"},
     {"MIN_PACKETS", "tuning", ">= 1", "minimum packets per wave partition"},
+    {"READ_PROBE_PERIOD", "diagnostic", "ns per pass (0 = off)", "tkspmv_time_stream_read: the load-only probe on a timetable (every wave sleeps off what it is ahead of it) -- the floor bench.py reports as read_only.paced_us is the smallest time over a handful of periods"},
     {"PARTITIONS_HINT", "diagnostic", "count", "wave partitions to pack (read probe experiments; an engine whose partitions exceed its streaming waves does not batch)"},
     {"DEVICE_PACK", "behaviour", "0 | 1 (default 1)", "0: pack the matrix on the host instead of on the device"},
     {"HOST_PATH", "behaviour", "0 | 1 (default 1)", "0: no host-visible result block / mapped x (tkspmv_run and tkspmv_read go through hipMemcpy)"},

@@ -40,7 +40,11 @@ def test_headline_line_on_the_drivers_command_line():
     # the host clock contains the device time of the same region
     assert d["ms_per_step"] * 1e3 >= r["kernel_us"] and abs(d["value"] - 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
     ro = r["read_only"]
-    assert 0.6 < ro["frac_of_peak"] < 1.0 and 0.7 < ro["headline_kernel_vs_read_only"] <= 1.0
+    # (the unpaced probe is no floor on every box -- its XCDs are served unevenly --: the paced product may come within a few per cent
+    #  of it or beat it; the probe on a timetable, `paced`, is one)
+    assert 0.6 < ro["frac_of_peak"] < 1.0 and 0.7 < ro["headline_kernel_vs_read_only"] <= 1.05
+    assert ro["paced"]["us_per_pass"] <= ro["us_per_pass"] * 1.001 and 0.6 < ro["paced"]["frac_of_peak"] < 1.0
+    assert 0.7 < r["kernel_vs_read_only_paced"] < 1.0 and abs(r["read_only_paced_us"] - ro["paced"]["us_per_pass"]) < 1e-9
 
 
 def test_sharded_line_rehearsed_with_one_rank():
