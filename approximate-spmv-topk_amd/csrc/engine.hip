@@ -1601,18 +1601,22 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
         uint32_t period_ns = 0;
         if (!opt("PACE_PERIOD")) {
             // (ms per TWO launches, the mean over `launches` of them in one go, the better of `passes` such series)
+            // (a HIP call that fails leaves `measure_failed` set: the timetable is then not taken, the pauses by rank stay)
+            bool measure_failed = false;
             auto measure = [&](uint32_t ns, int passes, int launches) -> float {
                 m.pace_period_ns = ns;
                 float b = 1e30f;
                 for (int pass = 0; pass < passes; ++pass) {
                     m.launch_batch(xs.data(), oi.data(), ov.data(), nq, m.stream);
-                    (void)hipEventRecord(m.ev0, m.stream);
+                    bool ok = hipEventRecord(m.ev0, m.stream) == hipSuccess;
                     for (int l = 0; l < launches; ++l) m.launch_batch(xs.data(), oi.data(), ov.data(), nq, m.stream);
-                    (void)hipEventRecord(m.ev1, m.stream);
-                    (void)hipEventSynchronize(m.ev1);
-                    (void)m.settle();
+                    ok = ok && hipEventRecord(m.ev1, m.stream) == hipSuccess && hipEventSynchronize(m.ev1) == hipSuccess && m.settle() == hipSuccess;
                     float ms = 0;
-                    (void)hipEventElapsedTime(&ms, m.ev0, m.ev1);
+                    ok = ok && hipEventElapsedTime(&ms, m.ev0, m.ev1) == hipSuccess && hipGetLastError() == hipSuccess;
+                    if (!ok) {
+                        measure_failed = true;
+                        return 1e30f;
+                    }
                     b = std::min(b, ms * 2.0f / (float)launches);
                 }
                 return b;
@@ -1644,7 +1648,7 @@ static int create_impl(const tkspmv_desc &d, EngineImpl &m, std::string &err, co
                     period_ns = ns;
                 }
             }
-            m.pace_period_ns = period_ms < best_ms[best] * 0.999f ? period_ns : 0u;
+            m.pace_period_ns = (!measure_failed && period_ms < best_ms[best] * 0.999f) ? period_ns : 0u;
         }
         const uint32_t tune_us = (uint32_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_tune).count();
         // the engine starts as if nothing had run: no carried thresholds, no pauses, no counters, no trust
