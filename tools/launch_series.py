@@ -21,7 +21,7 @@ nql = int(os.environ.get("QUERIES_PER_LAUNCH", 32))
 eng.time_query_batches(dxs.data_ptr(), 64, nql, 16)
 v = [x / 1e3 for x in eng.time_query_batches(dxs.data_ptr(), 64, nql, n)]
 c = eng.debug_counters()
-print(f"pace {c['pace_quantum']}x{c['pace_levels']} period {c.get('pace_period_ns')} replicas {os.environ.get('REPLICAS', 4)} carry {os.environ.get('TKSPMV_PACE_CARRY', '1')}: median {np.median(v):.2f} p95 {np.percentile(v, 95):.2f} (x{np.percentile(v, 95) / np.median(v):.3f}) min {min(v):.2f} max {max(v):.2f}")
+print(f"pace {c['pace_quantum']}x{c['pace_levels']} period {c.get('pace_period_ns')} replicas {os.environ.get('REPLICAS', 4)} carry {os.environ.get('TKSPMV_PACE_CARRY', '1')}: median {np.median(v):.2f} p95 {np.percentile(v, 95):.2f} (x{np.percentile(v, 95) / np.median(v):.3f}) min {min(v):.2f} max {max(v):.2f} mean {np.mean(v):.2f}")
 print(" ".join(f"{x:.1f}" for x in v))
 w = [x / 1e3 for x in eng.time_query_batches(dxs.data_ptr(), 64, 256, 12)]
 print("reps of 256 queries:", " ".join(f"{x:.2f}" for x in w))
