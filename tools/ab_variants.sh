@@ -7,8 +7,8 @@ cd "$(dirname "$0")/.."
 if [ "$1" = build ]; then
     d=_ab/$2
     rm -rf "$d"; mkdir -p "$d"
-    cp -r approximate-spmv-topk_amd include Makefile _pkg.py tools oracle "$d"/
-    mkdir -p "$d/tests"; cp tests/_*.py tests/conftest.py "$d/tests/" 2>/dev/null || true
+    cp -r approximate-spmv-topk_amd include Makefile _pkg.py bench.py tools oracle "$d"/
+    mkdir -p "$d/tests"; cp tests/_*.py tests/conftest.py tests/oracle_lib.py "$d/tests/" 2>/dev/null || true
     rm -f "$d"/approximate-spmv-topk_amd/libtkspmv.so
     (cd "$d" && sed -i "s/^HIPFLAGS := /HIPFLAGS := $3 /" Makefile && make 2>&1 | grep -E "error" || true)
     ls -la "$d"/approximate-spmv-topk_amd/libtkspmv.so
